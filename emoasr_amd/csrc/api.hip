@@ -1,0 +1,30 @@
+// Library-level plumbing: error strings, version, run-time options.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "common.h"
+#include "../../include/emoasr_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void emo_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+void emo_gemm_set_tr_read(int v);
+void emo_attn_set_tr_read(int v);
+
+extern "C" const char* emoasr_last_error(void) { return g_err; }
+extern "C" int emoasr_version(void) { return 1; }
+extern "C" int emoasr_set_option(const char* name, int value) {
+  if (strcmp(name, "tr_read") == 0) {
+    emo_gemm_set_tr_read(value);
+    emo_attn_set_tr_read(value);
+    return 0;
+  }
+  emo_set_error("unknown option '%s'", name);
+  return 1;
+}

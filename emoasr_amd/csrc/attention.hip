@@ -1,0 +1,706 @@
+// Fused multi-head attention with the Conformer relative-position term, forward and
+// backward, for head size DK = 64.  Scores never reach HBM.
+//
+// Reference semantics (all f32 there):
+//   asr/modeling/transformer.py:62-99   MultiHeadedAttention (mask -> finfo.min, softmax,
+//                                        masked_fill 0, dropout, .V)
+//   asr/modeling/conformer.py:68-95     RelMultiHeadedAttention: ac = (q+u).k^T,
+//                                        bd = rel_shift((q+v).p^T)  =>  bd[i,j] = (q_i+v).p[i-j]
+//   scores = (ac + bd) / sqrt(dk)
+// The rel_shift pad/view/slice dance of the reference is pure index arithmetic here:
+// the projected position table `pos` has row r <-> relative offset rel = Tq-1-r, so
+// bd[i,j] = (q_i+v) . pos[Tq-1-(i-j)].  For a 32x32 (query, key) tile only a band of 63
+// consecutive table rows is needed; the band product is computed with MFMA into a
+// 32x64 tile and "skewed" into place through a wave-private LDS buffer.
+//
+// Design: every wave works alone on a 32-row tile (no block barriers); a block is just
+// four independent waves.  k-contiguous MFMA operands are loaded as fragments straight
+// from global memory (the per-(b,h) slices are L2 resident); operands whose reduction
+// index is the row index in memory (V in forward; K, the band, Q, dO in backward) are
+// staged through wave-private LDS and read back transposed (ds_read_b64_tr_b16 in bf16,
+// plain b32 reads in f32).  Accumulator tiles are fed to the next MFMA in registers
+// ("column on the lane, rows in registers" chaining).
+//
+//   attn_fwd_kernel   : per 32 queries, loops over key tiles (online softmax)
+//   attn_bwd_dq_kernel: per 32 queries, loops over key tiles   -> dq, dbias_u, dbias_v
+//   attn_bwd_dkv_kernel: per 32 keys, loops over query tiles   -> dk, dv
+//   attn_bwd_dpos_kernel: per 32 table rows, loops over query tiles -> dpos
+#include "mma.h"
+#include "../../include/emoasr_hip.h"
+
+namespace {
+
+constexpr int DK = 64;
+
+template <typename T> struct AttnCfg {
+  static constexpr int NK = DK / Mma<T>::KSTEP;         // k-steps over the head dim (4 / 32)
+  static constexpr int NS = 32 / Mma<T>::KSTEP;         // k-steps over a 32-row tile (2 / 16)
+  static constexpr int LD = sizeof(T) == 2 ? 96 : 64;   // row stride of staged 64-wide LDS tiles
+};
+
+// ---- fragments straight from global memory (k-contiguous operand) -----------------
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::Frag frag_global(const T* base, long ld, int row, bool valid,
+                                                             int kk, int lane, const float* bias) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 f;
+    const int d0 = kk * 16 + 8 * (lane >> 5);
+    if (valid) f = *reinterpret_cast<const bf16x8*>(base + (long)row * ld + d0);
+    else for (int j = 0; j < 8; ++j) f[j] = (bf16)0.f;
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (bf16)((float)f[j] + bias[d0 + j]);
+    }
+    return f;
+  } else {
+    const int d = kk * 2 + (lane >> 5);
+    float v = valid ? base[(long)row * ld + d] : 0.f;
+    if (bias) v += bias[d];
+    return v;
+  }
+}
+
+// ---- stage NROWS x 64 rows into wave-private LDS (row-major, stride LD) --------------
+template <typename T, int NROWS>
+__device__ __forceinline__ void stage_rows(T* dst, const T* base, long ld, int row0, int row_lo, int row_hi,
+                                           int lane, const float* bias) {
+  constexpr int VEC = 16 / sizeof(T), PER_ROW = DK / VEC, LD = AttnCfg<T>::LD;
+#pragma unroll
+  for (int v = lane; v < NROWS * PER_ROW; v += 64) {
+    const int r = v / PER_ROW, piece = (v % PER_ROW) * VEC;
+    const int row = row0 + r;
+    Vec16<T> x;
+    if (row >= row_lo && row < row_hi) x = load16(base + (long)row * ld + piece);
+    else x.zero();
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) x.set(j, x.get(j) + bias[piece + j]);
+    }
+    store16(dst + r * LD + piece, x);
+  }
+}
+
+// ---- A operand for "Y = A . X" where X is a 32x32 accumulator tile fed as B ----------
+// lds tile is [k = 32 rows][64 cols] (stride LD); returns A[row = col0 + (lane&31)][k-step ks]
+// in the permuted k order the accumulator-as-operand trick needs.
+template <typename T, bool TR>
+__device__ __forceinline__ typename Mma<T>::Frag chain_a(const T* lds, int ks, int col0, int lane) {
+  constexpr int LD = AttnCfg<T>::LD;
+  if constexpr (sizeof(T) == 2) {
+    const int h = lane >> 5;
+    if constexpr (TR) {
+      union { bf16x8 f; s16x4 q[2]; } u;
+      u.q[0] = tr_read4(lds, LD, 16 * ks + 4 * h, col0, lane);
+      u.q[1] = tr_read4(lds, LD, 16 * ks + 8 + 4 * h, col0, lane);
+      return u.f;
+    } else {
+      bf16x8 f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = lds[(16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)) * LD + col0 + (lane & 31)];
+      return f;
+    }
+  } else {
+    return lds[c_row(ks, lane) * LD + col0 + (lane & 31)];
+  }
+}
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::Frag chain_b(const f32x16& x, int ks) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (bf16)x[8 * ks + j];
+    return f;
+  } else {
+    return x[ks];
+  }
+}
+
+__device__ __forceinline__ void zero16(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct HeadPtrs {  // per (b, h) base pointers (element type erased)
+  const void *q, *k, *v, *pos, *dout;
+  void *out, *dq, *dk, *dv;
+  const float *bias_u, *bias_v;
+  float *lse, *delta;
+  int klen;
+};
+
+template <typename T>
+__device__ __forceinline__ HeadPtrs head_ptrs(const emoasr_attn_t& a, int b, int h) {
+  HeadPtrs p;
+  const long ho = (long)h * DK;
+  p.q = (const T*)a.q + (long)b * a.Tq * a.ldq + ho;
+  p.k = (const T*)a.k + (long)b * a.Tk * a.ldk + ho;
+  p.v = (const T*)a.v + (long)b * a.Tk * a.ldv + ho;
+  p.pos = a.pos ? (const T*)a.pos + ho : nullptr;
+  p.dout = a.dout ? (const T*)a.dout + (long)b * a.Tq * a.ldo + ho : nullptr;
+  p.out = a.out ? (T*)a.out + (long)b * a.Tq * a.ldo + ho : nullptr;
+  p.dq = a.dq ? (T*)a.dq + (long)b * a.Tq * a.ldq + ho : nullptr;
+  p.dk = a.dk ? (T*)a.dk + (long)b * a.Tk * a.ldk + ho : nullptr;
+  p.dv = a.dv ? (T*)a.dv + (long)b * a.Tk * a.ldv + ho : nullptr;
+  p.bias_u = a.bias_u ? a.bias_u + ho : nullptr;
+  p.bias_v = a.bias_v ? a.bias_v + ho : nullptr;
+  p.lse = a.lse + ((long)b * a.H + h) * a.Tq;
+  p.delta = a.delta ? a.delta + ((long)b * a.H + h) * a.Tq : nullptr;
+  p.klen = a.klens ? min(a.klens[b], a.Tk) : a.Tk;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------
+// Score tile.  `row_*` fragments index the tile's rows, `col_*` its columns:
+//   SWAPPED  (forward, dq):   rows = keys j0.., cols = queries i0..   (row side = K / band)
+//   !SWAPPED (dkv, dpos):     rows = queries i0.., cols = keys j0..   (row side = Q)
+// Returns raw ac + bd (unscaled) in `acc` (C layout).
+// Band rows: r = rbase + c, c in [0,64), rbase = Tq - 32 - i0 + j0; element (i_l, j_l) uses
+// c = 31 - i_l + j_l.
+// ------------------------------------------------------------------------------------
+template <typename T, bool SWAPPED>
+__device__ __forceinline__ void score_tile(f32x16& acc, const emoasr_attn_t& a, const HeadPtrs& hp, int i0,
+                                           int j0, const typename Mma<T>::Frag* qu,
+                                           const typename Mma<T>::Frag* qv,
+                                           const typename Mma<T>::Frag* kf, float* Gs, int lane) {
+  using M_ = Mma<T>;
+  constexpr int NK = AttnCfg<T>::NK;
+  const T* kbase = (const T*)hp.k;
+  zero16(acc);
+  if constexpr (SWAPPED) {
+    const int krow = j0 + (lane & 31);
+    const bool kval = krow >= 0 && krow < a.Tk;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+      acc = M_::mma(frag_global<T>(kbase, a.ldk, krow, kval, kk, lane, nullptr), qu[kk], acc);
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) acc = M_::mma(qu[kk], kf[kk], acc);
+  }
+  if (hp.pos == nullptr) return;
+  const T* pbase = (const T*)hp.pos;
+  const int rbase = a.Tq - 32 - i0 + j0, rmax = 2 * a.Tq - 2;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    f32x16 g;
+    zero16(g);
+    const int prow = clampi(rbase + 32 * ct + (lane & 31), 0, rmax);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      const typename M_::Frag pf = frag_global<T>(pbase, a.ldp, prow, true, kk, lane, nullptr);
+      if constexpr (SWAPPED) g = M_::mma(pf, qv[kk], g);   // g[c][i]
+      else g = M_::mma(qv[kk], pf, g);                     // g[i][c]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if constexpr (SWAPPED) Gs[(32 * ct + c_row(r, lane)) * 32 + (lane & 31)] = g[r];
+      else Gs[c_row(r, lane) * 64 + 32 * ct + (lane & 31)] = g[r];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if constexpr (SWAPPED) {  // row = key j_l, col = query i_l
+      const int jl = c_row(r, lane), il = lane & 31;
+      acc[r] += Gs[(31 - il + jl) * 32 + il];
+    } else {                  // row = query i_l, col = key j_l
+      const int il = c_row(r, lane), jl = lane & 31;
+      acc[r] += Gs[il * 64 + 31 - il + jl];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint64_t drop_index(const emoasr_attn_t& a, int b, int h, int i, int j) {
+  return (((uint64_t)b * a.H + h) * a.Tq + i) * (uint64_t)a.Tk + j;
+}
+
+// write a [64 d][32 cols] transposed accumulator pair (rows d in registers, col = row index
+// of the destination matrix on the lane) to dst[row = r0 + (lane&31)][d], optionally summed
+// with a second pair.
+template <typename T>
+__device__ __forceinline__ void store_dT(T* dst, long ld, int r0, int rlimit, const f32x16* x,
+                                         float mul, int lane) {
+  const int row = r0 + (lane & 31);
+  if (row >= rlimit) return;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = x[dt][4 * g + e] * mul;
+      T* p = dst + (long)row * ld + 32 * dt + 8 * g + 4 * (lane >> 5);
+      if constexpr (sizeof(T) == 2) {
+        bf16x4 v;
+        v[0] = (bf16)o[0]; v[1] = (bf16)o[1]; v[2] = (bf16)o[2]; v[3] = (bf16)o[3];
+        *reinterpret_cast<bf16x4*>(p) = v;
+      } else {
+        *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+      }
+    }
+}
+
+// ====================================================================================
+// forward
+// ====================================================================================
+template <typename T, bool TR>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const emoasr_attn_t a) {
+  using M_ = Mma<T>;
+  constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = AttnCfg<T>::LD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  if (i0 >= a.Tq) return;
+  constexpr int WAVE_BYTES = 64 * 32 * 4 + 32 * LD * (int)sizeof(T);
+  float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
+  T* Vs = reinterpret_cast<T*>(smem + wave * WAVE_BYTES + 64 * 32 * 4);
+
+  const HeadPtrs hp = head_ptrs<T>(a, b, h);
+  const int qi = i0 + (lane & 31);
+  const bool qval = qi < a.Tq;
+  typename M_::Frag qu[NK], qv[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    qu[kk] = frag_global<T>((const T*)hp.q, a.ldq, qi, qval, kk, lane, hp.bias_u);
+    qv[kk] = hp.pos ? frag_global<T>((const T*)hp.q, a.ldq, qi, qval, kk, lane, hp.bias_v) : qu[kk];
+  }
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[2];
+  zero16(o[0]); zero16(o[1]);
+  int kend = hp.klen;
+  if (a.causal) kend = min(kend, i0 + 32);
+  for (int j0 = 0; j0 < kend; j0 += 32) {
+    f32x16 s;
+    score_tile<T, true>(s, a, hp, i0, j0, qu, qv, nullptr, Gs, lane);
+    stage_rows<T, 32>(Vs, (const T*)hp.v, a.ldv, j0, 0, a.Tk, lane, nullptr);
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kj = j0 + c_row(r, lane);
+      const bool masked = kj >= hp.klen || (a.causal && kj > qi);
+      s[r] = masked ? -INFINITY : s[r] * a.scale;
+      mt = fmaxf(mt, s[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float alpha = (m == -INFINITY) ? 0.f : __expf(m - mn);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - mn);
+      rs += p;
+      s[r] = p;
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    if (a.drop_p > 0.f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        s[r] *= dropout_scale(a.seed, drop_index(a, b, h, qi, j0 + c_row(r, lane)), a.drop_p);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+        o[dt] = M_::mma(chain_a<T, TR>(Vs, ks, 32 * dt, lane), chain_b<T>(s, ks), o[dt]);
+    __builtin_amdgcn_wave_barrier();
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  store_dT<T>((T*)hp.out, a.ldo, i0, a.Tq, o, inv, lane);
+  if (lane < 32 && qval) hp.lse[qi] = l > 0.f ? m + __logf(l) : -INFINITY;
+}
+
+// delta[b,h,i] = sum_d dout[b,i,h,d] * out[b,i,h,d]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const emoasr_attn_t a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*Tq*H
+  const long total = (long)a.B * a.Tq * a.H;
+  if (row >= total) return;
+  const int h = row % a.H;
+  const long bt = row / a.H;
+  const int i = bt % a.Tq, b = bt / a.Tq;
+  const float x = to_f32(((const T*)a.dout)[bt * a.ldo + h * DK + lane]) *
+                  to_f32(((const T*)a.out)[bt * a.ldo + h * DK + lane]);
+  const float s = wave_sum(x);
+  if (lane == 0) a.delta[((long)b * a.H + h) * a.Tq + i] = s;
+}
+
+// ====================================================================================
+// backward: dq (+ dbias_u, dbias_v).  Swapped tiles like the forward.
+// ====================================================================================
+template <typename T, bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const emoasr_attn_t a) {
+  using M_ = Mma<T>;
+  constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = AttnCfg<T>::LD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  if (i0 >= a.Tq) return;
+  constexpr int WAVE_BYTES = 64 * 32 * 4 + 96 * LD * (int)sizeof(T);
+  float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
+  T* Ks = reinterpret_cast<T*>(smem + wave * WAVE_BYTES + 64 * 32 * 4);  // [32][LD]
+  T* Bs = Ks + 32 * LD;                                                   // [64][LD] band rows
+
+  const HeadPtrs hp = head_ptrs<T>(a, b, h);
+  const int qi = i0 + (lane & 31);
+  const bool qval = qi < a.Tq;
+  typename M_::Frag qu[NK], qv[NK], dof[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    qu[kk] = frag_global<T>((const T*)hp.q, a.ldq, qi, qval, kk, lane, hp.bias_u);
+    qv[kk] = hp.pos ? frag_global<T>((const T*)hp.q, a.ldq, qi, qval, kk, lane, hp.bias_v) : qu[kk];
+    dof[kk] = frag_global<T>((const T*)hp.dout, a.ldo, qi, qval, kk, lane, nullptr);
+  }
+  const float lse_q = qval ? hp.lse[qi] : -INFINITY;
+  const float del_q = qval ? hp.delta[qi] : 0.f;
+  f32x16 dqu[2], dqv[2];
+  zero16(dqu[0]); zero16(dqu[1]); zero16(dqv[0]); zero16(dqv[1]);
+  int kend = hp.klen;
+  if (a.causal) kend = min(kend, i0 + 32);
+  for (int j0 = 0; j0 < kend; j0 += 32) {
+    f32x16 s;
+    score_tile<T, true>(s, a, hp, i0, j0, qu, qv, nullptr, Gs, lane);
+    // dP^T = V . dO^T   (rows keys, cols queries)
+    f32x16 dp;
+    zero16(dp);
+    {
+      const int krow = j0 + (lane & 31);
+      const bool kval = krow < a.Tk;
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk)
+        dp = M_::mma(frag_global<T>((const T*)hp.v, a.ldv, krow, kval, kk, lane, nullptr), dof[kk], dp);
+    }
+    f32x16 ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kj = j0 + c_row(r, lane);
+      const bool masked = kj >= hp.klen || (a.causal && kj > qi) || lse_q == -INFINITY;
+      const float p = masked ? 0.f : __expf(s[r] * a.scale - lse_q);
+      float dpr = dp[r];
+      if (a.drop_p > 0.f) dpr *= dropout_scale(a.seed, drop_index(a, b, h, qi, kj), a.drop_p);
+      ds[r] = p * (dpr - del_q) * a.scale;
+    }
+    // dQu^T += K^T . dS^T
+    stage_rows<T, 32>(Ks, (const T*)hp.k, a.ldk, j0, 0, a.Tk, lane, nullptr);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+        dqu[dt] = M_::mma(chain_a<T, TR>(Ks, ks, 32 * dt, lane), chain_b<T>(ds, ks), dqu[dt]);
+    if (hp.pos) {
+      // un-skew dS^T into the band: dG^T[c][i] = dS^T[c - 31 + i][i]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Gs[c_row(r, lane) * 32 + (lane & 31)] = ds[r];
+      const int rbase = a.Tq - 32 - i0 + j0;
+      stage_rows<T, 64>(Bs, (const T*)hp.pos, a.ldp, rbase, 0, 2 * a.Tq - 1, lane, nullptr);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x16 dg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * ct + c_row(r, lane) - 31 + (lane & 31);
+          dg[r] = (key >= 0 && key < 32) ? Gs[key * 32 + (lane & 31)] : 0.f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int ks = 0; ks < NS; ++ks)
+            dqv[dt] = M_::mma(chain_a<T, TR>(Bs + 32 * ct * LD, ks, 32 * dt, lane), chain_b<T>(dg, ks), dqv[dt]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // bias gradients: sum over the 32 queries of this tile (lanes within each half)
+  if (a.dbias_u || a.dbias_v) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float su = qval ? dqu[dt][r] : 0.f, sv = qval ? dqv[dt][r] : 0.f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { su += __shfl_xor(su, o, 64); sv += __shfl_xor(sv, o, 64); }
+        if ((lane & 31) == 0) {
+          const int d = h * DK + 32 * dt + c_row(r, lane);
+          if (a.dbias_u) atomicAdd(&a.dbias_u[d], su);
+          if (a.dbias_v && hp.pos) atomicAdd(&a.dbias_v[d], sv);
+        }
+      }
+  }
+  if (hp.pos) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqu[dt][r] += dqv[dt][r];
+  }
+  store_dT<T>((T*)hp.dq, a.ldq, i0, a.Tq, dqu, 1.f, lane);
+}
+
+// ====================================================================================
+// backward: dk, dv.  Non-swapped tiles (rows = queries, cols = this wave's 32 keys).
+// ====================================================================================
+template <typename T, bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const emoasr_attn_t a) {
+  using M_ = Mma<T>;
+  constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = AttnCfg<T>::LD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  if (j0 >= a.Tk) return;
+  constexpr int WAVE_BYTES = 32 * 64 * 4 + 64 * LD * (int)sizeof(T);
+  float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
+  T* Qs = reinterpret_cast<T*>(smem + wave * WAVE_BYTES + 32 * 64 * 4);  // [32][LD] q + u
+  T* Os = Qs + 32 * LD;                                                   // [32][LD] dO
+
+  const HeadPtrs hp = head_ptrs<T>(a, b, h);
+  const int kj = j0 + (lane & 31);
+  const bool kval = kj < a.Tk;
+  typename M_::Frag kf[NK], vf[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    kf[kk] = frag_global<T>((const T*)hp.k, a.ldk, kj, kval, kk, lane, nullptr);
+    vf[kk] = frag_global<T>((const T*)hp.v, a.ldv, kj, kval, kk, lane, nullptr);
+  }
+  f32x16 dk[2], dv[2];
+  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+  const bool key_dead = kj >= hp.klen;
+  const int istart = a.causal ? (j0 / 32) * 32 : 0;
+  if (j0 < hp.klen) {
+    for (int i0 = istart; i0 < a.Tq; i0 += 32) {
+      const int qrow = i0 + (lane & 31);
+      const bool qrv = qrow < a.Tq;
+      typename M_::Frag qu[NK], qv[NK], dof[NK];
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        qu[kk] = frag_global<T>((const T*)hp.q, a.ldq, qrow, qrv, kk, lane, hp.bias_u);
+        qv[kk] = hp.pos ? frag_global<T>((const T*)hp.q, a.ldq, qrow, qrv, kk, lane, hp.bias_v) : qu[kk];
+        dof[kk] = frag_global<T>((const T*)hp.dout, a.ldo, qrow, qrv, kk, lane, nullptr);
+      }
+      f32x16 s;
+      score_tile<T, false>(s, a, hp, i0, j0, qu, qv, kf, Gs, lane);
+      f32x16 dp;
+      zero16(dp);
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) dp = M_::mma(dof[kk], vf[kk], dp);  // dO . V^T
+      stage_rows<T, 32>(Qs, (const T*)hp.q, a.ldq, i0, 0, a.Tq, lane, hp.bias_u);
+      stage_rows<T, 32>(Os, (const T*)hp.dout, a.ldo, i0, 0, a.Tq, lane, nullptr);
+      f32x16 pd, ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = i0 + c_row(r, lane);
+        const bool qv_ = qi < a.Tq;
+        const float lse_q = qv_ ? hp.lse[qi] : -INFINITY;
+        const float del_q = qv_ ? hp.delta[qi] : 0.f;
+        const bool masked = key_dead || (a.causal && kj > qi) || lse_q == -INFINITY;
+        const float p = masked ? 0.f : __expf(s[r] * a.scale - lse_q);
+        const float dsc = a.drop_p > 0.f ? dropout_scale(a.seed, drop_index(a, b, h, qi, kj), a.drop_p) : 1.f;
+        pd[r] = p * dsc;
+        ds[r] = p * (dp[r] * dsc - del_q) * a.scale;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+          dv[dt] = M_::mma(chain_a<T, TR>(Os, ks, 32 * dt, lane), chain_b<T>(pd, ks), dv[dt]);
+          dk[dt] = M_::mma(chain_a<T, TR>(Qs, ks, 32 * dt, lane), chain_b<T>(ds, ks), dk[dt]);
+        }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  store_dT<T>((T*)hp.dk, a.ldk, j0, a.Tk, dk, 1.f, lane);
+  store_dT<T>((T*)hp.dv, a.ldv, j0, a.Tk, dv, 1.f, lane);
+}
+
+// ====================================================================================
+// backward: dpos[r, h*64 + d] += sum_{b,i} dBD[b,h,i, j = i - rel(r)] * (q[b,i,h,:] + v)[d]
+// block = (32 table rows, h, b); the four waves take query tiles round-robin and are
+// reduced through LDS before one set of f32 atomics.
+// ====================================================================================
+template <typename T, bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_dpos_kernel(const emoasr_attn_t a) {
+  using M_ = Mma<T>;
+  constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = AttnCfg<T>::LD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  constexpr int WAVE_BYTES = 2 * 32 * 64 * 4 + 32 * LD * (int)sizeof(T);
+  float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
+  float* Es = Gs + 32 * 64;                                                   // [32][64]
+  T* Qs = reinterpret_cast<T*>(smem + wave * WAVE_BYTES + 2 * 32 * 64 * 4);  // [32][LD] q + v
+
+  const HeadPtrs hp = head_ptrs<T>(a, b, h);
+  f32x16 acc[2];
+  zero16(acc[0]); zero16(acc[1]);
+  for (int i0 = wave * 32; i0 < a.Tq; i0 += 128) {
+    const int jbase = i0 + r0 - a.Tq + 1;  // key of (i_l = 0, r_l = 0); keys jbase .. jbase+62
+    if (jbase + 62 < 0 || jbase >= hp.klen) continue;
+    const int qrow = i0 + (lane & 31);
+    const bool qrv = qrow < a.Tq;
+    typename M_::Frag qu[NK], qv[NK], dof[NK];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      qu[kk] = frag_global<T>((const T*)hp.q, a.ldq, qrow, qrv, kk, lane, hp.bias_u);
+      qv[kk] = frag_global<T>((const T*)hp.q, a.ldq, qrow, qrv, kk, lane, hp.bias_v);
+      dof[kk] = frag_global<T>((const T*)hp.dout, a.ldo, qrow, qrv, kk, lane, nullptr);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j0 = jbase + 32 * t;
+      const int kj = j0 + (lane & 31);
+      const bool kval = kj >= 0 && kj < a.Tk;
+      typename M_::Frag kf[NK], vf[NK];
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        kf[kk] = frag_global<T>((const T*)hp.k, a.ldk, kj, kval, kk, lane, nullptr);
+        vf[kk] = frag_global<T>((const T*)hp.v, a.ldv, kj, kval, kk, lane, nullptr);
+      }
+      f32x16 s;
+      score_tile<T, false>(s, a, hp, i0, j0, qu, qv, kf, Gs, lane);
+      f32x16 dp;
+      zero16(dp);
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) dp = M_::mma(dof[kk], vf[kk], dp);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = i0 + c_row(r, lane);
+        const bool qv_ = qi < a.Tq;
+        const float lse_q = qv_ ? hp.lse[qi] : -INFINITY;
+        const float del_q = qv_ ? hp.delta[qi] : 0.f;
+        const bool masked = kj < 0 || kj >= hp.klen || lse_q == -INFINITY;
+        const float p = masked ? 0.f : __expf(s[r] * a.scale - lse_q);
+        const float dsc = a.drop_p > 0.f && !masked ? dropout_scale(a.seed, drop_index(a, b, h, qi, kj), a.drop_p) : 1.f;
+        Es[c_row(r, lane) * 64 + 32 * t + (lane & 31)] = p * (dp[r] * dsc - del_q) * a.scale;
+      }
+    }
+    stage_rows<T, 32>(Qs, (const T*)hp.q, a.ldq, i0, 0, a.Tq, lane, hp.bias_v);
+    __builtin_amdgcn_wave_barrier();
+    f32x16 e;  // e[i_l][r_l] = dS[i, key - jbase = i_l + r_l]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int il = c_row(r, lane);
+      e[r] = Es[il * 64 + il + (lane & 31)];
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+        acc[dt] = M_::mma(chain_a<T, TR>(Qs, ks, 32 * dt, lane), chain_b<T>(e, ks), acc[dt]);
+    __builtin_amdgcn_wave_barrier();
+  }
+  // cross-wave reduction: reuse the first 32 KiB of LDS as [4][2][16][64] f32
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave * 2 + dt) * 16 + r) * 64 + lane] = acc[dt][r];
+  __syncthreads();
+  if (wave == 0) {
+    const int row = r0 + (lane & 31);
+    if (row <= 2 * a.Tq - 2) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v += red[((w * 2 + dt) * 16 + r) * 64 + lane];
+          atomicAdd(&a.dpos[(long)row * (a.H * DK) + h * DK + 32 * dt + c_row(r, lane)], v);
+        }
+    }
+  }
+}
+
+template <typename K>
+int set_smem(K kernel, int bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { emo_set_error("hipFuncSetAttribute(%d): %s", bytes, hipGetErrorString(e)); return 1; }
+  }
+  return 0;
+}
+
+int g_tr = 1;
+
+int check_args(const emoasr_attn_t* a, int dtype) {
+  EMO_CHECK(a->DK == DK, "attention: DK=%d unsupported (64 only)", a->DK);
+  const int vec = dtype == EMO_BF16 ? 8 : 4;
+  EMO_CHECK(a->ldq % vec == 0 && a->ldk % vec == 0 && a->ldv % vec == 0 && a->ldo % vec == 0,
+            "attention: row strides must be multiples of %d elements", vec);
+  EMO_CHECK(!a->pos || (a->Tq == a->Tk && a->ldp % vec == 0), "attention: relative positions need Tq == Tk");
+  EMO_CHECK(!(a->pos && a->causal), "attention: causal + relative positions unsupported");
+  return 0;
+}
+
+template <typename T>
+int launch_fwd(const emoasr_attn_t& a, hipStream_t s) {
+  constexpr int LD = AttnCfg<T>::LD;
+  const int smem = 4 * (64 * 32 * 4 + 32 * LD * (int)sizeof(T));
+  dim3 grid(cdiv(a.Tq, 128), a.H, a.B);
+  if (g_tr) {
+    if (set_smem(attn_fwd_kernel<T, true>, smem)) return 1;
+    attn_fwd_kernel<T, true><<<grid, 256, smem, s>>>(a);
+  } else {
+    if (set_smem(attn_fwd_kernel<T, false>, smem)) return 1;
+    attn_fwd_kernel<T, false><<<grid, 256, smem, s>>>(a);
+  }
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, bool TR>
+int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
+  constexpr int LD = AttnCfg<T>::LD;
+  const long rows = (long)a.B * a.Tq * a.H;
+  attn_delta_kernel<T><<<cdiv(rows, 4), 256, 0, s>>>(a);
+  {
+    const int smem = 4 * (64 * 32 * 4 + 96 * LD * (int)sizeof(T));
+    if (set_smem(attn_bwd_dq_kernel<T, TR>, smem)) return 1;
+    dim3 grid(cdiv(a.Tq, 128), a.H, a.B);
+    attn_bwd_dq_kernel<T, TR><<<grid, 256, smem, s>>>(a);
+  }
+  {
+    const int smem = 4 * (32 * 64 * 4 + 64 * LD * (int)sizeof(T));
+    if (set_smem(attn_bwd_dkv_kernel<T, TR>, smem)) return 1;
+    dim3 grid(cdiv(a.Tk, 128), a.H, a.B);
+    attn_bwd_dkv_kernel<T, TR><<<grid, 256, smem, s>>>(a);
+  }
+  if (a.pos && a.dpos) {
+    const int smem = 4 * (2 * 32 * 64 * 4 + 32 * LD * (int)sizeof(T));
+    if (set_smem(attn_bwd_dpos_kernel<T, TR>, smem)) return 1;
+    dim3 grid(cdiv(2 * a.Tq - 1, 32), a.H, a.B);
+    attn_bwd_dpos_kernel<T, TR><<<grid, 256, smem, s>>>(a);
+  }
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+void emo_attn_set_tr_read(int v) { g_tr = v; }
+
+extern "C" int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream) {
+  if (check_args(a, dtype)) return 1;
+  if (a->B == 0 || a->Tq == 0) return 0;
+  EMO_DISPATCH(dtype, return (launch_fwd<T>(*a, (hipStream_t)stream)));
+  return 0;
+}
+
+extern "C" int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream) {
+  if (check_args(a, dtype)) return 1;
+  EMO_CHECK(a->dout && a->out && a->delta && a->dq && a->dk && a->dv, "attn_bwd: missing buffers");
+  if (a->B == 0 || a->Tq == 0) return 0;
+  EMO_DISPATCH(dtype, {
+    if (g_tr) return (launch_bwd_tr<T, true>(*a, (hipStream_t)stream));
+    return (launch_bwd_tr<T, false>(*a, (hipStream_t)stream));
+  });
+  return 0;
+}

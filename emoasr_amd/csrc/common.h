@@ -1,0 +1,192 @@
+// Common device helpers for the emoasr_amd HIP kernels (gfx950 / CDNA4 only).
+//
+// Conventions
+//   * wave = 64 lanes; blocks are multiples of 64 threads.
+//   * T is the "compute" element type: float (parity mode, exact-f32 MFMA) or
+//     __bf16 (throughput mode, bf16 MFMA with f32 accumulation).
+//   * statistics, reductions, softmax / LSE, lattices and gradients of
+//     parameters are always f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define EMO_WAVE 64
+
+// ---------------------------------------------------------------------------
+// scalar conversion
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// ---------------------------------------------------------------------------
+// 16-byte vectors of T: 4 floats or 8 bf16.
+// ---------------------------------------------------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  f32x4 v;
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+  __device__ __forceinline__ void zero() { v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+};
+template <> struct Vec16<bf16> {
+  static constexpr int N = 8;
+  bf16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+  __device__ __forceinline__ void zero() {
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)0.f;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> load16(const T* p) {
+  Vec16<T> r;
+  r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store16(T* p, const Vec16<T>& r) {
+  *reinterpret_cast<decltype(r.v)*>(p) = r.v;
+}
+
+// ---------------------------------------------------------------------------
+// wave / block reductions (f32)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum of one float per thread; `red` is LDS scratch of >= 16 floats.
+// All threads get the result.  blockDim.x must be a multiple of 64.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// activations
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float dswishf_(float x) {
+  const float s = sigmoidf_(x);
+  return s * (1.f + x * (1.f - s));
+}
+
+enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_SWISH = 2 };
+
+__device__ __forceinline__ float apply_act(int act, float x) {
+  if (act == EMO_ACT_RELU) return fmaxf(x, 0.f);
+  if (act == EMO_ACT_SWISH) return swishf_(x);
+  return x;
+}
+__device__ __forceinline__ float apply_dact(int act, float pre) {
+  if (act == EMO_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
+  if (act == EMO_ACT_SWISH) return dswishf_(pre);
+  return 1.f;
+}
+
+// ---------------------------------------------------------------------------
+// Counter-based dropout RNG.  keep(seed, idx) is a pure function so backward
+// kernels regenerate the forward mask instead of storing it.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU;
+  x ^= x >> 15; x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+// returns 0.f (dropped) or 1/(1-p) (kept).  p == 0 -> always 1.
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
+  if (p <= 0.f) return 1.f;
+  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  uint32_t h = hash_u32(lo ^ (uint32_t)seed);
+  h = hash_u32(h ^ hi ^ (uint32_t)(seed >> 32) ^ 0x9e3779b9U);
+  const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : 1.f / (1.f - p);
+}
+
+// ---------------------------------------------------------------------------
+// log-space helpers for the CTC / RNN-T lattices
+// ---------------------------------------------------------------------------
+#define EMO_NEG_INF (-INFINITY)
+__device__ __forceinline__ float log_add(float a, float b) {
+  if (a == EMO_NEG_INF) return b;
+  if (b == EMO_NEG_INF) return a;
+  const float m = fmaxf(a, b);
+  return m + log1pf(expf(-fabsf(a - b)));
+}
+__device__ __forceinline__ float log_add3(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  if (m == EMO_NEG_INF) return EMO_NEG_INF;
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// ---------------------------------------------------------------------------
+// host-side launch helpers
+// ---------------------------------------------------------------------------
+void emo_set_error(const char* fmt, ...);
+#define EMO_CHECK(cond, ...)            \
+  do {                                  \
+    if (!(cond)) {                      \
+      emo_set_error(__VA_ARGS__);       \
+      return 1;                         \
+    }                                   \
+  } while (0)
+#define EMO_LAUNCH_CHECK()                                              \
+  do {                                                                  \
+    hipError_t e__ = hipGetLastError();                                 \
+    if (e__ != hipSuccess) {                                            \
+      emo_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,      \
+                    hipGetErrorString(e__));                            \
+      return 2;                                                         \
+    }                                                                   \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+enum { EMO_F32 = 0, EMO_BF16 = 1 };
+#define EMO_DISPATCH(dtype, ...)                                        \
+  do {                                                                  \
+    if ((dtype) == EMO_F32) { typedef float T; __VA_ARGS__; }           \
+    else if ((dtype) == EMO_BF16) { typedef bf16 T; __VA_ARGS__; }      \
+    else { emo_set_error("bad dtype %d", (int)(dtype)); return 1; }     \
+  } while (0)

@@ -1,0 +1,263 @@
+// Conformer convolution module pieces (asr/modeling/conformer.py:98-143):
+// depthwise Conv1d(k=31, groups=C) over time, BatchNorm1d (training: batch statistics
+// over ALL B*T rows -- the reference never masks padded frames), Swish.
+// Channels-last activations [B, T, C]: threads run along C so every global access
+// is a coalesced row segment; the time window slides in registers.
+#include "common.h"
+#include "../../include/emoasr_hip.h"
+
+namespace {
+
+constexpr int DW_TT = 32;    // output frames per block
+constexpr int DW_MAXK = 31;  // kernel taps (compile-time bound of the register window)
+
+// y[b,t,c] = bias[c] + sum_j w[c,j] * x[b, t + j - pad, c]      (flip=0)
+// dx[b,t,c] =          sum_j w[c,K-1-j] * dy[b, t + j - pad, c]  (flip=1, no bias)
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const T* __restrict__ x,
+                                                     const float* __restrict__ w,
+                                                     const float* __restrict__ bias, T* __restrict__ y,
+                                                     int flip) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int b = blockIdx.z, t0 = blockIdx.x * DW_TT, pad = (K - 1) / 2;
+  float wr[DW_MAXK];
+#pragma unroll
+  for (int j = 0; j < DW_MAXK; ++j) wr[j] = j < K ? w[c * K + (flip ? K - 1 - j : j)] : 0.f;
+  const float bv = bias ? bias[c] : 0.f;
+  float win[DW_TT + DW_MAXK - 1];
+  const T* xb = x + (long)b * Tn * C + c;
+#pragma unroll
+  for (int i = 0; i < DW_TT + DW_MAXK - 1; ++i) {
+    const int t = t0 + i - pad;
+    win[i] = (i < DW_TT + K - 1 && t >= 0 && t < Tn) ? to_f32(xb[(long)t * C]) : 0.f;
+  }
+  T* yb = y + (long)b * Tn * C + c;
+#pragma unroll
+  for (int i = 0; i < DW_TT; ++i) {
+    if (t0 + i >= Tn) break;
+    float acc = bv;
+#pragma unroll
+    for (int j = 0; j < DW_MAXK; ++j) acc += wr[j] * win[i + j];
+    yb[(long)(t0 + i) * C] = from_f32<T>(acc);
+  }
+}
+
+// dw[c,j] += sum_{b,t} dy[b,t,c] * x[b,t+j-pad,c];  dbias[c] += sum dy
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(int Tn, int C, int K, const T* __restrict__ dy,
+                                                           const T* __restrict__ x, float* __restrict__ dw,
+                                                           float* __restrict__ dbias) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int b = blockIdx.z, t0 = blockIdx.x * DW_TT, pad = (K - 1) / 2;
+  float win[DW_TT + DW_MAXK - 1];
+  const T* xb = x + (long)b * Tn * C + c;
+#pragma unroll
+  for (int i = 0; i < DW_TT + DW_MAXK - 1; ++i) {
+    const int t = t0 + i - pad;
+    win[i] = (i < DW_TT + K - 1 && t >= 0 && t < Tn) ? to_f32(xb[(long)t * C]) : 0.f;
+  }
+  float acc[DW_MAXK];
+#pragma unroll
+  for (int j = 0; j < DW_MAXK; ++j) acc[j] = 0.f;
+  float sb = 0.f;
+  const T* dyb = dy + (long)b * Tn * C + c;
+#pragma unroll
+  for (int i = 0; i < DW_TT; ++i) {
+    const float d = (t0 + i < Tn) ? to_f32(dyb[(long)(t0 + i) * C]) : 0.f;
+    sb += d;
+#pragma unroll
+    for (int j = 0; j < DW_MAXK; ++j) acc[j] += d * win[i + j];
+  }
+#pragma unroll
+  for (int j = 0; j < DW_MAXK; ++j)
+    if (j < K) atomicAdd(&dw[c * K + j], acc[j]);
+  if (dbias) atomicAdd(&dbias[c], sb);
+}
+
+// ---- BatchNorm statistics: two passes (sum, then centred sum of squares) --------
+constexpr int BN_ROWS = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void bn_sum_kernel(int M, int C, const T* __restrict__ y,
+                                                     float* __restrict__ sum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * BN_ROWS, r1 = min(M, r0 + BN_ROWS);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += to_f32(y[(long)r * C + c]);
+  atomicAdd(&sum[c], s);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_var_kernel(int M, int C, const T* __restrict__ y,
+                                                     const float* __restrict__ sum,
+                                                     float* __restrict__ sq) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mu = sum[c] / M;
+  const int r0 = blockIdx.y * BN_ROWS, r1 = min(M, r0 + BN_ROWS);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) { const float d = to_f32(y[(long)r * C + c]) - mu; s += d * d; }
+  atomicAdd(&sq[c], s);
+}
+// mean/var hold sum / centred-sq-sum on entry; finalise and update running stats.
+__global__ void bn_finalize_kernel(int M, int C, float* mean, float* var, float* running_mean,
+                                   float* running_var, float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c] / M, vb = var[c] / M;
+  mean[c] = mu; var[c] = vb;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+  if (running_var) {
+    const float vu = M > 1 ? var[c] * M / (M - 1) : vb;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * vu;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_swish_fwd_kernel(long n, int C, const T* __restrict__ y,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ var,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           T* __restrict__ z) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = i % C;
+    const float xh = (to_f32(y[i]) - mean[c]) * rsqrtf(var[c] + eps);
+    z[i] = from_f32<T>(swishf_(gamma[c] * xh + beta[c]));
+  }
+}
+
+// pass 1: sums[c] += dbn, sums[C+c] += dbn*xhat  with dbn = dz * swish'(bn)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(int M, int C, const T* __restrict__ dz,
+                                                          const T* __restrict__ y,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ var,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ sums) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], is = rsqrtf(var[c] + eps), g = gamma[c], bt = beta[c];
+  const int r0 = blockIdx.y * BN_ROWS, r1 = min(M, r0 + BN_ROWS);
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const long i = (long)r * C + c;
+    const float xh = (to_f32(y[i]) - mu) * is;
+    const float dbn = to_f32(dz[i]) * dswishf_(g * xh + bt);
+    s1 += dbn; s2 += dbn * xh;
+  }
+  atomicAdd(&sums[c], s1);
+  atomicAdd(&sums[C + c], s2);
+}
+// pass 2: dy = gamma*invstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat)); row block 0 also
+// adds dgamma / dbeta.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int C, const T* __restrict__ dz,
+                                                           const T* __restrict__ y,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ var,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           const float* __restrict__ sums,
+                                                           T* __restrict__ dy, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], is = rsqrtf(var[c] + eps), g = gamma[c], bt = beta[c];
+  const float m1 = sums[c] / M, m2 = sums[C + c] / M;
+  if (blockIdx.y == 0) {
+    if (dbeta) atomicAdd(&dbeta[c], sums[c]);
+    if (dgamma) atomicAdd(&dgamma[c], sums[C + c]);
+  }
+  const int r0 = blockIdx.y * BN_ROWS, r1 = min(M, r0 + BN_ROWS);
+  for (int r = r0; r < r1; ++r) {
+    const long i = (long)r * C + c;
+    const float xh = (to_f32(y[i]) - mu) * is;
+    const float dbn = to_f32(dz[i]) * dswishf_(g * xh + bt);
+    dy[i] = from_f32<T>(g * is * (dbn - m1 - xh * m2));
+  }
+}
+
+inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+
+extern "C" int emoasr_dwconv_fwd(int dtype, int B, int Tn, int C, int K, const void* x, const float* w,
+                                 const float* bias, void* y, void* stream) {
+  EMO_CHECK(K <= DW_MAXK && (K & 1), "dwconv: K=%d unsupported (odd, <= %d)", K, DW_MAXK);
+  if (B * Tn == 0) return 0;
+  dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
+  EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)x, w,
+                                                                              bias, (T*)y, 0)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int emoasr_dwconv_bwd_x(int dtype, int B, int Tn, int C, int K, const void* dy, const float* w,
+                                   void* dx, void* stream) {
+  EMO_CHECK(K <= DW_MAXK && (K & 1), "dwconv: K=%d unsupported", K);
+  if (B * Tn == 0) return 0;
+  dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
+  EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)dy, w,
+                                                                              nullptr, (T*)dx, 1)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int emoasr_dwconv_bwd_w(int dtype, int B, int Tn, int C, int K, const void* dy, const void* x,
+                                   float* dw, float* dbias, int accumulate, void* stream) {
+  EMO_CHECK(K <= DW_MAXK && (K & 1), "dwconv: K=%d unsupported", K);
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipMemsetAsync(dw, 0, sizeof(float) * C * K, s);
+    if (dbias) hipMemsetAsync(dbias, 0, sizeof(float) * C, s);
+  }
+  if (B * Tn == 0) return 0;
+  dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
+  EMO_DISPATCH(dtype, (dwconv_bwd_w_kernel<T><<<grid, 256, 0, s>>>(Tn, C, K, (const T*)dy, (const T*)x, dw,
+                                                                  dbias)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_bn_stats(int dtype, int M, int C, const void* y, float* mean, float* var,
+                               float* running_mean, float* running_var, float momentum, void* stream) {
+  EMO_CHECK(M > 0, "bn_stats: empty batch");
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(mean, 0, sizeof(float) * C, s);
+  hipMemsetAsync(var, 0, sizeof(float) * C, s);
+  dim3 grid(cdiv(C, 256), cdiv(M, BN_ROWS));
+  EMO_DISPATCH(dtype, (bn_sum_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)y, mean)));
+  EMO_DISPATCH(dtype, (bn_var_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)y, mean, var)));
+  bn_finalize_kernel<<<cdiv(C, 256), 256, 0, s>>>(M, C, mean, var, running_mean, running_var, momentum);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_bn_swish_fwd(int dtype, int M, int C, const void* y, const float* mean,
+                                   const float* var, const float* gamma, const float* beta, float eps,
+                                   void* z, void* stream) {
+  const long n = (long)M * C;
+  if (n == 0) return 0;
+  EMO_DISPATCH(dtype, (bn_swish_fwd_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(
+                          n, C, (const T*)y, mean, var, gamma, beta, eps, (T*)z)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, const void* y,
+                                   const float* mean, const float* var, const float* gamma,
+                                   const float* beta, float eps, void* dy, float* dgamma, float* dbeta,
+                                   float* scratch, void* stream) {
+  EMO_CHECK(M > 0, "bn_swish_bwd: empty batch");
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(scratch, 0, sizeof(float) * 2 * C, s);
+  dim3 grid(cdiv(C, 256), cdiv(M, BN_ROWS));
+  EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
+                                                                 var, gamma, beta, eps, scratch)));
+  EMO_DISPATCH(dtype, (bn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
+                                                                  var, gamma, beta, eps, scratch, (T*)dy,
+                                                                  dgamma, dbeta)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}

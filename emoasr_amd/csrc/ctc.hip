@@ -1,0 +1,274 @@
+// CTC: row log-sum-exp over the vocabulary, forward/backward lattices, gradient
+// w.r.t. the logits, and greedy decoding.
+//
+// Reference semantics: asr/modeling/decoders/ctc.py:36-38,109-113 ->
+//   nn.CTCLoss(blank, reduction="sum", zero_infinity=True)(log_softmax(logits), ys, elens, ylens) / B
+// and ctc.py:176-201 (_greedy: raw-logit argmax, first max wins, collapse repeats,
+// drop blanks, <eos> kept).
+//
+// Lattice layout: extended label sequence l' = [blank, y1, blank, y2, ..., blank] with
+// S' = 2*ylen+1 states per utterance, padded to S = 2*Lmax+1.  The emissions
+// lp[b,t,s] = logits[b,t,l'_s] - lse[b,t] are gathered once by a fully parallel
+// kernel; the two sequential scans (alpha forward, beta backward in time) then stream
+// contiguous S-wide rows.  One block per (utterance, direction): states across lanes,
+// neighbour exchange through LDS, one barrier per frame.
+#include <algorithm>
+#include "common.h"
+#include "../../include/emoasr_hip.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_lse_kernel(int V, const T* __restrict__ logits, long ld,
+                                                      float* __restrict__ lse, int aligned) {
+  __shared__ float red[16];
+  const T* row = logits + (long)blockIdx.x * ld;
+  constexpr int VEC = 16 / sizeof(T);
+  float m = -INFINITY, s = 0.f;
+  const int nv = aligned ? V / VEC : 0;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    const Vec16<T> v = load16(row + (long)i * VEC);
+    float lm = v.get(0);
+#pragma unroll
+    for (int j = 1; j < VEC; ++j) lm = fmaxf(lm, v.get(j));
+    if (lm > m) { s *= __expf(m - lm); m = lm; }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s += __expf(v.get(j) - m);
+  }
+  for (int i = nv * VEC + threadIdx.x; i < V; i += 256) {
+    const float x = to_f32(row[i]);
+    if (x > m) { s *= __expf(m - x); m = x; }
+    s += __expf(x - m);
+  }
+  const float gm = block_max(m, red);
+  const float gs = block_sum(m == -INFINITY ? 0.f : s * __expf(m - gm), red);
+  if (threadIdx.x == 0) lse[blockIdx.x] = gm + logf(gs);
+}
+
+__device__ __forceinline__ int ext_label(const int* lab, int s, int blank) {
+  return (s & 1) ? lab[s >> 1] : blank;
+}
+
+// lp[b,t,s] = logits[b,t,l'_s] - lse[b,t]   (t < elens[b], s < 2*ylens[b]+1; else -inf)
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_gather_kernel(int Tn, int S, int Lmax, const T* __restrict__ logits,
+                                                         long ld, const float* __restrict__ lse,
+                                                         const int* __restrict__ labels,
+                                                         const int* __restrict__ elens,
+                                                         const int* __restrict__ ylens, int blank,
+                                                         float* __restrict__ lp) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int Sb = 2 * ylens[b] + 1;
+  const bool live = t < elens[b];
+  const long row = (long)b * Tn + t;
+  const float l = live ? lse[row] : 0.f;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    float v = -INFINITY;
+    if (live && s < Sb) v = to_f32(logits[row * ld + ext_label(labels + (long)b * Lmax, s, blank)]) - l;
+    lp[row * S + s] = v;
+  }
+}
+
+// blocks [0,B): alpha (forward in time); blocks [B,2B): beta (backward in time).
+__global__ __launch_bounds__(1024) void ctc_lattice_kernel(int B, int Tn, int S, int Lmax,
+                                                           const float* __restrict__ lp,
+                                                           const int* __restrict__ labels,
+                                                           const int* __restrict__ elens,
+                                                           const int* __restrict__ ylens, int blank,
+                                                           float* __restrict__ alpha, float* __restrict__ beta,
+                                                           float* __restrict__ nll) {
+  extern __shared__ float sh[];  // [2][S + 4]
+  const bool fwd = blockIdx.x < B;
+  const int b = fwd ? blockIdx.x : blockIdx.x - B;
+  const int s = threadIdx.x;
+  const int len = elens[b], L = ylens[b], Sb = 2 * L + 1;
+  const int* lab = labels + (long)b * Lmax;
+  float* out = (fwd ? alpha : beta) + (long)b * Tn * S;
+  const float* lpb = lp + (long)b * Tn * S;
+  if (len <= 0) {
+    if (fwd && s == 0) nll[b] = L == 0 ? 0.f : INFINITY;
+    return;
+  }
+  // can state s receive the skip transition (from s-2 forward / s+2 backward)?
+  bool skip = false;
+  const int SP = S + 4;
+  float* buf0 = sh + 2;           // index -2..S+1 valid
+  float* buf1 = sh + SP + 2;
+  if (s < Sb && (s & 1)) {
+    const int me = lab[s >> 1];
+    if (fwd) skip = s >= 3 && lab[(s >> 1) - 1] != me;
+    else skip = s + 2 < Sb && lab[(s >> 1) + 1] != me;
+  }
+  for (int i = threadIdx.x; i < 2 * SP; i += blockDim.x) sh[i] = -INFINITY;
+  __syncthreads();
+  // initial frame
+  {
+    const int t = fwd ? 0 : len - 1;
+    float v = -INFINITY;
+    if (s < Sb) {
+      const bool start = fwd ? (s <= 1) : (s >= Sb - 2);
+      if (start) v = lpb[(long)t * S + s];
+    }
+    if (s < S) { out[(long)t * S + s] = v; buf0[s] = v; }
+  }
+  __syncthreads();
+  float* prev = buf0; float* cur = buf1;
+  for (int i = 1; i < len; ++i) {
+    const int t = fwd ? i : len - 1 - i;
+    float v = -INFINITY;
+    if (s < Sb) {
+      const float e = lpb[(long)t * S + s];
+      const float a0 = prev[s];
+      const float a1 = fwd ? prev[s - 1] : prev[s + 1];
+      const float a2 = skip ? (fwd ? prev[s - 2] : prev[s + 2]) : -INFINITY;
+      v = log_add3(a0, a1, a2) + e;
+    }
+    if (s < S) { out[(long)t * S + s] = v; cur[s] = v; }
+    __syncthreads();
+    float* tmp = prev; prev = cur; cur = tmp;
+  }
+  if (fwd && s == 0) {
+    const float a = prev[Sb - 1];
+    const float c = Sb >= 2 ? prev[Sb - 2] : -INFINITY;
+    nll[b] = -log_add(a, c);
+  }
+}
+
+// one block per (b,t) row: softmax row in LDS, subtract state occupancies, scale, store.
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(int Tn, int V, int S, int Lmax,
+                                                       const T* __restrict__ logits, long ld,
+                                                       const float* __restrict__ lse,
+                                                       const int* __restrict__ labels,
+                                                       const int* __restrict__ elens,
+                                                       const int* __restrict__ ylens, int blank,
+                                                       const float* __restrict__ lp,
+                                                       const float* __restrict__ alpha,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ nll, float gscale,
+                                                       T* __restrict__ grad, long ldg) {
+  extern __shared__ float rowbuf[];  // [V]
+  const int b = blockIdx.y, t = blockIdx.x;
+  const long row = (long)b * Tn + t;
+  T* g = grad + row * ldg;
+  const float nl = nll[b];
+  if (t >= elens[b] || !isfinite(nl)) {
+    for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(0.f);
+    return;
+  }
+  const float l = lse[row];
+  const T* lg = logits + row * ld;
+  for (int v = threadIdx.x; v < V; v += 256) rowbuf[v] = __expf(to_f32(lg[v]) - l);
+  __syncthreads();
+  const int Sb = 2 * ylens[b] + 1;
+  const int* lab = labels + (long)b * Lmax;
+  for (int s = threadIdx.x; s < Sb; s += 256) {
+    const long o = row * S + s;
+    const float occ = __expf(alpha[o] + beta[o] - lp[o] + nl);
+    if (occ > 0.f) atomicAdd(&rowbuf[ext_label(lab, s, blank)], -occ);
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(rowbuf[v] * gscale);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_kernel(int V, const T* __restrict__ logits, long ld,
+                                                     int* __restrict__ best) {
+  __shared__ float rv[4];
+  __shared__ int ri[4];
+  const T* row = logits + (long)blockIdx.x * ld;
+  float m = -INFINITY; int mi = 0x7fffffff;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float x = to_f32(row[v]);
+    if (x > m || (x == m && v < mi)) { m = x; mi = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o, 64);
+    const int oi = __shfl_xor(mi, o, 64);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = m; ri[threadIdx.x >> 6] = mi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (rv[w] > m || (rv[w] == m && ri[w] < mi)) { m = rv[w]; mi = ri[w]; }
+    best[blockIdx.x] = mi == 0x7fffffff ? 0 : mi;
+  }
+}
+
+__global__ void collapse_kernel(int B, int Tn, const int* __restrict__ best, const int* __restrict__ elens,
+                                int blank, int* __restrict__ hyp, int* __restrict__ hyplen) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int len = min(elens[b], Tn);
+  int n = 0, prev = -1;
+  for (int t = 0; t < len; ++t) {
+    const int v = best[(long)b * Tn + t];
+    if (v != prev && v != blank) hyp[(long)b * Tn + n++] = v;
+    prev = v;
+  }
+  hyplen[b] = n;
+}
+
+}  // namespace
+
+extern "C" int emoasr_row_lse(int dtype, int M, int V, const void* logits, long ld, float* lse,
+                              void* stream) {
+  if (M == 0) return 0;
+  const int vec = dtype == EMO_BF16 ? 8 : 4;
+  const int aligned = (ld % vec == 0) && (((uintptr_t)logits & 15) == 0);
+  EMO_DISPATCH(dtype, (row_lse_kernel<T><<<M, 256, 0, (hipStream_t)stream>>>(V, (const T*)logits, ld, lse,
+                                                                            aligned)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_ctc_forward(int dtype, int B, int Tn, int V, int Lmax, const void* logits, long ld,
+                                  const float* lse, const int* labels, const int* elens, const int* ylens,
+                                  int blank, float* lp, float* alpha, float* beta, float* nll,
+                                  void* stream) {
+  const int S = 2 * Lmax + 1;
+  EMO_CHECK(S <= 1024, "ctc: 2*Lmax+1=%d exceeds 1024 lattice states", S);
+  if (B == 0 || Tn == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 ggrid(Tn, B);
+  const int gthreads = std::min(256, cdiv(S, 64) * 64);
+  EMO_DISPATCH(dtype, (ctc_gather_kernel<T><<<ggrid, gthreads, 0, s>>>(Tn, S, Lmax, (const T*)logits, ld, lse,
+                                                                      labels, elens, ylens, blank, lp)));
+  const int threads = cdiv(S, 64) * 64;
+  ctc_lattice_kernel<<<2 * B, threads, sizeof(float) * 2 * (S + 4), s>>>(B, Tn, S, Lmax, lp, labels, elens,
+                                                                        ylens, blank, alpha, beta, nll);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_ctc_grad(int dtype, int B, int Tn, int V, int Lmax, const void* logits, long ld,
+                               const float* lse, const int* labels, const int* elens, const int* ylens,
+                               int blank, const float* lp, const float* alpha, const float* beta,
+                               const float* nll, float gscale, void* grad, long ldg, void* stream) {
+  const int S = 2 * Lmax + 1;
+  EMO_CHECK((size_t)V * 4 <= 160 * 1024 - 256, "ctc_grad: V=%d too large for an LDS row", V);
+  if (B == 0 || Tn == 0) return 0;
+  dim3 grid(Tn, B);
+  EMO_DISPATCH(dtype, {
+    if ((size_t)V * 4 > 64 * 1024)
+      hipFuncSetAttribute((const void*)ctc_grad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, V * 4);
+    ctc_grad_kernel<T><<<grid, 256, sizeof(float) * V, (hipStream_t)stream>>>(
+        Tn, V, S, Lmax, (const T*)logits, ld, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale,
+        (T*)grad, ldg);
+  });
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_ctc_greedy(int dtype, int B, int Tn, int V, const void* logits, long ld,
+                                 const int* elens, int blank, int* best, int* hyp, int* hyplen,
+                                 void* stream) {
+  if (B == 0 || Tn == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  EMO_DISPATCH(dtype, (argmax_kernel<T><<<B * Tn, 256, 0, s>>>(V, (const T*)logits, ld, best)));
+  collapse_kernel<<<cdiv(B, 64), 64, 0, s>>>(B, Tn, best, elens, blank, hyp, hyplen);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}

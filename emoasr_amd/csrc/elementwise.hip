@@ -1,0 +1,160 @@
+// Element-wise, layout and column-reduction helpers (all HBM-bound).
+#include "common.h"
+#include "../../include/emoasr_hip.h"
+
+namespace {
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void strided_copy_kernel(const TI* __restrict__ in, TO* __restrict__ out,
+                                                           int d1, int d2, int d3, long s0, long s1,
+                                                           long s2, long s3, long n, int accumulate) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    long r = i;
+    const int i3 = r % d3; r /= d3;
+    const int i2 = r % d2; r /= d2;
+    const int i1 = r % d1; r /= d1;
+    const long src = r * s0 + i1 * s1 + i2 * s2 + i3 * s3;
+    float v = to_f32(in[src]);
+    if (accumulate) v += to_f32(out[i]);
+    out[i] = from_f32<TO>(v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_dropout_kernel(long n, const T* __restrict__ x,
+                                                            T* __restrict__ y, float scale, float p,
+                                                            uint64_t seed) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    y[i] = from_f32<T>(to_f32(x[i]) * scale * dropout_scale(seed, (uint64_t)i, p));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void posenc_kernel(int T_, int N, long n, const T* __restrict__ x,
+                                                     const float* __restrict__ pe, float scale, float p,
+                                                     uint64_t seed, T* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int col = i % N;
+    const int t = (i / N) % T_;
+    float v = to_f32(x[i]) * scale;
+    if (pe) v += pe[(long)t * N + col];
+    y[i] = from_f32<T>(v * dropout_scale(seed, (uint64_t)i, p));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(long n, const T* __restrict__ a, const T* __restrict__ b,
+                                                  T* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    y[i] = from_f32<T>(to_f32(a[i]) + to_f32(b[i]));
+}
+
+// out[n] += scale * sum_m X[m, n]; block = 256 columns x ROWS rows, atomics across row blocks.
+constexpr int CS_ROWS = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const T* __restrict__ X, long ldx,
+                                                     float* __restrict__ out, float scale) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += to_f32(X[(long)r * ldx + col]);
+  atomicAdd(&out[col], s * scale);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void glu_fwd_kernel(long n, int C, const T* __restrict__ in,
+                                                      T* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long m = i / C; const int c = i % C;
+    const float a = to_f32(in[m * 2 * C + c]), g = to_f32(in[m * 2 * C + C + c]);
+    out[i] = from_f32<T>(a * sigmoidf_(g));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(long n, int C, const T* __restrict__ in,
+                                                      const T* __restrict__ dout, T* __restrict__ din) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long m = i / C; const int c = i % C;
+    const float a = to_f32(in[m * 2 * C + c]), g = to_f32(in[m * 2 * C + C + c]);
+    const float s = sigmoidf_(g), d = to_f32(dout[i]);
+    din[m * 2 * C + c] = from_f32<T>(d * s);
+    din[m * 2 * C + C + c] = from_f32<T>(d * a * s * (1.f - s));
+  }
+}
+
+inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+
+extern "C" int emoasr_strided_copy(int dtype_in, int dtype_out, const void* in, void* out, int d0, int d1,
+                                   int d2, int d3, long s0, long s1, long s2, long s3, int accumulate,
+                                   void* stream) {
+  const long n = (long)d0 * d1 * d2 * d3;
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+#define SC(TI, TO) strided_copy_kernel<TI, TO><<<ew_grid(n), 256, 0, s>>>((const TI*)in, (TO*)out, d1, d2, d3, s0, s1, s2, s3, n, accumulate)
+  if (dtype_in == EMO_F32 && dtype_out == EMO_F32) SC(float, float);
+  else if (dtype_in == EMO_F32 && dtype_out == EMO_BF16) SC(float, bf16);
+  else if (dtype_in == EMO_BF16 && dtype_out == EMO_F32) SC(bf16, float);
+  else if (dtype_in == EMO_BF16 && dtype_out == EMO_BF16) SC(bf16, bf16);
+  else { emo_set_error("strided_copy: bad dtypes"); return 1; }
+#undef SC
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_scale_dropout(int dtype, long n, const void* x, void* y, float scale, float drop_p,
+                                    uint64_t seed, void* stream) {
+  if (n == 0) return 0;
+  EMO_DISPATCH(dtype, (scale_dropout_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(
+                          n, (const T*)x, (T*)y, scale, drop_p, seed)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_posenc(int dtype, int B, int T_, int N, const void* x, const float* pe, float scale,
+                             float drop_p, uint64_t seed, void* y, void* stream) {
+  const long n = (long)B * T_ * N;
+  if (n == 0) return 0;
+  EMO_DISPATCH(dtype, (posenc_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(
+                          T_, N, n, (const T*)x, pe, scale, drop_p, seed, (T*)y)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_add(int dtype, long n, const void* a, const void* b, void* y, void* stream) {
+  if (n == 0) return 0;
+  EMO_DISPATCH(dtype, (add_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(n, (const T*)a,
+                                                                                 (const T*)b, (T*)y)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_colsum(int dtype, int M, int N, const void* X, long ldx, float* out, float scale,
+                             int accumulate, void* stream) {
+  if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * N, (hipStream_t)stream);
+  if (M == 0) return 0;
+  dim3 grid(cdiv(N, 256), cdiv(M, CS_ROWS));
+  EMO_DISPATCH(dtype, (colsum_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(M, N, (const T*)X, ldx,
+                                                                              out, scale)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_glu_fwd(int dtype, int M, int C, const void* in, void* out, void* stream) {
+  const long n = (long)M * C;
+  if (n == 0) return 0;
+  EMO_DISPATCH(dtype, (glu_fwd_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(n, C, (const T*)in,
+                                                                                     (T*)out)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int emoasr_glu_bwd(int dtype, int M, int C, const void* in, const void* dout, void* din,
+                              void* stream) {
+  const long n = (long)M * C;
+  if (n == 0) return 0;
+  EMO_DISPATCH(dtype, (glu_bwd_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(
+                          n, C, (const T*)in, (const T*)dout, (T*)din)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,417 @@
+// MFMA GEMM kernels (gfx950): the contraction workhorse of the encoder.
+//
+//   gemm_nt : C[M,N]   = epilogue(alpha * A[M,K] . B[N,K]^T)       forward / dgrad
+//   gemm_tn : C[N1,N2] (+)= alpha * A[K,N1]^T . B[K,N2]            wgrad (f32 out, split-K)
+//
+// Replaces the nn.Linear / 1x1 Conv1d / Conv2d calls of the reference:
+//   asr/modeling/transformer.py:62-71,94,102-118 (q/k/v/out, FFN w1/w2),
+//   asr/modeling/conformer.py:62,103-117 (linear_pos, pointwise convs),
+//   asr/modeling/encoders/conv.py:9-19 (Conv2d k3 s2 as implicit GEMM, Linear),
+//   asr/modeling/decoders/ctc.py:34,103 (vocabulary head).
+//
+// Block = 256 threads = 4 waves in a 2x2 arrangement; each wave owns a
+// (BM/2)x(BN/2) patch made of 32x32 MFMA tiles.  Tiles are staged global ->
+// registers -> LDS (double buffered, one barrier per k-tile); the next k-tile's
+// global loads are issued before the current tile's MFMAs.
+#include <algorithm>
+#include "mma.h"
+#include "../../include/emoasr_hip.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// addressing of the "gathered" operand for the Conv2d(k3,s2) implicit GEMM
+// rows  m = (b, t2, f2)          -> base offset of the 3x3xC input patch
+// cols  k = (kh, kw, c)          -> (kh*F1 + kw)*C + c
+// The conv input is channels-last: y1[b, t1, f1, c].
+// ----------------------------------------------------------------------------
+struct ConvGeom {
+  int T1, F1, T2, F2, C;
+};
+__device__ __forceinline__ long conv_row_base(const ConvGeom& g, int m) {
+  const int per_b = g.T2 * g.F2;
+  const int b = m / per_b, r = m - b * per_b;
+  const int t2 = r / g.F2, f2 = r - t2 * g.F2;
+  return (((long)b * g.T1 + 2 * t2) * g.F1 + 2 * f2) * g.C;
+}
+__device__ __forceinline__ int conv_k_off(const ConvGeom& g, int k) {
+  const int p = k / g.C, c = k - p * g.C;
+  const int kh = p / 3, kw = p - kh * 3;
+  return (kh * g.F1 + kw) * g.C + c;
+}
+
+struct NtArgs {
+  int M, N, K;
+  const void* A; long lda;
+  const void* B; long ldb;
+  void* C; long ldc;
+  emoasr_epilogue_t ep;
+  ConvGeom cg;
+};
+
+template <typename T> struct TileCfg {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int BK = sizeof(T) == 2 ? 32 : 16;
+  static constexpr int KV = BK / VEC;                       // 16-byte vectors per tile row (= 4)
+  static constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 1);  // padded LDS row (elements)
+};
+
+template <typename T>
+__device__ __forceinline__ void lds_store_row(T* dst, const Vec16<T>& v) {
+  if constexpr (sizeof(T) == 2) {
+    store16(dst, v);  // row stride 80 B keeps 16-B alignment
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[j] = v.v[j];  // odd f32 row stride: scalar stores
+  }
+}
+
+template <typename T, int BM, int BN, int AMODE>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
+  using Cfg = TileCfg<T>;
+  using M_ = Mma<T>;
+  constexpr int VEC = Cfg::VEC, BK = Cfg::BK, KV = Cfg::KV, LD = Cfg::LD;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int A_IT = BM * KV / 256, B_IT = BN * KV / 256;
+  static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 threads");
+
+  __shared__ __attribute__((aligned(16))) T As[2][BM * LD];
+  __shared__ __attribute__((aligned(16))) T Bs[2][BN * LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const T* __restrict__ A = static_cast<const T*>(g.A);
+  const T* __restrict__ B = static_cast<const T*>(g.B);
+
+  // per-thread staging assignments (fixed rows across the k loop)
+  const T* a_ptr[A_IT]; bool a_ok[A_IT]; int a_lds[A_IT]; int a_kv[A_IT];
+  const T* b_ptr[B_IT]; bool b_ok[B_IT]; int b_lds[B_IT]; int b_kv[B_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int v = tid + i * 256, r = v / KV, kv = v % KV;
+    a_kv[i] = kv * VEC; a_lds[i] = r * LD + kv * VEC;
+    a_ok[i] = (m0 + r) < g.M;
+    const int row = a_ok[i] ? (m0 + r) : 0;
+    if constexpr (AMODE == 1) a_ptr[i] = A + conv_row_base(g.cg, row);
+    else a_ptr[i] = A + (long)row * g.lda;
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int v = tid + i * 256, r = v / KV, kv = v % KV;
+    b_kv[i] = kv * VEC; b_lds[i] = r * LD + kv * VEC;
+    b_ok[i] = (n0 + r) < g.N;
+    b_ptr[i] = B + (long)(b_ok[i] ? (n0 + r) : 0) * g.ldb;
+  }
+
+  Vec16<T> a_reg[A_IT], b_reg[B_IT];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int k = k0 + a_kv[i];
+      if (a_ok[i] && k < g.K) {
+        if constexpr (AMODE == 1) a_reg[i] = load16(a_ptr[i] + conv_k_off(g.cg, k));
+        else a_reg[i] = load16(a_ptr[i] + k);
+      } else a_reg[i].zero();
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int k = k0 + b_kv[i];
+      if (b_ok[i] && k < g.K) b_reg[i] = load16(b_ptr[i] + k);
+      else b_reg[i].zero();
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) lds_store_row(&As[buf][a_lds[i]], a_reg[i]);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) lds_store_row(&Bs[buf][b_lds[i]], b_reg[i]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (g.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += M_::KSTEP) {
+      typename M_::Frag af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = M_::load_kc(As[buf], LD, wm + i * 32, kk, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = M_::load_kc(Bs[buf], LD, wn + j * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(af[i], bfr[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------
+  const emoasr_epilogue_t& ep = g.ep;
+  const T* __restrict__ res = static_cast<const T*>(ep.residual);
+  const T* __restrict__ dpre = static_cast<const T*>(ep.dact_pre);
+  T* __restrict__ pre_out = static_cast<T*>(ep.pre_out);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn + j * 32 + c_col(lane);
+      if (col >= g.N) continue;
+      const float bias = ep.bias ? ep.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + i * 32 + c_row(r, lane);
+        if (row >= g.M) continue;
+        float v = ep.alpha * acc[i][j][r] + bias;
+        const long off = (long)row * g.ldc + col;
+        if (pre_out) pre_out[off] = from_f32<T>(v);
+        v = apply_act(ep.act, v);
+        if (dpre) v *= apply_dact(ep.dact, to_f32(dpre[off]));
+        if (ep.drop_p > 0.f) v *= dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col, ep.drop_p);
+        if (res) v = to_f32(res[(long)row * ep.ldr + col]) + ep.res_scale * v;
+        if (ep.out_f32) static_cast<float*>(g.C)[off] = v;
+        else static_cast<T*>(g.C)[off] = from_f32<T>(v);
+      }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// TN: C[n1, n2] += alpha * sum_k A[k, n1] * B[k, n2]      (f32 output, atomics
+// across split-K slices).  BMODE == 1 gathers B rows through the conv geometry:
+// B[k = (b,t2,f2)][n2 = (kh,kw,c)].
+// ----------------------------------------------------------------------------
+struct TnArgs {
+  int N1, N2, K;
+  const void* A; long lda;
+  const void* B; long ldb;
+  float* C; long ldc;
+  float alpha;
+  int k_tiles_per_split;
+  ConvGeom cg;
+};
+
+template <typename T, int BN1, int BN2, int BMODE, bool TR>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
+  using Cfg = TileCfg<T>;
+  using M_ = Mma<T>;
+  constexpr int VEC = Cfg::VEC, BK = Cfg::BK;
+  constexpr int PAD = sizeof(T) == 2 ? 32 : 0;
+  constexpr int LDA = BN1 + PAD, LDB = BN2 + PAD;
+  constexpr int W1 = BN1 / 2, W2 = BN2 / 2, TM = W1 / 32, TN = W2 / 32;
+  constexpr int AV = BN1 / VEC, BV = BN2 / VEC;  // vectors per k row
+  constexpr int A_IT = BK * AV / 256, B_IT = BK * BV / 256;
+  static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");
+
+  __shared__ __attribute__((aligned(16))) T As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) T Bs[2][BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w1 = (wave >> 1) * W1, w2 = (wave & 1) * W2;
+  const int n1_0 = blockIdx.y * BN1, n2_0 = blockIdx.x * BN2;
+  const T* __restrict__ A = static_cast<const T*>(g.A);
+  const T* __restrict__ B = static_cast<const T*>(g.B);
+
+  const int nk_total = (g.K + BK - 1) / BK;
+  const int kt_begin = blockIdx.z * g.k_tiles_per_split;
+  const int kt_end = nk_total < kt_begin + g.k_tiles_per_split ? nk_total : kt_begin + g.k_tiles_per_split;
+  if (kt_begin >= kt_end) return;
+
+  int b_koff = 0;
+  if constexpr (BMODE == 1) b_koff = conv_k_off(g.cg, n2_0);  // tile lies inside one (kh,kw)
+
+  Vec16<T> a_reg[A_IT], b_reg[B_IT];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int v = tid + i * 256, kr = v / AV, nv = (v % AV) * VEC;
+      const int k = k0 + kr, n = n1_0 + nv;
+      if (k < g.K && n < g.N1) a_reg[i] = load16(A + (long)k * g.lda + n);
+      else a_reg[i].zero();
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int v = tid + i * 256, kr = v / BV, nv = (v % BV) * VEC;
+      const int k = k0 + kr, n = n2_0 + nv;
+      if (k < g.K && n < g.N2) {
+        if constexpr (BMODE == 1) b_reg[i] = load16(B + conv_row_base(g.cg, k) + b_koff + nv);
+        else b_reg[i] = load16(B + (long)k * g.ldb + n);
+      } else b_reg[i].zero();
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int v = tid + i * 256, kr = v / AV, nv = (v % AV) * VEC;
+      store16(&As[buf][kr * LDA + nv], a_reg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int v = tid + i * 256, kr = v / BV, nv = (v % BV) * VEC;
+      store16(&Bs[buf][kr * LDB + nv], b_reg[i]);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_tile(kt_begin * BK);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += M_::KSTEP) {
+      typename M_::Frag af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = M_::template load_km<TR>(As[buf], LDA, kk, w1 + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = M_::template load_km<TR>(Bs[buf], LDB, kk, w2 + j * 32, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(af[i], bfr[j], acc[i][j]);
+    }
+    if (kt + 1 < kt_end) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n2_0 + w2 + j * 32 + c_col(lane);
+      if (col >= g.N2) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = n1_0 + w1 + i * 32 + c_row(r, lane);
+        if (row >= g.N1) continue;
+        atomicAdd(&g.C[(long)row * g.ldc + col], g.alpha * acc[i][j][r]);
+      }
+    }
+}
+
+int g_tr_read = 1;
+
+template <typename T, int AMODE>
+int launch_nt(const NtArgs& a, hipStream_t s) {
+  const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+  const long t12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64);
+  if (t128 >= 512) {
+    dim3 grid(cdiv(a.N, 128), cdiv(a.M, 128));
+    gemm_nt_kernel<T, 128, 128, AMODE><<<grid, 256, 0, s>>>(a);
+  } else if (t12864 >= 384) {
+    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 128));
+    gemm_nt_kernel<T, 128, 64, AMODE><<<grid, 256, 0, s>>>(a);
+  } else {
+    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64));
+    gemm_nt_kernel<T, 64, 64, AMODE><<<grid, 256, 0, s>>>(a);
+  }
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int BMODE>
+int launch_tn(TnArgs a, hipStream_t s) {
+  constexpr int BK = TileCfg<T>::BK;
+  const int nk = cdiv(a.K, BK);
+  const bool big = (long)cdiv(a.N1, 128) * cdiv(a.N2, 128) >= 8 && a.N1 >= 128 && a.N2 >= 128;
+  const int bn = big ? 128 : 64;
+  const long tiles = (long)cdiv(a.N1, bn) * cdiv(a.N2, bn);
+  // enough split-K slices to put ~2 blocks on every CU, at least 4 k-tiles each
+  int splits = (int)((512 + tiles - 1) / tiles);
+  splits = std::max(1, std::min(splits, nk / 4 > 0 ? nk / 4 : 1));
+  a.k_tiles_per_split = cdiv(nk, splits);
+  splits = cdiv(nk, a.k_tiles_per_split);
+  dim3 grid(cdiv(a.N2, bn), cdiv(a.N1, bn), splits);
+  if (big) {
+    if (g_tr_read) gemm_tn_kernel<T, 128, 128, BMODE, true><<<grid, 256, 0, s>>>(a);
+    else gemm_tn_kernel<T, 128, 128, BMODE, false><<<grid, 256, 0, s>>>(a);
+  } else {
+    if (g_tr_read) gemm_tn_kernel<T, 64, 64, BMODE, true><<<grid, 256, 0, s>>>(a);
+    else gemm_tn_kernel<T, 64, 64, BMODE, false><<<grid, 256, 0, s>>>(a);
+  }
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+void emo_gemm_set_tr_read(int v) { g_tr_read = v; }
+
+static int check_vec(long ld, int dtype, const char* what) {
+  const int vec = dtype == EMO_BF16 ? 8 : 4;
+  if (ld % vec != 0) { emo_set_error("gemm: %s=%ld must be a multiple of %d elements", what, ld, vec); return 1; }
+  return 0;
+}
+
+extern "C" int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B,
+                              long ldb, void* C, long ldc, const emoasr_epilogue_t* ep, void* stream) {
+  EMO_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem %d %d %d", M, N, K);
+  if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") || check_vec(K, dtype, "K")) return 1;
+  NtArgs a{};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  if (ep) a.ep = *ep; else { a.ep = emoasr_epilogue_t{}; a.ep.alpha = 1.f; }
+  EMO_DISPATCH(dtype, return (launch_nt<T, 0>(a, (hipStream_t)stream)));
+}
+
+extern "C" int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, long lda, const void* B,
+                              long ldb, float* C, long ldc, float alpha, int accumulate, void* stream) {
+  EMO_CHECK(N1 > 0 && N2 > 0 && K > 0, "gemm_tn: empty problem");
+  if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") || check_vec(N1, dtype, "N1") ||
+      check_vec(N2, dtype, "N2")) return 1;
+  if (!accumulate) {
+    if (ldc == N2) hipMemsetAsync(C, 0, sizeof(float) * (size_t)N1 * N2, (hipStream_t)stream);
+    else hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N2, N1, (hipStream_t)stream);
+  }
+  TnArgs a{};
+  a.N1 = N1; a.N2 = N2; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.alpha = alpha;
+  EMO_DISPATCH(dtype, return (launch_tn<T, 0>(a, (hipStream_t)stream)));
+}
+
+// Conv2d(C->C, k3, s2) over channels-last y1[B,T1,F1,C] as an implicit GEMM:
+//   y2[(b,t2,f2), n] = relu(bias[n] + sum_{kh,kw,c} y1[b,2t2+kh,2f2+kw,c] * W[n,(kh,kw,c)])
+extern "C" int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const void* y1, const void* w,
+                                void* y2, const emoasr_epilogue_t* ep, void* stream) {
+  EMO_CHECK(T1 >= 3 && F1 >= 3, "conv2: input too small (T1=%d F1=%d)", T1, F1);
+  const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  EMO_CHECK(C % 32 == 0, "conv2: C must be a multiple of 32");
+  NtArgs a{};
+  a.M = B * T2 * F2; a.N = C; a.K = 9 * C; a.A = y1; a.lda = 0; a.B = w; a.ldb = 9 * C; a.C = y2; a.ldc = C;
+  a.ep = *ep;
+  a.cg = ConvGeom{T1, F1, T2, F2, C};
+  EMO_DISPATCH(dtype, return (launch_nt<T, 1>(a, (hipStream_t)stream)));
+}
+
+// dW[n, (kh,kw,c)] (+)= sum_{(b,t2,f2)} dy2[(b,t2,f2), n] * y1[b,2t2+kh,2f2+kw,c]
+extern "C" int emoasr_conv2_wgrad(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* y1,
+                                  float* dw, int accumulate, void* stream) {
+  const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  EMO_CHECK(T1 >= 3 && F1 >= 3, "conv2_wgrad: input too small");
+  EMO_CHECK(C % 128 == 0, "conv2_wgrad: C must be a multiple of 128");
+  if (!accumulate) hipMemsetAsync(dw, 0, sizeof(float) * (size_t)C * 9 * C, (hipStream_t)stream);
+  TnArgs a{};
+  a.N1 = C; a.N2 = 9 * C; a.K = B * T2 * F2; a.A = dy2; a.lda = C; a.B = y1; a.ldb = 0; a.C = dw;
+  a.ldc = 9 * C; a.alpha = 1.f;
+  a.cg = ConvGeom{T1, F1, T2, F2, C};
+  EMO_DISPATCH(dtype, return (launch_tn<T, 1>(a, (hipStream_t)stream)));
+}

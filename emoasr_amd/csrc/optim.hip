@@ -1,0 +1,71 @@
+// Optimizer-side kernels on flat f32 buffers: squared gradient norm, Adam.
+// Reference: asr/train_asr.py:84-92 (clip_grad_norm_, NaN skip) + torch.optim.Adam with
+// coupled L2 weight decay (train_asr.py:228), lr set by ScheduledOptimizer (optimizers.py:56-82).
+#include "common.h"
+#include "../../include/emoasr_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(long n, const float* __restrict__ x, float* out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, float lr,
+                                                   float beta1, float beta2, float eps, float wd, float bc1,
+                                                   float bc2_sqrt, const float* __restrict__ gnorm_sq,
+                                                   float clip, float grad_mult) {
+  float mult = grad_mult;
+  if (gnorm_sq) {
+    const float nsq = *gnorm_sq * grad_mult * grad_mult;
+    if (!isfinite(nsq)) return;  // NaN / Inf gradient: skip the step (train_asr.py:88-89)
+    if (clip > 0.f) {
+      const float c = clip / (sqrtf(nsq) + 1e-6f);
+      if (c < 1.f) mult *= c;
+    }
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pi = p[i];
+    const float gi = g[i] * mult + wd * pi;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+
+extern "C" int emoasr_sqnorm(long n, const float* x, float* out, void* stream) {
+  if (n == 0) return 0;
+  EMO_CHECK(((uintptr_t)x & 15) == 0, "sqnorm: buffer must be 16-byte aligned");
+  sqnorm_kernel<<<ew_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(n, x, out);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_adam_step(long n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int step,
+                                const float* gnorm_sq, float clip, float grad_mult, void* stream) {
+  if (n == 0) return 0;
+  EMO_CHECK(step >= 1, "adam: step must be >= 1");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  adam_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay,
+                                                          bc1, sqrtf(bc2), gnorm_sq, clip, grad_mult);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}

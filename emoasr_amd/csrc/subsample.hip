@@ -1,0 +1,159 @@
+// Conv2d subsampling front-end, first layer and the col2im half of the second layer's
+// data gradient (asr/modeling/encoders/conv.py:9-15,20-23).
+//
+// conv1: Conv2d(1 -> C, k3, s2) + ReLU on x[B,T,F] (f32 features).  One block per
+// (b, t1): the three input rows it needs live in LDS, each thread owns one output
+// channel (9 weights in registers) and writes channels-last y1[b,t1,f1,:] rows, so
+// every store is a full coalesced C-wide segment.  conv2 runs as an implicit GEMM
+// over this layout (gemm.hip).
+#include "common.h"
+#include "../../include/emoasr_hip.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(int Tn, int F, int T1, int F1, int C,
+                                                        const float* __restrict__ x,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        T* __restrict__ y1) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];  // [3][F]
+  const int b = blockIdx.x / T1, t1 = blockIdx.x % T1;
+  const float* xb = x + ((long)b * Tn + 2 * t1) * F;
+  for (int i = threadIdx.x; i < 3 * F; i += blockDim.x) rows[i] = xb[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float wr[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) wr[j] = w[c * 9 + j];
+    const float bv = bias[c];
+    T* yo = y1 + ((long)b * T1 + t1) * F1 * C + c;
+    for (int f1 = 0; f1 < F1; ++f1) {
+      float acc = bv;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc += wr[kh * 3 + kw] * rows[kh * F + 2 * f1 + kw];
+      yo[(long)f1 * C] = from_f32<T>(fmaxf(acc, 0.f));
+    }
+  }
+}
+
+// dw1[c, kh*3+kw] += sum dy1[b,t1,f1,c] * x[b,2t1+kh,2f1+kw];  db1[c] += sum dy1
+constexpr int C1_TROWS = 4;  // t1 rows per block
+template <typename T>
+__global__ __launch_bounds__(1024) void conv1_wgrad_kernel(int Tn, int F, int T1, int F1, int C,
+                                                          const float* __restrict__ x,
+                                                          const T* __restrict__ dy1,
+                                                          float* __restrict__ dw, float* __restrict__ db) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];  // [3][F]
+  const int nchunk = (T1 + C1_TROWS - 1) / C1_TROWS;
+  const int b = blockIdx.x / nchunk, tc = blockIdx.x % nchunk;
+  float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float sb = 0.f;
+  const int c = threadIdx.x;  // launched with blockDim = C (<= 1024) rounded up to 64
+  for (int tt = 0; tt < C1_TROWS; ++tt) {
+    const int t1 = tc * C1_TROWS + tt;
+    if (t1 >= T1) break;
+    const float* xb = x + ((long)b * Tn + 2 * t1) * F;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * F; i += blockDim.x) rows[i] = xb[i];
+    __syncthreads();
+    if (c < C) {
+      const T* dyo = dy1 + ((long)b * T1 + t1) * F1 * C + c;
+      for (int f1 = 0; f1 < F1; ++f1) {
+        const float d = to_f32(dyo[(long)f1 * C]);
+        sb += d;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] += d * rows[kh * F + 2 * f1 + kw];
+      }
+    }
+  }
+  if (c < C) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) atomicAdd(&dw[c * 9 + j], acc[j]);
+    atomicAdd(&db[c], sb);
+  }
+}
+
+// dy1[b,t1,f1,c] = [y1 > 0] * sum over (kh,kw) with t1 = 2*t2+kh, f1 = 2*f2+kw of
+//                  dcol[(b,t2,f2), (kh*3+kw)*C + c]
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(int T1, int F1, int T2, int F2, int C, long n,
+                                                     const T* __restrict__ dcol, const T* __restrict__ y1,
+                                                     T* __restrict__ dy1) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = i % C;
+    long r = i / C;
+    const int f1 = r % F1; r /= F1;
+    const int t1 = r % T1;
+    const int b = r / T1;
+    float s = 0.f;
+    if (to_f32(y1[i]) > 0.f) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int tt = t1 - kh;
+        if (tt < 0 || (tt & 1)) continue;
+        const int t2 = tt >> 1;
+        if (t2 >= T2) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ff = f1 - kw;
+          if (ff < 0 || (ff & 1)) continue;
+          const int f2 = ff >> 1;
+          if (f2 >= F2) continue;
+          s += to_f32(dcol[(((long)b * T2 + t2) * F2 + f2) * (9L * C) + (kh * 3 + kw) * C + c]);
+        }
+      }
+    }
+    dy1[i] = from_f32<T>(s);
+  }
+}
+
+inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+
+extern "C" int emoasr_conv1_fwd(int dtype, int B, int Tn, int F, int C, const float* x, const float* w1,
+                                const float* b1, void* y1, void* stream) {
+  EMO_CHECK(Tn >= 3 && F >= 3, "conv1: input too small (T=%d F=%d)", Tn, F);
+  const int T1 = (Tn - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
+  if (B == 0) return 0;
+  EMO_DISPATCH(dtype, (conv1_fwd_kernel<T><<<B * T1, 256, 3 * F * sizeof(float), (hipStream_t)stream>>>(
+                          Tn, F, T1, F1, C, x, w1, b1, (T*)y1)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_conv1_wgrad(int dtype, int B, int Tn, int F, int C, const float* x, const void* dy1,
+                                  float* dw1, float* db1, int accumulate, void* stream) {
+  EMO_CHECK(Tn >= 3 && F >= 3, "conv1_wgrad: input too small");
+  EMO_CHECK(C <= 1024, "conv1_wgrad: C=%d > 1024", C);
+  const int T1 = (Tn - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipMemsetAsync(dw1, 0, sizeof(float) * C * 9, s);
+    hipMemsetAsync(db1, 0, sizeof(float) * C, s);
+  }
+  if (B == 0) return 0;
+  const int nchunk = cdiv(T1, C1_TROWS);
+  const int threads = cdiv(C, 64) * 64;
+  EMO_DISPATCH(dtype, (conv1_wgrad_kernel<T><<<B * nchunk, threads, 3 * F * sizeof(float), s>>>(
+                          Tn, F, T1, F1, C, x, (const T*)dy1, dw1, db1)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_conv2_col2im(int dtype, int B, int T1, int F1, int C, const void* dcol,
+                                   const void* y1, void* dy1, void* stream) {
+  EMO_CHECK(T1 >= 3 && F1 >= 3, "col2im: input too small");
+  const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  const long n = (long)B * T1 * F1 * C;
+  if (n == 0) return 0;
+  EMO_DISPATCH(dtype, (col2im_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(
+                          T1, F1, T2, F2, C, n, (const T*)dcol, (const T*)y1, (T*)dy1)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,117 @@
+"""ctypes binding of libemoasr_hip.so (the C ABI declared in include/emoasr_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or an entry
+point fails, an exception is raised.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_long, c_uint64,
+                    c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libemoasr_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+
+
+class Epilogue(Structure):
+    _fields_ = [("bias", c_void_p), ("residual", c_void_p), ("pre_out", c_void_p),
+                ("dact_pre", c_void_p), ("alpha", c_float), ("res_scale", c_float),
+                ("act", c_int), ("dact", c_int), ("ldr", c_int), ("out_f32", c_int),
+                ("drop_p", c_float), ("seed", c_uint64)]
+
+
+class AttnArgs(Structure):
+    _fields_ = [("B", c_int), ("H", c_int), ("DK", c_int), ("Tq", c_int), ("Tk", c_int),
+                ("ldq", c_long), ("ldk", c_long), ("ldv", c_long), ("ldo", c_long), ("ldp", c_long),
+                ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("pos", c_void_p),
+                ("bias_u", c_void_p), ("bias_v", c_void_p), ("klens", c_void_p),
+                ("causal", c_int), ("scale", c_float), ("drop_p", c_float), ("seed", c_uint64),
+                ("out", c_void_p), ("lse", c_void_p),
+                ("dout", c_void_p), ("delta", c_void_p),
+                ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
+                ("dpos", c_void_p), ("dbias_u", c_void_p), ("dbias_v", c_void_p)]
+
+
+P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
+
+# name -> argtypes (every function returns int status); mirrors include/emoasr_hip.h
+SIGNATURES = {
+    "emoasr_gemm_nt": [I, I, I, I, P, L, P, L, P, L, POINTER(Epilogue), P],
+    "emoasr_gemm_tn": [I, I, I, I, P, L, P, L, P, L, F, I, P],
+    "emoasr_colsum": [I, I, I, P, L, P, F, I, P],
+    "emoasr_conv1_fwd": [I, I, I, I, I, P, P, P, P, P],
+    "emoasr_conv1_wgrad": [I, I, I, I, I, P, P, P, P, I, P],
+    "emoasr_conv2_fwd": [I, I, I, I, I, P, P, P, POINTER(Epilogue), P],
+    "emoasr_conv2_wgrad": [I, I, I, I, I, P, P, P, I, P],
+    "emoasr_conv2_col2im": [I, I, I, I, I, P, P, P, P],
+    "emoasr_layernorm_fwd": [I, I, I, P, P, P, F, P, P, P, P],
+    "emoasr_layernorm_bwd": [I, I, I, P, P, P, P, P, P, P, P, P, P],
+    "emoasr_attn_fwd": [I, POINTER(AttnArgs), P],
+    "emoasr_attn_bwd": [I, POINTER(AttnArgs), P],
+    "emoasr_glu_fwd": [I, I, I, P, P, P],
+    "emoasr_glu_bwd": [I, I, I, P, P, P, P],
+    "emoasr_dwconv_fwd": [I, I, I, I, I, P, P, P, P, P],
+    "emoasr_dwconv_bwd_x": [I, I, I, I, I, P, P, P, P],
+    "emoasr_dwconv_bwd_w": [I, I, I, I, I, P, P, P, P, I, P],
+    "emoasr_bn_stats": [I, I, I, P, P, P, P, P, F, P],
+    "emoasr_bn_swish_fwd": [I, I, I, P, P, P, P, P, F, P, P],
+    "emoasr_bn_swish_bwd": [I, I, I, P, P, P, P, P, P, F, P, P, P, P, P],
+    "emoasr_strided_copy": [I, I, P, P, I, I, I, I, L, L, L, L, I, P],
+    "emoasr_scale_dropout": [I, L, P, P, F, F, U64, P],
+    "emoasr_posenc": [I, I, I, I, P, P, F, F, U64, P, P],
+    "emoasr_add": [I, L, P, P, P, P],
+    "emoasr_row_lse": [I, I, I, P, L, P, P],
+    "emoasr_ctc_forward": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, P],
+    "emoasr_ctc_grad": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, F, P, L, P],
+    "emoasr_ctc_greedy": [I, I, I, I, P, L, P, I, P, P, P, P],
+    "emoasr_sqnorm": [L, P, P, P],
+    "emoasr_adam_step": [L, P, P, P, P, F, F, F, F, F, I, P, F, F, P],
+    "emoasr_specaug_apply": [I, I, I, P, P, I, I, P, P, P],
+    "emoasr_fbank": [P, L, I, I, I, I, F, P, P, P, I, P],
+    "emoasr_cmvn": [I, I, P, P, P, P],
+}
+
+
+class EmoasrHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EmoasrHipError(
+            f"{LIB_PATH} not found: build it with `python -m emoasr_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.emoasr_last_error.restype = c_char_p
+    lib.emoasr_last_error.argtypes = []
+    lib.emoasr_version.restype = c_int
+    lib.emoasr_set_option.argtypes = [c_char_p, c_int]
+    lib.emoasr_set_option.restype = c_int
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = args
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise EmoasrHipError(f"{name} failed ({rc}): {lib.emoasr_last_error().decode()}")
+
+
+def set_option(name, value):
+    lib = load()
+    if lib.emoasr_set_option(name.encode(), int(value)) != 0:
+        raise EmoasrHipError(lib.emoasr_last_error().decode())

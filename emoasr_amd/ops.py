@@ -1,0 +1,379 @@
+"""Tensor-level wrappers over the C ABI (emoasr_amd/lib.py).
+
+torch is used only as the owner of device memory and of the current HIP stream; every
+function here enqueues hand-written HIP kernels from libemoasr_hip.so.  Nothing in this
+module has autograd: forward and backward ops are separate entry points and the model
+code (emoasr_amd/engine.py) sequences them explicitly.
+"""
+import ctypes
+from ctypes import byref, c_void_p
+
+import torch
+
+from . import lib
+from .lib import ACT_NONE, ACT_RELU, ACT_SWISH, BF16, F32, AttnArgs, Epilogue  # noqa: F401
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t):
+    return _DT[t.dtype]
+
+
+def _p(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype=None):
+    assert t.is_cuda, "emoasr_amd ops need device tensors (no CPU fallback)"
+    if dtype is not None:
+        assert t.dtype == dtype, f"expected {dtype}, got {t.dtype}"
+    return t
+
+
+def _rows(t):
+    """(rows, cols, ld) of a 2-D view whose last dim is contiguous."""
+    assert t.stride(-1) == 1
+    if t.dim() == 1:
+        return 1, t.shape[0], t.shape[0]
+    assert t.dim() == 2
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def make_epilogue(bias=None, act=ACT_NONE, alpha=1.0, residual=None, res_scale=1.0, pre_out=None,
+                  dact_pre=None, dact=ACT_NONE, drop_p=0.0, seed=0, out_f32=False):
+    ep = Epilogue()
+    ep.bias = None if bias is None else bias.data_ptr()
+    ep.residual = None if residual is None else residual.data_ptr()
+    ep.pre_out = None if pre_out is None else pre_out.data_ptr()
+    ep.dact_pre = None if dact_pre is None else dact_pre.data_ptr()
+    ep.alpha = alpha
+    ep.res_scale = res_scale
+    ep.act = act
+    ep.dact = dact
+    ep.ldr = 0 if residual is None else residual.stride(0)
+    ep.out_f32 = 1 if out_f32 else 0
+    ep.drop_p = drop_p
+    ep.seed = seed
+    return ep
+
+
+def gemm_nt(a, b, out=None, **epi):
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T)"""
+    M, K, lda = _rows(_chk(a))
+    N, Kb, ldb = _rows(_chk(b, a.dtype))
+    assert K == Kb, (a.shape, b.shape)
+    out_f32 = epi.get("out_f32", False)
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    ep = make_epilogue(**epi)
+    lib.call("emoasr_gemm_nt", dt(a), M, N, K, _p(a), lda, _p(b), ldb, _p(out), out.stride(0), byref(ep),
+             _stream())
+    return out
+
+
+def gemm_tn(a, b, out=None, alpha=1.0, accumulate=False):
+    """out[N1,N2] (+)= alpha * a[K,N1]^T @ b[K,N2]  (f32 out)"""
+    K, N1, lda = _rows(_chk(a))
+    Kb, N2, ldb = _rows(_chk(b, a.dtype))
+    assert K == Kb
+    if out is None:
+        assert not accumulate
+        out = torch.empty(N1, N2, device=a.device, dtype=torch.float32)
+    _chk(out, torch.float32)
+    lib.call("emoasr_gemm_tn", dt(a), N1, N2, K, _p(a), lda, _p(b), ldb, _p(out), out.stride(0), alpha,
+             int(accumulate), _stream())
+    return out
+
+
+def colsum(x, out=None, scale=1.0, accumulate=False):
+    M, N, ld = _rows(_chk(x))
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+    lib.call("emoasr_colsum", dt(x), M, N, _p(x), ld, _p(_chk(out, torch.float32)), scale, int(accumulate),
+             _stream())
+    return out
+
+
+# ---- front-end -----------------------------------------------------------------------
+def conv1_fwd(x, w1, b1, dtype):
+    B, T, F = x.shape
+    C = w1.shape[0]
+    T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
+    y1 = torch.empty(B, T1, F1, C, device=x.device, dtype=dtype)
+    lib.call("emoasr_conv1_fwd", _DT[dtype], B, T, F, C, _p(_chk(x, torch.float32)), _p(w1), _p(b1), _p(y1),
+             _stream())
+    return y1
+
+
+def conv1_wgrad(x, dy1, dw1, db1, accumulate=False):
+    B, T, F = x.shape
+    C = dy1.shape[-1]
+    lib.call("emoasr_conv1_wgrad", dt(dy1), B, T, F, C, _p(x), _p(dy1), _p(dw1), _p(db1), int(accumulate),
+             _stream())
+
+
+def conv2_fwd(y1, w, **epi):
+    B, T1, F1, C = y1.shape
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    y2 = torch.empty(B, T2, F2, C, device=y1.device, dtype=y1.dtype)
+    ep = make_epilogue(**epi)
+    lib.call("emoasr_conv2_fwd", dt(y1), B, T1, F1, C, _p(y1), _p(_chk(w, y1.dtype)), _p(y2), byref(ep),
+             _stream())
+    return y2
+
+
+def conv2_wgrad(dy2, y1, dw, accumulate=False):
+    B, T1, F1, C = y1.shape
+    lib.call("emoasr_conv2_wgrad", dt(y1), B, T1, F1, C, _p(dy2), _p(y1), _p(_chk(dw, torch.float32)),
+             int(accumulate), _stream())
+
+
+def conv2_col2im(dcol, y1):
+    B, T1, F1, C = y1.shape
+    dy1 = torch.empty_like(y1)
+    lib.call("emoasr_conv2_col2im", dt(y1), B, T1, F1, C, _p(dcol), _p(y1), _p(dy1), _stream())
+    return dy1
+
+
+# ---- LayerNorm -------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, want_stats=True):
+    M, N, ld = _rows(_chk(x))
+    assert ld == N
+    y = torch.empty_like(x)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
+    lib.call("emoasr_layernorm_fwd", dt(x), M, N, _p(x), _p(gamma), _p(beta), eps, _p(y), _p(mean), _p(rstd),
+             _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
+    M, N, ld = _rows(_chk(x))
+    dx = torch.empty_like(x)
+    lib.call("emoasr_layernorm_bwd", dt(x), M, N, _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+             _p(dgamma), _p(dbeta), _stream())
+    return dx
+
+
+# ---- attention -------------------------------------------------------------------------
+def _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, seed):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    a = AttnArgs()
+    a.B, a.H, a.DK, a.Tq, a.Tk = B, H, D // H, Tq, Tk
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    assert q.stride(0) == Tq * q.stride(1) and k.stride(0) == Tk * k.stride(1) and v.stride(0) == Tk * v.stride(1)
+    a.ldq, a.ldk, a.ldv = q.stride(1), k.stride(1), v.stride(1)
+    a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    if pos is not None:
+        a.pos, a.ldp = pos.data_ptr(), pos.stride(0)
+    a.bias_u = None if bias_u is None else bias_u.data_ptr()
+    a.bias_v = None if bias_v is None else bias_v.data_ptr()
+    a.klens = None if klens is None else klens.data_ptr()
+    a.causal = int(causal)
+    a.scale, a.drop_p, a.seed = scale, drop_p, seed
+    return a
+
+
+def attn_fwd(q, k, v, H, scale, pos=None, bias_u=None, bias_v=None, klens=None, causal=False, drop_p=0.0,
+             seed=0):
+    """q [B,Tq,D], k/v [B,Tk,D] (views with a row stride are fine) -> out [B,Tq,D], lse [B,H,Tq]"""
+    B, Tq, D = q.shape
+    a = _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, seed)
+    out = torch.empty(B, Tq, D, device=q.device, dtype=q.dtype)
+    lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+    a.out, a.ldo, a.lse = out.data_ptr(), D, lse.data_ptr()
+    lib.call("emoasr_attn_fwd", dt(q), byref(a), _stream())
+    return out, lse
+
+
+def attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=None, bias_u=None, bias_v=None, klens=None,
+             causal=False, drop_p=0.0, seed=0, dpos=None, dbias_u=None, dbias_v=None):
+    """dq/dk/dv are written (same strides as q/k/v); dpos/dbias_* are accumulated into."""
+    B, Tq, D = q.shape
+    a = _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, seed)
+    assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
+    assert dout.is_contiguous() and out.is_contiguous()
+    delta = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+    a.out, a.ldo, a.lse = out.data_ptr(), D, lse.data_ptr()
+    a.dout, a.delta = dout.data_ptr(), delta.data_ptr()
+    a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    a.dpos = None if dpos is None else dpos.data_ptr()
+    a.dbias_u = None if dbias_u is None else dbias_u.data_ptr()
+    a.dbias_v = None if dbias_v is None else dbias_v.data_ptr()
+    lib.call("emoasr_attn_bwd", dt(q), byref(a), _stream())
+
+
+# ---- conv module -----------------------------------------------------------------------
+def glu_fwd(x):
+    M, C2, ld = _rows(_chk(x))
+    out = torch.empty(M, C2 // 2, device=x.device, dtype=x.dtype)
+    lib.call("emoasr_glu_fwd", dt(x), M, C2 // 2, _p(x), _p(out), _stream())
+    return out
+
+
+def glu_bwd(x, dout):
+    M, C2, ld = _rows(_chk(x))
+    din = torch.empty_like(x)
+    lib.call("emoasr_glu_bwd", dt(x), M, C2 // 2, _p(x), _p(dout), _p(din), _stream())
+    return din
+
+
+def dwconv_fwd(x, w, bias):
+    B, T, C = x.shape
+    y = torch.empty_like(x)
+    lib.call("emoasr_dwconv_fwd", dt(x), B, T, C, w.shape[-1], _p(_chk(x)), _p(w), _p(bias), _p(y), _stream())
+    return y
+
+
+def dwconv_bwd_x(dy, w):
+    B, T, C = dy.shape
+    dx = torch.empty_like(dy)
+    lib.call("emoasr_dwconv_bwd_x", dt(dy), B, T, C, w.shape[-1], _p(dy), _p(w), _p(dx), _stream())
+    return dx
+
+
+def dwconv_bwd_w(dy, x, dw, dbias, accumulate=False):
+    B, T, C = dy.shape
+    lib.call("emoasr_dwconv_bwd_w", dt(dy), B, T, C, dw.shape[-1], _p(dy), _p(x), _p(dw), _p(dbias),
+             int(accumulate), _stream())
+
+
+def bn_stats(y, running_mean=None, running_var=None, momentum=0.1):
+    M, C, ld = _rows(_chk(y))
+    mean = torch.empty(C, device=y.device, dtype=torch.float32)
+    var = torch.empty(C, device=y.device, dtype=torch.float32)
+    lib.call("emoasr_bn_stats", dt(y), M, C, _p(y), _p(mean), _p(var), _p(running_mean), _p(running_var),
+             momentum, _stream())
+    return mean, var
+
+
+def bn_swish_fwd(y, mean, var, gamma, beta, eps):
+    M, C, ld = _rows(_chk(y))
+    z = torch.empty_like(y)
+    lib.call("emoasr_bn_swish_fwd", dt(y), M, C, _p(y), _p(mean), _p(var), _p(gamma), _p(beta), eps, _p(z),
+             _stream())
+    return z
+
+
+def bn_swish_bwd(dz, y, mean, var, gamma, beta, eps, dgamma, dbeta):
+    M, C, ld = _rows(_chk(y))
+    dy = torch.empty_like(y)
+    scratch = torch.empty(2 * C, device=y.device, dtype=torch.float32)
+    lib.call("emoasr_bn_swish_bwd", dt(y), M, C, _p(dz), _p(y), _p(mean), _p(var), _p(gamma), _p(beta), eps,
+             _p(dy), _p(dgamma), _p(dbeta), _p(scratch), _stream())
+    return dy
+
+
+# ---- element-wise ----------------------------------------------------------------------
+def strided_copy(src, out=None, out_dtype=None, accumulate=False):
+    """out (contiguous, src.shape) (+)= src (any strides, <= 4 dims); casts f32 <-> bf16."""
+    assert src.dim() <= 4
+    shape = [1] * (4 - src.dim()) + list(src.shape)
+    strides = [0] * (4 - src.dim()) + list(src.stride())
+    if out is None:
+        out = torch.empty(src.shape, device=src.device, dtype=out_dtype or src.dtype)
+    assert out.is_contiguous()
+    lib.call("emoasr_strided_copy", dt(src), dt(out), _p(src), _p(out), *shape, *strides, int(accumulate),
+             _stream())
+    return out
+
+
+def scale_dropout(x, scale=1.0, drop_p=0.0, seed=0):
+    y = torch.empty_like(x)
+    lib.call("emoasr_scale_dropout", dt(x), x.numel(), _p(_chk(x)), _p(y), scale, drop_p, seed, _stream())
+    return y
+
+
+def posenc(x, pe, scale, drop_p=0.0, seed=0):
+    B, T, N = x.shape
+    y = torch.empty_like(x)
+    lib.call("emoasr_posenc", dt(x), B, T, N, _p(_chk(x)), _p(pe), scale, drop_p, seed, _p(y), _stream())
+    return y
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    lib.call("emoasr_add", dt(a), a.numel(), _p(a), _p(b), _p(y), _stream())
+    return y
+
+
+# ---- CTC -------------------------------------------------------------------------------
+def row_lse(logits):
+    M, V, ld = _rows(_chk(logits))
+    lse = torch.empty(M, device=logits.device, dtype=torch.float32)
+    lib.call("emoasr_row_lse", dt(logits), M, V, _p(logits), ld, _p(lse), _stream())
+    return lse
+
+
+def ctc_forward(logits, lse, labels, elens, ylens, blank):
+    """logits [B,T,V]; labels int32 [B,Lmax]; elens/ylens int32 [B] -> (lp, alpha, beta, nll)"""
+    B, T, V = logits.shape
+    Lmax = labels.shape[1]
+    S = 2 * Lmax + 1
+    dev = logits.device
+    lp = torch.empty(B, T, S, device=dev, dtype=torch.float32)
+    alpha = torch.empty(B, T, S, device=dev, dtype=torch.float32)
+    beta = torch.empty(B, T, S, device=dev, dtype=torch.float32)
+    nll = torch.empty(B, device=dev, dtype=torch.float32)
+    lib.call("emoasr_ctc_forward", dt(logits), B, T, V, Lmax, _p(logits), logits.stride(1), _p(lse), _p(labels),
+             _p(elens), _p(ylens), blank, _p(lp), _p(alpha), _p(beta), _p(nll), _stream())
+    return lp, alpha, beta, nll
+
+
+def ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale):
+    B, T, V = logits.shape
+    grad = torch.empty_like(logits)
+    lib.call("emoasr_ctc_grad", dt(logits), B, T, V, labels.shape[1], _p(logits), logits.stride(1), _p(lse),
+             _p(labels), _p(elens), _p(ylens), blank, _p(lp), _p(alpha), _p(beta), _p(nll), gscale, _p(grad),
+             grad.stride(1), _stream())
+    return grad
+
+
+def ctc_greedy(logits, elens, blank):
+    B, T, V = logits.shape
+    dev = logits.device
+    best = torch.empty(B, T, device=dev, dtype=torch.int32)
+    hyp = torch.empty(B, T, device=dev, dtype=torch.int32)
+    hyplen = torch.empty(B, device=dev, dtype=torch.int32)
+    lib.call("emoasr_ctc_greedy", dt(logits), B, T, V, _p(logits), logits.stride(1), _p(elens), blank, _p(best),
+             _p(hyp), _p(hyplen), _stream())
+    return best, hyp, hyplen
+
+
+# ---- optimizer -------------------------------------------------------------------------
+def sqnorm(x, out):
+    lib.call("emoasr_sqnorm", x.numel(), _p(_chk(x, torch.float32)), _p(out), _stream())
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq=None, clip=0.0, grad_mult=1.0):
+    lib.call("emoasr_adam_step", p.numel(), _p(p), _p(g), _p(m), _p(v), lr, beta1, beta2, eps, weight_decay,
+             step, _p(gnorm_sq), clip, grad_mult, _stream())
+
+
+# ---- features --------------------------------------------------------------------------
+def specaug_apply(x, spans, nf, nt, xlens=None, fill=None):
+    B, T, F = x.shape
+    lib.call("emoasr_specaug_apply", B, T, F, _p(_chk(x, torch.float32)), _p(spans), nf, nt, _p(xlens), _p(fill),
+             _stream())
+    return x
+
+
+def cmvn(x, mean, std):
+    M = x.numel() // x.shape[-1]
+    lib.call("emoasr_cmvn", M, x.shape[-1], _p(x), _p(mean), _p(std), _stream())
+    return x
+
+
+def fbank(wav, frame_len, frame_shift, n_fft, n_mel, preemph, window, mel_fb):
+    n = wav.numel()
+    T = 1 + (n - frame_len) // frame_shift if n >= frame_len else 0
+    feats = torch.empty(T, n_mel, device=wav.device, dtype=torch.float32)
+    lib.call("emoasr_fbank", _p(wav), n, frame_len, frame_shift, n_fft, n_mel, preemph, _p(window), _p(mel_fb),
+             _p(feats), T, _stream())
+    return feats

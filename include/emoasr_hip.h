@@ -1,0 +1,213 @@
+/* emoasr_hip.h -- C ABI of libemoasr_hip.so, the MI355X (gfx950) device library
+ * behind the emoASR-compatible Python modules in emoasr_amd/.
+ *
+ * The reference (emonosuke/emoASR) is pure Python on PyTorch: its "FFI" for the
+ * hot path is the set of ATen / cuDNN calls made by asr/modeling/**.  Every
+ * entry point below replaces one such call site (cited per function) with a
+ * hand-written HIP kernel.  Signatures use plain device pointers, sizes and a
+ * hipStream_t passed as void*: no torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error;
+ *     emoasr_last_error() returns a message for the calling thread's last error.
+ *   - dtype: EMOASR_F32 (parity mode: exact-f32 MFMA) or EMOASR_BF16 (bf16 MFMA,
+ *     f32 accumulate).  "T*" below means a buffer of that element type.
+ *   - statistics, losses, lattices, parameter gradients and optimizer state are
+ *     always f32; lengths / labels are int32.
+ *   - all pointers are device pointers unless noted; kernels are enqueued on
+ *     `stream` and never synchronise the host.
+ *   - activations are row-major [rows, features] ("channels-last").
+ */
+#ifndef EMOASR_HIP_H
+#define EMOASR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { EMOASR_F32 = 0, EMOASR_BF16 = 1 };
+enum { EMOASR_ACT_NONE = 0, EMOASR_ACT_RELU = 1, EMOASR_ACT_SWISH = 2 };
+
+const char* emoasr_last_error(void);
+int emoasr_version(void);
+/* options: "tr_read" (1 = ds_read_b64_tr_b16 operand reads, 0 = scalar fallback) */
+int emoasr_set_option(const char* name, int value);
+
+/* GEMM epilogue, applied in this order to v = alpha*acc + bias[col]:
+ *   pre_out[row,col] = v            (if pre_out)
+ *   v = act(v)
+ *   v *= dact'(dact_pre[row,col])   (if dact_pre; derivative of activation `dact`)
+ *   v *= dropout(seed, row*N+col)   (if drop_p > 0; 0 or 1/(1-p))
+ *   v = residual[row,col] + res_scale*v   (if residual)
+ * pre_out / dact_pre share C's leading dimension; residual uses ldr. */
+typedef struct {
+  const float* bias;
+  const void* residual;
+  void* pre_out;
+  const void* dact_pre;
+  float alpha;
+  float res_scale;
+  int act;
+  int dact;
+  int ldr;
+  int out_f32; /* C is float* regardless of dtype */
+  float drop_p;
+  uint64_t seed;
+} emoasr_epilogue_t;
+
+/* C[M,N] = epilogue(A[M,K] . B[N,K]^T).  Replaces nn.Linear / Conv1d(k=1):
+ * asr/modeling/transformer.py:62-71,94,110-118; conformer.py:62,103-105,115-117;
+ * encoders/conv.py:16-19; decoders/ctc.py:34,103. */
+int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                   void* C, long ldc, const emoasr_epilogue_t* ep, void* stream);
+/* C[N1,N2] (+)= alpha * A[K,N1]^T . B[K,N2], f32 output (weight gradients; the
+ * autograd backward of the calls above). */
+int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, long lda, const void* B, long ldb,
+                   float* C, long ldc, float alpha, int accumulate, void* stream);
+/* out[N] (+)= scale * sum_rows X[M,N]   (bias gradients) */
+int emoasr_colsum(int dtype, int M, int N, const void* X, long ldx, float* out, float scale,
+                  int accumulate, void* stream);
+
+/* ---- Conv2d subsampling front-end (asr/modeling/encoders/conv.py:5-28) ------
+ * x f32 [B,T,F] -> y1 T [B,T1,F1,C] (channels-last), T1=(T-3)/2+1, F1=(F-3)/2+1
+ * w1 f32 [C,9], b1 f32 [C]; ReLU fused. */
+int emoasr_conv1_fwd(int dtype, int B, int T, int F, int C, const float* x, const float* w1,
+                     const float* b1, void* y1, void* stream);
+/* dw1[C,9], db1[C] (+)= from dy1 (gradient w.r.t. the pre-ReLU conv1 output) */
+int emoasr_conv1_wgrad(int dtype, int B, int T, int F, int C, const float* x, const void* dy1,
+                       float* dw1, float* db1, int accumulate, void* stream);
+/* y2[(b,t2,f2), n] = epilogue(sum y1[b,2t2+kh,2f2+kw,c] * w[n,(kh,kw,c)])  (implicit GEMM) */
+int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const void* y1, const void* w, void* y2,
+                     const emoasr_epilogue_t* ep, void* stream);
+int emoasr_conv2_wgrad(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* y1,
+                       float* dw, int accumulate, void* stream);
+/* dy1[b,t1,f1,c] = relu'(y1) * sum_{kh,kw} dcol[(b,t2,f2),(kh,kw,c)]  (col2im gather) */
+int emoasr_conv2_col2im(int dtype, int B, int T1, int F1, int C, const void* dcol, const void* y1,
+                        void* dy1, void* stream);
+
+/* ---- LayerNorm (nn.LayerNorm call sites: conformer.py:183-187,
+ * encoders/transformer.py:73, transformer.py:140-141,178-180) ------------------ */
+int emoasr_layernorm_fwd(int dtype, int M, int N, const void* x, const float* gamma, const float* beta,
+                         float eps, void* y, float* mean, float* rstd, void* stream);
+/* dx = dres + LN'(dy); dgamma/dbeta (+)= ; dres may be NULL */
+int emoasr_layernorm_bwd(int dtype, int M, int N, const void* dy, const void* x, const float* gamma,
+                         const float* mean, const float* rstd, const void* dres, void* dx,
+                         float* dgamma, float* dbeta, void* stream);
+
+/* ---- attention (transformer.py:48-99, conformer.py:57-95) -------------------
+ * q:[B,Tq,H*DK] k,v:[B,Tk,H*DK] with row strides ldq/ldk/ldv (elements), out [B,Tq,H*DK].
+ * pos: projected relative position table T [2*Tq-1, H*DK] (row r <-> rel = Tq-1-r) or NULL;
+ * bias_u / bias_v f32 [H*DK] or NULL.  klens int32 [B]: keys >= klens[b] are masked
+ * (NULL: none).  causal != 0 adds the lower-triangular mask (decoder self-attn).
+ * scores = ((q+u).k + (q+v).pos[i-j]) * scale; softmax; dropout(drop_p); .v
+ * lse f32 [B,H,Tq] is saved for backward. */
+typedef struct {
+  int B, H, DK, Tq, Tk;
+  long ldq, ldk, ldv, ldo, ldp;
+  const void *q, *k, *v, *pos;
+  const float *bias_u, *bias_v;
+  const int* klens;
+  int causal;
+  float scale;
+  float drop_p;
+  uint64_t seed;
+  void* out;
+  float* lse;
+  /* backward only */
+  const void* dout;
+  float* delta; /* scratch f32 [B,H,Tq] */
+  void *dq, *dk, *dv; /* T, same strides as q/k/v */
+  float *dpos;        /* f32 [2*Tq-1, H*DK], accumulated */
+  float *dbias_u, *dbias_v; /* f32 [H*DK], accumulated */
+} emoasr_attn_t;
+int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream);
+int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream);
+
+/* ---- Conformer convolution module (conformer.py:98-143) ---------------------- */
+/* out[M,C] = in[M,:C] * sigmoid(in[M,C:2C]) */
+int emoasr_glu_fwd(int dtype, int M, int C, const void* in, void* out, void* stream);
+int emoasr_glu_bwd(int dtype, int M, int C, const void* in, const void* dout, void* din, void* stream);
+/* depthwise Conv1d over time, channels-last x[B,T,C], w f32 [C,K], zero padding (K-1)/2 */
+int emoasr_dwconv_fwd(int dtype, int B, int T, int C, int K, const void* x, const float* w,
+                      const float* bias, void* y, void* stream);
+int emoasr_dwconv_bwd_x(int dtype, int B, int T, int C, int K, const void* dy, const float* w, void* dx,
+                        void* stream);
+int emoasr_dwconv_bwd_w(int dtype, int B, int T, int C, int K, const void* dy, const void* x, float* dw,
+                        float* dbias, int accumulate, void* stream);
+/* BatchNorm1d batch statistics over all M=B*T rows (padding included, as the reference):
+ * mean[C], var[C] (biased); if running_* != NULL they are updated with `momentum`
+ * (unbiased variance), exactly like nn.BatchNorm1d in training mode. */
+int emoasr_bn_stats(int dtype, int M, int C, const void* y, float* mean, float* var,
+                    float* running_mean, float* running_var, float momentum, void* stream);
+/* z = swish(gamma*(y-mean)/sqrt(var+eps)+beta) */
+int emoasr_bn_swish_fwd(int dtype, int M, int C, const void* y, const float* mean, const float* var,
+                        const float* gamma, const float* beta, float eps, void* z, void* stream);
+/* training-mode backward (batch statistics): dy from dz; dgamma/dbeta (+)=.
+ * scratch: f32 [2*C], zeroed by the call. */
+int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, const void* y, const float* mean,
+                        const float* var, const float* gamma, const float* beta, float eps, void* dy,
+                        float* dgamma, float* dbeta, float* scratch, void* stream);
+
+/* ---- element-wise / layout helpers ------------------------------------------ */
+/* out (contiguous [d0,d1,d2,d3], dtype_out) (+)= in[strides s0..s3 (elements), dtype_in] */
+int emoasr_strided_copy(int dtype_in, int dtype_out, const void* in, void* out, int d0, int d1, int d2,
+                        int d3, long s0, long s1, long s2, long s3, int accumulate, void* stream);
+/* y = x*scale*dropout(seed, i)  (n elements) */
+int emoasr_scale_dropout(int dtype, long n, const void* x, void* y, float scale, float drop_p,
+                         uint64_t seed, void* stream);
+/* y[b,t,:] = (x[b,t,:]*scale + pe[t,:]) * dropout   (absolute positional encoding,
+ * transformer.py:43-45); pe f32 [>=T, N] or NULL (conformer.py:49: scale only) */
+int emoasr_posenc(int dtype, int B, int T, int N, const void* x, const float* pe, float scale,
+                  float drop_p, uint64_t seed, void* y, void* stream);
+/* y[i] = a[i] + b[i] */
+int emoasr_add(int dtype, long n, const void* a, const void* b, void* y, void* stream);
+
+/* ---- CTC (decoders/ctc.py:36-38,103-115,176-201; torch.nn.CTCLoss semantics) -- */
+/* lse[m] = logsumexp_v logits[m,:V] */
+int emoasr_row_lse(int dtype, int M, int V, const void* logits, long ld, float* lse, void* stream);
+/* Forward-backward lattices.  S = 2*Lmax+1 states.  lp (scratch), alpha, beta: f32 [B,T,S];
+ * nll[b] = -log p(labels_b | x_b) (+inf if infeasible).  alpha and beta both include the
+ * emission at t, so occupancy(t,s) = exp(alpha+beta-lp+nll). */
+int emoasr_ctc_forward(int dtype, int B, int T, int V, int Lmax, const void* logits, long ld,
+                       const float* lse, const int* labels, const int* elens, const int* ylens, int blank,
+                       float* lp, float* alpha, float* beta, float* nll, void* stream);
+/* grad[b,t,v] = gscale * (softmax - occupancy) for t < elens[b]; 0 elsewhere and for
+ * utterances with nll = inf (zero_infinity=True). */
+int emoasr_ctc_grad(int dtype, int B, int T, int V, int Lmax, const void* logits, long ld,
+                    const float* lse, const int* labels, const int* elens, const int* ylens, int blank,
+                    const float* lp, const float* alpha, const float* beta, const float* nll,
+                    float gscale, void* grad, long ldg, void* stream);
+/* greedy: best[b,t] = argmax_v logits (first max wins); hyp[b,:hyplen[b]] = collapse
+ * repeats then drop blank, over t < elens[b] */
+int emoasr_ctc_greedy(int dtype, int B, int T, int V, const void* logits, long ld, const int* elens,
+                      int blank, int* best, int* hyp, int* hyplen, void* stream);
+
+/* ---- optimizer (asr/train_asr.py:84-92, torch.optim.Adam semantics) ---------- */
+/* out[0] += sum x^2 */
+int emoasr_sqnorm(long n, const float* x, float* out, void* stream);
+/* Adam with coupled L2 weight decay.  gnorm_sq (device, 1 float): gradients are
+ * scaled by min(1, clip/(sqrt(gnorm_sq)+1e-6)) when clip > 0 (clip_grad_norm_);
+ * the whole update is skipped on device if gnorm_sq is NaN/Inf (train_asr.py:88-89). */
+int emoasr_adam_step(long n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, const float* gnorm_sq,
+                     float clip, float grad_mult, void* stream);
+
+/* ---- on-GPU features --------------------------------------------------------- */
+/* SpecAugment (asr/spec_augment.py:39-95): zero (or fill) bands.  spans int32
+ * [B, nf+nt, 2] = (start, end) per mask, first nf are frequency masks; built on the
+ * host from the reference's sampling rule.  x f32 [B,T,F] in place. */
+int emoasr_specaug_apply(int B, int T, int F, float* x, const int* spans, int nf, int nt,
+                         const int* xlens, const float* fill, void* stream);
+/* Kaldi-compatible log-mel filterbank (corpora/utils/wav_to_feats.py:26-33 defaults):
+ * wav f32 [n_samples] (already scaled by 2^15) -> feats f32 [T, n_mel];
+ * mel_fb f32 [n_mel, n_fft/2+1] from the host. */
+int emoasr_fbank(const float* wav, long n_samples, int frame_len, int frame_shift, int n_fft, int n_mel,
+                 float preemph, const float* window, const float* mel_fb, float* feats, int T,
+                 void* stream);
+/* (x - mean[f]) / std[f] in place, f32 [M,F] */
+int emoasr_cmvn(int M, int F, float* x, const float* mean, const float* std, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,471 @@
+"""Per-kernel parity: every C-ABI entry point against a plain PyTorch fp32 expression of the
+same op (tolerances: f32 mode tight; bf16 mode relative to bf16 rounding of the operands)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype, f32=2e-5, bf16=2e-2):
+    return f32 if dtype == torch.float32 else bf16
+
+
+def _close(got, ref, tol, what=""):
+    got = got.float()
+    ref = ref.float()
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-6
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+def _rnd(dev, *shape, dtype=torch.float32, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).to(dtype)
+
+
+@pytest.fixture(autouse=True)
+def _seed():
+    torch.manual_seed(1234)
+
+
+@pytest.fixture(params=[1, 0], ids=["tr", "notr"])
+def tr_mode(request):
+    from emoasr_amd import lib
+    lib.set_option("tr_read", request.param)
+    yield request.param
+    lib.set_option("tr_read", 1)
+
+
+# ---------------------------------------------------------------- GEMM NT
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (77, 1000, 256), (130, 256, 4864),
+                                   (4100, 256, 1024), (64, 64, 32)])
+def test_gemm_nt_plain(dev, dtype, M, N, K):
+    from emoasr_amd import ops
+    a, b = _rnd(dev, M, K, dtype=dtype), _rnd(dev, N, K, dtype=dtype, scale=K ** -0.5)
+    out = ops.gemm_nt(a, b)
+    _close(out, a.float() @ b.float().t(), _tol(dtype), f"gemm_nt {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_gemm_nt_epilogue(dev, dtype):
+    from emoasr_amd import ops
+    M, N, K = 333, 512, 256
+    a, b = _rnd(dev, M, K, dtype=dtype), _rnd(dev, N, K, dtype=dtype, scale=K ** -0.5)
+    bias = _rnd(dev, N)
+    res = _rnd(dev, M, N, dtype=dtype)
+    acc = a.float() @ b.float().t()
+    # bias + swish + pre_out + residual
+    pre = torch.empty(M, N, device=dev, dtype=dtype)
+    out = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_SWISH, pre_out=pre, residual=res, res_scale=0.5, alpha=2.0)
+    pre_ref = 2.0 * acc + bias
+    _close(pre, pre_ref, _tol(dtype), "pre_out")
+    _close(out, res.float() + 0.5 * F.silu(pre_ref), _tol(dtype), "swish+res")
+    # relu, f32 output
+    out = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_RELU, out_f32=True)
+    assert out.dtype == torch.float32
+    _close(out, F.relu(acc + bias), _tol(dtype), "relu f32out")
+    # derivative epilogue: acc * swish'(u)
+    u = _rnd(dev, M, N, dtype=dtype)
+    out = ops.gemm_nt(a, b, dact_pre=u, dact=ops.ACT_SWISH)
+    uf = u.float()
+    s = torch.sigmoid(uf)
+    _close(out, acc * (s * (1 + uf * (1 - s))), _tol(dtype), "dswish")
+    out = ops.gemm_nt(a, b, dact_pre=u, dact=ops.ACT_RELU)
+    _close(out, acc * (uf > 0).float(), _tol(dtype), "drelu")
+
+
+def test_dropout_consistency(dev):
+    """GEMM epilogue dropout == scale_dropout kernel mask (same seed, same linear index)."""
+    from emoasr_amd import ops
+    M, N, K, p = 200, 256, 64, 0.25
+    a, b = _rnd(dev, M, K), _rnd(dev, N, K)
+    plain = ops.gemm_nt(a, b)
+    dropped = ops.gemm_nt(a, b, drop_p=p, seed=77)
+    mask = ops.scale_dropout(torch.ones(M, N, device=dev), 1.0, p, 77)
+    _close(dropped, plain * mask, 1e-6, "dropout mask")
+    frac = (mask == 0).float().mean().item()
+    assert abs(frac - p) < 0.02, f"drop fraction {frac}"
+    kept = mask[mask != 0]
+    assert torch.allclose(kept, torch.full_like(kept, 1 / (1 - p)))
+    mask2 = ops.scale_dropout(torch.ones(M, N, device=dev), 1.0, p, 78)
+    assert (mask2 != mask).any()
+
+
+# ---------------------------------------------------------------- GEMM TN
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("K,N1,N2", [(1000, 256, 256), (3001, 1024, 256), (777, 1000, 256), (500, 256, 2304),
+                                     (64, 64, 64)])
+def test_gemm_tn(dev, dtype, tr_mode, K, N1, N2):
+    from emoasr_amd import ops
+    a, b = _rnd(dev, K, N1, dtype=dtype), _rnd(dev, K, N2, dtype=dtype, scale=K ** -0.5)
+    ref = a.float().t() @ b.float()
+    out = ops.gemm_tn(a, b, alpha=0.5)
+    _close(out, 0.5 * ref, _tol(dtype), f"gemm_tn {K}x{N1}x{N2}")
+    ops.gemm_tn(a, b, out=out, alpha=1.0, accumulate=True)
+    _close(out, 1.5 * ref, _tol(dtype), "gemm_tn accumulate")
+
+
+def test_colsum(dev):
+    from emoasr_amd import ops
+    for dtype in DTYPES:
+        x = _rnd(dev, 1001, 768, dtype=dtype)
+        out = ops.colsum(x, scale=0.5)
+        _close(out, 0.5 * x.float().sum(0), 1e-4, "colsum")
+        ops.colsum(x, out=out, scale=1.0, accumulate=True)
+        _close(out, 1.5 * x.float().sum(0), 1e-4, "colsum acc")
+
+
+# ---------------------------------------------------------------- front-end convs
+def _conv2_weight_repack(w):  # (C, C, 3, 3) -> (C, (kh,kw,c))
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_frontend(dev, dtype, tr_mode):
+    from emoasr_amd import ops
+    B, T, Fd, C = 3, 67, 80, 128
+    x = _rnd(dev, B, T, Fd)
+    w1, b1 = _rnd(dev, C, 1, 3, 3, scale=0.3), _rnd(dev, C, scale=0.1)
+    w2, b2 = _rnd(dev, C, C, 3, 3, scale=(9 * C) ** -0.5), _rnd(dev, C, scale=0.1)
+    xr = x.clone().requires_grad_(True)
+    w1r, b1r, w2r, b2r = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    y1_ref = F.relu(F.conv2d(xr.unsqueeze(1), w1r, b1r, stride=2))
+    y1_ref.retain_grad()
+    y2_ref = F.relu(F.conv2d(y1_ref, w2r, b2r, stride=2))
+    g = torch.randn_like(y2_ref)
+    y2_ref.backward(g)
+
+    y1 = ops.conv1_fwd(x, w1.reshape(C, 9).contiguous(), b1, dtype)
+    _close(y1, y1_ref.permute(0, 2, 3, 1), _tol(dtype, 1e-5, 1e-2), "conv1")
+    w2p = _conv2_weight_repack(w2).to(dtype)
+    y2 = ops.conv2_fwd(y1, w2p, bias=b2, act=ops.ACT_RELU)
+    _close(y2, y2_ref.permute(0, 2, 3, 1), _tol(dtype), "conv2")
+    # backward: dy2 (pre-relu grad), wgrad, dgrad via dcol + col2im, conv1 wgrad
+    T2, F2 = y2.shape[1], y2.shape[2]
+    dy2 = (g.permute(0, 2, 3, 1) * (y2_ref.permute(0, 2, 3, 1) > 0)).contiguous().to(dtype)
+    dw2 = torch.empty(C, 9 * C, device=dev)
+    ops.conv2_wgrad(dy2, y1, dw2)
+    _close(dw2, _conv2_weight_repack(w2r.grad), _tol(dtype, 1e-4, 3e-2), "conv2 wgrad")
+    db2 = ops.colsum(dy2.reshape(-1, C))
+    _close(db2, b2r.grad, _tol(dtype, 1e-4, 3e-2), "conv2 bgrad")
+    w2pt = w2p.t().contiguous()  # [(kh,kw,c), n]
+    dcol = ops.gemm_nt(dy2.reshape(-1, C), w2pt)
+    dy1 = ops.conv2_col2im(dcol, y1)
+    # reference: grad wrt conv1 pre-relu output = y1_ref.grad * relu mask
+    dy1_ref = (y1_ref.grad * (y1_ref > 0)).permute(0, 2, 3, 1)
+    _close(dy1, dy1_ref, _tol(dtype, 1e-4, 3e-2), "col2im")
+    dw1 = torch.empty(C, 9, device=dev)
+    db1 = torch.empty(C, device=dev)
+    ops.conv1_wgrad(x, dy1, dw1, db1)
+    _close(dw1, w1r.grad.reshape(C, 9), _tol(dtype, 1e-4, 3e-2), "conv1 wgrad")
+    _close(db1, b1r.grad, _tol(dtype, 1e-4, 3e-2), "conv1 bgrad")
+
+
+# ---------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("N,eps", [(256, 1e-5), (256, 1e-12), (64, 1e-5), (1024, 1e-5)])
+def test_layernorm(dev, dtype, N, eps):
+    from emoasr_amd import ops
+    M = 517
+    x = _rnd(dev, M, N, dtype=dtype) * 2 + 0.5
+    g, b = _rnd(dev, N) + 1, _rnd(dev, N)
+    xr, gr, br = x.float().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (N,), gr, br, eps)
+    dy = _rnd(dev, M, N, dtype=dtype)
+    dres = _rnd(dev, M, N, dtype=dtype)
+    yr.backward(dy.float())
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, eps)
+    _close(y, yr, _tol(dtype, 1e-5, 1e-2), "ln fwd")
+    dg, db = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    dx = ops.layernorm_bwd(dy, x, g, mean, rstd, dres, dg, db)
+    _close(dx, xr.grad + dres.float(), _tol(dtype, 1e-5, 1e-2), "ln dx")
+    _close(dg, gr.grad, 1e-4, "ln dgamma")
+    _close(db, br.grad, 1e-4, "ln dbeta")
+
+
+# ---------------------------------------------------------------- attention
+def _attn_ref(q, k, v, H, scale, pos, bu, bv, klens, causal):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    dk = D // H
+    qh = q.view(B, Tq, H, dk).transpose(1, 2)
+    kh = k.view(B, Tk, H, dk).transpose(1, 2)
+    vh = v.view(B, Tk, H, dk).transpose(1, 2)
+    if bu is not None:
+        qu = qh + bu.view(1, H, 1, dk)
+    else:
+        qu = qh
+    scores = qu @ kh.transpose(-1, -2)
+    if pos is not None:
+        qv = qh + bv.view(1, H, 1, dk)
+        ph = pos.view(-1, H, dk).transpose(0, 1)  # (H, 2T-1, dk)
+        bd_full = qv @ ph.transpose(-1, -2).unsqueeze(0)  # (B,H,Tq,2T-1)
+        i = torch.arange(Tq, device=q.device).view(-1, 1)
+        j = torch.arange(Tk, device=q.device).view(1, -1)
+        idx = (Tq - 1 - (i - j)).expand(B, H, Tq, Tk)
+        scores = scores + torch.gather(bd_full, 3, idx)
+    scores = scores * scale
+    mask = torch.ones(B, 1, Tq, Tk, dtype=torch.bool, device=q.device)
+    if klens is not None:
+        mask = mask & (torch.arange(Tk, device=q.device).view(1, 1, 1, Tk) < klens.view(B, 1, 1, 1))
+    if causal:
+        mask = mask & torch.tril(torch.ones(Tq, Tk, dtype=torch.bool, device=q.device)).view(1, 1, Tq, Tk)
+    scores = scores.masked_fill(~mask, torch.finfo(torch.float32).min)
+    attn = torch.softmax(scores, -1).masked_fill(~mask, 0.0)
+    return (attn @ vh).transpose(1, 2).reshape(B, Tq, D)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", ["rel", "rel_long", "plain_mask", "causal", "cross"])
+def test_attention(dev, dtype, tr_mode, case):
+    from emoasr_amd import ops
+    H, dk = 4, 64
+    D = H * dk
+    cfg = {"rel": (3, 75, 75, True, False, [75, 40, 9]), "rel_long": (2, 299, 299, True, False, [299, 170]),
+           "plain_mask": (2, 50, 50, False, False, [50, 33]), "causal": (2, 41, 41, False, True, [41, 17]),
+           "cross": (2, 21, 83, False, False, [83, 60])}[case]
+    B, Tq, Tk, rel, causal, kl = cfg
+    klens = torch.tensor(kl, device=dev, dtype=torch.int32)
+    qkv = _rnd(dev, B, Tq, 3 * D, dtype=dtype)
+    if Tq == Tk:
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    else:
+        q = _rnd(dev, B, Tq, D, dtype=dtype)
+        kv = _rnd(dev, B, Tk, 2 * D, dtype=dtype)
+        k, v = kv[..., :D], kv[..., D:]
+    pos = _rnd(dev, 2 * Tq - 1, D, dtype=dtype) if rel else None
+    bu = _rnd(dev, D, scale=0.5) if rel else None
+    bv = _rnd(dev, D, scale=0.5) if rel else None
+    scale = 1 / math.sqrt(dk)
+    leaves = [t.float().clone().requires_grad_(True) if t is not None else None for t in (q, k, v, pos, bu, bv)]
+    ref = _attn_ref(*leaves[:3], H, scale, leaves[3], leaves[4], leaves[5], klens, causal)
+    dout = _rnd(dev, B, Tq, D, dtype=dtype)
+    ref.backward(dout.float())
+    out, lse = ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, causal=causal)
+    tol = _tol(dtype, 2e-5, 2e-2)
+    _close(out, ref, tol, f"attn fwd {case}")
+    if Tq == Tk:
+        dqkv = torch.zeros_like(qkv)
+        dq, dk_, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
+    else:
+        dq = torch.zeros_like(q)
+        dkv = torch.zeros_like(kv)
+        dk_, dv = dkv[..., :D], dkv[..., D:]
+    dpos = torch.zeros(2 * Tq - 1, D, device=dev) if rel else None
+    dbu = torch.zeros(D, device=dev) if rel else None
+    dbv = torch.zeros(D, device=dev) if rel else None
+    ops.attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk_, dv, pos=pos, bias_u=bu, bias_v=bv, klens=klens,
+                 causal=causal, dpos=dpos, dbias_u=dbu, dbias_v=dbv)
+    btol = _tol(dtype, 1e-4, 4e-2)
+    _close(dq, leaves[0].grad, btol, f"attn dq {case}")
+    _close(dk_, leaves[1].grad, btol, f"attn dk {case}")
+    _close(dv, leaves[2].grad, btol, f"attn dv {case}")
+    if rel:
+        _close(dpos, leaves[3].grad, btol, f"attn dpos {case}")
+        _close(dbu, leaves[4].grad, btol, f"attn dbias_u {case}")
+        _close(dbv, leaves[5].grad, btol, f"attn dbias_v {case}")
+
+
+def test_attention_dropout(dev):
+    """Dropout inside the fused kernel: forward/backward consistent with each other (finite
+    differences are impossible with a random mask, so check linearity in V and the drop rate)."""
+    from emoasr_amd import ops
+    B, T, H, D = 2, 64, 4, 256
+    q, k = _rnd(dev, B, T, D), _rnd(dev, B, T, D)
+    v = torch.ones(B, T, D, device=dev)
+    out0, _ = ops.attn_fwd(q, k, v, H, 0.125)
+    out1, _ = ops.attn_fwd(q, k, v, H, 0.125, drop_p=0.5, seed=5)
+    _close(out0, torch.ones_like(out0), 1e-5, "rows sum to one")
+    assert (out1 - 1).abs().mean() > 0.01 and abs(out1.mean().item() - 1) < 0.05
+    out2, _ = ops.attn_fwd(q, k, v, H, 0.125, drop_p=0.5, seed=5)
+    assert torch.equal(out1, out2)
+
+
+# ---------------------------------------------------------------- conv module
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_glu(dev, dtype):
+    from emoasr_amd import ops
+    x = _rnd(dev, 301, 512, dtype=dtype)
+    xr = x.float().requires_grad_(True)
+    yr = F.glu(xr, -1)
+    dy = _rnd(dev, 301, 256, dtype=dtype)
+    yr.backward(dy.float())
+    _close(ops.glu_fwd(x), yr, _tol(dtype, 1e-5, 1e-2), "glu")
+    _close(ops.glu_bwd(x, dy), xr.grad, _tol(dtype, 1e-5, 1e-2), "glu bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("T", [75, 32, 7])
+def test_dwconv(dev, dtype, T):
+    from emoasr_amd import ops
+    B, C, K = 3, 256, 31
+    x = _rnd(dev, B, T, C, dtype=dtype)
+    w, b = _rnd(dev, C, K, scale=0.2), _rnd(dev, C, scale=0.1)
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv1d(xr.transpose(1, 2), wr.unsqueeze(1), br, padding=15, groups=C).transpose(1, 2)
+    dy = _rnd(dev, B, T, C, dtype=dtype)
+    yr.backward(dy.float())
+    _close(ops.dwconv_fwd(x, w, b), yr, _tol(dtype, 1e-5, 1e-2), "dwconv")
+    _close(ops.dwconv_bwd_x(dy, w), xr.grad, _tol(dtype, 1e-5, 1e-2), "dwconv dx")
+    dw, db = torch.empty(C, K, device=dev), torch.empty(C, device=dev)
+    ops.dwconv_bwd_w(dy, x, dw, db)
+    _close(dw, wr.grad, 1e-4, "dwconv dw")
+    _close(db, br.grad, 1e-4, "dwconv db")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_batchnorm_swish(dev, dtype):
+    from emoasr_amd import ops
+    M, C, eps = 901, 256, 1e-5
+    y = _rnd(dev, M, C, dtype=dtype) * 1.5 + 0.3
+    g, b = _rnd(dev, C) + 1, _rnd(dev, C)
+    bn = torch.nn.BatchNorm1d(C).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(g); bn.bias.copy_(b)
+    yr = y.float().requires_grad_(True)
+    zr = F.silu(bn(yr))
+    dz = _rnd(dev, M, C, dtype=dtype)
+    zr.backward(dz.float())
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mean, var = ops.bn_stats(y, rm, rv, 0.1)
+    _close(mean, y.float().mean(0), 1e-5, "bn mean")
+    _close(var, y.float().var(0, unbiased=False), 1e-5, "bn var")
+    _close(rm, bn.running_mean, 1e-5, "running mean")
+    _close(rv, bn.running_var, 1e-5, "running var")
+    z = ops.bn_swish_fwd(y, mean, var, g, b, eps)
+    _close(z, zr, _tol(dtype, 1e-5, 1e-2), "bn swish")
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dy = ops.bn_swish_bwd(dz, y, mean, var, g, b, eps, dg, db)
+    _close(dy, yr.grad, _tol(dtype, 2e-5, 2e-2), "bn dy")
+    _close(dg, bn.weight.grad, 1e-4, "bn dgamma")
+    _close(db, bn.bias.grad, 1e-4, "bn dbeta")
+
+
+# ---------------------------------------------------------------- CTC
+def _ctc_case(dev, dtype, B=4, T=60, V=50, infeasible=False):
+    elens = torch.tensor([T, T - 7, T - 20, 11][:B], device=dev, dtype=torch.int32)
+    ylens = torch.tensor([12, 9, 0, 5][:B], device=dev, dtype=torch.int32)
+    if infeasible:
+        ylens[3] = 11  # with forced repeats below -> needs > 11 frames
+    Lmax = int(ylens.max())
+    labels = torch.randint(1, V, (B, Lmax), device=dev, dtype=torch.int32)
+    labels[0, 3] = labels[0, 2]  # repeated label
+    if infeasible:
+        labels[3, :] = 7
+    logits = _rnd(dev, B, T, V, dtype=dtype, scale=2.0)
+    return logits, labels, elens, ylens
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("infeasible", [False, True])
+def test_ctc(dev, dtype, infeasible):
+    from emoasr_amd import ops
+    logits, labels, elens, ylens = _ctc_case(dev, dtype, infeasible=infeasible)
+    B, T, V = logits.shape
+    lr = logits.float().requires_grad_(True)
+    ref = F.ctc_loss(lr.transpose(0, 1).log_softmax(2), labels.long(), elens.long(), ylens.long(), blank=0,
+                     reduction="sum", zero_infinity=True) / B
+    ref.backward()
+    nll_ref = F.ctc_loss(lr.detach().transpose(0, 1).log_softmax(2), labels.long(), elens.long(), ylens.long(),
+                         blank=0, reduction="none", zero_infinity=False)
+    lse = ops.row_lse(logits.view(B * T, V))
+    _close(lse, torch.logsumexp(logits.float(), -1).view(-1), 1e-5, "lse")
+    lp, alpha, beta, nll = ops.ctc_forward(logits, lse, labels, elens, ylens, 0)
+    fin = torch.isfinite(nll_ref)
+    assert torch.equal(torch.isfinite(nll), fin), (nll, nll_ref)
+    _close(nll[fin], nll_ref[fin], 1e-4, "nll")
+    grad = ops.ctc_grad(logits, lse, labels, elens, ylens, 0, lp, alpha, beta, nll, 1.0 / B)
+    _close(grad, lr.grad, _tol(dtype, 1e-4, 1e-2), "ctc grad")
+    loss = torch.where(fin, nll, torch.zeros_like(nll)).sum() / B
+    _close(loss, ref.detach(), 1e-4, "loss")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_ctc_greedy(dev, dtype):
+    from itertools import groupby
+    from emoasr_amd import ops
+    B, T, V = 3, 40, 33
+    logits = _rnd(dev, B, T, V, dtype=dtype)
+    logits[0, 5] = logits[0, 4]  # forced repeat
+    logits[1, :, 0] += 2.0       # lots of blanks
+    logits[2, 3, 10] = logits[2, 3, 20] = 50.0  # tie -> first index wins
+    elens = torch.tensor([40, 25, 8], device=dev, dtype=torch.int32)
+    best, hyp, hyplen = ops.ctc_greedy(logits, elens, 0)
+    ref_best = logits.float().argmax(-1)
+    for b in range(B):
+        n = int(elens[b])
+        assert torch.equal(best[b, :n].long(), ref_best[b, :n]), f"argmax row {b}"
+        idx = ref_best[b, :n].tolist()
+        want = [x for x, _ in groupby(idx) if x != 0]
+        got = hyp[b, :int(hyplen[b])].tolist()
+        assert got == want, (b, got, want)
+    assert int(best[2, 3]) == 10
+
+
+# ---------------------------------------------------------------- optimizer / misc
+def test_adam_and_norm(dev):
+    from emoasr_amd import ops
+    n = 100003
+    p0, g = _rnd(dev, n), _rnd(dev, n)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, weight_decay=1e-6)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    nsq = torch.zeros(1, device=dev)
+    for step in range(1, 4):
+        gs = g * step
+        pr.grad = gs.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 5.0)
+        opt.step()
+        nsq.zero_()
+        ops.sqnorm(gs, nsq)
+        _close(nsq, (gs.double() ** 2).sum().float().view(1), 1e-5, "sqnorm")
+        ops.adam_step(p, gs, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-6, step, gnorm_sq=nsq, clip=5.0)
+        _close(p, pr.detach(), 1e-5, f"adam step {step}")
+    # NaN gradient norm -> step skipped
+    before = p.clone()
+    nsq.fill_(float("nan"))
+    ops.adam_step(p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-6, 4, gnorm_sq=nsq, clip=5.0)
+    assert torch.equal(before, p)
+
+
+def test_strided_copy_posenc(dev):
+    from emoasr_amd import ops
+    w = _rnd(dev, 16, 24, 3, 3)
+    out = ops.strided_copy(w.permute(0, 2, 3, 1), out_dtype=torch.bfloat16)
+    assert torch.equal(out, w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16))
+    acc = torch.ones(24, 16, device=dev)
+    ops.strided_copy(_rnd(dev, 16, 24).t(), out=acc, accumulate=True)
+    x = _rnd(dev, 2, 9, 64)
+    pe = _rnd(dev, 20, 64)
+    _close(ops.posenc(x, pe, 8.0), x * 8.0 + pe[:9], 1e-6, "posenc")
+    _close(ops.posenc(x, None, 8.0), x * 8.0, 1e-6, "posenc scale only")
+    _close(ops.add(x, x), 2 * x, 1e-6, "add")
+
+
+def test_specaug_cmvn(dev):
+    from emoasr_amd import ops
+    B, T, Fd = 2, 50, 80
+    x = _rnd(dev, B, T, Fd)
+    spans = torch.tensor([[[3, 10], [70, 75], [5, 9], [0, 0]], [[0, 1], [20, 20], [40, 60], [10, 12]]],
+                         device=dev, dtype=torch.int32)
+    xlens = torch.tensor([50, 45], device=dev, dtype=torch.int32)
+    ref = x.clone()
+    for b in range(B):
+        n = int(xlens[b])
+        for m in range(2):
+            s, e = spans[b, m].tolist()
+            ref[b, :n, s:e] = 0
+        for m in range(2, 4):
+            s, e = spans[b, m].tolist()
+            ref[b, s:min(e, n)] = 0
+    got = ops.specaug_apply(x.clone(), spans, 2, 2, xlens)
+    assert torch.equal(got, ref)
+    mean, std = _rnd(dev, Fd), _rnd(dev, Fd).abs() + 0.5
+    _close(ops.cmvn(x.clone(), mean, std), (x - mean) / std, 1e-6, "cmvn")
