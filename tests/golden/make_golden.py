@@ -1,0 +1,114 @@
+"""Generate golden vectors by importing the reference (emonosuke/emoASR at /root/reference).
+
+Runs ONLY in the authoring container (the reference cannot travel).  Outputs small .npz
+fixtures next to this script; tests/test_oracle_golden.py pins oracle/ against them on CPU
+and tests/test_model_gpu.py pins the HIP engine against them on the GPU.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, REF)
+# warp_rnnt (third-party CUDA RNN-T loss) is imported at module import time by
+# asr/modeling/decoders/rnn_transducer.py:14 and is not installed here.
+sys.modules.setdefault("warp_rnnt", types.ModuleType("warp_rnnt"))
+
+from asr.modeling.asr import ASR  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+COMMON = dict(input_layer="conv2d", feat_dim=40, num_framestacks=1, enc_hidden_size=128,
+              enc_num_attention_heads=2, enc_num_layers=2, enc_intermediate_size=256,
+              dropout_enc_rate=0.0, dropout_attn_rate=0.0, dropout_dec_rate=0.0, vocab_size=40,
+              blank_id=0, eos_id=2, kd_weight=0, lsm_prob=0.1)
+CONFIGS = {
+    "l2_tiny": dict(COMMON, encoder_type="conformer", decoder_type="ctc", pos_encode_type="rel"),
+    "l1_tiny": dict(COMMON, encoder_type="transformer", decoder_type="ctc"),
+}
+
+
+def make_params(d):
+    return namedtuple("Params", d.keys())(**d)
+
+
+def make_batch(seed, feat_dim, vocab):
+    g = torch.Generator().manual_seed(seed)
+    xlens = torch.tensor([203, 167, 131, 64])
+    ylens = torch.tensor([9, 7, 5, 3])
+    B, T, L = len(xlens), int(xlens.max()), int(ylens.max())
+    xs = torch.randn(B, T, feat_dim, generator=g)
+    ys = torch.randint(3, vocab, (B, L), generator=g)
+    for b in range(B):
+        xs[b, xlens[b]:] = 0.0
+        ys[b, ylens[b]:] = 2  # padded with eos, as collate_fn does (datasets.py:160-170)
+    ys[0, 3] = ys[0, 2]  # a repeated label
+    eos = torch.full((B, 1), 2)
+    ys_in = torch.cat([eos, ys], 1)
+    ys_out = torch.cat([ys, eos], 1)
+    for b in range(B):
+        ys_out[b, ylens[b]] = 2
+        ys_out[b, ylens[b] + 1:] = 2
+    return xs, xlens, ys, ylens, ys_in, ys_out
+
+
+def run_ctc(name, cfg):
+    torch.manual_seed(0)
+    params = make_params(cfg)
+    model = ASR(params, phase="train")
+    # give BatchNorm non-trivial running statistics / affine parameters and the output
+    # layer a wider spread, so eval-mode greedy decoding is not dominated by ties
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("batch_norm.weight") or (".norm" in n and n.endswith("weight")):
+                p.add_(0.1 * torch.randn_like(p))
+            if n.endswith("batch_norm.bias") or (".norm" in n and n.endswith(".bias")):
+                p.add_(0.1 * torch.randn_like(p))
+        model.decoder.output.weight.mul_(3.0)
+    xs, xlens, ys, ylens, ys_in, ys_out = make_batch(1, cfg["feat_dim"], cfg["vocab_size"])
+    out = {}
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    for k, v in sd0.items():
+        out["sd/" + k] = v.numpy()
+    out.update(xs=xs.numpy(), xlens=xlens.numpy(), ys=ys.numpy(), ylens=ylens.numpy(),
+               ys_in=ys_in.numpy(), ys_out=ys_out.numpy())
+    # ---- train mode (dropout 0, BatchNorm batch statistics), loss + all gradients
+    model.train()
+    loss, loss_dict = model(xs, xlens, ys, ylens, ys_in, ys_out)
+    loss.backward()
+    out["train/loss"] = loss.detach().numpy()
+    for n, p in model.named_parameters():
+        out["grad/" + n] = p.grad.numpy()
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            out["sd_after/" + k] = v.clone().numpy()
+    # ---- eval mode from the ORIGINAL state: encoder outputs, logits, greedy decode
+    model.load_state_dict(sd0)
+    model.eval()
+    with torch.no_grad():
+        eouts, elens, _ = model.encoder(xs, xlens)
+        logits = model.decoder(eouts, elens)
+        loss_eval, _ = model(xs, xlens, ys, ylens, ys_in, ys_out)
+        hyps, _, _, aligns = model.decode(xs, xlens, beam_width=1)
+    out["eval/eouts"] = eouts.numpy()
+    out["eval/elens"] = elens.numpy()
+    out["eval/logits"] = logits.numpy()
+    out["eval/loss"] = loss_eval.numpy()
+    out["eval/hyp_lens"] = np.array([len(h) for h in hyps])
+    out["eval/hyps"] = np.array(sum(hyps, []), dtype=np.int64)
+    out["eval/aligns"] = np.array(sum(aligns, []), dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "loss", float(loss), "eval loss", float(loss_eval), "hyp lens", [len(h) for h in hyps],
+          "params", sum(p.numel() for p in model.parameters()))
+
+
+if __name__ == "__main__":
+    for name, cfg in CONFIGS.items():
+        run_ctc(name, cfg)
