@@ -40,6 +40,8 @@ __device__ __forceinline__ int conv_k_off(const ConvGeom& g, int k) {
   return (kh * g.F1 + kw) * g.C + c;
 }
 
+int g_tr_read = 1;
+
 struct NtArgs {
   int M, N, K;
   const void* A; long lda;
@@ -66,17 +68,21 @@ __device__ __forceinline__ void lds_store_row(T* dst, const Vec16<T>& v) {
   }
 }
 
-template <typename T, int BM, int BN, int AMODE>
+// BKM = true: B is stored [K][N] (k-major, row stride ldb) -> C = A . B   ("NN", used for dgrad)
+template <typename T, int BM, int BN, int AMODE, bool BKM, bool TR>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   using Cfg = TileCfg<T>;
   using M_ = Mma<T>;
   constexpr int VEC = Cfg::VEC, BK = Cfg::BK, KV = Cfg::KV, LD = Cfg::LD;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int A_IT = BM * KV / 256, B_IT = BN * KV / 256;
+  constexpr int LDBK = BN + (sizeof(T) == 2 ? 32 : 0);  // k-major B tile row stride
+  constexpr int BVK = BN / VEC;                          // vectors per k row (k-major B)
+  constexpr int A_IT = BM * KV / 256, B_IT = BKM ? BK * BVK / 256 : BN * KV / 256;
   static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 threads");
+  constexpr int BS_ELEMS = BKM ? BK * LDBK : BN * LD;
 
   __shared__ __attribute__((aligned(16))) T As[2][BM * LD];
-  __shared__ __attribute__((aligned(16))) T Bs[2][BN * LD];
+  __shared__ __attribute__((aligned(16))) T Bs[2][BS_ELEMS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
@@ -98,10 +104,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   }
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int v = tid + i * 256, r = v / KV, kv = v % KV;
-    b_kv[i] = kv * VEC; b_lds[i] = r * LD + kv * VEC;
-    b_ok[i] = (n0 + r) < g.N;
-    b_ptr[i] = B + (long)(b_ok[i] ? (n0 + r) : 0) * g.ldb;
+    const int v = tid + i * 256;
+    if constexpr (BKM) {
+      const int kr = v / BVK, nv = (v % BVK) * VEC;
+      b_kv[i] = kr; b_lds[i] = kr * LDBK + nv;
+      b_ok[i] = (n0 + nv) < g.N;
+      b_ptr[i] = B + (b_ok[i] ? (n0 + nv) : 0);
+    } else {
+      const int r = v / KV, kv = v % KV;
+      b_kv[i] = kv * VEC; b_lds[i] = r * LD + kv * VEC;
+      b_ok[i] = (n0 + r) < g.N;
+      b_ptr[i] = B + (long)(b_ok[i] ? (n0 + r) : 0) * g.ldb;
+    }
   }
 
   Vec16<T> a_reg[A_IT], b_reg[B_IT];
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int k = k0 + b_kv[i];
-      if (b_ok[i] && k < g.K) b_reg[i] = load16(b_ptr[i] + k);
+      if (b_ok[i] && k < g.K) b_reg[i] = load16(b_ptr[i] + (BKM ? (long)k * g.ldb : (long)k));
       else b_reg[i].zero();
     }
   };
@@ -125,7 +139,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) lds_store_row(&As[buf][a_lds[i]], a_reg[i]);
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) lds_store_row(&Bs[buf][b_lds[i]], b_reg[i]);
+    for (int i = 0; i < B_IT; ++i) {
+      if constexpr (BKM) store16(&Bs[buf][b_lds[i]], b_reg[i]);
+      else lds_store_row(&Bs[buf][b_lds[i]], b_reg[i]);
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -149,7 +166,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = M_::load_kc(As[buf], LD, wm + i * 32, kk, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[j] = M_::load_kc(Bs[buf], LD, wn + j * 32, kk, lane);
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (BKM) bfr[j] = M_::template load_km<TR>(Bs[buf], LDBK, kk, wn + j * 32, lane);
+        else bfr[j] = M_::load_kc(Bs[buf], LD, wn + j * 32, kk, lane);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -309,24 +329,28 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
     }
 }
 
-int g_tr_read = 1;
-
-template <typename T, int AMODE>
-int launch_nt(const NtArgs& a, hipStream_t s) {
+template <typename T, int AMODE, bool BKM, bool TR>
+int launch_nt_(const NtArgs& a, hipStream_t s) {
   const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
   const long t12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64);
   if (t128 >= 512) {
     dim3 grid(cdiv(a.N, 128), cdiv(a.M, 128));
-    gemm_nt_kernel<T, 128, 128, AMODE><<<grid, 256, 0, s>>>(a);
+    gemm_nt_kernel<T, 128, 128, AMODE, BKM, TR><<<grid, 256, 0, s>>>(a);
   } else if (t12864 >= 384) {
     dim3 grid(cdiv(a.N, 64), cdiv(a.M, 128));
-    gemm_nt_kernel<T, 128, 64, AMODE><<<grid, 256, 0, s>>>(a);
+    gemm_nt_kernel<T, 128, 64, AMODE, BKM, TR><<<grid, 256, 0, s>>>(a);
   } else {
     dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64));
-    gemm_nt_kernel<T, 64, 64, AMODE><<<grid, 256, 0, s>>>(a);
+    gemm_nt_kernel<T, 64, 64, AMODE, BKM, TR><<<grid, 256, 0, s>>>(a);
   }
   EMO_LAUNCH_CHECK();
   return 0;
+}
+template <typename T, int AMODE>
+int launch_nt(const NtArgs& a, hipStream_t s) { return launch_nt_<T, AMODE, false, true>(a, s); }
+template <typename T>
+int launch_nn(const NtArgs& a, hipStream_t s) {
+  return g_tr_read ? launch_nt_<T, 0, true, true>(a, s) : launch_nt_<T, 0, true, false>(a, s);
 }
 
 template <typename T, int BMODE>
@@ -371,6 +395,19 @@ extern "C" int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, lon
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   if (ep) a.ep = *ep; else { a.ep = emoasr_epilogue_t{}; a.ep.alpha = 1.f; }
   EMO_DISPATCH(dtype, return (launch_nt<T, 0>(a, (hipStream_t)stream)));
+}
+
+// C[M,N] = epilogue(A[M,K] . B[K,N])  -- B k-major; dgrad: dX = dY . W with W stored [out,in].
+extern "C" int emoasr_gemm_nn(int dtype, int M, int N, int K, const void* A, long lda, const void* B,
+                              long ldb, void* C, long ldc, const emoasr_epilogue_t* ep, void* stream) {
+  EMO_CHECK(M > 0 && N > 0 && K > 0, "gemm_nn: empty problem %d %d %d", M, N, K);
+  if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") || check_vec(K, dtype, "K") ||
+      check_vec(N, dtype, "N")) return 1;
+  NtArgs a{};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  if (ep) a.ep = *ep; else { a.ep = emoasr_epilogue_t{}; a.ep.alpha = 1.f; }
+  EMO_DISPATCH(dtype, return (launch_nn<T>(a, (hipStream_t)stream)));
+  return 0;
 }
 
 extern "C" int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, long lda, const void* B,

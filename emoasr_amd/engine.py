@@ -1,0 +1,475 @@
+"""Explicit forward/backward sequencing of the HIP kernels for the CTC models
+(Conv2d front-end -> Transformer/Conformer encoder -> CTC head).
+
+There is no autograd graph inside: forward() stashes what backward() needs, backward()
+walks the layers in reverse calling the hand-written gradient kernels and accumulates
+parameter gradients straight into a flat f32 gradient arena.  torch supplies device
+memory and the stream only.
+
+Reference behaviour being reproduced (file:line in /root/reference):
+  encoder      asr/modeling/encoders/transformer.py:84-113, encoders/conv.py:20-28
+  conformer    asr/modeling/conformer.py:47-54,77-95,121-143,191-229
+  transformer  asr/modeling/transformer.py:43-45,96-99,117-118,143-153
+  CTC          asr/modeling/decoders/ctc.py:103-115,176-201
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_SWISH
+
+_ALIGN = 64  # arena slot alignment in elements (256 B in f32, 128 B in bf16)
+
+
+def _cfg(cfg, key, default=None):
+    return getattr(cfg, key) if hasattr(cfg, key) else default
+
+
+class ParamArena:
+    """Re-homes a module's parameters into one flat f32 buffer (and their .grad into a
+    second one) so that (a) the optimizer, the gradient norm and the RCCL all-reduce work
+    on a single contiguous range, (b) q/k/v projection weights are adjacent and usable as
+    one fused [3d, d] GEMM operand, (c) the bf16 compute copy is one cast kernel."""
+
+    def __init__(self, module, compute_dtype):
+        named = list(module.named_parameters())
+        order, seen = [], set()
+        byname = dict(named)
+        for name, _ in named:
+            if name in seen:
+                continue
+            if name.endswith("linear_q.weight"):
+                base = name[: -len("linear_q.weight")]
+                group = [base + f"linear_{x}.{kind}" for kind in ("weight", "bias") for x in "qkv"]
+                if all(g in byname for g in group):
+                    for g in group:
+                        order.append(g)
+                        seen.add(g)
+                    continue
+            order.append(name)
+            seen.add(name)
+        self.names = order
+        self.params = [byname[n] for n in order]
+        dev = self.params[0].device
+        assert dev.type == "cuda", "emoasr_amd: move the model to the GPU first (no CPU path)"
+        self.offsets = {}
+        off = 0
+        for n, p in zip(order, self.params):
+            self.offsets[n] = off
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.size = off
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.compute_dtype = compute_dtype
+        self.shadow = self.flat if compute_dtype == torch.float32 else torch.zeros(off, device=dev, dtype=compute_dtype)
+        self.pviews, self.gviews = {}, {}
+        with torch.no_grad():
+            for n, p in zip(order, self.params):
+                o = self.offsets[n]
+                v = self.flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                self.pviews[n] = v
+                self.gviews[n] = self.grad[o:o + p.numel()].view(p.shape)
+                p.grad = self.gviews[n]
+        self.refresh_shadow()
+
+    def bound(self):
+        return all(p.data_ptr() == self.pviews[n].data_ptr() for n, p in zip(self.names, self.params))
+
+    def refresh_shadow(self):
+        if self.shadow is not self.flat:
+            ops.strided_copy(self.flat, out=self.shadow)
+
+    def attach_grads(self):
+        """Make sure every p.grad is its arena view (zero_grad(set_to_none=True) drops them)."""
+        missing = [n for n, p in zip(self.names, self.params) if p.grad is None or p.grad.data_ptr() != self.gviews[n].data_ptr()]
+        if not missing:
+            return
+        if len(missing) == len(self.names):
+            self.grad.zero_()
+        for n, p in zip(self.names, self.params):
+            if n in missing:
+                if len(missing) != len(self.names):
+                    self.gviews[n].zero_()
+                p.grad = self.gviews[n]
+
+    def w(self, name, shape=None):
+        """compute-dtype view of a parameter (GEMM operand)"""
+        o = self.offsets[name]
+        p = self.pviews[name]
+        v = self.shadow[o:o + p.numel()]
+        return v.view(shape if shape is not None else p.shape)
+
+    def w_span(self, first, last, shape):
+        o0 = self.offsets[first]
+        o1 = self.offsets[last] + self.pviews[last].numel()
+        n = 1
+        for s in shape:
+            n *= s
+        assert o1 - o0 == n, f"parameters {first}..{last} are not contiguous in the arena"
+        return self.shadow[o0:o1].view(shape)
+
+    def p(self, name):
+        return self.pviews[name]
+
+    def p_span(self, first, last, shape):
+        o0 = self.offsets[first]
+        o1 = self.offsets[last] + self.pviews[last].numel()
+        return self.flat[o0:o1].view(shape)
+
+    def g(self, name, shape=None):
+        v = self.gviews[name]
+        return v if shape is None else v.view(shape)
+
+    def g_span(self, first, last, shape):
+        o0 = self.offsets[first]
+        o1 = self.offsets[last] + self.pviews[last].numel()
+        return self.grad[o0:o1].view(shape)
+
+
+def sinusoid(positions, d, device):
+    positions = positions.to(torch.float32).view(-1, 1)
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    out = torch.zeros(positions.shape[0], d)
+    out[:, 0::2] = torch.sin(positions * div)
+    out[:, 1::2] = torch.cos(positions * div)
+    return out.to(device)
+
+
+class _Stash:
+    pass
+
+
+class CTCEngine:
+    """Forward / backward of encoder + CTC head on HIP kernels."""
+
+    def __init__(self, cfg, module, compute_dtype=torch.bfloat16, bn_buffers=None):
+        self.cfg = cfg
+        self.d = cfg.enc_hidden_size
+        self.h = cfg.enc_num_attention_heads
+        self.nl = cfg.enc_num_layers
+        self.conformer = cfg.encoder_type == "conformer"
+        self.rel = _cfg(cfg, "pos_encode_type", "abs") == "rel"
+        self.p_enc = float(_cfg(cfg, "dropout_enc_rate", 0.0))
+        self.p_att = float(_cfg(cfg, "dropout_attn_rate", 0.0))
+        self.dtype = compute_dtype
+        self.module = module
+        self.arena = ParamArena(module, compute_dtype)
+        self._tables = {}
+        self._bufs = {}
+        self.seed = 0x5EED
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ helpers
+    def ensure_bound(self):
+        if not self.arena.bound():
+            self.arena = ParamArena(self.module, self.dtype)
+
+    def _pos_table(self, T, device):
+        key = (self.rel, T)
+        if key not in self._tables:
+            if self.rel:
+                tab = sinusoid(torch.arange(T - 1, -T, -1), self.d, device)  # row r <-> rel = T-1-r
+            else:
+                tab = sinusoid(torch.arange(T), self.d, device)
+            self._tables[key] = tab
+        return self._tables[key]
+
+    def _seed(self, site):
+        return (self.seed * 1000003 + self.step_count * 4099 + site) & 0xFFFFFFFFFFFF
+
+    def _buffers(self, name):
+        b = self._bufs.get(name)
+        if b is None or not b.is_cuda:
+            self._bufs = dict(self.module.named_buffers())
+            b = self._bufs[name]
+        return b
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, xs, xlens_host, training, stash=None):
+        """xs f32 [B,T,F] (device), xlens_host: python list / CPU tensor.
+        -> eouts [B,T',d] (compute dtype), elens (list), stash (or None)"""
+        A, d, dt = self.arena, self.d, self.dtype
+        self.ensure_bound()
+        A.refresh_shadow()
+        stash = training if stash is None else stash
+        self._keep = stash
+        st = _Stash() if stash else None
+        p_enc = self.p_enc if training else 0.0
+        p_att = self.p_att if training else 0.0
+        B, T, Fd = xs.shape
+        dev = xs.device
+        xlens_host = [int(v) for v in xlens_host]
+        elens_host = [((v - 1) // 2 - 1) // 2 for v in xlens_host]
+        elens = torch.tensor(elens_host, dtype=torch.int32).to(dev, non_blocking=True)
+        pre = "encoder.conv."
+        C = d
+        # ---- Conv2d subsampling (channels-last) -----------------------------------
+        w1 = A.p(pre + "conv.0.weight").view(C, 9)
+        y1 = ops.conv1_fwd(xs, w1, A.p(pre + "conv.0.bias"), dt)
+        w2r = ops.strided_copy(A.p(pre + "conv.2.weight").permute(0, 2, 3, 1), out_dtype=dt).view(C, 9 * C)
+        y2 = ops.conv2_fwd(y1, w2r, bias=A.p(pre + "conv.2.bias"), act=ACT_RELU)
+        T2, F2 = y2.shape[1], y2.shape[2]
+        wl = A.p(pre + "output.weight")  # [d, C*F2] channel-major -> [d, F2*C]
+        wlr = ops.strided_copy(wl.view(d, C, F2).permute(0, 2, 1), out_dtype=dt).view(d, F2 * C)
+        M = B * T2
+        x = ops.gemm_nt(y2.view(M, F2 * C), wlr, bias=A.p(pre + "output.bias"))
+        # ---- positional encoding --------------------------------------------------
+        tab = self._pos_table(T2, dev)
+        scale = math.sqrt(d)
+        s_pe = self._seed(1)
+        if self.rel:
+            x = ops.posenc(x.view(B, T2, d), None, scale, p_enc, s_pe).view(M, d)
+            pos_t = ops.scale_dropout(ops.strided_copy(tab, out_dtype=dt), 1.0, p_enc, self._seed(2)) \
+                if p_enc > 0 else ops.strided_copy(tab, out_dtype=dt)
+        else:
+            x = ops.posenc(x.view(B, T2, d), tab, scale, p_enc, s_pe).view(M, d)
+            pos_t = None
+        if st is not None:
+            st.xs, st.y1, st.y2, st.w2r, st.wlr, st.pos_t = xs, y1, y2, w2r, wlr, pos_t
+            st.B, st.T2, st.F2, st.M, st.elens = B, T2, F2, M, elens
+            st.layers = []
+            st.s_pe = s_pe
+        for li in range(self.nl):
+            x, ls = self._layer_fwd(li, x, B, T2, elens, pos_t, p_enc, p_att, training)
+            if st is not None:
+                st.layers.append(ls)
+        eouts, mean, rstd = ops.layernorm_fwd(x, A.p("encoder.norm.weight"), A.p("encoder.norm.bias"), 1e-12, stash)
+        if st is not None:
+            st.x_final, st.fin_mean, st.fin_rstd = x, mean, rstd
+        return eouts.view(B, T2, d), elens_host, elens, st
+
+    def _ffn_fwd(self, name, x, res_scale, act, norm_name, eps, p_enc, site, training):
+        A = self.arena
+        h, mean, rstd = ops.layernorm_fwd(x, A.p(norm_name + ".weight"), A.p(norm_name + ".bias"), eps, self._keep)
+        u = torch.empty(x.shape[0], A.p(name + ".w1.weight").shape[0], device=x.device, dtype=x.dtype) if self._keep else None
+        s_in, s_out = self._seed(site), self._seed(site + 1)
+        a = ops.gemm_nt(h, A.w(name + ".w1.weight"), bias=A.p(name + ".w1.bias"), act=act, pre_out=u,
+                        drop_p=p_enc, seed=s_in)
+        y = ops.gemm_nt(a, A.w(name + ".w2.weight"), bias=A.p(name + ".w2.bias"), residual=x, res_scale=res_scale,
+                        drop_p=p_enc, seed=s_out)
+        return y, (x, mean, rstd, h, u, a, s_in, s_out)
+
+    def _attn_fwd(self, name, x, B, T, elens, pos_t, norm_name, eps, p_enc, p_att, site, training):
+        A, d, H = self.arena, self.d, self.h
+        h, mean, rstd = ops.layernorm_fwd(x, A.p(norm_name + ".weight"), A.p(norm_name + ".bias"), eps, self._keep)
+        wqkv = A.w_span(name + ".linear_q.weight", name + ".linear_v.weight", (3 * d, d))
+        bqkv = A.p_span(name + ".linear_q.bias", name + ".linear_v.bias", (3 * d,))
+        qkv = ops.gemm_nt(h, wqkv, bias=bqkv).view(B, T, 3 * d)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        s_att, s_out = self._seed(site), self._seed(site + 1)
+        scale = 1.0 / math.sqrt(d // H)
+        if pos_t is not None:
+            pp = ops.gemm_nt(pos_t, A.w(name + ".linear_pos.weight"))
+            bu, bv = A.p(name + ".pos_bias_u").view(-1), A.p(name + ".pos_bias_v").view(-1)
+        else:
+            pp = bu = bv = None
+        o, lse = ops.attn_fwd(q, k, v, H, scale, pos=pp, bias_u=bu, bias_v=bv, klens=elens, drop_p=p_att, seed=s_att)
+        y = ops.gemm_nt(o.view(B * T, d), A.w(name + ".linear_out.weight"), bias=A.p(name + ".linear_out.bias"),
+                        residual=x, res_scale=1.0, drop_p=p_enc, seed=s_out)
+        return y, (x, mean, rstd, h, qkv, pp, o, lse, s_att, s_out)
+
+    def _conv_fwd(self, name, x, B, T, norm_name, p_enc, site, training):
+        A, d = self.arena, self.d
+        h, mean, rstd = ops.layernorm_fwd(x, A.p(norm_name + ".weight"), A.p(norm_name + ".bias"), 1e-5, self._keep)
+        g = ops.gemm_nt(h, A.w(name + ".pointwise_conv1.weight", (2 * d, d)), bias=A.p(name + ".pointwise_conv1.bias"))
+        gl = ops.glu_fwd(g)
+        wd = A.p(name + ".depthwise_conv.weight")
+        c = ops.dwconv_fwd(gl.view(B, T, d), wd.view(d, wd.shape[-1]), A.p(name + ".depthwise_conv.bias")).view(B * T, d)
+        bn = name + ".batch_norm"
+        rm, rv = self._buffers(bn + ".running_mean"), self._buffers(bn + ".running_var")
+        if training:
+            bmean, bvar = ops.bn_stats(c, rm, rv, 0.1)
+            self._buffers(bn + ".num_batches_tracked").add_(1)
+        else:
+            bmean, bvar = rm, rv
+        z = ops.bn_swish_fwd(c, bmean, bvar, A.p(bn + ".weight"), A.p(bn + ".bias"), 1e-5)
+        s_out = self._seed(site)
+        y = ops.gemm_nt(z, A.w(name + ".pointwise_conv2.weight", (d, d)), bias=A.p(name + ".pointwise_conv2.bias"),
+                        residual=x, res_scale=1.0, drop_p=p_enc, seed=s_out)
+        return y, (x, mean, rstd, h, g, gl, c, bmean, bvar, z, s_out)
+
+    def _layer_fwd(self, li, x, B, T, elens, pos_t, p_enc, p_att, training):
+        name = f"encoder.transformers.{li}"
+        site = 100 + li * 20
+        A = self.arena
+        if self.conformer:
+            x, s_ffm = self._ffn_fwd(name + ".feed_forward_macaron", x, 0.5, ACT_SWISH, name + ".norm_ff_macaron", 1e-5,
+                                     p_enc, site, training)
+            if self.rel:
+                x, s_att = self._attn_fwd(name + ".self_attn", x, B, T, elens, pos_t, name + ".norm_self_attn", 1e-5,
+                                          p_enc, p_att, site + 2, training)
+                x, s_conv = self._conv_fwd(name + ".conv", x, B, T, name + ".norm_conv", p_enc, site + 4, training)
+            else:
+                x, s_conv = self._conv_fwd(name + ".conv", x, B, T, name + ".norm_conv", p_enc, site + 4, training)
+                x, s_att = self._attn_fwd(name + ".self_attn", x, B, T, elens, None, name + ".norm_self_attn", 1e-5,
+                                          p_enc, p_att, site + 2, training)
+            x, s_ff = self._ffn_fwd(name + ".feed_forward", x, 0.5, ACT_SWISH, name + ".norm_ff", 1e-5, p_enc, site + 6,
+                                    training)
+            y, mean, rstd = ops.layernorm_fwd(x, A.p(name + ".norm_final.weight"), A.p(name + ".norm_final.bias"), 1e-5,
+                                              self._keep)
+            return y, (s_ffm, s_att, s_conv, s_ff, (x, mean, rstd))
+        x, s_att = self._attn_fwd(name + ".self_attn", x, B, T, elens, None, name + ".norm1", 1e-12, p_enc, p_att,
+                                  site + 2, training)
+        x, s_ff = self._ffn_fwd(name + ".feed_forward", x, 1.0, ACT_RELU, name + ".norm2", 1e-12, p_enc, site + 6, training)
+        return x, (None, s_att, None, s_ff, None)
+
+    # ------------------------------------------------------------------ CTC head
+    def head_logits(self, eouts):
+        B, T, d = eouts.shape
+        A = self.arena
+        logits = ops.gemm_nt(eouts.reshape(B * T, d), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
+        return logits.view(B, T, -1)
+
+    def ctc_loss(self, logits, elens, ys_host, ylens_host, blank, want_grad, gscale_over_b=None):
+        """-> (loss 0-dim f32 tensor = sum_b nll_b / B with infeasible utterances zeroed, ctx)"""
+        B, T, V = logits.shape
+        dev = logits.device
+        ylens_host = [int(v) for v in ylens_host]
+        Lmax = max(max(ylens_host), 1)
+        labels = torch.as_tensor(ys_host)[:, :Lmax].to(torch.int32)
+        if labels.shape[1] < Lmax:
+            labels = torch.nn.functional.pad(labels, (0, Lmax - labels.shape[1]))
+        labels = labels.contiguous().to(dev, non_blocking=True)
+        ylens = torch.tensor(ylens_host, dtype=torch.int32).to(dev, non_blocking=True)
+        lse = ops.row_lse(logits.view(B * T, V))
+        lp, alpha, beta, nll = ops.ctc_forward(logits, lse, labels, elens, ylens, blank)
+        loss = torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll)).sum() / B
+        ctx = (logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll) if want_grad else None
+        return loss, ctx
+
+    def ctc_grad(self, ctx, gscale):
+        logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll = ctx
+        return ops.ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale / logits.shape[0])
+
+    def greedy(self, logits, elens, blank):
+        best, hyp, hyplen = ops.ctc_greedy(logits, elens, blank)
+        return best, hyp, hyplen
+
+    # ------------------------------------------------------------------ backward
+    def _lin_bwd(self, dy, x_in, wname, bname, alpha=1.0, **epi):
+        """gradients of y = x_in @ W^T + b given dy (already including any dropout mask);
+        returns dx = alpha * dy @ W with the optional epilogue."""
+        A = self.arena
+        ops.colsum(dy, out=A.g(bname), scale=alpha, accumulate=True)
+        w = A.w(wname)
+        w2 = w.view(w.shape[0], -1)
+        ops.gemm_tn(dy, x_in, out=A.g(wname, tuple(w2.shape)), alpha=alpha, accumulate=True)
+        return ops.gemm_nn(dy, w2, alpha=alpha, **epi)
+
+    def _branch_grad(self, dx, scale, p, seed):
+        """gradient entering a residual branch x + scale*dropout(f): returns (dy, alpha)."""
+        if p > 0:
+            return ops.scale_dropout(dx, scale, p, seed), 1.0
+        return dx, scale
+
+    def _ffn_bwd(self, name, norm_name, st, dx, res_scale, act):
+        A = self.arena
+        x, mean, rstd, h, u, a, s_in, s_out = st
+        p = self.p_enc
+        dy, alpha = self._branch_grad(dx, res_scale, p, s_out)
+        du = self._lin_bwd(dy, a, name + ".w2.weight", name + ".w2.bias", alpha, dact_pre=u, dact=act, drop_p=p, seed=s_in)
+        dh = self._lin_bwd(du, h, name + ".w1.weight", name + ".w1.bias")
+        return ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
+                                 A.g(norm_name + ".bias"))
+
+    def _attn_bwd(self, name, norm_name, st, dx, B, T, elens, pos_t):
+        A, d, H = self.arena, self.d, self.h
+        x, mean, rstd, h, qkv, pp, o, lse, s_att, s_out = st
+        dy, alpha = self._branch_grad(dx, 1.0, self.p_enc, s_out)
+        do = self._lin_bwd(dy, o.view(B * T, d), name + ".linear_out.weight", name + ".linear_out.bias", alpha)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        dq, dk, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
+        scale = 1.0 / math.sqrt(d // H)
+        if pp is not None:
+            dpos = torch.zeros(pp.shape, device=pp.device, dtype=torch.float32)
+            bu, bv = A.p(name + ".pos_bias_u").view(-1), A.p(name + ".pos_bias_v").view(-1)
+            gbu, gbv = A.g(name + ".pos_bias_u").view(-1), A.g(name + ".pos_bias_v").view(-1)
+        else:
+            dpos = bu = bv = gbu = gbv = None
+        ops.attn_bwd(do.view(B, T, d), o, lse, q, k, v, H, scale, dq, dk, dv, pos=pp, bias_u=bu, bias_v=bv, klens=elens,
+                     drop_p=self.p_att, seed=s_att, dpos=dpos, dbias_u=gbu, dbias_v=gbv)
+        if pp is not None:
+            dpos_t = dpos if self.dtype == torch.float32 else ops.strided_copy(dpos, out_dtype=self.dtype)
+            ops.gemm_tn(dpos_t, pos_t, out=A.g(name + ".linear_pos.weight"), accumulate=True)
+        dqkv2 = dqkv.view(B * T, 3 * d)
+        ops.colsum(dqkv2, out=A.g_span(name + ".linear_q.bias", name + ".linear_v.bias", (3 * d,)), accumulate=True)
+        ops.gemm_tn(dqkv2, h, out=A.g_span(name + ".linear_q.weight", name + ".linear_v.weight", (3 * d, d)),
+                    accumulate=True)
+        wqkv = A.w_span(name + ".linear_q.weight", name + ".linear_v.weight", (3 * d, d))
+        dh = ops.gemm_nn(dqkv2, wqkv)
+        return ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
+                                 A.g(norm_name + ".bias"))
+
+    def _conv_bwd(self, name, norm_name, st, dx, B, T):
+        A, d = self.arena, self.d
+        x, mean, rstd, h, g, gl, c, bmean, bvar, z, s_out = st
+        dy, alpha = self._branch_grad(dx, 1.0, self.p_enc, s_out)
+        dz = self._lin_bwd(dy, z, name + ".pointwise_conv2.weight", name + ".pointwise_conv2.bias", alpha)
+        bn = name + ".batch_norm"
+        dc = ops.bn_swish_bwd(dz, c, bmean, bvar, A.p(bn + ".weight"), A.p(bn + ".bias"), 1e-5, A.g(bn + ".weight"),
+                              A.g(bn + ".bias"))
+        wd = A.p(name + ".depthwise_conv.weight")
+        K = wd.shape[-1]
+        dgl = ops.dwconv_bwd_x(dc.view(B, T, d), wd.view(d, K))
+        ops.dwconv_bwd_w(dc.view(B, T, d), gl.view(B, T, d), A.g(name + ".depthwise_conv.weight").view(d, K),
+                         A.g(name + ".depthwise_conv.bias"), accumulate=True)
+        dg = ops.glu_bwd(g, dgl.view(B * T, d))
+        dh = self._lin_bwd(dg, h, name + ".pointwise_conv1.weight", name + ".pointwise_conv1.bias")
+        return ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
+                                 A.g(norm_name + ".bias"))
+
+    def backward(self, st, deouts):
+        """deouts: gradient w.r.t. encoder output [B,T',d] (compute dtype).  Accumulates into the
+        gradient arena (p.grad views)."""
+        A, d = self.arena, self.d
+        A.attach_grads()
+        B, T, M = st.B, st.T2, st.M
+        dx = ops.layernorm_bwd(deouts.reshape(M, d), st.x_final, A.p("encoder.norm.weight"), st.fin_mean, st.fin_rstd,
+                               None, A.g("encoder.norm.weight"), A.g("encoder.norm.bias"))
+        for li in reversed(range(self.nl)):
+            name = f"encoder.transformers.{li}"
+            s_ffm, s_att, s_conv, s_ff, s_fin = st.layers[li]
+            if self.conformer:
+                x, mean, rstd = s_fin
+                dx = ops.layernorm_bwd(dx, x, A.p(name + ".norm_final.weight"), mean, rstd, None,
+                                       A.g(name + ".norm_final.weight"), A.g(name + ".norm_final.bias"))
+                dx = self._ffn_bwd(name + ".feed_forward", name + ".norm_ff", s_ff, dx, 0.5, ACT_SWISH)
+                if self.rel:
+                    dx = self._conv_bwd(name + ".conv", name + ".norm_conv", s_conv, dx, B, T)
+                    dx = self._attn_bwd(name + ".self_attn", name + ".norm_self_attn", s_att, dx, B, T, st.elens, st.pos_t)
+                else:
+                    dx = self._attn_bwd(name + ".self_attn", name + ".norm_self_attn", s_att, dx, B, T, st.elens, None)
+                    dx = self._conv_bwd(name + ".conv", name + ".norm_conv", s_conv, dx, B, T)
+                dx = self._ffn_bwd(name + ".feed_forward_macaron", name + ".norm_ff_macaron", s_ffm, dx, 0.5, ACT_SWISH)
+            else:
+                dx = self._ffn_bwd(name + ".feed_forward", name + ".norm2", s_ff, dx, 1.0, ACT_RELU)
+                dx = self._attn_bwd(name + ".self_attn", name + ".norm1", s_att, dx, B, T, st.elens, None)
+        # ---- positional scaling, Linear, Conv2d x2 -----------------------------------
+        pre = "encoder.conv."
+        C, F2 = d, st.F2
+        dlin = ops.scale_dropout(dx, math.sqrt(d), self.p_enc, st.s_pe)
+        ops.colsum(dlin, out=A.g(pre + "output.bias"), accumulate=True)
+        y2f = st.y2.view(M, F2 * C)
+        dwl = ops.gemm_tn(dlin, y2f)  # [d, F2*C]  (f, c) order
+        gwl = A.g(pre + "output.weight").view(d, C, F2)
+        ops.strided_copy(dwl.view(d, F2, C).permute(0, 2, 1), out=gwl, accumulate=True)
+        dy2 = ops.gemm_nn(dlin, st.wlr, dact_pre=y2f, dact=ACT_RELU).view(M * F2, C)
+        ops.colsum(dy2, out=A.g(pre + "conv.2.bias"), accumulate=True)
+        dw2 = torch.empty(C, 9 * C, device=dx.device, dtype=torch.float32)
+        ops.conv2_wgrad(dy2, st.y1, dw2)
+        ops.strided_copy(dw2.view(C, 3, 3, C).permute(0, 3, 1, 2), out=A.g(pre + "conv.2.weight"), accumulate=True)
+        dcol = ops.gemm_nn(dy2, st.w2r)
+        dy1 = ops.conv2_col2im(dcol, st.y1)
+        ops.conv1_wgrad(st.xs, dy1, A.g(pre + "conv.0.weight").view(C, 9), A.g(pre + "conv.0.bias"), accumulate=True)
+
+    def head_backward(self, eouts, dlogits):
+        """-> deouts; accumulates the vocabulary head's gradients."""
+        B, T, d = eouts.shape
+        V = dlogits.shape[-1]
+        self.arena.attach_grads()
+        return self._lin_bwd(dlogits.view(B * T, V), eouts.reshape(B * T, d), "decoder.output.weight",
+                             "decoder.output.bias").view(B, T, d)

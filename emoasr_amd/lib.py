@@ -39,6 +39,7 @@ P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
 # name -> argtypes (every function returns int status); mirrors include/emoasr_hip.h
 SIGNATURES = {
     "emoasr_gemm_nt": [I, I, I, I, P, L, P, L, P, L, POINTER(Epilogue), P],
+    "emoasr_gemm_nn": [I, I, I, I, P, L, P, L, P, L, POINTER(Epilogue), P],
     "emoasr_gemm_tn": [I, I, I, I, P, L, P, L, P, L, F, I, P],
     "emoasr_colsum": [I, I, I, P, L, P, F, I, P],
     "emoasr_conv1_fwd": [I, I, I, I, I, P, P, P, P, P],

@@ -1,0 +1,57 @@
+"""ASR facade -- drop-in for asr/modeling/asr.py:21-95 with the compute on MI355X HIP kernels.
+
+    model = ASR(params, phase="train").cuda()
+    loss, loss_dict = model(xs, xlens, ys, ylens, ys_in, ys_out)       # loss.backward() works
+    hyps, scores, logits, aligns = model.decode(xs, xlens, beam_width=1)
+
+`compute_dtype`: torch.bfloat16 (throughput mode; f32 accumulation, statistics and lattices)
+or torch.float32 (parity mode: exact-f32 MFMA).
+"""
+import logging
+
+import torch
+import torch.nn as nn
+
+from .decoders.ctc import CTCDecoder
+from .encoders.transformer import TransformerEncoder
+
+
+class ASR(nn.Module):
+    def __init__(self, params, phase="train", compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.encoder_type = params.encoder_type
+        self.decoder_type = params.decoder_type
+        self.params = params
+        self.compute_dtype = compute_dtype
+        if self.encoder_type not in ("transformer", "conformer"):
+            raise NotImplementedError(f"emoasr_amd: encoder_type={self.encoder_type!r} is outside the HIP hot path")
+        self.encoder = TransformerEncoder(params, is_conformer=(self.encoder_type == "conformer"))
+        if self.decoder_type == "ctc":
+            self.decoder = CTCDecoder(params)
+        else:
+            raise NotImplementedError(f"emoasr_amd: decoder_type={self.decoder_type!r} is not built yet")
+        self.encoder._owner = [self]  # list: keeps the back-reference out of nn.Module registration
+        self.decoder._owner = [self]
+        self._engine = None
+        n = sum(p.numel() for p in self.parameters())
+        logging.info(f"ASR model #parameters: {n}")
+
+    def engine(self):
+        from ..engine import CTCEngine
+        if self._engine is None or self._engine.dtype != self.compute_dtype:
+            self._engine = CTCEngine(self.params, self, self.compute_dtype)
+        return self._engine
+
+    def forward(self, xs, xlens, ys, ylens, ys_in, ys_out, soft_labels=None, ps=None, plens=None):
+        xs = xs[:, : int(max(xlens))]
+        ys = ys[:, : int(max(ylens))]
+        eouts, elens, eouts_inter = self.encoder(xs, xlens)
+        loss, loss_dict, _ = self.decoder(eouts, elens, eouts_inter, ys, ylens, ys_in, ys_out, soft_labels, ps, plens)
+        return loss, loss_dict
+
+    def decode(self, xs, xlens, beam_width=1, len_weight=0, lm=None, lm_weight=0, decode_ctc_weight=0,
+               decode_phone=False):
+        with torch.no_grad():
+            eouts, elens, eouts_inter = self.encoder(xs, xlens)
+            return self.decoder.decode(eouts, elens, eouts_inter, beam_width, len_weight, lm, lm_weight,
+                                       decode_ctc_weight, decode_phone)

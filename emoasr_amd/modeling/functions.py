@@ -1,0 +1,100 @@
+"""autograd glue: two Functions connect the engine's explicit forward/backward to
+`loss.backward()`, one for the encoder stack and one for the CTC head, so the
+encoder/decoder module boundary of the reference survives.
+
+Parameter gradients are accumulated by the engine directly into the flat gradient arena
+(the parameters' .grad tensors are views of it); the Functions therefore return None for
+the parameter inputs.
+"""
+import torch
+
+
+def _engine_of(mod):
+    if mod._owner is None:
+        raise RuntimeError("emoasr_amd: encoder/decoder modules run through their owning ASR model")
+    return mod._owner[0].engine()
+
+
+def _host_list(lens):
+    if torch.is_tensor(lens):
+        return lens.tolist()  # device tensors sync here, like max(xlens) in asr.py:57
+    return [int(v) for v in lens]
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, training, xs, xlens_host, *params):
+        eouts, elens_host, elens_dev, st = eng.forward(xs, xlens_host, training, stash=True)
+        ctx.eng, ctx.st = eng, st
+        ctx.mark_non_differentiable(elens_dev)
+        return eouts, elens_dev
+
+    @staticmethod
+    def backward(ctx, deouts, _):
+        ctx.eng.backward(ctx.st, deouts.contiguous())
+        ctx.st = None
+        return (None,) * (4 + len(ctx.eng.arena.params))
+
+
+def encoder_apply(enc, xs, xlens):
+    eng = _engine_of(enc)
+    xs = xs.to(torch.float32).contiguous()
+    host = _host_list(xlens)
+    if torch.is_grad_enabled():
+        eng.step_count += 1
+        eouts, elens_dev = _EncoderFn.apply(eng, enc.training, xs, host, *eng.arena.params)
+    else:
+        eouts, _, elens_dev, _ = eng.forward(xs, host, enc.training, stash=False)
+    elens = torch.tensor([((v - 1) // 2 - 1) // 2 for v in host], dtype=torch.int64)
+    if torch.is_tensor(xlens):
+        elens = elens.to(xlens.device)
+    eouts._emo_elens_dev = elens_dev
+    return eouts, elens
+
+
+class _CTCLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, eouts, elens_dev, ys_host, ylens_host, blank, *params):
+        logits = eng.head_logits(eouts)
+        need = eouts.requires_grad or any(p.requires_grad for p in params)
+        loss, cctx = eng.ctc_loss(logits, elens_dev, ys_host, ylens_host, blank, need)
+        ctx.eng, ctx.cctx, ctx.eouts = eng, cctx, eouts
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, gloss, _):
+        eng = ctx.eng
+        dlogits = eng.ctc_grad(ctx.cctx, float(gloss))
+        deouts = eng.head_backward(ctx.eouts, dlogits)
+        ctx.cctx = None
+        return (None, deouts, None, None, None, None) + (None,) * len(eng.arena.params)
+
+
+def _elens_dev(eouts, elens):
+    dev = getattr(eouts, "_emo_elens_dev", None)
+    if dev is None:
+        dev = torch.as_tensor(elens).to(torch.int32).to(eouts.device)
+    return dev
+
+
+def ctc_head_apply(dec, eouts):
+    return _engine_of(dec).head_logits(eouts)
+
+
+def ctc_loss_apply(dec, eouts, elens, ys, ylens):
+    eng = _engine_of(dec)
+    ys_host = ys.cpu() if torch.is_tensor(ys) else torch.as_tensor(ys)
+    return _CTCLossFn.apply(eng, eouts, _elens_dev(eouts, elens), ys_host, _host_list(ylens), dec.blank_id,
+                            *eng.arena.params)
+
+
+def ctc_greedy_apply(dec, eouts, elens):
+    eng = _engine_of(dec)
+    logits = eng.head_logits(eouts)
+    best, hyp, hyplen = eng.greedy(logits, _elens_dev(eouts, elens), dec.blank_id)
+    best_h, hyp_h, n_h = best.cpu(), hyp.cpu(), hyplen.cpu().tolist()  # one D2H per batch
+    el = _host_list(elens)
+    hyps = [hyp_h[b, : n_h[b]].tolist() for b in range(len(n_h))]
+    aligns = [best_h[b, : el[b]].tolist() for b in range(len(n_h))]
+    return hyps, [None] * len(hyps), logits, aligns

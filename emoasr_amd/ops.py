@@ -76,6 +76,20 @@ def gemm_nt(a, b, out=None, **epi):
     return out
 
 
+def gemm_nn(a, b, out=None, **epi):
+    """out[M,N] = epilogue(a[M,K] @ b[K,N])   (b row-major [K,N]: dgrad with b = weight [out,in])"""
+    M, K, lda = _rows(_chk(a))
+    Kb, N, ldb = _rows(_chk(b, a.dtype))
+    assert K == Kb, (a.shape, b.shape)
+    out_f32 = epi.get("out_f32", False)
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    ep = make_epilogue(**epi)
+    lib.call("emoasr_gemm_nn", dt(a), M, N, K, _p(a), lda, _p(b), ldb, _p(out), out.stride(0), byref(ep),
+             _stream())
+    return out
+
+
 def gemm_tn(a, b, out=None, alpha=1.0, accumulate=False):
     """out[N1,N2] (+)= alpha * a[K,N1]^T @ b[K,N2]  (f32 out)"""
     K, N1, lda = _rows(_chk(a))

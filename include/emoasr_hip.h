@@ -60,6 +60,10 @@ typedef struct {
  * encoders/conv.py:16-19; decoders/ctc.py:34,103. */
 int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                    void* C, long ldc, const emoasr_epilogue_t* ep, void* stream);
+/* C[M,N] = epilogue(A[M,K] . B[K,N]) with B stored k-major (row stride ldb): the data
+ * gradient dX = dY . W of the calls above, straight from the [out,in] weight. */
+int emoasr_gemm_nn(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                   void* C, long ldc, const emoasr_epilogue_t* ep, void* stream);
 /* C[N1,N2] (+)= alpha * A[K,N1]^T . B[K,N2], f32 output (weight gradients; the
  * autograd backward of the calls above). */
 int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, long lda, const void* B, long ldb,
