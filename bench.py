@@ -1,0 +1,294 @@
+#!/usr/bin/env python
+"""Headline benchmark: training frames/s (and greedy-decode RTF) of the 23M Conformer-CTC (`L2`)
+on synthetic LibriSpeech-shaped batches, 80-dim features resident in HBM, SpecAugment on GPU,
+bf16 MFMA compute, fused Adam, one RCCL all-reduce of the flat gradient arena per step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+`roofline` (dominant kernel family: algorithmic FLOPs / HIP-event time over the timed region)
+and `cpu_baseline` (the CPU oracle, oracle/model.py, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+L2 = dict(input_layer="conv2d", feat_dim=80, num_framestacks=1, encoder_type="conformer", decoder_type="ctc",
+          pos_encode_type="rel", enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=12,
+          enc_intermediate_size=1024, dropout_enc_rate=0.1, dropout_attn_rate=0.1, vocab_size=10000, blank_id=0,
+          eos_id=2, kd_weight=0)
+OPT = dict(lr=5.0, warmup=25000, weight_decay=1e-6, clip_grad_norm=5.0)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def fwd_flops_per_utt(T, F=1024, V=10000, d=256, layers=12):
+    """closed form of SURVEY.md section 8d (exactly torch.utils.flop_counter on the reference)"""
+    T1 = (T - 1) // 2
+    Tp = (T1 - 1) // 2
+    conv1 = 2 * 9 * d * T1 * 39
+    conv2 = 2 * 9 * d * d * Tp * 19
+    lin = 2 * (d * 19) * d * Tp
+    layer = (2 * (4 * d * F) * Tp + 8 * d * d * Tp + 2 * d * d * (2 * Tp - 1) + 2 * d * Tp * Tp +
+             2 * d * Tp * (2 * Tp - 1) + 2 * d * Tp * Tp + 4 * d * d * Tp + 2 * 31 * d * Tp + 2 * d * d * Tp)
+    head = 2 * d * V * Tp
+    return conv1 + conv2 + lin + layers * layer + head
+
+
+class CallTimer:
+    """HIP-event timing of selected C-ABI entry points on the stream they are launched on."""
+
+    def __init__(self, lib_mod, names=None):
+        self.lib, self.names, self.rec = lib_mod, names, {}
+        self._orig = lib_mod.call
+
+    def __enter__(self):
+        def call(name, *args):
+            if self.names is not None and name not in self.names:
+                return self._orig(name, *args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._orig(name, *args)
+            e1.record()
+            flops = None
+            if name in ("emoasr_gemm_nt", "emoasr_gemm_nn", "emoasr_gemm_tn"):
+                flops = 2.0 * args[1] * args[2] * args[3]
+            elif name in ("emoasr_conv2_fwd", "emoasr_conv2_wgrad"):
+                B, T1, F1, C = args[1], args[2], args[3], args[4]
+                flops = 2.0 * B * ((T1 - 3) // 2 + 1) * ((F1 - 3) // 2 + 1) * C * 9 * C
+            self.rec.setdefault(name, []).append((e0, e1, flops))
+        self.lib.call = call
+        import emoasr_amd.ops as ops_mod
+        ops_mod.lib.call = call
+        return self
+
+    def __exit__(self, *a):
+        self.lib.call = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.rec.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+            fl = sum(f for _, _, f in evs if f is not None)
+            out[name] = dict(calls=len(evs), ms=ms, flops=fl)
+        return out
+
+
+def make_batches(rank, world, need, dev, seed=0):
+    from emoasr_amd.data import libri_shaped_lengths, pack_batches
+    xlens, ylens = libri_shaped_lengths(2000, seed)
+    batches = pack_batches(xlens, ylens, 30000, 3000, 50, 1)
+    order = list(range(len(batches)))
+    random.Random(seed).shuffle(order)
+    mine = [batches[order[(i * world + rank) % len(order)]] for i in range(need)]
+    g = torch.Generator().manual_seed(seed * 1000 + rank)
+    out = []
+    for idx in mine:
+        xl, yl = xlens[idx], ylens[idx]
+        B, T, L = len(idx), int(xl.max()), int(yl.max())
+        xs = torch.randn(B, T, 80, generator=g)
+        ys = torch.randint(3, L2["vocab_size"], (B, L), generator=g)
+        for b in range(B):
+            xs[b, xl[b]:] = 0
+            ys[b, yl[b]:] = L2["eos_id"]
+        out.append(SimpleNamespace(xs=xs.to(dev), xlens=[int(v) for v in xl], ys=ys, ylens=[int(v) for v in yl]))
+    return out
+
+
+def cpu_baseline(model, max_seconds=25.0):
+    """CPU oracle (fp32, torch eager on the host cores): fwd + bwd of one 4-utterance L2 batch."""
+    from oracle import model as om
+    cfg = SimpleNamespace(**dict(L2, dropout_enc_rate=0.0, dropout_attn_rate=0.0))
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k]
+    g = torch.Generator().manual_seed(0)
+    xlens = torch.tensor([1200, 1037, 911, 640])
+    ylens = torch.tensor([40, 33, 29, 20])
+    xs = torch.randn(4, 1200, 80, generator=g)
+    ys = torch.randint(3, 10000, (4, 40), generator=g)
+    for b in range(4):
+        xs[b, xlens[b]:] = 0
+    steps, t_total = 0, 0.0
+    for i in range(6):
+        t0 = time.perf_counter()
+        loss, _, _ = om.asr_ctc_forward(sd, cfg, xs, xlens, ys, ylens, training=True)
+        loss.backward()
+        for p in params:
+            p.grad = None
+        dt = time.perf_counter() - t0
+        if i == 0:
+            continue  # warm-up
+        steps += 1
+        t_total += dt
+        if t_total > max_seconds:
+            break
+    frames = int(xlens.sum()) * steps
+    return dict(value=frames / t_total, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} fwd+bwd steps of one L2 batch (4 utts, xlens 1200/1037/911/640, fp32, dropout 0, "
+                       f"no optimizer step) in {t_total:.1f}s")
+
+
+def decode_rtf(model, dev, n_utts=20, repeats=3):
+    """greedy CTC decode, batch 1 (reference protocol, asr/test_asr.py:226-263): wall / audio seconds"""
+    from emoasr_amd.data import libri_shaped_lengths
+    xlens, _ = libri_shaped_lengths(2000, 0)
+    rs = np.random.RandomState(1)
+    pick = rs.choice(len(xlens), n_utts, replace=False)
+    utts = [torch.randn(1, int(xlens[i]), 80).to(dev) for i in pick]
+    lens = [[int(xlens[i])] for i in pick]
+    model.eval()
+    for x, l in zip(utts[:3], lens[:3]):
+        model.decode(x, l)
+    torch.cuda.synchronize()
+    audio = sum(l[0] for l in lens) * 0.010
+    best = 1e9
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for x, l in zip(utts, lens):
+            model.decode(x, l)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / audio)
+    model.train()
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point GPU time table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from emoasr_amd import lib as emo_lib, ops
+    from emoasr_amd.data import specaug_spans
+    from emoasr_amd.modeling.asr import ASR
+    from emoasr_amd.train import ArenaAdam, noam_lr
+
+    torch.manual_seed(0)  # identical initial weights on every rank
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = ASR(SimpleNamespace(**L2), compute_dtype=dtype).to(dev)
+    model.train()
+    eng = model.engine()
+    eng.seed = 1234 + rank  # per-replica dropout streams
+    opt = ArenaAdam(eng.arena, lambda s: noam_lr(OPT["lr"], L2["enc_hidden_size"], OPT["warmup"], s),
+                    weight_decay=OPT["weight_decay"], clip_grad_norm=OPT["clip_grad_norm"])
+    batches = make_batches(rank, world, args.warmup + args.steps, dev)
+    np_rng, py_rng = np.random.RandomState(rank), random.Random(rank)
+
+    def step(bt):
+        xs = bt.xs.clone()
+        spans = torch.from_numpy(specaug_spans(bt.xlens, 80, np_rng=np_rng, py_rng=py_rng)).to(dev, non_blocking=True)
+        xl = torch.tensor(bt.xlens, dtype=torch.int32).to(dev, non_blocking=True)
+        ops.specaug_apply(xs, spans, 2, 2, xl)
+        loss, _ = model(xs, bt.xlens, bt.ys, bt.ylens, None, None)
+        opt.zero_grad()
+        loss.backward()
+        if world > 1:
+            opt.allreduce()
+        opt.step(grad_mult=1.0 / world)
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; the last warm-up step is instrumented per entry point to find the dominant kernel family
+    breakdown = None
+    for i in range(args.warmup):
+        if i == args.warmup - 1:
+            with CallTimer(emo_lib) as ct:
+                step(batches[i])
+            breakdown = ct.summary()
+        else:
+            step(batches[i])
+    dominant = max(breakdown, key=lambda k: breakdown[k]["ms"]) if breakdown else "emoasr_gemm_nt"
+    sync()
+    frames = sum(sum(b.xlens) for b in batches[args.warmup:])
+    with CallTimer(emo_lib, names={dominant}) as ct:
+        t0 = time.perf_counter()
+        for bt in batches[args.warmup:]:
+            loss = step(bt)
+        sync()
+        elapsed = time.perf_counter() - t0
+    dom = ct.summary().get(dominant, dict(calls=0, ms=0.0, flops=0.0))
+    tt = torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed, frames = tmax[0].item(), tt[1].item()
+    value = frames / elapsed
+
+    if rank == 0:
+        res = {
+            "metric": "train frames/sec + decode RTF, Conformer-CTC 23M, 80-mel, 1/2/4/8 GPU",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "CTC(Conformer) 23M `L2`, bf16, SpecAugment on-GPU, synthetic LibriSpeech-shaped "
+                                   "batches (2000 utts, lognormal lengths, ASRBatchSampler packing 30000 frames/50 utts "
+                                   "per GPU), fwd+bwd+all-reduce+clip+Adam, dropout 0.1",
+                       "params_M": sum(p.numel() for p in model.parameters()) / 1e6,
+                       "parallelism": f"dp{world}", "final_loss": float(loss.detach())},
+        }
+        mean_T = frames / world / args.steps / max(1, np.mean([len(b.xlens) for b in batches[args.warmup:]]))
+        train_flops = 3.0 * fwd_flops_per_utt(int(mean_T)) / max(mean_T, 1) * frames
+        res["model_mfma_frac"] = train_flops / elapsed / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12 * world)
+        if dom["calls"] and dom["flops"]:
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            res["roofline"] = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[args.dtype],
+                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": None,
+                               "launches": dom["calls"], "avg_us": 1e3 * dom["ms"] / dom["calls"],
+                               "share_of_step": dom["ms"] * 1e-3 / elapsed}
+        else:
+            res["roofline"] = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": None, "traffic": None, "launches": dom["calls"],
+                               "avg_us": 1e3 * dom["ms"] / max(dom["calls"], 1)}
+        if args.breakdown and breakdown:
+            tot = sum(v["ms"] for v in breakdown.values())
+            for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]):
+                tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
+                print(f"  {k:28s} calls {v['calls']:5d}  {v['ms']:9.3f} ms  {100 * v['ms'] / tot:5.1f}%  {tf:7.1f} TF/s",
+                      file=sys.stderr)
+            print(f"  total instrumented GPU time {tot:.2f} ms (one step, B={len(batches[args.warmup - 1].xlens)})", file=sys.stderr)
+        if world == 1 and not args.no_decode:
+            res["decode_rtf"] = decode_rtf(model, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

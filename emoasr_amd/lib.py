@@ -91,6 +91,10 @@ def load():
         raise EmoasrHipError(
             f"{LIB_PATH} not found: build it with `python -m emoasr_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch must load its HIP runtime first: the kernels are enqueued on torch's streams, so this
+    # library has to bind to the same libamdhip64 instance (loading ours first gives a second,
+    # device-less runtime: "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     lib.emoasr_last_error.restype = c_char_p
     lib.emoasr_last_error.argtypes = []

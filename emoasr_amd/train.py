@@ -1,0 +1,52 @@
+"""Training-step glue on the flat parameter arena: fused Adam (HIP), noam schedule, global-norm
+clipping and NaN skip on device, one RCCL all-reduce of the gradient arena per optimizer step.
+
+Reference semantics: asr/train_asr.py:35-97 (micro-batch / accumulate / clip / NaN skip / step),
+asr/optimizers.py:45-82 (ScheduledOptimizer: lr = base_lr * d^-0.5 * min(step^-0.5, step*warmup^-1.5)
+written to the param groups before Adam.step), torch.optim.Adam with coupled weight decay
+(train_asr.py:228).  Data parallelism replaces nn.DataParallel (train_asr.py:236-243): one
+process per GPU, loss = mean of per-replica batch-mean losses => all-reduce(sum) / world.
+"""
+import torch
+
+from . import ops
+
+
+def noam_lr(base_lr, d_model, warmup, step):
+    return base_lr * d_model ** (-0.5) * min(step ** (-0.5), step * warmup ** (-1.5))
+
+
+class ArenaAdam:
+    def __init__(self, arena, lr_fn, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad_norm=0.0):
+        self.arena = arena
+        self.lr_fn = lr_fn
+        self.betas, self.eps, self.wd, self.clip = betas, eps, weight_decay, clip_grad_norm
+        self.m = torch.zeros_like(arena.flat)
+        self.v = torch.zeros_like(arena.flat)
+        self.nsq = torch.zeros(1, device=arena.flat.device, dtype=torch.float32)
+        self._step = 0
+        self.lr = 0.0
+
+    def zero_grad(self):
+        self.arena.grad.zero_()
+
+    def allreduce(self, group=None):
+        import torch.distributed as dist
+        dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM, group=group)
+
+    def step(self, grad_mult=1.0):
+        """grad_mult: 1/world_size after a sum all-reduce (and/or 1/accum if not folded in the loss)."""
+        self._step += 1
+        self.lr = self.lr_fn(self._step)
+        self.nsq.zero_()
+        ops.sqnorm(self.arena.grad, self.nsq)
+        ops.adam_step(self.arena.flat, self.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.wd, self._step, gnorm_sq=self.nsq, clip=self.clip, grad_mult=grad_mult)
+
+    def state_dict(self):
+        return {"_step": self._step, "m": self.m, "v": self.v, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self._step = sd["_step"]
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
