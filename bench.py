@@ -188,6 +188,7 @@ def main():
 
     from emoasr_amd import lib as emo_lib, ops
     from emoasr_amd.data import specaug_spans
+    from emoasr_amd.engine import h2d_i32
     from emoasr_amd.modeling.asr import ASR
     from emoasr_amd.train import ArenaAdam, noam_lr
 
@@ -204,8 +205,8 @@ def main():
 
     def step(bt):
         xs = bt.xs.clone()
-        spans = torch.from_numpy(specaug_spans(bt.xlens, 80, np_rng=np_rng, py_rng=py_rng)).to(dev, non_blocking=True)
-        xl = torch.tensor(bt.xlens, dtype=torch.int32).to(dev, non_blocking=True)
+        spans = h2d_i32(specaug_spans(bt.xlens, 80, np_rng=np_rng, py_rng=py_rng), dev)
+        xl = h2d_i32(bt.xlens, dev)
         ops.specaug_apply(xs, spans, 2, 2, xl)
         loss, _ = model(xs, bt.xlens, bt.ys, bt.ylens, None, None)
         opt.zero_grad()

@@ -383,8 +383,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const emoasr_attn_t a)
       const bool masked = kj >= hp.klen || (a.causal && kj > qi) || lse_q == -INFINITY;
       const float p = masked ? 0.f : __expf(s[r] * a.scale - lse_q);
       float dpr = dp[r];
-      if (a.drop_p > 0.f) dpr *= dropout_scale(a.seed, drop_index(a, b, h, qi, kj), a.drop_p);
+      float dsc = 1.f;
+      if (a.drop_p > 0.f) dsc = dropout_scale(a.seed, drop_index(a, b, h, qi, kj), a.drop_p);
+      dpr *= dsc;
       ds[r] = p * (dpr - del_q) * a.scale;
+      // materialised mode: P^T (after dropout) and dS^T go to HBM once; dV, dK and dpos are then
+      // plain (batched) GEMMs over them instead of three more score recomputations.
+      if (a.pdT && qval && kj < a.Tk) {
+        const long o = (((long)b * a.H + h) * a.Tk + kj) * a.ldpd + qi;
+        ((T*)a.pdT)[o] = from_f32<T>(p * dsc);
+        ((T*)a.dsT)[o] = from_f32<T>(ds[r]);
+      }
     }
     // dQu^T += K^T . dS^T
     stage_rows<T, 32>(Ks, (const T*)hp.k, a.ldk, j0, 0, a.Tk, lane, nullptr);
@@ -397,17 +406,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const emoasr_attn_t a)
     if (hp.pos) {
       // un-skew dS^T into the band: dG^T[c][i] = dS^T[c - 31 + i][i]
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Gs[c_row(r, lane) * 32 + (lane & 31)] = ds[r];
+      for (int r = 0; r < 16; ++r) Gs[c_row(r, lane) * 33 + (lane & 31)] = ds[r];
       const int rbase = a.Tq - 32 - i0 + j0;
       stage_rows<T, 64>(Bs, (const T*)hp.pos, a.ldp, rbase, 0, 2 * a.Tq - 1, lane, nullptr);
       __builtin_amdgcn_wave_barrier();
+      if (a.dbd) {
+        // dBD[h, b, i, r] (r = table row, contiguous): lane <-> band column c, one query row per
+        // iteration, so every store is a contiguous 64-wide row segment.  Each (i, r) pair belongs
+        // to exactly one key tile, so this is a plain store.
+        T* drow = (T*)a.dbd + (((long)h * a.B + b) * a.Tq + i0) * a.ldbd;
+        const int row = rbase + lane;
+        const bool rok = row >= 0 && row < 2 * a.Tq - 1;
+        for (int il = 0; il < 32; ++il) {
+          const int key = lane - 31 + il;
+          if (rok && key >= 0 && key < 32 && i0 + il < a.Tq)
+            drow[(long)il * a.ldbd + row] = from_f32<T>(Gs[key * 33 + il]);
+        }
+      }
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         f32x16 dg;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = 32 * ct + c_row(r, lane) - 31 + (lane & 31);
-          dg[r] = (key >= 0 && key < 32) ? Gs[key * 32 + (lane & 31)] : 0.f;
+          dg[r] = (key >= 0 && key < 32) ? Gs[key * 33 + (lane & 31)] : 0.f;
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -619,6 +641,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos_kernel(const emoasr_attn_t 
   }
 }
 
+// dk[b,key,h,:] += rowsum_q(dS^T[b,h,key,:]) * u[h,:]   (K^T-side of the (q+u) bias; one wave per key row)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_dk_bias_kernel(const emoasr_attn_t a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*H*Tk
+  if (row >= (long)a.B * a.H * a.Tk) return;
+  const int key = row % a.Tk;
+  const long bh = row / a.Tk;
+  const int h = bh % a.H, b = bh / a.H;
+  const T* src = (const T*)a.dsT + row * a.ldpd;
+  float s = 0.f;
+  for (int i = lane; i < a.Tq; i += 64) s += to_f32(src[i]);
+  s = wave_sum(s);
+  T* dk = (T*)a.dk + ((long)b * a.Tk + key) * a.ldk + h * DK + lane;
+  *dk = from_f32<T>(to_f32(*dk) + s * a.bias_u[h * DK + lane]);
+}
+// dpos[r, h*64+d] += cs[h, r] * v[h*64+d]
+__global__ __launch_bounds__(256) void attn_dpos_bias_kernel(const emoasr_attn_t a) {
+  const int n = (2 * a.Tq - 1) * a.H * DK;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int col = i % (a.H * DK), r = i / (a.H * DK);
+  a.dpos[i] += a.cs[(long)(col / DK) * a.ldbd + r] * a.bias_v[col];
+}
+
 template <typename K>
 int set_smem(K kernel, int bytes) {
   if (bytes > 64 * 1024) {
@@ -667,6 +714,32 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
     dim3 grid(cdiv(a.Tq, 128), a.H, a.B);
     attn_bwd_dq_kernel<T, TR><<<grid, 256, smem, s>>>(a);
   }
+  if (a.pdT) {
+    // materialised mode: dV = Pd . dO, dK = dS . (Q + u), dpos_h = dBD_h^T . (Q_h + v)
+    const int dtype = sizeof(T) == 2 ? EMO_BF16 : EMO_F32;
+    const long sp_b = (long)a.H * a.Tk * a.ldpd, sp_h = (long)a.Tk * a.ldpd;
+    EMO_LAUNCH_CHECK();
+    if (emoasr_gemm_nn_batched(dtype, a.Tk, DK, a.Tq, a.pdT, a.ldpd, sp_b, sp_h, a.dout, a.ldo,
+                               (long)a.Tq * a.ldo, DK, a.dv, a.ldv, (long)a.Tk * a.ldv, DK, a.B, a.H, 1.f, s))
+      return 1;
+    if (emoasr_gemm_nn_batched(dtype, a.Tk, DK, a.Tq, a.dsT, a.ldpd, sp_b, sp_h, a.q, a.ldq,
+                               (long)a.Tq * a.ldq, DK, a.dk, a.ldk, (long)a.Tk * a.ldk, DK, a.B, a.H, 1.f, s))
+      return 1;
+    if (a.bias_u) attn_dk_bias_kernel<T><<<cdiv((long)a.B * a.H * a.Tk, 4), 256, 0, s>>>(a);
+    if (a.pos && a.dpos) {
+      const int R = 2 * a.Tq - 1;
+      hipMemsetAsync(a.cs, 0, sizeof(float) * a.H * a.ldbd, s);
+      for (int h = 0; h < a.H; ++h) {
+        const T* dbd_h = (const T*)a.dbd + (long)h * a.B * a.Tq * a.ldbd;
+        if (emoasr_gemm_tn(dtype, R, DK, a.B * a.Tq, dbd_h, a.ldbd, (const T*)a.q + h * DK, a.ldq,
+                           a.dpos + h * DK, (long)a.H * DK, 1.f, 1, a.cs + (long)h * a.ldbd, 1.f, s))
+          return 1;
+      }
+      attn_dpos_bias_kernel<<<cdiv((long)R * a.H * DK, 256), 256, 0, s>>>(a);
+    }
+    EMO_LAUNCH_CHECK();
+    return 0;
+  }
   {
     const int smem = 4 * (32 * 64 * 4 + 64 * LD * (int)sizeof(T));
     if (set_smem(attn_bwd_dkv_kernel<T, TR>, smem)) return 1;
@@ -697,6 +770,12 @@ extern "C" int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream) 
 extern "C" int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream) {
   if (check_args(a, dtype)) return 1;
   EMO_CHECK(a->dout && a->out && a->delta && a->dq && a->dk && a->dv, "attn_bwd: missing buffers");
+  if (a->pdT) {
+    EMO_CHECK(a->dsT && a->ldpd >= a->Tq && a->ldpd % 8 == 0, "attn_bwd: bad pdT/dsT scratch");
+    EMO_CHECK(!a->pos || !a->dpos || (a->dbd && a->cs && a->ldbd >= 2 * a->Tq - 1 && a->ldbd % 8 == 0),
+              "attn_bwd: bad dbd/cs scratch");
+    EMO_CHECK(a->k != nullptr && a->ldq * (long)a->Tq > 0, "attn_bwd: bad q");
+  }
   if (a->B == 0 || a->Tq == 0) return 0;
   EMO_DISPATCH(dtype, {
     if (g_tr) return (launch_bwd_tr<T, true>(*a, (hipStream_t)stream));

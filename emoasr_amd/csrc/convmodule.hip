@@ -10,6 +10,7 @@ namespace {
 
 constexpr int DW_TT = 32;    // output frames per block
 constexpr int DW_MAXK = 31;  // kernel taps (compile-time bound of the register window)
+constexpr int DW_WCHUNKS = 1; // time chunks per block in the weight-gradient kernel
 
 // y[b,t,c] = bias[c] + sum_j w[c,j] * x[b, t + j - pad, c]      (flip=0)
 // dx[b,t,c] =          sum_j w[c,K-1-j] * dy[b, t + j - pad, c]  (flip=1, no bias)
@@ -46,44 +47,76 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const
 // dw[c,j] += sum_{b,t} dy[b,t,c] * x[b,t+j-pad,c];  dbias[c] += sum dy
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(int Tn, int C, int K, const T* __restrict__ dy,
-                                                           const T* __restrict__ x, float* __restrict__ dw,
-                                                           float* __restrict__ dbias) {
+                                                           const T* __restrict__ x, float* __restrict__ part) {
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
-  const int b = blockIdx.z, t0 = blockIdx.x * DW_TT, pad = (K - 1) / 2;
-  float win[DW_TT + DW_MAXK - 1];
-  const T* xb = x + (long)b * Tn * C + c;
-#pragma unroll
-  for (int i = 0; i < DW_TT + DW_MAXK - 1; ++i) {
-    const int t = t0 + i - pad;
-    win[i] = (i < DW_TT + K - 1 && t >= 0 && t < Tn) ? to_f32(xb[(long)t * C]) : 0.f;
-  }
+  const int b = blockIdx.z, pad = (K - 1) / 2;
   float acc[DW_MAXK];
 #pragma unroll
   for (int j = 0; j < DW_MAXK; ++j) acc[j] = 0.f;
   float sb = 0.f;
+  const T* xb = x + (long)b * Tn * C + c;
   const T* dyb = dy + (long)b * Tn * C + c;
+  // several time chunks per block: fewer same-address atomics (f32 atomics collapse ~14x when
+  // every workgroup hits the same few KB)
+  for (int cc = 0; cc < DW_WCHUNKS; ++cc) {
+    const int t0 = (blockIdx.x * DW_WCHUNKS + cc) * DW_TT;
+    if (t0 >= Tn) break;
+    float win[DW_TT + DW_MAXK - 1];
 #pragma unroll
-  for (int i = 0; i < DW_TT; ++i) {
-    const float d = (t0 + i < Tn) ? to_f32(dyb[(long)(t0 + i) * C]) : 0.f;
-    sb += d;
+    for (int i = 0; i < DW_TT + DW_MAXK - 1; ++i) {
+      const int t = t0 + i - pad;
+      win[i] = (i < DW_TT + K - 1 && t >= 0 && t < Tn) ? to_f32(xb[(long)t * C]) : 0.f;
+    }
 #pragma unroll
-    for (int j = 0; j < DW_MAXK; ++j) acc[j] += d * win[i + j];
+    for (int i = 0; i < DW_TT; ++i) {
+      const float d = (t0 + i < Tn) ? to_f32(dyb[(long)(t0 + i) * C]) : 0.f;
+      sb += d;
+#pragma unroll
+      for (int j = 0; j < DW_MAXK; ++j) acc[j] += d * win[i + j];
+    }
   }
+  // per-block partials [blk][K+1][C] (coalesced along c); folded by dwconv_bwd_w_reduce_kernel
+  const long blk = ((long)blockIdx.z * gridDim.x + blockIdx.x);
+  float* p = part + blk * (K + 1) * C + c;
 #pragma unroll
   for (int j = 0; j < DW_MAXK; ++j)
-    if (j < K) atomicAdd(&dw[c * K + j], acc[j]);
-  if (dbias) atomicAdd(&dbias[c], sb);
+    if (j < K) p[(long)j * C] = acc[j];
+  p[(long)K * C] = sb;
+}
+
+__global__ __launch_bounds__(256) void dwconv_bwd_w_reduce_kernel(int nblk, int C, int K,
+                                                                  const float* __restrict__ part,
+                                                                  float* __restrict__ dw,
+                                                                  float* __restrict__ dbias) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;  // over (K+1)*C, laid out [j][c]
+  const int n = (K + 1) * C;
+  float s = 0.f;
+  if (i < n) {
+#pragma unroll 8
+    for (int b = wave; b < nblk; b += 4) s += part[(long)b * n + i];
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && i < n) {
+    s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    const int j = i / C, c = i % C;
+    if (j < K) dw[c * K + j] += s;
+    else if (dbias) dbias[c] += s;
+  }
 }
 
 // ---- BatchNorm statistics: two passes (sum, then centred sum of squares) --------
 constexpr int BN_ROWS = 16;
+constexpr int BN_STAT_ROWS = 64;  // rows per block in the reduction kernels (contended f32 atomics)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_sum_kernel(int M, int C, const T* __restrict__ y,
                                                      float* __restrict__ sum) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const int r0 = blockIdx.y * BN_ROWS, r1 = min(M, r0 + BN_ROWS);
+  const int r0 = blockIdx.y * BN_STAT_ROWS, r1 = min(M, r0 + BN_STAT_ROWS);
   float s = 0.f;
   for (int r = r0; r < r1; ++r) s += to_f32(y[(long)r * C + c]);
   atomicAdd(&sum[c], s);
@@ -95,7 +128,7 @@ __global__ __launch_bounds__(256) void bn_var_kernel(int M, int C, const T* __re
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const float mu = sum[c] / M;
-  const int r0 = blockIdx.y * BN_ROWS, r1 = min(M, r0 + BN_ROWS);
+  const int r0 = blockIdx.y * BN_STAT_ROWS, r1 = min(M, r0 + BN_STAT_ROWS);
   float s = 0.f;
   for (int r = r0; r < r1; ++r) { const float d = to_f32(y[(long)r * C + c]) - mu; s += d * d; }
   atomicAdd(&sq[c], s);
@@ -140,7 +173,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(int M, int C, const T*
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const float mu = mean[c], is = rsqrtf(var[c] + eps), g = gamma[c], bt = beta[c];
-  const int r0 = blockIdx.y * BN_ROWS, r1 = min(M, r0 + BN_ROWS);
+  const int r0 = blockIdx.y * BN_STAT_ROWS, r1 = min(M, r0 + BN_STAT_ROWS);
   float s1 = 0.f, s2 = 0.f;
   for (int r = r0; r < r1; ++r) {
     const long i = (long)r * C + c;
@@ -204,8 +237,12 @@ extern "C" int emoasr_dwconv_bwd_x(int dtype, int B, int Tn, int C, int K, const
   EMO_LAUNCH_CHECK();
   return 0;
 }
+extern "C" long emoasr_dwconv_bwd_w_scratch_floats(int B, int Tn, int C, int K) {
+  return (long)B * cdiv(Tn, DW_TT * DW_WCHUNKS) * (K + 1) * C;
+}
+
 extern "C" int emoasr_dwconv_bwd_w(int dtype, int B, int Tn, int C, int K, const void* dy, const void* x,
-                                   float* dw, float* dbias, int accumulate, void* stream) {
+                                   float* dw, float* dbias, int accumulate, float* scratch, void* stream) {
   EMO_CHECK(K <= DW_MAXK && (K & 1), "dwconv: K=%d unsupported", K);
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate) {
@@ -213,9 +250,11 @@ extern "C" int emoasr_dwconv_bwd_w(int dtype, int B, int Tn, int C, int K, const
     if (dbias) hipMemsetAsync(dbias, 0, sizeof(float) * C, s);
   }
   if (B * Tn == 0) return 0;
-  dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
-  EMO_DISPATCH(dtype, (dwconv_bwd_w_kernel<T><<<grid, 256, 0, s>>>(Tn, C, K, (const T*)dy, (const T*)x, dw,
-                                                                  dbias)));
+  EMO_CHECK(scratch != nullptr, "dwconv_bwd_w: scratch of emoasr_dwconv_bwd_w_scratch_floats() floats required");
+  dim3 grid(cdiv(Tn, DW_TT * DW_WCHUNKS), cdiv(C, 256), B);
+  EMO_DISPATCH(dtype, (dwconv_bwd_w_kernel<T><<<grid, 256, 0, s>>>(Tn, C, K, (const T*)dy, (const T*)x, scratch)));
+  const int nblk = grid.x * B;
+  dwconv_bwd_w_reduce_kernel<<<cdiv((K + 1) * C, 64), 256, 0, s>>>(nblk, C, K, scratch, dw, dbias);
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -226,7 +265,7 @@ extern "C" int emoasr_bn_stats(int dtype, int M, int C, const void* y, float* me
   hipStream_t s = (hipStream_t)stream;
   hipMemsetAsync(mean, 0, sizeof(float) * C, s);
   hipMemsetAsync(var, 0, sizeof(float) * C, s);
-  dim3 grid(cdiv(C, 256), cdiv(M, BN_ROWS));
+  dim3 grid(cdiv(C, 256), cdiv(M, BN_STAT_ROWS));
   EMO_DISPATCH(dtype, (bn_sum_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)y, mean)));
   EMO_DISPATCH(dtype, (bn_var_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)y, mean, var)));
   bn_finalize_kernel<<<cdiv(C, 256), 256, 0, s>>>(M, C, mean, var, running_mean, running_var, momentum);
@@ -253,8 +292,9 @@ extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, cons
   hipStream_t s = (hipStream_t)stream;
   hipMemsetAsync(scratch, 0, sizeof(float) * 2 * C, s);
   dim3 grid(cdiv(C, 256), cdiv(M, BN_ROWS));
-  EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
-                                                                 var, gamma, beta, eps, scratch)));
+  dim3 sgrid(cdiv(C, 256), cdiv(M, BN_STAT_ROWS));
+  EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<sgrid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
+                                                                  var, gamma, beta, eps, scratch)));
   EMO_DISPATCH(dtype, (bn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
                                                                   var, gamma, beta, eps, scratch, (T*)dy,
                                                                   dgamma, dbeta)));

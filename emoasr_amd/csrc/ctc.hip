@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(int Tn, int V, int S, int
                                                        const float* __restrict__ alpha,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ nll, float gscale,
+                                                       const float* __restrict__ gscale_dev,
                                                        T* __restrict__ grad, long ldg) {
   extern __shared__ float rowbuf[];  // [V]
   const int b = blockIdx.y, t = blockIdx.x;
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(int Tn, int V, int S, int
     if (occ > 0.f) atomicAdd(&rowbuf[ext_label(lab, s, blank)], -occ);
   }
   __syncthreads();
-  for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(rowbuf[v] * gscale);
+  const float gs = gscale_dev ? gscale * gscale_dev[0] : gscale;
+  for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(rowbuf[v] * gs);
 }
 
 template <typename T>
@@ -246,7 +248,8 @@ extern "C" int emoasr_ctc_forward(int dtype, int B, int Tn, int V, int Lmax, con
 extern "C" int emoasr_ctc_grad(int dtype, int B, int Tn, int V, int Lmax, const void* logits, long ld,
                                const float* lse, const int* labels, const int* elens, const int* ylens,
                                int blank, const float* lp, const float* alpha, const float* beta,
-                               const float* nll, float gscale, void* grad, long ldg, void* stream) {
+                               const float* nll, float gscale, const float* gscale_dev, void* grad, long ldg,
+                               void* stream) {
   const int S = 2 * Lmax + 1;
   EMO_CHECK((size_t)V * 4 <= 160 * 1024 - 256, "ctc_grad: V=%d too large for an LDS row", V);
   if (B == 0 || Tn == 0) return 0;
@@ -256,6 +259,7 @@ extern "C" int emoasr_ctc_grad(int dtype, int B, int Tn, int V, int Lmax, const 
       hipFuncSetAttribute((const void*)ctc_grad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, V * 4);
     ctc_grad_kernel<T><<<grid, 256, sizeof(float) * V, (hipStream_t)stream>>>(
         Tn, V, S, Lmax, (const T*)logits, ld, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale,
+        gscale_dev,
         (T*)grad, ldg);
   });
   EMO_LAUNCH_CHECK();

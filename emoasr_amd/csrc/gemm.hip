@@ -49,14 +49,45 @@ struct NtArgs {
   void* C; long ldc;
   emoasr_epilogue_t ep;
   ConvGeom cg;
+  int nh;  // batched: blockIdx.z = b * nh + h, two-level strides below (elements); 0 = not batched
+  long sa_b, sa_h, sb_b, sb_h, sc_b, sc_h;
 };
 
+#ifndef EMO_BK_BF16
+#define EMO_BK_BF16 32
+#endif
 template <typename T> struct TileCfg {
   static constexpr int VEC = 16 / sizeof(T);
-  static constexpr int BK = sizeof(T) == 2 ? 32 : 16;
+  static constexpr int BK = sizeof(T) == 2 ? EMO_BK_BF16 : 16;
   static constexpr int KV = BK / VEC;                       // 16-byte vectors per tile row (= 4)
   static constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 1);  // padded LDS row (elements)
 };
+
+// 8 consecutive elements of T <-> 8 floats (16 bytes of bf16, 32 bytes of f32)
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&o)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+  } else {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&o)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)o[e];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  } else {
+    *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
+  }
+}
 
 template <typename T>
 __device__ __forceinline__ void lds_store_row(T* dst, const Vec16<T>& v) {
@@ -69,6 +100,11 @@ __device__ __forceinline__ void lds_store_row(T* dst, const Vec16<T>& v) {
 }
 
 // BKM = true: B is stored [K][N] (k-major, row stride ldb) -> C = A . B   ("NN", used for dgrad)
+//
+// Loads are branch-free: out-of-range rows / k-vectors read a clamped in-bounds address and are
+// zeroed with a select, so the k-loop has no exec-mask branches.  The epilogue transposes each
+// 32x32 accumulator tile through wave-private LDS so that every lane owns 8 consecutive columns
+// of one row: bias / saved-activation / residual traffic and the output are 16-byte accesses.
 template <typename T, int BM, int BN, int AMODE, bool BKM, bool TR>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   using Cfg = TileCfg<T>;
@@ -79,18 +115,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   constexpr int BVK = BN / VEC;                          // vectors per k row (k-major B)
   constexpr int A_IT = BM * KV / 256, B_IT = BKM ? BK * BVK / 256 : BN * KV / 256;
   static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 threads");
-  constexpr int BS_ELEMS = BKM ? BK * LDBK : BN * LD;
+  constexpr int AS_ELEMS = BM * LD, BS_ELEMS = BKM ? BK * LDBK : BN * LD;
+  constexpr int EP_LD = 36;                               // f32 row stride of the epilogue tile
+  constexpr int STAGE_BYTES = 2 * (AS_ELEMS + BS_ELEMS) * (int)sizeof(T);
+  constexpr int EPI_BYTES = 4 * 32 * EP_LD * 4;
+  constexpr int SMEM_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 
-  __shared__ __attribute__((aligned(16))) T As[2][BM * LD];
-  __shared__ __attribute__((aligned(16))) T Bs[2][BS_ELEMS];
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+  T* As0 = reinterpret_cast<T*>(smem);
+  T* Bs0 = As0 + 2 * AS_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const T* __restrict__ A = static_cast<const T*>(g.A);
   const T* __restrict__ B = static_cast<const T*>(g.B);
+  long c_base = 0;
+  if (g.nh > 0) {
+    const int bb = blockIdx.z / g.nh, hh = blockIdx.z % g.nh;
+    A += bb * g.sa_b + hh * g.sa_h;
+    B += bb * g.sb_b + hh * g.sb_h;
+    c_base = bb * g.sc_b + hh * g.sc_h;
+  }
 
-  // per-thread staging assignments (fixed rows across the k loop)
+  // per-thread staging assignments (fixed rows across the k loop); invalid rows alias row 0
   const T* a_ptr[A_IT]; bool a_ok[A_IT]; int a_lds[A_IT]; int a_kv[A_IT];
   const T* b_ptr[B_IT]; bool b_ok[B_IT]; int b_lds[B_IT]; int b_kv[B_IT];
 #pragma unroll
@@ -123,25 +171,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int k = k0 + a_kv[i];
-      if (a_ok[i] && k < g.K) {
-        if constexpr (AMODE == 1) a_reg[i] = load16(a_ptr[i] + conv_k_off(g.cg, k));
-        else a_reg[i] = load16(a_ptr[i] + k);
-      } else a_reg[i].zero();
+      const bool ok = a_ok[i] && k < g.K;
+      const int kc = ok ? k : 0;  // clamped: always a readable address
+      if constexpr (AMODE == 1) a_reg[i] = load16(a_ptr[i] + conv_k_off(g.cg, kc));
+      else a_reg[i] = load16(a_ptr[i] + kc);
+      if (!ok) a_reg[i].zero();
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int k = k0 + b_kv[i];
-      if (b_ok[i] && k < g.K) b_reg[i] = load16(b_ptr[i] + (BKM ? (long)k * g.ldb : (long)k));
-      else b_reg[i].zero();
+      const bool ok = b_ok[i] && k < g.K;
+      const int kc = ok ? k : 0;
+      b_reg[i] = load16(b_ptr[i] + (BKM ? (long)kc * g.ldb : (long)kc));
+      if (!ok) b_reg[i].zero();
     }
   };
   auto store_tile = [&](int buf) {
+    T* As = As0 + buf * AS_ELEMS;
+    T* Bs = Bs0 + buf * BS_ELEMS;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) lds_store_row(&As[buf][a_lds[i]], a_reg[i]);
+    for (int i = 0; i < A_IT; ++i) lds_store_row(&As[a_lds[i]], a_reg[i]);
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      if constexpr (BKM) store16(&Bs[buf][b_lds[i]], b_reg[i]);
-      else lds_store_row(&Bs[buf][b_lds[i]], b_reg[i]);
+      if constexpr (BKM) store16(&Bs[b_lds[i]], b_reg[i]);
+      else lds_store_row(&Bs[b_lds[i]], b_reg[i]);
     }
   };
 
@@ -159,16 +212,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
+    const T* As = As0 + buf * AS_ELEMS;
+    const T* Bs = Bs0 + buf * BS_ELEMS;
     if (kt + 1 < nk) load_tile((kt + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += M_::KSTEP) {
       typename M_::Frag af[TM], bfr[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = M_::load_kc(As[buf], LD, wm + i * 32, kk, lane);
+      for (int i = 0; i < TM; ++i) af[i] = M_::load_kc(As, LD, wm + i * 32, kk, lane);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if constexpr (BKM) bfr[j] = M_::template load_km<TR>(Bs[buf], LDBK, kk, wn + j * 32, lane);
-        else bfr[j] = M_::load_kc(Bs[buf], LD, wn + j * 32, kk, lane);
+        if constexpr (BKM) bfr[j] = M_::template load_km<TR>(Bs, LDBK, kk, wn + j * 32, lane);
+        else bfr[j] = M_::load_kc(Bs, LD, wn + j * 32, kk, lane);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -180,31 +235,85 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   }
 
   // ---- epilogue -------------------------------------------------------------
+  // (the loop ended with a barrier: the staging buffers are free to be reused)
   const emoasr_epilogue_t& ep = g.ep;
   const T* __restrict__ res = static_cast<const T*>(ep.residual);
   const T* __restrict__ dpre = static_cast<const T*>(ep.dact_pre);
   T* __restrict__ pre_out = static_cast<T*>(ep.pre_out);
+  float* sc = reinterpret_cast<float*>(smem) + wave * 32 * EP_LD;
+  const int er = lane >> 2, ec = (lane & 3) * 8;  // this lane's row (per 16-row pass) and column group
+  const bool vec_ok = (g.N % 8 == 0) && (g.ldc % 8 == 0) && (!res || ep.ldr % 8 == 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn + j * 32 + c_col(lane);
-      if (col >= g.N) continue;
-      const float bias = ep.bias ? ep.bias[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + i * 32 + c_row(r, lane);
-        if (row >= g.M) continue;
-        float v = ep.alpha * acc[i][j][r] + bias;
-        const long off = (long)row * g.ldc + col;
-        if (pre_out) pre_out[off] = from_f32<T>(v);
-        v = apply_act(ep.act, v);
-        if (dpre) v *= apply_dact(ep.dact, to_f32(dpre[off]));
-        if (ep.drop_p > 0.f) v *= dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col, ep.drop_p);
-        if (res) v = to_f32(res[(long)row * ep.ldr + col]) + ep.res_scale * v;
-        if (ep.out_f32) static_cast<float*>(g.C)[off] = v;
-        else static_cast<T*>(g.C)[off] = from_f32<T>(v);
+      for (int r = 0; r < 16; ++r) sc[c_row(r, lane) * EP_LD + c_col(lane)] = acc[i][j][r];
+      __builtin_amdgcn_wave_barrier();
+      const int col = n0 + wn + j * 32 + ec;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int lrow = pass * 16 + er;
+        const int row = m0 + wm + i * 32 + lrow;
+        if (row < g.M && col < g.N) {
+          float v[8];
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sc[lrow * EP_LD + ec]);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&sc[lrow * EP_LD + ec + 4]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+          const long off = c_base + (long)row * g.ldc + col;
+          if (vec_ok) {
+            if (ep.bias) {
+              const f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.bias + col);
+              const f32x4 b1 = *reinterpret_cast<const f32x4*>(ep.bias + col + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] = ep.alpha * v[e] + b0[e]; v[4 + e] = ep.alpha * v[4 + e] + b1[e]; }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
+            }
+            if (pre_out) store8<T>(pre_out + off, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = apply_act(ep.act, v[e]);
+            if (dpre) {
+              float d[8];
+              load8<T>(dpre + off, d);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= apply_dact(ep.dact, d[e]);
+            }
+            if (ep.drop_p > 0.f) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                v[e] *= dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col + e, ep.drop_p);
+            }
+            if (res) {
+              float d[8];
+              load8<T>(res + (long)row * ep.ldr + col, d);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = d[e] + ep.res_scale * v[e];
+            }
+            if (ep.out_f32) {
+              float* o = static_cast<float*>(g.C) + off;
+              *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+              *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+              store8<T>(static_cast<T*>(g.C) + off, v);
+            }
+          } else {
+            for (int e = 0; e < 8 && col + e < g.N; ++e) {
+              float x = ep.alpha * v[e] + (ep.bias ? ep.bias[col + e] : 0.f);
+              if (pre_out) pre_out[off + e] = from_f32<T>(x);
+              x = apply_act(ep.act, x);
+              if (dpre) x *= apply_dact(ep.dact, to_f32(dpre[off + e]));
+              if (ep.drop_p > 0.f) x *= dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col + e, ep.drop_p);
+              if (res) x = to_f32(res[(long)row * ep.ldr + col + e]) + ep.res_scale * x;
+              if (ep.out_f32) static_cast<float*>(g.C)[off + e] = x;
+              else static_cast<T*>(g.C)[off + e] = from_f32<T>(x);
+            }
+          }
+        }
       }
+      __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -220,6 +329,8 @@ struct TnArgs {
   float* C; long ldc;
   float alpha;
   int k_tiles_per_split;
+  float* colsum;       // optional: colsum[n1] += colsum_scale * sum_k A[k, n1]  (bias gradient)
+  float colsum_scale;
   ConvGeom cg;
 };
 
@@ -292,12 +403,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool do_colsum = g.colsum != nullptr && blockIdx.x == 0 && tid < BN1;
+  float csum = 0.f;
   load_tile(kt_begin * BK);
   store_tile(0);
   __syncthreads();
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int buf = (kt - kt_begin) & 1;
     if (kt + 1 < kt_end) load_tile((kt + 1) * BK);
+    if (do_colsum) {
+#pragma unroll
+      for (int k = 0; k < BK; ++k) csum += to_f32(As[buf][k * LDA + tid]);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += M_::KSTEP) {
       typename M_::Frag af[TM], bfr[TN];
@@ -327,20 +444,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
         atomicAdd(&g.C[(long)row * g.ldc + col], g.alpha * acc[i][j][r]);
       }
     }
+  if (do_colsum && n1_0 + tid < g.N1) atomicAdd(&g.colsum[n1_0 + tid], g.colsum_scale * csum);
 }
 
 template <typename T, int AMODE, bool BKM, bool TR>
-int launch_nt_(const NtArgs& a, hipStream_t s) {
-  const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-  const long t12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64);
+int launch_nt_(const NtArgs& a, hipStream_t s, int nz = 1) {
+  const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * nz;
+  const long t12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64) * nz;
   if (t128 >= 512) {
-    dim3 grid(cdiv(a.N, 128), cdiv(a.M, 128));
+    dim3 grid(cdiv(a.N, 128), cdiv(a.M, 128), nz);
     gemm_nt_kernel<T, 128, 128, AMODE, BKM, TR><<<grid, 256, 0, s>>>(a);
   } else if (t12864 >= 384) {
-    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 128));
+    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 128), nz);
     gemm_nt_kernel<T, 128, 64, AMODE, BKM, TR><<<grid, 256, 0, s>>>(a);
   } else {
-    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64));
+    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64), nz);
     gemm_nt_kernel<T, 64, 64, AMODE, BKM, TR><<<grid, 256, 0, s>>>(a);
   }
   EMO_LAUNCH_CHECK();
@@ -349,19 +467,25 @@ int launch_nt_(const NtArgs& a, hipStream_t s) {
 template <typename T, int AMODE>
 int launch_nt(const NtArgs& a, hipStream_t s) { return launch_nt_<T, AMODE, false, true>(a, s); }
 template <typename T>
-int launch_nn(const NtArgs& a, hipStream_t s) {
-  return g_tr_read ? launch_nt_<T, 0, true, true>(a, s) : launch_nt_<T, 0, true, false>(a, s);
+int launch_nn(const NtArgs& a, hipStream_t s, int nz = 1) {
+  return g_tr_read ? launch_nt_<T, 0, true, true>(a, s, nz) : launch_nt_<T, 0, true, false>(a, s, nz);
 }
 
 template <typename T, int BMODE>
 int launch_tn(TnArgs a, hipStream_t s) {
   constexpr int BK = TileCfg<T>::BK;
   const int nk = cdiv(a.K, BK);
-  const bool big = (long)cdiv(a.N1, 128) * cdiv(a.N2, 128) >= 8 && a.N1 >= 128 && a.N2 >= 128;
+  const bool big = (long)cdiv(a.N1, 128) * cdiv(a.N2, 128) >= 32 && a.N1 >= 128 && a.N2 >= 128;
   const int bn = big ? 128 : 64;
   const long tiles = (long)cdiv(a.N1, bn) * cdiv(a.N2, bn);
-  // enough split-K slices to put ~2 blocks on every CU, at least 4 k-tiles each
+  // split-K: enough slices to put ~2 blocks on every CU with at least 4 k-tiles each, but keep
+  // the f32 atomic traffic (output bytes x slices) around 8 MB: global float atomics run at
+  // ~1.3 TB/s chip-wide, so more slices than that make the kernel atomic-bound.
   int splits = (int)((512 + tiles - 1) / tiles);
+  const long out_bytes = (long)a.N1 * a.N2 * 4;
+  const int cap = (int)std::max(1L, (8L << 20) / out_bytes);
+  const int floor_splits = (int)std::min((long)splits, (128 + tiles - 1) / tiles);  // never starve the chip
+  splits = std::max(floor_splits, std::min(splits, cap));
   splits = std::max(1, std::min(splits, nk / 4 > 0 ? nk / 4 : 1));
   a.k_tiles_per_split = cdiv(nk, splits);
   splits = cdiv(nk, a.k_tiles_per_split);
@@ -410,18 +534,40 @@ extern "C" int emoasr_gemm_nn(int dtype, int M, int N, int K, const void* A, lon
   return 0;
 }
 
+// Batched C[b,h] = alpha * A[b,h] . B[b,h] (B k-major), two-level batch strides in elements.
+// Used by the attention backward: dV = Pd^T-stored . dO and dK = dS^T-stored . Q per (batch, head).
+extern "C" int emoasr_gemm_nn_batched(int dtype, int M, int N, int K, const void* A, long lda, long sa_b,
+                                      long sa_h, const void* B, long ldb, long sb_b, long sb_h, void* C,
+                                      long ldc, long sc_b, long sc_h, int nb, int nh, float alpha,
+                                      void* stream) {
+  EMO_CHECK(M > 0 && N > 0 && K > 0 && nb > 0 && nh > 0, "gemm_nn_batched: empty problem");
+  // K need not be a multiple of the vector width: rows of A are padded up to lda (zero-filled)
+  if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") ||
+      check_vec(N, dtype, "N") || check_vec(sa_b, dtype, "sa_b") || check_vec(sa_h, dtype, "sa_h") ||
+      check_vec(sb_b, dtype, "sb_b") || check_vec(sb_h, dtype, "sb_h")) return 1;
+  NtArgs a{};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.ep = emoasr_epilogue_t{}; a.ep.alpha = alpha;
+  a.nh = nh; a.sa_b = sa_b; a.sa_h = sa_h; a.sb_b = sb_b; a.sb_h = sb_h; a.sc_b = sc_b; a.sc_h = sc_h;
+  EMO_DISPATCH(dtype, return (launch_nn<T>(a, (hipStream_t)stream, nb * nh)));
+  return 0;
+}
+
 extern "C" int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, long lda, const void* B,
-                              long ldb, float* C, long ldc, float alpha, int accumulate, void* stream) {
+                              long ldb, float* C, long ldc, float alpha, int accumulate, float* colsum,
+                              float colsum_scale, void* stream) {
   EMO_CHECK(N1 > 0 && N2 > 0 && K > 0, "gemm_tn: empty problem");
-  if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") || check_vec(N1, dtype, "N1") ||
-      check_vec(N2, dtype, "N2")) return 1;
+  // N1 may be ragged when lda is padded (rows readable up to lda)
+  if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") || check_vec(N2, dtype, "N2")) return 1;
+  EMO_CHECK(N1 % (dtype == EMO_BF16 ? 8 : 4) == 0 || lda >= (N1 + 7) / 8 * 8, "gemm_tn: ragged N1 needs padded lda");
   if (!accumulate) {
     if (ldc == N2) hipMemsetAsync(C, 0, sizeof(float) * (size_t)N1 * N2, (hipStream_t)stream);
     else hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N2, N1, (hipStream_t)stream);
+    if (colsum) hipMemsetAsync(colsum, 0, sizeof(float) * N1, (hipStream_t)stream);
   }
   TnArgs a{};
   a.N1 = N1; a.N2 = N2; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
-  a.alpha = alpha;
+  a.alpha = alpha; a.colsum = colsum; a.colsum_scale = colsum_scale;
   EMO_DISPATCH(dtype, return (launch_tn<T, 0>(a, (hipStream_t)stream)));
 }
 
@@ -441,14 +587,17 @@ extern "C" int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const v
 
 // dW[n, (kh,kw,c)] (+)= sum_{(b,t2,f2)} dy2[(b,t2,f2), n] * y1[b,2t2+kh,2f2+kw,c]
 extern "C" int emoasr_conv2_wgrad(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* y1,
-                                  float* dw, int accumulate, void* stream) {
+                                  float* dw, float* dbias, int accumulate, void* stream) {
   const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
   EMO_CHECK(T1 >= 3 && F1 >= 3, "conv2_wgrad: input too small");
   EMO_CHECK(C % 128 == 0, "conv2_wgrad: C must be a multiple of 128");
-  if (!accumulate) hipMemsetAsync(dw, 0, sizeof(float) * (size_t)C * 9 * C, (hipStream_t)stream);
+  if (!accumulate) {
+    hipMemsetAsync(dw, 0, sizeof(float) * (size_t)C * 9 * C, (hipStream_t)stream);
+    if (dbias) hipMemsetAsync(dbias, 0, sizeof(float) * C, (hipStream_t)stream);
+  }
   TnArgs a{};
   a.N1 = C; a.N2 = 9 * C; a.K = B * T2 * F2; a.A = dy2; a.lda = C; a.B = y1; a.ldb = 0; a.C = dw;
-  a.ldc = 9 * C; a.alpha = 1.f;
+  a.ldc = 9 * C; a.alpha = 1.f; a.colsum = dbias; a.colsum_scale = 1.f;
   a.cg = ConvGeom{T1, F1, T2, F2, C};
   EMO_DISPATCH(dtype, return (launch_tn<T, 1>(a, (hipStream_t)stream)));
 }

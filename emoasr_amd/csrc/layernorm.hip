@@ -4,6 +4,7 @@
 //
 // HBM-bound: one wave per row, 4 consecutive features per lane per pass, row kept
 // in registers between the statistics and the normalisation (x is read once).
+#include <algorithm>
 #include "common.h"
 #include "../../include/emoasr_hip.h"
 
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int N, const T* __re
 // Each block walks ROWS_PER_BLOCK rows (one wave per row at a time) and keeps the
 // per-feature dgamma / dbeta partial sums in registers; one LDS reduction and one
 // f32 atomic per feature per block at the end.
-constexpr int LN_BWD_ROWS = 32;
+constexpr int LN_BWD_MAXBLK = 256;  // persistent blocks, 4 rows (one per wave) in flight each
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int N, const T* __restrict__ dy,
@@ -89,8 +90,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int N, const T* __re
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
-                                                     float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta) {
+                                                     float* __restrict__ dgamma_part) {
   __shared__ float red[4][2][LN_MAXC * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dg[LN_MAXC][4], db[LN_MAXC][4], g[LN_MAXC][4];
@@ -103,10 +103,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int N, const T* __re
       g[c][j] = col < N ? gamma[col + j] : 0.f;
     }
   }
-  const int row0 = blockIdx.x * LN_BWD_ROWS;
-  for (int r = wave; r < LN_BWD_ROWS; r += 4) {
-    const int row = row0 + r;
-    if (row >= M) break;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
     float xh[LN_MAXC][4], gy[LN_MAXC][4];
     float s1 = 0.f, s2 = 0.f;
@@ -143,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int N, const T* __re
       }
     }
   }
-  if (!dgamma && !dbeta) return;
+  if (!dgamma_part) return;
 #pragma unroll
   for (int c = 0; c < LN_MAXC; ++c)
 #pragma unroll
@@ -152,11 +149,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int N, const T* __re
       red[wave][1][c * 256 + lane * 4 + j] = db[c][j];
     }
   __syncthreads();
+  // per-block partial sums; a second tiny kernel folds them (no contended atomics)
+  float* part = dgamma_part + (long)blockIdx.x * 2 * N;
   for (int col = threadIdx.x; col < N; col += 256) {
-    const float a = red[0][0][col] + red[1][0][col] + red[2][0][col] + red[3][0][col];
-    const float b = red[0][1][col] + red[1][1][col] + red[2][1][col] + red[3][1][col];
-    if (dgamma) atomicAdd(&dgamma[col], a);
-    if (dbeta) atomicAdd(&dbeta[col], b);
+    part[col] = red[0][0][col] + red[1][0][col] + red[2][0][col] + red[3][0][col];
+    part[N + col] = red[0][1][col] + red[1][1][col] + red[2][1][col] + red[3][1][col];
+  }
+}
+
+// 64 columns per block, 4 row groups (one per wave) summed through LDS
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(int nblk, int N, const float* __restrict__ part,
+                                                              float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;  // over 2N
+  float s = 0.f;
+  if (col < 2 * N) {
+#pragma unroll 8
+    for (int b = wave; b < nblk; b += 4) s += part[(long)b * 2 * N + col];
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && col < 2 * N) {
+    s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (col < N) { if (dgamma) dgamma[col] += s; }
+    else if (dbeta) dbeta[col - N] += s;
   }
 }
 
@@ -176,12 +194,20 @@ extern "C" int emoasr_layernorm_fwd(int dtype, int M, int N, const void* x, cons
 extern "C" int emoasr_layernorm_bwd(int dtype, int M, int N, const void* dy, const void* x,
                                     const float* gamma, const float* mean, const float* rstd,
                                     const void* dres, void* dx, float* dgamma, float* dbeta,
-                                    void* stream) {
+                                    float* scratch, void* stream) {
   EMO_CHECK(N % 4 == 0 && N <= LN_MAXC * 256, "layernorm: N=%d unsupported", N);
   if (M == 0) return 0;
-  EMO_DISPATCH(dtype, (ln_bwd_kernel<T><<<cdiv(M, LN_BWD_ROWS), 256, 0, (hipStream_t)stream>>>(
+  const bool want = dgamma || dbeta;
+  EMO_CHECK(!want || scratch, "layernorm_bwd: scratch (%d floats) required for dgamma/dbeta",
+            LN_BWD_MAXBLK * 2 * N);
+  const int nblk = std::min(cdiv(M, 4), LN_BWD_MAXBLK);
+  EMO_DISPATCH(dtype, (ln_bwd_kernel<T><<<nblk, 256, 0, (hipStream_t)stream>>>(
                           M, N, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx,
-                          dgamma, dbeta)));
+                          want ? scratch : nullptr)));
+  if (want)
+    ln_bwd_finalize_kernel<<<cdiv(2 * N, 64), 256, 0, (hipStream_t)stream>>>(nblk, N, scratch, dgamma, dbeta);
   EMO_LAUNCH_CHECK();
   return 0;
 }
+
+extern "C" int emoasr_layernorm_bwd_scratch_floats(int N) { return LN_BWD_MAXBLK * 2 * N; }

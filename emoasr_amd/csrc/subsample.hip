@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(int Tn, int F, int T1, i
 }
 
 // dw1[c, kh*3+kw] += sum dy1[b,t1,f1,c] * x[b,2t1+kh,2f1+kw];  db1[c] += sum dy1
-constexpr int C1_TROWS = 4;  // t1 rows per block
+constexpr int C1_TROWS = 16;  // t1 rows per block (fewer, less contended f32 atomics)
 template <typename T>
 __global__ __launch_bounds__(1024) void conv1_wgrad_kernel(int Tn, int F, int T1, int F1, int C,
                                                           const float* __restrict__ x,

@@ -142,6 +142,12 @@ class _Stash:
     pass
 
 
+def h2d_i32(values, device):
+    """small host array -> int32 device tensor through pinned memory (asynchronous H2D)"""
+    t = torch.as_tensor(values, dtype=torch.int32)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class CTCEngine:
     """Forward / backward of encoder + CTC head on HIP kernels."""
 
@@ -158,6 +164,8 @@ class CTCEngine:
         self.module = module
         self.arena = ParamArena(module, compute_dtype)
         self._tables = {}
+        self._attn_scratch = None
+        self._attn_scratch_elens = None
         self._bufs = {}
         self.seed = 0x5EED
         self.step_count = 0
@@ -167,15 +175,21 @@ class CTCEngine:
         if not self.arena.bound():
             self.arena = ParamArena(self.module, self.dtype)
 
-    def _pos_table(self, T, device):
-        key = (self.rel, T)
+    def _pos_table(self, T, device, max_len=5000):
+        """sinusoid table slice for T frames; the full table is built once (like the reference's
+        max_len=5000 tables, conformer.py:17,23 / transformer.py:16,22) and sliced per batch."""
+        max_len = max(max_len, T)
+        key = (self.rel, max_len, str(device))
         if key not in self._tables:
             if self.rel:
-                tab = sinusoid(torch.arange(T - 1, -T, -1), self.d, device)  # row r <-> rel = T-1-r
+                tab = sinusoid(torch.arange(max_len - 1, -max_len, -1), self.d, device)  # row r <-> rel = max_len-1-r
             else:
-                tab = sinusoid(torch.arange(T), self.d, device)
+                tab = sinusoid(torch.arange(max_len), self.d, device)
             self._tables[key] = tab
-        return self._tables[key]
+        tab = self._tables[key]
+        if self.rel:
+            return tab[max_len - T: max_len - 1 + T]  # rows <-> rel = T-1 ... -(T-1)
+        return tab[:T]
 
     def _seed(self, site):
         return (self.seed * 1000003 + self.step_count * 4099 + site) & 0xFFFFFFFFFFFF
@@ -203,7 +217,7 @@ class CTCEngine:
         dev = xs.device
         xlens_host = [int(v) for v in xlens_host]
         elens_host = [((v - 1) // 2 - 1) // 2 for v in xlens_host]
-        elens = torch.tensor(elens_host, dtype=torch.int32).to(dev, non_blocking=True)
+        elens = h2d_i32(elens_host, dev)
         pre = "encoder.conv."
         C = d
         # ---- Conv2d subsampling (channels-last) -----------------------------------
@@ -332,17 +346,18 @@ class CTCEngine:
         labels = torch.as_tensor(ys_host)[:, :Lmax].to(torch.int32)
         if labels.shape[1] < Lmax:
             labels = torch.nn.functional.pad(labels, (0, Lmax - labels.shape[1]))
-        labels = labels.contiguous().to(dev, non_blocking=True)
-        ylens = torch.tensor(ylens_host, dtype=torch.int32).to(dev, non_blocking=True)
+        labels = h2d_i32(labels.contiguous(), dev)
+        ylens = h2d_i32(ylens_host, dev)
         lse = ops.row_lse(logits.view(B * T, V))
         lp, alpha, beta, nll = ops.ctc_forward(logits, lse, labels, elens, ylens, blank)
         loss = torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll)).sum() / B
         ctx = (logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll) if want_grad else None
         return loss, ctx
 
-    def ctc_grad(self, ctx, gscale):
+    def ctc_grad(self, ctx, gscale, gscale_dev=None):
         logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll = ctx
-        return ops.ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale / logits.shape[0])
+        return ops.ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale / logits.shape[0],
+                            gscale_dev)
 
     def greedy(self, logits, elens, blank):
         best, hyp, hyplen = ops.ctc_greedy(logits, elens, blank)
@@ -353,10 +368,10 @@ class CTCEngine:
         """gradients of y = x_in @ W^T + b given dy (already including any dropout mask);
         returns dx = alpha * dy @ W with the optional epilogue."""
         A = self.arena
-        ops.colsum(dy, out=A.g(bname), scale=alpha, accumulate=True)
         w = A.w(wname)
         w2 = w.view(w.shape[0], -1)
-        ops.gemm_tn(dy, x_in, out=A.g(wname, tuple(w2.shape)), alpha=alpha, accumulate=True)
+        ops.gemm_tn(dy, x_in, out=A.g(wname, tuple(w2.shape)), alpha=alpha, accumulate=True, colsum=A.g(bname),
+                    colsum_scale=alpha)
         return ops.gemm_nn(dy, w2, alpha=alpha, **epi)
 
     def _branch_grad(self, dx, scale, p, seed):
@@ -390,15 +405,19 @@ class CTCEngine:
             gbu, gbv = A.g(name + ".pos_bias_u").view(-1), A.g(name + ".pos_bias_v").view(-1)
         else:
             dpos = bu = bv = gbu = gbv = None
+        key = (B, H, T, T, qkv.dtype, pp is not None)
+        if self._attn_scratch is None or self._attn_scratch.key != key or self._attn_scratch_elens is not elens:
+            # zeroed once per step: every layer masks the same (key >= elens) entries
+            self._attn_scratch = ops.AttnScratch(B, H, T, T, qkv.dtype, qkv.device, pp is not None)
+            self._attn_scratch_elens = elens
         ops.attn_bwd(do.view(B, T, d), o, lse, q, k, v, H, scale, dq, dk, dv, pos=pp, bias_u=bu, bias_v=bv, klens=elens,
-                     drop_p=self.p_att, seed=s_att, dpos=dpos, dbias_u=gbu, dbias_v=gbv)
+                     drop_p=self.p_att, seed=s_att, dpos=dpos, dbias_u=gbu, dbias_v=gbv, scratch=self._attn_scratch)
         if pp is not None:
             dpos_t = dpos if self.dtype == torch.float32 else ops.strided_copy(dpos, out_dtype=self.dtype)
             ops.gemm_tn(dpos_t, pos_t, out=A.g(name + ".linear_pos.weight"), accumulate=True)
         dqkv2 = dqkv.view(B * T, 3 * d)
-        ops.colsum(dqkv2, out=A.g_span(name + ".linear_q.bias", name + ".linear_v.bias", (3 * d,)), accumulate=True)
         ops.gemm_tn(dqkv2, h, out=A.g_span(name + ".linear_q.weight", name + ".linear_v.weight", (3 * d, d)),
-                    accumulate=True)
+                    accumulate=True, colsum=A.g_span(name + ".linear_q.bias", name + ".linear_v.bias", (3 * d,)))
         wqkv = A.w_span(name + ".linear_q.weight", name + ".linear_v.weight", (3 * d, d))
         dh = ops.gemm_nn(dqkv2, wqkv)
         return ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
@@ -452,15 +471,14 @@ class CTCEngine:
         pre = "encoder.conv."
         C, F2 = d, st.F2
         dlin = ops.scale_dropout(dx, math.sqrt(d), self.p_enc, st.s_pe)
-        ops.colsum(dlin, out=A.g(pre + "output.bias"), accumulate=True)
         y2f = st.y2.view(M, F2 * C)
-        dwl = ops.gemm_tn(dlin, y2f)  # [d, F2*C]  (f, c) order
+        dwl = torch.zeros(d, F2 * C, device=dx.device, dtype=torch.float32)  # (f, c) order
+        ops.gemm_tn(dlin, y2f, out=dwl, accumulate=True, colsum=A.g(pre + "output.bias"))
         gwl = A.g(pre + "output.weight").view(d, C, F2)
         ops.strided_copy(dwl.view(d, F2, C).permute(0, 2, 1), out=gwl, accumulate=True)
         dy2 = ops.gemm_nn(dlin, st.wlr, dact_pre=y2f, dact=ACT_RELU).view(M * F2, C)
-        ops.colsum(dy2, out=A.g(pre + "conv.2.bias"), accumulate=True)
-        dw2 = torch.empty(C, 9 * C, device=dx.device, dtype=torch.float32)
-        ops.conv2_wgrad(dy2, st.y1, dw2)
+        dw2 = torch.zeros(C, 9 * C, device=dx.device, dtype=torch.float32)
+        ops.conv2_wgrad(dy2, st.y1, dw2, dbias=A.g(pre + "conv.2.bias"), accumulate=True)
         ops.strided_copy(dw2.view(C, 3, 3, C).permute(0, 3, 1, 2), out=A.g(pre + "conv.2.weight"), accumulate=True)
         dcol = ops.gemm_nn(dy2, st.w2r)
         dy1 = ops.conv2_col2im(dcol, st.y1)

@@ -31,7 +31,9 @@ class AttnArgs(Structure):
                 ("out", c_void_p), ("lse", c_void_p),
                 ("dout", c_void_p), ("delta", c_void_p),
                 ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
-                ("dpos", c_void_p), ("dbias_u", c_void_p), ("dbias_v", c_void_p)]
+                ("dpos", c_void_p), ("dbias_u", c_void_p), ("dbias_v", c_void_p),
+                ("pdT", c_void_p), ("dsT", c_void_p), ("dbd", c_void_p),
+                ("ldpd", c_long), ("ldbd", c_long), ("cs", c_void_p)]
 
 
 P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
@@ -40,22 +42,23 @@ P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
 SIGNATURES = {
     "emoasr_gemm_nt": [I, I, I, I, P, L, P, L, P, L, POINTER(Epilogue), P],
     "emoasr_gemm_nn": [I, I, I, I, P, L, P, L, P, L, POINTER(Epilogue), P],
-    "emoasr_gemm_tn": [I, I, I, I, P, L, P, L, P, L, F, I, P],
+    "emoasr_gemm_tn": [I, I, I, I, P, L, P, L, P, L, F, I, P, F, P],
+    "emoasr_gemm_nn_batched": [I, I, I, I, P, L, L, L, P, L, L, L, P, L, L, L, I, I, F, P],
     "emoasr_colsum": [I, I, I, P, L, P, F, I, P],
     "emoasr_conv1_fwd": [I, I, I, I, I, P, P, P, P, P],
     "emoasr_conv1_wgrad": [I, I, I, I, I, P, P, P, P, I, P],
     "emoasr_conv2_fwd": [I, I, I, I, I, P, P, P, POINTER(Epilogue), P],
-    "emoasr_conv2_wgrad": [I, I, I, I, I, P, P, P, I, P],
+    "emoasr_conv2_wgrad": [I, I, I, I, I, P, P, P, P, I, P],
     "emoasr_conv2_col2im": [I, I, I, I, I, P, P, P, P],
     "emoasr_layernorm_fwd": [I, I, I, P, P, P, F, P, P, P, P],
-    "emoasr_layernorm_bwd": [I, I, I, P, P, P, P, P, P, P, P, P, P],
+    "emoasr_layernorm_bwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     "emoasr_attn_fwd": [I, POINTER(AttnArgs), P],
     "emoasr_attn_bwd": [I, POINTER(AttnArgs), P],
     "emoasr_glu_fwd": [I, I, I, P, P, P],
     "emoasr_glu_bwd": [I, I, I, P, P, P, P],
     "emoasr_dwconv_fwd": [I, I, I, I, I, P, P, P, P, P],
     "emoasr_dwconv_bwd_x": [I, I, I, I, I, P, P, P, P],
-    "emoasr_dwconv_bwd_w": [I, I, I, I, I, P, P, P, P, I, P],
+    "emoasr_dwconv_bwd_w": [I, I, I, I, I, P, P, P, P, I, P, P],
     "emoasr_bn_stats": [I, I, I, P, P, P, P, P, F, P],
     "emoasr_bn_swish_fwd": [I, I, I, P, P, P, P, P, F, P, P],
     "emoasr_bn_swish_bwd": [I, I, I, P, P, P, P, P, P, F, P, P, P, P, P],
@@ -65,7 +68,7 @@ SIGNATURES = {
     "emoasr_add": [I, L, P, P, P, P],
     "emoasr_row_lse": [I, I, I, P, L, P, P],
     "emoasr_ctc_forward": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, P],
-    "emoasr_ctc_grad": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, F, P, L, P],
+    "emoasr_ctc_grad": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, F, P, P, L, P],
     "emoasr_ctc_greedy": [I, I, I, I, P, L, P, I, P, P, P, P],
     "emoasr_sqnorm": [L, P, P, P],
     "emoasr_adam_step": [L, P, P, P, P, F, F, F, F, F, I, P, F, F, P],

@@ -65,7 +65,8 @@ class _CTCLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _):
         eng = ctx.eng
-        dlogits = eng.ctc_grad(ctx.cctx, float(gloss))
+        gdev = gloss.to(torch.float32).reshape(1) if gloss.is_cuda else None  # no host sync
+        dlogits = eng.ctc_grad(ctx.cctx, 1.0 if gdev is not None else float(gloss), gdev)
         deouts = eng.head_backward(ctx.eouts, dlogits)
         ctx.cctx = None
         return (None, deouts, None, None, None, None) + (None,) * len(eng.arena.params)

@@ -90,8 +90,9 @@ def gemm_nn(a, b, out=None, **epi):
     return out
 
 
-def gemm_tn(a, b, out=None, alpha=1.0, accumulate=False):
-    """out[N1,N2] (+)= alpha * a[K,N1]^T @ b[K,N2]  (f32 out)"""
+def gemm_tn(a, b, out=None, alpha=1.0, accumulate=False, colsum=None, colsum_scale=1.0):
+    """out[N1,N2] (+)= alpha * a[K,N1]^T @ b[K,N2]  (f32 out);
+    colsum[N1] (+)= colsum_scale * a.sum(0) (fused bias gradient)"""
     K, N1, lda = _rows(_chk(a))
     Kb, N2, ldb = _rows(_chk(b, a.dtype))
     assert K == Kb
@@ -100,7 +101,15 @@ def gemm_tn(a, b, out=None, alpha=1.0, accumulate=False):
         out = torch.empty(N1, N2, device=a.device, dtype=torch.float32)
     _chk(out, torch.float32)
     lib.call("emoasr_gemm_tn", dt(a), N1, N2, K, _p(a), lda, _p(b), ldb, _p(out), out.stride(0), alpha,
-             int(accumulate), _stream())
+             int(accumulate), _p(colsum), colsum_scale, _stream())
+    return out
+
+
+def gemm_nn_batched(a, b, out, M, N, K, lda, sa, ldb, sb, ldc, sc, nb, nh, alpha=1.0):
+    """out[b,h] = alpha * a[b,h] (M x K, k-contiguous) @ b[b,h] (K x N, k-major); s* = (outer, inner)
+    batch strides in elements; base pointers are the tensors' data pointers."""
+    lib.call("emoasr_gemm_nn_batched", dt(a), M, N, K, _p(a), lda, sa[0], sa[1], _p(b), ldb, sb[0], sb[1],
+             _p(out), ldc, sc[0], sc[1], nb, nh, alpha, _stream())
     return out
 
 
@@ -141,10 +150,10 @@ def conv2_fwd(y1, w, **epi):
     return y2
 
 
-def conv2_wgrad(dy2, y1, dw, accumulate=False):
+def conv2_wgrad(dy2, y1, dw, dbias=None, accumulate=False):
     B, T1, F1, C = y1.shape
     lib.call("emoasr_conv2_wgrad", dt(y1), B, T1, F1, C, _p(dy2), _p(y1), _p(_chk(dw, torch.float32)),
-             int(accumulate), _stream())
+             _p(dbias), int(accumulate), _stream())
 
 
 def conv2_col2im(dcol, y1):
@@ -169,8 +178,11 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats=True):
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
     M, N, ld = _rows(_chk(x))
     dx = torch.empty_like(x)
+    scratch = None
+    if dgamma is not None or dbeta is not None:
+        scratch = torch.empty(512 * 2 * N, device=x.device, dtype=torch.float32)
     lib.call("emoasr_layernorm_bwd", dt(x), M, N, _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
-             _p(dgamma), _p(dbeta), _stream())
+             _p(dgamma), _p(dbeta), _p(scratch), _stream())
     return dx
 
 
@@ -206,9 +218,26 @@ def attn_fwd(q, k, v, H, scale, pos=None, bias_u=None, bias_v=None, klens=None, 
     return out, lse
 
 
+class AttnScratch:
+    """Zero-initialised HBM scratch of the materialised attention backward (P^T, dS^T, dBD band).
+    Reusable across calls that share (B, H, Tq, Tk, klens) -- e.g. all layers of one step."""
+
+    def __init__(self, B, H, Tq, Tk, dtype, device, rel):
+        self.key = (B, H, Tq, Tk, dtype, rel)
+        self.ldpd = (Tq + 7) // 8 * 8
+        self.ldbd = (2 * Tq - 1 + 7) // 8 * 8
+        self.pdT = torch.zeros(B, H, Tk, self.ldpd, device=device, dtype=dtype)
+        self.dsT = torch.zeros(B, H, Tk, self.ldpd, device=device, dtype=dtype)
+        self.dbd = torch.zeros(H, B, Tq, self.ldbd, device=device, dtype=dtype) if rel else None
+        self.cs = torch.empty(H, self.ldbd, device=device, dtype=torch.float32) if rel else None
+
+
 def attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=None, bias_u=None, bias_v=None, klens=None,
-             causal=False, drop_p=0.0, seed=0, dpos=None, dbias_u=None, dbias_v=None):
-    """dq/dk/dv are written (same strides as q/k/v); dpos/dbias_* are accumulated into."""
+             causal=False, drop_p=0.0, seed=0, dpos=None, dbias_u=None, dbias_v=None, scratch=None,
+             materialise=True):
+    """dq/dk/dv are written (same strides as q/k/v); dpos/dbias_* are accumulated into.
+    materialise=True: dV/dK/dpos through batched GEMMs over stored P^T/dS^T (scratch is allocated
+    here unless an AttnScratch for this shape/mask is passed); False: score-recompute kernels."""
     B, Tq, D = q.shape
     a = _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, seed)
     assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
@@ -220,6 +249,14 @@ def attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=None, bias_u=Non
     a.dpos = None if dpos is None else dpos.data_ptr()
     a.dbias_u = None if dbias_u is None else dbias_u.data_ptr()
     a.dbias_v = None if dbias_v is None else dbias_v.data_ptr()
+    if materialise:
+        rel = pos is not None
+        if scratch is None:
+            scratch = AttnScratch(B, H, Tq, k.shape[1], q.dtype, q.device, rel)
+        assert scratch.key == (B, H, Tq, k.shape[1], q.dtype, rel), "AttnScratch built for another shape"
+        a.pdT, a.dsT, a.ldpd = scratch.pdT.data_ptr(), scratch.dsT.data_ptr(), scratch.ldpd
+        if rel:
+            a.dbd, a.ldbd, a.cs = scratch.dbd.data_ptr(), scratch.ldbd, scratch.cs.data_ptr()
     lib.call("emoasr_attn_bwd", dt(q), byref(a), _stream())
 
 
@@ -254,8 +291,10 @@ def dwconv_bwd_x(dy, w):
 
 def dwconv_bwd_w(dy, x, dw, dbias, accumulate=False):
     B, T, C = dy.shape
-    lib.call("emoasr_dwconv_bwd_w", dt(dy), B, T, C, dw.shape[-1], _p(dy), _p(x), _p(dw), _p(dbias),
-             int(accumulate), _stream())
+    K = dw.shape[-1]
+    scratch = torch.empty(B * ((T + 31) // 32) * (K + 1) * C, device=dy.device, dtype=torch.float32)
+    lib.call("emoasr_dwconv_bwd_w", dt(dy), B, T, C, K, _p(dy), _p(x), _p(dw), _p(dbias),
+             int(accumulate), _p(scratch), _stream())
 
 
 def bn_stats(y, running_mean=None, running_var=None, momentum=0.1):
@@ -340,11 +379,12 @@ def ctc_forward(logits, lse, labels, elens, ylens, blank):
     return lp, alpha, beta, nll
 
 
-def ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale):
+def ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale, gscale_dev=None):
     B, T, V = logits.shape
     grad = torch.empty_like(logits)
     lib.call("emoasr_ctc_grad", dt(logits), B, T, V, labels.shape[1], _p(logits), logits.stride(1), _p(lse),
-             _p(labels), _p(elens), _p(ylens), blank, _p(lp), _p(alpha), _p(beta), _p(nll), gscale, _p(grad),
+             _p(labels), _p(elens), _p(ylens), blank, _p(lp), _p(alpha), _p(beta), _p(nll), gscale, _p(gscale_dev),
+             _p(grad),
              grad.stride(1), _stream())
     return grad
 

@@ -64,10 +64,17 @@ int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, cons
  * gradient dX = dY . W of the calls above, straight from the [out,in] weight. */
 int emoasr_gemm_nn(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                    void* C, long ldc, const emoasr_epilogue_t* ep, void* stream);
+/* batched form: C[b,h] = alpha * A[b,h] . B[b,h]; s*_b / s*_h are the outer / inner batch strides
+ * (elements).  Attention backward: dV[b,h] = Pd[b,h] . dO[b,h], dK[b,h] = dS[b,h] . Q[b,h]. */
+int emoasr_gemm_nn_batched(int dtype, int M, int N, int K, const void* A, long lda, long sa_b, long sa_h,
+                           const void* B, long ldb, long sb_b, long sb_h, void* C, long ldc, long sc_b,
+                           long sc_h, int nb, int nh, float alpha, void* stream);
 /* C[N1,N2] (+)= alpha * A[K,N1]^T . B[K,N2], f32 output (weight gradients; the
- * autograd backward of the calls above). */
+ * autograd backward of the calls above).  If colsum != NULL the kernel also produces
+ * colsum[N1] (+)= colsum_scale * sum_k A[k,:] (the bias gradient) from the staged A tiles. */
 int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, long lda, const void* B, long ldb,
-                   float* C, long ldc, float alpha, int accumulate, void* stream);
+                   float* C, long ldc, float alpha, int accumulate, float* colsum, float colsum_scale,
+                   void* stream);
 /* out[N] (+)= scale * sum_rows X[M,N]   (bias gradients) */
 int emoasr_colsum(int dtype, int M, int N, const void* X, long ldx, float* out, float scale,
                   int accumulate, void* stream);
@@ -83,8 +90,9 @@ int emoasr_conv1_wgrad(int dtype, int B, int T, int F, int C, const float* x, co
 /* y2[(b,t2,f2), n] = epilogue(sum y1[b,2t2+kh,2f2+kw,c] * w[n,(kh,kw,c)])  (implicit GEMM) */
 int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const void* y1, const void* w, void* y2,
                      const emoasr_epilogue_t* ep, void* stream);
+/* dw[n,(kh,kw,c)] (+)= dy2^T . im2col(y1);  dbias[n] (+)= sum dy2 (may be NULL) */
 int emoasr_conv2_wgrad(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* y1,
-                       float* dw, int accumulate, void* stream);
+                       float* dw, float* dbias, int accumulate, void* stream);
 /* dy1[b,t1,f1,c] = relu'(y1) * sum_{kh,kw} dcol[(b,t2,f2),(kh,kw,c)]  (col2im gather) */
 int emoasr_conv2_col2im(int dtype, int B, int T1, int F1, int C, const void* dcol, const void* y1,
                         void* dy1, void* stream);
@@ -93,10 +101,12 @@ int emoasr_conv2_col2im(int dtype, int B, int T1, int F1, int C, const void* dco
  * encoders/transformer.py:73, transformer.py:140-141,178-180) ------------------ */
 int emoasr_layernorm_fwd(int dtype, int M, int N, const void* x, const float* gamma, const float* beta,
                          float eps, void* y, float* mean, float* rstd, void* stream);
-/* dx = dres + LN'(dy); dgamma/dbeta (+)= ; dres may be NULL */
+/* dx = dres + LN'(dy); dgamma/dbeta (+)= ; dres may be NULL.  scratch: f32 workspace of
+ * emoasr_layernorm_bwd_scratch_floats(N) floats (per-block partial sums; NULL if no dgamma/dbeta) */
 int emoasr_layernorm_bwd(int dtype, int M, int N, const void* dy, const void* x, const float* gamma,
                          const float* mean, const float* rstd, const void* dres, void* dx,
-                         float* dgamma, float* dbeta, void* stream);
+                         float* dgamma, float* dbeta, float* scratch, void* stream);
+int emoasr_layernorm_bwd_scratch_floats(int N);
 
 /* ---- attention (transformer.py:48-99, conformer.py:57-95) -------------------
  * q:[B,Tq,H*DK] k,v:[B,Tk,H*DK] with row strides ldq/ldk/ldv (elements), out [B,Tq,H*DK].
@@ -123,6 +133,17 @@ typedef struct {
   void *dq, *dk, *dv; /* T, same strides as q/k/v */
   float *dpos;        /* f32 [2*Tq-1, H*DK], accumulated */
   float *dbias_u, *dbias_v; /* f32 [H*DK], accumulated */
+  /* optional backward scratch ("materialised" mode): when pdT != NULL the dq kernel stores the
+   * dropped probabilities P^T and dS^T (and the un-shifted dBD band) once, and dV / dK / dpos are
+   * computed by batched GEMMs over them instead of recomputing the scores three more times.
+   * All three must be zero-filled by the caller before the first use for a given
+   * (B, Tq, Tk, klens) and may then be reused by later calls with the same masks (the set of
+   * never-written entries does not change).  Row strides ldpd >= Tq, ldbd >= 2*Tq-1, both
+   * multiples of 8 elements. */
+  void *pdT, *dsT;    /* T [B,H,Tk,ldpd] */
+  void *dbd;          /* T [H,B,Tq,ldbd]; NULL without relative positions */
+  long ldpd, ldbd;
+  float* cs;          /* f32 [H, ldbd] scratch */
 } emoasr_attn_t;
 int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream);
 int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream);
@@ -136,8 +157,10 @@ int emoasr_dwconv_fwd(int dtype, int B, int T, int C, int K, const void* x, cons
                       const float* bias, void* y, void* stream);
 int emoasr_dwconv_bwd_x(int dtype, int B, int T, int C, int K, const void* dy, const float* w, void* dx,
                         void* stream);
+/* scratch: emoasr_dwconv_bwd_w_scratch_floats(B,T,C,K) floats of per-block partial sums */
 int emoasr_dwconv_bwd_w(int dtype, int B, int T, int C, int K, const void* dy, const void* x, float* dw,
-                        float* dbias, int accumulate, void* stream);
+                        float* dbias, int accumulate, float* scratch, void* stream);
+long emoasr_dwconv_bwd_w_scratch_floats(int B, int T, int C, int K);
 /* BatchNorm1d batch statistics over all M=B*T rows (padding included, as the reference):
  * mean[C], var[C] (biased); if running_* != NULL they are updated with `momentum`
  * (unbiased variance), exactly like nn.BatchNorm1d in training mode. */
@@ -175,12 +198,13 @@ int emoasr_row_lse(int dtype, int M, int V, const void* logits, long ld, float* 
 int emoasr_ctc_forward(int dtype, int B, int T, int V, int Lmax, const void* logits, long ld,
                        const float* lse, const int* labels, const int* elens, const int* ylens, int blank,
                        float* lp, float* alpha, float* beta, float* nll, void* stream);
-/* grad[b,t,v] = gscale * (softmax - occupancy) for t < elens[b]; 0 elsewhere and for
+/* gscale_dev (device, 1 float, may be NULL) multiplies gscale without a host sync.
+ * grad[b,t,v] = gscale * (softmax - occupancy) for t < elens[b]; 0 elsewhere and for
  * utterances with nll = inf (zero_infinity=True). */
 int emoasr_ctc_grad(int dtype, int B, int T, int V, int Lmax, const void* logits, long ld,
                     const float* lse, const int* labels, const int* elens, const int* ylens, int blank,
                     const float* lp, const float* alpha, const float* beta, const float* nll,
-                    float gscale, void* grad, long ldg, void* stream);
+                    float gscale, const float* gscale_dev, void* grad, long ldg, void* stream);
 /* greedy: best[b,t] = argmax_v logits (first max wins); hyp[b,:hyplen[b]] = collapse
  * repeats then drop blank, over t < elens[b] */
 int emoasr_ctc_greedy(int dtype, int B, int T, int V, const void* logits, long ld, const int* elens,

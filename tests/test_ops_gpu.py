@@ -106,10 +106,32 @@ def test_gemm_tn(dev, dtype, tr_mode, K, N1, N2):
     from emoasr_amd import ops
     a, b = _rnd(dev, K, N1, dtype=dtype), _rnd(dev, K, N2, dtype=dtype, scale=K ** -0.5)
     ref = a.float().t() @ b.float()
-    out = ops.gemm_tn(a, b, alpha=0.5)
+    cs = torch.empty(N1, device=dev)
+    out = ops.gemm_tn(a, b, alpha=0.5, colsum=cs, colsum_scale=2.0)
     _close(out, 0.5 * ref, _tol(dtype), f"gemm_tn {K}x{N1}x{N2}")
-    ops.gemm_tn(a, b, out=out, alpha=1.0, accumulate=True)
+    _close(cs, 2.0 * a.float().sum(0), 1e-4, "fused colsum")
+    ops.gemm_tn(a, b, out=out, alpha=1.0, accumulate=True, colsum=cs, colsum_scale=1.0)
     _close(out, 1.5 * ref, _tol(dtype), "gemm_tn accumulate")
+    _close(cs, 3.0 * a.float().sum(0), 1e-4, "fused colsum accumulate")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_gemm_nn(dev, dtype, tr_mode):
+    from emoasr_amd import ops
+    for M, N, K in [(300, 256, 1024), (1000, 1024, 256), (77, 2304, 256), (130, 4864, 256), (64, 64, 32)]:
+        a, b = _rnd(dev, M, K, dtype=dtype), _rnd(dev, K, N, dtype=dtype, scale=K ** -0.5)
+        _close(ops.gemm_nn(a, b, alpha=0.5), 0.5 * (a.float() @ b.float()), _tol(dtype), f"gemm_nn {M}x{N}x{K}")
+    # batched, ragged K with zero-padded rows (the attention-backward use)
+    nb, nh, Mr, Kr, N = 2, 3, 45, 37, 64
+    lda = 40
+    a = torch.zeros(nb, nh, Mr, lda, device=dev, dtype=dtype)
+    a[..., :Kr] = _rnd(dev, nb, nh, Mr, Kr, dtype=dtype)
+    b = _rnd(dev, nb, Kr, nh * N, dtype=dtype)
+    out = torch.zeros(nb, Mr, nh * N, device=dev, dtype=dtype)
+    ops.gemm_nn_batched(a, b, out, Mr, N, Kr, lda, (nh * Mr * lda, Mr * lda), nh * N, (Kr * nh * N, N), nh * N,
+                        (Mr * nh * N, N), nb, nh)
+    ref = torch.einsum("bhmk,bkhn->bmhn", a[..., :Kr].float(), b.float().view(nb, Kr, nh, N)).reshape(nb, Mr, nh * N)
+    _close(out, ref, _tol(dtype), "gemm_nn_batched")
 
 
 def test_colsum(dev):
@@ -151,9 +173,9 @@ def test_frontend(dev, dtype, tr_mode):
     T2, F2 = y2.shape[1], y2.shape[2]
     dy2 = (g.permute(0, 2, 3, 1) * (y2_ref.permute(0, 2, 3, 1) > 0)).contiguous().to(dtype)
     dw2 = torch.empty(C, 9 * C, device=dev)
-    ops.conv2_wgrad(dy2, y1, dw2)
+    db2 = torch.empty(C, device=dev)
+    ops.conv2_wgrad(dy2, y1, dw2, dbias=db2)
     _close(dw2, _conv2_weight_repack(w2r.grad), _tol(dtype, 1e-4, 3e-2), "conv2 wgrad")
-    db2 = ops.colsum(dy2.reshape(-1, C))
     _close(db2, b2r.grad, _tol(dtype, 1e-4, 3e-2), "conv2 bgrad")
     w2pt = w2p.t().contiguous()  # [(kh,kw,c), n]
     dcol = ops.gemm_nt(dy2.reshape(-1, C), w2pt)
@@ -224,7 +246,8 @@ def _attn_ref(q, k, v, H, scale, pos, bu, bv, klens, causal):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", ["rel", "rel_long", "plain_mask", "causal", "cross"])
-def test_attention(dev, dtype, tr_mode, case):
+@pytest.mark.parametrize("mat", [True, False], ids=["gemmbwd", "recompute"])
+def test_attention(dev, dtype, tr_mode, case, mat):
     from emoasr_amd import ops
     H, dk = 4, 64
     D = H * dk
@@ -262,7 +285,7 @@ def test_attention(dev, dtype, tr_mode, case):
     dbu = torch.zeros(D, device=dev) if rel else None
     dbv = torch.zeros(D, device=dev) if rel else None
     ops.attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk_, dv, pos=pos, bias_u=bu, bias_v=bv, klens=klens,
-                 causal=causal, dpos=dpos, dbias_u=dbu, dbias_v=dbv)
+                 causal=causal, dpos=dpos, dbias_u=dbu, dbias_v=dbv, materialise=mat)
     btol = _tol(dtype, 1e-4, 4e-2)
     _close(dq, leaves[0].grad, btol, f"attn dq {case}")
     _close(dk_, leaves[1].grad, btol, f"attn dk {case}")

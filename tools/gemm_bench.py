@@ -1,0 +1,43 @@
+"""Micro-benchmark of the GEMM entry points on the L2 model's shapes (B*T' = 7200 rows)."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from emoasr_amd import ops
+
+dev = torch.device("cuda:0")
+M = int(os.environ.get("M", 7200))
+dt = torch.bfloat16
+shapes_nt = [("ffn1", M, 1024, 256), ("ffn2", M, 256, 1024), ("qkv", M, 768, 256), ("out", M, 256, 256),
+             ("pw1", M, 512, 256), ("head", M, 10000, 256), ("lin", M, 256, 4864)]
+shapes_nn = [("d_ffn2", M, 1024, 256), ("d_ffn1", M, 256, 1024), ("d_qkv", M, 256, 768), ("d_out", M, 256, 256),
+             ("d_head", M, 256, 10000), ("d_lin", M, 4864, 256), ("dcol", M * 19, 2304, 256)]
+shapes_tn = [("w_ffn1", 1024, 256, M), ("w_ffn2", 256, 1024, M), ("w_qkv", 768, 256, M), ("w_out", 256, 256, M),
+             ("w_head", 10000, 256, M), ("w_lin", 256, 4864, M)]
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3  # us
+
+def rnd(*s): return torch.randn(*s, device=dev).to(dt)
+tot = 0.0
+for name, m, n, k in shapes_nt:
+    a, b = rnd(m, k), rnd(n, k); out = torch.empty(m, n, device=dev, dtype=dt); bias = torch.randn(n, device=dev)
+    us = timeit(lambda: ops.gemm_nt(a, b, out=out, bias=bias))
+    tot += us
+    print(f"nt {name:8s} {m}x{n}x{k}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TF/s  {(m*k+n*k+m*n)*2/us/1e3:7.1f} GB/s")
+for name, m, n, k in shapes_nn:
+    a, b = rnd(m, k), rnd(k, n); out = torch.empty(m, n, device=dev, dtype=dt)
+    us = timeit(lambda: ops.gemm_nn(a, b, out=out))
+    tot += us
+    print(f"nn {name:8s} {m}x{n}x{k}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TF/s  {(m*k+n*k+m*n)*2/us/1e3:7.1f} GB/s")
+for name, n1, n2, k in shapes_tn:
+    a, b = rnd(k, n1), rnd(k, n2); out = torch.zeros(n1, n2, device=dev); cs = torch.zeros(n1, device=dev)
+    us = timeit(lambda: ops.gemm_tn(a, b, out=out, accumulate=True, colsum=cs))
+    tot += us
+    print(f"tn {name:8s} {n1}x{n2}x{k}: {us:8.1f} us  {2*n1*n2*k/us/1e6:7.1f} TF/s")
+print(f"sum {tot:.1f} us")
