@@ -9,11 +9,18 @@ process per GPU, loss = mean of per-replica batch-mean losses => all-reduce(sum)
 """
 import torch
 
-from . import ops
 
 
 def noam_lr(base_lr, d_model, warmup, step):
     return base_lr * d_model ** (-0.5) * min(step ** (-0.5), step * warmup ** (-1.5))
+
+
+def allreduce_sum_(flat, group=None):
+    """one collective per optimizer step: sum the flat gradient buffer over the data-parallel ranks
+    (backend nccl = RCCL over xGMI on the GPU box; gloo in the CPU tests)"""
+    import torch.distributed as dist
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
 
 
 class ArenaAdam:
@@ -31,14 +38,14 @@ class ArenaAdam:
         self.arena.grad.zero_()
 
     def allreduce(self, group=None):
-        import torch.distributed as dist
-        dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM, group=group)
+        allreduce_sum_(self.arena.grad, group)
 
     def step(self, grad_mult=1.0):
         """grad_mult: 1/world_size after a sum all-reduce (and/or 1/accum if not folded in the loss)."""
         self._step += 1
         self.lr = self.lr_fn(self._step)
         self.nsq.zero_()
+        from . import ops
         ops.sqnorm(self.arena.grad, self.nsq)
         ops.adam_step(self.arena.flat, self.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
                       self.eps, self.wd, self._step, gnorm_sq=self.nsq, clip=self.clip, grad_mult=grad_mult)
