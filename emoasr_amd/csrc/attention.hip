@@ -274,6 +274,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const emoasr_attn_t a) {
     f32x16 s;
     score_tile<T, true>(s, a, hp, i0, j0, qu, qv, nullptr, Gs, lane);
     stage_rows<T, 32>(Vs, (const T*)hp.v, a.ldv, j0, 0, a.Tk, lane, nullptr);
+    if (a.st && qval) {  // keep the scaled scores for the backward pass (32 queries contiguous per key row)
+      float* srow = a.st + (((long)b * a.H + h) * a.Tk + j0) * a.ldst + qi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = c_row(r, lane);
+        if (j0 + kl < a.Tk) srow[(long)kl * a.ldst] = s[r] * a.scale;
+      }
+    }
     float mt = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -334,38 +342,70 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const emoasr_attn_t a) 
 // ====================================================================================
 // backward: dq (+ dbias_u, dbias_v).  Swapped tiles like the forward.
 // ====================================================================================
-template <typename T, bool TR>
+constexpr int DQ_GS_FLOATS = 2176;  // >= 64*32 (score skew tile) and 2*32*33 (dS / P images)
+
+template <typename T>
+__device__ __forceinline__ void store_vec8(T* p, const float (&o)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)o[e];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  } else {
+    *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
+  }
+}
+
+// STORED: the forward kept the scaled scores S^T (a.st); no score recomputation here and the
+// (q+v) part of dq is left to a batched GEMM over the dBD band this kernel stores.
+template <typename T, bool TR, bool STORED>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const emoasr_attn_t a) {
   using M_ = Mma<T>;
   constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = AttnCfg<T>::LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;  // one query tile per block; the 4 waves split the key tiles
   if (i0 >= a.Tq) return;
-  constexpr int WAVE_BYTES = 64 * 32 * 4 + 96 * LD * (int)sizeof(T);
+  constexpr int PD_OFF = 32 * 33;              // second [32][33] f32 tile (dropped probabilities)
+  constexpr int WAVE_BYTES = DQ_GS_FLOATS * 4 + 96 * LD * (int)sizeof(T);
   float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
-  T* Ks = reinterpret_cast<T*>(smem + wave * WAVE_BYTES + 64 * 32 * 4);  // [32][LD]
-  T* Bs = Ks + 32 * LD;                                                   // [64][LD] band rows
+  T* Ks = reinterpret_cast<T*>(smem + wave * WAVE_BYTES + DQ_GS_FLOATS * 4);  // [32][LD]
+  T* Bs = Ks + 32 * LD;                                                        // [64][LD] band rows
 
   const HeadPtrs hp = head_ptrs<T>(a, b, h);
   const int qi = i0 + (lane & 31);
   const bool qval = qi < a.Tq;
-  typename M_::Frag qu[NK], qv[NK], dof[NK];
+  typename M_::Frag qu[STORED ? 1 : NK], qv[STORED ? 1 : NK], dof[NK];
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) {
-    qu[kk] = frag_global<T>((const T*)hp.q, a.ldq, qi, qval, kk, lane, hp.bias_u);
-    qv[kk] = hp.pos ? frag_global<T>((const T*)hp.q, a.ldq, qi, qval, kk, lane, hp.bias_v) : qu[kk];
+    if constexpr (!STORED) {
+      qu[kk] = frag_global<T>((const T*)hp.q, a.ldq, qi, qval, kk, lane, hp.bias_u);
+      qv[kk] = hp.pos ? frag_global<T>((const T*)hp.q, a.ldq, qi, qval, kk, lane, hp.bias_v) : qu[kk];
+    }
     dof[kk] = frag_global<T>((const T*)hp.dout, a.ldo, qi, qval, kk, lane, nullptr);
   }
   const float lse_q = qval ? hp.lse[qi] : -INFINITY;
   const float del_q = qval ? hp.delta[qi] : 0.f;
+  const uint64_t drop_base = drop_index(a, b, h, qi, 0);
   f32x16 dqu[2], dqv[2];
   zero16(dqu[0]); zero16(dqu[1]); zero16(dqv[0]); zero16(dqv[1]);
   int kend = hp.klen;
   if (a.causal) kend = min(kend, i0 + 32);
-  for (int j0 = 0; j0 < kend; j0 += 32) {
+  for (int j0 = wave * 32; j0 < kend; j0 += 128) {
     f32x16 s;
-    score_tile<T, true>(s, a, hp, i0, j0, qu, qv, nullptr, Gs, lane);
+    if constexpr (STORED) {
+      const float* srow = a.st + (((long)b * a.H + h) * a.Tk + j0) * a.ldst + qi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = c_row(r, lane);
+        s[r] = (qval && j0 + kl < a.Tk) ? srow[(long)kl * a.ldst] : 0.f;
+      }
+    } else {
+      score_tile<T, true>(s, a, hp, i0, j0, qu, qv, nullptr, Gs, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] *= a.scale;
+    }
     // dP^T = V . dO^T   (rows keys, cols queries)
     f32x16 dp;
     zero16(dp);
@@ -381,34 +421,50 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const emoasr_attn_t a)
     for (int r = 0; r < 16; ++r) {
       const int kj = j0 + c_row(r, lane);
       const bool masked = kj >= hp.klen || (a.causal && kj > qi) || lse_q == -INFINITY;
-      const float p = masked ? 0.f : __expf(s[r] * a.scale - lse_q);
+      const float p = masked ? 0.f : __expf(s[r] - lse_q);
       float dpr = dp[r];
       float dsc = 1.f;
-      if (a.drop_p > 0.f) dsc = dropout_scale(a.seed, drop_index(a, b, h, qi, kj), a.drop_p);
+      if (a.drop_p > 0.f) dsc = dropout_scale(a.seed, drop_base + (uint64_t)kj, a.drop_p);
       dpr *= dsc;
       ds[r] = p * (dpr - del_q) * a.scale;
-      // materialised mode: P^T (after dropout) and dS^T go to HBM once; dV, dK and dpos are then
-      // plain (batched) GEMMs over them instead of three more score recomputations.
-      if (a.pdT && qval && kj < a.Tk) {
-        const long o = (((long)b * a.H + h) * a.Tk + kj) * a.ldpd + qi;
-        ((T*)a.pdT)[o] = from_f32<T>(p * dsc);
-        ((T*)a.dsT)[o] = from_f32<T>(ds[r]);
-      }
+      // tiles go through wave-private LDS ([key][query], stride 33): the same image feeds the
+      // 16-byte row stores below and the band un-skew further down
+      Gs[c_row(r, lane) * 33 + (lane & 31)] = ds[r];
+      Gs[PD_OFF + c_row(r, lane) * 33 + (lane & 31)] = p * dsc;
     }
     // dQu^T += K^T . dS^T
     stage_rows<T, 32>(Ks, (const T*)hp.k, a.ldk, j0, 0, a.Tk, lane, nullptr);
     __builtin_amdgcn_wave_barrier();
+    if (a.pdT) {
+      // materialised mode: P^T (after dropout) and dS^T go to HBM once, as whole 16-query row pieces;
+      // dV, dK and dpos are then (batched) GEMMs over them instead of more score recomputations.
+      const int kl = lane >> 1, c0 = (lane & 1) * 16;
+      if (j0 + kl < a.Tk) {
+        const long o = (((long)b * a.H + h) * a.Tk + j0 + kl) * a.ldpd + i0 + c0;
+#pragma unroll
+        for (int g8 = 0; g8 < 2; ++g8) {
+          if (i0 + c0 + 8 * g8 < a.ldpd) {  // padded columns may hold anything (never multiplied in)
+            float vd[8], vp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              vd[e] = Gs[kl * 33 + c0 + 8 * g8 + e];
+              vp[e] = Gs[PD_OFF + kl * 33 + c0 + 8 * g8 + e];
+            }
+            store_vec8<T>((T*)a.dsT + o + 8 * g8, vd);
+            store_vec8<T>((T*)a.pdT + o + 8 * g8, vp);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int ks = 0; ks < NS; ++ks)
         dqu[dt] = M_::mma(chain_a<T, TR>(Ks, ks, 32 * dt, lane), chain_b<T>(ds, ks), dqu[dt]);
     if (hp.pos) {
-      // un-skew dS^T into the band: dG^T[c][i] = dS^T[c - 31 + i][i]
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Gs[c_row(r, lane) * 33 + (lane & 31)] = ds[r];
+      // un-skew dS^T (already in Gs, [key][query] stride 33) into the band: dG^T[c][i] = dS^T[c - 31 + i][i]
       const int rbase = a.Tq - 32 - i0 + j0;
-      stage_rows<T, 64>(Bs, (const T*)hp.pos, a.ldp, rbase, 0, 2 * a.Tq - 1, lane, nullptr);
+      if constexpr (!STORED) stage_rows<T, 64>(Bs, (const T*)hp.pos, a.ldp, rbase, 0, 2 * a.Tq - 1, lane, nullptr);
       __builtin_amdgcn_wave_barrier();
       if (a.dbd) {
         // dBD[h, b, i, r] (r = table row, contiguous): lane <-> band column c, one query row per
@@ -423,6 +479,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const emoasr_attn_t a)
             drow[(long)il * a.ldbd + row] = from_f32<T>(Gs[key * 33 + il]);
         }
       }
+      if constexpr (!STORED)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         f32x16 dg;
@@ -440,6 +497,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const emoasr_attn_t a)
     }
     __builtin_amdgcn_wave_barrier();
   }
+  // fold the four waves' partial dQu / dQv (each saw a quarter of the key tiles) through LDS; the
+  // wave-private staging regions are free now
+  {
+    float* mine = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        mine[((dt * 16 + r) * 2 + 0) * 64 + lane] = dqu[dt][r];
+        mine[((dt * 16 + r) * 2 + 1) * 64 + lane] = dqv[dt][r];
+      }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float* other = reinterpret_cast<const float*>(smem + w * WAVE_BYTES);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dqu[dt][r] += other[((dt * 16 + r) * 2 + 0) * 64 + lane];
+          dqv[dt][r] += other[((dt * 16 + r) * 2 + 1) * 64 + lane];
+        }
+    }
+  }
   // bias gradients: sum over the 32 queries of this tile (lanes within each half)
   if (a.dbias_u || a.dbias_v) {
 #pragma unroll
@@ -452,11 +535,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const emoasr_attn_t a)
         if ((lane & 31) == 0) {
           const int d = h * DK + 32 * dt + c_row(r, lane);
           if (a.dbias_u) atomicAdd(&a.dbias_u[d], su);
-          if (a.dbias_v && hp.pos) atomicAdd(&a.dbias_v[d], sv);
+          if (!STORED && a.dbias_v && hp.pos) atomicAdd(&a.dbias_v[d], sv);
         }
       }
   }
-  if (hp.pos) {
+  if (!STORED && hp.pos) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -666,6 +749,18 @@ __global__ __launch_bounds__(256) void attn_dpos_bias_kernel(const emoasr_attn_t
   a.dpos[i] += a.cs[(long)(col / DK) * a.ldbd + r] * a.bias_v[col];
 }
 
+// dbias_v[h*64+d] += sum_r cs[h, r] * pos[r, h*64+d]   (cs = column sums of dBD_h)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_dbias_v_kernel(const emoasr_attn_t a) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= a.H * DK) return;
+  const float* cs = a.cs + (long)(col / DK) * a.ldbd;
+  const T* pos = (const T*)a.pos + col;
+  float s = 0.f;
+  for (int r = 0; r < 2 * a.Tq - 1; ++r) s += cs[r] * to_f32(pos[(long)r * a.ldp]);
+  a.dbias_v[col] += s;
+}
+
 template <typename K>
 int set_smem(K kernel, int bytes) {
   if (bytes > 64 * 1024) {
@@ -709,10 +804,15 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
   const long rows = (long)a.B * a.Tq * a.H;
   attn_delta_kernel<T><<<cdiv(rows, 4), 256, 0, s>>>(a);
   {
-    const int smem = 4 * (64 * 32 * 4 + 96 * LD * (int)sizeof(T));
-    if (set_smem(attn_bwd_dq_kernel<T, TR>, smem)) return 1;
-    dim3 grid(cdiv(a.Tq, 128), a.H, a.B);
-    attn_bwd_dq_kernel<T, TR><<<grid, 256, smem, s>>>(a);
+    const int smem = 4 * (DQ_GS_FLOATS * 4 + 96 * LD * (int)sizeof(T));
+    dim3 grid(cdiv(a.Tq, 32), a.H, a.B);
+    if (a.st && a.pdT) {
+      if (set_smem(attn_bwd_dq_kernel<T, TR, true>, smem)) return 1;
+      attn_bwd_dq_kernel<T, TR, true><<<grid, 256, smem, s>>>(a);
+    } else {
+      if (set_smem(attn_bwd_dq_kernel<T, TR, false>, smem)) return 1;
+      attn_bwd_dq_kernel<T, TR, false><<<grid, 256, smem, s>>>(a);
+    }
   }
   if (a.pdT) {
     // materialised mode: dV = Pd . dO, dK = dS . (Q + u), dpos_h = dBD_h^T . (Q_h + v)
@@ -720,10 +820,10 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
     const long sp_b = (long)a.H * a.Tk * a.ldpd, sp_h = (long)a.Tk * a.ldpd;
     EMO_LAUNCH_CHECK();
     if (emoasr_gemm_nn_batched(dtype, a.Tk, DK, a.Tq, a.pdT, a.ldpd, sp_b, sp_h, a.dout, a.ldo,
-                               (long)a.Tq * a.ldo, DK, a.dv, a.ldv, (long)a.Tk * a.ldv, DK, a.B, a.H, 1.f, s))
+                               (long)a.Tq * a.ldo, DK, a.dv, a.ldv, (long)a.Tk * a.ldv, DK, a.B, a.H, 1.f, 0, s))
       return 1;
     if (emoasr_gemm_nn_batched(dtype, a.Tk, DK, a.Tq, a.dsT, a.ldpd, sp_b, sp_h, a.q, a.ldq,
-                               (long)a.Tq * a.ldq, DK, a.dk, a.ldk, (long)a.Tk * a.ldk, DK, a.B, a.H, 1.f, s))
+                               (long)a.Tq * a.ldq, DK, a.dk, a.ldk, (long)a.Tk * a.ldk, DK, a.B, a.H, 1.f, 0, s))
       return 1;
     if (a.bias_u) attn_dk_bias_kernel<T><<<cdiv((long)a.B * a.H * a.Tk, 4), 256, 0, s>>>(a);
     if (a.pos && a.dpos) {
@@ -736,6 +836,14 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
           return 1;
       }
       attn_dpos_bias_kernel<<<cdiv((long)R * a.H * DK, 256), 256, 0, s>>>(a);
+      if (a.st) {
+        // dq += dBD . pos  (the (q+v) term), batched over (b, h); dbias_v from the column sums
+        if (emoasr_gemm_nn_batched(dtype, a.Tq, DK, R, a.dbd, a.ldbd, (long)a.Tq * a.ldbd,
+                                   (long)a.B * a.Tq * a.ldbd, a.pos, a.ldp, 0, DK, a.dq, a.ldq,
+                                   (long)a.Tq * a.ldq, DK, a.B, a.H, 1.f, 1, s))
+          return 1;
+        if (a.dbias_v) attn_dbias_v_kernel<T><<<cdiv(a.H * DK, 256), 256, 0, s>>>(a);
+      }
     }
     EMO_LAUNCH_CHECK();
     return 0;
@@ -774,7 +882,7 @@ extern "C" int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream) 
     EMO_CHECK(a->dsT && a->ldpd >= a->Tq && a->ldpd % 8 == 0, "attn_bwd: bad pdT/dsT scratch");
     EMO_CHECK(!a->pos || !a->dpos || (a->dbd && a->cs && a->ldbd >= 2 * a->Tq - 1 && a->ldbd % 8 == 0),
               "attn_bwd: bad dbd/cs scratch");
-    EMO_CHECK(a->k != nullptr && a->ldq * (long)a->Tq > 0, "attn_bwd: bad q");
+    EMO_CHECK(!a->st || a->ldst >= a->Tq, "attn_bwd: bad st");
   }
   if (a->B == 0 || a->Tq == 0) return 0;
   EMO_DISPATCH(dtype, {

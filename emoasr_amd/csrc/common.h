@@ -137,9 +137,10 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
 // returns 0.f (dropped) or 1/(1-p) (kept).  p == 0 -> always 1.
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
   if (p <= 0.f) return 1.f;
-  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  uint32_t h = hash_u32(lo ^ (uint32_t)seed);
-  h = hash_u32(h ^ hi ^ (uint32_t)(seed >> 32) ^ 0x9e3779b9U);
+  // one avalanche round over (idx, seed): ~10 integer ops per element (the masks are regenerated in
+  // every backward kernel, so this sits on the VALU critical path of the attention kernels)
+  const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  const uint32_t h = hash_u32((lo * 0x9E3779B1U) ^ (hi * 0x85EBCA77U) ^ (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0xC2B2AE3DU));
   const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
   return u < p ? 0.f : 1.f / (1.f - p);
 }

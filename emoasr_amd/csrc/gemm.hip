@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
             }
             if (res) {
               float d[8];
-              load8<T>(res + (long)row * ep.ldr + col, d);
+              load8<T>(res + (g.nh > 0 ? c_base : 0) + (long)row * ep.ldr + col, d);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = d[e] + ep.res_scale * v[e];
             }
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
               x = apply_act(ep.act, x);
               if (dpre) x *= apply_dact(ep.dact, to_f32(dpre[off + e]));
               if (ep.drop_p > 0.f) x *= dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col + e, ep.drop_p);
-              if (res) x = to_f32(res[(long)row * ep.ldr + col + e]) + ep.res_scale * x;
+              if (res) x = to_f32(res[(g.nh > 0 ? c_base : 0) + (long)row * ep.ldr + col + e]) + ep.res_scale * x;
               if (ep.out_f32) static_cast<float*>(g.C)[off + e] = x;
               else static_cast<T*>(g.C)[off + e] = from_f32<T>(x);
             }
@@ -539,7 +539,7 @@ extern "C" int emoasr_gemm_nn(int dtype, int M, int N, int K, const void* A, lon
 extern "C" int emoasr_gemm_nn_batched(int dtype, int M, int N, int K, const void* A, long lda, long sa_b,
                                       long sa_h, const void* B, long ldb, long sb_b, long sb_h, void* C,
                                       long ldc, long sc_b, long sc_h, int nb, int nh, float alpha,
-                                      void* stream) {
+                                      int accumulate, void* stream) {
   EMO_CHECK(M > 0 && N > 0 && K > 0 && nb > 0 && nh > 0, "gemm_nn_batched: empty problem");
   // K need not be a multiple of the vector width: rows of A are padded up to lda (zero-filled)
   if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") ||
@@ -548,6 +548,7 @@ extern "C" int emoasr_gemm_nn_batched(int dtype, int M, int N, int K, const void
   NtArgs a{};
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.ep = emoasr_epilogue_t{}; a.ep.alpha = alpha;
+  if (accumulate) { a.ep.residual = C; a.ep.ldr = (int)ldc; a.ep.res_scale = 1.f; }  // C += (batch offset applied in-kernel)
   a.nh = nh; a.sa_b = sa_b; a.sa_h = sa_h; a.sb_b = sb_b; a.sb_h = sb_h; a.sc_b = sc_b; a.sc_h = sc_h;
   EMO_DISPATCH(dtype, return (launch_nn<T>(a, (hipStream_t)stream, nb * nh)));
   return 0;

@@ -13,6 +13,7 @@ Reference behaviour being reproduced (file:line in /root/reference):
   CTC          asr/modeling/decoders/ctc.py:103-115,176-201
 """
 import math
+import os
 
 import torch
 
@@ -64,6 +65,7 @@ class ParamArena:
         self.compute_dtype = compute_dtype
         self.shadow = self.flat if compute_dtype == torch.float32 else torch.zeros(off, device=dev, dtype=compute_dtype)
         self.pviews, self.gviews = {}, {}
+        self._vcache = {}
         with torch.no_grad():
             for n, p in zip(order, self.params):
                 o = self.offsets[n]
@@ -95,38 +97,46 @@ class ParamArena:
                     self.gviews[n].zero_()
                 p.grad = self.gviews[n]
 
-    def w(self, name, shape=None):
-        """compute-dtype view of a parameter (GEMM operand)"""
-        o = self.offsets[name]
-        p = self.pviews[name]
-        v = self.shadow[o:o + p.numel()]
-        return v.view(shape if shape is not None else p.shape)
+    # views are created once and cached: the arena never moves
+    def _cached(self, key, make):
+        v = self._vcache.get(key)
+        if v is None:
+            v = self._vcache[key] = make()
+        return v
 
-    def w_span(self, first, last, shape):
+    def _span(self, buf, first, last, shape):
         o0 = self.offsets[first]
         o1 = self.offsets[last] + self.pviews[last].numel()
         n = 1
         for s in shape:
             n *= s
         assert o1 - o0 == n, f"parameters {first}..{last} are not contiguous in the arena"
-        return self.shadow[o0:o1].view(shape)
+        return buf[o0:o1].view(shape)
+
+    def w(self, name, shape=None):
+        """compute-dtype view of a parameter (GEMM operand)"""
+        def make():
+            o = self.offsets[name]
+            p = self.pviews[name]
+            return self.shadow[o:o + p.numel()].view(shape if shape is not None else p.shape)
+        return self._cached(("w", name, shape), make)
+
+    def w_span(self, first, last, shape):
+        return self._cached(("ws", first, last, shape), lambda: self._span(self.shadow, first, last, shape))
 
     def p(self, name):
         return self.pviews[name]
 
     def p_span(self, first, last, shape):
-        o0 = self.offsets[first]
-        o1 = self.offsets[last] + self.pviews[last].numel()
-        return self.flat[o0:o1].view(shape)
+        return self._cached(("ps", first, last, shape), lambda: self._span(self.flat, first, last, shape))
 
     def g(self, name, shape=None):
-        v = self.gviews[name]
-        return v if shape is None else v.view(shape)
+        if shape is None:
+            return self.gviews[name]
+        return self._cached(("g", name, shape), lambda: self.gviews[name].view(shape))
 
     def g_span(self, first, last, shape):
-        o0 = self.offsets[first]
-        o1 = self.offsets[last] + self.pviews[last].numel()
-        return self.grad[o0:o1].view(shape)
+        return self._cached(("gs", first, last, shape), lambda: self._span(self.grad, first, last, shape))
 
 
 def sinusoid(positions, d, device):
@@ -165,6 +175,8 @@ class CTCEngine:
         self.arena = ParamArena(module, compute_dtype)
         self._tables = {}
         self._attn_scratch = None
+        # keep the scaled scores S^T of the forward for the backward (1) or recompute them (0)
+        self.attn_store_scores = os.environ.get("EMOASR_ATTN_STORED", "0") == "1"
         self._attn_scratch_elens = None
         self._bufs = {}
         self.seed = 0x5EED
@@ -205,6 +217,10 @@ class CTCEngine:
     def forward(self, xs, xlens_host, training, stash=None):
         """xs f32 [B,T,F] (device), xlens_host: python list / CPU tensor.
         -> eouts [B,T',d] (compute dtype), elens (list), stash (or None)"""
+        with ops.stream_scope():
+            return self._forward(xs, xlens_host, training, stash)
+
+    def _forward(self, xs, xlens_host, training, stash):
         A, d, dt = self.arena, self.d, self.dtype
         self.ensure_bound()
         A.refresh_shadow()
@@ -280,10 +296,16 @@ class CTCEngine:
             bu, bv = A.p(name + ".pos_bias_u").view(-1), A.p(name + ".pos_bias_v").view(-1)
         else:
             pp = bu = bv = None
-        o, lse = ops.attn_fwd(q, k, v, H, scale, pos=pp, bias_u=bu, bias_v=bv, klens=elens, drop_p=p_att, seed=s_att)
+        if self._keep and self.attn_store_scores:
+            o, lse, sts = ops.attn_fwd(q, k, v, H, scale, pos=pp, bias_u=bu, bias_v=bv, klens=elens, drop_p=p_att,
+                                       seed=s_att, store_scores=True)
+        else:
+            o, lse = ops.attn_fwd(q, k, v, H, scale, pos=pp, bias_u=bu, bias_v=bv, klens=elens, drop_p=p_att,
+                                  seed=s_att)
+            sts = None
         y = ops.gemm_nt(o.view(B * T, d), A.w(name + ".linear_out.weight"), bias=A.p(name + ".linear_out.bias"),
                         residual=x, res_scale=1.0, drop_p=p_enc, seed=s_out)
-        return y, (x, mean, rstd, h, qkv, pp, o, lse, s_att, s_out)
+        return y, (x, mean, rstd, h, qkv, pp, o, lse, s_att, s_out, sts)
 
     def _conv_fwd(self, name, x, B, T, norm_name, p_enc, site, training):
         A, d = self.arena, self.d
@@ -392,7 +414,7 @@ class CTCEngine:
 
     def _attn_bwd(self, name, norm_name, st, dx, B, T, elens, pos_t):
         A, d, H = self.arena, self.d, self.h
-        x, mean, rstd, h, qkv, pp, o, lse, s_att, s_out = st
+        x, mean, rstd, h, qkv, pp, o, lse, s_att, s_out, sts = st
         dy, alpha = self._branch_grad(dx, 1.0, self.p_enc, s_out)
         do = self._lin_bwd(dy, o.view(B * T, d), name + ".linear_out.weight", name + ".linear_out.bias", alpha)
         dqkv = torch.empty_like(qkv)
@@ -411,7 +433,8 @@ class CTCEngine:
             self._attn_scratch = ops.AttnScratch(B, H, T, T, qkv.dtype, qkv.device, pp is not None)
             self._attn_scratch_elens = elens
         ops.attn_bwd(do.view(B, T, d), o, lse, q, k, v, H, scale, dq, dk, dv, pos=pp, bias_u=bu, bias_v=bv, klens=elens,
-                     drop_p=self.p_att, seed=s_att, dpos=dpos, dbias_u=gbu, dbias_v=gbv, scratch=self._attn_scratch)
+                     drop_p=self.p_att, seed=s_att, dpos=dpos, dbias_u=gbu, dbias_v=gbv, scratch=self._attn_scratch,
+                     st=sts)
         if pp is not None:
             dpos_t = dpos if self.dtype == torch.float32 else ops.strided_copy(dpos, out_dtype=self.dtype)
             ops.gemm_tn(dpos_t, pos_t, out=A.g(name + ".linear_pos.weight"), accumulate=True)
@@ -444,6 +467,10 @@ class CTCEngine:
     def backward(self, st, deouts):
         """deouts: gradient w.r.t. encoder output [B,T',d] (compute dtype).  Accumulates into the
         gradient arena (p.grad views)."""
+        with ops.stream_scope():
+            return self._backward(st, deouts)
+
+    def _backward(self, st, deouts):
         A, d = self.arena, self.d
         A.attach_grads()
         B, T, M = st.B, st.T2, st.M

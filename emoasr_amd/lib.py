@@ -33,7 +33,8 @@ class AttnArgs(Structure):
                 ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
                 ("dpos", c_void_p), ("dbias_u", c_void_p), ("dbias_v", c_void_p),
                 ("pdT", c_void_p), ("dsT", c_void_p), ("dbd", c_void_p),
-                ("ldpd", c_long), ("ldbd", c_long), ("cs", c_void_p)]
+                ("ldpd", c_long), ("ldbd", c_long), ("cs", c_void_p),
+                ("st", c_void_p), ("ldst", c_long)]
 
 
 P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
@@ -43,7 +44,7 @@ SIGNATURES = {
     "emoasr_gemm_nt": [I, I, I, I, P, L, P, L, P, L, POINTER(Epilogue), P],
     "emoasr_gemm_nn": [I, I, I, I, P, L, P, L, P, L, POINTER(Epilogue), P],
     "emoasr_gemm_tn": [I, I, I, I, P, L, P, L, P, L, F, I, P, F, P],
-    "emoasr_gemm_nn_batched": [I, I, I, I, P, L, L, L, P, L, L, L, P, L, L, L, I, I, F, P],
+    "emoasr_gemm_nn_batched": [I, I, I, I, P, L, L, L, P, L, L, L, P, L, L, L, I, I, F, I, P],
     "emoasr_colsum": [I, I, I, P, L, P, F, I, P],
     "emoasr_conv1_fwd": [I, I, I, I, I, P, P, P, P, P],
     "emoasr_conv1_wgrad": [I, I, I, I, I, P, P, P, P, I, P],
@@ -112,11 +113,16 @@ def load():
     return lib
 
 
+_FN = {}
+
+
 def call(name, *args):
-    lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
-        raise EmoasrHipError(f"{name} failed ({rc}): {lib.emoasr_last_error().decode()}")
+        raise EmoasrHipError(f"{name} failed ({rc}): {load().emoasr_last_error().decode()}")
 
 
 def set_option(name, value):

@@ -24,8 +24,29 @@ def _p(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+_STREAM_CACHE = None
+
+
 def _stream():
+    if _STREAM_CACHE is not None:
+        return _STREAM_CACHE
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class stream_scope:
+    """Resolve torch's current stream once for a whole forward/backward sequence (the lookup costs
+    more than a kernel launch when done per op)."""
+
+    def __enter__(self):
+        global _STREAM_CACHE
+        self.prev = _STREAM_CACHE
+        _STREAM_CACHE = c_void_p(torch.cuda.current_stream().cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        global _STREAM_CACHE
+        _STREAM_CACHE = self.prev
+        return False
 
 
 def _chk(t, dtype=None):
@@ -46,20 +67,12 @@ def _rows(t):
 
 def make_epilogue(bias=None, act=ACT_NONE, alpha=1.0, residual=None, res_scale=1.0, pre_out=None,
                   dact_pre=None, dact=ACT_NONE, drop_p=0.0, seed=0, out_f32=False):
-    ep = Epilogue()
-    ep.bias = None if bias is None else bias.data_ptr()
-    ep.residual = None if residual is None else residual.data_ptr()
-    ep.pre_out = None if pre_out is None else pre_out.data_ptr()
-    ep.dact_pre = None if dact_pre is None else dact_pre.data_ptr()
-    ep.alpha = alpha
-    ep.res_scale = res_scale
-    ep.act = act
-    ep.dact = dact
-    ep.ldr = 0 if residual is None else residual.stride(0)
-    ep.out_f32 = 1 if out_f32 else 0
-    ep.drop_p = drop_p
-    ep.seed = seed
-    return ep
+    return Epilogue(None if bias is None else bias.data_ptr(),
+                    None if residual is None else residual.data_ptr(),
+                    None if pre_out is None else pre_out.data_ptr(),
+                    None if dact_pre is None else dact_pre.data_ptr(),
+                    alpha, res_scale, act, dact, 0 if residual is None else residual.stride(0),
+                    1 if out_f32 else 0, drop_p, seed)
 
 
 def gemm_nt(a, b, out=None, **epi):
@@ -105,11 +118,11 @@ def gemm_tn(a, b, out=None, alpha=1.0, accumulate=False, colsum=None, colsum_sca
     return out
 
 
-def gemm_nn_batched(a, b, out, M, N, K, lda, sa, ldb, sb, ldc, sc, nb, nh, alpha=1.0):
-    """out[b,h] = alpha * a[b,h] (M x K, k-contiguous) @ b[b,h] (K x N, k-major); s* = (outer, inner)
+def gemm_nn_batched(a, b, out, M, N, K, lda, sa, ldb, sb, ldc, sc, nb, nh, alpha=1.0, accumulate=False):
+    """out[b,h] (+)= alpha * a[b,h] (M x K, k-contiguous) @ b[b,h] (K x N, k-major); s* = (outer, inner)
     batch strides in elements; base pointers are the tensors' data pointers."""
     lib.call("emoasr_gemm_nn_batched", dt(a), M, N, K, _p(a), lda, sa[0], sa[1], _p(b), ldb, sb[0], sb[1],
-             _p(out), ldc, sc[0], sc[1], nb, nh, alpha, _stream())
+             _p(out), ldc, sc[0], sc[1], nb, nh, alpha, int(accumulate), _stream())
     return out
 
 
@@ -207,15 +220,20 @@ def _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, se
 
 
 def attn_fwd(q, k, v, H, scale, pos=None, bias_u=None, bias_v=None, klens=None, causal=False, drop_p=0.0,
-             seed=0):
-    """q [B,Tq,D], k/v [B,Tk,D] (views with a row stride are fine) -> out [B,Tq,D], lse [B,H,Tq]"""
+             seed=0, store_scores=False):
+    """q [B,Tq,D], k/v [B,Tk,D] (views with a row stride are fine) -> out [B,Tq,D], lse [B,H,Tq]
+    (+ st f32 [B,H,Tk,ldst], the scaled scores S^T kept for the backward, if store_scores)"""
     B, Tq, D = q.shape
     a = _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, seed)
     out = torch.empty(B, Tq, D, device=q.device, dtype=q.dtype)
     lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
     a.out, a.ldo, a.lse = out.data_ptr(), D, lse.data_ptr()
+    st = None
+    if store_scores:
+        st = torch.empty(B, H, k.shape[1], (Tq + 7) // 8 * 8, device=q.device, dtype=torch.float32)
+        a.st, a.ldst = st.data_ptr(), st.shape[-1]
     lib.call("emoasr_attn_fwd", dt(q), byref(a), _stream())
-    return out, lse
+    return (out, lse, st) if store_scores else (out, lse)
 
 
 class AttnScratch:
@@ -234,7 +252,7 @@ class AttnScratch:
 
 def attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=None, bias_u=None, bias_v=None, klens=None,
              causal=False, drop_p=0.0, seed=0, dpos=None, dbias_u=None, dbias_v=None, scratch=None,
-             materialise=True):
+             materialise=True, st=None):
     """dq/dk/dv are written (same strides as q/k/v); dpos/dbias_* are accumulated into.
     materialise=True: dV/dK/dpos through batched GEMMs over stored P^T/dS^T (scratch is allocated
     here unless an AttnScratch for this shape/mask is passed); False: score-recompute kernels."""
@@ -257,6 +275,8 @@ def attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=None, bias_u=Non
         a.pdT, a.dsT, a.ldpd = scratch.pdT.data_ptr(), scratch.dsT.data_ptr(), scratch.ldpd
         if rel:
             a.dbd, a.ldbd, a.cs = scratch.dbd.data_ptr(), scratch.ldbd, scratch.cs.data_ptr()
+        if st is not None:  # scores stored by attn_fwd(store_scores=True): no recomputation
+            a.st, a.ldst = st.data_ptr(), st.shape[-1]
     lib.call("emoasr_attn_bwd", dt(q), byref(a), _stream())
 
 

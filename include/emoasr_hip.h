@@ -68,7 +68,7 @@ int emoasr_gemm_nn(int dtype, int M, int N, int K, const void* A, long lda, cons
  * (elements).  Attention backward: dV[b,h] = Pd[b,h] . dO[b,h], dK[b,h] = dS[b,h] . Q[b,h]. */
 int emoasr_gemm_nn_batched(int dtype, int M, int N, int K, const void* A, long lda, long sa_b, long sa_h,
                            const void* B, long ldb, long sb_b, long sb_h, void* C, long ldc, long sc_b,
-                           long sc_h, int nb, int nh, float alpha, void* stream);
+                           long sc_h, int nb, int nh, float alpha, int accumulate, void* stream);
 /* C[N1,N2] (+)= alpha * A[K,N1]^T . B[K,N2], f32 output (weight gradients; the
  * autograd backward of the calls above).  If colsum != NULL the kernel also produces
  * colsum[N1] (+)= colsum_scale * sum_k A[k,:] (the bias gradient) from the staged A tiles. */
@@ -144,6 +144,12 @@ typedef struct {
   void *dbd;          /* T [H,B,Tq,ldbd]; NULL without relative positions */
   long ldpd, ldbd;
   float* cs;          /* f32 [H, ldbd] scratch */
+  /* optional: scaled scores S^T, f32 [B,H,Tk,ldst] (ldst >= Tq).  The forward stores them when
+   * st != NULL; a backward given the same buffer (with the scratch above) reads them back instead
+   * of recomputing (q+u).k + (q+v).pos, and computes the (q+v) part of dq as a batched GEMM over
+   * the stored dBD band. */
+  float* st;
+  long ldst;
 } emoasr_attn_t;
 int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream);
 int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream);

@@ -246,7 +246,7 @@ def _attn_ref(q, k, v, H, scale, pos, bu, bv, klens, causal):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", ["rel", "rel_long", "plain_mask", "causal", "cross"])
-@pytest.mark.parametrize("mat", [True, False], ids=["gemmbwd", "recompute"])
+@pytest.mark.parametrize("mat", ["stored", True, False], ids=["stored", "gemmbwd", "recompute"])
 def test_attention(dev, dtype, tr_mode, case, mat):
     from emoasr_amd import ops
     H, dk = 4, 64
@@ -271,7 +271,12 @@ def test_attention(dev, dtype, tr_mode, case, mat):
     ref = _attn_ref(*leaves[:3], H, scale, leaves[3], leaves[4], leaves[5], klens, causal)
     dout = _rnd(dev, B, Tq, D, dtype=dtype)
     ref.backward(dout.float())
-    out, lse = ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, causal=causal)
+    st = None
+    if mat == "stored":
+        out, lse, st = ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, causal=causal,
+                                    store_scores=True)
+    else:
+        out, lse = ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, causal=causal)
     tol = _tol(dtype, 2e-5, 2e-2)
     _close(out, ref, tol, f"attn fwd {case}")
     if Tq == Tk:
@@ -285,7 +290,7 @@ def test_attention(dev, dtype, tr_mode, case, mat):
     dbu = torch.zeros(D, device=dev) if rel else None
     dbv = torch.zeros(D, device=dev) if rel else None
     ops.attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk_, dv, pos=pos, bias_u=bu, bias_v=bv, klens=klens,
-                 causal=causal, dpos=dpos, dbias_u=dbu, dbias_v=dbv, materialise=mat)
+                 causal=causal, dpos=dpos, dbias_u=dbu, dbias_v=dbv, materialise=bool(mat), st=st)
     btol = _tol(dtype, 1e-4, 4e-2)
     _close(dq, leaves[0].grad, btol, f"attn dq {case}")
     _close(dk_, leaves[1].grad, btol, f"attn dk {case}")
