@@ -109,6 +109,77 @@ def run_ctc(name, cfg):
           "params", sum(p.numel() for p in model.parameters()))
 
 
+L3 = dict(COMMON, encoder_type="conformer", decoder_type="transformer", pos_encode_type="rel",
+          dec_hidden_size=128, dec_num_attention_heads=2, dec_num_layers=2, dec_intermediate_size=256,
+          mtl_ctc_weight=0.3, loss_normalize_length=False, loss_normalize_batch=True, max_decode_ylen=20)
+LM_CFG = dict(lm_type="transformer", vocab_size=40, hidden_size=128, num_layers=2, num_attention_heads=2,
+              intermediate_size=256, max_seq_len=64)
+DECODE_SETTINGS = [dict(beam_width=4, len_weight=0.0, lm_weight=0.0, decode_ctc_weight=0.0),
+                   dict(beam_width=4, len_weight=0.0, lm_weight=0.0, decode_ctc_weight=0.3),
+                   dict(beam_width=4, len_weight=0.1, lm_weight=0.3, decode_ctc_weight=0.3),
+                   dict(beam_width=3, len_weight=0.2, lm_weight=0.5, decode_ctc_weight=0.0)]
+
+
+def run_l3():
+    from lm.modeling.lm import LM
+    torch.manual_seed(0)
+    model = ASR(make_params(L3), phase="train")
+    lm = LM(make_params(LM_CFG))
+    lm.eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".norm" in n or "batch_norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+        model.decoder.output.weight.mul_(2.0)
+        model.decoder.ctc.output.bias[L3["blank_id"]] += 5.0  # blank-dominated CTC: short prefixes keep non-negligible mass
+        model.decoder.output.bias[L3["eos_id"]] += 2.5  # random-init decoders never emit <eos> otherwise
+        for n, p in lm.named_parameters():
+            if "LayerNorm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+        lm.lm.transformer.cls.predictions.bias.add_(0.5 * torch.randn(LM_CFG["vocab_size"]))
+    xs, xlens, ys, ylens, ys_in, ys_out = make_batch(1, L3["feat_dim"], L3["vocab_size"])
+    out = {}
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    for k, v in sd0.items():
+        out["sd/" + k] = v.numpy()
+    for k, v in lm.state_dict().items():
+        out["lm/" + k] = v.clone().numpy()
+    out.update(xs=xs.numpy(), xlens=xlens.numpy(), ys=ys.numpy(), ylens=ylens.numpy(), ys_in=ys_in.numpy(),
+               ys_out=ys_out.numpy())
+    model.train()
+    loss, loss_dict = model(xs, xlens, ys, ylens, ys_in, ys_out)
+    loss.backward()
+    out["train/loss"] = loss.detach().numpy()
+    out["train/loss_att"] = loss_dict["loss_att"].detach().numpy()
+    out["train/loss_ctc"] = loss_dict["loss_ctc"].detach().numpy()
+    for n, p in model.named_parameters():
+        out["grad/" + n] = p.grad.clone().numpy()
+    model.load_state_dict(sd0)
+    model.eval()
+    with torch.no_grad():
+        eouts, elens, _ = model.encoder(xs, xlens)
+        logits = model.decoder(eouts, elens, None, ys, ylens, ys_in, None)
+        out["eval/eouts"] = eouts.numpy()
+        out["eval/att_logits"] = logits.numpy()
+        ystest = torch.randint(3, LM_CFG["vocab_size"], (3, 9))
+        yl = torch.tensor([9, 6, 2])
+        lp, _ = lm.predict(ystest, yl)
+        out["lm_test/ys"], out["lm_test/ylens"], out["lm_test/logp"] = ystest.numpy(), yl.numpy(), lp.numpy()
+        import warnings
+        for si, st in enumerate(DECODE_SETTINGS):
+            for b in range(2):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    hyps, scores, _, _ = model.decode(xs[b:b + 1, : xlens[b]], xlens[b:b + 1], lm=lm, **st)
+                out[f"decode/{si}/{b}/lens"] = np.array([len(h) for h in hyps])
+                out[f"decode/{si}/{b}/hyps"] = np.array(sum(hyps, []), dtype=np.int64)
+                out[f"decode/{si}/{b}/scores"] = np.array(scores, dtype=np.float64)
+                print("decode", si, b, [len(h) for h in hyps], [round(s, 3) for s in scores])
+    np.savez_compressed(os.path.join(OUT, "l3_tiny.npz"), **out)
+    print("l3_tiny loss", float(loss.detach()), {k: float(v) for k, v in loss_dict.items()})
+
+
 if __name__ == "__main__":
     for name, cfg in CONFIGS.items():
         run_ctc(name, cfg)
+    run_l3()

@@ -17,11 +17,27 @@ CONFIGS = {
 }
 
 
+L3 = dict(COMMON, encoder_type="conformer", decoder_type="transformer", pos_encode_type="rel",
+          dec_hidden_size=128, dec_num_attention_heads=2, dec_num_layers=2, dec_intermediate_size=256,
+          mtl_ctc_weight=0.3, loss_normalize_length=False, loss_normalize_batch=True, max_decode_ylen=20)
+CONFIGS["l3_tiny"] = L3
+LM_CFG = dict(lm_type="transformer", vocab_size=40, hidden_size=128, num_layers=2, num_attention_heads=2,
+              intermediate_size=256, max_seq_len=64)
+DECODE_SETTINGS = [dict(beam_width=4, len_weight=0.0, lm_weight=0.0, decode_ctc_weight=0.0),
+                   dict(beam_width=4, len_weight=0.0, lm_weight=0.0, decode_ctc_weight=0.3),
+                   dict(beam_width=4, len_weight=0.1, lm_weight=0.3, decode_ctc_weight=0.3),
+                   dict(beam_width=3, len_weight=0.2, lm_weight=0.5, decode_ctc_weight=0.0)]
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     g = {k: torch.from_numpy(z[k]) for k in z.files}
     sd = {k[3:]: v for k, v in g.items() if k.startswith("sd/")}
     return SimpleNamespace(**CONFIGS[name]), sd, g
+
+
+def lm_state(g):
+    return {k[3:]: v for k, v in g.items() if k.startswith("lm/")}
 
 
 def split_ragged(flat, lens):
