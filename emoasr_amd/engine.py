@@ -152,13 +152,17 @@ class _Stash:
     pass
 
 
+class _DecoderMixinPlaceholder:
+    pass
+
+
 def h2d_i32(values, device):
     """small host array -> int32 device tensor through pinned memory (asynchronous H2D)"""
     t = torch.as_tensor(values, dtype=torch.int32)
     return t.pin_memory().to(device, non_blocking=True)
 
 
-class CTCEngine:
+class CTCEngine(_DecoderMixinPlaceholder):
     """Forward / backward of encoder + CTC head on HIP kernels."""
 
     def __init__(self, cfg, module, compute_dtype=torch.bfloat16, bn_buffers=None):
@@ -174,12 +178,13 @@ class CTCEngine:
         self.module = module
         self.arena = ParamArena(module, compute_dtype)
         self._tables = {}
-        self._attn_scratch = None
+        self._scratch_cache = {}
         # keep the scaled scores S^T of the forward for the backward (1) or recompute them (0)
         self.attn_store_scores = os.environ.get("EMOASR_ATTN_STORED", "0") == "1"
-        self._attn_scratch_elens = None
         self._bufs = {}
         self.seed = 0x5EED
+        if _cfg(cfg, "decoder_type", "ctc") == "transformer":
+            self._dec_init()
         self.step_count = 0
 
     # ------------------------------------------------------------------ helpers
@@ -282,8 +287,10 @@ class CTCEngine:
                         drop_p=p_enc, seed=s_out)
         return y, (x, mean, rstd, h, u, a, s_in, s_out)
 
-    def _attn_fwd(self, name, x, B, T, elens, pos_t, norm_name, eps, p_enc, p_att, site, training):
-        A, d, H = self.arena, self.d, self.h
+    def _attn_fwd(self, name, x, B, T, elens, pos_t, norm_name, eps, p_enc, p_att, site, training, dims=None,
+                  causal=False):
+        A = self.arena
+        d, H = dims if dims is not None else (self.d, self.h)
         h, mean, rstd = ops.layernorm_fwd(x, A.p(norm_name + ".weight"), A.p(norm_name + ".bias"), eps, self._keep)
         wqkv = A.w_span(name + ".linear_q.weight", name + ".linear_v.weight", (3 * d, d))
         bqkv = A.p_span(name + ".linear_q.bias", name + ".linear_v.bias", (3 * d,))
@@ -298,10 +305,10 @@ class CTCEngine:
             pp = bu = bv = None
         if self._keep and self.attn_store_scores:
             o, lse, sts = ops.attn_fwd(q, k, v, H, scale, pos=pp, bias_u=bu, bias_v=bv, klens=elens, drop_p=p_att,
-                                       seed=s_att, store_scores=True)
+                                       seed=s_att, store_scores=True, causal=causal)
         else:
             o, lse = ops.attn_fwd(q, k, v, H, scale, pos=pp, bias_u=bu, bias_v=bv, klens=elens, drop_p=p_att,
-                                  seed=s_att)
+                                  seed=s_att, causal=causal)
             sts = None
         y = ops.gemm_nt(o.view(B * T, d), A.w(name + ".linear_out.weight"), bias=A.p(name + ".linear_out.bias"),
                         residual=x, res_scale=1.0, drop_p=p_enc, seed=s_out)
@@ -353,10 +360,10 @@ class CTCEngine:
         return x, (None, s_att, None, s_ff, None)
 
     # ------------------------------------------------------------------ CTC head
-    def head_logits(self, eouts):
+    def head_logits(self, eouts, head="decoder.output"):
         B, T, d = eouts.shape
         A = self.arena
-        logits = ops.gemm_nt(eouts.reshape(B * T, d), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
+        logits = ops.gemm_nt(eouts.reshape(B * T, d), A.w(head + ".weight"), bias=A.p(head + ".bias"))
         return logits.view(B, T, -1)
 
     def ctc_loss(self, logits, elens, ys_host, ylens_host, blank, want_grad, gscale_over_b=None):
@@ -402,20 +409,23 @@ class CTCEngine:
             return ops.scale_dropout(dx, scale, p, seed), 1.0
         return dx, scale
 
-    def _ffn_bwd(self, name, norm_name, st, dx, res_scale, act):
+    def _ffn_bwd(self, name, norm_name, st, dx, res_scale, act, p=None):
         A = self.arena
         x, mean, rstd, h, u, a, s_in, s_out = st
-        p = self.p_enc
+        p = self.p_enc if p is None else p
         dy, alpha = self._branch_grad(dx, res_scale, p, s_out)
         du = self._lin_bwd(dy, a, name + ".w2.weight", name + ".w2.bias", alpha, dact_pre=u, dact=act, drop_p=p, seed=s_in)
         dh = self._lin_bwd(du, h, name + ".w1.weight", name + ".w1.bias")
         return ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
                                  A.g(norm_name + ".bias"))
 
-    def _attn_bwd(self, name, norm_name, st, dx, B, T, elens, pos_t):
-        A, d, H = self.arena, self.d, self.h
+    def _attn_bwd(self, name, norm_name, st, dx, B, T, elens, pos_t, dims=None, causal=False, p_res=None, p_att=None):
+        A = self.arena
+        d, H = dims if dims is not None else (self.d, self.h)
+        p_res = self.p_enc if p_res is None else p_res
+        p_att = self.p_att if p_att is None else p_att
         x, mean, rstd, h, qkv, pp, o, lse, s_att, s_out, sts = st
-        dy, alpha = self._branch_grad(dx, 1.0, self.p_enc, s_out)
+        dy, alpha = self._branch_grad(dx, 1.0, p_res, s_out)
         do = self._lin_bwd(dy, o.view(B * T, d), name + ".linear_out.weight", name + ".linear_out.bias", alpha)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
@@ -427,13 +437,9 @@ class CTCEngine:
             gbu, gbv = A.g(name + ".pos_bias_u").view(-1), A.g(name + ".pos_bias_v").view(-1)
         else:
             dpos = bu = bv = gbu = gbv = None
-        key = (B, H, T, T, qkv.dtype, pp is not None)
-        if self._attn_scratch is None or self._attn_scratch.key != key or self._attn_scratch_elens is not elens:
-            # zeroed once per step: every layer masks the same (key >= elens) entries
-            self._attn_scratch = ops.AttnScratch(B, H, T, T, qkv.dtype, qkv.device, pp is not None)
-            self._attn_scratch_elens = elens
+        scratch = self._scratch_for(B, H, T, T, qkv.dtype, qkv.device, pp is not None, elens, causal)
         ops.attn_bwd(do.view(B, T, d), o, lse, q, k, v, H, scale, dq, dk, dv, pos=pp, bias_u=bu, bias_v=bv, klens=elens,
-                     drop_p=self.p_att, seed=s_att, dpos=dpos, dbias_u=gbu, dbias_v=gbv, scratch=self._attn_scratch,
+                     causal=causal, drop_p=p_att, seed=s_att, dpos=dpos, dbias_u=gbu, dbias_v=gbv, scratch=scratch,
                      st=sts)
         if pp is not None:
             dpos_t = dpos if self.dtype == torch.float32 else ops.strided_copy(dpos, out_dtype=self.dtype)
@@ -445,6 +451,18 @@ class CTCEngine:
         dh = ops.gemm_nn(dqkv2, wqkv)
         return ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
                                  A.g(norm_name + ".bias"))
+
+    def _scratch_for(self, B, H, Tq, Tk, dtype, device, rel, klens, causal):
+        """attention-backward scratch, zeroed once per (shape, mask): every layer of a step masks the
+        same entries, so the buffers are reused across layers."""
+        key = (B, H, Tq, Tk, dtype, rel, id(klens), causal)
+        sc = self._scratch_cache.get(key)
+        if sc is None:
+            if len(self._scratch_cache) > 4:
+                self._scratch_cache.clear()
+            sc = self._scratch_cache[key] = ops.AttnScratch(B, H, Tq, Tk, dtype, device, rel)
+            sc._klens = klens  # keep the mask tensor alive while its id() keys the cache
+        return sc
 
     def _conv_bwd(self, name, norm_name, st, dx, B, T):
         A, d = self.arena, self.d
@@ -511,10 +529,148 @@ class CTCEngine:
         dy1 = ops.conv2_col2im(dcol, st.y1)
         ops.conv1_wgrad(st.xs, dy1, A.g(pre + "conv.0.weight").view(C, 9), A.g(pre + "conv.0.bias"), accumulate=True)
 
-    def head_backward(self, eouts, dlogits):
+    def head_backward(self, eouts, dlogits, head="decoder.output"):
         """-> deouts; accumulates the vocabulary head's gradients."""
         B, T, d = eouts.shape
         V = dlogits.shape[-1]
         self.arena.attach_grads()
-        return self._lin_bwd(dlogits.view(B * T, V), eouts.reshape(B * T, d), "decoder.output.weight",
-                             "decoder.output.bias").view(B, T, d)
+        return self._lin_bwd(dlogits.view(B * T, V), eouts.reshape(B * T, d), head + ".weight",
+                             head + ".bias").view(B, T, d)
+
+
+# =======================================================================================
+# Transformer decoder (attention loss with label smoothing, auxiliary CTC)
+#   reference: asr/modeling/decoders/transformer.py:82-146, asr/modeling/transformer.py:156-198
+# =======================================================================================
+class _DecoderMixin:
+    def _dec_init(self):
+        cfg = self.cfg
+        self.dd = cfg.dec_hidden_size
+        self.dh = cfg.dec_num_attention_heads
+        self.dnl = cfg.dec_num_layers
+        self.p_dec = float(_cfg(cfg, "dropout_dec_rate", 0.0))
+        self.lsm = float(_cfg(cfg, "lsm_prob", 0.0))
+        self.norm_len = bool(_cfg(cfg, "loss_normalize_length", False))
+        self.norm_batch = bool(_cfg(cfg, "loss_normalize_batch", True))
+        self.mtl_ctc = float(_cfg(cfg, "mtl_ctc_weight", 0.0))
+
+    def _abs_table(self, L, device, d):
+        key = ("abs", d, str(device))
+        if key not in self._tables or self._tables[key].shape[0] < L:
+            self._tables[key] = sinusoid(torch.arange(max(L, 512)), d, device)
+        return self._tables[key]
+
+    def dec_forward(self, eouts, elens_dev, ys_in, ylens_host, training, keep):
+        """teacher-forced decoder: -> logits [B, L, V] (compute dtype), stash"""
+        with ops.stream_scope():
+            return self._dec_forward(eouts, elens_dev, ys_in, ylens_host, training, keep)
+
+    def _dec_forward(self, eouts, elens_dev, ys_in, ylens_host, training, keep):
+        A, dd, dh = self.arena, self.dd, self.dh
+        self._keep = keep
+        B, T, d = eouts.shape
+        L = ys_in.shape[1]
+        dev = eouts.device
+        p = self.p_dec if training else 0.0
+        p_att = self.p_att if training else 0.0
+        ids = h2d_i32(torch.as_tensor(ys_in).contiguous(), dev)
+        kself = h2d_i32([int(y) + 1 for y in ylens_host], dev)
+        s_emb = self._seed(5000)
+        x = ops.embed_fwd(ids, A.w("decoder.embed.weight"), self._abs_table(L, dev, dd), math.sqrt(dd), p, s_emb)
+        x = x.view(B * L, dd)
+        mem2 = eouts.reshape(B * T, d)
+        scale = 1.0 / math.sqrt(dd // dh)
+        layers = []
+        for li in range(self.dnl):
+            name = f"decoder.transformers.{li}"
+            site = 5100 + li * 20
+            x, s_self = self._attn_fwd(name + ".self_attn", x, B, L, kself, None, name + ".norm1", 1e-12, p, p_att, site,
+                                       training, dims=(dd, dh), causal=True)
+            # ---- source attention: queries from the decoder, keys/values from the encoder memory
+            sa = name + ".src_attn"
+            h2, m2, r2 = ops.layernorm_fwd(x, A.p(name + ".norm2.weight"), A.p(name + ".norm2.bias"), 1e-12, keep)
+            q2 = ops.gemm_nt(h2, A.w(sa + ".linear_q.weight"), bias=A.p(sa + ".linear_q.bias")).view(B, L, dd)
+            wkv = A.w_span(sa + ".linear_k.weight", sa + ".linear_v.weight", (2 * dd, d))
+            bkv = A.p_span(sa + ".linear_k.bias", sa + ".linear_v.bias", (2 * dd,))
+            kv = ops.gemm_nt(mem2, wkv, bias=bkv).view(B, T, 2 * dd)
+            s_att, s_out = self._seed(site + 4), self._seed(site + 5)
+            o2, lse2 = ops.attn_fwd(q2, kv[..., :dd], kv[..., dd:], dh, scale, klens=elens_dev, drop_p=p_att, seed=s_att)
+            x1 = ops.gemm_nt(o2.view(B * L, dd), A.w(sa + ".linear_out.weight"), bias=A.p(sa + ".linear_out.bias"),
+                             residual=x, res_scale=1.0, drop_p=p, seed=s_out)
+            s_src = (x, m2, r2, h2, q2, kv, o2, lse2, s_att, s_out)
+            x, s_ff = self._ffn_fwd(name + ".feed_forward", x1, 1.0, ACT_RELU, name + ".norm3", 1e-12, p, site + 8, training)
+            layers.append((s_self, s_src, s_ff))
+        y, mean, rstd = ops.layernorm_fwd(x, A.p("decoder.norm.weight"), A.p("decoder.norm.bias"), 1e-12, keep)
+        logits = ops.gemm_nt(y, A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
+        st = None
+        if keep:
+            st = _Stash()
+            st.B, st.L, st.T, st.ids, st.kself, st.elens, st.s_emb = B, L, T, ids, kself, elens_dev, s_emb
+            st.layers, st.x_final, st.mean, st.rstd, st.y, st.mem2 = layers, x, mean, rstd, y, mem2
+            st.p, st.p_att = p, p_att
+        return logits.view(B, L, -1), st
+
+    def att_loss(self, logits, ys_out, ylens_host, want_grad=False, gscale_dev=None):
+        """LabelSmoothingLoss over t < ylens+1 -> (loss 0-dim f32, dlogits | None)"""
+        B, L, V = logits.shape
+        dev = logits.device
+        w = torch.zeros(B, L, dtype=torch.float32)
+        for b, yl in enumerate(ylens_host):
+            n = int(yl) + 1
+            w[b, :n] = (1.0 / B if self.norm_batch else 1.0) / (n if self.norm_len else 1.0)
+        w = w.pin_memory().to(dev, non_blocking=True)
+        labels = h2d_i32(torch.as_tensor(ys_out)[:, :L].contiguous(), dev)
+        rows, grad = ops.lsm_loss(logits.view(B * L, V), labels.view(-1), w.view(-1), self.lsm, want_grad, 1.0, gscale_dev)
+        return rows.sum(), (grad.view(B, L, V) if grad is not None else None)
+
+    def dec_backward(self, st, dlogits):
+        """-> d_eouts [B,T,d]; accumulates decoder parameter gradients"""
+        with ops.stream_scope():
+            return self._dec_backward(st, dlogits)
+
+    def _dec_backward(self, st, dlogits):
+        A, dd, dh = self.arena, self.dd, self.dh
+        A.attach_grads()
+        B, L, T = st.B, st.L, st.T
+        p, p_att = st.p, st.p_att
+        d = st.mem2.shape[1]
+        dy = self._lin_bwd(dlogits.reshape(B * L, -1), st.y, "decoder.output.weight", "decoder.output.bias")
+        dx = ops.layernorm_bwd(dy, st.x_final, A.p("decoder.norm.weight"), st.mean, st.rstd, None,
+                               A.g("decoder.norm.weight"), A.g("decoder.norm.bias"))
+        scale = 1.0 / math.sqrt(dd // dh)
+        dmem = None
+        for li in reversed(range(self.dnl)):
+            name = f"decoder.transformers.{li}"
+            s_self, s_src, s_ff = st.layers[li]
+            dx = self._ffn_bwd(name + ".feed_forward", name + ".norm3", s_ff, dx, 1.0, ACT_RELU, p=p)
+            # ---- source attention
+            sa = name + ".src_attn"
+            x, m2, r2, h2, q2, kv, o2, lse2, s_att, s_out = s_src
+            dyb, alpha = self._branch_grad(dx, 1.0, p, s_out)
+            do2 = self._lin_bwd(dyb, o2.view(B * L, dd), sa + ".linear_out.weight", sa + ".linear_out.bias", alpha)
+            dq2 = torch.empty_like(q2)
+            dkv = torch.empty_like(kv)
+            scratch = self._scratch_for(B, dh, L, T, q2.dtype, q2.device, False, st.elens, False)
+            ops.attn_bwd(do2.view(B, L, dd), o2, lse2, q2, kv[..., :dd], kv[..., dd:], dh, scale, dq2, dkv[..., :dd],
+                         dkv[..., dd:], klens=st.elens, drop_p=p_att, seed=s_att, scratch=scratch)
+            dh2 = self._lin_bwd(dq2.view(B * L, dd), h2, sa + ".linear_q.weight", sa + ".linear_q.bias")
+            dkv2 = dkv.view(B * T, 2 * dd)
+            ops.gemm_tn(dkv2, st.mem2, out=A.g_span(sa + ".linear_k.weight", sa + ".linear_v.weight", (2 * dd, d)),
+                        accumulate=True, colsum=A.g_span(sa + ".linear_k.bias", sa + ".linear_v.bias", (2 * dd,)))
+            wkv = A.w_span(sa + ".linear_k.weight", sa + ".linear_v.weight", (2 * dd, d))
+            if dmem is None:
+                dmem = ops.gemm_nn(dkv2, wkv)
+            else:
+                ops.gemm_nn(dkv2, wkv, out=dmem, residual=dmem, res_scale=1.0)
+            dx = ops.layernorm_bwd(dh2, x, A.p(name + ".norm2.weight"), m2, r2, dx, A.g(name + ".norm2.weight"),
+                                   A.g(name + ".norm2.bias"))
+            dx = self._attn_bwd(name + ".self_attn", name + ".norm1", s_self, dx, B, L, st.kself, None, dims=(dd, dh),
+                                causal=True, p_res=p, p_att=p_att)
+        ops.embed_bwd(st.ids, dx, math.sqrt(dd), A.g("decoder.embed.weight"), p, st.s_emb)
+        return dmem.view(B, T, d)
+
+
+for _n, _f in list(vars(_DecoderMixin).items()):
+    if not _n.startswith("__"):
+        setattr(CTCEngine, _n, _f)
+ASREngine = CTCEngine

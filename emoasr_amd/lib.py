@@ -71,6 +71,9 @@ SIGNATURES = {
     "emoasr_ctc_forward": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, P],
     "emoasr_ctc_grad": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, F, P, P, L, P],
     "emoasr_ctc_greedy": [I, I, I, I, P, L, P, I, P, P, P, P],
+    "emoasr_embed_fwd": [I, I, I, I, P, P, P, F, F, U64, P, P],
+    "emoasr_embed_bwd": [I, I, I, P, P, F, F, U64, P, P],
+    "emoasr_lsm_loss": [I, I, I, P, L, P, P, F, P, F, P, P, L, P],
     "emoasr_sqnorm": [L, P, P, P],
     "emoasr_adam_step": [L, P, P, P, P, F, F, F, F, F, I, P, F, F, P],
     "emoasr_specaug_apply": [I, I, I, P, P, I, I, P, P, P],

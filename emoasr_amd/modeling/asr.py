@@ -28,6 +28,11 @@ class ASR(nn.Module):
         self.encoder = TransformerEncoder(params, is_conformer=(self.encoder_type == "conformer"))
         if self.decoder_type == "ctc":
             self.decoder = CTCDecoder(params)
+        elif self.decoder_type == "transformer":
+            from .decoders.transformer import TransformerDecoder
+            self.decoder = TransformerDecoder(params)
+            if hasattr(self.decoder, "ctc"):
+                self.decoder.ctc._owner = [self]
         else:
             raise NotImplementedError(f"emoasr_amd: decoder_type={self.decoder_type!r} is not built yet")
         self.encoder._owner = [self]  # list: keeps the back-reference out of nn.Module registration
@@ -45,6 +50,9 @@ class ASR(nn.Module):
     def forward(self, xs, xlens, ys, ylens, ys_in, ys_out, soft_labels=None, ps=None, plens=None):
         xs = xs[:, : int(max(xlens))]
         ys = ys[:, : int(max(ylens))]
+        if ys_in is not None:
+            ys_in = ys_in[:, : int(max(ylens)) + 1]
+            ys_out = ys_out[:, : int(max(ylens)) + 1]
         eouts, elens, eouts_inter = self.encoder(xs, xlens)
         loss, loss_dict, _ = self.decoder(eouts, elens, eouts_inter, ys, ylens, ys_in, ys_out, soft_labels, ps, plens)
         return loss, loss_dict

@@ -85,3 +85,17 @@ class Conv2dEncoder(_Holder):
         self.conv = nn.Sequential(nn.Conv2d(1, output_dim, 3, 2), nn.ReLU(), nn.Conv2d(output_dim, output_dim, 3, 2),
                                   nn.ReLU())
         self.output = nn.Linear(output_dim * (((input_dim - 1) // 2 - 1) // 2), output_dim)
+
+
+class TransformerDecoderLayer(_Holder):
+    """asr/modeling/transformer.py:156-180"""
+
+    def __init__(self, heads, hidden, inner):
+        super().__init__()
+        self.dec_hidden_size = hidden
+        self.self_attn = MultiHeadedAttention(heads, hidden)
+        self.src_attn = MultiHeadedAttention(heads, hidden)
+        self.feed_forward = PositionwiseFeedForward(hidden, inner)
+        self.norm1 = nn.LayerNorm(hidden, eps=1e-12)
+        self.norm2 = nn.LayerNorm(hidden, eps=1e-12)
+        self.norm3 = nn.LayerNorm(hidden, eps=1e-12)

@@ -99,3 +99,58 @@ def ctc_greedy_apply(dec, eouts, elens):
     hyps = [hyp_h[b, : n_h[b]].tolist() for b in range(len(n_h))]
     aligns = [best_h[b, : el[b]].tolist() for b in range(len(n_h))]
     return hyps, [None] * len(hyps), logits, aligns
+
+
+# ---------------------------------------------------------------------------------------
+# Transformer decoder: attention loss (+ auxiliary CTC) as one autograd node over the encoder output
+# ---------------------------------------------------------------------------------------
+class _AttnDecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, training, eouts, elens_dev, ys_host, ylens_host, ys_in, ys_out, blank, *params):
+        logits, st = eng.dec_forward(eouts, elens_dev, ys_in, ylens_host, training, True)
+        loss_att, _ = eng.att_loss(logits, ys_out, ylens_host)
+        loss_ctc, cctx, loss = None, None, loss_att
+        if eng.mtl_ctc > 0:
+            ctc_logits = eng.head_logits(eouts, "decoder.ctc.output")
+            loss_ctc, cctx = eng.ctc_loss(ctc_logits, elens_dev, ys_host, ylens_host, blank, True)
+            loss = loss_att + eng.mtl_ctc * loss_ctc
+        else:
+            loss_ctc = torch.zeros_like(loss_att)
+        ctx.eng, ctx.st, ctx.cctx, ctx.eouts, ctx.logits = eng, st, cctx, eouts, logits
+        ctx.ys_out, ctx.ylens_host = ys_out, ylens_host
+        ctx.mark_non_differentiable(logits)
+        return loss, loss_att, loss_ctc, logits
+
+    @staticmethod
+    def backward(ctx, g_total, g_att, g_ctc, _):
+        eng = ctx.eng
+        g_att_eff = (g_total + g_att).to(torch.float32).reshape(1)
+        _, dlogits = eng.att_loss(ctx.logits, ctx.ys_out, ctx.ylens_host, True, g_att_eff)
+        deouts = eng.dec_backward(ctx.st, dlogits)
+        if ctx.cctx is not None:
+            g_ctc_eff = (g_total * eng.mtl_ctc + g_ctc).to(torch.float32).reshape(1)
+            dcl = eng.ctc_grad(ctx.cctx, 1.0, g_ctc_eff)
+            from .. import ops
+            deouts = ops.add(deouts, eng.head_backward(ctx.eouts, dcl, "decoder.ctc.output"))
+        ctx.st = ctx.cctx = None
+        return (None, None, deouts, None, None, None, None, None, None) + (None,) * len(eng.arena.params)
+
+
+def attn_decoder_apply(dec, eouts, elens, ys, ylens, ys_in, ys_out):
+    eng = _engine_of(dec)
+    ylens_host = _host_list(ylens)
+    L = max(ylens_host) + 1
+    ys_host = ys.cpu() if torch.is_tensor(ys) else torch.as_tensor(ys)
+    ys_in = (ys_in.cpu() if torch.is_tensor(ys_in) else torch.as_tensor(ys_in))[:, :L]
+    ys_out = (ys_out.cpu() if torch.is_tensor(ys_out) else torch.as_tensor(ys_out))[:, :L]
+    return _AttnDecoderFn.apply(eng, dec.training, eouts, _elens_dev(eouts, elens), ys_host, ylens_host, ys_in, ys_out,
+                                dec.blank_id, *eng.arena.params)
+
+
+def attn_decoder_logits(dec, eouts, elens, ys_in, ylens):
+    eng = _engine_of(dec)
+    ys_in = ys_in.cpu() if torch.is_tensor(ys_in) else torch.as_tensor(ys_in)
+    ylens_host = _host_list(ylens) if ylens is not None else [ys_in.shape[1] - 1] * ys_in.shape[0]
+    with torch.no_grad():
+        logits, _ = eng.dec_forward(eouts, _elens_dev(eouts, elens), ys_in, ylens_host, dec.training, False)
+    return logits

@@ -420,6 +420,33 @@ def ctc_greedy(logits, elens, blank):
     return best, hyp, hyplen
 
 
+# ---- Transformer decoder side ------------------------------------------------------------
+def embed_fwd(ids, table, pe, scale, drop_p=0.0, seed=0):
+    """ids int32 [B,L]; table [V,d] (compute dtype); pe f32 [>=L,d] or None -> [B,L,d]"""
+    B, L = ids.shape
+    d = table.shape[1]
+    out = torch.empty(B, L, d, device=table.device, dtype=table.dtype)
+    lib.call("emoasr_embed_fwd", dt(table), B * L, L, d, _p(ids), _p(table), _p(pe), scale, drop_p, seed, _p(out),
+             _stream())
+    return out
+
+
+def embed_bwd(ids, dout, scale, dtable, drop_p=0.0, seed=0):
+    B, L = ids.shape
+    lib.call("emoasr_embed_bwd", dt(dout), B * L, dout.shape[-1], _p(ids), _p(dout), scale, drop_p, seed,
+             _p(_chk(dtable, torch.float32)), _stream())
+
+
+def lsm_loss(logits, labels, w, lsm_prob, want_grad=False, gscale=1.0, gscale_dev=None):
+    """logits [M,V]; labels int32 [M]; w f32 [M] row weights (0 = padded) -> (loss_rows f32 [M], grad | None)"""
+    M, V, ld = _rows(_chk(logits))
+    loss = torch.empty(M, device=logits.device, dtype=torch.float32)
+    grad = torch.empty_like(logits) if want_grad else None
+    lib.call("emoasr_lsm_loss", dt(logits), M, V, _p(logits), ld, _p(labels), _p(w), lsm_prob, _p(loss), gscale,
+             _p(gscale_dev), _p(grad), 0 if grad is None else grad.stride(0), _stream())
+    return loss, grad
+
+
 # ---- optimizer -------------------------------------------------------------------------
 def sqnorm(x, out):
     lib.call("emoasr_sqnorm", x.numel(), _p(_chk(x, torch.float32)), _p(out), _stream())

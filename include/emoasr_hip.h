@@ -216,6 +216,20 @@ int emoasr_ctc_grad(int dtype, int B, int T, int V, int Lmax, const void* logits
 int emoasr_ctc_greedy(int dtype, int B, int T, int V, const void* logits, long ld, const int* elens,
                       int blank, int* best, int* hyp, int* hyplen, void* stream);
 
+/* ---- Transformer decoder side (decoders/transformer.py:82-146, criteria.py:5-46) ---- */
+/* out[m,:] = (table[ids[m],:]*scale + pe[m % L,:]) * dropout   (embedding + PositionalEncoder) */
+int emoasr_embed_fwd(int dtype, int M, int L, int d, const int* ids, const void* table, const float* pe,
+                     float scale, float drop_p, uint64_t seed, void* out, void* stream);
+/* dtable[ids[m],:] += dout[m,:]*scale*dropout  (f32 atomics) */
+int emoasr_embed_bwd(int dtype, int M, int d, const int* ids, const void* dout, float scale, float drop_p,
+                     uint64_t seed, float* dtable, void* stream);
+/* LabelSmoothingLoss rows: w[m] = 0 for padded positions, else the row weight (1/B [/ylen]);
+ * loss[m] = -w*sum_v q[v]*log_softmax(logits[m])[v], q = 1-eps on labels[m], eps/(V-1) elsewhere;
+ * grad (may be NULL) = gscale*[gscale_dev]*w*(softmax - q) */
+int emoasr_lsm_loss(int dtype, int M, int V, const void* logits, long ld, const int* labels, const float* w,
+                    float lsm_prob, float* loss, float gscale, const float* gscale_dev, void* grad, long ldg,
+                    void* stream);
+
 /* ---- optimizer (asr/train_asr.py:84-92, torch.optim.Adam semantics) ---------- */
 /* out[0] += sum x^2 */
 int emoasr_sqnorm(long n, const float* x, float* out, void* stream);
