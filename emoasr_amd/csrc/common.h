@@ -111,16 +111,23 @@ __device__ __forceinline__ float dswishf_(float x) {
   return s * (1.f + x * (1.f - s));
 }
 
-enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_SWISH = 2 };
+enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_SWISH = 2, EMO_ACT_GELU = 3 };
+
+__device__ __forceinline__ float geluf_(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgeluf_(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
 
 __device__ __forceinline__ float apply_act(int act, float x) {
   if (act == EMO_ACT_RELU) return fmaxf(x, 0.f);
   if (act == EMO_ACT_SWISH) return swishf_(x);
+  if (act == EMO_ACT_GELU) return geluf_(x);
   return x;
 }
 __device__ __forceinline__ float apply_dact(int act, float pre) {
   if (act == EMO_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
   if (act == EMO_ACT_SWISH) return dswishf_(pre);
+  if (act == EMO_ACT_GELU) return dgeluf_(pre);
   return 1.f;
 }
 

@@ -111,3 +111,167 @@ extern "C" int emoasr_lsm_loss(int dtype, int M, int V, const void* logits, long
   EMO_LAUNCH_CHECK();
   return 0;
 }
+
+// =======================================================================================
+// Beam-search side kernels (asr/modeling/decoders/transformer.py:161-294, ctc_score.py:13-85)
+// =======================================================================================
+namespace {
+
+// out[m, v] = log_softmax(x[m, :V])[v] + mu * add[m, v]        (add optional, row stride lda)
+template <typename T>
+__global__ __launch_bounds__(256) void log_softmax_kernel(int V, const T* __restrict__ x, long ldx,
+                                                          const float* __restrict__ add, long lda, float mu,
+                                                          float* __restrict__ out, long ldo) {
+  __shared__ float red[16];
+  const long m = blockIdx.x;
+  const T* row = x + m * ldx;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, to_f32(row[v]));
+  mx = block_max(mx, red);
+  float se = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) se += expf(to_f32(row[v]) - mx);
+  se = block_sum(se, red);
+  const float lse = mx + logf(se);
+  for (int v = threadIdx.x; v < V; v += 256) {
+    float r = to_f32(row[v]) - lse;
+    if (add) r += mu * add[m * lda + v];
+    out[m * ldo + v] = r;
+  }
+}
+
+// k largest of each row, descending, ties -> lowest index.  k <= 64.  One block per row: k rounds of
+// block-wide arg-max over a private copy in LDS (V floats).
+__global__ __launch_bounds__(256) void topk_kernel(int V, int k, const float* __restrict__ x, long ldx,
+                                                   const float* __restrict__ aux, long ldaux,
+                                                   float* __restrict__ vals, int* __restrict__ idx,
+                                                   float* __restrict__ aux_out) {
+  extern __shared__ float buf[];  // [V]
+  __shared__ float rv[4];
+  __shared__ int ri[4];
+  const long m = blockIdx.x;
+  for (int v = threadIdx.x; v < V; v += 256) buf[v] = x[m * ldx + v];
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += 256) {
+      const float c = buf[v];
+      if (c > best || (c == best && v < bi)) { best = c; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
+      if (bi == 0x7fffffff) bi = 0;
+      vals[m * k + j] = best;
+      idx[m * k + j] = bi;
+      if (aux_out) aux_out[m * k + j] = aux[m * ldaux + bi];
+      buf[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
+#define EMO_LOG0 (-1e10f)
+__device__ __forceinline__ float np_logaddexp(float a, float b) {
+  // numpy.logaddexp semantics for finite inputs
+  const float d = a - b;
+  return d > 0.f ? a + log1pf(expf(-d)) : b + log1pf(expf(d));
+}
+
+// One block per beam m, one thread per candidate c.  x: CTC log-probs [T, V].
+// r_prev: the parent's state [T,2]: prev_states + (parent[m]*cw_prev + pcand[m]) * T*2, or init_state
+// when prev_states == NULL.  Outputs log_psi [nb, cw] and states [nb, cw, T, 2].
+__global__ void ctc_prefix_kernel(int Tn, int V, int cw, const float* __restrict__ x,
+                                  const float* __restrict__ prev_states, int cw_prev,
+                                  const int* __restrict__ parent, const int* __restrict__ pcand,
+                                  const float* __restrict__ init_state, const int* __restrict__ last,
+                                  const int* __restrict__ out_len, const int* __restrict__ cands, int blank,
+                                  int eos, float* __restrict__ log_psi, float* __restrict__ states) {
+  const int m = blockIdx.x, c = threadIdx.x;
+  if (c >= cw) return;
+  const float* rp = prev_states ? prev_states + ((long)parent[m] * cw_prev + pcand[m]) * Tn * 2 : init_state;
+  const int tok = cands[m * cw + c];
+  const int olen = out_len[m];
+  const bool same = olen > 0 && tok == last[m];
+  float* r = states + ((long)m * cw + c) * Tn * 2;
+  for (int t = 0; t < Tn; ++t) { r[2 * t] = EMO_LOG0; r[2 * t + 1] = EMO_LOG0; }
+  if (olen == 0) r[0] = x[tok];
+  const int start = olen > 1 ? olen : 1;
+  float rn = r[2 * (start - 1)], rb = r[2 * (start - 1) + 1];
+  float psi = rn;
+  for (int t = start; t < Tn; ++t) {
+    const float pn = rp[2 * (t - 1)], pb = rp[2 * (t - 1) + 1];
+    const float phi = same ? pb : np_logaddexp(pn, pb);
+    const float xt = x[(long)t * V + tok];
+    const float nn = np_logaddexp(rn, phi) + xt;
+    const float nb_ = np_logaddexp(rn, rb) + x[(long)t * V + blank];
+    psi = np_logaddexp(psi, phi + xt);
+    rn = nn; rb = nb_;
+    r[2 * t] = rn; r[2 * t + 1] = rb;
+  }
+  if (tok == eos) psi = np_logaddexp(rp[2 * (Tn - 1)], rp[2 * (Tn - 1) + 1]);
+  if (tok == blank) psi = EMO_LOG0;
+  log_psi[m * cw + c] = psi;
+}
+
+// initial state: r[t,1] = running sum of the blank log-probs (float32, step by step), r[t,0] = LOG_0
+__global__ void ctc_prefix_init_kernel(int Tn, int V, const float* __restrict__ x, int blank,
+                                       float* __restrict__ r) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float acc = 0.f;
+  for (int t = 0; t < Tn; ++t) {
+    acc = t == 0 ? x[blank] : acc + x[(long)t * V + blank];
+    r[2 * t] = EMO_LOG0;
+    r[2 * t + 1] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int emoasr_log_softmax(int dtype, int M, int V, const void* x, long ldx, const float* add, long lda,
+                                  float mu, float* out, long ldo, void* stream) {
+  if (M == 0) return 0;
+  EMO_DISPATCH(dtype, (log_softmax_kernel<T><<<M, 256, 0, (hipStream_t)stream>>>(V, (const T*)x, ldx, add, lda, mu,
+                                                                                out, ldo)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_topk(int M, int V, int k, const float* x, long ldx, const float* aux, long ldaux,
+                           float* vals, int* idx, float* aux_out, void* stream) {
+  if (M == 0) return 0;
+  EMO_CHECK(k >= 1 && k <= V, "topk: k=%d V=%d", k, V);
+  EMO_CHECK((size_t)V * 4 <= 150 * 1024, "topk: V=%d too large for an LDS row", V);
+  if ((size_t)V * 4 > 60 * 1024)
+    hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V * 4);
+  topk_kernel<<<M, 256, sizeof(float) * V, (hipStream_t)stream>>>(V, k, x, ldx, aux, ldaux, vals, idx, aux_out);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_ctc_prefix_init(int T, int V, const float* x, int blank, float* r, void* stream) {
+  ctc_prefix_init_kernel<<<1, 64, 0, (hipStream_t)stream>>>(T, V, x, blank, r);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_ctc_prefix_score(int nb, int T, int V, int cw, const float* x, const float* prev_states,
+                                       int cw_prev, const int* parent, const int* pcand, const float* init_state,
+                                       const int* last, const int* out_len, const int* cands, int blank, int eos,
+                                       float* log_psi, float* states, void* stream) {
+  if (nb == 0) return 0;
+  EMO_CHECK(cw >= 1 && cw <= 1024, "ctc_prefix_score: cw=%d", cw);
+  EMO_CHECK(prev_states || init_state, "ctc_prefix_score: no previous state");
+  ctc_prefix_kernel<<<nb, cdiv(cw, 64) * 64, 0, (hipStream_t)stream>>>(T, V, cw, x, prev_states, cw_prev, parent, pcand,
+                                                                     init_state, last, out_len, cands, blank, eos,
+                                                                     log_psi, states);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}

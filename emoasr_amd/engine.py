@@ -40,14 +40,18 @@ class ParamArena:
         for name, _ in named:
             if name in seen:
                 continue
+            group = None
             if name.endswith("linear_q.weight"):
                 base = name[: -len("linear_q.weight")]
                 group = [base + f"linear_{x}.{kind}" for kind in ("weight", "bias") for x in "qkv"]
-                if all(g in byname for g in group):
-                    for g in group:
-                        order.append(g)
-                        seen.add(g)
-                    continue
+            elif name.endswith("self.query.weight"):  # BERT-style LM layers
+                base = name[: -len("query.weight")]
+                group = [base + f"{x}.{kind}" for kind in ("weight", "bias") for x in ("query", "key", "value")]
+            if group is not None and all(g in byname for g in group):
+                for g in group:
+                    order.append(g)
+                    seen.add(g)
+                continue
             order.append(name)
             seen.add(name)
         self.names = order

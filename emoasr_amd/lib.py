@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libemoasr_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_GELU = 0, 1, 2, 3
 
 
 class Epilogue(Structure):
@@ -74,6 +74,10 @@ SIGNATURES = {
     "emoasr_embed_fwd": [I, I, I, I, P, P, P, F, F, U64, P, P],
     "emoasr_embed_bwd": [I, I, I, P, P, F, F, U64, P, P],
     "emoasr_lsm_loss": [I, I, I, P, L, P, P, F, P, F, P, P, L, P],
+    "emoasr_log_softmax": [I, I, I, P, L, P, L, F, P, L, P],
+    "emoasr_topk": [I, I, I, P, L, P, L, P, P, P, P],
+    "emoasr_ctc_prefix_init": [I, I, P, I, P, P],
+    "emoasr_ctc_prefix_score": [I, I, I, I, P, P, I, P, P, P, P, P, P, I, I, P, P, P],
     "emoasr_sqnorm": [L, P, P, P],
     "emoasr_adam_step": [L, P, P, P, P, F, F, F, F, F, I, P, F, F, P],
     "emoasr_specaug_apply": [I, I, I, P, P, I, I, P, P, P],

@@ -11,7 +11,7 @@ from ctypes import byref, c_void_p
 import torch
 
 from . import lib
-from .lib import ACT_NONE, ACT_RELU, ACT_SWISH, BF16, F32, AttnArgs, Epilogue  # noqa: F401
+from .lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SWISH, BF16, F32, AttnArgs, Epilogue  # noqa: F401
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -445,6 +445,46 @@ def lsm_loss(logits, labels, w, lsm_prob, want_grad=False, gscale=1.0, gscale_de
     lib.call("emoasr_lsm_loss", dt(logits), M, V, _p(logits), ld, _p(labels), _p(w), lsm_prob, _p(loss), gscale,
              _p(gscale_dev), _p(grad), 0 if grad is None else grad.stride(0), _stream())
     return loss, grad
+
+
+# ---- beam search -----------------------------------------------------------------------------
+def log_softmax(x, add=None, mu=0.0):
+    """x [M,V] (row stride allowed) -> f32 [M,V] = log_softmax(x) + mu*add[:, :V]"""
+    M, V, ld = _rows(_chk(x))
+    out = torch.empty(M, V, device=x.device, dtype=torch.float32)
+    lib.call("emoasr_log_softmax", dt(x), M, V, _p(x), ld, _p(add), 0 if add is None else add.stride(0), mu, _p(out),
+             V, _stream())
+    return out
+
+
+def topk(x, k, aux=None):
+    """x f32 [M,V] -> (vals [M,k], idx int32 [M,k], aux gathered [M,k] | None)"""
+    M, V, ld = _rows(_chk(x, torch.float32))
+    vals = torch.empty(M, k, device=x.device, dtype=torch.float32)
+    idx = torch.empty(M, k, device=x.device, dtype=torch.int32)
+    aux_out = torch.empty(M, k, device=x.device, dtype=torch.float32) if aux is not None else None
+    lib.call("emoasr_topk", M, V, k, _p(x), ld, _p(aux), 0 if aux is None else aux.stride(0), _p(vals), _p(idx),
+             _p(aux_out), _stream())
+    return vals, idx, aux_out
+
+
+def ctc_prefix_init(x, blank):
+    T, V = x.shape
+    r = torch.empty(T, 2, device=x.device, dtype=torch.float32)
+    lib.call("emoasr_ctc_prefix_init", T, V, _p(_chk(x, torch.float32)), blank, _p(r), _stream())
+    return r
+
+
+def ctc_prefix_score(x, cands, last, out_len, blank, eos, prev_states=None, parent=None, pcand=None, init_state=None):
+    """x f32 [T,V]; cands int32 [nb,cw]; last/out_len int32 [nb] -> (log_psi [nb,cw], states [nb,cw,T,2])"""
+    T, V = x.shape
+    nb, cw = cands.shape
+    log_psi = torch.empty(nb, cw, device=x.device, dtype=torch.float32)
+    states = torch.empty(nb, cw, T, 2, device=x.device, dtype=torch.float32)
+    cw_prev = 0 if prev_states is None else prev_states.shape[1]
+    lib.call("emoasr_ctc_prefix_score", nb, T, V, cw, _p(x), _p(prev_states), cw_prev, _p(parent), _p(pcand),
+             _p(init_state), _p(last), _p(out_len), _p(cands), blank, eos, _p(log_psi), _p(states), _stream())
+    return log_psi, states
 
 
 # ---- optimizer -------------------------------------------------------------------------

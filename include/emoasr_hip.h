@@ -230,6 +230,25 @@ int emoasr_lsm_loss(int dtype, int M, int V, const void* logits, long ld, const 
                     float lsm_prob, float* loss, float gscale, const float* gscale_dev, void* grad, long ldg,
                     void* stream);
 
+/* ---- joint CTC/attention beam search (decoders/transformer.py:161-294, ctc_score.py:13-85) ---- */
+/* out[m,v] = log_softmax(x[m,:V])[v] + mu*add[m,v]   (add may be NULL; f32 out) */
+int emoasr_log_softmax(int dtype, int M, int V, const void* x, long ldx, const float* add, long lda, float mu,
+                       float* out, long ldo, void* stream);
+/* k largest per row, descending, ties to the lowest index; aux (optional) is gathered at the same
+ * indices into aux_out */
+int emoasr_topk(int M, int V, int k, const float* x, long ldx, const float* aux, long ldaux, float* vals,
+                int* idx, float* aux_out, void* stream);
+/* CTCPrefixScorer.initial_state: r f32 [T,2] from the CTC log-probs x f32 [T,V] */
+int emoasr_ctc_prefix_init(int T, int V, const float* x, int blank, float* r, void* stream);
+/* CTCPrefixScorer.__call__ for nb beams x cw candidates.  Beam m's previous state is
+ * prev_states[parent[m], pcand[m]] (prev_states f32 [*, cw_prev, T, 2]) or init_state when
+ * prev_states == NULL; last[m] / out_len[m] = last label and number of labels of the prefix.
+ * -> log_psi f32 [nb,cw], states f32 [nb,cw,T,2] */
+int emoasr_ctc_prefix_score(int nb, int T, int V, int cw, const float* x, const float* prev_states, int cw_prev,
+                            const int* parent, const int* pcand, const float* init_state, const int* last,
+                            const int* out_len, const int* cands, int blank, int eos, float* log_psi,
+                            float* states, void* stream);
+
 /* ---- optimizer (asr/train_asr.py:84-92, torch.optim.Adam semantics) ---------- */
 /* out[0] += sum x^2 */
 int emoasr_sqnorm(long n, const float* x, float* out, void* stream);

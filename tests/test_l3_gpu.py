@@ -78,3 +78,96 @@ def test_label_smoothing_module(dev):
         (got * 2.0).backward()
         assert abs(got.item() - ref.item()) < 1e-4 * abs(ref.item())
         assert torch.allclose(x.grad.cpu(), 2.0 * ref_in.grad, rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------- decode side
+def test_log_softmax_topk(dev):
+    from emoasr_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(5, 1000, device=dev)
+    add = torch.randn(5, 1200, device=dev)
+    out = ops.log_softmax(x, add=add, mu=0.3)
+    ref = torch.log_softmax(x, -1) + 0.3 * add[:, :1000]
+    assert torch.allclose(out, ref, atol=1e-5)
+    xb = torch.randn(3, 7, 40, device=dev).to(torch.bfloat16)
+    out = ops.log_softmax(xb[:, 6])
+    assert torch.allclose(out, torch.log_softmax(xb[:, 6].float(), -1), atol=1e-5)
+    ref[0, 10] = ref[0, 20] = 99.0  # tie -> lowest index first
+    vals, idx, aux = ops.topk(ref, 15, aux=add)
+    tv, ti = torch.topk(ref, 15, dim=1)
+    assert torch.equal(vals, tv)
+    assert idx[0, 0].item() == 10 and idx[0, 1].item() == 20
+    assert torch.equal(idx[1:].long(), ti[1:])
+    assert torch.equal(aux, torch.gather(add, 1, idx.long()))
+
+
+def test_ctc_prefix_scorer_kernel(dev):
+    import numpy as np
+    from emoasr_amd import ops
+    from oracle.decoder import CTCPrefixScorer
+    rs = np.random.RandomState(0)
+    T, V, blank, eos = 37, 40, 0, 2
+    x = np.log(rs.dirichlet(np.ones(V) * 0.5, size=T)).astype(np.float32)
+    sc = CTCPrefixScorer(x, blank, eos)
+    xd = torch.from_numpy(x).to(dev)
+    r0 = ops.ctc_prefix_init(xd, blank)
+    assert np.allclose(r0.cpu().numpy(), sc.initial_state(), rtol=1e-6, atol=1e-4)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    # step 0: one beam [eos]; step 1: two beams extending candidates 1 and 3 of step 0
+    c0 = np.array([[5, 2, 0, 7, 9]], dtype=np.int32)
+    psi0, st0 = ops.ctc_prefix_score(xd, i32(c0), i32([eos]), i32([0]), blank, eos, init_state=r0)
+    ref_psi0, ref_st0 = sc([eos], c0[0], sc.initial_state())
+    assert np.allclose(psi0.cpu().numpy()[0], ref_psi0, rtol=1e-5, atol=1e-4)
+    c1 = np.array([[5, 2, 7, 11, 0], [7, 7, 2, 5, 30]], dtype=np.int32)
+    hyps = [[eos, 5], [eos, 7]]
+    psi1, st1 = ops.ctc_prefix_score(xd, i32(c1), i32([5, 7]), i32([1, 1]), blank, eos, prev_states=st0, parent=i32([0, 0]),
+                                     pcand=i32([0, 3]))
+    for m, (hyp, pc) in enumerate(zip(hyps, [0, 3])):
+        ref_psi, ref_st = sc(hyp, c1[m], ref_st0[pc])
+        assert np.allclose(psi1.cpu().numpy()[m], ref_psi, rtol=1e-5, atol=1e-4), m
+        got = st1.cpu().numpy()[m][:, 1:]
+        assert np.allclose(got, ref_st[:, 1:], rtol=1e-5, atol=1e-4), m
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_lm_predict(dev, dtype):
+    from emoasr_amd.modeling.lm import LM
+    cfg, sd, g = load_golden("l3_tiny")
+    lm = LM(SimpleNamespace(**LM_CFG), compute_dtype=dtype)
+    lm.load_state_dict(lm_state(g))
+    lm = lm.to(dev).eval()
+    lp, states = lm.predict(g["lm_test/ys"], g["lm_test/ylens"])
+    assert states is None and lp.shape == g["lm_test/logp"].shape
+    err = (lp.cpu() - g["lm_test/logp"]).abs().max().item()
+    assert err < (2e-3 if dtype == torch.float32 else 0.15), err
+
+
+def test_joint_beam_search_f32(dev):
+    """hypotheses identical to the reference's, scores within 1e-3, for attention-only, +CTC, +CTC+LM, +LM"""
+    from emoasr_amd.modeling.lm import LM
+    model, g = _build(torch.float32, dev)
+    model.eval()
+    lm = LM(SimpleNamespace(**LM_CFG), compute_dtype=torch.float32)
+    lm.load_state_dict(lm_state(g))
+    lm = lm.to(dev).eval()
+    for si, st in enumerate(DECODE_SETTINGS):
+        for b in range(2):
+            n = int(g["xlens"][b])
+            hyps, scores, _, _ = model.decode(g["xs"][b:b + 1, :n].to(dev), g["xlens"][b:b + 1], lm=lm, **st)
+            want = split_ragged(g[f"decode/{si}/{b}/hyps"], g[f"decode/{si}/{b}/lens"])
+            assert hyps == want, (si, b, hyps, want)
+            ref = g[f"decode/{si}/{b}/scores"].numpy()
+            assert max(abs(a - c) for a, c in zip(scores, ref)) < 1e-2 + 1e-3 * abs(ref).max(), (si, b, scores, ref)
+
+
+def test_joint_beam_search_bf16_runs(dev):
+    from emoasr_amd.modeling.lm import LM
+    model, g = _build(torch.bfloat16, dev)
+    model.eval()
+    lm = LM(SimpleNamespace(**LM_CFG), compute_dtype=torch.bfloat16)
+    lm.load_state_dict(lm_state(g))
+    lm = lm.to(dev).eval()
+    n = int(g["xlens"][0])
+    hyps, scores, _, _ = model.decode(g["xs"][:1, :n].to(dev), g["xlens"][:1], lm=lm, **DECODE_SETTINGS[2])
+    ref = g["decode/2/0/scores"].numpy()
+    assert len(hyps) >= 1 and abs(scores[0] - ref[0]) < 0.05 * abs(ref[0])
