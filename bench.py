@@ -164,6 +164,46 @@ def decode_rtf(model, dev, n_utts=20, repeats=3):
     return best
 
 
+L3 = dict(L2, decoder_type="transformer", dec_hidden_size=256, dec_num_attention_heads=4, dec_num_layers=6,
+          dec_intermediate_size=1024, dropout_dec_rate=0.1, mtl_ctc_weight=0.3, lsm_prob=0.1,
+          loss_normalize_length=False, loss_normalize_batch=True, max_decode_ylen=256)
+LM12 = dict(lm_type="transformer", vocab_size=10000, hidden_size=256, num_layers=12, num_attention_heads=4,
+            intermediate_size=1024, max_seq_len=256)
+
+
+def decode_rtf_l33(dev, dtype, n_utts=5):
+    """config 4 (`L3-3`): joint CTC+attention beam 10 with Transformer-LM shallow fusion, batch 1.
+    Random-init weights never emit <eos>, so every utterance is decoded for exactly
+    ylen+1 = round(xlen/30)+1 output steps with a full beam (max_decode_ylen is set per utterance):
+    the per-step work of a real decode of that length, without early termination."""
+    import math
+    from emoasr_amd.data import libri_shaped_lengths
+    from emoasr_amd.modeling.asr import ASR
+    from emoasr_amd.modeling.lm import LM
+    torch.manual_seed(1)
+    model = ASR(SimpleNamespace(**L3), compute_dtype=dtype).to(dev).eval()
+    lm = LM(SimpleNamespace(**LM12), compute_dtype=dtype).to(dev).eval()
+    xlens, _ = libri_shaped_lengths(2000, 0)
+    rs = np.random.RandomState(2)
+    pick = rs.choice(len(xlens), n_utts, replace=False)
+    utts = [(torch.randn(1, int(xlens[i]), 80).to(dev), [int(xlens[i])]) for i in pick]
+    kw = dict(beam_width=10, len_weight=0.0, lm=lm, lm_weight=0.3, decode_ctc_weight=0.3)
+    model.decoder.max_decode_ylen = 8
+    model.decode(*utts[0], **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = []
+    for x, l in utts:
+        model.decoder.max_decode_ylen = max(1, round(l[0] / 30.0)) + 1
+        steps.append(model.decoder.max_decode_ylen)
+        model.decode(x, l, **kw)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    audio = sum(l[0] for _, l in utts) * 0.010
+    return dict(rtf=wall / audio, mean_out_steps=float(np.mean(steps)), ms_per_step=1e3 * wall / sum(steps), utts=n_utts,
+                beam=10, lm_weight=0.3, decode_ctc_weight=0.3, forced_steps=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,6 +323,7 @@ def main():
             print(f"  total instrumented GPU time {tot:.2f} ms (one step, B={len(batches[args.warmup - 1].xlens)})", file=sys.stderr)
         if world == 1 and not args.no_decode:
             res["decode_rtf"] = decode_rtf(model, dev)
+            res["decode_l33"] = decode_rtf_l33(dev, dtype)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(res), flush=True)
