@@ -179,7 +179,75 @@ def run_l3():
     print("l3_tiny loss", float(loss.detach()), {k: float(v) for k, v in loss_dict.items()})
 
 
+L4 = dict(COMMON, encoder_type="conformer", decoder_type="rnn_transducer", pos_encode_type="rel",
+          embedding_size=64, dec_hidden_size=128, dec_num_layers=2, joint_hidden_size=128, dropout_emb_rate=0.0,
+          mtl_ctc_weight=0.3)
+
+
+def run_l4():
+    """RNN-T.  warp_rnnt is absent: the reference network runs with oracle.rnnt.rnnt_loss plugged in as
+    warp_rnnt.rnnt_loss (loss value unpinned; LSTM / joint / aux CTC / greedy decode pinned)."""
+    sys.path.insert(0, "/root/repo")
+    from oracle import rnnt as orn
+    sys.modules["warp_rnnt"].rnnt_loss = orn.rnnt_loss
+    sys.modules["warp_rnnt"].__version__ = "oracle-restatement"
+    import asr.modeling.decoders.rnn_transducer as rt
+    rt.warp_rnnt = sys.modules["warp_rnnt"]
+    torch.manual_seed(0)
+    model = ASR(make_params(L4), phase="train")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".norm" in n or "batch_norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    xs, xlens, ys, ylens, ys_in, ys_out = make_batch(1, L4["feat_dim"], L4["vocab_size"])
+    # a random-init transducer either never or always emits blank; fit the tiny model to this batch for a
+    # couple of hundred Adam steps so that greedy decoding produces real label/blank interleavings
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    model.train()
+    for it in range(int(os.environ.get("L4_FIT_STEPS", 120))):
+        opt.zero_grad()
+        l, _ = model(xs, xlens, ys, ylens, ys_in, ys_out)
+        l.backward()
+        opt.step()
+        if it % 50 == 0:
+            print("  fit", it, float(l.detach()))
+    out = {}
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    for k, v in sd0.items():
+        out["sd/" + k] = v.numpy()
+    out.update(xs=xs.numpy(), xlens=xlens.numpy(), ys=ys.numpy(), ylens=ylens.numpy(), ys_in=ys_in.numpy(),
+               ys_out=ys_out.numpy())
+    model.train()
+    loss, loss_dict = model(xs, xlens, ys, ylens, ys_in, ys_out)
+    loss.backward()
+    out["train/loss"] = loss.detach().numpy()
+    out["train/loss_rnnt"] = loss_dict["loss_rnnt"].detach().numpy()
+    out["train/loss_ctc"] = loss_dict["loss_ctc"].detach().numpy()
+    for n, p in model.named_parameters():
+        out["grad/" + n] = p.grad.clone().numpy()
+    model.load_state_dict(sd0)
+    model.eval()
+    with torch.no_grad():
+        eouts, elens, _ = model.encoder(xs, xlens)
+        douts, _ = model.decoder.recurrency(ys_in, None)
+        out["eval/douts"] = douts.numpy()
+        out["eval/joint_logits_b0"] = model.decoder.joint(eouts[:1, :20], douts[:1]).numpy()
+        hyps, _, _, aligns = model.decoder._greedy(eouts, elens)
+    out["eval/hyp_lens"] = np.array([len(h) for h in hyps])
+    out["eval/hyps"] = np.array(sum(hyps, []), dtype=np.int64)
+    out["eval/align_lens"] = np.array([len(a) for a in aligns])
+    out["eval/aligns"] = np.array(sum(aligns, []), dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "l4_tiny.npz"), **out)
+    print("l4_tiny loss", float(loss.detach()), {k: float(v) for k, v in loss_dict.items()}, "hyp lens",
+          [len(h) for h in hyps], "align lens", [len(a) for a in aligns])
+
+
 if __name__ == "__main__":
-    for name, cfg in CONFIGS.items():
-        run_ctc(name, cfg)
-    run_l3()
+    which = sys.argv[1:] or ["ctc", "l3", "l4"]
+    if "ctc" in which:
+        for name, cfg in CONFIGS.items():
+            run_ctc(name, cfg)
+    if "l3" in which:
+        run_l3()
+    if "l4" in which:
+        run_l4()

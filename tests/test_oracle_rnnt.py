@@ -1,0 +1,87 @@
+"""Oracle part 3 (RNN-T): the transducer loss restatement is validated by brute-force path
+enumeration and finite differences (warp_rnnt is absent: parity unpinned for the loss value);
+the network around it is pinned to the reference through tests/golden/l4_tiny.npz."""
+import itertools
+
+import numpy as np
+import torch
+
+from oracle import model as om
+from oracle import rnnt as orn
+from tests.util import load_golden, split_ragged
+
+
+def _brute(lp, labels, T, U, blank):
+    """sum over all monotone paths: T blanks (one per frame) interleaved with U labels in order"""
+    total = 0.0
+    for pos in itertools.combinations(range(T + U), U):  # positions of label emissions
+        t = u = 0
+        logp = 0.0
+        ok = True
+        for step in range(T + U):
+            if step in pos:
+                logp += lp[t, u, labels[u]].item()
+                u += 1
+            else:
+                logp += lp[t, u, blank].item()
+                t += 1
+            if t == T and step < T + U - 1:
+                ok = False  # the last blank must be the final step
+                break
+        if ok and t == T and u == U:
+            total += np.exp(logp)
+    return -np.log(total)
+
+
+def test_loss_against_path_enumeration():
+    torch.manual_seed(0)
+    for T, U in [(1, 0), (3, 2), (4, 3), (2, 3)]:
+        V = 5
+        lp = torch.log_softmax(torch.randn(1, T, U + 1, V, dtype=torch.float64), -1)
+        labels = torch.randint(1, V, (1, max(U, 1)))
+        got = orn.rnnt_nll(lp, labels, [T], [U], blank=0)[0].item()
+        assert abs(got - _brute(lp[0], labels[0], T, U, 0)) < 1e-9, (T, U)
+
+
+def test_loss_gradient_finite_differences():
+    torch.manual_seed(1)
+    T, U, V = 4, 2, 4
+    z = torch.randn(2, T, U + 1, V, dtype=torch.float64, requires_grad=True)
+    labels = torch.randint(1, V, (2, U))
+    flens, llens = [4, 3], [2, 1]
+    f = lambda x: orn.rnnt_loss(torch.log_softmax(x, -1), labels, flens, llens, reduction="mean", blank=0)
+    assert torch.autograd.gradcheck(f, (z,), eps=1e-6, atol=1e-6)
+    # cells outside (flens, llens) get no gradient
+    f(z).backward()
+    assert z.grad[1, 3].abs().max() == 0 and z.grad[1, :, 2].abs().max() == 0
+
+
+def test_network_pinned_to_reference():
+    cfg, sd, g = load_golden("l4_tiny")
+    with torch.no_grad():
+        eouts, elens = om.encoder_forward(sd, cfg, g["xs"], g["xlens"])
+        douts, _ = orn.recurrency(sd, cfg, g["ys_in"])
+        jl = orn.joint(sd, eouts[:1, :20], douts[:1])
+        hyps, aligns = orn.rnnt_greedy(sd, cfg, eouts, elens)
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    assert rel(douts, g["eval/douts"]) < 1e-4
+    assert rel(jl, g["eval/joint_logits_b0"]) < 1e-4
+    assert hyps == split_ragged(g["eval/hyps"], g["eval/hyp_lens"])
+    assert aligns == split_ragged(g["eval/aligns"], g["eval/align_lens"])
+
+
+def test_train_loss_and_grads():
+    cfg, sd, g = load_golden("l4_tiny")
+    sd = {k: v.clone() for k, v in sd.items()}
+    params = {k: v for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    for v in params.values():
+        v.requires_grad_(True)
+    eouts, elens = om.encoder_forward(sd, cfg, g["xs"], g["xlens"], training=True)
+    loss, ld, _ = orn.rnnt_decoder_forward(sd, cfg, eouts, elens, g["ys"], g["ylens"], g["ys_in"])
+    loss.backward()
+    for k, ref in (("loss_rnnt", "train/loss_rnnt"), ("loss_ctc", "train/loss_ctc"), ("loss_total", "train/loss")):
+        assert abs(ld[k].item() - g[ref].item()) < 1e-4 * abs(g[ref].item()), k
+    gmax = max(g["grad/" + k].abs().max().item() for k in params)
+    worst = max(((v.grad - g["grad/" + k]).abs().max() / max(g["grad/" + k].abs().max().item(), 1e-2 * gmax)).item()
+                for k, v in params.items())
+    assert worst < 5e-3, worst

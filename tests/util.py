@@ -21,6 +21,10 @@ L3 = dict(COMMON, encoder_type="conformer", decoder_type="transformer", pos_enco
           dec_hidden_size=128, dec_num_attention_heads=2, dec_num_layers=2, dec_intermediate_size=256,
           mtl_ctc_weight=0.3, loss_normalize_length=False, loss_normalize_batch=True, max_decode_ylen=20)
 CONFIGS["l3_tiny"] = L3
+L4 = dict(COMMON, encoder_type="conformer", decoder_type="rnn_transducer", pos_encode_type="rel",
+          embedding_size=64, dec_hidden_size=128, dec_num_layers=2, joint_hidden_size=128, dropout_emb_rate=0.0,
+          mtl_ctc_weight=0.3)
+CONFIGS["l4_tiny"] = L4
 LM_CFG = dict(lm_type="transformer", vocab_size=40, hidden_size=128, num_layers=2, num_attention_heads=2,
               intermediate_size=256, max_seq_len=64)
 DECODE_SETTINGS = [dict(beam_width=4, len_weight=0.0, lm_weight=0.0, decode_ctc_weight=0.0),
