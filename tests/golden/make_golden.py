@@ -211,6 +211,7 @@ def run_l4():
         opt.step()
         if it % 50 == 0:
             print("  fit", it, float(l.detach()))
+    opt.zero_grad()
     out = {}
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     for k, v in sd0.items():
