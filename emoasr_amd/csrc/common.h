@@ -111,7 +111,8 @@ __device__ __forceinline__ float dswishf_(float x) {
   return s * (1.f + x * (1.f - s));
 }
 
-enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_SWISH = 2, EMO_ACT_GELU = 3 };
+enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_SWISH = 2, EMO_ACT_GELU = 3, EMO_ACT_TANH = 4,
+       EMO_DACT_TANH_OUT = 5 };
 
 __device__ __forceinline__ float geluf_(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgeluf_(float x) {
@@ -122,12 +123,15 @@ __device__ __forceinline__ float apply_act(int act, float x) {
   if (act == EMO_ACT_RELU) return fmaxf(x, 0.f);
   if (act == EMO_ACT_SWISH) return swishf_(x);
   if (act == EMO_ACT_GELU) return geluf_(x);
+  if (act == EMO_ACT_TANH) return tanhf(x);
   return x;
 }
 __device__ __forceinline__ float apply_dact(int act, float pre) {
   if (act == EMO_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
   if (act == EMO_ACT_SWISH) return dswishf_(pre);
   if (act == EMO_ACT_GELU) return dgeluf_(pre);
+  if (act == EMO_ACT_TANH) { const float t = tanhf(pre); return 1.f - t * t; }
+  if (act == EMO_DACT_TANH_OUT) return 1.f - pre * pre;  // `pre` holds tanh's OUTPUT here
   return 1.f;
 }
 

@@ -1,0 +1,327 @@
+// RNN-Transducer decoder kernels: LSTM cell (prediction network), joint-network broadcast/tanh and
+// its reductions, transducer lattice (alpha/beta over anti-diagonals) with the gradient w.r.t. the
+// joint logits, row arg-max for greedy decoding.
+//
+// Reference: asr/modeling/decoders/rnn_transducer.py:81-240 (recurrency :158-192, joint :147-156,
+// loss call :102-115 -> third-party warp_rnnt.rnnt_loss, greedy :194-240).  The loss follows the
+// published transducer forward-backward (Graves 2012) with that call's semantics: log-softmax
+// over V per (t,u) cell, blank index, mean over the batch, no frame averaging; it is checked against
+// oracle/rnnt.py (path enumeration) -- warp_rnnt itself is absent, parity unpinned.
+#include "common.h"
+#include "../../include/emoasr_hip.h"
+
+namespace {
+
+// gates_pre [B,4H] (i|f|g|o pre-activations), c_prev f32 [B,H] (NULL = zeros)
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(int B, int H, const T* __restrict__ gp,
+                                                            const float* __restrict__ c_prev,
+                                                            T* __restrict__ h, long ldh, float* __restrict__ c,
+                                                            T* __restrict__ ga) {
+  const int n = B * H;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int b = i / H, j = i % H;
+    const T* g4 = gp + (long)b * 4 * H;
+    const float ig = sigmoidf_(to_f32(g4[j])), fg = sigmoidf_(to_f32(g4[H + j]));
+    const float gg = tanhf(to_f32(g4[2 * H + j])), og = sigmoidf_(to_f32(g4[3 * H + j]));
+    const float cn = fg * (c_prev ? c_prev[i] : 0.f) + ig * gg;
+    c[i] = cn;
+    h[(long)b * ldh + j] = from_f32<T>(og * tanhf(cn));
+    T* a4 = ga + (long)b * 4 * H;
+    a4[j] = from_f32<T>(ig); a4[H + j] = from_f32<T>(fg); a4[2 * H + j] = from_f32<T>(gg); a4[3 * H + j] = from_f32<T>(og);
+  }
+}
+
+// dh_out (from the layer above, row stride lddh) + dh_rec (recurrent, may be NULL) ; dc in/out f32
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(int B, int H, const T* __restrict__ dh_out, long lddh,
+                                                            const T* __restrict__ dh_rec,
+                                                            float* __restrict__ dc, const T* __restrict__ ga,
+                                                            const float* __restrict__ c_prev,
+                                                            const float* __restrict__ c, T* __restrict__ dgp) {
+  const int n = B * H;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int b = i / H, j = i % H;
+    const T* a4 = ga + (long)b * 4 * H;
+    const float ig = to_f32(a4[j]), fg = to_f32(a4[H + j]), gg = to_f32(a4[2 * H + j]), og = to_f32(a4[3 * H + j]);
+    float dh = to_f32(dh_out[(long)b * lddh + j]);
+    if (dh_rec) dh += to_f32(dh_rec[i]);
+    const float tc = tanhf(c[i]);
+    const float dct = dc[i] + dh * og * (1.f - tc * tc);
+    const float cp = c_prev ? c_prev[i] : 0.f;
+    T* d4 = dgp + (long)b * 4 * H;
+    d4[j] = from_f32<T>(dct * gg * ig * (1.f - ig));
+    d4[H + j] = from_f32<T>(dct * cp * fg * (1.f - fg));
+    d4[2 * H + j] = from_f32<T>(dct * ig * (1.f - gg * gg));
+    d4[3 * H + j] = from_f32<T>(dh * tc * og * (1.f - og));
+    dc[i] = dct * fg;
+  }
+}
+
+// h[b,t,u,:] = tanh(e[b,t,:] + g[b,u,:])
+template <typename T>
+__global__ __launch_bounds__(256) void joint_tanh_kernel(long n, int Tn, int U, int J, const T* __restrict__ e,
+                                                         const T* __restrict__ g, T* __restrict__ h) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int j = i % J;
+    long r = i / J;
+    const int u = r % U; r /= U;
+    const int t = r % Tn;
+    const long b = r / Tn;
+    h[i] = from_f32<T>(tanhf(to_f32(e[(b * Tn + t) * J + j]) + to_f32(g[(b * U + u) * J + j])));
+  }
+}
+// mode 0: de[b,t,j] = sum_u d[b,t,u,j];  mode 1: dg[b,u,j] = sum_t d[b,t,u,j]
+template <typename T>
+__global__ __launch_bounds__(256) void joint_reduce_kernel(int mode, int Bn, int Tn, int U, int J,
+                                                           const T* __restrict__ d, T* __restrict__ out) {
+  const long n = (long)Bn * (mode == 0 ? Tn : U) * J;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int j = i % J;
+    long r = i / J;
+    float s = 0.f;
+    if (mode == 0) {
+      const int t = r % Tn; const long b = r / Tn;
+      const T* p = d + ((b * Tn + t) * U) * J + j;
+      for (int u = 0; u < U; ++u) s += to_f32(p[(long)u * J]);
+    } else {
+      const int u = r % U; const long b = r / U;
+      const T* p = d + ((b * Tn) * U + u) * J + j;
+      for (int t = 0; t < Tn; ++t) s += to_f32(p[(long)t * U * J]);
+    }
+    out[i] = from_f32<T>(s);
+  }
+}
+
+// one wave per (b,t,u) row: lse over V, blank and label log-probs
+template <typename T>
+__global__ __launch_bounds__(256) void rnnt_gather_kernel(long rows, int Tn, int U, int V, int Lmax,
+                                                          const T* __restrict__ z, const int* __restrict__ labels,
+                                                          const int* __restrict__ ylens, int blank,
+                                                          float* __restrict__ lse, float* __restrict__ lpb,
+                                                          float* __restrict__ lpy) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* zr = z + row * V;
+  float m = -INFINITY;
+  for (int v = lane; v < V; v += 64) m = fmaxf(m, to_f32(zr[v]));
+  m = wave_max(m);
+  float s = 0.f;
+  for (int v = lane; v < V; v += 64) s += __expf(to_f32(zr[v]) - m);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float l = m + logf(s);
+    const int u = row % U;
+    const long b = row / ((long)Tn * U);
+    lse[row] = l;
+    lpb[row] = to_f32(zr[blank]) - l;
+    lpy[row] = u < ylens[b] ? to_f32(zr[labels[b * Lmax + u]]) - l : -INFINITY;
+  }
+}
+
+// blocks [0,B): alpha; [B,2B): beta.  Threads = label positions u; anti-diagonals d = t + u.
+__global__ __launch_bounds__(1024) void rnnt_lattice_kernel(int Bn, int Tn, int U, const float* __restrict__ lpb,
+                                                            const float* __restrict__ lpy,
+                                                            const int* __restrict__ elens,
+                                                            const int* __restrict__ ylens,
+                                                            float* __restrict__ alpha, float* __restrict__ beta,
+                                                            float* __restrict__ nll) {
+  extern __shared__ float sh[];  // [2][U+2]
+  const bool fwd = blockIdx.x < Bn;
+  const int b = fwd ? blockIdx.x : blockIdx.x - Bn;
+  const int u = threadIdx.x;
+  const int T = min(elens[b], Tn), Ub = ylens[b];  // valid cells: t < T, u <= Ub
+  const float* pb = lpb + (long)b * Tn * U;
+  const float* py = lpy + (long)b * Tn * U;
+  float* out = (fwd ? alpha : beta) + (long)b * Tn * U;
+  float* cur = sh + 1;
+  float* prv = sh + (U + 2) + 1;
+  if (T <= 0) { if (fwd && u == 0) nll[b] = INFINITY; return; }
+  for (int i = threadIdx.x; i < 2 * (U + 2); i += blockDim.x) sh[i] = -INFINITY;
+  __syncthreads();
+  float own = -INFINITY;  // this thread's value on its previous diagonal (alpha[t-1,u] / beta[t+1,u])
+  const int nd = T + Ub;  // diagonals 0 .. T+Ub-1
+  for (int d = 0; d < nd; ++d) {
+    float v = -INFINITY;
+    bool act = false;
+    if (fwd) {
+      const int t = d - u;
+      if (u <= Ub && t >= 0 && t < T) {
+        act = true;
+        if (t == 0 && u == 0) v = 0.f;
+        else {
+          const float stay = t > 0 ? own + pb[(long)(t - 1) * U + u] : -INFINITY;
+          const float emit = u > 0 ? prv[u - 1] + py[(long)t * U + u - 1] : -INFINITY;
+          v = log_add(stay, emit);
+        }
+        out[(long)t * U + u] = v;
+      }
+    } else {
+      // reversed diagonal: t = T-1 - (d - (Ub - u))
+      const int t = T - 1 - (d - (Ub - u));
+      if (u <= Ub && t >= 0 && t < T && d - (Ub - u) >= 0) {
+        act = true;
+        if (t == T - 1 && u == Ub) v = pb[(long)t * U + u];
+        else {
+          const float stay = t < T - 1 ? own + pb[(long)t * U + u] : -INFINITY;
+          const float emit = u < Ub ? prv[u + 1] + py[(long)t * U + u] : -INFINITY;
+          v = log_add(stay, emit);
+        }
+        out[(long)t * U + u] = v;
+      }
+    }
+    if (u < U) cur[u] = act ? v : -INFINITY;
+    if (act) own = v;
+    __syncthreads();
+    float* tmp = cur; cur = prv; prv = tmp;
+  }
+  if (fwd && u == 0) nll[b] = -(out[(long)(T - 1) * U + Ub] + pb[(long)(T - 1) * U + Ub]);
+}
+
+// one wave per row: dz = gs * (p * occ - [v=blank] gb - [v=y] gy), zero outside the valid lattice
+template <typename T>
+__global__ __launch_bounds__(256) void rnnt_grad_kernel(long rows, int Tn, int U, int V, int Lmax,
+                                                        const T* __restrict__ z, const float* __restrict__ lse,
+                                                        const float* __restrict__ lpb, const float* __restrict__ lpy,
+                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                        const int* __restrict__ labels, const int* __restrict__ elens,
+                                                        const int* __restrict__ ylens, const float* __restrict__ nll,
+                                                        int blank, float gscale, const float* __restrict__ gscale_dev,
+                                                        T* __restrict__ dz) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int u = row % U;
+  const int t = (row / U) % Tn;
+  const long b = row / ((long)Tn * U);
+  const int Tb = min(elens[b], Tn), Ub = ylens[b];
+  T* dr = dz + row * V;
+  const float nl = nll[b];
+  if (t >= Tb || u > Ub || !isfinite(nl)) {
+    for (int v = lane; v < V; v += 64) dr[v] = from_f32<T>(0.f);
+    return;
+  }
+  const float gs = gscale_dev ? gscale * gscale_dev[0] : gscale;
+  const float a = alpha[row];
+  float gb = 0.f, gy = 0.f;
+  if (t == Tb - 1) { if (u == Ub) gb = __expf(a + lpb[row] + nl); }
+  else gb = __expf(a + lpb[row] + beta[row + U] + nl);
+  int y = -1;
+  if (u < Ub) { y = labels[b * Lmax + u]; gy = __expf(a + lpy[row] + beta[row + 1] + nl); }
+  const float occ = gb + gy;
+  const float l = lse[row];
+  const T* zr = z + row * V;
+  for (int v = lane; v < V; v += 64) {
+    float g = __expf(to_f32(zr[v]) - l) * occ;
+    if (v == blank) g -= gb;
+    if (v == y) g -= gy;
+    dr[v] = from_f32<T>(g * gs);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(int V, const T* __restrict__ x, long ldx,
+                                                          int* __restrict__ out) {
+  __shared__ float rv[4];
+  __shared__ int ri[4];
+  const T* row = x + (long)blockIdx.x * ldx;
+  float m = -INFINITY; int mi = 0x7fffffff;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float c = to_f32(row[v]);
+    if (c > m || (c == m && v < mi)) { m = c; mi = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o, 64);
+    const int oi = __shfl_xor(mi, o, 64);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = m; ri[threadIdx.x >> 6] = mi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (rv[w] > m || (rv[w] == m && ri[w] < mi)) { m = rv[w]; mi = ri[w]; }
+    out[blockIdx.x] = mi == 0x7fffffff ? 0 : mi;
+  }
+}
+
+inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+
+extern "C" int emoasr_lstm_cell_fwd(int dtype, int B, int H, const void* gates_pre, const float* c_prev, void* h,
+                                    long ldh, float* c, void* gates_act, void* stream) {
+  if (B == 0) return 0;
+  EMO_DISPATCH(dtype, (lstm_cell_fwd_kernel<T><<<ew_grid((long)B * H), 256, 0, (hipStream_t)stream>>>(
+                          B, H, (const T*)gates_pre, c_prev, (T*)h, ldh, c, (T*)gates_act)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_lstm_cell_bwd(int dtype, int B, int H, const void* dh_out, long lddh, const void* dh_rec,
+                                    float* dc, const void* gates_act, const float* c_prev, const float* c,
+                                    void* dgates_pre, void* stream) {
+  if (B == 0) return 0;
+  EMO_DISPATCH(dtype, (lstm_cell_bwd_kernel<T><<<ew_grid((long)B * H), 256, 0, (hipStream_t)stream>>>(
+                          B, H, (const T*)dh_out, lddh, (const T*)dh_rec, dc, (const T*)gates_act, c_prev, c,
+                          (T*)dgates_pre)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_joint_tanh(int dtype, int B, int T_, int U, int J, const void* e, const void* g, void* h,
+                                 void* stream) {
+  const long n = (long)B * T_ * U * J;
+  if (n == 0) return 0;
+  EMO_DISPATCH(dtype, (joint_tanh_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(n, T_, U, J, (const T*)e,
+                                                                                        (const T*)g, (T*)h)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_joint_reduce(int dtype, int B, int T_, int U, int J, const void* d, void* de, void* dg,
+                                   void* stream) {
+  if ((long)B * T_ * U * J == 0) return 0;
+  EMO_DISPATCH(dtype, {
+    joint_reduce_kernel<T><<<ew_grid((long)B * T_ * J), 256, 0, (hipStream_t)stream>>>(0, B, T_, U, J, (const T*)d, (T*)de);
+    joint_reduce_kernel<T><<<ew_grid((long)B * U * J), 256, 0, (hipStream_t)stream>>>(1, B, T_, U, J, (const T*)d, (T*)dg);
+  });
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_rnnt_forward(int dtype, int B, int T_, int U, int V, int Lmax, const void* logits,
+                                   const int* labels, const int* elens, const int* ylens, int blank, float* lse,
+                                   float* lpb, float* lpy, float* alpha, float* beta, float* nll, void* stream) {
+  const long rows = (long)B * T_ * U;
+  if (rows == 0) return 0;
+  EMO_CHECK(U <= 1024, "rnnt: U=%d exceeds 1024 label positions", U);
+  hipStream_t s = (hipStream_t)stream;
+  EMO_DISPATCH(dtype, (rnnt_gather_kernel<T><<<cdiv(rows, 4), 256, 0, s>>>(rows, T_, U, V, Lmax, (const T*)logits, labels,
+                                                                          ylens, blank, lse, lpb, lpy)));
+  rnnt_lattice_kernel<<<2 * B, cdiv(U, 64) * 64, sizeof(float) * 2 * (U + 2), s>>>(B, T_, U, lpb, lpy, elens, ylens, alpha,
+                                                                                   beta, nll);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_rnnt_grad(int dtype, int B, int T_, int U, int V, int Lmax, const void* logits, const float* lse,
+                                const float* lpb, const float* lpy, const float* alpha, const float* beta,
+                                const int* labels, const int* elens, const int* ylens, const float* nll, int blank,
+                                float gscale, const float* gscale_dev, void* dlogits, void* stream) {
+  const long rows = (long)B * T_ * U;
+  if (rows == 0) return 0;
+  EMO_DISPATCH(dtype, (rnnt_grad_kernel<T><<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(
+                          rows, T_, U, V, Lmax, (const T*)logits, lse, lpb, lpy, alpha, beta, labels, elens, ylens, nll,
+                          blank, gscale, gscale_dev, (T*)dlogits)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_argmax_rows(int dtype, int M, int V, const void* x, long ldx, int* out, void* stream) {
+  if (M == 0) return 0;
+  EMO_DISPATCH(dtype, (argmax_rows_kernel<T><<<M, 256, 0, (hipStream_t)stream>>>(V, (const T*)x, ldx, out)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}

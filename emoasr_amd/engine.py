@@ -189,6 +189,8 @@ class CTCEngine(_DecoderMixinPlaceholder):
         self.seed = 0x5EED
         if _cfg(cfg, "decoder_type", "ctc") == "transformer":
             self._dec_init()
+        if _cfg(cfg, "decoder_type", "ctc") == "rnn_transducer":
+            self._rnnt_init()
         self.step_count = 0
 
     # ------------------------------------------------------------------ helpers
@@ -678,3 +680,174 @@ for _n, _f in list(vars(_DecoderMixin).items()):
     if not _n.startswith("__"):
         setattr(CTCEngine, _n, _f)
 ASREngine = CTCEngine
+
+
+# =======================================================================================
+# RNN-Transducer decoder: LSTM prediction network, joint network, transducer loss, greedy decode
+#   reference: asr/modeling/decoders/rnn_transducer.py:81-240
+# =======================================================================================
+class _RNNTMixin:
+    def _rnnt_init(self):
+        cfg = self.cfg
+        self.r_emb = cfg.embedding_size
+        self.r_H = cfg.dec_hidden_size
+        self.r_nl = cfg.dec_num_layers
+        self.r_J = cfg.joint_hidden_size
+        self.p_emb = float(_cfg(cfg, "dropout_emb_rate", 0.0))
+        self.p_dec = float(_cfg(cfg, "dropout_dec_rate", 0.0))
+        self.mtl_ctc = float(_cfg(cfg, "mtl_ctc_weight", 0.0))
+
+    def _lstm_bias(self, name):
+        A = self.arena
+        return A.p(name + ".bias_ih_l0") + A.p(name + ".bias_hh_l0")  # tiny f32 add (glue)
+
+    def rnnt_recurrency(self, ids_tm, state, training, keep):
+        """prediction network, TIME-MAJOR: ids_tm int32 [U,B] -> douts [U,B,H]; state = (hs, cs) lists of
+        per-layer [B,H] tensors (h in compute dtype, c f32) or None."""
+        A, H = self.arena, self.r_H
+        U, B = ids_tm.shape
+        p_emb = self.p_emb if training else 0.0
+        p = self.p_dec if training else 0.0
+        s_emb = self._seed(7000)
+        x = ops.embed_fwd(ids_tm, A.w("decoder.embed.weight"), None, 1.0, p_emb, s_emb)  # [U,B,E]
+        dev = x.device
+        layers, new_h, new_c = [], [], []
+        for l in range(self.r_nl):
+            name = f"decoder.rnns.{l}"
+            w_ih, w_hh = A.w(name + ".weight_ih_l0"), A.w(name + ".weight_hh_l0")
+            nin = x.shape[-1]
+            pre = ops.gemm_nt(x.view(U * B, nin), w_ih, bias=self._lstm_bias(name)).view(U, B, 4 * H)
+            hseq = torch.empty(U, B, H, device=dev, dtype=x.dtype)
+            cseq = torch.empty(U, B, H, device=dev, dtype=torch.float32)
+            gact = torch.empty(U, B, 4 * H, device=dev, dtype=x.dtype)
+            h_prev = state[0][l] if state is not None else None
+            c_prev = state[1][l] if state is not None else None
+            for u in range(U):
+                gates = pre[u] if h_prev is None else ops.gemm_nt(h_prev, w_hh, residual=pre[u], res_scale=1.0)
+                ops.lstm_cell_fwd(gates, c_prev, hseq[u], cseq[u], gact[u])
+                h_prev, c_prev = hseq[u], cseq[u]
+            new_h.append(h_prev)
+            new_c.append(c_prev)
+            s_do = self._seed(7010 + l)
+            y = ops.scale_dropout(hseq, 1.0, p, s_do) if p > 0 else hseq
+            if keep:
+                layers.append((x, hseq, cseq, gact, s_do, state[0][l] if state is not None else None,
+                               state[1][l] if state is not None else None))
+            x = y
+        st = None
+        if keep:
+            st = _Stash()
+            st.ids, st.layers, st.s_emb, st.p, st.p_emb = ids_tm, layers, s_emb, p, p_emb
+        return x, (new_h, new_c), st
+
+    def rnnt_recurrency_bwd(self, st, dy):
+        """dy [U,B,H] gradient w.r.t. the prediction-network output; accumulates parameter gradients"""
+        A, H = self.arena, self.r_H
+        U, B = st.ids.shape
+        for l in reversed(range(self.r_nl)):
+            name = f"decoder.rnns.{l}"
+            x_in, hseq, cseq, gact, s_do, h0, c0 = st.layers[l]
+            w_ih, w_hh = A.w(name + ".weight_ih_l0"), A.w(name + ".weight_hh_l0")
+            dh_seq = ops.scale_dropout(dy, 1.0, st.p, s_do) if st.p > 0 else dy
+            dgp = torch.empty(U, B, 4 * H, device=dy.device, dtype=dy.dtype)
+            dc = torch.zeros(B, H, device=dy.device, dtype=torch.float32)
+            dh_rec = None
+            for u in reversed(range(U)):
+                ops.lstm_cell_bwd(dh_seq[u], dh_rec, dc, gact[u], cseq[u - 1] if u > 0 else c0, cseq[u], dgp[u])
+                if u > 0 or h0 is not None:
+                    dh_rec = ops.gemm_nn(dgp[u], w_hh)
+            nin = x_in.shape[-1]
+            dgp2 = dgp.view(U * B, 4 * H)
+            ops.gemm_tn(dgp2, x_in.reshape(U * B, nin), out=A.g(name + ".weight_ih_l0"), accumulate=True,
+                        colsum=A.g(name + ".bias_ih_l0"))
+            ops.colsum(dgp2, out=A.g(name + ".bias_hh_l0"), accumulate=True)
+            if U > 1:
+                ops.gemm_tn(dgp[1:].reshape((U - 1) * B, 4 * H), hseq[:-1].reshape((U - 1) * B, H),
+                            out=A.g(name + ".weight_hh_l0"), accumulate=True)
+            dy = ops.gemm_nn(dgp2, w_ih).view(U, B, nin)
+        ops.embed_bwd(st.ids, dy, 1.0, A.g("decoder.embed.weight"), st.p_emb, st.s_emb)
+
+    def rnnt_forward(self, eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training):
+        """-> (loss_rnnt 0-dim, logits [B,T,U,V], stash)"""
+        with ops.stream_scope():
+            A, J = self.arena, self.r_J
+            B, T, d = eouts.shape
+            dev = eouts.device
+            U = ys_in.shape[1]
+            ids_tm = h2d_i32(torch.as_tensor(ys_in).t().contiguous(), dev)  # [U,B]
+            douts, _, rst = self.rnnt_recurrency(ids_tm, None, training, True)
+            e = ops.gemm_nt(eouts.reshape(B * T, d), A.w("decoder.w_enc.weight"), bias=A.p("decoder.w_enc.bias")).view(B, T, J)
+            g_tm = ops.gemm_nt(douts.view(U * B, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
+            g = ops.strided_copy(g_tm.view(U, B, J).permute(1, 0, 2))  # [B,U,J]
+            h = ops.joint_tanh(e, g)
+            logits = ops.gemm_nt(h.view(B * T * U, J), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
+            logits = logits.view(B, T, U, -1)
+            labels = torch.as_tensor(ys_host)[:, : max(U - 1, 1)].to(torch.int32)
+            if labels.shape[1] < max(U - 1, 1):
+                labels = torch.nn.functional.pad(labels, (0, max(U - 1, 1) - labels.shape[1]))
+            labels = h2d_i32(labels.contiguous(), dev)
+            ylens = h2d_i32([int(v) for v in ylens_host], dev)
+            ctx, nll = ops.rnnt_forward(logits, labels, elens_dev, ylens, blank)
+            st = _Stash()
+            st.rst, st.douts, st.h, st.logits, st.ctx, st.nll = rst, douts, h, logits, ctx, nll
+            st.labels, st.elens, st.ylens, st.blank, st.eouts = labels, elens_dev, ylens, blank, eouts
+            st.B, st.T, st.U = B, T, U
+            return nll.mean(), logits, st
+
+    def rnnt_backward(self, st, gscale_dev):
+        """-> d_eouts [B,T,d]; accumulates decoder gradients (the logits buffer is overwritten by its gradient)"""
+        with ops.stream_scope():
+            A, J, H = self.arena, self.r_J, self.r_H
+            A.attach_grads()
+            B, T, U = st.B, st.T, st.U
+            dz = ops.rnnt_grad(st.logits, st.ctx, st.nll, st.labels, st.elens, st.ylens, st.blank, 1.0 / B, gscale_dev,
+                               out=st.logits)
+            V = dz.shape[-1]
+            dz2 = dz.view(B * T * U, V)
+            h2 = st.h.view(B * T * U, J)
+            ops.gemm_tn(dz2, h2, out=A.g("decoder.output.weight"), accumulate=True, colsum=A.g("decoder.output.bias"))
+            dpre = ops.gemm_nn(dz2, A.w("decoder.output.weight"), dact_pre=h2, dact=ops.DACT_TANH_OUT)
+            de, dg = ops.joint_reduce(dpre.view(B, T, U, J))
+            d = st.eouts.shape[2]
+            deouts = self._lin_bwd(de.view(B * T, J), st.eouts.reshape(B * T, d), "decoder.w_enc.weight",
+                                   "decoder.w_enc.bias").view(B, T, d)
+            dg_tm = ops.strided_copy(dg.permute(1, 0, 2)).view(U * B, J)
+            ddouts = self._lin_bwd(dg_tm, st.douts.view(U * B, H), "decoder.w_dec.weight", "decoder.w_dec.bias")
+            self.rnnt_recurrency_bwd(st.rst, ddouts.view(U, B, H))
+            return deouts
+
+    def rnnt_greedy(self, eouts, elens_host, blank, eos, max_seq_len=256):
+        """time-synchronous greedy search (rnn_transducer.py:194-240): one joint evaluation, one arg-max
+        and one 4-byte D2H per emitted symbol; the LSTM advances only on non-blank symbols."""
+        with ops.stream_scope(), torch.no_grad():
+            A, J = self.arena, self.r_J
+            A.refresh_shadow()
+            dev = eouts.device
+            hyps, aligns = [], []
+            for b in range(eouts.shape[0]):
+                T = int(elens_host[b])
+                e_all = ops.gemm_nt(eouts[b, :max(T, 1)], A.w("decoder.w_enc.weight"), bias=A.p("decoder.w_enc.bias"))
+                dout, state, _ = self.rnnt_recurrency(h2d_i32([[eos]], dev), None, False, False)
+                g = ops.gemm_nt(dout.view(1, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
+                hyp, align, t = [], [], 0
+                while t < T:
+                    h = ops.joint_tanh(e_all[t].view(1, 1, J), g.view(1, 1, J))
+                    logits = ops.gemm_nt(h.view(1, J), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
+                    tok = int(ops.argmax_rows(logits).item())
+                    align.append(tok)
+                    if tok == blank:
+                        t += 1
+                    else:
+                        hyp.append(tok)
+                        dout, state, _ = self.rnnt_recurrency(h2d_i32([[tok]], dev), state, False, False)
+                        g = ops.gemm_nt(dout.view(1, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
+                    if len(hyp) > max_seq_len:
+                        break
+                hyps.append(hyp)
+                aligns.append(align)
+            return hyps, aligns
+
+
+for _n, _f in list(vars(_RNNTMixin).items()):
+    if not _n.startswith("__"):
+        setattr(CTCEngine, _n, _f)

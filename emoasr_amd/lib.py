@@ -78,6 +78,13 @@ SIGNATURES = {
     "emoasr_topk": [I, I, I, P, L, P, L, P, P, P, P],
     "emoasr_ctc_prefix_init": [I, I, P, I, P, P],
     "emoasr_ctc_prefix_score": [I, I, I, I, P, P, I, P, P, P, P, P, P, I, I, P, P, P],
+    "emoasr_lstm_cell_fwd": [I, I, I, P, P, P, L, P, P, P],
+    "emoasr_lstm_cell_bwd": [I, I, I, P, L, P, P, P, P, P, P, P],
+    "emoasr_joint_tanh": [I, I, I, I, I, P, P, P, P],
+    "emoasr_joint_reduce": [I, I, I, I, I, P, P, P, P],
+    "emoasr_rnnt_forward": [I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P],
+    "emoasr_rnnt_grad": [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, F, P, P, P],
+    "emoasr_argmax_rows": [I, I, I, P, L, P, P],
     "emoasr_sqnorm": [L, P, P, P],
     "emoasr_adam_step": [L, P, P, P, P, F, F, F, F, F, I, P, F, F, P],
     "emoasr_specaug_apply": [I, I, I, P, P, I, I, P, P, P],

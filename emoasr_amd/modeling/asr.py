@@ -33,6 +33,11 @@ class ASR(nn.Module):
             self.decoder = TransformerDecoder(params)
             if hasattr(self.decoder, "ctc"):
                 self.decoder.ctc._owner = [self]
+        elif self.decoder_type == "rnn_transducer":
+            from .decoders.rnn_transducer import RNNTDecoder
+            self.decoder = RNNTDecoder(params, phase)
+            if hasattr(self.decoder, "ctc"):
+                self.decoder.ctc._owner = [self]
         else:
             raise NotImplementedError(f"emoasr_amd: decoder_type={self.decoder_type!r} is not built yet")
         self.encoder._owner = [self]  # list: keeps the back-reference out of nn.Module registration

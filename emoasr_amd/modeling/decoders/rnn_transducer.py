@@ -1,0 +1,62 @@
+"""RNNTDecoder -- module API of asr/modeling/decoders/rnn_transducer.py:24-346 on the HIP engine.
+
+    decoder(eouts, elens, eouts_inter, ys, ylens, ys_in, ys_out) -> (loss, loss_dict, logits [B,T,L+1,V])
+    decoder.decode(eouts, elens, beam_width=1, ...)              -> (hyps, None, None, None)
+
+The transducer loss is the HIP lattice kernel (`emoasr_rnnt_forward/_grad`) -- the reference calls the
+third-party warp_rnnt package here (rnn_transducer.py:106-115).  Only greedy decoding (beam_width <= 1)
+is on the path; like the reference, decode() discards scores/logits/aligns (:339-346).
+"""
+import torch.nn as nn
+
+from ..functions import rnnt_apply, rnnt_greedy_apply
+from .ctc import CTCDecoder
+
+
+class RNNTDecoder(nn.Module):
+    def __init__(self, params, phase="train"):
+        super().__init__()
+        if params.kd_weight > 0:
+            raise NotImplementedError("emoasr_amd: kd_weight > 0 is outside the HIP hot path")
+        self.dec_num_layers = params.dec_num_layers
+        self.dec_hidden_size = params.dec_hidden_size
+        self.eos_id = params.eos_id
+        self.blank_id = params.blank_id
+        self.max_seq_len = 256
+        self.mtl_ctc_weight = params.mtl_ctc_weight
+        self.kd_weight = params.kd_weight
+        self.embed = nn.Embedding(params.vocab_size, params.embedding_size)
+        self.rnns = nn.ModuleList()
+        nin = params.embedding_size
+        for _ in range(self.dec_num_layers):
+            self.rnns.append(nn.LSTM(input_size=nin, hidden_size=params.dec_hidden_size, num_layers=1, batch_first=True))
+            nin = params.dec_hidden_size
+        self.w_enc = nn.Linear(params.enc_hidden_size, params.joint_hidden_size)
+        self.w_dec = nn.Linear(params.dec_hidden_size, params.joint_hidden_size)
+        self.output = nn.Linear(params.joint_hidden_size, params.vocab_size)
+        if self.mtl_ctc_weight > 0:
+            self.ctc = CTCDecoder(params)
+        self._owner = None
+
+    def forward(self, eouts, elens, eouts_inter=None, ys=None, ylens=None, ys_in=None, ys_out=None,
+                soft_labels=None, ps=None, plens=None):
+        loss, loss_rnnt, loss_ctc, logits = rnnt_apply(self, eouts, elens, ys, ylens, ys_in)
+        loss_dict = {"loss_rnnt": loss_rnnt}
+        if self.mtl_ctc_weight > 0:
+            loss_dict["loss_ctc"] = loss_ctc
+        loss_dict["loss_total"] = loss
+        return loss, loss_dict, logits
+
+    def decode(self, eouts, elens, eouts_inter=None, beam_width=1, len_weight=0, lm=None, lm_weight=0,
+               decode_ctc_weight=0, decode_phone=False):
+        if beam_width > 1:
+            raise NotImplementedError("emoasr_amd: RNN-T beam search (ALSD) is scheduled after the greedy path")
+        if decode_ctc_weight == 1:
+            self.ctc._owner = self._owner
+            return self.ctc.decode(eouts, elens, beam_width=1)
+        hyps, aligns = rnnt_greedy_apply(self, eouts, elens)
+        return hyps, None, None, None
+
+    def _greedy(self, eouts, elens, decode_ctc_weight=0):
+        hyps, aligns = rnnt_greedy_apply(self, eouts, elens)
+        return hyps, [None] * len(hyps), None, aligns

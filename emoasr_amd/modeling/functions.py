@@ -154,3 +154,50 @@ def attn_decoder_logits(dec, eouts, elens, ys_in, ylens):
     with torch.no_grad():
         logits, _ = eng.dec_forward(eouts, _elens_dev(eouts, elens), ys_in, ylens_host, dec.training, False)
     return logits
+
+
+# ---------------------------------------------------------------------------------------
+# RNN-T: transducer loss (+ auxiliary CTC) as one autograd node over the encoder output
+# ---------------------------------------------------------------------------------------
+class _RNNTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, training, eouts, elens_dev, ys_host, ylens_host, ys_in, blank, *params):
+        loss_rnnt, logits, st = eng.rnnt_forward(eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training)
+        cctx, loss = None, loss_rnnt
+        if eng.mtl_ctc > 0:
+            ctc_logits = eng.head_logits(eouts, "decoder.ctc.output")
+            loss_ctc, cctx = eng.ctc_loss(ctc_logits, elens_dev, ys_host, ylens_host, blank, True)
+            loss = loss_rnnt + eng.mtl_ctc * loss_ctc
+        else:
+            loss_ctc = torch.zeros_like(loss_rnnt)
+        ctx.eng, ctx.st, ctx.cctx, ctx.eouts = eng, st, cctx, eouts
+        out_logits = logits.detach().clone() if False else logits
+        ctx.mark_non_differentiable(out_logits)
+        return loss, loss_rnnt, loss_ctc, out_logits
+
+    @staticmethod
+    def backward(ctx, g_total, g_rnnt, g_ctc, _):
+        eng = ctx.eng
+        deouts = eng.rnnt_backward(ctx.st, (g_total + g_rnnt).to(torch.float32).reshape(1))
+        if ctx.cctx is not None:
+            g_ctc_eff = (g_total * eng.mtl_ctc + g_ctc).to(torch.float32).reshape(1)
+            dcl = eng.ctc_grad(ctx.cctx, 1.0, g_ctc_eff)
+            from .. import ops
+            deouts = ops.add(deouts, eng.head_backward(ctx.eouts, dcl, "decoder.ctc.output"))
+        ctx.st = ctx.cctx = None
+        return (None, None, deouts, None, None, None, None, None) + (None,) * len(eng.arena.params)
+
+
+def rnnt_apply(dec, eouts, elens, ys, ylens, ys_in):
+    eng = _engine_of(dec)
+    ylens_host = _host_list(ylens)
+    L = max(ylens_host)
+    ys_host = (ys.cpu() if torch.is_tensor(ys) else torch.as_tensor(ys))[:, :L]
+    ys_in = (ys_in.cpu() if torch.is_tensor(ys_in) else torch.as_tensor(ys_in))[:, : L + 1]
+    return _RNNTFn.apply(eng, dec.training, eouts, _elens_dev(eouts, elens), ys_host, ylens_host, ys_in, dec.blank_id,
+                         *eng.arena.params)
+
+
+def rnnt_greedy_apply(dec, eouts, elens):
+    eng = _engine_of(dec)
+    return eng.rnnt_greedy(eouts, _host_list(elens), dec.blank_id, dec.eos_id, dec.max_seq_len)

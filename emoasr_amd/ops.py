@@ -487,6 +487,68 @@ def ctc_prefix_score(x, cands, last, out_len, blank, eos, prev_states=None, pare
     return log_psi, states
 
 
+# ---- RNN-T -------------------------------------------------------------------------------------
+DACT_TANH_OUT = 5
+
+
+def lstm_cell_fwd(gates_pre, c_prev, h_out, c_out, gates_act):
+    """gates_pre [B,4H]; c_prev f32 [B,H] | None; h_out: [B,H] view (row stride allowed)"""
+    B, H4 = gates_pre.shape
+    lib.call("emoasr_lstm_cell_fwd", dt(gates_pre), B, H4 // 4, _p(gates_pre), _p(c_prev), _p(h_out), h_out.stride(0),
+             _p(c_out), _p(gates_act), _stream())
+
+
+def lstm_cell_bwd(dh_out, dh_rec, dc, gates_act, c_prev, c, dgates_pre):
+    B, H4 = gates_act.shape
+    lib.call("emoasr_lstm_cell_bwd", dt(gates_act), B, H4 // 4, _p(dh_out), dh_out.stride(0), _p(dh_rec), _p(dc),
+             _p(gates_act), _p(c_prev), _p(c), _p(dgates_pre), _stream())
+
+
+def joint_tanh(e, g):
+    """e [B,T,J], g [B,U,J] -> tanh(e[:, :, None] + g[:, None]) [B,T,U,J]"""
+    B, T, J = e.shape
+    U = g.shape[1]
+    h = torch.empty(B, T, U, J, device=e.device, dtype=e.dtype)
+    lib.call("emoasr_joint_tanh", dt(e), B, T, U, J, _p(e), _p(g), _p(h), _stream())
+    return h
+
+
+def joint_reduce(d):
+    B, T, U, J = d.shape
+    de = torch.empty(B, T, J, device=d.device, dtype=d.dtype)
+    dg = torch.empty(B, U, J, device=d.device, dtype=d.dtype)
+    lib.call("emoasr_joint_reduce", dt(d), B, T, U, J, _p(d), _p(de), _p(dg), _stream())
+    return de, dg
+
+
+def rnnt_forward(logits, labels, elens, ylens, blank):
+    """logits [B,T,U,V]; labels int32 [B,Lmax] (U = Lmax+1) -> ctx tuple, nll f32 [B]"""
+    B, T, U, V = logits.shape
+    dev = logits.device
+    f = lambda: torch.empty(B, T, U, device=dev, dtype=torch.float32)
+    lse, lpb, lpy, alpha, beta = f(), f(), f(), f(), f()
+    nll = torch.empty(B, device=dev, dtype=torch.float32)
+    lib.call("emoasr_rnnt_forward", dt(logits), B, T, U, V, labels.shape[1], _p(logits), _p(labels), _p(elens), _p(ylens),
+             blank, _p(lse), _p(lpb), _p(lpy), _p(alpha), _p(beta), _p(nll), _stream())
+    return (lse, lpb, lpy, alpha, beta), nll
+
+
+def rnnt_grad(logits, ctx, nll, labels, elens, ylens, blank, gscale, gscale_dev=None, out=None):
+    B, T, U, V = logits.shape
+    lse, lpb, lpy, alpha, beta = ctx
+    dz = torch.empty_like(logits) if out is None else out
+    lib.call("emoasr_rnnt_grad", dt(logits), B, T, U, V, labels.shape[1], _p(logits), _p(lse), _p(lpb), _p(lpy), _p(alpha),
+             _p(beta), _p(labels), _p(elens), _p(ylens), _p(nll), blank, gscale, _p(gscale_dev), _p(dz), _stream())
+    return dz
+
+
+def argmax_rows(x):
+    M, V, ld = _rows(_chk(x))
+    out = torch.empty(M, device=x.device, dtype=torch.int32)
+    lib.call("emoasr_argmax_rows", dt(x), M, V, _p(x), ld, _p(out), _stream())
+    return out
+
+
 # ---- optimizer -------------------------------------------------------------------------
 def sqnorm(x, out):
     lib.call("emoasr_sqnorm", x.numel(), _p(_chk(x, torch.float32)), _p(out), _stream())

@@ -249,6 +249,31 @@ int emoasr_ctc_prefix_score(int nb, int T, int V, int cw, const float* x, const 
                             const int* out_len, const int* cands, int blank, int eos, float* log_psi,
                             float* states, void* stream);
 
+/* ---- RNN-Transducer decoder (decoders/rnn_transducer.py:81-240) ----------------------
+ * LSTM cell (nn.LSTM gate order i,f,g,o): gates_pre T [B,4H] = x.W_ih^T + h.W_hh^T + b;
+ * c_prev / c f32 [B,H]; h T rows of stride ldh; gates_act T [B,4H] saved for the backward. */
+int emoasr_lstm_cell_fwd(int dtype, int B, int H, const void* gates_pre, const float* c_prev, void* h, long ldh,
+                         float* c, void* gates_act, void* stream);
+/* dgates_pre from dh_out (row stride lddh) + dh_rec (may be NULL); dc f32 [B,H] is updated in place */
+int emoasr_lstm_cell_bwd(int dtype, int B, int H, const void* dh_out, long lddh, const void* dh_rec, float* dc,
+                         const void* gates_act, const float* c_prev, const float* c, void* dgates_pre,
+                         void* stream);
+/* joint network: h[b,t,u,:] = tanh(e[b,t,:] + g[b,u,:]) ; reductions of d(pre-tanh) back to de / dg */
+int emoasr_joint_tanh(int dtype, int B, int T, int U, int J, const void* e, const void* g, void* h, void* stream);
+int emoasr_joint_reduce(int dtype, int B, int T, int U, int J, const void* d, void* de, void* dg, void* stream);
+/* transducer lattice on joint logits T [B,T,U,V] (U = Lmax+1): per-cell lse / blank / label log-probs,
+ * alpha, beta f32 [B,T,U], nll[b] = -log p(y_b|x_b) */
+int emoasr_rnnt_forward(int dtype, int B, int T, int U, int V, int Lmax, const void* logits, const int* labels,
+                        const int* elens, const int* ylens, int blank, float* lse, float* lpb, float* lpy,
+                        float* alpha, float* beta, float* nll, void* stream);
+/* dlogits = gscale*[gscale_dev]*(softmax*occ - [blank]gamma_b - [label]gamma_y); 0 outside (elens, ylens) */
+int emoasr_rnnt_grad(int dtype, int B, int T, int U, int V, int Lmax, const void* logits, const float* lse,
+                     const float* lpb, const float* lpy, const float* alpha, const float* beta, const int* labels,
+                     const int* elens, const int* ylens, const float* nll, int blank, float gscale,
+                     const float* gscale_dev, void* dlogits, void* stream);
+/* out[m] = argmax_v x[m,:V] (first maximum) */
+int emoasr_argmax_rows(int dtype, int M, int V, const void* x, long ldx, int* out, void* stream);
+
 /* ---- optimizer (asr/train_asr.py:84-92, torch.optim.Adam semantics) ---------- */
 /* out[0] += sum x^2 */
 int emoasr_sqnorm(long n, const float* x, float* out, void* stream);
