@@ -15,6 +15,8 @@ void emo_set_error(const char* fmt, ...) {
 }
 
 void emo_gemm_set_tr_read(int v);
+void emo_gemm_set_tile(int v);
+void emo_gemm_set_kb(int v);
 void emo_attn_set_tr_read(int v);
 
 extern "C" const char* emoasr_last_error(void) { return g_err; }
@@ -25,6 +27,8 @@ extern "C" int emoasr_set_option(const char* name, int value) {
     emo_attn_set_tr_read(value);
     return 0;
   }
+  if (strcmp(name, "gemm_tile") == 0) { emo_gemm_set_tile(value); return 0; }
+  if (strcmp(name, "gemm_kb") == 0) { emo_gemm_set_kb(value); return 0; }
   emo_set_error("unknown option '%s'", name);
   return 1;
 }

@@ -41,6 +41,7 @@ __device__ __forceinline__ int conv_k_off(const ConvGeom& g, int k) {
 }
 
 int g_tr_read = 1;
+int g_gemm_tile = 0, g_gemm_kb = 0;
 
 struct NtArgs {
   int M, N, K;
@@ -53,15 +54,30 @@ struct NtArgs {
   long sa_b, sa_h, sb_b, sb_h, sc_b, sc_h;
 };
 
-#ifndef EMO_BK_BF16
-#define EMO_BK_BF16 32
-#endif
-template <typename T> struct TileCfg {
+// KB scales the k extent of a tile: bf16 uses BK = 32 for short reductions (K = 256: fewer, cheaper
+// pipeline fill steps) and BK = 64 for long ones (half the barriers per MFMA) -- measured per shape.
+template <typename T, int KB = 1> struct TileCfg {
   static constexpr int VEC = 16 / sizeof(T);
-  static constexpr int BK = sizeof(T) == 2 ? EMO_BK_BF16 : 16;
+  static constexpr int BK = (sizeof(T) == 2 ? 32 : 16) * KB;
   static constexpr int KV = BK / VEC;                       // 16-byte vectors per tile row (= 4)
   static constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 1);  // padded LDS row (elements)
 };
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+// 16-byte buffer load with hardware bounds check: an offset of 0xFFFFFFFF (or anything past the
+// descriptor's size) returns zeros, so row / k guards become one v_cndmask on the offset -- no
+// exec-mask branches and a statically countable number of loads per k-step.
+template <typename T>
+__device__ __forceinline__ Vec16<T> buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  Vec16<T> o;
+  o.v = __builtin_bit_cast(decltype(o.v), v);
+  return o;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFF, 0x00020000);
+}
+#define EMO_OOB 0xFFFFFFFFu
 
 // 8 consecutive elements of T <-> 8 floats (16 bytes of bf16, 32 bytes of f32)
 template <typename T>
@@ -105,9 +121,9 @@ __device__ __forceinline__ void lds_store_row(T* dst, const Vec16<T>& v) {
 // zeroed with a select, so the k-loop has no exec-mask branches.  The epilogue transposes each
 // 32x32 accumulator tile through wave-private LDS so that every lane owns 8 consecutive columns
 // of one row: bias / saved-activation / residual traffic and the output are 16-byte accesses.
-template <typename T, int BM, int BN, int AMODE, bool BKM, bool TR>
+template <typename T, int BM, int BN, int AMODE, bool BKM, bool TR, int KB>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
-  using Cfg = TileCfg<T>;
+  using Cfg = TileCfg<T, KB>;
   using M_ = Mma<T>;
   constexpr int VEC = Cfg::VEC, BK = Cfg::BK, KV = Cfg::KV, LD = Cfg::LD;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -138,17 +154,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
     c_base = bb * g.sc_b + hh * g.sc_h;
   }
 
-  // per-thread staging assignments (fixed rows across the k loop); invalid rows alias row 0
-  const T* a_ptr[A_IT]; bool a_ok[A_IT]; int a_lds[A_IT]; int a_kv[A_IT];
-  const T* b_ptr[B_IT]; bool b_ok[B_IT]; int b_lds[B_IT]; int b_kv[B_IT];
+  // per-thread staging assignments (fixed rows across the k loop): byte offsets into the A / B
+  // buffer descriptors (operands are < 4 GiB, checked on the host)
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A), rsB = make_rsrc(B);
+  constexpr unsigned SZ = sizeof(T);
+  unsigned a_off[A_IT]; bool a_ok[A_IT]; int a_lds[A_IT]; int a_kv[A_IT];
+  unsigned b_off[B_IT]; bool b_ok[B_IT]; int b_lds[B_IT]; int b_kv[B_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int v = tid + i * 256, r = v / KV, kv = v % KV;
     a_kv[i] = kv * VEC; a_lds[i] = r * LD + kv * VEC;
     a_ok[i] = (m0 + r) < g.M;
     const int row = a_ok[i] ? (m0 + r) : 0;
-    if constexpr (AMODE == 1) a_ptr[i] = A + conv_row_base(g.cg, row);
-    else a_ptr[i] = A + (long)row * g.lda;
+    if constexpr (AMODE == 1) a_off[i] = (unsigned)(conv_row_base(g.cg, row) * SZ);
+    else a_off[i] = (unsigned)((long)row * g.lda * SZ);
   }
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
@@ -157,44 +176,46 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
       const int kr = v / BVK, nv = (v % BVK) * VEC;
       b_kv[i] = kr; b_lds[i] = kr * LDBK + nv;
       b_ok[i] = (n0 + nv) < g.N;
-      b_ptr[i] = B + (b_ok[i] ? (n0 + nv) : 0);
+      b_off[i] = (unsigned)((n0 + nv) * SZ);
     } else {
       const int r = v / KV, kv = v % KV;
       b_kv[i] = kv * VEC; b_lds[i] = r * LD + kv * VEC;
       b_ok[i] = (n0 + r) < g.N;
-      b_ptr[i] = B + (long)(b_ok[i] ? (n0 + r) : 0) * g.ldb;
+      b_off[i] = (unsigned)((long)(b_ok[i] ? (n0 + r) : 0) * g.ldb * SZ);
     }
   }
 
-  Vec16<T> a_reg[A_IT], b_reg[B_IT];
-  auto load_tile = [&](int k0) {
+  // Register ring, 3 tiles deep: the global loads of tile kt+2 are issued while tile kt is being
+  // multiplied and tile kt+1 is copied register -> LDS, so two full k-steps of MFMA + LDS work
+  // cover the memory latency (the two-barrier loop waited on vmcnt(0) two thirds of the time).
+  struct Stage { Vec16<T> a[A_IT], b[B_IT]; };
+  auto load_tile = [&](Stage& r, int k0) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int k = k0 + a_kv[i];
       const bool ok = a_ok[i] && k < g.K;
-      const int kc = ok ? k : 0;  // clamped: always a readable address
-      if constexpr (AMODE == 1) a_reg[i] = load16(a_ptr[i] + conv_k_off(g.cg, kc));
-      else a_reg[i] = load16(a_ptr[i] + kc);
-      if (!ok) a_reg[i].zero();
+      unsigned off;
+      if constexpr (AMODE == 1) off = a_off[i] + (unsigned)conv_k_off(g.cg, ok ? k : 0) * SZ;
+      else off = a_off[i] + (unsigned)k * SZ;
+      r.a[i] = buf_load16<T>(rsA, ok ? off : EMO_OOB);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int k = k0 + b_kv[i];
       const bool ok = b_ok[i] && k < g.K;
-      const int kc = ok ? k : 0;
-      b_reg[i] = load16(b_ptr[i] + (BKM ? (long)kc * g.ldb : (long)kc));
-      if (!ok) b_reg[i].zero();
+      const unsigned off = BKM ? b_off[i] + (unsigned)((long)k * g.ldb * SZ) : b_off[i] + (unsigned)k * SZ;
+      r.b[i] = buf_load16<T>(rsB, ok ? off : EMO_OOB);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const Stage& r, int buf) {
     T* As = As0 + buf * AS_ELEMS;
     T* Bs = Bs0 + buf * BS_ELEMS;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) lds_store_row(&As[a_lds[i]], a_reg[i]);
+    for (int i = 0; i < A_IT; ++i) lds_store_row(&As[a_lds[i]], r.a[i]);
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      if constexpr (BKM) store16(&Bs[b_lds[i]], b_reg[i]);
-      else lds_store_row(&Bs[b_lds[i]], b_reg[i]);
+      if constexpr (BKM) store16(&Bs[b_lds[i]], r.b[i]);
+      else lds_store_row(&Bs[b_lds[i]], r.b[i]);
     }
   };
 
@@ -206,15 +227,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (g.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  auto compute_tile = [&](int buf) {
     const T* As = As0 + buf * AS_ELEMS;
     const T* Bs = Bs0 + buf * BS_ELEMS;
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += M_::KSTEP) {
       typename M_::Frag af[TM], bfr[TN];
@@ -230,8 +245,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(af[i], bfr[j], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+  };
+
+  const int nk = (g.K + BK - 1) / BK;
+  Stage s0, s1, s2;  // named stages: static register indexing (a runtime-indexed ring would spill)
+  load_tile(s0, 0);
+  load_tile(s1, BK);
+  store_tile(s0, 0);
+  __syncthreads();
+  // step(kt): tile kt is in LDS[kt&1]; `nxt` holds tile kt+1 (in flight or landed); `fre` is free
+  // loads / stores are issued unconditionally (tiles past K use out-of-bounds buffer offsets and stage zeros):
+  // with a static number of loads per step the compiler can wait with a counted vmcnt(N) for the
+  // older stage only, instead of draining the stage it has just issued.
+  auto step = [&](int kt, Stage& nxt, Stage& fre) {
+    load_tile(fre, (kt + 2) * BK);
+    compute_tile(kt & 1);
+    store_tile(nxt, (kt + 1) & 1);
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 3) {
+    step(kt, s1, s2);
+    if (kt + 1 < nk) step(kt + 1, s2, s0);
+    if (kt + 2 < nk) step(kt + 2, s0, s1);
   }
 
   // ---- epilogue -------------------------------------------------------------
@@ -243,12 +278,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   float* sc = reinterpret_cast<float*>(smem) + wave * 32 * EP_LD;
   const int er = lane >> 2, ec = (lane & 3) * 8;  // this lane's row (per 16-row pass) and column group
   const bool vec_ok = (g.N % 8 == 0) && (g.ldc % 8 == 0) && (!res || ep.ldr % 8 == 0);
+  // one 32x32 accumulator tile -> LDS transpose -> fused epilogue -> 16-byte stores.  Called with
+  // constant (i, j) below: a (TM x TN) loop around this body is too big for the unroller, and a
+  // runtime-indexed acc[i][j] would drop the accumulators into scratch for the whole k loop.
+  auto epilogue_tile = [&](const f32x16& a, const int i, const int j) __attribute__((always_inline)) {
+    {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[c_row(r, lane) * EP_LD + c_col(lane)] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) sc[c_row(r, lane) * EP_LD + c_col(lane)] = a[r];
       __builtin_amdgcn_wave_barrier();
       const int col = n0 + wn + j * 32 + ec;
 #pragma unroll
@@ -315,6 +351,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+  };
+  epilogue_tile(acc[0][0], 0, 0);
+  if constexpr (TN > 1) epilogue_tile(acc[0][TN - 1], 0, TN - 1);
+  if constexpr (TM > 1) {
+    epilogue_tile(acc[TM - 1][0], TM - 1, 0);
+    if constexpr (TN > 1) epilogue_tile(acc[TM - 1][TN - 1], TM - 1, TN - 1);
+  }
+  static_assert(TM <= 2 && TN <= 2, "epilogue is written for at most 2x2 tiles per wave");
 }
 
 // ----------------------------------------------------------------------------
@@ -334,9 +378,9 @@ struct TnArgs {
   ConvGeom cg;
 };
 
-template <typename T, int BN1, int BN2, int BMODE, bool TR>
+template <typename T, int BN1, int BN2, int BMODE, bool TR, int KB>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
-  using Cfg = TileCfg<T>;
+  using Cfg = TileCfg<T, KB>;
   using M_ = Mma<T>;
   constexpr int VEC = Cfg::VEC, BK = Cfg::BK;
   constexpr int PAD = sizeof(T) == 2 ? 32 : 0;
@@ -364,22 +408,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
   if constexpr (BMODE == 1) b_koff = conv_k_off(g.cg, n2_0);  // tile lies inside one (kh,kw)
 
   Vec16<T> a_reg[A_IT], b_reg[B_IT];
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A), rsB = make_rsrc(B);
+  constexpr unsigned SZ = sizeof(T);
   auto load_tile = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int v = tid + i * 256, kr = v / AV, nv = (v % AV) * VEC;
       const int k = k0 + kr, n = n1_0 + nv;
-      if (k < g.K && n < g.N1) a_reg[i] = load16(A + (long)k * g.lda + n);
-      else a_reg[i].zero();
+      const bool ok = k < g.K && n < g.N1;
+      a_reg[i] = buf_load16<T>(rsA, ok ? (unsigned)(((long)k * g.lda + n) * SZ) : EMO_OOB);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int v = tid + i * 256, kr = v / BV, nv = (v % BV) * VEC;
       const int k = k0 + kr, n = n2_0 + nv;
-      if (k < g.K && n < g.N2) {
-        if constexpr (BMODE == 1) b_reg[i] = load16(B + conv_row_base(g.cg, k) + b_koff + nv);
-        else b_reg[i] = load16(B + (long)k * g.ldb + n);
-      } else b_reg[i].zero();
+      const bool ok = k < g.K && n < g.N2;
+      unsigned off;
+      if constexpr (BMODE == 1) off = (unsigned)((conv_row_base(g.cg, ok ? k : 0) + b_koff + nv) * SZ);
+      else off = (unsigned)(((long)k * g.ldb + n) * SZ);
+      b_reg[i] = buf_load16<T>(rsB, ok ? off : EMO_OOB);
     }
   };
   auto store_tile = [&](int buf) {
@@ -410,7 +457,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
   __syncthreads();
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int buf = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) load_tile((kt + 1) * BK);
+    load_tile(kt + 1 < kt_end ? (kt + 1) * BK : g.K);  // past-the-end tile: all offsets out of bounds -> zeros
     if (do_colsum) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) csum += to_f32(As[buf][k * LDA + tid]);
@@ -427,7 +474,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(af[i], bfr[j], acc[i][j]);
     }
-    if (kt + 1 < kt_end) store_tile(buf ^ 1);
+    store_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -449,18 +496,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
 
 template <typename T, int AMODE, bool BKM, bool TR>
 int launch_nt_(const NtArgs& a, hipStream_t s, int nz = 1) {
-  const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * nz;
+  // Tile: 128x64 once that still gives >= 384 blocks (1.5 per CU), else 64x64.  (A 128x128 tile
+  // was measured slower than 128x64 on every shape of the L2 model.)  k extent: BK = 64 for long
+  // bf16 reductions, 32 for K = 256.  g_gemm_tile / g_gemm_kb: tuning overrides (emoasr_set_option).
   const long t12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64) * nz;
-  if (t128 >= 512) {
-    dim3 grid(cdiv(a.N, 128), cdiv(a.M, 128), nz);
-    gemm_nt_kernel<T, 128, 128, AMODE, BKM, TR><<<grid, 256, 0, s>>>(a);
-  } else if (t12864 >= 384) {
-    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 128), nz);
-    gemm_nt_kernel<T, 128, 64, AMODE, BKM, TR><<<grid, 256, 0, s>>>(a);
-  } else {
-    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64), nz);
-    gemm_nt_kernel<T, 64, 64, AMODE, BKM, TR><<<grid, 256, 0, s>>>(a);
-  }
+  const int tile = g_gemm_tile ? g_gemm_tile : (t12864 >= 384 ? 2 : 3);
+  const int kb = sizeof(T) == 2 ? (g_gemm_kb ? g_gemm_kb : (a.K >= 512 ? 2 : 1)) : 1;
+#define EMO_NT_LAUNCH(BM_, BN_)                                                           \
+  do {                                                                                    \
+    dim3 grid(cdiv(a.N, BN_), cdiv(a.M, BM_), nz);                                        \
+    if constexpr (sizeof(T) == 2) {                                                       \
+      if (kb == 2) gemm_nt_kernel<T, BM_, BN_, AMODE, BKM, TR, 2><<<grid, 256, 0, s>>>(a); \
+      else gemm_nt_kernel<T, BM_, BN_, AMODE, BKM, TR, 1><<<grid, 256, 0, s>>>(a);         \
+    } else {                                                                              \
+      gemm_nt_kernel<T, BM_, BN_, AMODE, BKM, TR, 1><<<grid, 256, 0, s>>>(a);              \
+    }                                                                                     \
+  } while (0)
+  if (tile == 2) EMO_NT_LAUNCH(128, 64);
+  else EMO_NT_LAUNCH(64, 64);
+#undef EMO_NT_LAUNCH
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -473,7 +527,8 @@ int launch_nn(const NtArgs& a, hipStream_t s, int nz = 1) {
 
 template <typename T, int BMODE>
 int launch_tn(TnArgs a, hipStream_t s) {
-  constexpr int BK = TileCfg<T>::BK;
+  const int kb = sizeof(T) == 2 ? (g_gemm_kb ? g_gemm_kb : (a.K >= 512 ? 2 : 1)) : 1;
+  const int BK = TileCfg<T>::BK * kb;
   const int nk = cdiv(a.K, BK);
   const bool big = (long)cdiv(a.N1, 128) * cdiv(a.N2, 128) >= 32 && a.N1 >= 128 && a.N2 >= 128;
   const int bn = big ? 128 : 64;
@@ -490,13 +545,23 @@ int launch_tn(TnArgs a, hipStream_t s) {
   a.k_tiles_per_split = cdiv(nk, splits);
   splits = cdiv(nk, a.k_tiles_per_split);
   dim3 grid(cdiv(a.N2, bn), cdiv(a.N1, bn), splits);
+#define EMO_TN_LAUNCH(BN_, TR_)                                                     \
+  do {                                                                              \
+    if constexpr (sizeof(T) == 2) {                                                 \
+      if (kb == 2) gemm_tn_kernel<T, BN_, BN_, BMODE, TR_, 2><<<grid, 256, 0, s>>>(a); \
+      else gemm_tn_kernel<T, BN_, BN_, BMODE, TR_, 1><<<grid, 256, 0, s>>>(a);         \
+    } else {                                                                        \
+      gemm_tn_kernel<T, BN_, BN_, BMODE, TR_, 1><<<grid, 256, 0, s>>>(a);              \
+    }                                                                               \
+  } while (0)
   if (big) {
-    if (g_tr_read) gemm_tn_kernel<T, 128, 128, BMODE, true><<<grid, 256, 0, s>>>(a);
-    else gemm_tn_kernel<T, 128, 128, BMODE, false><<<grid, 256, 0, s>>>(a);
+    if (g_tr_read) EMO_TN_LAUNCH(128, true);
+    else EMO_TN_LAUNCH(128, false);
   } else {
-    if (g_tr_read) gemm_tn_kernel<T, 64, 64, BMODE, true><<<grid, 256, 0, s>>>(a);
-    else gemm_tn_kernel<T, 64, 64, BMODE, false><<<grid, 256, 0, s>>>(a);
+    if (g_tr_read) EMO_TN_LAUNCH(64, true);
+    else EMO_TN_LAUNCH(64, false);
   }
+#undef EMO_TN_LAUNCH
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -504,6 +569,8 @@ int launch_tn(TnArgs a, hipStream_t s) {
 }  // namespace
 
 void emo_gemm_set_tr_read(int v) { g_tr_read = v; }
+void emo_gemm_set_tile(int v) { g_gemm_tile = v; }
+void emo_gemm_set_kb(int v) { g_gemm_kb = v; }
 
 static int check_vec(long ld, int dtype, const char* what) {
   const int vec = dtype == EMO_BF16 ? 8 : 4;

@@ -9,7 +9,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_long, c_uint
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libemoasr_hip.so")
+LIB_PATH = os.environ.get("EMOASR_HIP_LIB") or os.path.join(_HERE, "libemoasr_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_GELU = 0, 1, 2, 3
