@@ -51,6 +51,7 @@ class CallTimer:
 
     def __init__(self, lib_mod, names=None):
         self.lib, self.names, self.rec = lib_mod, names, {}
+        self.attn_pairs = 0.0  # sum over the batch of (valid queries x valid keys), set per step by the caller
         self._orig = lib_mod.call
 
     def __enter__(self):
@@ -67,6 +68,14 @@ class CallTimer:
             elif name in ("emoasr_conv2_fwd", "emoasr_conv2_wgrad"):
                 B, T1, F1, C = args[1], args[2], args[3], args[4]
                 flops = 2.0 * B * ((T1 - 3) // 2 + 1) * ((F1 - 3) // 2 + 1) * C * 9 * C
+            elif name in ("emoasr_attn_fwd", "emoasr_attn_bwd") and self.attn_pairs:
+                # algorithmic matmul count over the VALID (query, key) pairs only (padding excluded):
+                # fwd: Q K^T, Q pos^T (band), P V; bwd adds the recomputation of both score products plus
+                # dP = dO V^T, dV = P^T dO, dQ = dS K (+ dS pos), dK = dS^T Q, dpos = dS^T Q
+                a = args[1]._obj
+                relpos = bool(a.pos)
+                nmm = ((3 if relpos else 2) if name == "emoasr_attn_fwd" else (8 if relpos else 5))
+                flops = 2.0 * nmm * a.H * a.DK * self.attn_pairs
             self.rec.setdefault(name, []).append((e0, e1, flops))
         self.lib.call = call
         import emoasr_amd.ops as ops_mod
@@ -256,6 +265,10 @@ def main():
         opt.step(grad_mult=1.0 / world)
         return loss
 
+    def attn_pairs(bt):
+        sub = [((t - 3) // 2 + 1 - 3) // 2 + 1 for t in bt.xlens]  # Conv2dEncoder: two stride-2 3x3 convs
+        return float(sum(t * t for t in sub))
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
@@ -267,6 +280,7 @@ def main():
     for i in range(args.warmup):
         if i == args.warmup - 1:
             with CallTimer(emo_lib) as ct:
+                ct.attn_pairs = attn_pairs(batches[i])
                 step(batches[i])
             breakdown = ct.summary()
         else:
@@ -277,6 +291,7 @@ def main():
     with CallTimer(emo_lib, names={dominant}) as ct:
         t0 = time.perf_counter()
         for bt in batches[args.warmup:]:
+            ct.attn_pairs = attn_pairs(bt)
             loss = step(bt)
         sync()
         elapsed = time.perf_counter() - t0
