@@ -829,11 +829,19 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
     if (a.pos && a.dpos) {
       const int R = 2 * a.Tq - 1;
       hipMemsetAsync(a.cs, 0, sizeof(float) * a.H * a.ldbd, s);
-      for (int h = 0; h < a.H; ++h) {
-        const T* dbd_h = (const T*)a.dbd + (long)h * a.B * a.Tq * a.ldbd;
-        if (emoasr_gemm_tn(dtype, R, DK, a.B * a.Tq, dbd_h, a.ldbd, (const T*)a.q + h * DK, a.ldq,
-                           a.dpos + h * DK, (long)a.H * DK, 1.f, 1, a.cs + (long)h * a.ldbd, 1.f, s))
-          return 1;
+      // one product per head (reduction over all B*Tq query rows), grouped into one launch
+      for (int h0 = 0; h0 < a.H; h0 += EMOASR_TN_GROUP_MAX) {
+        emoasr_tn_problem_t pr[EMOASR_TN_GROUP_MAX];
+        const int nh = min(a.H - h0, EMOASR_TN_GROUP_MAX);
+        for (int i = 0; i < nh; ++i) {
+          const int h = h0 + i;
+          pr[i] = emoasr_tn_problem_t{R, DK, a.B * a.Tq,
+                                      (const T*)a.dbd + (long)h * a.B * a.Tq * a.ldbd, a.ldbd,
+                                      (const T*)a.q + h * DK, a.ldq,
+                                      a.dpos + h * DK, (long)a.H * DK, 1.f,
+                                      a.cs + (long)h * a.ldbd, 1.f};
+        }
+        if (emoasr_gemm_tn_grouped(dtype, nh, pr, s)) return 1;
       }
       attn_dpos_bias_kernel<<<cdiv((long)R * a.H * DK, 256), 256, 0, s>>>(a);
       if (a.st) {

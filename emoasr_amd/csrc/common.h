@@ -65,6 +65,35 @@ __device__ __forceinline__ void store16(T* p, const Vec16<T>& r) {
 }
 
 // ---------------------------------------------------------------------------
+// Bounds-checked buffer loads.  An offset of EMO_OOB (or anything past the descriptor's size)
+// returns zeros, so a row / time / k guard is one v_cndmask on the offset: no exec-mask branch and
+// no s_waitcnt vmcnt(0) per guarded load (what `cond ? *p : 0` compiles to), i.e. a run of guarded
+// loads stays in flight together.  Offsets are bytes and 32-bit: operands must be < 4 GiB.
+// ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#define EMO_OOB 0xFFFFFFFFu
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFF, 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ Vec16<T> buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  Vec16<T> o;
+  o.v = __builtin_bit_cast(decltype(o.v), v);
+  return o;
+}
+// one element of T (2 or 4 bytes) as f32
+template <typename T>
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  if constexpr (sizeof(T) == 2) {
+    const unsigned short u = __builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0);
+    return __uint_as_float((unsigned)u << 16);
+  } else {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+  }
+}
+
+// ---------------------------------------------------------------------------
 // wave / block reductions (f32)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

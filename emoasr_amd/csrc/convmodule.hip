@@ -14,11 +14,15 @@ constexpr int DW_WCHUNKS = 1; // time chunks per block in the weight-gradient ke
 
 // y[b,t,c] = bias[c] + sum_j w[c,j] * x[b, t + j - pad, c]      (flip=0)
 // dx[b,t,c] =          sum_j w[c,K-1-j] * dy[b, t + j - pad, c]  (flip=1, no bias)
+// The time window is loaded with bounds-checked buffer loads (common.h): all DW_TT + K - 1 guarded
+// loads of a thread are in flight together.  `part` (optional, forward only): per-block BatchNorm
+// partial statistics [block][2][C] = (sum, centred sum of squares about the block mean) of the
+// STORED (rounded to T) outputs of this block's rows; emoasr_bn_stats_finalize merges them.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const T* __restrict__ x,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ bias, T* __restrict__ y,
-                                                     int flip) {
+                                                     int flip, float* __restrict__ part) {
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   const int b = blockIdx.z, t0 = blockIdx.x * DW_TT, pad = (K - 1) / 2;
@@ -27,21 +31,89 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const
   for (int j = 0; j < DW_MAXK; ++j) wr[j] = j < K ? w[c * K + (flip ? K - 1 - j : j)] : 0.f;
   const float bv = bias ? bias[c] : 0.f;
   float win[DW_TT + DW_MAXK - 1];
-  const T* xb = x + (long)b * Tn * C + c;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(x + (long)b * Tn * C);  // one utterance: < 4 GiB
 #pragma unroll
   for (int i = 0; i < DW_TT + DW_MAXK - 1; ++i) {
     const int t = t0 + i - pad;
-    win[i] = (i < DW_TT + K - 1 && t >= 0 && t < Tn) ? to_f32(xb[(long)t * C]) : 0.f;
+    const bool ok = i < DW_TT + K - 1 && t >= 0 && t < Tn;
+    win[i] = buf_load_f32<T>(rs, ok ? (unsigned)(((long)t * C + c) * sizeof(T)) : EMO_OOB);
   }
   T* yb = y + (long)b * Tn * C + c;
+  float out[DW_TT];
+  float s = 0.f;
 #pragma unroll
   for (int i = 0; i < DW_TT; ++i) {
-    if (t0 + i >= Tn) break;
     float acc = bv;
 #pragma unroll
     for (int j = 0; j < DW_MAXK; ++j) acc += wr[j] * win[i + j];
-    yb[(long)(t0 + i) * C] = from_f32<T>(acc);
+    const T r = from_f32<T>(acc);
+    out[i] = t0 + i < Tn ? to_f32(r) : 0.f;
+    s += out[i];
+    if (t0 + i < Tn) yb[(long)(t0 + i) * C] = r;
   }
+  if (part) {
+    const int n = min(DW_TT, Tn - t0);
+    const float mb = s / n;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DW_TT; ++i) {
+      const float d = out[i] - mb;
+      m2 += i < n ? d * d : 0.f;
+    }
+    float* p = part + ((long)b * gridDim.x + blockIdx.x) * 2 * C + c;
+    p[0] = s;
+    p[C] = m2;
+  }
+}
+
+// Merge of the per-block partials (Chan et al.): mean = sum_b s_b / M,
+// M2 = sum_b [ m2_b + n_b (s_b / n_b - mean)^2 ]; var = M2 / M (biased, used to normalise),
+// running_var gets the unbiased M2 / (M - 1) like nn.BatchNorm1d.  One block = 64 channels x 16
+// groups of partial blocks.
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B, int Tn, int C, const float* __restrict__ part,
+                                                                 float* __restrict__ mean, float* __restrict__ var,
+                                                                 float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var, float momentum,
+                                                                 long long* __restrict__ num_batches_tracked) {
+  __shared__ float red[16][64];
+  __shared__ float mean_s[64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int nx = (Tn + DW_TT - 1) / DW_TT, nblk = B * nx;
+  const float M = (float)B * Tn;
+  float s = 0.f;
+  if (c < C)
+    for (int k = grp; k < nblk; k += 16) s += part[(long)k * 2 * C + c];
+  red[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][lane];
+    mean_s[lane] = t / M;
+  }
+  __syncthreads();
+  const float mu = mean_s[lane];
+  float m2 = 0.f;
+  if (c < C)
+    for (int k = grp; k < nblk; k += 16) {
+      const int n = min(DW_TT, Tn - (k % nx) * DW_TT);
+      const float d = part[(long)k * 2 * C + c] / n - mu;
+      m2 += part[(long)k * 2 * C + C + c] + n * d * d;
+    }
+  __syncthreads();
+  red[grp][lane] = m2;
+  __syncthreads();
+  if (grp == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][lane];
+    mean[c] = mu;
+    var[c] = t / M;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (M > 1.f ? t / (M - 1.f) : t / M);
+  }
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
 }
 
 // dw[c,j] += sum_{b,t} dy[b,t,c] * x[b,t+j-pad,c];  dbias[c] += sum dy
@@ -55,8 +127,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(int Tn, int C, int K,
 #pragma unroll
   for (int j = 0; j < DW_MAXK; ++j) acc[j] = 0.f;
   float sb = 0.f;
-  const T* xb = x + (long)b * Tn * C + c;
-  const T* dyb = dy + (long)b * Tn * C + c;
+  const __amdgpu_buffer_rsrc_t rsx = make_rsrc(x + (long)b * Tn * C), rsd = make_rsrc(dy + (long)b * Tn * C);
   // several time chunks per block: fewer same-address atomics (f32 atomics collapse ~14x when
   // every workgroup hits the same few KB)
   for (int cc = 0; cc < DW_WCHUNKS; ++cc) {
@@ -66,11 +137,16 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(int Tn, int C, int K,
 #pragma unroll
     for (int i = 0; i < DW_TT + DW_MAXK - 1; ++i) {
       const int t = t0 + i - pad;
-      win[i] = (i < DW_TT + K - 1 && t >= 0 && t < Tn) ? to_f32(xb[(long)t * C]) : 0.f;
+      const bool ok = i < DW_TT + K - 1 && t >= 0 && t < Tn;
+      win[i] = buf_load_f32<T>(rsx, ok ? (unsigned)(((long)t * C + c) * sizeof(T)) : EMO_OOB);
     }
+    float dv[DW_TT];
+#pragma unroll
+    for (int i = 0; i < DW_TT; ++i)
+      dv[i] = buf_load_f32<T>(rsd, t0 + i < Tn ? (unsigned)(((long)(t0 + i) * C + c) * sizeof(T)) : EMO_OOB);
 #pragma unroll
     for (int i = 0; i < DW_TT; ++i) {
-      const float d = (t0 + i < Tn) ? to_f32(dyb[(long)(t0 + i) * C]) : 0.f;
+      const float d = dv[i];
       sb += d;
 #pragma unroll
       for (int j = 0; j < DW_MAXK; ++j) acc[j] += d * win[i + j];
@@ -223,7 +299,33 @@ extern "C" int emoasr_dwconv_fwd(int dtype, int B, int Tn, int C, int K, const v
   if (B * Tn == 0) return 0;
   dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
   EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)x, w,
-                                                                              bias, (T*)y, 0)));
+                                                                              bias, (T*)y, 0, nullptr)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+// Forward fused with the BatchNorm batch-statistics partials of its output (conformer.py:129-131:
+// depthwise_conv -> batch_norm): `part` holds emoasr_dwconv_stats_floats() floats and is consumed by
+// emoasr_bn_stats_finalize.  Replaces two memsets + two reduction passes over y.
+extern "C" long emoasr_dwconv_stats_floats(int B, int Tn, int C) { return (long)B * cdiv(Tn, DW_TT) * 2 * C; }
+
+extern "C" int emoasr_dwconv_fwd_stats(int dtype, int B, int Tn, int C, int K, const void* x, const float* w,
+                                       const float* bias, void* y, float* part, void* stream) {
+  EMO_CHECK(K <= DW_MAXK && (K & 1), "dwconv: K=%d unsupported", K);
+  EMO_CHECK(part != nullptr && B * Tn > 0, "dwconv_fwd_stats: needs a non-empty batch and the partials buffer");
+  dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
+  EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)x, w,
+                                                                              bias, (T*)y, 0, part)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_bn_stats_finalize(int B, int Tn, int C, const float* part, float* mean, float* var,
+                                        float* running_mean, float* running_var, float momentum,
+                                        long long* num_batches_tracked, void* stream) {
+  EMO_CHECK(B * Tn > 0, "bn_stats_finalize: empty batch");
+  bn_stats_finalize_kernel<<<cdiv(C, 64), 1024, 0, (hipStream_t)stream>>>(B, Tn, C, part, mean, var, running_mean,
+                                                                          running_var, momentum, num_batches_tracked);
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -233,7 +335,7 @@ extern "C" int emoasr_dwconv_bwd_x(int dtype, int B, int Tn, int C, int K, const
   if (B * Tn == 0) return 0;
   dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
   EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)dy, w,
-                                                                              nullptr, (T*)dx, 1)));
+                                                                              nullptr, (T*)dx, 1, nullptr)));
   EMO_LAUNCH_CHECK();
   return 0;
 }

@@ -63,21 +63,6 @@ template <typename T, int KB = 1> struct TileCfg {
   static constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 1);  // padded LDS row (elements)
 };
 
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-// 16-byte buffer load with hardware bounds check: an offset of 0xFFFFFFFF (or anything past the
-// descriptor's size) returns zeros, so row / k guards become one v_cndmask on the offset -- no
-// exec-mask branches and a statically countable number of loads per k-step.
-template <typename T>
-__device__ __forceinline__ Vec16<T> buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
-  Vec16<T> o;
-  o.v = __builtin_bit_cast(decltype(o.v), v);
-  return o;
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFF, 0x00020000);
-}
-#define EMO_OOB 0xFFFFFFFFu
 
 // 8 consecutive elements of T <-> 8 floats (16 bytes of bf16, 32 bytes of f32)
 template <typename T>
@@ -378,8 +363,9 @@ struct TnArgs {
   ConvGeom cg;
 };
 
+// one (n1 tile, n2 tile, k slice) of a TN product; shared by the plain and the grouped kernels
 template <typename T, int BN1, int BN2, int BMODE, bool TR, int KB>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
+__device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const int by, const int bz) {
   using Cfg = TileCfg<T, KB>;
   using M_ = Mma<T>;
   constexpr int VEC = Cfg::VEC, BK = Cfg::BK;
@@ -395,28 +381,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w1 = (wave >> 1) * W1, w2 = (wave & 1) * W2;
-  const int n1_0 = blockIdx.y * BN1, n2_0 = blockIdx.x * BN2;
+  const int n1_0 = by * BN1, n2_0 = bx * BN2;
   const T* __restrict__ A = static_cast<const T*>(g.A);
   const T* __restrict__ B = static_cast<const T*>(g.B);
 
   const int nk_total = (g.K + BK - 1) / BK;
-  const int kt_begin = blockIdx.z * g.k_tiles_per_split;
+  const int kt_begin = bz * g.k_tiles_per_split;
   const int kt_end = nk_total < kt_begin + g.k_tiles_per_split ? nk_total : kt_begin + g.k_tiles_per_split;
   if (kt_begin >= kt_end) return;
 
   int b_koff = 0;
   if constexpr (BMODE == 1) b_koff = conv_k_off(g.cg, n2_0);  // tile lies inside one (kh,kw)
 
-  Vec16<T> a_reg[A_IT], b_reg[B_IT];
+  struct Stage { Vec16<T> a[A_IT], b[B_IT]; };
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A), rsB = make_rsrc(B);
   constexpr unsigned SZ = sizeof(T);
-  auto load_tile = [&](int k0) {
+  auto load_tile = [&](Stage& st, int kt) {
+    const int k0 = kt < kt_end ? kt * BK : g.K;  // past this block's k slice: every offset out of bounds -> zeros
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int v = tid + i * 256, kr = v / AV, nv = (v % AV) * VEC;
       const int k = k0 + kr, n = n1_0 + nv;
       const bool ok = k < g.K && n < g.N1;
-      a_reg[i] = buf_load16<T>(rsA, ok ? (unsigned)(((long)k * g.lda + n) * SZ) : EMO_OOB);
+      st.a[i] = buf_load16<T>(rsA, ok ? (unsigned)(((long)k * g.lda + n) * SZ) : EMO_OOB);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -426,19 +413,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
       unsigned off;
       if constexpr (BMODE == 1) off = (unsigned)((conv_row_base(g.cg, ok ? k : 0) + b_koff + nv) * SZ);
       else off = (unsigned)(((long)k * g.ldb + n) * SZ);
-      b_reg[i] = buf_load16<T>(rsB, ok ? off : EMO_OOB);
+      st.b[i] = buf_load16<T>(rsB, ok ? off : EMO_OOB);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const Stage& st, int buf) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int v = tid + i * 256, kr = v / AV, nv = (v % AV) * VEC;
-      store16(&As[buf][kr * LDA + nv], a_reg[i]);
+      store16(&As[buf][kr * LDA + nv], st.a[i]);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int v = tid + i * 256, kr = v / BV, nv = (v % BV) * VEC;
-      store16(&Bs[buf][kr * LDB + nv], b_reg[i]);
+      store16(&Bs[buf][kr * LDB + nv], st.b[i]);
     }
   };
 
@@ -450,14 +437,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const bool do_colsum = g.colsum != nullptr && blockIdx.x == 0 && tid < BN1;
+  const bool do_colsum = g.colsum != nullptr && bx == 0 && tid < BN1;
   float csum = 0.f;
-  load_tile(kt_begin * BK);
-  store_tile(0);
+  // same 3-deep register ring as the NT kernel (see there)
+  Stage s0, s1, s2;
+  load_tile(s0, kt_begin);
+  load_tile(s1, kt_begin + 1);
+  store_tile(s0, 0);
   __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
+  auto step = [&](int kt, Stage& nxt, Stage& fre) {
     const int buf = (kt - kt_begin) & 1;
-    load_tile(kt + 1 < kt_end ? (kt + 1) * BK : g.K);  // past-the-end tile: all offsets out of bounds -> zeros
+    load_tile(fre, kt + 2);
     if (do_colsum) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) csum += to_f32(As[buf][k * LDA + tid]);
@@ -474,8 +464,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(af[i], bfr[j], acc[i][j]);
     }
-    store_tile(buf ^ 1);
+    store_tile(nxt, buf ^ 1);
     __syncthreads();
+  };
+  for (int kt = kt_begin; kt < kt_end; kt += 3) {
+    step(kt, s1, s2);
+    if (kt + 1 < kt_end) step(kt + 1, s2, s0);
+    if (kt + 2 < kt_end) step(kt + 2, s0, s1);
   }
 
 #pragma unroll
@@ -492,6 +487,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
       }
     }
   if (do_colsum && n1_0 + tid < g.N1) atomicAdd(&g.colsum[n1_0 + tid], g.colsum_scale * csum);
+}
+
+template <typename T, int BN1, int BN2, int BMODE, bool TR, int KB>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
+  tn_block<T, BN1, BN2, BMODE, TR, KB>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped form: up to EMOASR_TN_GROUP_MAX independent products in one launch (the ~10 weight
+// gradients of one encoder layer: each alone is 16..64 tiles, far too few for 256 CUs).  Blocks
+// are numbered problem by problem; start[p] is the first block of problem p.
+struct TnGroup {
+  int n;
+  int start[EMOASR_TN_GROUP_MAX + 1];
+  TnArgs p[EMOASR_TN_GROUP_MAX];
+};
+template <typename T, bool TR, int KB>
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup G) {
+  int p = 0;
+  while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
+  const TnArgs& g = G.p[p];
+  const int local = blockIdx.x - G.start[p];
+  const int tx = (g.N2 + 63) / 64, ty = (g.N1 + 63) / 64;
+  tn_block<T, 64, 64, 0, TR, KB>(g, local % tx, (local / tx) % ty, local / (tx * ty));
 }
 
 template <typename T, int AMODE, bool BKM, bool TR>
@@ -637,6 +655,54 @@ extern "C" int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, l
   a.N1 = N1; a.N2 = N2; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.alpha = alpha; a.colsum = colsum; a.colsum_scale = colsum_scale;
   EMO_DISPATCH(dtype, return (launch_tn<T, 0>(a, (hipStream_t)stream)));
+}
+
+// Grouped weight-gradient products (always accumulating): see TnGroup.
+extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_t* probs, void* stream) {
+  EMO_CHECK(n > 0 && n <= EMOASR_TN_GROUP_MAX, "gemm_tn_grouped: n=%d outside 1..%d", n, EMOASR_TN_GROUP_MAX);
+  const int kb = dtype == EMO_BF16 ? 2 : 1;
+  const int BK = (dtype == EMO_BF16 ? 32 : 16) * kb;
+  TnGroup G{};
+  G.n = n;
+  long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const emoasr_tn_problem_t& q = probs[i];
+    EMO_CHECK(q.N1 > 0 && q.N2 > 0 && q.K > 0, "gemm_tn_grouped: empty problem %d", i);
+    if (check_vec(q.lda, dtype, "lda") || check_vec(q.ldb, dtype, "ldb") || check_vec(q.N2, dtype, "N2")) return 1;
+    EMO_CHECK(q.N1 % (dtype == EMO_BF16 ? 8 : 4) == 0 || q.lda >= (q.N1 + 7) / 8 * 8,
+              "gemm_tn_grouped: ragged N1 needs padded lda");
+    tiles += (long)cdiv(q.N1, 64) * cdiv(q.N2, 64);
+  }
+  // one split factor for the whole group: ~3 blocks per CU over all problems, at least 4 k-tiles per
+  // slice, and per problem no more f32 atomic traffic than ~8 MB (see launch_tn)
+  const int want = (int)std::max(1L, (768 + tiles - 1) / tiles);
+  int start = 0;
+  for (int i = 0; i < n; ++i) {
+    const emoasr_tn_problem_t& q = probs[i];
+    TnArgs& a = G.p[i];
+    a.N1 = q.N1; a.N2 = q.N2; a.K = q.K; a.A = q.A; a.lda = q.lda; a.B = q.B; a.ldb = q.ldb;
+    a.C = q.C; a.ldc = q.ldc; a.alpha = q.alpha; a.colsum = q.colsum; a.colsum_scale = q.colsum_scale;
+    const int nk = cdiv(q.K, BK);
+    const int cap = (int)std::max(1L, (8L << 20) / ((long)q.N1 * q.N2 * 4));
+    int splits = std::max(1, std::min(std::min(want, cap), nk / 4 > 0 ? nk / 4 : 1));
+    a.k_tiles_per_split = cdiv(nk, splits);
+    splits = cdiv(nk, a.k_tiles_per_split);
+    G.start[i] = start;
+    start += cdiv(q.N1, 64) * cdiv(q.N2, 64) * splits;
+  }
+  G.start[n] = start;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EMO_BF16) {
+    if (g_tr_read) gemm_tn_grouped_kernel<bf16, true, 2><<<start, 256, 0, s>>>(G);
+    else gemm_tn_grouped_kernel<bf16, false, 2><<<start, 256, 0, s>>>(G);
+  } else if (dtype == EMO_F32) {
+    gemm_tn_grouped_kernel<float, true, 1><<<start, 256, 0, s>>>(G);
+  } else {
+    emo_set_error("bad dtype %d", dtype);
+    return 1;
+  }
+  EMO_LAUNCH_CHECK();
+  return 0;
 }
 
 // Conv2d(C->C, k3, s2) over channels-last y1[B,T1,F1,C] as an implicit GEMM:

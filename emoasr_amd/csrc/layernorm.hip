@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int N, const T* __re
 // Each block walks ROWS_PER_BLOCK rows (one wave per row at a time) and keeps the
 // per-feature dgamma / dbeta partial sums in registers; one LDS reduction and one
 // f32 atomic per feature per block at the end.
-constexpr int LN_BWD_MAXBLK = 256;  // persistent blocks, 4 rows (one per wave) in flight each
+constexpr int LN_BWD_MAXBLK = 256;   // general kernel: persistent blocks, 4 rows (one per wave) in flight each
+constexpr int LN_BWD8_MAXBLK = 1024;  // N % 8 == 0 kernel: 8 rows (one per half-wave) in flight each
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int N, const T* __restrict__ dy,
@@ -157,24 +158,148 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int N, const T* __re
   }
 }
 
-// 64 columns per block, 4 row groups (one per wave) summed through LDS
+// ---- fast path (N % 8 == 0): one HALF-wave per row, 8 consecutive features (16 bytes of bf16) per
+// lane per 256-feature chunk, 8 rows in flight per block and one row per half-wave per sweep at the
+// model's sizes (M = 7200 rows -> 900 blocks): the kernel is one round trip of loads deep instead of
+// seven dependent ones.  NC = number of 256-feature chunks.
+template <typename T>
+__device__ __forceinline__ void ln_load8(const T* p, float (&o)[8]) {
+  const Vec16<T> v = load16(p);
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v.get(j);
+  } else {
+    const Vec16<T> w = load16(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = v.get(j); o[4 + j] = w.get(j); }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void ln_store8(T* p, const float (&o)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    Vec16<T> v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.set(j, o[j]);
+    store16(p, v);
+  } else {
+    Vec16<T> v, w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v.set(j, o[j]); w.set(j, o[4 + j]); }
+    store16(p, v);
+    store16(p + 4, w);
+  }
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_bwd8_kernel(int M, int N, const T* __restrict__ dy,
+                                                      const T* __restrict__ x,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd,
+                                                      const T* __restrict__ dres, T* __restrict__ dx,
+                                                      float* __restrict__ dgamma_part) {
+  extern __shared__ float red8[];  // [4 waves][2][N]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
+  float dg[NC][8], db[NC][8], g[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = c * 256 + hl * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dg[c][j] = 0.f; db[c][j] = 0.f;
+      g[c][j] = col < N ? gamma[col + j] : 0.f;
+    }
+  }
+  for (int row = (blockIdx.x * 4 + wave) * 2 + half; row < M; row += gridDim.x * 8) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NC][8], gy[NC][8], o[NC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = c * 256 + hl * 8;
+      if (col < N) {
+        float xv[8], dv[8];
+        ln_load8(x + (long)row * N + col, xv);
+        ln_load8(dy + (long)row * N + col, dv);
+        if (dres) ln_load8(dres + (long)row * N + col, o[c]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[c][j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xh[c][j] = (xv[j] - mu) * rs;
+          gy[c][j] = dv[j] * g[c][j];
+          s1 += gy[c][j];
+          s2 += gy[c][j] * xh[c][j];
+          dg[c][j] += dv[j] * xh[c][j];
+          db[c][j] += dv[j];
+        }
+      }
+    }
+    // the two halves of a wave may run different trip counts; xor offsets < 32 stay inside a half
+    s1 = half_wave_sum(s1) / N;
+    s2 = half_wave_sum(s2) / N;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = c * 256 + hl * 8;
+      if (col < N) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[c][j] += rs * (gy[c][j] - s1 - xh[c][j] * s2);
+        ln_store8(dx + (long)row * N + col, o[c]);
+      }
+    }
+  }
+  if (!dgamma_part) return;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = c * 256 + hl * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = dg[c][j] + __shfl_xor(dg[c][j], 32, 64);
+      const float b = db[c][j] + __shfl_xor(db[c][j], 32, 64);
+      if (half == 0 && col < N) {
+        red8[(wave * 2 + 0) * N + col + j] = a;
+        red8[(wave * 2 + 1) * N + col + j] = b;
+      }
+    }
+  }
+  __syncthreads();
+  float* part = dgamma_part + (long)blockIdx.x * 2 * N;
+  for (int i = threadIdx.x; i < 2 * N; i += 256) {
+    const int which = i / N, col = i - which * N;
+    part[i] = red8[(0 * 2 + which) * N + col] + red8[(1 * 2 + which) * N + col] +
+              red8[(2 * 2 + which) * N + col] + red8[(3 * 2 + which) * N + col];
+  }
+}
+
+// Folds the per-block partials: 64 columns (of the 2N) per block in x, a slice of the partial rows
+// per block in y (4 waves each), then one f32 atomic per column per block (gridDim.y-way contention
+// only; dgamma / dbeta are accumulated into, as torch's .grad is).
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(int nblk, int N, const float* __restrict__ part,
                                                               float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;  // over 2N
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
   float s = 0.f;
   if (col < 2 * N) {
 #pragma unroll 8
-    for (int b = wave; b < nblk; b += 4) s += part[(long)b * 2 * N + col];
+    for (int b = b0 + wave; b < b1; b += 4) s += part[(long)b * 2 * N + col];
   }
   red[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && col < 2 * N) {
     s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-    if (col < N) { if (dgamma) dgamma[col] += s; }
-    else if (dbeta) dbeta[col - N] += s;
+    if (col < N) { if (dgamma) atomicAdd(&dgamma[col], s); }
+    else if (dbeta) atomicAdd(&dbeta[col - N], s);
   }
 }
 
@@ -199,15 +324,34 @@ extern "C" int emoasr_layernorm_bwd(int dtype, int M, int N, const void* dy, con
   if (M == 0) return 0;
   const bool want = dgamma || dbeta;
   EMO_CHECK(!want || scratch, "layernorm_bwd: scratch (%d floats) required for dgamma/dbeta",
-            LN_BWD_MAXBLK * 2 * N);
-  const int nblk = std::min(cdiv(M, 4), LN_BWD_MAXBLK);
-  EMO_DISPATCH(dtype, (ln_bwd_kernel<T><<<nblk, 256, 0, (hipStream_t)stream>>>(
-                          M, N, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx,
-                          want ? scratch : nullptr)));
-  if (want)
-    ln_bwd_finalize_kernel<<<cdiv(2 * N, 64), 256, 0, (hipStream_t)stream>>>(nblk, N, scratch, dgamma, dbeta);
+            LN_BWD8_MAXBLK * 2 * N);
+  int nblk;
+  hipStream_t s = (hipStream_t)stream;
+  float* part = want ? scratch : nullptr;
+  if (N % 8 == 0) {
+    nblk = std::min(cdiv(M, 8), LN_BWD8_MAXBLK);
+    const int smem = 4 * 2 * N * (int)sizeof(float);
+#define EMO_LN8(NC_)                                                                              \
+  EMO_DISPATCH(dtype, (ln_bwd8_kernel<T, NC_><<<nblk, 256, smem, s>>>(M, N, (const T*)dy, (const T*)x, gamma, mean, \
+                                                                      rstd, (const T*)dres, (T*)dx, part)))
+    switch (cdiv(N, 256)) {
+      case 1: EMO_LN8(1); break;
+      case 2: EMO_LN8(2); break;
+      case 3: EMO_LN8(3); break;
+      default: EMO_LN8(4); break;
+    }
+#undef EMO_LN8
+  } else {
+    nblk = std::min(cdiv(M, 4), LN_BWD_MAXBLK);
+    EMO_DISPATCH(dtype, (ln_bwd_kernel<T><<<nblk, 256, 0, s>>>(M, N, (const T*)dy, (const T*)x, gamma, mean, rstd,
+                                                               (const T*)dres, (T*)dx, part)));
+  }
+  if (want) {
+    dim3 grid(cdiv(2 * N, 64), std::max(1, std::min(8, nblk / 32)));
+    ln_bwd_finalize_kernel<<<grid, 256, 0, s>>>(nblk, N, scratch, dgamma, dbeta);
+  }
   EMO_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int emoasr_layernorm_bwd_scratch_floats(int N) { return LN_BWD_MAXBLK * 2 * N; }
+extern "C" int emoasr_layernorm_bwd_scratch_floats(int N) { return LN_BWD8_MAXBLK * 2 * N; }

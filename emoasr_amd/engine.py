@@ -183,6 +183,10 @@ class CTCEngine(_DecoderMixinPlaceholder):
         self.arena = ParamArena(module, compute_dtype)
         self._tables = {}
         self._scratch_cache = {}
+        # weight gradients of one encoder layer as one grouped launch (EMOASR_WGRAD_GROUP=0: one by one)
+        self._group_wgrads = os.environ.get("EMOASR_WGRAD_GROUP", "1") != "0"
+        self._defer_wgrads = False
+        self._wq = []
         # keep the scaled scores S^T of the forward for the backward (1) or recompute them (0)
         self.attn_store_scores = os.environ.get("EMOASR_ATTN_STORED", "0") == "1"
         self._bufs = {}
@@ -326,14 +330,15 @@ class CTCEngine(_DecoderMixinPlaceholder):
         g = ops.gemm_nt(h, A.w(name + ".pointwise_conv1.weight", (2 * d, d)), bias=A.p(name + ".pointwise_conv1.bias"))
         gl = ops.glu_fwd(g)
         wd = A.p(name + ".depthwise_conv.weight")
-        c = ops.dwconv_fwd(gl.view(B, T, d), wd.view(d, wd.shape[-1]), A.p(name + ".depthwise_conv.bias")).view(B * T, d)
         bn = name + ".batch_norm"
         rm, rv = self._buffers(bn + ".running_mean"), self._buffers(bn + ".running_var")
-        if training:
-            bmean, bvar = ops.bn_stats(c, rm, rv, 0.1)
-            self._buffers(bn + ".num_batches_tracked").add_(1)
+        wdk, bd = wd.view(d, wd.shape[-1]), A.p(name + ".depthwise_conv.bias")
+        if training:  # batch statistics come out of the conv kernel (per-block partials + one merge)
+            c, bmean, bvar = ops.dwconv_bn_stats_fwd(gl.view(B, T, d), wdk, bd, rm, rv, 0.1,
+                                                     self._buffers(bn + ".num_batches_tracked"))
         else:
-            bmean, bvar = rm, rv
+            c, bmean, bvar = ops.dwconv_fwd(gl.view(B, T, d), wdk, bd), rm, rv
+        c = c.view(B * T, d)
         z = ops.bn_swish_fwd(c, bmean, bvar, A.p(bn + ".weight"), A.p(bn + ".bias"), 1e-5)
         s_out = self._seed(site)
         y = ops.gemm_nt(z, A.w(name + ".pointwise_conv2.weight", (d, d)), bias=A.p(name + ".pointwise_conv2.bias"),
@@ -405,9 +410,23 @@ class CTCEngine(_DecoderMixinPlaceholder):
         A = self.arena
         w = A.w(wname)
         w2 = w.view(w.shape[0], -1)
-        ops.gemm_tn(dy, x_in, out=A.g(wname, tuple(w2.shape)), alpha=alpha, accumulate=True, colsum=A.g(bname),
-                    colsum_scale=alpha)
+        self._wgrad(dy, x_in, A.g(wname, tuple(w2.shape)), alpha, A.g(bname), alpha)
         return ops.gemm_nn(dy, w2, alpha=alpha, **epi)
+
+    def _wgrad(self, dy, x_in, out, alpha=1.0, colsum=None, colsum_scale=1.0):
+        """out += alpha * dy^T @ x_in (+ bias gradient).  Inside the encoder backward the products of
+        one layer are queued and run as ONE grouped launch (_flush_wgrads): each alone is 16..64
+        tiles.  The queue holds references, so operands stay alive (and nothing in the layer
+        backward writes them in place) until the flush."""
+        if self._defer_wgrads:
+            self._wq.append((dy, x_in, out, alpha, colsum, colsum_scale))
+        else:
+            ops.gemm_tn(dy, x_in, out=out, alpha=alpha, accumulate=True, colsum=colsum, colsum_scale=colsum_scale)
+
+    def _flush_wgrads(self):
+        if self._wq:
+            ops.gemm_tn_grouped(self._wq)
+            self._wq = []
 
     def _branch_grad(self, dx, scale, p, seed):
         """gradient entering a residual branch x + scale*dropout(f): returns (dy, alpha)."""
@@ -449,10 +468,10 @@ class CTCEngine(_DecoderMixinPlaceholder):
                      st=sts)
         if pp is not None:
             dpos_t = dpos if self.dtype == torch.float32 else ops.strided_copy(dpos, out_dtype=self.dtype)
-            ops.gemm_tn(dpos_t, pos_t, out=A.g(name + ".linear_pos.weight"), accumulate=True)
+            self._wgrad(dpos_t, pos_t, A.g(name + ".linear_pos.weight"))
         dqkv2 = dqkv.view(B * T, 3 * d)
-        ops.gemm_tn(dqkv2, h, out=A.g_span(name + ".linear_q.weight", name + ".linear_v.weight", (3 * d, d)),
-                    accumulate=True, colsum=A.g_span(name + ".linear_q.bias", name + ".linear_v.bias", (3 * d,)))
+        self._wgrad(dqkv2, h, A.g_span(name + ".linear_q.weight", name + ".linear_v.weight", (3 * d, d)),
+                    1.0, A.g_span(name + ".linear_q.bias", name + ".linear_v.bias", (3 * d,)))
         wqkv = A.w_span(name + ".linear_q.weight", name + ".linear_v.weight", (3 * d, d))
         dh = ops.gemm_nn(dqkv2, wqkv)
         return ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
@@ -491,8 +510,13 @@ class CTCEngine(_DecoderMixinPlaceholder):
     def backward(self, st, deouts):
         """deouts: gradient w.r.t. encoder output [B,T',d] (compute dtype).  Accumulates into the
         gradient arena (p.grad views)."""
-        with ops.stream_scope():
-            return self._backward(st, deouts)
+        self._defer_wgrads = self._group_wgrads
+        try:
+            with ops.stream_scope():
+                return self._backward(st, deouts)
+        finally:
+            self._defer_wgrads = False
+            self._wq = []
 
     def _backward(self, st, deouts):
         A, d = self.arena, self.d
@@ -518,6 +542,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
             else:
                 dx = self._ffn_bwd(name + ".feed_forward", name + ".norm2", s_ff, dx, 1.0, ACT_RELU)
                 dx = self._attn_bwd(name + ".self_attn", name + ".norm1", s_att, dx, B, T, st.elens, None)
+            self._flush_wgrads()
         # ---- positional scaling, Linear, Conv2d x2 -----------------------------------
         pre = "encoder.conv."
         C, F2 = d, st.F2

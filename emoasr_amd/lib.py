@@ -37,6 +37,14 @@ class AttnArgs(Structure):
                 ("st", c_void_p), ("ldst", c_long)]
 
 
+class TnProblem(Structure):
+    _fields_ = [("N1", c_int), ("N2", c_int), ("K", c_int), ("A", c_void_p), ("lda", c_long),
+                ("B", c_void_p), ("ldb", c_long), ("C", c_void_p), ("ldc", c_long), ("alpha", c_float),
+                ("colsum", c_void_p), ("colsum_scale", c_float)]
+
+
+TN_GROUP_MAX = 16
+
 P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
 
 # name -> argtypes (every function returns int status); mirrors include/emoasr_hip.h
@@ -45,6 +53,7 @@ SIGNATURES = {
     "emoasr_gemm_nn": [I, I, I, I, P, L, P, L, P, L, POINTER(Epilogue), P],
     "emoasr_gemm_tn": [I, I, I, I, P, L, P, L, P, L, F, I, P, F, P],
     "emoasr_gemm_nn_batched": [I, I, I, I, P, L, L, L, P, L, L, L, P, L, L, L, I, I, F, I, P],
+    "emoasr_gemm_tn_grouped": [I, I, POINTER(TnProblem), P],
     "emoasr_colsum": [I, I, I, P, L, P, F, I, P],
     "emoasr_conv1_fwd": [I, I, I, I, I, P, P, P, P, P],
     "emoasr_conv1_wgrad": [I, I, I, I, I, P, P, P, P, I, P],
@@ -59,6 +68,8 @@ SIGNATURES = {
     "emoasr_glu_bwd": [I, I, I, P, P, P, P],
     "emoasr_dwconv_fwd": [I, I, I, I, I, P, P, P, P, P],
     "emoasr_dwconv_bwd_x": [I, I, I, I, I, P, P, P, P],
+    "emoasr_dwconv_fwd_stats": [I, I, I, I, I, P, P, P, P, P, P],
+    "emoasr_bn_stats_finalize": [I, I, I, P, P, P, P, P, F, P, P],
     "emoasr_dwconv_bwd_w": [I, I, I, I, I, P, P, P, P, I, P, P],
     "emoasr_bn_stats": [I, I, I, P, P, P, P, P, F, P],
     "emoasr_bn_swish_fwd": [I, I, I, P, P, P, P, P, F, P, P],

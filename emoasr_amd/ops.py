@@ -118,6 +118,24 @@ def gemm_tn(a, b, out=None, alpha=1.0, accumulate=False, colsum=None, colsum_sca
     return out
 
 
+def gemm_tn_grouped(problems):
+    """problems: list of (a[K,N1], b[K,N2], out[N1,N2] f32, alpha, colsum or None, colsum_scale); every
+    out (and colsum) is accumulated into, all in one launch per lib.TN_GROUP_MAX problems."""
+    for i0 in range(0, len(problems), lib.TN_GROUP_MAX):
+        chunk = problems[i0:i0 + lib.TN_GROUP_MAX]
+        arr = (lib.TnProblem * len(chunk))()
+        for q, (a, b, out, alpha, colsum, colsum_scale) in zip(arr, chunk):
+            K, N1, lda = _rows(_chk(a))
+            Kb, N2, ldb = _rows(_chk(b, a.dtype))
+            assert K == Kb and out.shape == (N1, N2) and a.dtype == chunk[0][0].dtype
+            _chk(out, torch.float32)
+            q.N1, q.N2, q.K, q.A, q.lda, q.B, q.ldb = N1, N2, K, a.data_ptr(), lda, b.data_ptr(), ldb
+            q.C, q.ldc, q.alpha = out.data_ptr(), out.stride(0), alpha
+            q.colsum = None if colsum is None else colsum.data_ptr()
+            q.colsum_scale = colsum_scale
+        lib.call("emoasr_gemm_tn_grouped", dt(chunk[0][0]), len(chunk), arr, _stream())
+
+
 def gemm_nn_batched(a, b, out, M, N, K, lda, sa, ldb, sb, ldc, sc, nb, nh, alpha=1.0, accumulate=False):
     """out[b,h] (+)= alpha * a[b,h] (M x K, k-contiguous) @ b[b,h] (K x N, k-major); s* = (outer, inner)
     batch strides in elements; base pointers are the tensors' data pointers."""
@@ -193,7 +211,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
     dx = torch.empty_like(x)
     scratch = None
     if dgamma is not None or dbeta is not None:
-        scratch = torch.empty(512 * 2 * N, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(1024 * 2 * N, device=x.device, dtype=torch.float32)  # emoasr_layernorm_bwd_scratch_floats(N)
     lib.call("emoasr_layernorm_bwd", dt(x), M, N, _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
              _p(dgamma), _p(dbeta), _p(scratch), _stream())
     return dx
@@ -300,6 +318,23 @@ def dwconv_fwd(x, w, bias):
     y = torch.empty_like(x)
     lib.call("emoasr_dwconv_fwd", dt(x), B, T, C, w.shape[-1], _p(_chk(x)), _p(w), _p(bias), _p(y), _stream())
     return y
+
+
+def dwconv_bn_stats_fwd(x, w, bias, running_mean=None, running_var=None, momentum=0.1, num_batches_tracked=None):
+    """depthwise conv + training-mode BatchNorm statistics of its output in two launches:
+    -> (y, batch mean [C], biased batch var [C]); running stats / counter updated in place."""
+    B, T, C = x.shape
+    y = torch.empty_like(x)
+    part = torch.empty(B * ((T + 31) // 32) * 2 * C, device=x.device, dtype=torch.float32)  # emoasr_dwconv_stats_floats
+    lib.call("emoasr_dwconv_fwd_stats", dt(x), B, T, C, w.shape[-1], _p(_chk(x)), _p(w), _p(bias), _p(y), _p(part),
+             _stream())
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    var = torch.empty(C, device=x.device, dtype=torch.float32)
+    if num_batches_tracked is not None:
+        _chk(num_batches_tracked, torch.int64)
+    lib.call("emoasr_bn_stats_finalize", B, T, C, _p(part), _p(mean), _p(var), _p(running_mean), _p(running_var),
+             momentum, _p(num_batches_tracked), _stream())
+    return y, mean, var
 
 
 def dwconv_bwd_x(dy, w):

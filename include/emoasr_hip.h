@@ -75,6 +75,21 @@ int emoasr_gemm_nn_batched(int dtype, int M, int N, int K, const void* A, long l
 int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, long lda, const void* B, long ldb,
                    float* C, long ldc, float alpha, int accumulate, float* colsum, float colsum_scale,
                    void* stream);
+/* Grouped form of emoasr_gemm_tn: n <= EMOASR_TN_GROUP_MAX independent, always-accumulating
+ * products C_i += alpha_i * A_i^T . B_i (+ colsum_i) in ONE launch.  One encoder layer's backward
+ * has ~10 weight gradients of 16..64 output tiles each (autograd would run them as 10 separate
+ * addmm kernels); grouped they fill the chip. */
+#define EMOASR_TN_GROUP_MAX 16
+typedef struct emoasr_tn_problem {
+  int N1, N2, K;
+  const void* A; long lda;
+  const void* B; long ldb;
+  float* C; long ldc;
+  float alpha;
+  float* colsum;        /* optional bias gradient, see emoasr_gemm_tn */
+  float colsum_scale;
+} emoasr_tn_problem_t;
+int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_t* probs, void* stream);
 /* out[N] (+)= scale * sum_rows X[M,N]   (bias gradients) */
 int emoasr_colsum(int dtype, int M, int N, const void* X, long ldx, float* out, float scale,
                   int accumulate, void* stream);
@@ -163,6 +178,17 @@ int emoasr_dwconv_fwd(int dtype, int B, int T, int C, int K, const void* x, cons
                       const float* bias, void* y, void* stream);
 int emoasr_dwconv_bwd_x(int dtype, int B, int T, int C, int K, const void* dy, const float* w, void* dx,
                         void* stream);
+/* depthwise_conv -> batch_norm of conformer.py:129-131 with the batch statistics fused: the conv also
+ * writes per-block (sum, centred sum of squares) partials of its stored output into `part`
+ * (emoasr_dwconv_stats_floats(B,T,C) floats); emoasr_bn_stats_finalize merges them (Chan's parallel
+ * variance) into mean / biased var [C], updates the running statistics (unbiased var, `momentum`) and
+ * increments num_batches_tracked (int64 on the device; all three optional), as nn.BatchNorm1d does. */
+long emoasr_dwconv_stats_floats(int B, int T, int C);
+int emoasr_dwconv_fwd_stats(int dtype, int B, int T, int C, int K, const void* x, const float* w,
+                            const float* bias, void* y, float* part, void* stream);
+int emoasr_bn_stats_finalize(int B, int T, int C, const float* part, float* mean, float* var,
+                             float* running_mean, float* running_var, float momentum,
+                             long long* num_batches_tracked, void* stream);
 /* scratch: emoasr_dwconv_bwd_w_scratch_floats(B,T,C,K) floats of per-block partial sums */
 int emoasr_dwconv_bwd_w(int dtype, int B, int T, int C, int K, const void* dy, const void* x, float* dw,
                         float* dbias, int accumulate, float* scratch, void* stream);

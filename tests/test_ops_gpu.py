@@ -497,3 +497,47 @@ def test_specaug_cmvn(dev):
     assert torch.equal(got, ref)
     mean, std = _rnd(dev, Fd), _rnd(dev, Fd).abs() + 0.5
     _close(ops.cmvn(x.clone(), mean, std), (x - mean) / std, 1e-6, "cmvn")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_gemm_tn_grouped(dev, dtype, tr_mode):
+    """grouped weight-gradient launch == the same products one by one (f32 accumulate + colsum)"""
+    from emoasr_amd import ops
+    shapes = [(200, 64, 96), (1000, 256, 64), (77, 40, 8), (513, 128, 256), (300, 768, 64)]
+    probs, refs = [], []
+    for i, (K, N1, N2) in enumerate(shapes * 4):  # 20 problems: crosses the 16-problem chunk limit
+        lda = (N1 + 7) // 8 * 8
+        a = _rnd(dev, K, lda, dtype=dtype)[:, :N1]
+        b = _rnd(dev, K, N2, dtype=dtype, scale=K ** -0.5)
+        out = torch.randn(N1, N2, device=dev)
+        cs = torch.randn(N1, device=dev) if i % 2 == 0 else None
+        alpha = 0.5 + 0.25 * (i % 3)
+        refs.append((out + alpha * (a.float().t() @ b.float()), None if cs is None else cs + 2.0 * a.float().sum(0)))
+        probs.append((a, b, out, alpha, cs, 2.0))
+    ops.gemm_tn_grouped(probs)
+    for i, ((a, b, out, alpha, cs, _), (ref, ref_cs)) in enumerate(zip(probs, refs)):
+        _close(out, ref, _tol(dtype), f"grouped problem {i}")
+        if cs is not None:
+            _close(cs, ref_cs, 1e-4, f"grouped colsum {i}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_dwconv_bn_stats_fused(dev, dtype):
+    """conv + fused batch statistics == separate conv, then torch mean / var over all B*T rows
+    (padded frames included, as the reference's BatchNorm1d sees them)"""
+    from emoasr_amd import ops
+    for B, T, C, K in [(3, 77, 256, 31), (2, 32, 64, 15), (1, 5, 320, 31)]:
+        x = _rnd(dev, B, T, C, dtype=dtype)
+        w, bias = torch.randn(C, K, device=dev) * 0.2, torch.randn(C, device=dev)
+        rm, rv = torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5
+        nbt = torch.tensor(7, device=dev, dtype=torch.int64)
+        rm0, rv0 = rm.clone(), rv.clone()
+        y, mean, var = ops.dwconv_bn_stats_fwd(x, w, bias, rm, rv, 0.1, nbt)
+        y_ref = ops.dwconv_fwd(x, w, bias)
+        assert torch.equal(y, y_ref)
+        yf = y.float().view(B * T, C)
+        _close(mean, yf.mean(0), 1e-5, "fused bn mean")
+        _close(var, yf.var(0, unbiased=False), 1e-4, "fused bn var")
+        _close(rm, 0.9 * rm0 + 0.1 * yf.mean(0), 1e-5, "running mean")
+        _close(rv, 0.9 * rv0 + 0.1 * yf.var(0, unbiased=True), 1e-4, "running var")
+        assert int(nbt) == 8
