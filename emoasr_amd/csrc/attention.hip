@@ -35,18 +35,21 @@ constexpr int DK = 64;
 template <typename T> struct AttnCfg {
   static constexpr int NK = DK / Mma<T>::KSTEP;         // k-steps over the head dim (4 / 32)
   static constexpr int NS = 32 / Mma<T>::KSTEP;         // k-steps over a 32-row tile (2 / 16)
-  static constexpr int LD = sizeof(T) == 2 ? 96 : 64;   // row stride of staged 64-wide LDS tiles
+  static constexpr int LD = sizeof(T) == 2 ? 72 : 64;   // row stride of staged 64-wide LDS tiles (bf16: 144 B rows ->
+                                                        // conflict-free 16-byte k-contiguous reads)
 };
 
 // ---- fragments straight from global memory (k-contiguous operand) -----------------
 template <typename T>
 __device__ __forceinline__ typename Mma<T>::Frag frag_global(const T* base, long ld, int row, bool valid,
                                                              int kk, int lane, const float* bias) {
+  // bounds-checked buffer loads (common.h): an invalid row is an out-of-range offset, not a branch,
+  // so the NK fragment loads of a tile are all in flight together.  `base` is per (batch, head):
+  // wave-uniform, and one utterance's rows are far below the 4 GiB offset range.
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(base);
   if constexpr (sizeof(T) == 2) {
-    bf16x8 f;
     const int d0 = kk * 16 + 8 * (lane >> 5);
-    if (valid) f = *reinterpret_cast<const bf16x8*>(base + (long)row * ld + d0);
-    else for (int j = 0; j < 8; ++j) f[j] = (bf16)0.f;
+    bf16x8 f = buf_load16<T>(rs, valid ? (unsigned)(((long)row * ld + d0) * 2) : EMO_OOB).v;
     if (bias) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = (bf16)((float)f[j] + bias[d0 + j]);
@@ -54,7 +57,7 @@ __device__ __forceinline__ typename Mma<T>::Frag frag_global(const T* base, long
     return f;
   } else {
     const int d = kk * 2 + (lane >> 5);
-    float v = valid ? base[(long)row * ld + d] : 0.f;
+    float v = buf_load_f32<T>(rs, valid ? (unsigned)(((long)row * ld + d) * 4) : EMO_OOB);
     if (bias) v += bias[d];
     return v;
   }
@@ -65,13 +68,13 @@ template <typename T, int NROWS>
 __device__ __forceinline__ void stage_rows(T* dst, const T* base, long ld, int row0, int row_lo, int row_hi,
                                            int lane, const float* bias) {
   constexpr int VEC = 16 / sizeof(T), PER_ROW = DK / VEC, LD = AttnCfg<T>::LD;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(base);
 #pragma unroll
   for (int v = lane; v < NROWS * PER_ROW; v += 64) {
     const int r = v / PER_ROW, piece = (v % PER_ROW) * VEC;
     const int row = row0 + r;
-    Vec16<T> x;
-    if (row >= row_lo && row < row_hi) x = load16(base + (long)row * ld + piece);
-    else x.zero();
+    const bool ok = row >= row_lo && row < row_hi;
+    Vec16<T> x = buf_load16<T>(rs, ok ? (unsigned)(((long)row * ld + piece) * sizeof(T)) : EMO_OOB);
     if (bias) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) x.set(j, x.get(j) + bias[piece + j]);
@@ -337,6 +340,30 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const emoasr_attn_t a) 
                   to_f32(((const T*)a.out)[bt * a.ldo + h * DK + lane]);
   const float s = wave_sum(x);
   if (lane == 0) a.delta[((long)b * a.H + h) * a.Tq + i] = s;
+  if (a.qu) {  // Q + pos_bias_u / Q + pos_bias_v, dense [B,Tq,H*DK]: operands of the dK and dpos GEMMs
+    const float qx = to_f32(((const T*)a.q)[bt * a.ldq + h * DK + lane]);
+    const long o = (bt * a.H + h) * DK + lane;
+    ((T*)a.qu)[o] = from_f32<T>(qx + a.bias_u[h * DK + lane]);
+    ((T*)a.qv)[o] = from_f32<T>(qx + a.bias_v[h * DK + lane]);
+  }
+}
+
+// dbias_u / dbias_v += sum over (batch, query tile) of the partials the dq kernel wrote:
+// part[blk][h][which][d]; one block per (h, which), 4 waves split the partial rows
+__global__ __launch_bounds__(256) void attn_dbias_reduce_kernel(int nblk, int H, const float* __restrict__ part,
+                                                                float* __restrict__ dbias_u,
+                                                                float* __restrict__ dbias_v) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.x >> 1, which = blockIdx.x & 1;
+  float* dst = which ? dbias_v : dbias_u;
+  if (!dst) return;
+  float s = 0.f;
+#pragma unroll 8
+  for (int k = wave; k < nblk; k += 4) s += part[(((long)k * H + h) * 2 + which) * DK + lane];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) dst[h * DK + lane] += red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 // ====================================================================================
@@ -540,6 +567,280 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const emoasr_attn_t a)
       }
   }
   if (!STORED && hp.pos) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqu[dt][r] += dqv[dt][r];
+  }
+  store_dT<T>((T*)hp.dq, a.ldq, i0, a.Tq, dqu, 1.f, lane);
+}
+
+// ====================================================================================
+// backward, materialised mode (the default path): dq, dbias_u, dbias_v and the P^T / dS^T / dBD
+// images the batched GEMMs of launch_bwd_tr consume.  Same mathematics as attn_bwd_dq_kernel,
+// restructured around memory latency:
+//   * every global operand of a key tile (K rows, the 64 band rows of pos, the V fragments) is
+//     fetched ONCE, one tile ahead, into registers with bounds-checked buffer loads while the
+//     current tile is being worked on; K and pos reach the MFMAs through LDS in both roles
+//     (score operand via k-contiguous reads, dQ operand via transposed reads);
+//   * the band skew runs in two 32x32 halves and the dS / P images are kept in T, so a wave needs
+//     ~18.5 KB of LDS in bf16: two blocks (8 waves) per CU instead of one.
+// ====================================================================================
+#ifndef EMO_DQ_SKIP
+#define EMO_DQ_SKIP 0  // timing experiments only: bit mask of pieces to leave out (results are then wrong)
+#endif
+template <typename T> struct DqCfg {
+  static constexpr int IMG_LD = sizeof(T) == 2 ? 40 : 33;  // image row stride (bf16: 80 B rows -> 16-byte reads)
+  static constexpr int IMG_ELEMS = 32 * IMG_LD;
+  static constexpr int IMG_BYTES = 2 * IMG_ELEMS * (int)sizeof(T);
+  static constexpr int GS_BYTES = ((IMG_BYTES > 32 * 32 * 4 ? IMG_BYTES : 32 * 32 * 4) + 15) / 16 * 16;
+  static constexpr int RED_BYTES = 2 * 32 * 64 * 4;         // cross-wave dq reduction image
+  static constexpr int STAGE_BYTES = 96 * AttnCfg<T>::LD * (int)sizeof(T);
+  static constexpr int WAVE_BYTES =
+      GS_BYTES + STAGE_BYTES > RED_BYTES ? GS_BYTES + STAGE_BYTES : RED_BYTES;
+  static constexpr int KR = 32 * DK * (int)sizeof(T) / 16 / 64;  // 16-byte pieces of a 32-row tile per lane
+};
+
+template <typename T, bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const emoasr_attn_t a) {
+  using M_ = Mma<T>;
+  using C_ = DqCfg<T>;
+  constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = AttnCfg<T>::LD;
+  constexpr int KR = C_::KR, IMG = C_::IMG_LD, VEC = 16 / sizeof(T), PER_ROW = DK / VEC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31;
+  const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  if (i0 >= a.Tq) return;
+  char* mine = smem + wave * C_::WAVE_BYTES;
+  float* Gs = reinterpret_cast<float*>(mine);              // one 32x32 f32 skew half ...
+  T* img_ds = reinterpret_cast<T*>(mine);                  // ... later reused by the dS^T / P^T images
+  T* img_p = img_ds + C_::IMG_ELEMS;
+  T* Ks = reinterpret_cast<T*>(mine + C_::GS_BYTES);       // [32][LD]
+  T* Bs = Ks + 32 * LD;                                    // [64][LD] band rows
+
+  const HeadPtrs hp = head_ptrs<T>(a, b, h);
+  const bool rel = hp.pos != nullptr;
+  const int qi = i0 + il;
+  const bool qval = qi < a.Tq;
+  typename M_::Frag qu[NK], qv[NK], dof[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    qu[kk] = frag_global<T>((const T*)hp.q, a.ldq, qi, qval, kk, lane, hp.bias_u);
+    qv[kk] = rel ? frag_global<T>((const T*)hp.q, a.ldq, qi, qval, kk, lane, hp.bias_v) : qu[kk];
+    dof[kk] = frag_global<T>((const T*)hp.dout, a.ldo, qi, qval, kk, lane, nullptr);
+  }
+  const float lse_q = qval ? hp.lse[qi] : -INFINITY;
+  const float del_q = qval ? hp.delta[qi] : 0.f;
+  const uint64_t drop_base = drop_index(a, b, h, qi, 0);
+  f32x16 dqu[2], dqv[2];
+  zero16(dqu[0]); zero16(dqu[1]); zero16(dqv[0]); zero16(dqv[1]);
+  int kend = hp.klen;
+  if (a.causal) kend = min(kend, i0 + 32);
+
+  // ---- one-tile-ahead operand fetch ------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k), rsP = make_rsrc(rel ? hp.pos : hp.k);
+  Vec16<T> kreg[KR], preg[2 * KR];
+  typename M_::Frag vf[NK];
+  auto fetch = [&](int j0) {
+    const bool live = j0 < kend;  // past the last tile: every offset out of bounds, no traffic
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+      const int v = lane + 64 * i, r = v / PER_ROW, piece = (v % PER_ROW) * VEC, row = j0 + r;
+      kreg[i] = buf_load16<T>(rsK, live && row < a.Tk ? (unsigned)(((long)row * a.ldk + piece) * sizeof(T)) : EMO_OOB);
+    }
+    if (rel) {
+      const int rbase = a.Tq - 32 - i0 + j0;
+#pragma unroll
+      for (int i = 0; i < 2 * KR; ++i) {
+        const int v = lane + 64 * i, r = v / PER_ROW, piece = (v % PER_ROW) * VEC, row = rbase + r;
+        const bool ok = live && row >= 0 && row < 2 * a.Tq - 1;
+        preg[i] = buf_load16<T>(rsP, ok ? (unsigned)(((long)row * a.ldp + piece) * sizeof(T)) : EMO_OOB);
+      }
+    }
+    const int krow = j0 + il;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+      vf[kk] = frag_global<T>((const T*)hp.v, a.ldv, krow, live && krow < a.Tk, kk, lane, nullptr);
+  };
+  fetch(wave * 32);
+
+  for (int j0 = wave * 32; j0 < kend; j0 += 128) {
+    // registers -> LDS (the previous iteration ended with a wave barrier: the stage is free)
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+      const int v = lane + 64 * i;
+      store16(Ks + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, kreg[i]);
+    }
+    if (rel) {
+#pragma unroll
+      for (int i = 0; i < 2 * KR; ++i) {
+        const int v = lane + 64 * i;
+        store16(Bs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, preg[i]);
+      }
+    }
+    // dP^T = V . dO^T   (rows keys, cols queries), then the next tile's loads go out
+    f32x16 dp;
+    zero16(dp);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) dp = M_::mma(vf[kk], dof[kk], dp);
+    __builtin_amdgcn_wave_barrier();
+    fetch(j0 + 128);
+
+    // S^T = K . (Q+u)^T + skew(pos_band . (Q+v)^T)
+    f32x16 s;
+    zero16(s);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) s = M_::mma(M_::load_kc(Ks, LD, 0, kk * M_::KSTEP, lane), qu[kk], s);
+    if (rel && !(EMO_DQ_SKIP & 8)) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x16 g;
+        zero16(g);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+          g = M_::mma(M_::load_kc(Bs + 32 * ct * LD, LD, 0, kk * M_::KSTEP, lane), qv[kk], g);  // g[c][i]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Gs[c_row(r, lane) * 32 + il] = g[r];
+        __builtin_amdgcn_wave_barrier();
+        // element (key jl, query il) sits in band column c = 31 - il + jl: first half iff jl <= il
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int jl = c_row(r, lane);
+          const int c = ct == 0 ? 31 - il + jl : jl - il - 1;
+          const bool use = ct == 0 ? jl <= il : jl > il;
+          const float gv = Gs[(use ? c : 0) * 32 + il];
+          s[r] += use ? gv : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    f32x16 ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kj = j0 + c_row(r, lane);
+      const bool masked = kj >= hp.klen || (a.causal && kj > qi) || lse_q == -INFINITY;
+      const float p = masked ? 0.f : __expf(s[r] * a.scale - lse_q);
+      float dsc = 1.f;
+      if (a.drop_p > 0.f && !(EMO_DQ_SKIP & 4)) dsc = dropout_scale(a.seed, drop_base + (uint64_t)kj, a.drop_p);
+      ds[r] = p * (dp[r] * dsc - del_q) * a.scale;
+      img_ds[c_row(r, lane) * IMG + il] = from_f32<T>(ds[r]);
+      img_p[c_row(r, lane) * IMG + il] = from_f32<T>(p * dsc);
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      // P^T (after dropout) and dS^T go to HBM once, as 16-query row pieces
+      const int kl = lane >> 1, c0 = (lane & 1) * 16;
+      if (j0 + kl < a.Tk && !(EMO_DQ_SKIP & 2)) {
+        const long o = (((long)b * a.H + h) * a.Tk + j0 + kl) * a.ldpd + i0 + c0;
+#pragma unroll
+        for (int g8 = 0; g8 < 2; ++g8) {
+          if (i0 + c0 + 8 * g8 < a.ldpd) {  // padded columns may hold anything (never multiplied in)
+            if constexpr (sizeof(T) == 2) {
+              *reinterpret_cast<bf16x8*>((T*)a.dsT + o + 8 * g8) =
+                  *reinterpret_cast<const bf16x8*>(img_ds + kl * IMG + c0 + 8 * g8);
+              *reinterpret_cast<bf16x8*>((T*)a.pdT + o + 8 * g8) =
+                  *reinterpret_cast<const bf16x8*>(img_p + kl * IMG + c0 + 8 * g8);
+            } else {
+              float vd[8], vp[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                vd[e] = img_ds[kl * IMG + c0 + 8 * g8 + e];
+                vp[e] = img_p[kl * IMG + c0 + 8 * g8 + e];
+              }
+              store_vec8<T>((T*)a.dsT + o + 8 * g8, vd);
+              store_vec8<T>((T*)a.pdT + o + 8 * g8, vp);
+            }
+          }
+        }
+      }
+    }
+    // dQu^T += K^T . dS^T
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+        dqu[dt] = M_::mma(chain_a<T, TR>(Ks, ks, 32 * dt, lane), chain_b<T>(ds, ks), dqu[dt]);
+    if (rel) {
+      const int rbase = a.Tq - 32 - i0 + j0;
+      if (a.dbd && !(EMO_DQ_SKIP & 1)) {
+        // dBD[h, b, i, r] (r = table row, contiguous): lane <-> band column, one query row per
+        // iteration -> contiguous 64-wide row segments.  Each (i, r) belongs to exactly one key tile.
+        T* drow = (T*)a.dbd + (((long)h * a.B + b) * a.Tq + i0) * a.ldbd;
+        const int row = rbase + lane;
+        const bool rok = row >= 0 && row < 2 * a.Tq - 1;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) {
+          const int key = lane - 31 + q;
+          if (rok && key >= 0 && key < 32 && i0 + q < a.Tq) drow[(long)q * a.ldbd + row] = img_ds[key * IMG + q];
+        }
+      }
+      if (!(EMO_DQ_SKIP & 16))
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x16 dg;  // dG^T[c][i] = dS^T[c - 31 + i][i]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * ct + c_row(r, lane) - 31 + il;
+          const bool in = key >= 0 && key < 32;
+          const float gv = to_f32(img_ds[(in ? key : 0) * IMG + il]);
+          dg[r] = in ? gv : 0.f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int ks = 0; ks < NS; ++ks)
+            dqv[dt] = M_::mma(chain_a<T, TR>(Bs + 32 * ct * LD, ks, 32 * dt, lane), chain_b<T>(dg, ks), dqv[dt]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // fold the four waves' partial dQu / dQv through LDS (the wave-private regions are free now)
+  {
+    float* red = reinterpret_cast<float*>(mine);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        red[((dt * 16 + r) * 2 + 0) * 64 + lane] = dqu[dt][r];
+        red[((dt * 16 + r) * 2 + 1) * 64 + lane] = dqv[dt][r];
+      }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float* other = reinterpret_cast<const float*>(smem + w * C_::WAVE_BYTES);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dqu[dt][r] += other[((dt * 16 + r) * 2 + 0) * 64 + lane];
+          dqv[dt][r] += other[((dt * 16 + r) * 2 + 1) * 64 + lane];
+        }
+    }
+  }
+  if (a.dbias_u || a.dbias_v) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float su = qval ? dqu[dt][r] : 0.f, sv = qval ? dqv[dt][r] : 0.f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { su += __shfl_xor(su, o, 64); sv += __shfl_xor(sv, o, 64); }
+        if (il == 0) {
+          const int d = 32 * dt + c_row(r, lane);
+          if (a.dbias_part) {  // per-(batch, query tile) partials, folded by attn_dbias_reduce_kernel
+            float* pp = a.dbias_part + ((((long)b * gridDim.x + blockIdx.x) * a.H + h) * 2) * DK + d;
+            pp[0] = su;
+            pp[DK] = rel ? sv : 0.f;
+          } else {
+            if (a.dbias_u) atomicAdd(&a.dbias_u[h * DK + d], su);
+            if (a.dbias_v && rel) atomicAdd(&a.dbias_v[h * DK + d], sv);
+          }
+        }
+      }
+  }
+  if (rel) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -803,7 +1104,15 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
   constexpr int LD = AttnCfg<T>::LD;
   const long rows = (long)a.B * a.Tq * a.H;
   attn_delta_kernel<T><<<cdiv(rows, 4), 256, 0, s>>>(a);
-  {
+  if (a.pdT && !a.st) {
+    const int smem = 4 * DqCfg<T>::WAVE_BYTES;
+    dim3 grid(cdiv(a.Tq, 32), a.H, a.B);
+    if (set_smem(attn_bwd_dq2_kernel<T, TR>, smem)) return 1;
+    attn_bwd_dq2_kernel<T, TR><<<grid, 256, smem, s>>>(a);
+    if (a.dbias_part && (a.dbias_u || a.dbias_v))
+      attn_dbias_reduce_kernel<<<2 * a.H, 256, 0, s>>>(a.B * (int)grid.x, a.H, a.dbias_part, a.dbias_u,
+                                                        a.pos ? a.dbias_v : nullptr);
+  } else {
     const int smem = 4 * (DQ_GS_FLOATS * 4 + 96 * LD * (int)sizeof(T));
     dim3 grid(cdiv(a.Tq, 32), a.H, a.B);
     if (a.st && a.pdT) {
@@ -822,11 +1131,28 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
     if (emoasr_gemm_nn_batched(dtype, a.Tk, DK, a.Tq, a.pdT, a.ldpd, sp_b, sp_h, a.dout, a.ldo,
                                (long)a.Tq * a.ldo, DK, a.dv, a.ldv, (long)a.Tk * a.ldv, DK, a.B, a.H, 1.f, 0, s))
       return 1;
-    if (emoasr_gemm_nn_batched(dtype, a.Tk, DK, a.Tq, a.dsT, a.ldpd, sp_b, sp_h, a.q, a.ldq,
-                               (long)a.Tq * a.ldq, DK, a.dk, a.ldk, (long)a.Tk * a.ldk, DK, a.B, a.H, 1.f, 0, s))
+    const bool dense_q = a.qu && a.qv && !a.st;  // Q+u / Q+v materialised by the delta pass
+    const void* qk = dense_q ? a.qu : a.q;
+    const long ldqk = dense_q ? (long)a.H * DK : a.ldq;
+    if (emoasr_gemm_nn_batched(dtype, a.Tk, DK, a.Tq, a.dsT, a.ldpd, sp_b, sp_h, qk, ldqk,
+                               (long)a.Tq * ldqk, DK, a.dk, a.ldk, (long)a.Tk * a.ldk, DK, a.B, a.H, 1.f, 0, s))
       return 1;
-    if (a.bias_u) attn_dk_bias_kernel<T><<<cdiv((long)a.B * a.H * a.Tk, 4), 256, 0, s>>>(a);
-    if (a.pos && a.dpos) {
+    if (a.bias_u && !dense_q) attn_dk_bias_kernel<T><<<cdiv((long)a.B * a.H * a.Tk, 4), 256, 0, s>>>(a);
+    if (a.pos && a.dpos && dense_q) {
+      const int R = 2 * a.Tq - 1;
+      for (int h0 = 0; h0 < a.H; h0 += EMOASR_TN_GROUP_MAX) {
+        emoasr_tn_problem_t pr[EMOASR_TN_GROUP_MAX];
+        const int nh = min(a.H - h0, EMOASR_TN_GROUP_MAX);
+        for (int i = 0; i < nh; ++i) {
+          const int h = h0 + i;
+          pr[i] = emoasr_tn_problem_t{R, DK, a.B * a.Tq,
+                                      (const T*)a.dbd + (long)h * a.B * a.Tq * a.ldbd, a.ldbd,
+                                      (const T*)a.qv + h * DK, ldqk,
+                                      a.dpos + h * DK, (long)a.H * DK, 1.f, nullptr, 0.f};
+        }
+        if (emoasr_gemm_tn_grouped(dtype, nh, pr, s)) return 1;
+      }
+    } else if (a.pos && a.dpos) {
       const int R = 2 * a.Tq - 1;
       hipMemsetAsync(a.cs, 0, sizeof(float) * a.H * a.ldbd, s);
       // one product per head (reduction over all B*Tq query rows), grouped into one launch

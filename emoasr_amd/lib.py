@@ -34,7 +34,8 @@ class AttnArgs(Structure):
                 ("dpos", c_void_p), ("dbias_u", c_void_p), ("dbias_v", c_void_p),
                 ("pdT", c_void_p), ("dsT", c_void_p), ("dbd", c_void_p),
                 ("ldpd", c_long), ("ldbd", c_long), ("cs", c_void_p),
-                ("st", c_void_p), ("ldst", c_long)]
+                ("st", c_void_p), ("ldst", c_long),
+                ("qu", c_void_p), ("qv", c_void_p), ("dbias_part", c_void_p)]
 
 
 class TnProblem(Structure):

@@ -266,6 +266,10 @@ class AttnScratch:
         self.dsT = torch.zeros(B, H, Tk, self.ldpd, device=device, dtype=dtype)
         self.dbd = torch.zeros(H, B, Tq, self.ldbd, device=device, dtype=dtype) if rel else None
         self.cs = torch.empty(H, self.ldbd, device=device, dtype=torch.float32) if rel else None
+        # Q + pos_bias_u / Q + pos_bias_v and the per-query-tile dbias partial sums (emoasr_attn_t.qu/qv/dbias_part)
+        self.qu = torch.empty(B, Tq, H * 64, device=device, dtype=dtype) if rel else None
+        self.qv = torch.empty(B, Tq, H * 64, device=device, dtype=dtype) if rel else None
+        self.dbias_part = torch.empty(B * ((Tq + 31) // 32), H, 2, 64, device=device, dtype=torch.float32)
 
 
 def attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=None, bias_u=None, bias_v=None, klens=None,
@@ -293,6 +297,9 @@ def attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=None, bias_u=Non
         a.pdT, a.dsT, a.ldpd = scratch.pdT.data_ptr(), scratch.dsT.data_ptr(), scratch.ldpd
         if rel:
             a.dbd, a.ldbd, a.cs = scratch.dbd.data_ptr(), scratch.ldbd, scratch.cs.data_ptr()
+            if bias_u is not None and bias_v is not None and q.shape[2] == H * 64:
+                a.qu, a.qv = scratch.qu.data_ptr(), scratch.qv.data_ptr()
+        a.dbias_part = scratch.dbias_part.data_ptr()
         if st is not None:  # scores stored by attn_fwd(store_scores=True): no recomputation
             a.st, a.ldst = st.data_ptr(), st.shape[-1]
     lib.call("emoasr_attn_bwd", dt(q), byref(a), _stream())

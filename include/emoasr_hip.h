@@ -165,6 +165,12 @@ typedef struct {
    * the stored dBD band. */
   float* st;
   long ldst;
+  /* optional, materialised backward only: Q + pos_bias_u and Q + pos_bias_v as dense T [B,Tq,H*DK]
+   * tensors (written by the backward's first pass; the dK and dpos GEMMs then need no bias fix-up
+   * passes), and per-(batch, query tile) partial sums of dbias_u / dbias_v, f32
+   * [B * ceil(Tq/32), H, 2, DK], folded by one small reduction instead of contended atomics. */
+  void *qu, *qv;
+  float* dbias_part;
 } emoasr_attn_t;
 int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream);
 int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream);

@@ -1,6 +1,6 @@
 """Time the attention entry points alone at the L2 shape (B=24, T'=299)."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import math, torch
 from emoasr_amd import ops
 dev = torch.device("cuda:0")

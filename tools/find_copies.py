@@ -1,6 +1,6 @@
 """Which call sites issue torch copy / fill ops in one training step?  (monkeypatched Tensor methods)"""
 import os, sys, traceback
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = ["bench.py", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-decode"]
 import torch
 from collections import Counter

@@ -1,6 +1,6 @@
 """Micro-benchmark of the GEMM entry points on the L2 model's shapes (B*T' = 7200 rows)."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from emoasr_amd import ops
 

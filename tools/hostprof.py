@@ -1,5 +1,5 @@
 import cProfile, pstats, sys, time, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = ["bench.py", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-decode"]
 import torch
 import bench

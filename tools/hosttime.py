@@ -1,6 +1,6 @@
 """Measure host-side cost of one training step: (a) python only (C calls skipped), (b) full."""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from types import SimpleNamespace
 import bench
