@@ -326,25 +326,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const emoasr_attn_t a) {
   if (lane < 32 && qval) hp.lse[qi] = l > 0.f ? m + __logf(l) : -INFINITY;
 }
 
-// delta[b,h,i] = sum_d dout[b,i,h,d] * out[b,i,h,d]
+// delta[b,h,i] = sum_d dout[b,i,h,d] * out[b,i,h,d]; optionally also Q + pos_bias_u / Q + pos_bias_v as
+// dense [B,Tq,H*DK] tensors (operands of the dK and dpos GEMMs).  8 lanes x 8 elements per (b,i,h) row.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const emoasr_attn_t a) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*Tq*H
-  const long total = (long)a.B * a.Tq * a.H;
-  if (row >= total) return;
-  const int h = row % a.H;
-  const long bt = row / a.H;
-  const int i = bt % a.Tq, b = bt / a.Tq;
-  const float x = to_f32(((const T*)a.dout)[bt * a.ldo + h * DK + lane]) *
-                  to_f32(((const T*)a.out)[bt * a.ldo + h * DK + lane]);
-  const float s = wave_sum(x);
-  if (lane == 0) a.delta[((long)b * a.H + h) * a.Tq + i] = s;
-  if (a.qu) {  // Q + pos_bias_u / Q + pos_bias_v, dense [B,Tq,H*DK]: operands of the dK and dpos GEMMs
-    const float qx = to_f32(((const T*)a.q)[bt * a.ldq + h * DK + lane]);
-    const long o = (bt * a.H + h) * DK + lane;
-    ((T*)a.qu)[o] = from_f32<T>(qx + a.bias_u[h * DK + lane]);
-    ((T*)a.qv)[o] = from_f32<T>(qx + a.bias_v[h * DK + lane]);
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over B*Tq*H rows x 8 lanes
+  const long row = idx >> 3, total = (long)a.B * a.Tq * a.H;
+  const int d0 = (int)(idx & 7) * 8;
+  const bool ok = row < total;
+  const int h = ok ? (int)(row % a.H) : 0;
+  const long bt = ok ? row / a.H : 0;
+  float dv[8], ov[8];
+  load8<T>((const T*)a.dout + bt * a.ldo + h * DK + d0, dv);
+  load8<T>((const T*)a.out + bt * a.ldo + h * DK + d0, ov);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += dv[j] * ov[j];
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  if (!ok) return;
+  const int i = (int)(bt % a.Tq), b = (int)(bt / a.Tq);
+  if (d0 == 0) a.delta[((long)b * a.H + h) * a.Tq + i] = s;
+  if (a.qu) {
+    float qx[8], u[8], v[8];
+    load8<T>((const T*)a.q + bt * a.ldq + h * DK + d0, qx);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { u[j] = qx[j] + a.bias_u[h * DK + d0 + j]; v[j] = qx[j] + a.bias_v[h * DK + d0 + j]; }
+    const long o = (bt * a.H + h) * DK + d0;
+    store8<T>((T*)a.qu + o, u);
+    store8<T>((T*)a.qv + o, v);
   }
 }
 
@@ -1103,7 +1112,7 @@ template <typename T, bool TR>
 int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
   constexpr int LD = AttnCfg<T>::LD;
   const long rows = (long)a.B * a.Tq * a.H;
-  attn_delta_kernel<T><<<cdiv(rows, 4), 256, 0, s>>>(a);
+  attn_delta_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a);
   if (a.pdT && !a.st) {
     const int smem = 4 * DqCfg<T>::WAVE_BYTES;
     dim3 grid(cdiv(a.Tq, 32), a.H, a.B);

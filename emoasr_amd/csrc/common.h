@@ -93,6 +93,48 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
   }
 }
 
+// 8 consecutive elements of T as f32 (one 16-byte load for bf16, two for f32); zeros when !ok
+template <typename T>
+__device__ __forceinline__ void buf_load8(__amdgpu_buffer_rsrc_t r, long elem_off, bool ok, float (&o)[8]) {
+  const unsigned off = ok ? (unsigned)(elem_off * (long)sizeof(T)) : EMO_OOB;
+  const Vec16<T> v = buf_load16<T>(r, off);
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v.get(j);
+  } else {
+    const Vec16<T> w = buf_load16<T>(r, ok ? off + 16u : EMO_OOB);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = v.get(j); o[4 + j] = w.get(j); }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&o)[8]) {
+  const Vec16<T> v = load16(p);
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v.get(j);
+  } else {
+    const Vec16<T> w = load16(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = v.get(j); o[4 + j] = w.get(j); }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&o)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    Vec16<T> v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.set(j, o[j]);
+    store16(p, v);
+  } else {
+    Vec16<T> v, w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v.set(j, o[j]); w.set(j, o[4 + j]); }
+    store16(p, v);
+    store16(p + 4, w);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // wave / block reductions (f32)
 // ---------------------------------------------------------------------------

@@ -82,8 +82,10 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B, int Tn, 
   const int nx = (Tn + DW_TT - 1) / DW_TT, nblk = B * nx;
   const float M = (float)B * Tn;
   float s = 0.f;
-  if (c < C)
+  if (c < C) {
+#pragma unroll 16
     for (int k = grp; k < nblk; k += 16) s += part[(long)k * 2 * C + c];
+  }
   red[grp][lane] = s;
   __syncthreads();
   if (grp == 0) {
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B, int Tn, 
   const float mu = mean_s[lane];
   float m2 = 0.f;
   if (c < C)
+#pragma unroll 16
     for (int k = grp; k < nblk; k += 16) {
       const int n = min(DW_TT, Tn - (k % nx) * DW_TT);
       const float d = part[(long)k * 2 * C + c] / n - mu;
@@ -237,7 +240,15 @@ __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(long n, int C, const 
   }
 }
 
-// pass 1: sums[c] += dbn, sums[C+c] += dbn*xhat  with dbn = dz * swish'(bn)
+// ---- BatchNorm + Swish backward (training statistics), C % 8 == 0 ------------------------------
+// Layout of both passes: a block is 8 row-lanes x 32 channel groups of 8 channels (16-byte loads);
+// rows r0 + lane_row + 8*it.  Pass 1 writes per-block partial sums [block][2][C] (no atomics, no
+// zeroing); pass 2 first folds the few partial rows for its channels (block-cooperatively through
+// LDS), then applies.
+constexpr int BN_SUM_ROWS = 128;  // rows per block of pass 1 (-> M/128 partial rows)
+constexpr int BN_APPLY_ROWS = 32; // rows per block of pass 2
+
+// pass 1: part[blk][c] = sum dbn, part[blk][C+c] = sum dbn*xhat   with dbn = dz * swish'(bn)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(int M, int C, const T* __restrict__ dz,
                                                           const T* __restrict__ y,
@@ -245,20 +256,45 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(int M, int C, const T*
                                                           const float* __restrict__ var,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ sums) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float mu = mean[c], is = rsqrtf(var[c] + eps), g = gamma[c], bt = beta[c];
-  const int r0 = blockIdx.y * BN_STAT_ROWS, r1 = min(M, r0 + BN_STAT_ROWS);
-  float s1 = 0.f, s2 = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const long i = (long)r * C + c;
-    const float xh = (to_f32(y[i]) - mu) * is;
-    const float dbn = to_f32(dz[i]) * dswishf_(g * xh + bt);
-    s1 += dbn; s2 += dbn * xh;
+                                                          float* __restrict__ part) {
+  __shared__ float red[8][2][256];
+  const int hl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + hl * 8;
+  const bool cok = c < C;
+  float mu[8], is[8], g[8], bt[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = cok ? mean[c + j] : 0.f; is[j] = cok ? rsqrtf(var[c + j] + eps) : 0.f;
+    g[j] = cok ? gamma[c + j] : 0.f; bt[j] = cok ? beta[c + j] : 0.f;
+    s1[j] = 0.f; s2[j] = 0.f;
   }
-  atomicAdd(&sums[c], s1);
-  atomicAdd(&sums[C + c], s2);
+  const __amdgpu_buffer_rsrc_t rsy = make_rsrc(y), rsd = make_rsrc(dz);
+  const int r0 = blockIdx.y * BN_SUM_ROWS;
+#pragma unroll 4
+  for (int it = 0; it < BN_SUM_ROWS / 8; ++it) {
+    const int r = r0 + rl + 8 * it;
+    const bool ok = cok && r < M;
+    float yv[8], dv[8];
+    buf_load8<T>(rsy, (long)r * C + c, ok, yv);
+    buf_load8<T>(rsd, (long)r * C + c, ok, dv);  // dz = 0 past the end: contributes nothing
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (yv[j] - mu[j]) * is[j];
+      const float dbn = dv[j] * dswishf_(g[j] * xh + bt[j]);
+      s1[j] += dbn; s2[j] += dbn * xh;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[rl][0][hl * 8 + j] = s1[j]; red[rl][1][hl * 8 + j] = s2[j]; }
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < C) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a += red[k][0][threadIdx.x]; b += red[k][1][threadIdx.x]; }
+    part[(long)blockIdx.y * 2 * C + cc] = a;
+    part[(long)blockIdx.y * 2 * C + C + cc] = b;
+  }
 }
 // pass 2: dy = gamma*invstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat)); row block 0 also
 // adds dgamma / dbeta.
@@ -269,23 +305,50 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int C, const T
                                                            const float* __restrict__ var,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps,
-                                                           const float* __restrict__ sums,
+                                                           const float* __restrict__ part, int npart,
                                                            T* __restrict__ dy, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float mu = mean[c], is = rsqrtf(var[c] + eps), g = gamma[c], bt = beta[c];
-  const float m1 = sums[c] / M, m2 = sums[C + c] / M;
-  if (blockIdx.y == 0) {
-    if (dbeta) atomicAdd(&dbeta[c], sums[c]);
-    if (dgamma) atomicAdd(&dgamma[c], sums[C + c]);
+  __shared__ float tot[2][256];
+  {
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    float a = 0.f, b = 0.f;
+    if (cc < C) {
+#pragma unroll 8
+      for (int k = 0; k < npart; ++k) { a += part[(long)k * 2 * C + cc]; b += part[(long)k * 2 * C + C + cc]; }
+      if (blockIdx.y == 0) {
+        if (dbeta) dbeta[cc] += a;
+        if (dgamma) dgamma[cc] += b;
+      }
+    }
+    tot[0][threadIdx.x] = a / M;
+    tot[1][threadIdx.x] = b / M;
   }
-  const int r0 = blockIdx.y * BN_ROWS, r1 = min(M, r0 + BN_ROWS);
-  for (int r = r0; r < r1; ++r) {
-    const long i = (long)r * C + c;
-    const float xh = (to_f32(y[i]) - mu) * is;
-    const float dbn = to_f32(dz[i]) * dswishf_(g * xh + bt);
-    dy[i] = from_f32<T>(g * is * (dbn - m1 - xh * m2));
+  __syncthreads();
+  const int hl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + hl * 8;
+  if (c >= C) return;
+  float mu[8], is[8], g[8], bt[8], m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = mean[c + j]; is[j] = rsqrtf(var[c + j] + eps); g[j] = gamma[c + j]; bt[j] = beta[c + j];
+    m1[j] = tot[0][hl * 8 + j]; m2[j] = tot[1][hl * 8 + j];
+  }
+  const __amdgpu_buffer_rsrc_t rsy = make_rsrc(y), rsd = make_rsrc(dz);
+  const int r0 = blockIdx.y * BN_APPLY_ROWS;
+#pragma unroll
+  for (int it = 0; it < BN_APPLY_ROWS / 8; ++it) {
+    const int r = r0 + rl + 8 * it;
+    const bool ok = r < M;
+    float yv[8], dv[8], o[8];
+    buf_load8<T>(rsy, (long)r * C + c, ok, yv);
+    buf_load8<T>(rsd, (long)r * C + c, ok, dv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (yv[j] - mu[j]) * is[j];
+      const float dbn = dv[j] * dswishf_(g[j] * xh + bt[j]);
+      o[j] = g[j] * is[j] * (dbn - m1[j] - xh * m2[j]);
+    }
+    if (ok) store8<T>(dy + (long)r * C + c, o);
   }
 }
 
@@ -386,19 +449,23 @@ extern "C" int emoasr_bn_swish_fwd(int dtype, int M, int C, const void* y, const
   return 0;
 }
 
+extern "C" long emoasr_bn_swish_bwd_scratch_floats(int M, int C) { return (long)cdiv(M, BN_SUM_ROWS) * 2 * C; }
+
 extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, const void* y,
                                    const float* mean, const float* var, const float* gamma,
                                    const float* beta, float eps, void* dy, float* dgamma, float* dbeta,
                                    float* scratch, void* stream) {
   EMO_CHECK(M > 0, "bn_swish_bwd: empty batch");
   hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(scratch, 0, sizeof(float) * 2 * C, s);
-  dim3 grid(cdiv(C, 256), cdiv(M, BN_ROWS));
-  dim3 sgrid(cdiv(C, 256), cdiv(M, BN_STAT_ROWS));
+  EMO_CHECK(C % 8 == 0, "bn_swish_bwd: C=%d must be a multiple of 8", C);
+  EMO_CHECK((long)M * C * (dtype == EMO_BF16 ? 2 : 4) < (1L << 32), "bn_swish_bwd: activation larger than 4 GiB");
+  const int npart = cdiv(M, BN_SUM_ROWS);
+  dim3 grid(cdiv(C, 256), cdiv(M, BN_APPLY_ROWS));
+  dim3 sgrid(cdiv(C, 256), npart);
   EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<sgrid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
                                                                   var, gamma, beta, eps, scratch)));
   EMO_DISPATCH(dtype, (bn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
-                                                                  var, gamma, beta, eps, scratch, (T*)dy,
+                                                                  var, gamma, beta, eps, scratch, npart, (T*)dy,
                                                                   dgamma, dbeta)));
   EMO_LAUNCH_CHECK();
   return 0;

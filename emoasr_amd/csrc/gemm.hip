@@ -64,32 +64,6 @@ template <typename T, int KB = 1> struct TileCfg {
 };
 
 
-// 8 consecutive elements of T <-> 8 floats (16 bytes of bf16, 32 bytes of f32)
-template <typename T>
-__device__ __forceinline__ void load8(const T* p, float (&o)[8]) {
-  if constexpr (sizeof(T) == 2) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
-  } else {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
-  }
-}
-template <typename T>
-__device__ __forceinline__ void store8(T* p, const float (&o)[8]) {
-  if constexpr (sizeof(T) == 2) {
-    bf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (bf16)o[e];
-    *reinterpret_cast<bf16x8*>(p) = v;
-  } else {
-    *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
-    *reinterpret_cast<f32x4*>(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
-  }
-}
-
 template <typename T>
 __device__ __forceinline__ void lds_store_row(T* dst, const Vec16<T>& v) {
   if constexpr (sizeof(T) == 2) {

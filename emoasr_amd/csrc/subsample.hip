@@ -40,75 +40,113 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(int Tn, int F, int T1, i
 }
 
 // dw1[c, kh*3+kw] += sum dy1[b,t1,f1,c] * x[b,2t1+kh,2f1+kw];  db1[c] += sum dy1
-constexpr int C1_TROWS = 16;  // t1 rows per block (fewer, less contended f32 atomics)
+// Block = (b, chunk of C1_TROWS t1 rows, 256 channels); thread = 8 channels x one of 8 f1 lanes
+// (the f1 lanes of a channel group are adjacent lanes: 16-byte dy1 loads, 128-byte row segments, and a
+// 3-step shuffle folds them at the end).  The input rows of C1_SUB t1 rows are staged in LDS at a time.
+// One atomic per (block, output): large row chunks keep the same-address contention low.
+constexpr int C1_TROWS = 64;
+constexpr int C1_SUB = 8;
 template <typename T>
-__global__ __launch_bounds__(1024) void conv1_wgrad_kernel(int Tn, int F, int T1, int F1, int C,
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(int Tn, int F, int T1, int F1, int C,
                                                           const float* __restrict__ x,
                                                           const T* __restrict__ dy1,
                                                           float* __restrict__ dw, float* __restrict__ db) {
-  extern __shared__ __attribute__((aligned(16))) float rows[];  // [3][F]
+  extern __shared__ __attribute__((aligned(16))) float rows[];  // [2*C1_SUB+1][F]
   const int nchunk = (T1 + C1_TROWS - 1) / C1_TROWS;
   const int b = blockIdx.x / nchunk, tc = blockIdx.x % nchunk;
-  float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float sb = 0.f;
-  const int c = threadIdx.x;  // launched with blockDim = C (<= 1024) rounded up to 64
-  for (int tt = 0; tt < C1_TROWS; ++tt) {
-    const int t1 = tc * C1_TROWS + tt;
-    if (t1 >= T1) break;
-    const float* xb = x + ((long)b * Tn + 2 * t1) * F;
+  const int fl = threadIdx.x & 7, c = blockIdx.y * 256 + (threadIdx.x >> 3) * 8;
+  const bool cok = c < C;
+  float acc[9][8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sb[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j][e] = 0.f;
+  }
+  const __amdgpu_buffer_rsrc_t rsd = make_rsrc(dy1 + (long)b * T1 * F1 * C);
+  const int t_end = min(T1, (tc + 1) * C1_TROWS);
+  for (int ts = tc * C1_TROWS; ts < t_end; ts += C1_SUB) {
+    const int nt = min(C1_SUB, t_end - ts);
+    const float* xb = x + ((long)b * Tn + 2 * ts) * F;
     __syncthreads();
-    for (int i = threadIdx.x; i < 3 * F; i += blockDim.x) rows[i] = xb[i];
+    for (int i = threadIdx.x; i < (2 * nt + 1) * F; i += 256) rows[i] = xb[i];
     __syncthreads();
-    if (c < C) {
-      const T* dyo = dy1 + ((long)b * T1 + t1) * F1 * C + c;
-      for (int f1 = 0; f1 < F1; ++f1) {
-        const float d = to_f32(dyo[(long)f1 * C]);
-        sb += d;
+    for (int tt = 0; tt < nt; ++tt) {
+      const float* r0 = rows + 2 * tt * F;
+      for (int f1 = fl; f1 < F1; f1 += 8) {
+        float d[8];
+        buf_load8<T>(rsd, ((long)(ts + tt) * F1 + f1) * C + c, cok, d);
+        float xv[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] += d * rows[kh * F + 2 * f1 + kw];
+          for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = r0[kh * F + 2 * f1 + kw];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sb[e] += d[e];
+#pragma unroll
+          for (int j = 0; j < 9; ++j) acc[j][e] += d[e] * xv[j];
+        }
       }
     }
   }
-  if (c < C) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j) atomicAdd(&dw[c * 9 + j], acc[j]);
-    atomicAdd(&db[c], sb);
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) sb[e] += __shfl_xor(sb[e], o, 64);
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) acc[j][e] += __shfl_xor(acc[j][e], o, 64);
+  }
+  if (cok && fl == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) atomicAdd(&dw[(c + e) * 9 + j], acc[j][e]);
+      atomicAdd(&db[c + e], sb[e]);
+    }
   }
 }
 
 // dy1[b,t1,f1,c] = [y1 > 0] * sum over (kh,kw) with t1 = 2*t2+kh, f1 = 2*f2+kw of
 //                  dcol[(b,t2,f2), (kh*3+kw)*C + c]
+// One thread = 8 consecutive channels of one (b,t1,f1) position (16-byte accesses).  All nine taps are
+// loaded unconditionally with bounds-checked buffer loads: taps of the wrong parity or outside the
+// output grid get an out-of-range offset (zeros, no traffic), so the loads are in flight together.
 template <typename T>
-__global__ __launch_bounds__(256) void col2im_kernel(int T1, int F1, int T2, int F2, int C, long n,
+__global__ __launch_bounds__(256) void col2im_kernel(int T1, int F1, int T2, int F2, int C, long nvec,
                                                      const T* __restrict__ dcol, const T* __restrict__ y1,
                                                      T* __restrict__ dy1) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int c = i % C;
-    long r = i / C;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(dcol);
+  const int cv = C / 8;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+    const int c = (int)(v % cv) * 8;
+    long r = v / cv;
     const int f1 = r % F1; r /= F1;
     const int t1 = r % T1;
     const int b = r / T1;
-    float s = 0.f;
-    if (to_f32(y1[i]) > 0.f) {
+    float yv[8], s[8];
+    load8<T>(y1 + v * 8, yv);
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int tt = t1 - kh;
-        if (tt < 0 || (tt & 1)) continue;
-        const int t2 = tt >> 1;
-        if (t2 >= T2) continue;
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int ff = f1 - kw;
-          if (ff < 0 || (ff & 1)) continue;
-          const int f2 = ff >> 1;
-          if (f2 >= F2) continue;
-          s += to_f32(dcol[(((long)b * T2 + t2) * F2 + f2) * (9L * C) + (kh * 3 + kw) * C + c]);
-        }
+    for (int kh = 0; kh < 3; ++kh) {
+      const int tt = t1 - kh, t2 = tt >> 1;
+      const bool tok = tt >= 0 && !(tt & 1) && t2 < T2;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ff = f1 - kw, f2 = ff >> 1;
+        const bool ok = tok && ff >= 0 && !(ff & 1) && f2 < F2;
+        float d[8];
+        buf_load8<T>(rs, (((long)b * T2 + t2) * F2 + f2) * (9L * C) + (kh * 3 + kw) * C + c, ok, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += d[e];
       }
     }
-    dy1[i] = from_f32<T>(s);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = yv[e] > 0.f ? s[e] : 0.f;
+    store8<T>(dy1 + v * 8, s);
   }
 }
 
@@ -138,9 +176,10 @@ extern "C" int emoasr_conv1_wgrad(int dtype, int B, int Tn, int F, int C, const 
     hipMemsetAsync(db1, 0, sizeof(float) * C, s);
   }
   if (B == 0) return 0;
+  EMO_CHECK(C % 8 == 0, "conv1_wgrad: C must be a multiple of 8");
   const int nchunk = cdiv(T1, C1_TROWS);
-  const int threads = cdiv(C, 64) * 64;
-  EMO_DISPATCH(dtype, (conv1_wgrad_kernel<T><<<B * nchunk, threads, 3 * F * sizeof(float), s>>>(
+  dim3 grid(B * nchunk, cdiv(C, 256));
+  EMO_DISPATCH(dtype, (conv1_wgrad_kernel<T><<<grid, 256, (2 * C1_SUB + 1) * F * sizeof(float), s>>>(
                           Tn, F, T1, F1, C, x, (const T*)dy1, dw1, db1)));
   EMO_LAUNCH_CHECK();
   return 0;
@@ -152,8 +191,10 @@ extern "C" int emoasr_conv2_col2im(int dtype, int B, int T1, int F1, int C, cons
   const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
   const long n = (long)B * T1 * F1 * C;
   if (n == 0) return 0;
-  EMO_DISPATCH(dtype, (col2im_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(
-                          T1, F1, T2, F2, C, n, (const T*)dcol, (const T*)y1, (T*)dy1)));
+  EMO_CHECK(C % 8 == 0, "col2im: C must be a multiple of 8");
+  EMO_CHECK((long)B * T2 * F2 * 9 * C * (dtype == EMO_BF16 ? 2 : 4) < (1L << 32), "col2im: dcol larger than 4 GiB");
+  EMO_DISPATCH(dtype, (col2im_kernel<T><<<ew_grid(n / 8), 256, 0, (hipStream_t)stream>>>(
+                          T1, F1, T2, F2, C, n / 8, (const T*)dcol, (const T*)y1, (T*)dy1)));
   EMO_LAUNCH_CHECK();
   return 0;
 }

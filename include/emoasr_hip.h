@@ -207,8 +207,10 @@ int emoasr_bn_stats(int dtype, int M, int C, const void* y, float* mean, float* 
 /* z = swish(gamma*(y-mean)/sqrt(var+eps)+beta) */
 int emoasr_bn_swish_fwd(int dtype, int M, int C, const void* y, const float* mean, const float* var,
                         const float* gamma, const float* beta, float eps, void* z, void* stream);
-/* training-mode backward (batch statistics): dy from dz; dgamma/dbeta (+)=.
- * scratch: f32 [2*C], zeroed by the call. */
+/* training-mode backward (batch statistics): dy from dz; dgamma/dbeta (+)=.  C % 8 == 0.
+ * scratch: emoasr_bn_swish_bwd_scratch_floats(M, C) floats of per-block partial sums
+ * (ceil(M/128) x 2 x C); needs no initialisation. */
+long emoasr_bn_swish_bwd_scratch_floats(int M, int C);
 int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, const void* y, const float* mean,
                         const float* var, const float* gamma, const float* beta, float eps, void* dy,
                         float* dgamma, float* dbeta, float* scratch, void* stream);
