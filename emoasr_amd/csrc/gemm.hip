@@ -41,7 +41,7 @@ __device__ __forceinline__ int conv_k_off(const ConvGeom& g, int k) {
 }
 
 int g_tr_read = 1;
-int g_gemm_tile = 0, g_gemm_kb = 0;
+int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1;
 
 struct NtArgs {
   int M, N, K;
@@ -52,6 +52,7 @@ struct NtArgs {
   ConvGeom cg;
   int nh;  // batched: blockIdx.z = b * nh + h, two-level strides below (elements); 0 = not batched
   long sa_b, sa_h, sb_b, sb_h, sc_b, sc_h;
+  int xcd;  // remap block ids so that each XCD works on a contiguous band of rows
 };
 
 // KB scales the k extent of a tile: bf16 uses BK = 32 for short reductions (K = 256: fewer, cheaper
@@ -102,7 +103,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+  // the linear block id is re-read as (xcd, slot): XCD x then owns a contiguous band of output rows
+  // (its A rows are fetched into one L2 only) and walks it n-fastest.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd) {
+    const int nblk = gridDim.x * gridDim.y, pid = by * gridDim.x + bx;
+    const int per = nblk / 8, rem = nblk - per * 8;  // the first `rem` XCDs hold one more block
+    const int x = pid % 8, slot = pid / 8;
+    const int lin = x * per + min(x, rem) + slot;
+    by = lin / gridDim.x;
+    bx = lin - by * gridDim.x;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const T* __restrict__ A = static_cast<const T*>(g.A);
   const T* __restrict__ B = static_cast<const T*>(g.B);
   long c_base = 0;
@@ -487,7 +500,9 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup G) {
 }
 
 template <typename T, int AMODE, bool BKM, bool TR>
-int launch_nt_(const NtArgs& a, hipStream_t s, int nz = 1) {
+int launch_nt_(const NtArgs& a_in, hipStream_t s, int nz = 1) {
+  NtArgs a = a_in;
+  a.xcd = g_gemm_xcd;
   // Tile: 128x64 once that still gives >= 384 blocks (1.5 per CU), else 64x64.  (A 128x128 tile
   // was measured slower than 128x64 on every shape of the L2 model.)  k extent: BK = 64 for long
   // bf16 reductions, 32 for K = 256.  g_gemm_tile / g_gemm_kb: tuning overrides (emoasr_set_option).
@@ -563,6 +578,7 @@ int launch_tn(TnArgs a, hipStream_t s) {
 void emo_gemm_set_tr_read(int v) { g_tr_read = v; }
 void emo_gemm_set_tile(int v) { g_gemm_tile = v; }
 void emo_gemm_set_kb(int v) { g_gemm_kb = v; }
+void emo_gemm_set_xcd(int v) { g_gemm_xcd = v; }
 
 static int check_vec(long ld, int dtype, const char* what) {
   const int vec = dtype == EMO_BF16 ? 8 : 4;

@@ -118,9 +118,11 @@ def gemm_tn(a, b, out=None, alpha=1.0, accumulate=False, colsum=None, colsum_sca
     return out
 
 
-def gemm_tn_grouped(problems):
+def gemm_tn_grouped(problems, stream=None):
     """problems: list of (a[K,N1], b[K,N2], out[N1,N2] f32, alpha, colsum or None, colsum_scale); every
-    out (and colsum) is accumulated into, all in one launch per lib.TN_GROUP_MAX problems."""
+    out (and colsum) is accumulated into, all in one launch per lib.TN_GROUP_MAX problems.
+    stream: raw HIP stream handle (int) to enqueue on instead of torch's current stream."""
+    sptr = _stream() if stream is None else c_void_p(stream)
     for i0 in range(0, len(problems), lib.TN_GROUP_MAX):
         chunk = problems[i0:i0 + lib.TN_GROUP_MAX]
         arr = (lib.TnProblem * len(chunk))()
@@ -133,7 +135,7 @@ def gemm_tn_grouped(problems):
             q.C, q.ldc, q.alpha = out.data_ptr(), out.stride(0), alpha
             q.colsum = None if colsum is None else colsum.data_ptr()
             q.colsum_scale = colsum_scale
-        lib.call("emoasr_gemm_tn_grouped", dt(chunk[0][0]), len(chunk), arr, _stream())
+        lib.call("emoasr_gemm_tn_grouped", dt(chunk[0][0]), len(chunk), arr, sptr)
 
 
 def gemm_nn_batched(a, b, out, M, N, K, lda, sa, ldb, sb, ldc, sc, nb, nh, alpha=1.0, accumulate=False):
