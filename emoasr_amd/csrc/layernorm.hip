@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void ln_bwd8_kernel(int M, int N, const T* __r
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ rstd,
                                                       const T* __restrict__ dres, T* __restrict__ dx,
-                                                      float* __restrict__ dgamma_part) {
+                                                      float* __restrict__ dgamma_part, T* __restrict__ dy2,
+                                                      float scale2, float p2, uint64_t seed2) {
   extern __shared__ float red8[];  // [4 waves][2][N]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
   float dg[NC][8], db[NC][8], g[NC][8];
@@ -252,6 +253,14 @@ __global__ __launch_bounds__(256) void ln_bwd8_kernel(int M, int N, const T* __r
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[c][j] += rs * (gy[c][j] - s1 - xh[c][j] * s2);
         ln_store8(dx + (long)row * N + col, o[c]);
+        if (dy2) {  // gradient entering the next residual branch x + scale2 * dropout(f(x)), from the ROUNDED dx
+          float o2[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            o2[j] = to_f32(from_f32<T>(o[c][j])) * scale2 *
+                    dropout_scale(seed2, (uint64_t)((long)row * N + col + j), p2);
+          ln_store8(dy2 + (long)row * N + col, o2);
+        }
       }
     }
   }
@@ -303,6 +312,39 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(int nblk, int N, c
   }
 }
 
+// several deferred finalizations in one launch: blockIdx.z = item
+struct LnFinGroup {
+  int n;
+  int nblk[EMOASR_LN_FINALIZE_MAX];
+  emoasr_ln_finalize_item_t it[EMOASR_LN_FINALIZE_MAX];
+};
+__global__ __launch_bounds__(256) void ln_bwd_finalize_grouped_kernel(const LnFinGroup G) {
+  __shared__ float red[4][64];
+  const emoasr_ln_finalize_item_t& it = G.it[blockIdx.z];
+  const int N = it.N, nblk = G.nblk[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;  // over 2N
+  if (blockIdx.x * 64 >= 2 * N) return;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float s = 0.f;
+  if (col < 2 * N) {
+#pragma unroll 8
+    for (int b = b0 + wave; b < b1; b += 4) s += it.part[(long)b * 2 * N + col];
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && col < 2 * N) {
+    s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (col < N) { if (it.dgamma) atomicAdd(&it.dgamma[col], s); }
+    else if (it.dbeta) atomicAdd(&it.dbeta[col - N], s);
+  }
+}
+
+int ln_bwd_nblk(int M, int N) {
+  return N % 8 == 0 ? std::min(cdiv(M, 8), LN_BWD8_MAXBLK) : std::min(cdiv(M, 4), LN_BWD_MAXBLK);
+}
+
 }  // namespace
 
 extern "C" int emoasr_layernorm_fwd(int dtype, int M, int N, const void* x, const float* gamma,
@@ -316,24 +358,27 @@ extern "C" int emoasr_layernorm_fwd(int dtype, int M, int N, const void* x, cons
   return 0;
 }
 
-extern "C" int emoasr_layernorm_bwd(int dtype, int M, int N, const void* dy, const void* x,
-                                    const float* gamma, const float* mean, const float* rstd,
-                                    const void* dres, void* dx, float* dgamma, float* dbeta,
-                                    float* scratch, void* stream) {
+extern "C" int emoasr_layernorm_bwd_ex(int dtype, int M, int N, const void* dy, const void* x,
+                                       const float* gamma, const float* mean, const float* rstd,
+                                       const void* dres, void* dx, float* dgamma, float* dbeta,
+                                       float* scratch, const emoasr_ln_bwd_opts_t* opts, void* stream) {
   EMO_CHECK(N % 4 == 0 && N <= LN_MAXC * 256, "layernorm: N=%d unsupported", N);
   if (M == 0) return 0;
   const bool want = dgamma || dbeta;
   EMO_CHECK(!want || scratch, "layernorm_bwd: scratch (%d floats) required for dgamma/dbeta",
             LN_BWD8_MAXBLK * 2 * N);
-  int nblk;
+  const int nblk = ln_bwd_nblk(M, N);
   hipStream_t s = (hipStream_t)stream;
   float* part = want ? scratch : nullptr;
+  void* dy2 = opts ? opts->dy2 : nullptr;
+  const float scale2 = opts ? opts->scale2 : 1.f, p2 = opts ? opts->drop_p2 : 0.f;
+  const uint64_t seed2 = opts ? opts->seed2 : 0;
   if (N % 8 == 0) {
-    nblk = std::min(cdiv(M, 8), LN_BWD8_MAXBLK);
     const int smem = 4 * 2 * N * (int)sizeof(float);
 #define EMO_LN8(NC_)                                                                              \
   EMO_DISPATCH(dtype, (ln_bwd8_kernel<T, NC_><<<nblk, 256, smem, s>>>(M, N, (const T*)dy, (const T*)x, gamma, mean, \
-                                                                      rstd, (const T*)dres, (T*)dx, part)))
+                                                                      rstd, (const T*)dres, (T*)dx, part,          \
+                                                                      (T*)dy2, scale2, p2, seed2)))
     switch (cdiv(N, 256)) {
       case 1: EMO_LN8(1); break;
       case 2: EMO_LN8(2); break;
@@ -342,14 +387,42 @@ extern "C" int emoasr_layernorm_bwd(int dtype, int M, int N, const void* dy, con
     }
 #undef EMO_LN8
   } else {
-    nblk = std::min(cdiv(M, 4), LN_BWD_MAXBLK);
     EMO_DISPATCH(dtype, (ln_bwd_kernel<T><<<nblk, 256, 0, s>>>(M, N, (const T*)dy, (const T*)x, gamma, mean, rstd,
                                                                (const T*)dres, (T*)dx, part)));
+    if (dy2 && emoasr_scale_dropout(dtype, (long)M * N, dx, dy2, scale2, p2, seed2, stream)) return 1;
   }
-  if (want) {
+  if (want && !(opts && opts->defer_finalize)) {
     dim3 grid(cdiv(2 * N, 64), std::max(1, std::min(8, nblk / 32)));
     ln_bwd_finalize_kernel<<<grid, 256, 0, s>>>(nblk, N, scratch, dgamma, dbeta);
   }
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_layernorm_bwd(int dtype, int M, int N, const void* dy, const void* x,
+                                    const float* gamma, const float* mean, const float* rstd,
+                                    const void* dres, void* dx, float* dgamma, float* dbeta,
+                                    float* scratch, void* stream) {
+  return emoasr_layernorm_bwd_ex(dtype, M, N, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, nullptr,
+                                 stream);
+}
+
+extern "C" int emoasr_layernorm_bwd_finalize(int n, const emoasr_ln_finalize_item_t* items, void* stream) {
+  EMO_CHECK(n >= 0 && n <= EMOASR_LN_FINALIZE_MAX, "layernorm_bwd_finalize: n=%d outside 0..%d", n,
+            EMOASR_LN_FINALIZE_MAX);
+  if (n == 0) return 0;
+  LnFinGroup G{};
+  G.n = n;
+  int maxn = 0, maxblk = 0;
+  for (int i = 0; i < n; ++i) {
+    EMO_CHECK(items[i].part && items[i].M > 0, "layernorm_bwd_finalize: bad item %d", i);
+    G.it[i] = items[i];
+    G.nblk[i] = ln_bwd_nblk(items[i].M, items[i].N);
+    maxn = std::max(maxn, items[i].N);
+    maxblk = std::max(maxblk, G.nblk[i]);
+  }
+  dim3 grid(cdiv(2 * maxn, 64), std::max(1, std::min(8, maxblk / 32)), n);
+  ln_bwd_finalize_grouped_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(G);
   EMO_LAUNCH_CHECK();
   return 0;
 }

@@ -187,6 +187,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
         self._group_wgrads = os.environ.get("EMOASR_WGRAD_GROUP", "1") != "0"
         self._defer_wgrads = False
         self._wq = []
+        self._ln_deferred = []
         # EMOASR_WGRAD_SIDE=1: run them on a side stream (measured slower on MI355X: 13.97 vs 13.62 ms/step)
         self._side_wgrads = os.environ.get("EMOASR_WGRAD_SIDE", "0") != "0"
         self._side, self._inflight = None, []
@@ -453,29 +454,42 @@ class CTCEngine(_DecoderMixinPlaceholder):
             torch.cuda.current_stream().wait_event(ev)
             self._inflight = []
 
-    def _branch_grad(self, dx, scale, p, seed):
-        """gradient entering a residual branch x + scale*dropout(f): returns (dy, alpha)."""
+    def _branch_grad(self, dx, scale, p, seed, pre=None):
+        """gradient entering a residual branch x + scale*dropout(f): returns (dy, alpha).
+        pre: the same dropout(dx * scale) already produced by the LayerNorm backward that made dx."""
         if p > 0:
-            return ops.scale_dropout(dx, scale, p, seed), 1.0
+            return (pre if pre is not None else ops.scale_dropout(dx, scale, p, seed)), 1.0
         return dx, scale
 
-    def _ffn_bwd(self, name, norm_name, st, dx, res_scale, act, p=None):
+    def _ln_bwd(self, dh, x, norm_name, mean, rstd, dx, nxt=None):
+        """LayerNorm backward closing a sublayer.  nxt = (scale, p, seed) of the residual branch the
+        backward sweep enters next: its dropout mask is applied here too (second output), which
+        saves that branch's scale_dropout pass.  Inside the encoder backward the dgamma / dbeta
+        folds of all LayerNorms are deferred to one grouped launch.  -> (dx_new, dy_next or None)"""
         A = self.arena
+        branch = nxt if (nxt is not None and nxt[1] > 0) else None
+        out = ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
+                                A.g(norm_name + ".bias"), branch=branch,
+                                deferred=self._ln_deferred if self._defer_wgrads else None)
+        return out if branch is not None else (out, None)
+
+    def _ffn_bwd(self, name, norm_name, st, dx, res_scale, act, p=None, pre=None, nxt=None):
         x, mean, rstd, h, u, a, s_in, s_out = st
         p = self.p_enc if p is None else p
-        dy, alpha = self._branch_grad(dx, res_scale, p, s_out)
+        dy, alpha = self._branch_grad(dx, res_scale, p, s_out, pre)
         du = self._lin_bwd(dy, a, name + ".w2.weight", name + ".w2.bias", alpha, dact_pre=u, dact=act, drop_p=p, seed=s_in)
         dh = self._lin_bwd(du, h, name + ".w1.weight", name + ".w1.bias")
-        return ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
-                                 A.g(norm_name + ".bias"))
+        r = self._ln_bwd(dh, x, norm_name, mean, rstd, dx, nxt)
+        return r if nxt is not None else r[0]
 
-    def _attn_bwd(self, name, norm_name, st, dx, B, T, elens, pos_t, dims=None, causal=False, p_res=None, p_att=None):
+    def _attn_bwd(self, name, norm_name, st, dx, B, T, elens, pos_t, dims=None, causal=False, p_res=None, p_att=None,
+                  pre=None, nxt=None):
         A = self.arena
         d, H = dims if dims is not None else (self.d, self.h)
         p_res = self.p_enc if p_res is None else p_res
         p_att = self.p_att if p_att is None else p_att
         x, mean, rstd, h, qkv, pp, o, lse, s_att, s_out, sts = st
-        dy, alpha = self._branch_grad(dx, 1.0, p_res, s_out)
+        dy, alpha = self._branch_grad(dx, 1.0, p_res, s_out, pre)
         do = self._lin_bwd(dy, o.view(B * T, d), name + ".linear_out.weight", name + ".linear_out.bias", alpha)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
@@ -499,8 +513,8 @@ class CTCEngine(_DecoderMixinPlaceholder):
                     1.0, A.g_span(name + ".linear_q.bias", name + ".linear_v.bias", (3 * d,)))
         wqkv = A.w_span(name + ".linear_q.weight", name + ".linear_v.weight", (3 * d, d))
         dh = ops.gemm_nn(dqkv2, wqkv)
-        return ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
-                                 A.g(norm_name + ".bias"))
+        r = self._ln_bwd(dh, x, norm_name, mean, rstd, dx, nxt)
+        return r if nxt is not None else r[0]
 
     def _scratch_for(self, B, H, Tq, Tk, dtype, device, rel, klens, causal):
         """attention-backward scratch, zeroed once per (shape, mask): every layer of a step masks the
@@ -514,10 +528,10 @@ class CTCEngine(_DecoderMixinPlaceholder):
             sc._klens = klens  # keep the mask tensor alive while its id() keys the cache
         return sc
 
-    def _conv_bwd(self, name, norm_name, st, dx, B, T):
+    def _conv_bwd(self, name, norm_name, st, dx, B, T, pre=None, nxt=None):
         A, d = self.arena, self.d
         x, mean, rstd, h, g, gl, c, bmean, bvar, z, s_out = st
-        dy, alpha = self._branch_grad(dx, 1.0, self.p_enc, s_out)
+        dy, alpha = self._branch_grad(dx, 1.0, self.p_enc, s_out, pre)
         dz = self._lin_bwd(dy, z, name + ".pointwise_conv2.weight", name + ".pointwise_conv2.bias", alpha)
         bn = name + ".batch_norm"
         dc = ops.bn_swish_bwd(dz, c, bmean, bvar, A.p(bn + ".weight"), A.p(bn + ".bias"), 1e-5, A.g(bn + ".weight"),
@@ -529,8 +543,8 @@ class CTCEngine(_DecoderMixinPlaceholder):
                          A.g(name + ".depthwise_conv.bias"), accumulate=True)
         dg = ops.glu_bwd(g, dgl.view(B * T, d))
         dh = self._lin_bwd(dg, h, name + ".pointwise_conv1.weight", name + ".pointwise_conv1.bias")
-        return ops.layernorm_bwd(dh, x, A.p(norm_name + ".weight"), mean, rstd, dx, A.g(norm_name + ".weight"),
-                                 A.g(norm_name + ".bias"))
+        r = self._ln_bwd(dh, x, norm_name, mean, rstd, dx, nxt)
+        return r if nxt is not None else r[0]
 
     def backward(self, st, deouts):
         """deouts: gradient w.r.t. encoder output [B,T',d] (compute dtype).  Accumulates into the
@@ -542,33 +556,62 @@ class CTCEngine(_DecoderMixinPlaceholder):
         finally:
             self._defer_wgrads = False
             self._wq = []
+            self._ln_deferred = []
             self._join_side()
 
     def _backward(self, st, deouts):
         A, d = self.arena, self.d
         A.attach_grads()
         B, T, M = st.B, st.T2, st.M
-        dx = ops.layernorm_bwd(deouts.reshape(M, d), st.x_final, A.p("encoder.norm.weight"), st.fin_mean, st.fin_rstd,
-                               None, A.g("encoder.norm.weight"), A.g("encoder.norm.bias"))
-        for li in reversed(range(self.nl)):
+        # Every LayerNorm backward of the sweep also emits the dropout-masked gradient of the residual
+        # branch entered next (nxt = (scale, p, seed of that branch's output dropout)).
+        p = self.p_enc
+        nl = self.nl
+
+        def br(li, which):  # branch spec of sublayer `which` of layer li
+            s_ffm, s_att, s_conv, s_ff, _ = st.layers[li]
+            if which == "ff":
+                return (0.5 if self.conformer else 1.0, p, s_ff[7])
+            if which == "ffm":
+                return (0.5, p, s_ffm[7])
+            if which == "att":
+                return (1.0, p, s_att[9])
+            return (1.0, p, s_conv[10])
+
+        first = None if self.conformer else br(nl - 1, "ff")
+        dx, pre = self._ln_bwd(deouts.reshape(M, d), st.x_final, "encoder.norm", st.fin_mean, st.fin_rstd, None, first)
+        for li in reversed(range(nl)):
             name = f"encoder.transformers.{li}"
             s_ffm, s_att, s_conv, s_ff, s_fin = st.layers[li]
             if self.conformer:
                 x, mean, rstd = s_fin
-                dx = ops.layernorm_bwd(dx, x, A.p(name + ".norm_final.weight"), mean, rstd, None,
-                                       A.g(name + ".norm_final.weight"), A.g(name + ".norm_final.bias"))
-                dx = self._ffn_bwd(name + ".feed_forward", name + ".norm_ff", s_ff, dx, 0.5, ACT_SWISH)
+                dx, pre = self._ln_bwd(dx, x, name + ".norm_final", mean, rstd, None, br(li, "ff"))
                 if self.rel:
-                    dx = self._conv_bwd(name + ".conv", name + ".norm_conv", s_conv, dx, B, T)
-                    dx = self._attn_bwd(name + ".self_attn", name + ".norm_self_attn", s_att, dx, B, T, st.elens, st.pos_t)
+                    dx, pre = self._ffn_bwd(name + ".feed_forward", name + ".norm_ff", s_ff, dx, 0.5, ACT_SWISH, pre=pre,
+                                            nxt=br(li, "conv"))
+                    dx, pre = self._conv_bwd(name + ".conv", name + ".norm_conv", s_conv, dx, B, T, pre=pre,
+                                             nxt=br(li, "att"))
+                    dx, pre = self._attn_bwd(name + ".self_attn", name + ".norm_self_attn", s_att, dx, B, T, st.elens,
+                                             st.pos_t, pre=pre, nxt=br(li, "ffm"))
                 else:
-                    dx = self._attn_bwd(name + ".self_attn", name + ".norm_self_attn", s_att, dx, B, T, st.elens, None)
-                    dx = self._conv_bwd(name + ".conv", name + ".norm_conv", s_conv, dx, B, T)
-                dx = self._ffn_bwd(name + ".feed_forward_macaron", name + ".norm_ff_macaron", s_ffm, dx, 0.5, ACT_SWISH)
+                    dx, pre = self._ffn_bwd(name + ".feed_forward", name + ".norm_ff", s_ff, dx, 0.5, ACT_SWISH, pre=pre,
+                                            nxt=br(li, "att"))
+                    dx, pre = self._attn_bwd(name + ".self_attn", name + ".norm_self_attn", s_att, dx, B, T, st.elens,
+                                             None, pre=pre, nxt=br(li, "conv"))
+                    dx, pre = self._conv_bwd(name + ".conv", name + ".norm_conv", s_conv, dx, B, T, pre=pre,
+                                             nxt=br(li, "ffm"))
+                dx = self._ffn_bwd(name + ".feed_forward_macaron", name + ".norm_ff_macaron", s_ffm, dx, 0.5, ACT_SWISH,
+                                   pre=pre)
             else:
-                dx = self._ffn_bwd(name + ".feed_forward", name + ".norm2", s_ff, dx, 1.0, ACT_RELU)
-                dx = self._attn_bwd(name + ".self_attn", name + ".norm1", s_att, dx, B, T, st.elens, None)
+                dx, pre = self._ffn_bwd(name + ".feed_forward", name + ".norm2", s_ff, dx, 1.0, ACT_RELU, pre=pre,
+                                        nxt=br(li, "att"))
+                if li > 0:
+                    dx, pre = self._attn_bwd(name + ".self_attn", name + ".norm1", s_att, dx, B, T, st.elens, None,
+                                             pre=pre, nxt=br(li - 1, "ff"))
+                else:
+                    dx = self._attn_bwd(name + ".self_attn", name + ".norm1", s_att, dx, B, T, st.elens, None, pre=pre)
             self._flush_wgrads()
+        ops.layernorm_bwd_finalize(self._ln_deferred)
         # ---- positional scaling, Linear, Conv2d x2 -----------------------------------
         pre = "encoder.conv."
         C, F2 = d, st.F2

@@ -46,6 +46,18 @@ class TnProblem(Structure):
 
 TN_GROUP_MAX = 16
 
+
+class LnBwdOpts(Structure):
+    _fields_ = [("dy2", c_void_p), ("scale2", c_float), ("drop_p2", c_float), ("seed2", c_uint64),
+                ("defer_finalize", c_int)]
+
+
+class LnFinalizeItem(Structure):
+    _fields_ = [("M", c_int), ("N", c_int), ("part", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p)]
+
+
+LN_FINALIZE_MAX = 64
+
 P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
 
 # name -> argtypes (every function returns int status); mirrors include/emoasr_hip.h
@@ -63,6 +75,8 @@ SIGNATURES = {
     "emoasr_conv2_col2im": [I, I, I, I, I, P, P, P, P],
     "emoasr_layernorm_fwd": [I, I, I, P, P, P, F, P, P, P, P],
     "emoasr_layernorm_bwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P],
+    "emoasr_layernorm_bwd_ex": [I, I, I, P, P, P, P, P, P, P, P, P, P, POINTER(LnBwdOpts), P],
+    "emoasr_layernorm_bwd_finalize": [I, POINTER(LnFinalizeItem), P],
     "emoasr_attn_fwd": [I, POINTER(AttnArgs), P],
     "emoasr_attn_bwd": [I, POINTER(AttnArgs), P],
     "emoasr_glu_fwd": [I, I, I, P, P, P],

@@ -208,15 +208,44 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, branch=None, deferred=None):
+    """dx = dres + LN'(dy); dgamma / dbeta accumulated.
+    branch=(scale, p, seed): also return dropout(dx * scale) -- the gradient entering the next residual
+    branch of the backward sweep (replaces a scale_dropout pass); returns (dx, dy_branch).
+    deferred: a list; the dgamma/dbeta fold is postponed and recorded there for layernorm_bwd_finalize."""
     M, N, ld = _rows(_chk(x))
     dx = torch.empty_like(x)
     scratch = None
     if dgamma is not None or dbeta is not None:
         scratch = torch.empty(1024 * 2 * N, device=x.device, dtype=torch.float32)  # emoasr_layernorm_bwd_scratch_floats(N)
-    lib.call("emoasr_layernorm_bwd", dt(x), M, N, _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
-             _p(dgamma), _p(dbeta), _p(scratch), _stream())
-    return dx
+    if branch is None and deferred is None:
+        lib.call("emoasr_layernorm_bwd", dt(x), M, N, _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+                 _p(dgamma), _p(dbeta), _p(scratch), _stream())
+        return dx
+    o = lib.LnBwdOpts()
+    dy2 = None
+    if branch is not None:
+        dy2 = torch.empty_like(x)
+        o.dy2, o.scale2, o.drop_p2, o.seed2 = dy2.data_ptr(), branch[0], branch[1], branch[2]
+    if deferred is not None and scratch is not None:
+        o.defer_finalize = 1
+        deferred.append((M, N, scratch, dgamma, dbeta))
+    lib.call("emoasr_layernorm_bwd_ex", dt(x), M, N, _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+             _p(dgamma), _p(dbeta), _p(scratch), byref(o), _stream())
+    return dx if branch is None else (dx, dy2)
+
+
+def layernorm_bwd_finalize(deferred):
+    """fold the dgamma / dbeta partials of deferred layernorm_bwd calls (one launch per 64 of them)"""
+    for i0 in range(0, len(deferred), lib.LN_FINALIZE_MAX):
+        chunk = deferred[i0:i0 + lib.LN_FINALIZE_MAX]
+        arr = (lib.LnFinalizeItem * len(chunk))()
+        for it, (M, N, scratch, dgamma, dbeta) in zip(arr, chunk):
+            it.M, it.N, it.part = M, N, scratch.data_ptr()
+            it.dgamma = None if dgamma is None else dgamma.data_ptr()
+            it.dbeta = None if dbeta is None else dbeta.data_ptr()
+        lib.call("emoasr_layernorm_bwd_finalize", len(chunk), arr, _stream())
+    del deferred[:]
 
 
 # ---- attention -------------------------------------------------------------------------

@@ -122,6 +122,29 @@ int emoasr_layernorm_bwd(int dtype, int M, int N, const void* dy, const void* x,
                          const float* mean, const float* rstd, const void* dres, void* dx,
                          float* dgamma, float* dbeta, float* scratch, void* stream);
 int emoasr_layernorm_bwd_scratch_floats(int N);
+/* Extended form.  dy2 (optional) = dropout(dx * scale2; drop_p2, seed2), computed from the stored dx:
+ * the gradient entering the next residual branch x + scale2 * dropout(f(x)) of the backward sweep, so
+ * that branch needs no separate emoasr_scale_dropout pass (same mask index: row * N + col).
+ * defer_finalize != 0 leaves the dgamma / dbeta partial sums in `scratch` (which must then stay
+ * untouched) for one emoasr_layernorm_bwd_finalize call that folds up to EMOASR_LN_FINALIZE_MAX
+ * LayerNorms in a single launch. */
+typedef struct emoasr_ln_bwd_opts {
+  void* dy2;
+  float scale2, drop_p2;
+  uint64_t seed2;
+  int defer_finalize;
+} emoasr_ln_bwd_opts_t;
+int emoasr_layernorm_bwd_ex(int dtype, int M, int N, const void* dy, const void* x, const float* gamma,
+                            const float* mean, const float* rstd, const void* dres, void* dx,
+                            float* dgamma, float* dbeta, float* scratch, const emoasr_ln_bwd_opts_t* opts,
+                            void* stream);
+#define EMOASR_LN_FINALIZE_MAX 64
+typedef struct emoasr_ln_finalize_item {
+  int M, N;              /* the M, N of the deferred emoasr_layernorm_bwd_ex call */
+  const float* part;     /* its scratch */
+  float *dgamma, *dbeta; /* accumulated into (either may be NULL) */
+} emoasr_ln_finalize_item_t;
+int emoasr_layernorm_bwd_finalize(int n, const emoasr_ln_finalize_item_t* items, void* stream);
 
 /* ---- attention (transformer.py:48-99, conformer.py:57-95) -------------------
  * q:[B,Tq,H*DK] k,v:[B,Tk,H*DK] with row strides ldq/ldk/ldv (elements), out [B,Tq,H*DK].

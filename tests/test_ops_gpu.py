@@ -541,3 +541,30 @@ def test_dwconv_bn_stats_fused(dev, dtype):
         _close(rm, 0.9 * rm0 + 0.1 * yf.mean(0), 1e-5, "running mean")
         _close(rv, 0.9 * rv0 + 0.1 * yf.var(0, unbiased=True), 1e-4, "running var")
         assert int(nbt) == 8
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_layernorm_bwd_branch_and_deferred(dev, dtype):
+    """extended LayerNorm backward: the fused branch output equals scale_dropout of the stored dx bit for
+    bit, and the deferred grouped finalize gives the same dgamma / dbeta as the immediate one"""
+    from emoasr_amd import ops
+    M, N = 333, 256
+    x, dy, dres = _rnd(dev, M, N, dtype=dtype), _rnd(dev, M, N, dtype=dtype), _rnd(dev, M, N, dtype=dtype)
+    gamma = torch.randn(N, device=dev)
+    mean = x.float().mean(1)
+    rstd = (x.float().var(1, unbiased=False) + 1e-5).rsqrt()
+    dg0, db0 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    dx0 = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dg0, db0)
+    deferred = []
+    dg1, db1 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    dg2, db2 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    dx1, dyb = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dg1, db1, branch=(0.5, 0.1, 77), deferred=deferred)
+    dx2 = ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, dg2, db2, deferred=deferred)
+    assert torch.equal(dx0, dx1)
+    assert torch.equal(dyb, ops.scale_dropout(dx0, 0.5, 0.1, 77))
+    assert float(dg1.abs().max()) == 0.0 and len(deferred) == 2  # nothing folded yet
+    ops.layernorm_bwd_finalize(deferred)
+    _close(dg1, dg0, 1e-5, "deferred dgamma")
+    _close(db1, db0, 1e-5, "deferred dbeta")
+    _close(dg2, dg0, 1e-5, "second deferred item")
+    assert deferred == [] and dx2.shape == dx0.shape

@@ -44,3 +44,10 @@ t0 = time.perf_counter()
 for bt in batches[3:9]: step(bt)
 torch.cuda.synchronize()
 print(f"python-only (C calls skipped): {1e3*(time.perf_counter()-t0)/6:.2f} ms/step")
+import cProfile, pstats
+pr = cProfile.Profile()
+pr.enable()
+for bt in batches[3:9]: step(bt)
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr, stream=sys.stdout).sort_stats("tottime").print_stats(28)
