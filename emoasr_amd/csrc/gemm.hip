@@ -378,7 +378,25 @@ __device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const in
   if (kt_begin >= kt_end) return;
 
   int b_koff = 0;
-  if constexpr (BMODE == 1) b_koff = conv_k_off(g.cg, n2_0);  // tile lies inside one (kh,kw)
+  // conv gather: the rows a thread loads advance by a fixed step (256 / BV rows) from one load to the
+  // next, across tiles too, so (b, t2, f2) is carried incrementally -- two integer divisions per block
+  // instead of two per 16-byte load (they cost more VALU time than the tile's MFMAs).
+  int cv_b = 0, cv_t2 = 0, cv_f2 = 0;
+  if constexpr (BMODE == 1) {
+    b_koff = conv_k_off(g.cg, n2_0);  // tile lies inside one (kh,kw)
+    const int k = kt_begin * BK + tid / BV, per_b = g.cg.T2 * g.cg.F2;
+    cv_b = k / per_b;
+    const int r = k - cv_b * per_b;
+    cv_t2 = r / g.cg.F2;
+    cv_f2 = r - cv_t2 * g.cg.F2;
+  }
+  auto conv_next_row = [&]() -> long {  // row base of the current row, then step to this thread's next row
+    const long base = (((long)cv_b * g.cg.T1 + 2 * cv_t2) * g.cg.F1 + 2 * cv_f2) * g.cg.C;
+    cv_f2 += 256 / BV;
+    while (cv_f2 >= g.cg.F2) { cv_f2 -= g.cg.F2; ++cv_t2; }
+    while (cv_t2 >= g.cg.T2) { cv_t2 -= g.cg.T2; ++cv_b; }
+    return base;
+  };
 
   struct Stage { Vec16<T> a[A_IT], b[B_IT]; };
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A), rsB = make_rsrc(B);
@@ -398,7 +416,7 @@ __device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const in
       const int k = k0 + kr, n = n2_0 + nv;
       const bool ok = k < g.K && n < g.N2;
       unsigned off;
-      if constexpr (BMODE == 1) off = (unsigned)((conv_row_base(g.cg, ok ? k : 0) + b_koff + nv) * SZ);
+      if constexpr (BMODE == 1) off = (unsigned)((conv_next_row() + b_koff + nv) * SZ);  // load_tile runs for kt_begin, +1, +2, ... in order
       else off = (unsigned)(((long)k * g.ldb + n) * SZ);
       st.b[i] = buf_load16<T>(rsB, ok ? off : EMO_OOB);
     }
