@@ -93,6 +93,16 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
   }
 }
 
+// one element of T from an f32 value; an out-of-range offset (EMO_OOB) drops the store
+template <typename T>
+__device__ __forceinline__ void buf_store_elem(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+  if constexpr (sizeof(T) == 2) {
+    const bf16 h = (bf16)v;
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), r, byte_off, 0, 0);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 0);
+  }
+}
 // 8 consecutive elements of T as f32 (one 16-byte load for bf16, two for f32); zeros when !ok
 template <typename T>
 __device__ __forceinline__ void buf_load8(__amdgpu_buffer_rsrc_t r, long elem_off, bool ok, float (&o)[8]) {
