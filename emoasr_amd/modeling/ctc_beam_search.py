@@ -1,0 +1,100 @@
+"""CTC prefix beam search with LM shallow fusion for CTC-only models -- the decode path of
+asr/modeling/decoders/ctc.py:203-344 (`CTCDecoder._beam_search`) and :372-397 (`_merge_ctc_paths`).
+
+Split of work: the acoustic side runs once per utterance on the GPU (output projection, log-softmax
+and the per-frame top-k, all frames in one launch each: emoasr_gemm_nt / emoasr_log_softmax /
+emoasr_topk) and comes to the host in one copy; the Transformer LM scores all live prefixes of a frame
+in one batched device call (LM.predict, as the reference batches them with pad_sequence, ctc.py:241-260);
+the prefix bookkeeping itself -- a few dozen scalar updates per frame -- is host code in float64, like
+the reference's python floats.
+
+Reference behaviour kept on purpose (it decides which prefixes survive):
+  * the LM score of the k-th candidate extension of a prefix also contains the LM scores of the
+    candidates tried before it (`score_lm +=` inside the candidate loop, ctc.py:309-310);
+  * length bonus = len_weight * (number of non-<eos> tokens of the PARENT prefix + 1) (ctc.py:308);
+  * when two paths reach the same prefix, probabilities are merged but the LM / length scores of the
+    first path are kept (ctc.py:388-393);
+  * hypotheses start with <eos> (the LM's BOS) and scores are returned best first.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+from .functions import _engine_of
+
+NEG = -1e10  # LOG_0 of decoders/ctc.py:23
+
+
+def _lse2(a, b):
+    m = a if a > b else b
+    return m + math.log(math.exp(a - m) + math.exp(b - m))
+
+
+class _Prefix:
+    __slots__ = ("toks", "p_b", "p_nb", "asr", "lm", "len_bonus", "n_plain")
+
+    def __init__(self, toks, p_b, p_nb, asr, lm, len_bonus, n_plain):
+        self.toks, self.p_b, self.p_nb, self.asr, self.lm, self.len_bonus = toks, p_b, p_nb, asr, lm, len_bonus
+        self.n_plain = n_plain  # tokens that are not <eos>
+
+    @property
+    def total(self):
+        return self.asr + self.lm + self.len_bonus
+
+
+def ctc_prefix_beam_search(dec, eouts, elens, beam_width, len_weight=0.0, lm=None, lm_weight=0.0):
+    """-> (hyps, scores, logits) for ONE utterance (the reference asserts batch size 1, ctc.py:212)."""
+    assert eouts.shape[0] == 1, "CTC beam search decodes one utterance at a time (ctc.py:212)"
+    eng = _engine_of(dec)
+    blank, eos, V = dec.blank_id, dec.eos_id, dec.vocab_size
+    with torch.no_grad():
+        logits = eng.head_logits(eouts)                      # [1, T, V]
+        T = logits.shape[1]
+        logp_dev = ops.log_softmax(logits.view(T, V))        # f32 [T, V]
+        k = min(beam_width, V)
+        _, top_dev, _ = ops.topk(logp_dev, k)                # ids sorted by descending score, per frame
+        logp = logp_dev.cpu().numpy().astype(np.float64)     # one D2H for the whole utterance
+        top = top_dev.cpu().numpy()
+    use_lm = lm is not None and lm_weight > 0
+    live = [_Prefix((eos,), 0.0, NEG, 0.0, 0.0, 0.0, 0)]
+    for t in range(T):
+        row = logp[t]
+        lp_blank = float(row[blank])
+        cands = [(int(v), float(row[v])) for v in top[t] if int(v) != blank]
+        if use_lm:
+            n = max(len(p.toks) for p in live)
+            batch = torch.zeros(len(live), n, dtype=torch.int64)  # 0-padded like pad_sequence (ctc.py:243-246)
+            for i, p in enumerate(live):
+                batch[i, : len(p.toks)] = torch.tensor(p.toks)
+            lm_lp, _ = lm.predict(batch, [len(p.toks) for p in live])
+            lm_lp = lm_lp.cpu().numpy().astype(np.float64)
+        table, order = {}, []  # prefix -> _Prefix, in first-seen order (dict merge of ctc.py:374-395)
+
+        def put(q):
+            old = table.get(q.toks)
+            if old is None:
+                table[q.toks] = q
+                order.append(q)
+            else:  # same label sequence reached twice: fold the path probabilities only
+                old.p_b, old.p_nb, old.asr = _lse2(old.p_b, q.p_b), _lse2(old.p_nb, q.p_nb), _lse2(old.asr, q.asr)
+
+        for i, p in enumerate(live):
+            last = p.toks[-1] if len(p.toks) > 1 else None
+            # stay on the same prefix: blank, or a repeat of its last label
+            stay_b = _lse2(p.p_b + lp_blank, p.p_nb + lp_blank)
+            stay_nb = p.p_nb + float(row[last]) if last is not None else NEG
+            put(_Prefix(p.toks, stay_b, stay_nb, _lse2(stay_b, stay_nb), p.lm, p.len_bonus, p.n_plain))
+            # extend by each of the frame's top-k labels
+            lm_run = p.lm
+            bonus = len_weight * (p.n_plain + 1)
+            for v, lp_v in cands:
+                ext_nb = p.p_b + lp_v if v == last else _lse2(p.p_b + lp_v, p.p_nb + lp_v)
+                if use_lm:
+                    lm_run += lm_weight * float(lm_lp[i, v])
+                put(_Prefix(p.toks + (v,), NEG, ext_nb, _lse2(NEG, ext_nb), lm_run, bonus,
+                            p.n_plain + (0 if v == eos else 1)))
+        order.sort(key=lambda q: q.total, reverse=True)  # stable, like sorted() in ctc.py:338
+        live = order[:beam_width]
+    return [list(p.toks) for p in live], [p.total for p in live], logits

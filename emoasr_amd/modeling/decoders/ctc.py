@@ -2,6 +2,7 @@
 
     decoder(eouts, elens, eouts_inter=None, ys=None, ylens=None, ...) -> logits | (loss, loss_dict, logits)
     decoder.decode(eouts, elens, eouts_inter, beam_width, ...) -> (hyps, scores, logits, aligns)
+    (beam_width <= 1: greedy; > 1: CTC prefix beam search with optional LM fusion, ctc.py:203-344)
 """
 import logging
 
@@ -34,8 +35,10 @@ class CTCDecoder(nn.Module):
 
     def decode(self, eouts, elens, eouts_inter=None, beam_width=1, len_weight=0, lm=None, lm_weight=0,
                decode_ctc_weight=0, decode_phone=False):
-        if beam_width > 1:
-            raise NotImplementedError("emoasr_amd: CTC prefix beam search is scheduled after the greedy path")
-        if lm_weight > 0:
-            logging.warning("greedy decoding: LM is not used")
-        return ctc_greedy_apply(self, eouts, elens)
+        if beam_width <= 1:
+            if lm_weight > 0:
+                logging.warning("greedy decoding: LM is not used")
+            return ctc_greedy_apply(self, eouts, elens)
+        from ..ctc_beam_search import ctc_prefix_beam_search
+        hyps, scores, logits = ctc_prefix_beam_search(self, eouts, elens, beam_width, len_weight, lm, lm_weight)
+        return hyps, scores, logits, None

@@ -243,6 +243,45 @@ def run_l4():
           [len(h) for h in hyps], "align lens", [len(a) for a in aligns])
 
 
+CTC_BEAM_SETTINGS = [dict(beam_width=4, len_weight=0.0, lm_weight=0.0),
+                     dict(beam_width=4, len_weight=0.1, lm_weight=0.3),
+                     dict(beam_width=3, len_weight=0.2, lm_weight=0.5)]
+
+
+def run_ctc_beam():
+    """CTC prefix beam search with LM shallow fusion (decoders/ctc.py:203-344,372-397) on the l2_tiny
+    model and the l3_tiny LM; weights are read back from those fixtures (not stored twice) except the
+    sharpened output layer (a random-init CTC head is near-uniform: every beam decision would be a tie)."""
+    from lm.modeling.lm import LM
+    ctc = np.load(os.path.join(OUT, "l2_tiny.npz"))
+    l3 = np.load(os.path.join(OUT, "l3_tiny.npz"))
+    model = ASR(make_params(CONFIGS["l2_tiny"]), phase="test")
+    model.load_state_dict({k[3:]: torch.from_numpy(ctc[k]) for k in ctc.files if k.startswith("sd/")})
+    lm = LM(make_params(LM_CFG))
+    lm.load_state_dict({k[3:]: torch.from_numpy(l3[k]) for k in l3.files if k.startswith("lm/")})
+    model.eval()
+    lm.eval()
+    torch.manual_seed(3)
+    with torch.no_grad():
+        model.decoder.output.weight.mul_(4.0)
+        model.decoder.output.bias.add_(0.5 * torch.randn(model.decoder.output.bias.shape))
+        model.decoder.output.bias[0] += 6.0  # blank-dominated frames, like a trained CTC model
+    out = {"sd_override/decoder.output.weight": model.decoder.output.weight.detach().clone().numpy(),
+           "sd_override/decoder.output.bias": model.decoder.output.bias.detach().clone().numpy()}
+    xs, xlens = torch.from_numpy(ctc["xs"]), torch.from_numpy(ctc["xlens"])
+    with torch.no_grad():
+        for si, st in enumerate(CTC_BEAM_SETTINGS):
+            for b in (1, 2, 3):
+                hyps, scores, logits, _ = model.decode(xs[b:b + 1, : xlens[b]], xlens[b:b + 1], lm=lm, **st)
+                out[f"decode/{si}/{b}/lens"] = np.array([len(h) for h in hyps])
+                out[f"decode/{si}/{b}/hyps"] = np.array(sum([list(map(int, h)) for h in hyps], []), dtype=np.int64)
+                out[f"decode/{si}/{b}/scores"] = np.array(scores, dtype=np.float64)
+                if si == 0:
+                    out[f"logits/{b}"] = logits.numpy()
+                print("ctc beam", si, b, [len(h) for h in hyps], [round(float(s), 3) for s in scores])
+    np.savez_compressed(os.path.join(OUT, "ctcbeam_tiny.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ctc", "l3", "l4"]
     if "ctc" in which:
@@ -252,3 +291,5 @@ if __name__ == "__main__":
         run_l3()
     if "l4" in which:
         run_l4()
+    if "ctcbeam" in which:  # needs l2_tiny.npz and l3_tiny.npz (reads their weights)
+        run_ctc_beam()

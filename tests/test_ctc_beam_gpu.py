@@ -1,0 +1,47 @@
+"""CTC prefix beam search with LM shallow fusion on the GPU against the reference's outputs
+(tests/golden/ctcbeam_tiny.npz): same hypotheses in the same order, scores within 1e-3."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import CONFIGS, CTC_BEAM_SETTINGS, LM_CFG, load_ctc_beam_golden, split_ragged
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(dtype, dev):
+    from emoasr_amd.modeling.asr import ASR
+    from emoasr_amd.modeling.lm import LM
+    cfg, sd, lmsd, g2, gb = load_ctc_beam_golden()
+    model = ASR(SimpleNamespace(**CONFIGS["l2_tiny"]), compute_dtype=dtype)
+    model.load_state_dict(sd)
+    lm = LM(SimpleNamespace(**LM_CFG), compute_dtype=dtype)
+    lm.load_state_dict(lmsd)
+    return model.to(dev).eval(), lm.to(dev).eval(), g2, gb
+
+
+@pytest.mark.parametrize("si", range(len(CTC_BEAM_SETTINGS)))
+def test_ctc_beam_search_f32(dev, si):
+    model, lm, g2, gb = _build(torch.float32, dev)
+    st = CTC_BEAM_SETTINGS[si]
+    for b in (1, 2, 3):
+        n = int(g2["xlens"][b])
+        hyps, scores, logits, aligns = model.decode(g2["xs"][b:b + 1, :n].to(dev), g2["xlens"][b:b + 1], lm=lm, **st)
+        assert aligns is None
+        if si == 0:
+            ref = gb[f"logits/{b}"]
+            assert ((logits.float().cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-3
+        assert hyps == split_ragged(gb[f"decode/{si}/{b}/hyps"], gb[f"decode/{si}/{b}/lens"]), (si, b)
+        np.testing.assert_allclose(scores, gb[f"decode/{si}/{b}/scores"].numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_ctc_beam_search_bf16_runs(dev):
+    """throughput mode: same code path end to end; the best hypothesis is a plausible label sequence"""
+    model, lm, g2, gb = _build(torch.bfloat16, dev)
+    n = int(g2["xlens"][3])
+    hyps, scores, _, _ = model.decode(g2["xs"][3:4, :n].to(dev), g2["xlens"][3:4], beam_width=4, len_weight=0.1, lm=lm,
+                                      lm_weight=0.3)
+    assert len(hyps) == 4 and hyps[0][0] == 2 and all(0 < v < 40 for v in hyps[0])
+    assert scores == sorted(scores, reverse=True) and all(np.isfinite(scores))

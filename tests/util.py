@@ -50,3 +50,22 @@ def split_ragged(flat, lens):
         out.append(flat[o:o + n].tolist())
         o += n
     return out
+
+
+CTC_BEAM_SETTINGS = [dict(beam_width=4, len_weight=0.0, lm_weight=0.0),
+                     dict(beam_width=4, len_weight=0.1, lm_weight=0.3),
+                     dict(beam_width=3, len_weight=0.2, lm_weight=0.5)]
+
+
+def load_ctc_beam_golden():
+    """ctcbeam_tiny: the l2_tiny model with a sharpened output layer + the l3_tiny LM (weights are read
+    from those fixtures) and the reference's CTC prefix beam search outputs."""
+    cfg, sd, g2 = load_golden("l2_tiny")
+    _, _, g3 = load_golden("l3_tiny")
+    z = np.load(os.path.join(GOLDEN, "ctcbeam_tiny.npz"))
+    gb = {k: torch.from_numpy(z[k]) for k in z.files}
+    sd = dict(sd)
+    for k, v in gb.items():
+        if k.startswith("sd_override/"):
+            sd[k[len("sd_override/"):]] = v
+    return cfg, sd, lm_state(g3), g2, gb
