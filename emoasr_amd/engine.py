@@ -35,6 +35,7 @@ class ParamArena:
 
     def __init__(self, module, compute_dtype):
         named = list(module.named_parameters())
+        self.module_order = [n for n, _ in named]  # position in module.parameters(): torch optimizers index by it
         order, seen = [], set()
         byname = dict(named)
         for name, _ in named:

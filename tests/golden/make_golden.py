@@ -282,6 +282,49 @@ def run_ctc_beam():
     np.savez_compressed(os.path.join(OUT, "ctcbeam_tiny.npz"), **out)
 
 
+def run_hostio():
+    """known answers for the host-side formats, from the reference's own functions: WER alignment
+    (asr/metrics.py:20-105), subword -> word joining (utils/vocab.py:45-64), batch packing
+    (asr/datasets.py:200-234).  Stored as JSON (small, readable)."""
+    import json
+    import random as pyrandom
+    from asr.datasets import ASRBatchSampler
+    from asr.metrics import compute_wer
+    from utils.vocab import Vocab
+    rng = pyrandom.Random(7)
+    words = ["a", "b", "c", "d", "e", "f"]
+    wer_cases = []
+    for _ in range(40):
+        ref = [rng.choice(words) for _ in range(rng.randint(1, 9))]
+        hyp = [rng.choice(words) for _ in range(rng.randint(0, 9))]
+        cer = rng.random() < 0.3
+        wer, w = compute_wer(list(hyp), list(ref), cer=cer)
+        wer_cases.append(dict(hyp=hyp, ref=ref, cer=cer, wer=wer, n_sub=w["n_sub"], n_ins=w["n_ins"], n_del=w["n_del"],
+                              n_ref=w["n_ref"], error_list=w["error_list"]))
+    pieces = ["\u2581he", "llo", "\u2581wor", "ld", "<eos>", "\u2581a", "b", "<unk>", "c", "\u2581", "x>"]
+    sw_cases = []
+    for _ in range(30):
+        seq = [rng.choice(pieces) for _ in range(rng.randint(1, 8))]
+        sw_cases.append(dict(subwords=seq, words=Vocab.subwords_to_words(None, seq)))
+    pack_cases = []
+    for _ in range(8):
+        n = rng.randint(5, 60)
+        xlens = sorted(rng.randint(50, 900) for _ in range(n))
+        ylens = [max(1, x // 30 + rng.randint(-2, 2)) for x in xlens]
+        prm = make_params(dict(max_xlens_batch=rng.choice([1000, 2500, 4000]), max_ylens_batch=rng.choice([40, 90, 300]),
+                               batch_size=rng.choice([3, 8, 50])))
+        mbs = rng.choice([1, 1, 2, 3])
+        import pandas as pd
+        dset = types.SimpleNamespace(data=pd.DataFrame(dict(xlen=xlens, ylen=ylens)))
+        sampler = ASRBatchSampler(dset, prm, min_batch_size=mbs)
+        pack_cases.append(dict(xlens=xlens, ylens=ylens, max_xlens_batch=prm.max_xlens_batch,
+                               max_ylens_batch=prm.max_ylens_batch, batch_size=prm.batch_size, min_batch_size=mbs,
+                               batches=sorted(sampler.indices_batches)))
+    with open(os.path.join(OUT, "hostio.json"), "w") as f:
+        json.dump(dict(wer=wer_cases, subwords=sw_cases, packing=pack_cases), f)
+    print("hostio:", len(wer_cases), "wer,", len(sw_cases), "subword,", len(pack_cases), "packing cases")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ctc", "l3", "l4"]
     if "ctc" in which:
@@ -291,5 +334,7 @@ if __name__ == "__main__":
         run_l3()
     if "l4" in which:
         run_l4()
+    if "hostio" in which:
+        run_hostio()
     if "ctcbeam" in which:  # needs l2_tiny.npz and l3_tiny.npz (reads their weights)
         run_ctc_beam()
