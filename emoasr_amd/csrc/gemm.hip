@@ -43,6 +43,15 @@ __device__ __forceinline__ int conv_k_off(const ConvGeom& g, int k) {
 int g_tr_read = 1;
 int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1;
 
+// XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Reading
+// the linear id as (xcd, slot) makes XCD x work on ONE contiguous range of the logical block list, so
+// blocks that share operand tiles (a band of output rows in NT; one k slice in TN) share an L2.
+__device__ __forceinline__ int xcd_remap(int pid, int nblk) {
+  const int per = nblk / 8, rem = nblk - per * 8;  // the first `rem` XCDs hold one more block
+  const int x = pid % 8, slot = pid / 8;
+  return x * per + min(x, rem) + slot;
+}
+
 struct NtArgs {
   int M, N, K;
   const void* A; long lda;
@@ -108,10 +117,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   // (its A rows are fetched into one L2 only) and walks it n-fastest.
   int bx = blockIdx.x, by = blockIdx.y;
   if (g.xcd) {
-    const int nblk = gridDim.x * gridDim.y, pid = by * gridDim.x + bx;
-    const int per = nblk / 8, rem = nblk - per * 8;  // the first `rem` XCDs hold one more block
-    const int x = pid % 8, slot = pid / 8;
-    const int lin = x * per + min(x, rem) + slot;
+    const int lin = xcd_remap(by * gridDim.x + bx, gridDim.x * gridDim.y);
     by = lin / gridDim.x;
     bx = lin - by * gridDim.x;
   }
@@ -496,7 +502,10 @@ __device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const in
 
 template <typename T, int BN1, int BN2, int BMODE, bool TR, int KB>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
-  tn_block<T, BN1, BN2, BMODE, TR, KB>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+  // all (n1, n2) tiles of one k slice read the same rows of A and B: keep a slice on one XCD
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int lin = xcd_remap((blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x, gx * gy * gridDim.z);
+  tn_block<T, BN1, BN2, BMODE, TR, KB>(g, lin % gx, (lin / gx) % gy, lin / (gx * gy));
 }
 
 // Grouped form: up to EMOASR_TN_GROUP_MAX independent products in one launch (the ~10 weight
@@ -509,10 +518,11 @@ struct TnGroup {
 };
 template <typename T, bool TR, int KB>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup G) {
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);  // see gemm_tn_kernel
   int p = 0;
-  while (p + 1 < G.n && (int)blockIdx.x >= G.start[p + 1]) ++p;
+  while (p + 1 < G.n && bid >= G.start[p + 1]) ++p;
   const TnArgs& g = G.p[p];
-  const int local = blockIdx.x - G.start[p];
+  const int local = bid - G.start[p];
   const int tx = (g.N2 + 63) / 64, ty = (g.N1 + 63) / 64;
   tn_block<T, 64, 64, 0, TR, KB>(g, local % tx, (local / tx) % ty, local / (tx * ty));
 }
