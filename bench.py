@@ -252,6 +252,12 @@ def main():
     batches = make_batches(rank, world, args.warmup + args.steps, dev)
     np_rng, py_rng = np.random.RandomState(rank), random.Random(rank)
 
+    buckets = None
+    if world > 1 and os.environ.get("EMOASR_DP_OVERLAP", "1") != "0":
+        from emoasr_amd.train import GradBuckets
+        buckets = GradBuckets(eng.arena.grad)
+        eng.grad_hook = buckets.ready
+
     def step(bt):
         xs = bt.xs.clone()
         spans = h2d_i32(specaug_spans(bt.xlens, 80, np_rng=np_rng, py_rng=py_rng), dev)
@@ -260,7 +266,9 @@ def main():
         loss, _ = model(xs, bt.xlens, bt.ys, bt.ylens, None, None)
         opt.zero_grad()
         loss.backward()
-        if world > 1:
+        if buckets is not None:
+            buckets.finish()   # the tail ranges went out during the backward sweep (train.GradBuckets)
+        elif world > 1:
             opt.allreduce()
         opt.step(grad_mult=1.0 / world)
         return loss

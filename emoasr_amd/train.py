@@ -23,6 +23,38 @@ def allreduce_sum_(flat, group=None):
     return flat
 
 
+class GradBuckets:
+    """Overlap of the gradient all-reduce with the backward sweep.  The backward finishes gradients from
+    the END of the flat arena towards its start (decoder / head first, then encoder layers 11..0, then
+    the front-end), so `ready(lo)` -- "everything at or above offset lo is final" -- lets the tail
+    [lo, done) go out as an asynchronous all-reduce while the layers below are still being
+    differentiated.  Ranges are merged until they reach `min_elems` (a few large collectives: xGMI rings
+    are per-link bound).  `finish()` sends what is left and waits; the sum over all ranges is exactly
+    one all-reduce of the whole buffer (train_asr.py:67-71 semantics are applied by the optimizer's
+    grad_mult = 1/world, as before)."""
+
+    def __init__(self, flat_grad, group=None, min_elems=4 << 20):
+        self.flat, self.group, self.min_elems = flat_grad, group, min_elems
+        self.done = flat_grad.numel()
+        self.handles = []
+
+    def ready(self, lo, force=False):
+        import torch.distributed as dist
+        lo = max(0, int(lo))
+        if lo >= self.done or (self.done - lo < self.min_elems and not force and lo > 0):
+            return
+        self.handles.append(dist.all_reduce(self.flat[lo:self.done], op=dist.ReduceOp.SUM, group=self.group,
+                                            async_op=True))
+        self.done = lo
+
+    def finish(self):
+        self.ready(0, force=True)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.done = self.flat.numel()
+
+
 class ArenaAdam:
     def __init__(self, arena, lr_fn, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad_norm=0.0):
         self.arena = arena

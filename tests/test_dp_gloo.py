@@ -98,3 +98,33 @@ def test_sampler_rule_and_specaug_spans():
     assert (sp[:, :2, 1] <= 80).all() and (sp[:, :2, 1] - sp[:, :2, 0] < 30).all()
     assert (sp[0, 2:, 1] <= 300).all() and (sp[1, 2:, 1] <= 50).all()
     assert (sp[:, 2:, 1] - sp[:, 2:, 0] < 40).all()
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emoasr_amd.train import GradBuckets, allreduce_sum_
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(10_000, generator=g)
+    ref = flat.clone()
+    allreduce_sum_(ref)
+    buckets = GradBuckets(flat, min_elems=1500)
+    for lo in (9_500, 9_000, 7_000, 6_900, 3_000, 2_999):  # the backward sweep reports ranges from the end
+        buckets.ready(lo)
+    n_async = len(buckets.handles)
+    buckets.finish()
+    if rank == 0:
+        torch.save({"same": bool(torch.equal(flat, ref)), "n_async": n_async, "done": buckets.done}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_overlap_allreduce_equals_one_allreduce(tmp_path):
+    """train.GradBuckets: tail ranges all-reduced asynchronously as the backward sweep reports them sum to
+    exactly one all-reduce of the whole flat gradient; small ranges are merged up to min_elems"""
+    world, out = 2, str(tmp_path / "b.pt")
+    mp.spawn(_bucket_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = torch.load(out)
+    assert got["same"] and got["done"] == 10_000
+    assert got["n_async"] == 2  # [7000,10000) and [3000,7000): the 500/1000/100/1-element pieces were merged
