@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   constexpr int A_IT = BM * KV / 256, B_IT = BKM ? BK * BVK / 256 : BN * KV / 256;
   static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 threads");
   constexpr int AS_ELEMS = BM * LD, BS_ELEMS = BKM ? BK * LDBK : BN * LD;
-  constexpr int EP_LD = 36;                               // f32 row stride of the epilogue tile
+  constexpr int EP_LD = BN + 4;                           // f32 row stride of the staged block tile
   constexpr int STAGE_BYTES = 2 * (AS_ELEMS + BS_ELEMS) * (int)sizeof(T);
-  constexpr int EPI_BYTES = 4 * 32 * EP_LD * 4;
+  constexpr int EPI_BYTES = BM * EP_LD * 4;
   constexpr int SMEM_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
@@ -253,88 +253,88 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   const T* __restrict__ res = static_cast<const T*>(ep.residual);
   const T* __restrict__ dpre = static_cast<const T*>(ep.dact_pre);
   T* __restrict__ pre_out = static_cast<T*>(ep.pre_out);
-  float* sc = reinterpret_cast<float*>(smem) + wave * 32 * EP_LD;
-  const int er = lane >> 2, ec = (lane & 3) * 8;  // this lane's row (per 16-row pass) and column group
   const bool vec_ok = (g.N % 8 == 0) && (g.ldc % 8 == 0) && (!res || ep.ldr % 8 == 0);
-  // one 32x32 accumulator tile -> LDS transpose -> fused epilogue -> 16-byte stores.  Called with
-  // constant (i, j) below: a (TM x TN) loop around this body is too big for the unroller, and a
-  // runtime-indexed acc[i][j] would drop the accumulators into scratch for the whole k loop.
-  auto epilogue_tile = [&](const f32x16& a, const int i, const int j) __attribute__((always_inline)) {
-    {
+  // The whole BM x BN block tile goes through LDS (f32, row stride BN + 4), then the 256 threads walk it
+  // row-major: BN / 8 adjacent lanes cover one full tile row, so every global access of the epilogue
+  // (C, residual, dact_pre, pre_out) is a contiguous 2*BN-byte row segment -- full 128-byte lines for
+  // BN = 64.  (Per-wave 32-column staging wrote 64-byte half lines and ran the stores of the K = 256
+  // products at ~2.3 TB/s: the epilogue cost as much as the k loop.)
+  float* sc = reinterpret_cast<float*>(smem);
+  auto stage_tile = [&](const f32x16& a, const int i, const int j) __attribute__((always_inline)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[c_row(r, lane) * EP_LD + c_col(lane)] = a[r];
-      __builtin_amdgcn_wave_barrier();
-      const int col = n0 + wn + j * 32 + ec;
+    for (int r = 0; r < 16; ++r) sc[(wm + i * 32 + c_row(r, lane)) * EP_LD + wn + j * 32 + c_col(lane)] = a[r];
+  };
+  stage_tile(acc[0][0], 0, 0);
+  if constexpr (TN > 1) stage_tile(acc[0][TN - 1], 0, TN - 1);
+  if constexpr (TM > 1) {
+    stage_tile(acc[TM - 1][0], TM - 1, 0);
+    if constexpr (TN > 1) stage_tile(acc[TM - 1][TN - 1], TM - 1, TN - 1);
+  }
+  __syncthreads();
+  constexpr int LPR = BN / 8, RPP = 256 / LPR;  // lanes per tile row, rows per pass
+  const int er = tid / LPR, ec = (tid % LPR) * 8;
+  const int col = n0 + ec;
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int lrow = pass * 16 + er;
-        const int row = m0 + wm + i * 32 + lrow;
-        if (row < g.M && col < g.N) {
-          float v[8];
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sc[lrow * EP_LD + ec]);
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&sc[lrow * EP_LD + ec + 4]);
+  for (int pass = 0; pass < BM / RPP; ++pass) {
+    const int lrow = pass * RPP + er;
+    const int row = m0 + lrow;
+    if (row < g.M && col < g.N) {
+      float v[8];
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sc[lrow * EP_LD + ec]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&sc[lrow * EP_LD + ec + 4]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-          const long off = c_base + (long)row * g.ldc + col;
-          if (vec_ok) {
-            if (ep.bias) {
-              const f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.bias + col);
-              const f32x4 b1 = *reinterpret_cast<const f32x4*>(ep.bias + col + 4);
+      for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+      const long off = c_base + (long)row * g.ldc + col;
+      if (vec_ok) {
+        if (ep.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.bias + col);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(ep.bias + col + 4);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] = ep.alpha * v[e] + b0[e]; v[4 + e] = ep.alpha * v[4 + e] + b1[e]; }
-            } else {
+          for (int e = 0; e < 4; ++e) { v[e] = ep.alpha * v[e] + b0[e]; v[4 + e] = ep.alpha * v[4 + e] + b1[e]; }
+        } else {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
-            }
-            if (pre_out) store8<T>(pre_out + off, v);
+          for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
+        }
+        if (pre_out) store8<T>(pre_out + off, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = apply_act(ep.act, v[e]);
-            if (dpre) {
-              float d[8];
-              load8<T>(dpre + off, d);
+        for (int e = 0; e < 8; ++e) v[e] = apply_act(ep.act, v[e]);
+        if (dpre) {
+          float d[8];
+          load8<T>(dpre + off, d);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= apply_dact(ep.dact, d[e]);
-            }
-            if (ep.drop_p > 0.f) {
+          for (int e = 0; e < 8; ++e) v[e] *= apply_dact(ep.dact, d[e]);
+        }
+        if (ep.drop_p > 0.f) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e)
-                v[e] *= dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col + e, ep.drop_p);
-            }
-            if (res) {
-              float d[8];
-              load8<T>(res + (g.nh > 0 ? c_base : 0) + (long)row * ep.ldr + col, d);
+          for (int e = 0; e < 8; ++e)
+            v[e] *= dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col + e, ep.drop_p);
+        }
+        if (res) {
+          float d[8];
+          load8<T>(res + (g.nh > 0 ? c_base : 0) + (long)row * ep.ldr + col, d);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = d[e] + ep.res_scale * v[e];
-            }
-            if (ep.out_f32) {
-              float* o = static_cast<float*>(g.C) + off;
-              *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-              *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            } else {
-              store8<T>(static_cast<T*>(g.C) + off, v);
-            }
-          } else {
-            for (int e = 0; e < 8 && col + e < g.N; ++e) {
-              float x = ep.alpha * v[e] + (ep.bias ? ep.bias[col + e] : 0.f);
-              if (pre_out) pre_out[off + e] = from_f32<T>(x);
-              x = apply_act(ep.act, x);
-              if (dpre) x *= apply_dact(ep.dact, to_f32(dpre[off + e]));
-              if (ep.drop_p > 0.f) x *= dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col + e, ep.drop_p);
-              if (res) x = to_f32(res[(g.nh > 0 ? c_base : 0) + (long)row * ep.ldr + col + e]) + ep.res_scale * x;
-              if (ep.out_f32) static_cast<float*>(g.C)[off + e] = x;
-              else static_cast<T*>(g.C)[off + e] = from_f32<T>(x);
-            }
-          }
+          for (int e = 0; e < 8; ++e) v[e] = d[e] + ep.res_scale * v[e];
+        }
+        if (ep.out_f32) {
+          float* o = static_cast<float*>(g.C) + off;
+          *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          store8<T>(static_cast<T*>(g.C) + off, v);
+        }
+      } else {
+        for (int e = 0; e < 8 && col + e < g.N; ++e) {
+          float x = ep.alpha * v[e] + (ep.bias ? ep.bias[col + e] : 0.f);
+          if (pre_out) pre_out[off + e] = from_f32<T>(x);
+          x = apply_act(ep.act, x);
+          if (dpre) x *= apply_dact(ep.dact, to_f32(dpre[off + e]));
+          if (ep.drop_p > 0.f) x *= dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col + e, ep.drop_p);
+          if (res) x = to_f32(res[(g.nh > 0 ? c_base : 0) + (long)row * ep.ldr + col + e]) + ep.res_scale * x;
+          if (ep.out_f32) static_cast<float*>(g.C)[off + e] = x;
+          else static_cast<T*>(g.C)[off + e] = from_f32<T>(x);
         }
       }
-      __builtin_amdgcn_wave_barrier();
     }
-  };
-  epilogue_tile(acc[0][0], 0, 0);
-  if constexpr (TN > 1) epilogue_tile(acc[0][TN - 1], 0, TN - 1);
-  if constexpr (TM > 1) {
-    epilogue_tile(acc[TM - 1][0], TM - 1, 0);
-    if constexpr (TN > 1) epilogue_tile(acc[TM - 1][TN - 1], TM - 1, TN - 1);
   }
   static_assert(TM <= 2 && TN <= 2, "epilogue is written for at most 2x2 tiles per wave");
 }
@@ -547,7 +547,8 @@ int launch_nt_(const NtArgs& a_in, hipStream_t s, int nz = 1) {
       gemm_nt_kernel<T, BM_, BN_, AMODE, BKM, TR, 1><<<grid, 256, 0, s>>>(a);              \
     }                                                                                     \
   } while (0)
-  if (tile == 2) EMO_NT_LAUNCH(128, 64);
+  if (tile == 1) EMO_NT_LAUNCH(128, 128);
+  else if (tile == 2) EMO_NT_LAUNCH(128, 64);
   else EMO_NT_LAUNCH(64, 64);
 #undef EMO_NT_LAUNCH
   EMO_LAUNCH_CHECK();
