@@ -46,6 +46,26 @@ def fwd_flops_per_utt(T, F=1024, V=10000, d=256, layers=12):
     return conv1 + conv2 + lin + layers * layer + head
 
 
+def pmc_traffic(entry):
+    """HBM bytes per call of a C-ABI entry point from the committed PMC passes (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE x 2 + WRITE_SIZE per kernel family, separate --pmc runs of this bench; tools/pmc_traffic.py).
+    None when the file is absent or the entry's kernels are not mapped."""
+    fam = {"emoasr_gemm_nn": ("gemm_nn[",), "emoasr_gemm_nt": ("gemm_nt[",),
+           "emoasr_gemm_tn_grouped": ("gemm_tn_grouped_kernel",),
+           "emoasr_attn_bwd": ("attn_bwd_dq2_kernel", "attn_delta_kernel", "gemm_nn_batched[", "attn_dbias_reduce_kernel"),
+           "emoasr_attn_fwd": ("attn_fwd_kernel",)}.get(entry)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if fam is None or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        fams = json.load(f)["families"]
+    hit = {k: v for k, v in fams.items() if k.startswith(fam)}
+    if not hit:
+        return None
+    lead = max(v["launches"] for v in hit.values()) if entry.startswith("emoasr_attn") else sum(v["launches"] for v in hit.values())
+    return sum(v["traffic_bytes_per_launch"] * v["launches"] for v in hit.values()) / lead
+
+
 class CallTimer:
     """HIP-event timing of selected C-ABI entry points on the stream they are launched on."""
 
@@ -330,7 +350,7 @@ def main():
         if dom["calls"] and dom["flops"]:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             res["roofline"] = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[args.dtype],
-                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": pmc_traffic(dominant),
                                "launches": dom["calls"], "avg_us": 1e3 * dom["ms"] / dom["calls"],
                                "share_of_step": dom["ms"] * 1e-3 / elapsed}
         else:
