@@ -193,6 +193,9 @@ class CTCEngine(_DecoderMixinPlaceholder):
         # arena offsets >= lo are final (train.GradBuckets.ready overlaps their all-reduce with the rest)
         self.grad_hook = None
         self._layer_lo = None
+        # Conformer layers sequenced in C++ (EMOASR_CPP_LAYER=0: one FFI call per kernel from Python)
+        self._cpp_layers = os.environ.get("EMOASR_CPP_LAYER", "1") != "0"
+        self._layer_rt = None
         # EMOASR_WGRAD_SIDE=1: run them on a side stream (measured slower on MI355X: 13.97 vs 13.62 ms/step)
         self._side_wgrads = os.environ.get("EMOASR_WGRAD_SIDE", "0") != "0"
         self._side, self._inflight = None, []
@@ -286,10 +289,23 @@ class CTCEngine(_DecoderMixinPlaceholder):
             st.B, st.T2, st.F2, st.M, st.elens = B, T2, F2, M, elens
             st.layers = []
             st.s_pe = s_pe
-        for li in range(self.nl):
-            x, ls = self._layer_fwd(li, x, B, T2, elens, pos_t, p_enc, p_att, training)
-            if st is not None:
-                st.layers.append(ls)
+        if self._cpp_layers and self.conformer and self.rel and not self.attn_store_scores:
+            # one C-ABI call per layer (csrc/layer.hip); intermediates land in per-layer workspaces and
+            # become tensors only when the backward sweep asks for them (layer_rt.LayerStash)
+            if self._layer_rt is None:
+                from .layer_rt import ConformerLayerRuntime
+                self._layer_rt = ConformerLayerRuntime(self)
+            cur = x
+            for li in range(self.nl):
+                cur = self._layer_rt.forward(li, cur, B, T2, elens, pos_t, p_enc, p_att, training, self._keep)
+                if st is not None:
+                    st.layers.append(cur)
+            x = cur.tv("y")
+        else:
+            for li in range(self.nl):
+                x, ls = self._layer_fwd(li, x, B, T2, elens, pos_t, p_enc, p_att, training)
+                if st is not None:
+                    st.layers.append(ls)
         eouts, mean, rstd = ops.layernorm_fwd(x, A.p("encoder.norm.weight"), A.p("encoder.norm.bias"), 1e-12, stash)
         if st is not None:
             st.x_final, st.fin_mean, st.fin_rstd = x, mean, rstd

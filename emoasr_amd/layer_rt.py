@@ -1,0 +1,188 @@
+"""Python side of the C++ layer runtime (csrc/layer.hip: emoasr_conformer_layer_fwd).
+
+One FFI call per Conformer layer instead of ~24: per layer this module keeps a cached parameter struct
+(pointers into the flat arenas, stable across steps) and, per (B, T) shape, the layout of two
+workspaces (compute dtype / f32) that receive every intermediate.  The backward needs those
+intermediates as tensors; the views are created lazily, when the backward sweep reaches the layer.
+"""
+import ctypes
+
+import torch
+
+from . import lib, ops
+
+_ALIGN_T, _ALIGN_F = 64, 16  # elements: 128-byte (bf16) / 64-byte (f32) aligned slots
+
+
+def _round(n, a):
+    return (n + a - 1) // a * a
+
+
+class _Layout:
+    """offsets (in elements) of every forward intermediate of one layer for a (B, T) shape"""
+
+    def __init__(self, B, T, d, H, F):
+        M, R = B * T, 2 * T - 1
+        t_fields = [("ffm_h", (M, d)), ("ffm_u", (M, F)), ("ffm_a", (M, F)), ("ffm_y", (M, d)),
+                    ("at_h", (M, d)), ("qkv", (B, T, 3 * d)), ("pp", (R, d)), ("o", (B, T, d)), ("at_y", (M, d)),
+                    ("cv_h", (M, d)), ("g", (M, 2 * d)), ("gl", (M, d)), ("c", (M, d)), ("z", (M, d)), ("cv_y", (M, d)),
+                    ("ff_h", (M, d)), ("ff_u", (M, F)), ("ff_a", (M, F)), ("ff_y", (M, d)), ("y", (M, d))]
+        f_fields = [("ffm_mean", (M,)), ("ffm_rstd", (M,)), ("lse", (B, H, T)), ("at_mean", (M,)), ("at_rstd", (M,)),
+                    ("bmean", (d,)), ("bvar", (d,)), ("bn_part", (B * ((T + 31) // 32) * 2 * d,)),
+                    ("cv_mean", (M,)), ("cv_rstd", (M,)), ("ff_mean", (M,)), ("ff_rstd", (M,)),
+                    ("fin_mean", (M,)), ("fin_rstd", (M,))]
+        self.t, self.f = {}, {}
+        off = 0
+        for name, shape in t_fields:
+            n = 1
+            for s in shape:
+                n *= s
+            self.t[name] = (off, n, shape)
+            off += _round(n, _ALIGN_T)
+        self.nt = off
+        off = 0
+        for name, shape in f_fields:
+            n = 1
+            for s in shape:
+                n *= s
+            self.f[name] = (off, n, shape)
+            off += _round(n, _ALIGN_F)
+        self.nf = off
+
+
+class LayerStash:
+    """What one layer's forward left behind; iterating yields the (s_ffm, s_att, s_conv, s_ff, s_fin) tuples
+    engine._backward expects, with tensor views built on first use."""
+    __slots__ = ("wt", "wf", "lay", "x_in", "seeds", "_tup")
+
+    def __init__(self, wt, wf, lay, x_in, seeds):
+        self.wt, self.wf, self.lay, self.x_in, self.seeds, self._tup = wt, wf, lay, x_in, seeds, None
+
+    def tv(self, name):
+        o, n, shape = self.lay.t[name]
+        return self.wt[o:o + n].view(shape)
+
+    def fv(self, name):
+        o, n, shape = self.lay.f[name]
+        return self.wf[o:o + n].view(shape)
+
+    def input(self):
+        """the layer input as a tensor (a tensor, or the previous layer's stash whose output it is)"""
+        x = self.x_in
+        if isinstance(x, LayerStash):
+            x = self.x_in = x.tv("y")
+        return x
+
+    def __iter__(self):
+        if self._tup is None:
+            tv, fv, s = self.tv, self.fv, self.seeds
+            x0 = self.input()
+            x1, x2, x3, x4 = tv("ffm_y"), tv("at_y"), tv("cv_y"), tv("ff_y")
+            s_ffm = (x0, fv("ffm_mean"), fv("ffm_rstd"), tv("ffm_h"), tv("ffm_u"), tv("ffm_a"), s[0], s[1])
+            s_att = (x1, fv("at_mean"), fv("at_rstd"), tv("at_h"), tv("qkv"), tv("pp"), tv("o"), fv("lse"), s[2], s[3], None)
+            s_conv = (x2, fv("cv_mean"), fv("cv_rstd"), tv("cv_h"), tv("g"), tv("gl"), tv("c"), fv("bmean"), fv("bvar"),
+                      tv("z"), s[4])
+            s_ff = (x3, fv("ff_mean"), fv("ff_rstd"), tv("ff_h"), tv("ff_u"), tv("ff_a"), s[5], s[6])
+            self._tup = (s_ffm, s_att, s_conv, s_ff, (x4, fv("fin_mean"), fv("fin_rstd")))
+        return iter(self._tup)
+
+    def __getitem__(self, i):
+        return tuple(self)[i]
+
+
+class ConformerLayerRuntime:
+    def __init__(self, eng):
+        self.eng = eng
+        self.params = {}    # layer index -> (lib.ConformerLayer, guard)
+        self.layouts = {}   # (B, T) -> _Layout
+
+    def _layer_params(self, li):
+        eng, A = self.eng, self.eng.arena
+        name = f"encoder.transformers.{li}"
+        bn = name + ".conv.batch_norm"
+        rm = eng._buffers(bn + ".running_mean")
+        guard = (A.flat.data_ptr(), A.shadow.data_ptr(), rm.data_ptr())
+        hit = self.params.get(li)
+        if hit is not None and hit[1] == guard:
+            return hit[0]
+        d = eng.d
+        L = lib.ConformerLayer()
+        L.d, L.H = d, eng.h
+        w1 = A.w(name + ".feed_forward.w1.weight")
+        L.F = w1.shape[0]
+        wd = A.p(name + ".conv.depthwise_conv.weight")
+        L.K = wd.shape[-1]
+
+        def ffn(dst, pre, norm):
+            dst.ln_g, dst.ln_b = A.p(norm + ".weight").data_ptr(), A.p(norm + ".bias").data_ptr()
+            dst.w1, dst.b1 = A.w(pre + ".w1.weight").data_ptr(), A.p(pre + ".w1.bias").data_ptr()
+            dst.w2, dst.b2 = A.w(pre + ".w2.weight").data_ptr(), A.p(pre + ".w2.bias").data_ptr()
+
+        ffn(L.ffm, name + ".feed_forward_macaron", name + ".norm_ff_macaron")
+        ffn(L.ff, name + ".feed_forward", name + ".norm_ff")
+        sa = name + ".self_attn"
+        L.att_ln_g, L.att_ln_b = A.p(name + ".norm_self_attn.weight").data_ptr(), A.p(name + ".norm_self_attn.bias").data_ptr()
+        L.wqkv = A.w_span(sa + ".linear_q.weight", sa + ".linear_v.weight", (3 * d, d)).data_ptr()
+        L.bqkv = A.p_span(sa + ".linear_q.bias", sa + ".linear_v.bias", (3 * d,)).data_ptr()
+        L.wpos = A.w(sa + ".linear_pos.weight").data_ptr()
+        L.bias_u, L.bias_v = A.p(sa + ".pos_bias_u").data_ptr(), A.p(sa + ".pos_bias_v").data_ptr()
+        L.wout, L.bout = A.w(sa + ".linear_out.weight").data_ptr(), A.p(sa + ".linear_out.bias").data_ptr()
+        cv = name + ".conv"
+        L.cv_ln_g, L.cv_ln_b = A.p(name + ".norm_conv.weight").data_ptr(), A.p(name + ".norm_conv.bias").data_ptr()
+        L.pw1, L.pw1_b = A.w(cv + ".pointwise_conv1.weight", (2 * d, d)).data_ptr(), A.p(cv + ".pointwise_conv1.bias").data_ptr()
+        L.dw_w, L.dw_b = wd.data_ptr(), A.p(cv + ".depthwise_conv.bias").data_ptr()
+        L.bn_g, L.bn_b = A.p(bn + ".weight").data_ptr(), A.p(bn + ".bias").data_ptr()
+        L.bn_rm, L.bn_rv = rm.data_ptr(), eng._buffers(bn + ".running_var").data_ptr()
+        L.bn_nbt = eng._buffers(bn + ".num_batches_tracked").data_ptr()
+        L.pw2, L.pw2_b = A.w(cv + ".pointwise_conv2.weight", (d, d)).data_ptr(), A.p(cv + ".pointwise_conv2.bias").data_ptr()
+        L.fin_ln_g, L.fin_ln_b = A.p(name + ".norm_final.weight").data_ptr(), A.p(name + ".norm_final.bias").data_ptr()
+        self.params[li] = (L, guard)
+        return L
+
+    def forward(self, li, x, B, T, elens, pos_t, p_enc, p_att, training, keep):
+        """x: tensor [B*T, d] or the previous layer's LayerStash.  -> LayerStash (its tv("y") is the output)"""
+        eng = self.eng
+        L = self._layer_params(li)
+        lay = self.layouts.get((B, T))
+        if lay is None:
+            if len(self.layouts) > 64:
+                self.layouts.clear()
+            lay = self.layouts[(B, T)] = _Layout(B, T, eng.d, eng.h, L.F)
+        dev = pos_t.device
+        wt = torch.empty(lay.nt, device=dev, dtype=eng.dtype)
+        wf = torch.empty(lay.nf, device=dev, dtype=torch.float32)
+        site = 100 + li * 20
+        seeds = tuple(eng._seed(site + k) for k in (0, 1, 2, 3, 4, 6, 7))
+        st = LayerStash(wt, wf, lay, x, seeds)
+        esz = wt.element_size()
+        tb, fb = wt.data_ptr(), wf.data_ptr()
+        t, f = lay.t, lay.f
+        io = lib.ConformerFwd()
+        io.B, io.T = B, T
+        io.x = tb_prev(x, esz)
+        io.pos_t, io.klens = pos_t.data_ptr(), elens.data_ptr()
+        io.training, io.p_enc, io.p_att = int(training), p_enc, p_att
+        io.seed[:] = seeds
+        io.ffm.h, io.ffm.u, io.ffm.a, io.ffm.y = (tb + t["ffm_h"][0] * esz, tb + t["ffm_u"][0] * esz if keep else None,
+                                                  tb + t["ffm_a"][0] * esz, tb + t["ffm_y"][0] * esz)
+        io.ff.h, io.ff.u, io.ff.a, io.ff.y = (tb + t["ff_h"][0] * esz, tb + t["ff_u"][0] * esz if keep else None,
+                                              tb + t["ff_a"][0] * esz, tb + t["ff_y"][0] * esz)
+        for k in ("at_h", "qkv", "pp", "o", "at_y", "cv_h", "g", "gl", "c", "z", "cv_y", "y"):
+            setattr(io, k, tb + t[k][0] * esz)
+        io.lse = fb + f["lse"][0] * 4
+        io.bmean, io.bvar, io.bn_part = fb + f["bmean"][0] * 4, fb + f["bvar"][0] * 4, fb + f["bn_part"][0] * 4
+        if keep:
+            io.ffm.mean, io.ffm.rstd = fb + f["ffm_mean"][0] * 4, fb + f["ffm_rstd"][0] * 4
+            io.ff.mean, io.ff.rstd = fb + f["ff_mean"][0] * 4, fb + f["ff_rstd"][0] * 4
+            io.at_mean, io.at_rstd = fb + f["at_mean"][0] * 4, fb + f["at_rstd"][0] * 4
+            io.cv_mean, io.cv_rstd = fb + f["cv_mean"][0] * 4, fb + f["cv_rstd"][0] * 4
+            io.fin_mean, io.fin_rstd = fb + f["fin_mean"][0] * 4, fb + f["fin_rstd"][0] * 4
+        lib.call("emoasr_conformer_layer_fwd", ops.dt(wt), ctypes.byref(L), ctypes.byref(io), ops._stream())
+        return st
+
+
+def tb_prev(x, esz):
+    """device address of a layer input given as a tensor or as the previous layer's stash"""
+    if isinstance(x, LayerStash):
+        return x.wt.data_ptr() + x.lay.t["y"][0] * esz
+    return x.data_ptr()

@@ -58,6 +58,38 @@ class LnFinalizeItem(Structure):
 
 LN_FINALIZE_MAX = 64
 
+
+class FfnParams(Structure):
+    _fields_ = [("ln_g", c_void_p), ("ln_b", c_void_p), ("w1", c_void_p), ("b1", c_void_p),
+                ("w2", c_void_p), ("b2", c_void_p)]
+
+
+class ConformerLayer(Structure):
+    _fields_ = [("d", c_int), ("H", c_int), ("F", c_int), ("K", c_int), ("ffm", FfnParams), ("ff", FfnParams),
+                ("att_ln_g", c_void_p), ("att_ln_b", c_void_p), ("wqkv", c_void_p), ("bqkv", c_void_p),
+                ("wpos", c_void_p), ("bias_u", c_void_p), ("bias_v", c_void_p), ("wout", c_void_p), ("bout", c_void_p),
+                ("cv_ln_g", c_void_p), ("cv_ln_b", c_void_p), ("pw1", c_void_p), ("pw1_b", c_void_p),
+                ("dw_w", c_void_p), ("dw_b", c_void_p), ("bn_g", c_void_p), ("bn_b", c_void_p),
+                ("bn_rm", c_void_p), ("bn_rv", c_void_p), ("bn_nbt", c_void_p), ("pw2", c_void_p), ("pw2_b", c_void_p),
+                ("fin_ln_g", c_void_p), ("fin_ln_b", c_void_p)]
+
+
+class FfnStash(Structure):
+    _fields_ = [("h", c_void_p), ("u", c_void_p), ("a", c_void_p), ("y", c_void_p), ("mean", c_void_p),
+                ("rstd", c_void_p)]
+
+
+class ConformerFwd(Structure):
+    _fields_ = [("B", c_int), ("T", c_int), ("x", c_void_p), ("pos_t", c_void_p), ("klens", c_void_p),
+                ("training", c_int), ("p_enc", c_float), ("p_att", c_float), ("seed", c_uint64 * 7),
+                ("ffm", FfnStash), ("ff", FfnStash),
+                ("at_h", c_void_p), ("qkv", c_void_p), ("pp", c_void_p), ("o", c_void_p), ("at_y", c_void_p),
+                ("lse", c_void_p), ("at_mean", c_void_p), ("at_rstd", c_void_p),
+                ("cv_h", c_void_p), ("g", c_void_p), ("gl", c_void_p), ("c", c_void_p), ("z", c_void_p),
+                ("cv_y", c_void_p), ("bmean", c_void_p), ("bvar", c_void_p), ("bn_part", c_void_p),
+                ("cv_mean", c_void_p), ("cv_rstd", c_void_p),
+                ("y", c_void_p), ("fin_mean", c_void_p), ("fin_rstd", c_void_p)]
+
 P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
 
 # name -> argtypes (every function returns int status); mirrors include/emoasr_hip.h
@@ -77,6 +109,7 @@ SIGNATURES = {
     "emoasr_layernorm_bwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     "emoasr_layernorm_bwd_ex": [I, I, I, P, P, P, P, P, P, P, P, P, P, POINTER(LnBwdOpts), P],
     "emoasr_layernorm_bwd_finalize": [I, POINTER(LnFinalizeItem), P],
+    "emoasr_conformer_layer_fwd": [I, POINTER(ConformerLayer), POINTER(ConformerFwd), P],
     "emoasr_attn_fwd": [I, POINTER(AttnArgs), P],
     "emoasr_attn_bwd": [I, POINTER(AttnArgs), P],
     "emoasr_glu_fwd": [I, I, I, P, P, P],

@@ -331,6 +331,56 @@ int emoasr_rnnt_grad(int dtype, int B, int T, int U, int V, int Lmax, const void
 /* out[m] = argmax_v x[m,:V] (first maximum) */
 int emoasr_argmax_rows(int dtype, int M, int V, const void* x, long ldx, int* out, void* stream);
 
+/* ---- one Conformer encoder layer, forward, sequenced on the host in C++ ---------
+ * ConformerEncoderLayer.forward (asr/modeling/conformer.py:146-225) with relative-position attention:
+ *   x += 0.5 * drop(FFN_macaron(LN(x)));  x += drop(RelMHA(LN(x)));  x += drop(ConvModule(LN(x)));
+ *   x += 0.5 * drop(FFN(LN(x)));  y = LN(x)
+ * as ONE call that enqueues the ~24 kernels above on `stream` (the caller pays one FFI crossing per
+ * layer instead of one per kernel).  Every intermediate the backward needs is written to
+ * caller-provided buffers (emoasr_conformer_fwd_t); mean / rstd / u pointers may be NULL for inference.
+ * Weights (w*, pw*, wqkv [3d,d], wpos, wout) are in the compute dtype, everything else f32.
+ * seed[] = {ffm_in, ffm_out, att_probs, att_out, conv_out, ff_in, ff_out} dropout streams. */
+typedef struct emoasr_ffn_params {
+  const float *ln_g, *ln_b;
+  const void* w1; const float* b1;   /* [F,d], [F] */
+  const void* w2; const float* b2;   /* [d,F], [d] */
+} emoasr_ffn_params_t;
+typedef struct emoasr_conformer_layer {
+  int d, H, F, K;                    /* model dim, heads, FFN inner dim, depthwise kernel size */
+  emoasr_ffn_params_t ffm, ff;
+  const float *att_ln_g, *att_ln_b;
+  const void* wqkv; const float* bqkv;
+  const void* wpos;
+  const float *bias_u, *bias_v;
+  const void* wout; const float* bout;
+  const float *cv_ln_g, *cv_ln_b;
+  const void* pw1; const float* pw1_b;   /* [2d,d] */
+  const float *dw_w, *dw_b;              /* [d,K], [d] */
+  const float *bn_g, *bn_b;
+  float *bn_rm, *bn_rv; long long* bn_nbt;
+  const void* pw2; const float* pw2_b;
+  const float *fin_ln_g, *fin_ln_b;
+} emoasr_conformer_layer_t;
+typedef struct emoasr_ffn_stash {
+  void *h, *u, *a, *y;               /* LN out [M,d], pre-activation [M,F] (optional), activation [M,F], block output [M,d] */
+  float *mean, *rstd;
+} emoasr_ffn_stash_t;
+typedef struct emoasr_conformer_fwd {
+  int B, T;
+  const void* x;                     /* [B*T, d] */
+  const void* pos_t;                 /* [2T-1, d] relative position table (after dropout), compute dtype */
+  const int* klens;                  /* int32 [B] valid frames */
+  int training;                      /* batch statistics + running-stat update in BatchNorm */
+  float p_enc, p_att;
+  uint64_t seed[7];
+  emoasr_ffn_stash_t ffm, ff;
+  void *at_h, *qkv, *pp, *o, *at_y; float *lse, *at_mean, *at_rstd;
+  void *cv_h, *g, *gl, *c, *z, *cv_y; float *bmean, *bvar, *bn_part, *cv_mean, *cv_rstd;
+  void* y; float *fin_mean, *fin_rstd;
+} emoasr_conformer_fwd_t;
+int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* layer,
+                               const emoasr_conformer_fwd_t* io, void* stream);
+
 /* ---- optimizer (asr/train_asr.py:84-92, torch.optim.Adam semantics) ---------- */
 /* out[0] += sum x^2 */
 int emoasr_sqnorm(long n, const float* x, float* out, void* stream);
