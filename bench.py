@@ -193,6 +193,92 @@ def decode_rtf(model, dev, n_utts=20, repeats=3):
     return best
 
 
+def decode_rtf_batched(model, dev, batch=32, repeats=3):
+    """greedy CTC decode at a batched operating point: `batch` length-sorted neighbours per call"""
+    from emoasr_amd.data import libri_shaped_lengths
+    xlens, _ = libri_shaped_lengths(2000, 0)
+    lens = [int(v) for v in xlens[1000:1000 + batch]]
+    xs = torch.randn(batch, max(lens), 80)
+    for b, n in enumerate(lens):
+        xs[b, n:] = 0
+    xs = xs.to(dev)
+    model.eval()
+    model.decode(xs, lens)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        model.decode(xs, lens)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / (sum(lens) * 0.010))
+    model.train()
+    return best
+
+
+L4 = dict(L2, decoder_type="rnn_transducer", vocab_size=1000, embedding_size=256, dec_hidden_size=512, dec_num_layers=2,
+          joint_hidden_size=512, dropout_emb_rate=0.1, dropout_dec_rate=0.1, mtl_ctc_weight=0.3, lsm_prob=0.0)
+
+
+def l4_rnnt(dev, dtype, steps=5, warmup=2, n_dec=5):
+    """config 5 (`L4`): RNN-T (Conformer) 26 M -- training frames/s (fwd + transducer lattice + bwd + Adam on
+    LibriSpeech-shaped batches, 12 000-frame budget: the joint logits are [B,T',U+1,1000]) and streaming greedy
+    decode RTF at batch 1 (decode steps capped by the model's own max-symbols rule)."""
+    from emoasr_amd.data import libri_shaped_lengths, pack_batches
+    from emoasr_amd.modeling.asr import ASR
+    from emoasr_amd.train import ArenaAdam, noam_lr
+    torch.manual_seed(2)
+    model = ASR(SimpleNamespace(**L4), compute_dtype=dtype).to(dev).train()
+    eng = model.engine()
+    opt = ArenaAdam(eng.arena, lambda s: noam_lr(OPT["lr"], 256, OPT["warmup"], s), weight_decay=OPT["weight_decay"],
+                    clip_grad_norm=OPT["clip_grad_norm"])
+    xlens, ylens = libri_shaped_lengths(2000, 0)
+    batches = pack_batches(xlens, ylens, 12000, 1200, 50, 1)
+    rs = random.Random(3)
+    rs.shuffle(batches)
+    g = torch.Generator().manual_seed(5)
+    data = []
+    for idx in batches[: steps + warmup]:
+        xl, yl = [int(xlens[i]) for i in idx], [int(ylens[i]) for i in idx]
+        xs = torch.randn(len(idx), max(xl), 80, generator=g)
+        ys = torch.randint(3, L4["vocab_size"], (len(idx), max(yl)), generator=g)
+        eos = torch.full((len(idx), 1), L4["eos_id"])
+        for b in range(len(idx)):
+            xs[b, xl[b]:] = 0
+            ys[b, yl[b]:] = L4["eos_id"]
+        data.append((xs.to(dev), xl, ys, yl, torch.cat([eos, ys], 1), torch.cat([ys, eos], 1)))
+
+    def step(bt):
+        loss, _ = model(*bt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for bt in data[:warmup]:
+        step(bt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for bt in data[warmup:]:
+        loss = step(bt)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    frames = sum(sum(bt[1]) for bt in data[warmup:])
+    out = dict(train_frames_per_s=frames / el, ms_per_step=1e3 * el / steps, frames_per_step=frames / steps,
+               params_M=sum(p.numel() for p in model.parameters()) / 1e6, final_loss=float(loss.detach()))
+    model.eval()
+    rs2 = np.random.RandomState(4)
+    pick = rs2.choice(len(xlens), n_dec, replace=False)
+    utts = [(torch.randn(1, int(xlens[i]), 80).to(dev), [int(xlens[i])]) for i in pick]
+    model.decode(*utts[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for x, l in utts:
+        model.decode(x, l)
+    torch.cuda.synchronize()
+    out["greedy_rtf"] = (time.perf_counter() - t0) / (sum(l[0] for _, l in utts) * 0.010)
+    return out
+
+
 L3 = dict(L2, decoder_type="transformer", dec_hidden_size=256, dec_num_attention_heads=4, dec_num_layers=6,
           dec_intermediate_size=1024, dropout_dec_rate=0.1, mtl_ctc_weight=0.3, lsm_prob=0.1,
           loss_normalize_length=False, loss_normalize_batch=True, max_decode_ylen=256)
@@ -366,7 +452,9 @@ def main():
             print(f"  total instrumented GPU time {tot:.2f} ms (one step, B={len(batches[args.warmup - 1].xlens)})", file=sys.stderr)
         if world == 1 and not args.no_decode:
             res["decode_rtf"] = decode_rtf(model, dev)
+            res["decode_rtf_batch32"] = decode_rtf_batched(model, dev)
             res["decode_l33"] = decode_rtf_l33(dev, dtype)
+            res["l4_rnnt"] = l4_rnnt(dev, dtype)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(res), flush=True)
