@@ -193,6 +193,26 @@ def decode_rtf(model, dev, n_utts=20, repeats=3):
     return best
 
 
+def logmel_rate(dev, batch_xlens, repeats=3):
+    """on-GPU Kaldi log-mel of one training batch's raw audio (N = 160 (T - 1) + 400 samples of N(0, 0.05) per
+    utterance): feature frames per second of the fbank kernel alone"""
+    from emoasr_amd.features import LogMel
+    lm = LogMel(dev)
+    g = torch.Generator().manual_seed(9)
+    wavs = [(0.05 * torch.randn(160 * (int(t) - 1) + 400, generator=g)).to(dev) for t in batch_xlens]
+    for w in wavs[:2]:
+        lm(w)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for w in wavs:
+            lm(w)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return sum(int(t) for t in batch_xlens) / best
+
+
 def decode_rtf_batched(model, dev, batch=32, repeats=3):
     """greedy CTC decode at a batched operating point: `batch` length-sorted neighbours per call"""
     from emoasr_amd.data import libri_shaped_lengths
@@ -453,6 +473,8 @@ def main():
         if world == 1 and not args.no_decode:
             res["decode_rtf"] = decode_rtf(model, dev)
             res["decode_rtf_batch32"] = decode_rtf_batched(model, dev)
+            fb = logmel_rate(dev, batches[-1].xlens)
+            res["logmel"] = {"frames_per_s": fb, "train_frames_per_s_with_logmel": 1.0 / (1.0 / value + 1.0 / fb)}
             res["decode_l33"] = decode_rtf_l33(dev, dtype)
             res["l4_rnnt"] = l4_rnnt(dev, dtype)
         if world == 1 and not args.no_cpu_baseline:
