@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   constexpr int AS_ELEMS = BM * LD, BS_ELEMS = BKM ? BK * LDBK : BN * LD;
   constexpr int EP_LD = BN + 4;                           // f32 row stride of the staged block tile
   constexpr int STAGE_BYTES = 2 * (AS_ELEMS + BS_ELEMS) * (int)sizeof(T);
-  constexpr int EPI_BYTES = BM * EP_LD * 4;
+  constexpr int EPI_ROWS = (BM * BN > 128 * 64) ? BM / 2 : BM;  // the 128x128 tile is staged in two 64-row halves
+  constexpr int EPI_BYTES = EPI_ROWS * EP_LD * 4;
   constexpr int SMEM_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
@@ -260,9 +261,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   // BN = 64.  (Per-wave 32-column staging wrote 64-byte half lines and ran the stores of the K = 256
   // products at ~2.3 TB/s: the epilogue cost as much as the k loop.)
   float* sc = reinterpret_cast<float*>(smem);
-  auto stage_tile = [&](const f32x16& a, const int i, const int j) __attribute__((always_inline)) {
+  constexpr int LPR = BN / 8, RPP = 256 / LPR;  // lanes per tile row, rows per pass
+  const int er = tid / LPR, ec = (tid % LPR) * 8;
+  const int col = n0 + ec;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[(wm + i * 32 + c_row(r, lane)) * EP_LD + wn + j * 32 + c_col(lane)] = a[r];
+  for (int half = 0; half < BM / EPI_ROWS; ++half) {
+  const int hrow0 = half * EPI_ROWS;
+  if (half > 0) __syncthreads();  // the previous half has been read
+  auto stage_tile = [&](const f32x16& a, const int i, const int j) __attribute__((always_inline)) {
+    const int r0 = wm + i * 32 - hrow0;
+    if (r0 >= 0 && r0 < EPI_ROWS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[(r0 + c_row(r, lane)) * EP_LD + wn + j * 32 + c_col(lane)] = a[r];
+    }
   };
   stage_tile(acc[0][0], 0, 0);
   if constexpr (TN > 1) stage_tile(acc[0][TN - 1], 0, TN - 1);
@@ -271,13 +282,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
     if constexpr (TN > 1) stage_tile(acc[TM - 1][TN - 1], TM - 1, TN - 1);
   }
   __syncthreads();
-  constexpr int LPR = BN / 8, RPP = 256 / LPR;  // lanes per tile row, rows per pass
-  const int er = tid / LPR, ec = (tid % LPR) * 8;
-  const int col = n0 + ec;
 #pragma unroll
-  for (int pass = 0; pass < BM / RPP; ++pass) {
+  for (int pass = 0; pass < EPI_ROWS / RPP; ++pass) {
     const int lrow = pass * RPP + er;
-    const int row = m0 + lrow;
+    const int row = m0 + hrow0 + lrow;
     if (row < g.M && col < g.N) {
       float v[8];
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sc[lrow * EP_LD + ec]);
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
         }
       }
     }
+  }
   }
   static_assert(TM <= 2 && TN <= 2, "epilogue is written for at most 2x2 tiles per wave");
 }
