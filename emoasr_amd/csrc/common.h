@@ -216,6 +216,60 @@ __device__ __forceinline__ float apply_dact(int act, float pre) {
   return 1.f;
 }
 
+// Vector forms: ONE dispatch on the (wave-uniform) activation code per group of N values.  Calling
+// apply_act / apply_dact per element inside an unrolled loop makes the compiler emit the whole
+// compare-and-branch ladder (with the erf / tanh / exp expansions behind it) once per element: the GEMM
+// epilogue was ~12 000 instructions and ~900 scalar branches long, most of a K = 256 tile's time.
+template <int N>
+__device__ __forceinline__ void act_vec(int act, float (&v)[N]) {
+  switch (act) {
+    case EMO_ACT_RELU:
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.f);
+      break;
+    case EMO_ACT_SWISH:
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] = swishf_(v[e]);
+      break;
+    case EMO_ACT_GELU:
+#pragma unroll 1
+      for (int e = 0; e < N; ++e) v[e] = geluf_(v[e]);
+      break;
+    case EMO_ACT_TANH:
+#pragma unroll 1
+      for (int e = 0; e < N; ++e) v[e] = tanhf(v[e]);
+      break;
+    default: break;
+  }
+}
+// v[e] *= act'(pre[e])   (EMO_DACT_TANH_OUT: pre holds tanh's output)
+template <int N>
+__device__ __forceinline__ void dact_vec(int act, const float (&pre)[N], float (&v)[N]) {
+  switch (act) {
+    case EMO_ACT_RELU:
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] = pre[e] > 0.f ? v[e] : 0.f;
+      break;
+    case EMO_ACT_SWISH:
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] *= dswishf_(pre[e]);
+      break;
+    case EMO_ACT_GELU:
+#pragma unroll 1
+      for (int e = 0; e < N; ++e) v[e] *= dgeluf_(pre[e]);
+      break;
+    case EMO_ACT_TANH:
+#pragma unroll 1
+      for (int e = 0; e < N; ++e) { const float t = tanhf(pre[e]); v[e] *= 1.f - t * t; }
+      break;
+    case EMO_DACT_TANH_OUT:
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] *= 1.f - pre[e] * pre[e];
+      break;
+    default: break;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Counter-based dropout RNG.  keep(seed, idx) is a pure function so backward
 // kernels regenerate the forward mask instead of storing it.

@@ -304,13 +304,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
           for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
         }
         if (pre_out) store8<T>(pre_out + off, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = apply_act(ep.act, v[e]);
+        act_vec<8>(ep.act, v);
         if (dpre) {
           float d[8];
           load8<T>(dpre + off, d);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= apply_dact(ep.dact, d[e]);
+          dact_vec<8>(ep.dact, d, v);
         }
         if (ep.drop_p > 0.f) {
 #pragma unroll
