@@ -774,13 +774,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const emoasr_attn_t a
       if (a.dbd && !(EMO_DQ_SKIP & 1)) {
         // dBD[h, b, i, r] (r = table row, contiguous): lane <-> band column, one query row per
         // iteration -> contiguous 64-wide row segments.  Each (i, r) belongs to exactly one key tile.
-        T* drow = (T*)a.dbd + (((long)h * a.B + b) * a.Tq + i0) * a.ldbd;
+        // element stores through a buffer descriptor: one 32-bit offset per store, out-of-range lanes are
+        // dropped by the bounds check instead of being branched around (32 stores per tile)
+        const __amdgpu_buffer_rsrc_t rsBd = make_rsrc((T*)a.dbd + (((long)h * a.B + b) * a.Tq + i0) * a.ldbd);
         const int row = rbase + lane;
         const bool rok = row >= 0 && row < 2 * a.Tq - 1;
+        const int qmax = min(32, a.Tq - i0);
 #pragma unroll 8
         for (int q = 0; q < 32; ++q) {
           const int key = lane - 31 + q;
-          if (rok && key >= 0 && key < 32 && i0 + q < a.Tq) drow[(long)q * a.ldbd + row] = img_ds[key * IMG + q];
+          const bool ok = rok && key >= 0 && key < 32 && q < qmax;
+          buf_store_elem<T>(rsBd, ok ? (unsigned)(((long)q * a.ldbd + row) * sizeof(T)) : EMO_OOB,
+                            to_f32(img_ds[(ok ? key : 0) * IMG + q]));
         }
       }
       if (!(EMO_DQ_SKIP & 16))
