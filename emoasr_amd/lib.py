@@ -59,6 +59,37 @@ class LnFinalizeItem(Structure):
 LN_FINALIZE_MAX = 64
 
 
+class Lin(Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p)]
+
+
+class LnP(Structure):
+    _fields_ = [("g", c_void_p), ("b", c_void_p)]
+
+
+class DecoderLayer(Structure):
+    _fields_ = [("ln1", LnP), ("ln2", LnP), ("ln3", LnP), ("qkv", Lin), ("out", Lin), ("q2", Lin), ("out2", Lin),
+                ("w1", Lin), ("w2", Lin)]
+
+
+class DecoderInfer(Structure):
+    _fields_ = [("nb", c_int), ("L", c_int), ("T", c_int), ("dd", c_int), ("H", c_int), ("F", c_int), ("V", c_int),
+                ("ids", c_void_p), ("embed", c_void_p), ("pe", c_void_p), ("emb_scale", c_float),
+                ("kself", c_void_p), ("kmem", c_void_p), ("kv", POINTER(c_void_p)),
+                ("ln_out", LnP), ("out", Lin), ("logits_last", c_void_p), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t)]
+
+
+class BertLayer(Structure):
+    _fields_ = [("qkv", Lin), ("attn_out", Lin), ("ln_attn", LnP), ("inter", Lin), ("out", Lin), ("ln_out", LnP)]
+
+
+class BertInfer(Structure):
+    _fields_ = [("nb", c_int), ("L", c_int), ("d", c_int), ("H", c_int), ("F", c_int), ("V", c_int),
+                ("ids", c_void_p), ("word_emb", c_void_p), ("pe", c_void_p), ("ln_emb", LnP), ("klens", c_void_p),
+                ("transform", Lin), ("ln_transform", LnP), ("out_bias", c_void_p), ("logp", c_void_p),
+                ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t)]
+
+
 class FfnParams(Structure):
     _fields_ = [("ln_g", c_void_p), ("ln_b", c_void_p), ("w1", c_void_p), ("b1", c_void_p),
                 ("w2", c_void_p), ("b2", c_void_p)]
@@ -110,6 +141,8 @@ SIGNATURES = {
     "emoasr_layernorm_bwd_ex": [I, I, I, P, P, P, P, P, P, P, P, P, P, POINTER(LnBwdOpts), P],
     "emoasr_layernorm_bwd_finalize": [I, POINTER(LnFinalizeItem), P],
     "emoasr_conformer_layer_fwd": [I, POINTER(ConformerLayer), POINTER(ConformerFwd), P],
+    "emoasr_transformer_decoder_infer": [I, I, POINTER(DecoderLayer), POINTER(DecoderInfer), P],
+    "emoasr_bert_lm_infer": [I, I, POINTER(BertLayer), POINTER(BertInfer), P],
     "emoasr_attn_fwd": [I, POINTER(AttnArgs), P],
     "emoasr_attn_bwd": [I, POINTER(AttnArgs), P],
     "emoasr_glu_fwd": [I, I, I, P, P, P],

@@ -11,6 +11,8 @@ log-probabilities, log-softmax + fusion, top-k candidate selection, CTC prefix s
 (beam, candidate) with the scorer states kept on the device.  Host side: one small D2H per step
 (candidate ids/scores), then the reference's own list bookkeeping (sort, prune, finish).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -36,17 +38,35 @@ def joint_beam_search(dec, eouts, elens, beam_width, len_weight=0, lm=None, lm_w
             x = ops.log_softmax(ctc_logits.view(T, V))
             init_state = ops.ctc_prefix_init(x, blank)
             cw = min(V, int(beam_width * CTC_BEAM_WIDTH_RATIO))
+        # C++ step runtime (csrc/decode_rt.hip): one C-ABI call per network per output step, cross-attention
+        # K / V of the memory projected once per utterance.  EMOASR_CPP_DECODE=0: per-kernel Python sequencing.
+        rt = lmrt = None
+        if os.environ.get("EMOASR_CPP_DECODE", "1") != "0":
+            from ..decode_rt import DecoderStepRuntime, LMStepRuntime
+            rt = getattr(eng, "_dec_rt", None)
+            if rt is None:
+                rt = eng._dec_rt = DecoderStepRuntime(eng)
+            rt.begin(eouts, beam_width)
+            if use_lm and hasattr(lm, "predict_device"):
+                lmrt = getattr(lm, "_step_rt", None)
+                if lmrt is None:
+                    lmrt = lm._step_rt = LMStepRuntime(lm)
         beams = [dict(hyp=[eos], score=0.0, score_ctc=np.float32(0.0), parent=0, pcand=0)]
         prev_states = None
         results = []
         for i in range(dec.max_decode_ylen):
             nb = len(beams)
             ys_in = torch.tensor([b["hyp"] for b in beams], dtype=torch.int64)
-            mem = eouts.expand(nb, T, eouts.shape[2]).contiguous()
-            el = h2d_i32([T] * nb, dev)
-            logits, _ = eng.dec_forward(mem, el, ys_in, [i] * nb, False, False)  # [nb, i+1, V]
-            last = logits[:, i]
-            lm_lp = lm.predict_device(ys_in, [i + 1] * nb) if use_lm else None
+            if rt is not None:
+                with ops.stream_scope():
+                    last = rt.step(ys_in)                                            # [nb, V]
+                    lm_lp = (lmrt.step(ys_in) if lmrt is not None else lm.predict_device(ys_in, [i + 1] * nb)) if use_lm else None
+            else:
+                mem = eouts.expand(nb, T, eouts.shape[2]).contiguous()
+                el = h2d_i32([T] * nb, dev)
+                logits, _ = eng.dec_forward(mem, el, ys_in, [i] * nb, False, False)  # [nb, i+1, V]
+                last = logits[:, i]
+                lm_lp = lm.predict_device(ys_in, [i + 1] * nb) if use_lm else None
             scores_pre = ops.log_softmax(last, add=lm_lp, mu=mu)  # = scores_att (+ lm: the in-place alias quirk)
             if use_ctc:
                 vals, cands, lm_at = ops.topk(scores_pre, cw, aux=lm_lp)

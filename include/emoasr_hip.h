@@ -20,6 +20,7 @@
  */
 #ifndef EMOASR_HIP_H
 #define EMOASR_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -380,6 +381,53 @@ typedef struct emoasr_conformer_fwd {
 } emoasr_conformer_fwd_t;
 int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* layer,
                                const emoasr_conformer_fwd_t* io, void* stream);
+
+/* ---- beam-search step runtime (inference): the Transformer decoder over the whole prefix and the
+ * Transformer LM's next-token distribution, each as ONE call per output step ---------------------------
+ * emoasr_transformer_decoder_infer: TransformerDecoder.forward_one_step (decoders/transformer.py:148-159;
+ * layers: transformer.py:156-198, eps 1e-12, ReLU FFN) for nb live hypotheses of L tokens each.  Like the
+ * reference it recomputes the prefix (no self-attention cache); unlike it, the cross-attention keys / values
+ * of the encoder memory are projected once per utterance (kv[l]: [nb,T,2*dd], K then V) and only the LAST
+ * position goes through the output projection: logits_last [nb,V].
+ * emoasr_bert_lm_infer: TransformerLM.predict (lm/modeling/transformer.py:62-77 over the BERT-style stack,
+ * modeling_bert.py:159-303,360-436): log-softmax of the next-token logits at position L-1, f32 [nb,V].
+ * `ws`: scratch of at least emoasr_decode_ws_bytes(...) bytes. */
+typedef struct emoasr_lin { const void* w; const float* b; } emoasr_lin_t;   /* weight (compute dtype), bias f32 */
+typedef struct emoasr_lnp { const float *g, *b; } emoasr_lnp_t;
+typedef struct emoasr_decoder_layer {
+  emoasr_lnp_t ln1, ln2, ln3;
+  emoasr_lin_t qkv, out;        /* self-attention: fused [3dd,dd] projection, output */
+  emoasr_lin_t q2, out2;        /* source attention (K / V come from the cache) */
+  emoasr_lin_t w1, w2;          /* feed-forward [F,dd], [dd,F] */
+} emoasr_decoder_layer_t;
+typedef struct emoasr_decoder_infer {
+  int nb, L, T, dd, H, F, V;
+  const int* ids;               /* int32 [nb,L] */
+  const void* embed; const float* pe; float emb_scale;   /* token table [V,dd], abs. position table f32 [>=L,dd] */
+  const int *kself, *kmem;      /* int32 [nb]: valid prefix length (= L), valid memory frames */
+  const void* const* kv;        /* nl pointers */
+  emoasr_lnp_t ln_out; emoasr_lin_t out;
+  void* logits_last;
+  void* ws; size_t ws_bytes;
+} emoasr_decoder_infer_t;
+typedef struct emoasr_bert_layer {
+  emoasr_lin_t qkv, attn_out; emoasr_lnp_t ln_attn;
+  emoasr_lin_t inter, out; emoasr_lnp_t ln_out;
+} emoasr_bert_layer_t;
+typedef struct emoasr_bert_infer {
+  int nb, L, d, H, F, V;
+  const int* ids; const void* word_emb; const float* pe;  /* pe = position + token-type-0 embeddings, f32 [>=L,d] */
+  emoasr_lnp_t ln_emb;
+  const int* klens;
+  emoasr_lin_t transform; emoasr_lnp_t ln_transform; const float* out_bias;
+  float* logp;
+  void* ws; size_t ws_bytes;
+} emoasr_bert_infer_t;
+size_t emoasr_decode_ws_bytes(int dtype, int nb, int L, int d, int H, int F, int V);
+int emoasr_transformer_decoder_infer(int dtype, int nl, const emoasr_decoder_layer_t* layers,
+                                     const emoasr_decoder_infer_t* io, void* stream);
+int emoasr_bert_lm_infer(int dtype, int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_infer_t* io,
+                         void* stream);
 
 /* ---- optimizer (asr/train_asr.py:84-92, torch.optim.Adam semantics) ---------- */
 /* out[0] += sum x^2 */
