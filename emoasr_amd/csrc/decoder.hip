@@ -185,40 +185,75 @@ __device__ __forceinline__ float np_logaddexp(float a, float b) {
   return d > 0.f ? a + log1pf(expf(-d)) : b + log1pf(expf(d));
 }
 
-// One block per beam m, one thread per candidate c.  x: CTC log-probs [T, V].
+// One wave per (beam m, candidate c).  x: CTC log-probs [T, V].
 // r_prev: the parent's state [T,2]: prev_states + (parent[m]*cw_prev + pcand[m]) * T*2, or init_state
 // when prev_states == NULL.  Outputs log_psi [nb, cw] and states [nb, cw, T, 2].
-__global__ void ctc_prefix_kernel(int Tn, int V, int cw, const float* __restrict__ x,
-                                  const float* __restrict__ prev_states, int cw_prev,
-                                  const int* __restrict__ parent, const int* __restrict__ pcand,
-                                  const float* __restrict__ init_state, const int* __restrict__ last,
-                                  const int* __restrict__ out_len, const int* __restrict__ cands, int blank,
-                                  int eos, float* __restrict__ log_psi, float* __restrict__ states) {
-  const int m = blockIdx.x, c = threadIdx.x;
-  if (c >= cw) return;
+// The recursion over t is sequential (and kept in the reference's float32 operation order: ctc_score.py:47-76),
+// but everything it consumes is not: per chunk of 64 frames the lanes fetch the parent state and the two
+// emission columns (one memory round trip per chunk instead of four per frame) and compute phi; lane 0 then
+// runs the 64 dependent steps out of LDS and the lanes write the new state rows back coalesced.
+__global__ __launch_bounds__(64) void ctc_prefix_kernel(int Tn, int V, int cw, const float* __restrict__ x,
+                                                        const float* __restrict__ prev_states, int cw_prev,
+                                                        const int* __restrict__ parent, const int* __restrict__ pcand,
+                                                        const float* __restrict__ init_state,
+                                                        const int* __restrict__ last, const int* __restrict__ out_len,
+                                                        const int* __restrict__ cands, int blank, int eos,
+                                                        float* __restrict__ log_psi, float* __restrict__ states) {
+  __shared__ float s_phi[64], s_x[64], s_xb[64], s_rn[64], s_rb[64];
+  const int m = blockIdx.x / cw, c = blockIdx.x % cw, lane = threadIdx.x;
   const float* rp = prev_states ? prev_states + ((long)parent[m] * cw_prev + pcand[m]) * Tn * 2 : init_state;
   const int tok = cands[m * cw + c];
   const int olen = out_len[m];
   const bool same = olen > 0 && tok == last[m];
   float* r = states + ((long)m * cw + c) * Tn * 2;
-  for (int t = 0; t < Tn; ++t) { r[2 * t] = EMO_LOG0; r[2 * t + 1] = EMO_LOG0; }
-  if (olen == 0) r[0] = x[tok];
   const int start = olen > 1 ? olen : 1;
-  float rn = r[2 * (start - 1)], rb = r[2 * (start - 1) + 1];
-  float psi = rn;
-  for (int t = start; t < Tn; ++t) {
-    const float pn = rp[2 * (t - 1)], pb = rp[2 * (t - 1) + 1];
-    const float phi = same ? pb : np_logaddexp(pn, pb);
-    const float xt = x[(long)t * V + tok];
-    const float nn = np_logaddexp(rn, phi) + xt;
-    const float nb_ = np_logaddexp(rn, rb) + x[(long)t * V + blank];
-    psi = np_logaddexp(psi, phi + xt);
-    rn = nn; rb = nb_;
-    r[2 * t] = rn; r[2 * t + 1] = rb;
+  // rows before `start` keep their initial value: LOG_0, except r[0][0] = x[0][tok] for an empty prefix
+  for (int t = lane; t < start && t < Tn; t += 64) {
+    r[2 * t] = (t == 0 && olen == 0) ? x[tok] : EMO_LOG0;
+    r[2 * t + 1] = EMO_LOG0;
   }
-  if (tok == eos) psi = np_logaddexp(rp[2 * (Tn - 1)], rp[2 * (Tn - 1) + 1]);
-  if (tok == blank) psi = EMO_LOG0;
-  log_psi[m * cw + c] = psi;
+  // The three recursions have one shape, v <- logaddexp(v, a_t) + b_t:
+  //   lane 0: r^n   a = phi_t            b = x_t[tok]
+  //   lane 1: psi   a = phi_t + x_t[tok] b = 0
+  //   lane 2: r^b   a = r^n_{t-1}        b = x_t[blank]     (a comes from lane 0, one step behind)
+  // so lanes 0..2 run them in lockstep: one logaddexp per frame on the critical path instead of three.
+  const float v0 = (start == 1 && olen == 0) ? x[tok] : EMO_LOG0;
+  float v = lane == 2 ? EMO_LOG0 : v0;  // rn = psi = v0, rb = LOG_0
+  for (int t0 = start; t0 < Tn; t0 += 64) {
+    const int t = t0 + lane;
+    if (t < Tn) {
+      const float pn = rp[2 * (t - 1)], pb = rp[2 * (t - 1) + 1];
+      s_phi[lane] = same ? pb : np_logaddexp(pn, pb);
+      s_x[lane] = x[(long)t * V + tok];
+      s_xb[lane] = x[(long)t * V + blank];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int n = min(64, Tn - t0);
+    for (int i = 0; i < n; ++i) {
+      const float rn_prev = __shfl(v, 0, 64);
+      const float phi = s_phi[i], xt = s_x[i];
+      const float a = lane == 0 ? phi : (lane == 1 ? phi + xt : rn_prev);
+      const float bb = lane == 0 ? xt : (lane == 1 ? 0.f : s_xb[i]);
+      if (lane < 3) {
+        // same formula as np_logaddexp with the hardware exp / log (v_exp_f32, v_log_f32): |error| < 1e-7 in
+        // absolute terms per step against scores of magnitude 10..100 (the library expf / log1pf pair is ~4x
+        // the latency of this loop's critical path)
+        const float d = v - a;
+        v = (d > 0.f ? v + __logf(1.f + __expf(-d)) : a + __logf(1.f + __expf(d))) + bb;
+      }
+      if (lane == 0) s_rn[i] = v;
+      if (lane == 2) s_rb[i] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (t < Tn) { r[2 * t] = s_rn[lane]; r[2 * t + 1] = s_rb[lane]; }
+    __builtin_amdgcn_wave_barrier();
+  }
+  float psi = __shfl(v, 1, 64);
+  if (lane == 0) {
+    if (tok == eos) psi = np_logaddexp(rp[2 * (Tn - 1)], rp[2 * (Tn - 1) + 1]);
+    if (tok == blank) psi = EMO_LOG0;
+    log_psi[m * cw + c] = psi;
+  }
 }
 
 // initial state: r[t,1] = running sum of the blank log-probs (float32, step by step), r[t,0] = LOG_0
@@ -269,7 +304,7 @@ extern "C" int emoasr_ctc_prefix_score(int nb, int T, int V, int cw, const float
   if (nb == 0) return 0;
   EMO_CHECK(cw >= 1 && cw <= 1024, "ctc_prefix_score: cw=%d", cw);
   EMO_CHECK(prev_states || init_state, "ctc_prefix_score: no previous state");
-  ctc_prefix_kernel<<<nb, cdiv(cw, 64) * 64, 0, (hipStream_t)stream>>>(T, V, cw, x, prev_states, cw_prev, parent, pcand,
+  ctc_prefix_kernel<<<nb * cw, 64, 0, (hipStream_t)stream>>>(T, V, cw, x, prev_states, cw_prev, parent, pcand,
                                                                      init_state, last, out_len, cands, blank, eos,
                                                                      log_psi, states);
   EMO_LAUNCH_CHECK();

@@ -51,6 +51,11 @@ def joint_beam_search(dec, eouts, elens, beam_width, len_weight=0, lm=None, lm_w
                 lmrt = getattr(lm, "_step_rt", None)
                 if lmrt is None:
                     lmrt = lm._step_rt = LMStepRuntime(lm)
+        side = None
+        if lmrt is not None and os.environ.get("EMOASR_DECODE_STREAMS", "1") != "0":
+            side = getattr(eng, "_lm_stream", None)
+            if side is None:
+                side = eng._lm_stream = torch.cuda.Stream(device=dev)
         beams = [dict(hyp=[eos], score=0.0, score_ctc=np.float32(0.0), parent=0, pcand=0)]
         prev_states = None
         results = []
@@ -58,9 +63,21 @@ def joint_beam_search(dec, eouts, elens, beam_width, len_weight=0, lm=None, lm_w
             nb = len(beams)
             ys_in = torch.tensor([b["hyp"] for b in beams], dtype=torch.int64)
             if rt is not None:
-                with ops.stream_scope():
-                    last = rt.step(ys_in)                                            # [nb, V]
-                    lm_lp = (lmrt.step(ys_in) if lmrt is not None else lm.predict_device(ys_in, [i + 1] * nb)) if use_lm else None
+                if lmrt is not None and side is not None:
+                    # the LM and the decoder are independent chains of ~90 small kernels each: run the LM on a
+                    # second stream so the two chains overlap (both are bound by the per-kernel dispatch floor)
+                    main = torch.cuda.current_stream()
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side), ops.stream_scope():
+                        lm_lp = lmrt.step(ys_in)
+                    with ops.stream_scope():
+                        last = rt.step(ys_in)                                        # [nb, V]
+                    main.wait_stream(side)
+                    lm_lp.record_stream(main)
+                else:
+                    with ops.stream_scope():
+                        last = rt.step(ys_in)
+                        lm_lp = (lmrt.step(ys_in) if lmrt is not None else lm.predict_device(ys_in, [i + 1] * nb)) if use_lm else None
             else:
                 mem = eouts.expand(nb, T, eouts.shape[2]).contiguous()
                 el = h2d_i32([T] * nb, dev)
