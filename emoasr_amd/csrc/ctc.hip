@@ -153,13 +153,28 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(int Tn, int V, int S, int
   const long row = (long)b * Tn + t;
   T* g = grad + row * ldg;
   const float nl = nll[b];
+  const bool vec = (V % 8 == 0) && (ld % 8 == 0) && (ldg % 8 == 0);  // 16-byte row accesses
   if (t >= elens[b] || !isfinite(nl)) {
-    for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(0.f);
+    if (vec) {
+      float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int v = threadIdx.x * 8; v < V; v += 2048) store8<T>(g + v, z);
+    } else {
+      for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(0.f);
+    }
     return;
   }
   const float l = lse[row];
   const T* lg = logits + row * ld;
-  for (int v = threadIdx.x; v < V; v += 256) rowbuf[v] = __expf(to_f32(lg[v]) - l);
+  if (vec) {
+    for (int v = threadIdx.x * 8; v < V; v += 2048) {
+      float x[8];
+      load8<T>(lg + v, x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rowbuf[v + e] = __expf(x[e] - l);
+    }
+  } else {
+    for (int v = threadIdx.x; v < V; v += 256) rowbuf[v] = __expf(to_f32(lg[v]) - l);
+  }
   __syncthreads();
   const int Sb = 2 * ylens[b] + 1;
   const int* lab = labels + (long)b * Lmax;
@@ -170,7 +185,16 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(int Tn, int V, int S, int
   }
   __syncthreads();
   const float gs = gscale_dev ? gscale * gscale_dev[0] : gscale;
-  for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(rowbuf[v] * gs);
+  if (vec) {
+    for (int v = threadIdx.x * 8; v < V; v += 2048) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = rowbuf[v + e] * gs;
+      store8<T>(g + v, x);
+    }
+  } else {
+    for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(rowbuf[v] * gs);
+  }
 }
 
 template <typename T>
