@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(int Tn, int F, int T1, i
 // One atomic per (block, output): large row chunks keep the same-address contention low.
 constexpr int C1_TROWS = 64;
 constexpr int C1_SUB = 8;
+constexpr int C1_FJ = 8;   // f1 positions per lane (8 lanes stride 8): F1 <= 64
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int Tn, int F, int T1, int F1, int C,
                                                           const float* __restrict__ x,
@@ -71,11 +72,38 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int Tn, int F, int T1,
     __syncthreads();
     for (int i = threadIdx.x; i < (2 * nt + 1) * F; i += 256) rows[i] = xb[i];
     __syncthreads();
+    // all loads of one t1 row (up to C1_FJ f1 positions per lane) are issued before the first is used, and
+    // the next row's are issued before this row is multiplied: with one wave per SIMD an un-pipelined loop
+    // paid a full memory round trip per 16-byte load (~300 of them per thread)
+    constexpr int NV = 8 * (int)sizeof(T) / 16;  // 16-byte pieces per 8 channels (1 for bf16, 2 for f32)
+    Vec16<T> dn[C1_FJ][NV];
+    auto fetch_row = [&](int tt) {
+#pragma unroll
+      for (int j = 0; j < C1_FJ; ++j) {
+        const int f1 = fl + 8 * j;
+        const bool ok = cok && tt < nt && f1 < F1;
+        const long eo = ((long)(ts + tt) * F1 + f1) * C + c;
+#pragma unroll
+        for (int p = 0; p < NV; ++p)
+          dn[j][p] = buf_load16<T>(rsd, ok ? (unsigned)((eo * sizeof(T)) + 16 * p) : EMO_OOB);
+      }
+    };
+    fetch_row(0);
     for (int tt = 0; tt < nt; ++tt) {
       const float* r0 = rows + 2 * tt * F;
-      for (int f1 = fl; f1 < F1; f1 += 8) {
+      Vec16<T> dc[C1_FJ][NV];
+#pragma unroll
+      for (int j = 0; j < C1_FJ; ++j)
+#pragma unroll
+        for (int p = 0; p < NV; ++p) dc[j][p] = dn[j][p];
+      fetch_row(tt + 1);
+#pragma unroll
+      for (int j = 0; j < C1_FJ; ++j) {
+        const int f1 = fl + 8 * j;
+        if (f1 >= F1) break;
         float d[8];
-        buf_load8<T>(rsd, ((long)(ts + tt) * F1 + f1) * C + c, cok, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = dc[j][e / Vec16<T>::N].get(e % Vec16<T>::N);
         float xv[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
@@ -85,7 +113,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int Tn, int F, int T1,
         for (int e = 0; e < 8; ++e) {
           sb[e] += d[e];
 #pragma unroll
-          for (int j = 0; j < 9; ++j) acc[j][e] += d[e] * xv[j];
+          for (int q = 0; q < 9; ++q) acc[q][e] += d[e] * xv[q];
         }
       }
     }
@@ -177,6 +205,7 @@ extern "C" int emoasr_conv1_wgrad(int dtype, int B, int Tn, int F, int C, const 
   }
   if (B == 0) return 0;
   EMO_CHECK(C % 8 == 0, "conv1_wgrad: C must be a multiple of 8");
+  EMO_CHECK(F1 <= 8 * C1_FJ, "conv1_wgrad: F1=%d > %d", F1, 8 * C1_FJ);
   const int nchunk = cdiv(T1, C1_TROWS);
   dim3 grid(B * nchunk, cdiv(C, 256));
   EMO_DISPATCH(dtype, (conv1_wgrad_kernel<T><<<grid, 256, (2 * C1_SUB + 1) * F * sizeof(float), s>>>(
