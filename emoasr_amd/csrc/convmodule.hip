@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(long n, int C, const 
 // rows r0 + lane_row + 8*it.  Pass 1 writes per-block partial sums [block][2][C] (no atomics, no
 // zeroing); pass 2 first folds the few partial rows for its channels (block-cooperatively through
 // LDS), then applies.
-constexpr int BN_SUM_ROWS = 128;  // rows per block of pass 1 (-> M/128 partial rows)
+constexpr int BN_SUM_ROWS = 64;  // rows per block of pass 1 (-> M/64 partial rows; 128: fewer, slower blocks; 32: pass 2 folds too many)
 constexpr int BN_APPLY_ROWS = 32; // rows per block of pass 2
 
 // pass 1: part[blk][c] = sum dbn, part[blk][C+c] = sum dbn*xhat   with dbn = dz * swish'(bn)

@@ -410,7 +410,7 @@ def bn_swish_fwd(y, mean, var, gamma, beta, eps):
 def bn_swish_bwd(dz, y, mean, var, gamma, beta, eps, dgamma, dbeta):
     M, C, ld = _rows(_chk(y))
     dy = torch.empty_like(y)
-    scratch = torch.empty((M + 127) // 128 * 2 * C, device=y.device, dtype=torch.float32)  # emoasr_bn_swish_bwd_scratch_floats
+    scratch = torch.empty((M + 63) // 64 * 2 * C, device=y.device, dtype=torch.float32)  # emoasr_bn_swish_bwd_scratch_floats
     lib.call("emoasr_bn_swish_bwd", dt(y), M, C, _p(dz), _p(y), _p(mean), _p(var), _p(gamma), _p(beta), eps,
              _p(dy), _p(dgamma), _p(dbeta), _p(scratch), _stream())
     return dy

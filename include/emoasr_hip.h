@@ -233,7 +233,7 @@ int emoasr_bn_swish_fwd(int dtype, int M, int C, const void* y, const float* mea
                         const float* gamma, const float* beta, float eps, void* z, void* stream);
 /* training-mode backward (batch statistics): dy from dz; dgamma/dbeta (+)=.  C % 8 == 0.
  * scratch: emoasr_bn_swish_bwd_scratch_floats(M, C) floats of per-block partial sums
- * (ceil(M/128) x 2 x C); needs no initialisation. */
+ * (ceil(M/64) x 2 x C); needs no initialisation. */
 long emoasr_bn_swish_bwd_scratch_floats(int M, int C);
 int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, const void* y, const float* mean,
                         const float* var, const float* gamma, const float* beta, float eps, void* dy,
