@@ -523,15 +523,15 @@ struct TnGroup {
   int start[EMOASR_TN_GROUP_MAX + 1];
   TnArgs p[EMOASR_TN_GROUP_MAX];
 };
-template <typename T, bool TR, int KB>
+template <typename T, bool TR, int KB, int BT>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup G) {
   const int bid = xcd_remap(blockIdx.x, gridDim.x);  // see gemm_tn_kernel
   int p = 0;
   while (p + 1 < G.n && bid >= G.start[p + 1]) ++p;
   const TnArgs& g = G.p[p];
   const int local = bid - G.start[p];
-  const int tx = (g.N2 + 63) / 64, ty = (g.N1 + 63) / 64;
-  tn_block<T, 64, 64, 0, TR, KB>(g, local % tx, (local / tx) % ty, local / (tx * ty));
+  const int tx = (g.N2 + BT - 1) / BT, ty = (g.N1 + BT - 1) / BT;
+  tn_block<T, BT, BT, 0, TR, KB>(g, local % tx, (local / tx) % ty, local / (tx * ty));
 }
 
 template <typename T, int AMODE, bool BKM, bool TR>
@@ -691,13 +691,18 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   TnGroup G{};
   G.n = n;
   long tiles = 0;
+  // 128x128 tiles (16 MFMAs per wave and k step instead of 4) when every product is at least that large
+  int bt = 128;
+  for (int i = 0; i < n; ++i)
+    if (probs[i].N1 < 128 || probs[i].N2 < 128) bt = 64;
+  if (g_gemm_tile == 3) bt = 64;
   for (int i = 0; i < n; ++i) {
     const emoasr_tn_problem_t& q = probs[i];
     EMO_CHECK(q.N1 > 0 && q.N2 > 0 && q.K > 0, "gemm_tn_grouped: empty problem %d", i);
     if (check_vec(q.lda, dtype, "lda") || check_vec(q.ldb, dtype, "ldb") || check_vec(q.N2, dtype, "N2")) return 1;
     EMO_CHECK(q.N1 % (dtype == EMO_BF16 ? 8 : 4) == 0 || q.lda >= (q.N1 + 7) / 8 * 8,
               "gemm_tn_grouped: ragged N1 needs padded lda");
-    tiles += (long)cdiv(q.N1, 64) * cdiv(q.N2, 64);
+    tiles += (long)cdiv(q.N1, bt) * cdiv(q.N2, bt);
   }
   // one split factor for the whole group: ~3 blocks per CU over all problems, at least 4 k-tiles per
   // slice, and per problem no more f32 atomic traffic than ~8 MB (see launch_tn)
@@ -714,15 +719,21 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
     a.k_tiles_per_split = cdiv(nk, splits);
     splits = cdiv(nk, a.k_tiles_per_split);
     G.start[i] = start;
-    start += cdiv(q.N1, 64) * cdiv(q.N2, 64) * splits;
+    start += cdiv(q.N1, bt) * cdiv(q.N2, bt) * splits;
   }
   G.start[n] = start;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == EMO_BF16) {
-    if (g_tr_read) gemm_tn_grouped_kernel<bf16, true, 2><<<start, 256, 0, s>>>(G);
-    else gemm_tn_grouped_kernel<bf16, false, 2><<<start, 256, 0, s>>>(G);
+    if (bt == 128) {
+      if (g_tr_read) gemm_tn_grouped_kernel<bf16, true, 2, 128><<<start, 256, 0, s>>>(G);
+      else gemm_tn_grouped_kernel<bf16, false, 2, 128><<<start, 256, 0, s>>>(G);
+    } else {
+      if (g_tr_read) gemm_tn_grouped_kernel<bf16, true, 2, 64><<<start, 256, 0, s>>>(G);
+      else gemm_tn_grouped_kernel<bf16, false, 2, 64><<<start, 256, 0, s>>>(G);
+    }
   } else if (dtype == EMO_F32) {
-    gemm_tn_grouped_kernel<float, true, 1><<<start, 256, 0, s>>>(G);
+    if (bt == 128) gemm_tn_grouped_kernel<float, true, 1, 128><<<start, 256, 0, s>>>(G);
+    else gemm_tn_grouped_kernel<float, true, 1, 64><<<start, 256, 0, s>>>(G);
   } else {
     emo_set_error("bad dtype %d", dtype);
     return 1;
