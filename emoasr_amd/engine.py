@@ -977,6 +977,85 @@ class _RNNTMixin:
             return hyps, aligns
 
 
+    def rnnt_beam_search(self, eouts, beam_width, blank, eos, num_expands=3):
+        """alignment-length synchronous beam search for ONE utterance (rnn_transducer.py:242-325,348-359).
+
+        eouts [1,T,d].  Per frame up to `num_expands` rounds; each round is one batched prediction-network
+        step over the live hypotheses (every hypothesis keeps the LSTM state from before its last label, as
+        the reference does), one joint + output GEMM, log-softmax and top-k on the device, and ONE D2H of
+        (blank score, k scores, k ids) per live hypothesis; bookkeeping (stable sort by float64 score, merge
+        of equal label sequences by log-add, cut to the beam) stays on the host like the reference.
+        Returns the surviving label sequences best-first, including the leading <sos>."""
+        import numpy as np
+        with ops.stream_scope(), torch.no_grad():
+            A, J, H, nl = self.arena, self.r_J, self.r_H, self.r_nl
+            A.refresh_shadow()
+            dev = eouts.device
+            T = eouts.shape[1]
+            e_all = ops.gemm_nt(eouts[0], A.w("decoder.w_enc.weight"), bias=A.p("decoder.w_enc.bias"))  # [T,J]
+            cdt = e_all.dtype
+            zero = ([torch.zeros(1, H, device=dev, dtype=cdt) for _ in range(nl)],
+                    [torch.zeros(1, H, device=dev, dtype=torch.float32) for _ in range(nl)])
+            beams = [([eos], 0.0, (zero, 0))]  # (hyp, score, (state tensors, row))
+
+            def merge(cands):
+                seen = {}
+                for hyp, score, st in cands:
+                    key = tuple(hyp)
+                    if key in seen:
+                        seen[key][1] = float(np.logaddexp(seen[key][1], score))
+                    else:
+                        seen[key] = [hyp, score, st]
+                return [tuple(c) for c in seen.values()]
+
+            def gather(live):
+                srcs = {id(st[0]): st[0] for _, _, st in live}
+                if len(srcs) == 1:
+                    (hs, cs), = srcs.values()
+                    rows = [st[1] for _, _, st in live]
+                    if rows == list(range(hs[0].shape[0])):
+                        return hs, cs
+                    ix = torch.tensor(rows, device=dev)
+                    return [h.index_select(0, ix) for h in hs], [c.index_select(0, ix) for c in cs]
+                hs = [torch.cat([st[0][0][l][st[1]:st[1] + 1] for _, _, st in live]) for l in range(nl)]
+                cs = [torch.cat([st[0][1][l][st[1]:st[1] + 1] for _, _, st in live]) for l in range(nl)]
+                return hs, cs
+
+            for t in range(T):
+                frame_out, live = [], beams
+                for v in range(num_expands):
+                    nb = len(live)
+                    if nb == 0:
+                        break
+                    prev = gather(live)
+                    ids = h2d_i32([[hyp[-1] for hyp, _, _ in live]], dev)  # [1,nb]
+                    dout, (nh, nc), _ = self.rnnt_recurrency(ids, prev, False, False)
+                    g = ops.gemm_nt(dout.view(nb, H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
+                    h = ops.joint_tanh(e_all[t].view(1, 1, J), g.view(1, nb, J))
+                    logits = ops.gemm_nt(h.view(nb, J), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
+                    lp = ops.log_softmax(logits)
+                    last = v == num_expands - 1
+                    if last:
+                        host = lp[:, blank].cpu().double().numpy().reshape(nb, 1)
+                    else:
+                        vals, idx, _ = ops.topk(lp[:, 1:], beam_width)
+                        host = torch.cat([lp[:, blank:blank + 1], vals, idx.to(torch.float32)], 1).cpu().double().numpy()
+                    for i, (hyp, score, st) in enumerate(live):
+                        frame_out.append((hyp, score + float(host[i, 0]), st))
+                    grown = []
+                    if not last:
+                        after = (nh, nc)
+                        for i, (hyp, score, st) in enumerate(live):
+                            for k in range(beam_width):
+                                grown.append((hyp + [int(host[i, 1 + beam_width + k]) + 1],
+                                              score + float(host[i, 1 + k]), (after, i)))
+                    grown.sort(key=lambda c: -c[1])
+                    live = merge(grown)[:beam_width]
+                frame_out.sort(key=lambda c: -c[1])
+                beams = merge(frame_out)[:beam_width]
+            return [hyp for hyp, _, _ in beams]
+
+
 for _n, _f in list(vars(_RNNTMixin).items()):
     if not _n.startswith("__"):
         setattr(CTCEngine, _n, _f)

@@ -4,12 +4,14 @@
     decoder.decode(eouts, elens, beam_width=1, ...)              -> (hyps, None, None, None)
 
 The transducer loss is the HIP lattice kernel (`emoasr_rnnt_forward/_grad`) -- the reference calls the
-third-party warp_rnnt package here (rnn_transducer.py:106-115).  Only greedy decoding (beam_width <= 1)
-is on the path; like the reference, decode() discards scores/logits/aligns (:339-346).
+third-party warp_rnnt package here (rnn_transducer.py:106-115).  beam_width <= 1: time-synchronous greedy
+search; > 1: alignment-length synchronous beam search (:242-325, batch size 1, hypotheses keep the leading
+<sos>, LM arguments unused -- all as in the reference).  Like the reference, decode() discards
+scores/logits/aligns (:339-346).
 """
 import torch.nn as nn
 
-from ..functions import rnnt_apply, rnnt_greedy_apply
+from ..functions import rnnt_apply, rnnt_beam_apply, rnnt_greedy_apply
 from .ctc import CTCDecoder
 
 
@@ -50,7 +52,7 @@ class RNNTDecoder(nn.Module):
     def decode(self, eouts, elens, eouts_inter=None, beam_width=1, len_weight=0, lm=None, lm_weight=0,
                decode_ctc_weight=0, decode_phone=False):
         if beam_width > 1:
-            raise NotImplementedError("emoasr_amd: RNN-T beam search (ALSD) is scheduled after the greedy path")
+            return self._beam_search(eouts, elens, beam_width, len_weight, lm, lm_weight), None, None, None
         if decode_ctc_weight == 1:
             self.ctc._owner = self._owner
             return self.ctc.decode(eouts, elens, beam_width=1)
@@ -60,3 +62,7 @@ class RNNTDecoder(nn.Module):
     def _greedy(self, eouts, elens, decode_ctc_weight=0):
         hyps, aligns = rnnt_greedy_apply(self, eouts, elens)
         return hyps, [None] * len(hyps), None, aligns
+
+    def _beam_search(self, eouts, elens, beam_width=1, len_weight=0, lm=None, lm_weight=0):
+        assert eouts.size(0) == 1  # rnn_transducer.py:251
+        return rnnt_beam_apply(self, eouts, beam_width)

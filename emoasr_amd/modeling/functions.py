@@ -201,3 +201,7 @@ def rnnt_apply(dec, eouts, elens, ys, ylens, ys_in):
 def rnnt_greedy_apply(dec, eouts, elens):
     eng = _engine_of(dec)
     return eng.rnnt_greedy(eouts, _host_list(elens), dec.blank_id, dec.eos_id, dec.max_seq_len)
+
+
+def rnnt_beam_apply(dec, eouts, beam_width):
+    return _engine_of(dec).rnnt_beam_search(eouts, beam_width, dec.blank_id, dec.eos_id)

@@ -13,6 +13,7 @@ tests/test_oracle_rnnt.py; everything around the loss (LSTM, joint, auxiliary CT
 pinned to the reference by tests/golden/l4_tiny.npz, generated with this function plugged in as
 `warp_rnnt.rnnt_loss`.
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -123,3 +124,55 @@ def rnnt_greedy(sd, cfg, eouts, elens, prefix="decoder", max_seq_len=256):
         hyps.append(hyp)
         aligns.append(align)
     return hyps, aligns
+
+
+def _merge_same_hyp(cands):
+    """rnn_transducer.py:348-359: candidates (already sorted best-first) with the same label sequence are
+    folded into the first one, whose score becomes the log-sum of the scores; order of first occurrence."""
+    seen = {}
+    for c in cands:
+        key = tuple(c["hyp"])
+        if key in seen:
+            seen[key]["score"] = float(np.logaddexp(seen[key]["score"], c["score"]))
+        else:
+            seen[key] = c
+    return list(seen.values())
+
+
+def rnnt_beam_search(sd, cfg, eouts, beam_width, prefix="decoder", num_expands=3):
+    """alignment-length synchronous decoding, one utterance (rnn_transducer.py:242-325).
+
+    Every hypothesis carries the LSTM state from BEFORE its last label was consumed (blank extensions keep
+    it, :290-294), so each expansion re-runs the prediction network on `hyp[-1]`.  Per frame: up to
+    `num_expands` rounds; a round extends every live hypothesis by blank (collected for the next frame) and,
+    except in the last round, by its `beam_width` best non-blank labels (:301-312); after each round and
+    after each frame the candidates are sorted by score (stable), merged by label sequence and cut to
+    `beam_width`.  Returns the surviving label sequences, INCLUDING the leading <sos> (= eos id), best first.
+    """
+    n, H = cfg.dec_num_layers, cfg.dec_hidden_size
+    zero = (torch.zeros(n, 1, H), torch.zeros(n, 1, H))
+    beams = [dict(hyp=[cfg.eos_id], score=0.0, state=zero)]
+    for t in range(eouts.shape[1]):
+        frame_out, live = [], beams
+        for v in range(num_expands):
+            ys = torch.tensor([[b["hyp"][-1]] for b in live])
+            prev = (torch.cat([b["state"][0] for b in live], 1), torch.cat([b["state"][1] for b in live], 1))
+            douts, (hs, cs) = recurrency(sd, cfg, ys, prev, prefix)
+            lp = torch.log_softmax(joint(sd, eouts[:, t:t + 1], douts, prefix)[:, 0, 0], -1)
+            for i, b in enumerate(live):
+                frame_out.append(dict(hyp=b["hyp"], score=b["score"] + lp[i, cfg.blank_id].item(), state=b["state"]))
+            grown = []
+            if v < num_expands - 1:
+                for i, b in enumerate(live):
+                    top, idx = torch.topk(lp[i, 1:], beam_width)
+                    after = (hs[:, i:i + 1], cs[:, i:i + 1])
+                    for k in range(beam_width):
+                        grown.append(dict(hyp=b["hyp"] + [int(idx[k]) + 1], score=b["score"] + top[k].item(),
+                                          state=after))
+            grown.sort(key=lambda c: -c["score"])
+            live = _merge_same_hyp(grown)[:beam_width]
+            if not live:
+                break
+        frame_out.sort(key=lambda c: -c["score"])
+        beams = _merge_same_hyp(frame_out)[:beam_width]
+    return [b["hyp"] for b in beams]

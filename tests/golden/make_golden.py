@@ -325,6 +325,34 @@ def run_hostio():
     print("hostio:", len(wer_cases), "wer,", len(sw_cases), "subword,", len(pack_cases), "packing cases")
 
 
+RNNT_BEAM_WIDTHS = [2, 4]
+
+
+def run_rnnt_beam():
+    """RNN-T alignment-length synchronous beam search (rnn_transducer.py:242-325) on the fitted l4_tiny
+    weights, one utterance at a time (the reference asserts batch size 1) -> rnntbeam_tiny.npz."""
+    g = np.load(os.path.join(OUT, "l4_tiny.npz"))
+    model = ASR(make_params(L4), phase="test")
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")})
+    model.eval()
+    xs, xlens = torch.from_numpy(g["xs"]), torch.from_numpy(g["xlens"])
+    out = {}
+    with torch.no_grad():
+        for bw in RNNT_BEAM_WIDTHS:
+            flat, lens, nhyp = [], [], []
+            for b in range(xs.shape[0]):
+                hyps, _, _, _ = model.decode(xs[b:b + 1, :int(xlens[b])], xlens[b:b + 1], beam_width=bw)
+                nhyp.append(len(hyps))
+                for h in hyps:
+                    lens.append(len(h))
+                    flat += [int(v) for v in h]
+            out[f"bw{bw}/n_hyps"] = np.array(nhyp)
+            out[f"bw{bw}/hyp_lens"] = np.array(lens)
+            out[f"bw{bw}/hyps"] = np.array(flat, dtype=np.int64)
+            print("rnnt beam", bw, "n_hyps", nhyp, "first hyp lens", lens[:4])
+    np.savez_compressed(os.path.join(OUT, "rnntbeam_tiny.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ctc", "l3", "l4"]
     if "ctc" in which:
@@ -336,5 +364,7 @@ if __name__ == "__main__":
         run_l4()
     if "hostio" in which:
         run_hostio()
+    if "rnntbeam" in which:  # needs l4_tiny.npz (reads its weights)
+        run_rnnt_beam()
     if "ctcbeam" in which:  # needs l2_tiny.npz and l3_tiny.npz (reads their weights)
         run_ctc_beam()

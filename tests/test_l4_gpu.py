@@ -80,6 +80,23 @@ def test_greedy_decode_f32(dev):
     assert hyps2 == hyps and s2 is None and l2 is None and a2 is None  # decode() discards them (quirk 7)
 
 
+def test_beam_search_f32(dev):
+    """ALSD beam search (rnn_transducer.py:242-325): the same hypotheses, in the same order, as the
+    reference produced for the fitted l4_tiny weights (tests/golden/rnntbeam_tiny.npz)"""
+    from tests.util import RNNT_BEAM_WIDTHS, load_rnnt_beam_golden
+    model, g = _build(torch.float32, dev)
+    model.eval()
+    want = load_rnnt_beam_golden()
+    with torch.no_grad():
+        for b in range(g["xs"].shape[0]):
+            n = int(g["xlens"][b])
+            for bw in RNNT_BEAM_WIDTHS:
+                hyps, scores, logits, aligns = model.decode(g["xs"][b:b + 1, :n].to(dev), g["xlens"][b:b + 1],
+                                                            beam_width=bw)
+                assert hyps == want[bw][b], (b, bw, hyps, want[bw][b])
+                assert scores is None and logits is None and aligns is None
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_train_loss_and_grads(dev, dtype):
     model, g = _build(dtype, dev)

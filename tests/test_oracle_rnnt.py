@@ -85,3 +85,16 @@ def test_train_loss_and_grads():
     worst = max(((v.grad - g["grad/" + k]).abs().max() / max(g["grad/" + k].abs().max().item(), 1e-2 * gmax)).item()
                 for k, v in params.items())
     assert worst < 5e-3, worst
+
+
+def test_beam_search_pinned_to_reference():
+    """ALSD beam search (rnn_transducer.py:242-325): every surviving hypothesis, in order"""
+    from tests.util import RNNT_BEAM_WIDTHS, load_rnnt_beam_golden
+    cfg, sd, g = load_golden("l4_tiny")
+    want = load_rnnt_beam_golden()
+    with torch.no_grad():
+        for b in range(g["xs"].shape[0]):
+            n = int(g["xlens"][b])
+            eouts, _ = om.encoder_forward(sd, cfg, g["xs"][b:b + 1, :n], g["xlens"][b:b + 1])
+            for bw in RNNT_BEAM_WIDTHS:
+                assert orn.rnnt_beam_search(sd, cfg, eouts, bw) == want[bw][b], (b, bw)

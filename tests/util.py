@@ -69,3 +69,20 @@ def load_ctc_beam_golden():
         if k.startswith("sd_override/"):
             sd[k[len("sd_override/"):]] = v
     return cfg, sd, lm_state(g3), g2, gb
+
+
+RNNT_BEAM_WIDTHS = [2, 4]
+
+
+def load_rnnt_beam_golden():
+    """-> {beam_width: [per utterance: list of hyps (each incl. the leading <sos>)]}"""
+    g = np.load(os.path.join(GOLDEN, "rnntbeam_tiny.npz"))
+    out = {}
+    for bw in RNNT_BEAM_WIDTHS:
+        flat = split_ragged(g[f"bw{bw}/hyps"], g[f"bw{bw}/hyp_lens"])
+        per, k = [], 0
+        for n in g[f"bw{bw}/n_hyps"].tolist():
+            per.append(flat[k:k + n])
+            k += n
+        out[bw] = per
+    return out
