@@ -177,6 +177,10 @@ class CTCEngine(_DecoderMixinPlaceholder):
         self.nl = cfg.enc_num_layers
         self.conformer = cfg.encoder_type == "conformer"
         self.rel = _cfg(cfg, "pos_encode_type", "abs") == "rel"
+        # intermediate branch after layer `inter_layer` (encoders/transformer.py:75-82); 0 = none
+        inter_on = (_cfg(cfg, "mtl_inter_ctc_weight", 0) or 0) > 0 or (_cfg(cfg, "mtl_phone_ctc_weight", 0) or 0) > 0
+        self.inter_layer = int(cfg.inter_ctc_layer_id) if inter_on else 0
+        self.eouts_inter = None
         self.p_enc = float(_cfg(cfg, "dropout_enc_rate", 0.0))
         self.p_att = float(_cfg(cfg, "dropout_attn_rate", 0.0))
         self.dtype = compute_dtype
@@ -300,12 +304,23 @@ class CTCEngine(_DecoderMixinPlaceholder):
                 cur = self._layer_rt.forward(li, cur, B, T2, elens, pos_t, p_enc, p_att, training, self._keep)
                 if st is not None:
                     st.layers.append(cur)
+                if li + 1 == self.inter_layer:
+                    x_inter = cur.tv("y")
             x = cur.tv("y")
         else:
             for li in range(self.nl):
                 x, ls = self._layer_fwd(li, x, B, T2, elens, pos_t, p_enc, p_att, training)
                 if st is not None:
                     st.layers.append(ls)
+                if li + 1 == self.inter_layer:
+                    x_inter = x
+        # the intermediate branch goes through the SAME final LayerNorm (encoders/transformer.py:104-107)
+        self.eouts_inter = None
+        if self.inter_layer > 0:
+            ei, mi, ri = ops.layernorm_fwd(x_inter, A.p("encoder.norm.weight"), A.p("encoder.norm.bias"), 1e-12, stash)
+            self.eouts_inter = ei.view(B, T2, d)
+            if st is not None:
+                st.x_inter, st.int_mean, st.int_rstd = x_inter, mi, ri
         eouts, mean, rstd = ops.layernorm_fwd(x, A.p("encoder.norm.weight"), A.p("encoder.norm.bias"), 1e-12, stash)
         if st is not None:
             st.x_final, st.fin_mean, st.fin_rstd = x, mean, rstd
@@ -399,8 +414,13 @@ class CTCEngine(_DecoderMixinPlaceholder):
     def head_logits(self, eouts, head="decoder.output"):
         B, T, d = eouts.shape
         A = self.arena
-        logits = ops.gemm_nt(eouts.reshape(B * T, d), A.w(head + ".weight"), bias=A.p(head + ".bias"))
-        return logits.view(B, T, -1)
+        w = A.w(head + ".weight")
+        V = w.shape[0]
+        out = None
+        if V % 8:  # ragged vocabulary (phone heads): rows padded to the GEMMs' 16-byte leading-dimension rule
+            out = torch.empty(B * T, (V + 7) // 8 * 8, device=eouts.device, dtype=eouts.dtype)[:, :V]
+        logits = ops.gemm_nt(eouts.reshape(B * T, d), w, out=out, bias=A.p(head + ".bias"))
+        return logits.view(B, T, V)
 
     def ctc_loss(self, logits, elens, ys_host, ylens_host, blank, want_grad, gscale_over_b=None):
         """-> (loss 0-dim f32 tensor = sum_b nll_b / B with infeasible utterances zeroed, ctx)"""
@@ -578,20 +598,20 @@ class CTCEngine(_DecoderMixinPlaceholder):
         r = self._ln_bwd(dh, x, norm_name, mean, rstd, dx, nxt)
         return r if nxt is not None else r[0]
 
-    def backward(self, st, deouts):
-        """deouts: gradient w.r.t. encoder output [B,T',d] (compute dtype).  Accumulates into the
-        gradient arena (p.grad views)."""
+    def backward(self, st, deouts, deouts_inter=None):
+        """deouts: gradient w.r.t. encoder output [B,T',d] (compute dtype); deouts_inter: gradient w.r.t. the
+        intermediate branch (or None).  Accumulates into the gradient arena (p.grad views)."""
         self._defer_wgrads = self._group_wgrads
         try:
             with ops.stream_scope():
-                return self._backward(st, deouts)
+                return self._backward(st, deouts, deouts_inter)
         finally:
             self._defer_wgrads = False
             self._wq = []
             self._ln_deferred = []
             self._join_side()
 
-    def _backward(self, st, deouts):
+    def _backward(self, st, deouts, deouts_inter=None):
         A, d = self.arena, self.d
         A.attach_grads()
         B, T, M = st.B, st.T2, st.M
@@ -610,11 +630,17 @@ class CTCEngine(_DecoderMixinPlaceholder):
                 return (1.0, p, s_att[9])
             return (1.0, p, s_conv[10])
 
-        first = None if self.conformer else br(nl - 1, "ff")
+        # the intermediate branch's gradient joins dx where the sweep reaches the output of layer `inter`-1;
+        # a dropout-masked branch gradient carried across that point would be stale, so it is not produced
+        inter = self.inter_layer if deouts_inter is not None else 0
+        first = None if (self.conformer or inter == nl) else br(nl - 1, "ff")
         dx, pre = self._ln_bwd(deouts.reshape(M, d), st.x_final, "encoder.norm", st.fin_mean, st.fin_rstd, None, first)
         for li in reversed(range(nl)):
             name = f"encoder.transformers.{li}"
             s_ffm, s_att, s_conv, s_ff, s_fin = st.layers[li]
+            if li + 1 == inter:
+                dx, _ = self._ln_bwd(deouts_inter.reshape(M, d), st.x_inter, "encoder.norm", st.int_mean, st.int_rstd, dx)
+                pre = None
             if self.conformer:
                 x, mean, rstd = s_fin
                 dx, pre = self._ln_bwd(dx, x, name + ".norm_final", mean, rstd, None, br(li, "ff"))
@@ -637,13 +663,17 @@ class CTCEngine(_DecoderMixinPlaceholder):
             else:
                 dx, pre = self._ffn_bwd(name + ".feed_forward", name + ".norm2", s_ff, dx, 1.0, ACT_RELU, pre=pre,
                                         nxt=br(li, "att"))
-                if li > 0:
+                if li > 0 and li == inter:
+                    dx, pre = self._attn_bwd(name + ".self_attn", name + ".norm1", s_att, dx, B, T, st.elens, None,
+                                             pre=pre), None
+                elif li > 0:
                     dx, pre = self._attn_bwd(name + ".self_attn", name + ".norm1", s_att, dx, B, T, st.elens, None,
                                              pre=pre, nxt=br(li - 1, "ff"))
                 else:
                     dx = self._attn_bwd(name + ".self_attn", name + ".norm1", s_att, dx, B, T, st.elens, None, pre=pre)
             self._flush_wgrads()
-            if self.grad_hook is not None:
+            if self.grad_hook is not None and li + 1 <= (inter if inter > 0 else nl):
+                # (with an intermediate branch, encoder.norm's gradient is final only once layer inter-1 is done)
                 ops.layernorm_bwd_finalize(self._ln_deferred)  # this layer's LayerNorm gradients must be final too
                 self.grad_hook(self._layer_offset(li))
         ops.layernorm_bwd_finalize(self._ln_deferred)
@@ -669,8 +699,17 @@ class CTCEngine(_DecoderMixinPlaceholder):
         B, T, d = eouts.shape
         V = dlogits.shape[-1]
         self.arena.attach_grads()
-        return self._lin_bwd(dlogits.view(B * T, V), eouts.reshape(B * T, d), head + ".weight",
-                             head + ".bias").view(B, T, d)
+        d2 = dlogits.reshape(B * T, V)
+        if V % 8 == 0:
+            return self._lin_bwd(d2.contiguous(), eouts.reshape(B * T, d), head + ".weight", head + ".bias").view(B, T, d)
+        # ragged vocabulary (phone heads): zero-padded copies give the GEMMs their 8-element K / row rule
+        A, Vp = self.arena, (V + 7) // 8 * 8
+        dpad = torch.zeros(B * T, Vp, device=d2.device, dtype=d2.dtype)
+        dpad[:, :V].copy_(d2)
+        wpad = torch.zeros(Vp, d, device=d2.device, dtype=d2.dtype)
+        wpad[:V].copy_(A.w(head + ".weight"))
+        self._wgrad(dpad[:, :V], eouts.reshape(B * T, d), A.g(head + ".weight"), 1.0, A.g(head + ".bias"), 1.0)
+        return ops.gemm_nn(dpad, wpad).view(B, T, d)
 
 
 # =======================================================================================
@@ -757,6 +796,27 @@ class _DecoderMixin:
         labels = h2d_i32(torch.as_tensor(ys_out)[:, :L].contiguous(), dev)
         rows, grad = ops.lsm_loss(logits.view(B * L, V), labels.view(-1), w.view(-1), self.lsm, want_grad, 1.0, gscale_dev)
         return rows.sum(), (grad.view(B, L, V) if grad is not None else None)
+
+    def att_kd_loss(self, logits, ys_out, ylens_host, soft, scale_soft=None, scale_hard=None):
+        """DistillLoss over t < ylens+1 (criteria.py:66-100, decoders/transformer.py:117-126).
+        Without scales -> (loss_soft, loss_hard, None); with device scalars scale_soft / scale_hard (the
+        incoming gradients of the two sums) -> (None, None, dlogits)."""
+        B, L, V = logits.shape
+        dev = logits.device
+        w = torch.zeros(B, L, dtype=torch.float32)
+        for b, yl in enumerate(ylens_host):
+            n = int(yl) + 1
+            w[b, :n] = (1.0 / B if self.norm_batch else 1.0) / (n if self.norm_len else 1.0)
+        w = w.pin_memory().to(dev, non_blocking=True).view(-1)
+        labels = h2d_i32(torch.as_tensor(ys_out)[:, :L].contiguous(), dev).view(-1)
+        src = torch.arange(B * L, device=dev, dtype=torch.int32)
+        z, q = logits.view(B * L, V), soft.view(B * L, V)
+        if scale_soft is None:
+            rs, _ = ops.soft_ce(z, q, src, None, w, None, self.lsm)
+            rh, _ = ops.soft_ce(z, None, None, labels, None, w, self.lsm)
+            return rs.sum(), rh.sum(), None
+        _, grad = ops.soft_ce(z, q, src, labels, w * scale_soft, w * scale_hard, self.lsm, want_grad=True)
+        return None, None, grad.view(B, L, V)
 
     def dec_backward(self, st, dlogits):
         """-> d_eouts [B,T,d]; accumulates decoder parameter gradients"""
@@ -923,14 +983,17 @@ class _RNNTMixin:
             st.B, st.T, st.U = B, T, U
             return nll.mean(), logits, st
 
-    def rnnt_backward(self, st, gscale_dev):
-        """-> d_eouts [B,T,d]; accumulates decoder gradients (the logits buffer is overwritten by its gradient)"""
+    def rnnt_backward(self, st, gscale_dev, extra_dlogits=None):
+        """-> d_eouts [B,T,d]; accumulates decoder gradients (the logits buffer is overwritten by its gradient).
+        extra_dlogits [B*T*U,V]: gradient of another loss on the same logits (distillation), added in."""
         with ops.stream_scope():
             A, J, H = self.arena, self.r_J, self.r_H
             A.attach_grads()
             B, T, U = st.B, st.T, st.U
             dz = ops.rnnt_grad(st.logits, st.ctx, st.nll, st.labels, st.elens, st.ylens, st.blank, 1.0 / B, gscale_dev,
                                out=st.logits)
+            if extra_dlogits is not None:
+                ops.strided_copy(extra_dlogits.view(dz.shape), out=dz, accumulate=True)
             V = dz.shape[-1]
             dz2 = dz.view(B * T * U, V)
             h2 = st.h.view(B * T * U, J)

@@ -166,6 +166,9 @@ SIGNATURES = {
     "emoasr_embed_fwd": [I, I, I, I, P, P, P, F, F, U64, P, P],
     "emoasr_embed_bwd": [I, I, I, P, P, F, F, U64, P, P],
     "emoasr_lsm_loss": [I, I, I, P, L, P, P, F, P, F, P, P, L, P],
+    "emoasr_soft_ce": [I, I, I, P, L, P, P, L, P, P, P, P, F, P, F, P, P, L, P],
+    "emoasr_ctc_best_path": [I, I, I, P, P, P, P, P, P, I, P, P],
+    "emoasr_ctc_label_map": [I, I, P, P, I, I, P, P, P],
     "emoasr_log_softmax": [I, I, I, P, L, P, L, F, P, L, P],
     "emoasr_topk": [I, I, I, P, L, P, L, P, P, P, P],
     "emoasr_ctc_prefix_init": [I, I, P, I, P, P],

@@ -50,7 +50,7 @@ def ctc_prefix_beam_search(dec, eouts, elens, beam_width, len_weight=0.0, lm=Non
     eng = _engine_of(dec)
     blank, eos, V = dec.blank_id, dec.eos_id, dec.vocab_size
     with torch.no_grad():
-        logits = eng.head_logits(eouts)                      # [1, T, V]
+        logits = eng.head_logits(eouts, getattr(dec, "_prefix", "decoder") + ".output")                      # [1, T, V]
         T = logits.shape[1]
         logp_dev = ops.log_softmax(logits.view(T, V))        # f32 [T, V]
         k = min(beam_width, V)

@@ -18,8 +18,13 @@ from .ctc import CTCDecoder
 class RNNTDecoder(nn.Module):
     def __init__(self, params, phase="train"):
         super().__init__()
-        if params.kd_weight > 0:
-            raise NotImplementedError("emoasr_amd: kd_weight > 0 is outside the HIP hot path")
+        if params.kd_weight > 0 and phase == "train":
+            self.kd_type = params.kd_type
+            self.reduce_main_loss_kd = params.reduce_main_loss_kd
+            if self.kd_type != "word":
+                # kd_type "align" needs RNNTForcedAligner (Numba CUDA kernels, rnnt_aligner.py:14-198); the loss
+                # itself exists (criteria.RNNTAlignDistillLoss)
+                raise NotImplementedError("emoasr_amd: RNN-T distillation is provided for kd_type 'word' only")
         self.dec_num_layers = params.dec_num_layers
         self.dec_hidden_size = params.dec_hidden_size
         self.eos_id = params.eos_id
@@ -37,15 +42,20 @@ class RNNTDecoder(nn.Module):
         self.w_dec = nn.Linear(params.dec_hidden_size, params.joint_hidden_size)
         self.output = nn.Linear(params.joint_hidden_size, params.vocab_size)
         if self.mtl_ctc_weight > 0:
-            self.ctc = CTCDecoder(params)
+            self.ctc = CTCDecoder(params, prefix="decoder.ctc")
         self._owner = None
 
     def forward(self, eouts, elens, eouts_inter=None, ys=None, ylens=None, ys_in=None, ys_out=None,
                 soft_labels=None, ps=None, plens=None):
-        loss, loss_rnnt, loss_ctc, logits = rnnt_apply(self, eouts, elens, ys, ylens, ys_in)
+        kd = None
+        if self.kd_weight > 0 and soft_labels is not None:
+            kd = (soft_labels, self.kd_weight, self.reduce_main_loss_kd)
+        loss, loss_rnnt, loss_ctc, logits, loss_kd = rnnt_apply(self, eouts, elens, ys, ylens, ys_in, kd)
         loss_dict = {"loss_rnnt": loss_rnnt}
         if self.mtl_ctc_weight > 0:
             loss_dict["loss_ctc"] = loss_ctc
+        if kd is not None:
+            loss_dict["loss_kd"] = loss_kd
         loss_dict["loss_total"] = loss
         return loss, loss_dict, logits
 

@@ -16,8 +16,6 @@ class TransformerDecoder(nn.Module):
         super().__init__()
         if cmlm:
             raise NotImplementedError("emoasr_amd: conditional masked LM decoding is outside the HIP hot path")
-        if params.kd_weight > 0:
-            raise NotImplementedError("emoasr_amd: kd_weight > 0 is outside the HIP hot path")
         self.vocab_size = params.vocab_size
         self.embed = nn.Embedding(self.vocab_size, params.dec_hidden_size)
         self.dec_num_layers = params.dec_num_layers
@@ -26,7 +24,7 @@ class TransformerDecoder(nn.Module):
             for _ in range(self.dec_num_layers))
         self.mtl_ctc_weight = params.mtl_ctc_weight
         if self.mtl_ctc_weight > 0:
-            self.ctc = CTCDecoder(params)
+            self.ctc = CTCDecoder(params, prefix="decoder.ctc")
         self.norm = nn.LayerNorm(params.dec_hidden_size, eps=1e-12)
         self.output = nn.Linear(params.dec_hidden_size, self.vocab_size)
         self.kd_weight = params.kd_weight
@@ -39,8 +37,10 @@ class TransformerDecoder(nn.Module):
                 soft_labels=None, ps=None, plens=None):
         if ys_out is None:
             return attn_decoder_logits(self, eouts, elens, ys_in, ylens)
-        loss, loss_att, loss_ctc, logits = attn_decoder_apply(self, eouts, elens, ys, ylens, ys_in, ys_out)
-        loss_dict = {"loss_att": loss_att}
+        kd = self.kd_weight > 0 and soft_labels is not None  # DistillLoss replaces the label-smoothing loss (:71-79)
+        loss, loss_att, loss_ctc, logits, loss_kd = attn_decoder_apply(self, eouts, elens, ys, ylens, ys_in, ys_out,
+                                                                       soft_labels if kd else None, self.kd_weight)
+        loss_dict = {"loss_kd": loss_kd, "loss_att": loss_att} if kd else {"loss_att": loss_att}
         if self.mtl_ctc_weight > 0:
             loss_dict["loss_ctc"] = loss_ctc
         loss_dict["loss_total"] = loss

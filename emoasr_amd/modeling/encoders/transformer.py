@@ -35,11 +35,8 @@ class TransformerEncoder(nn.Module):
         self.norm = nn.LayerNorm(d, eps=1e-12)
         inter = (hasattr(params, "mtl_inter_ctc_weight") and params.mtl_inter_ctc_weight > 0) or \
                 (hasattr(params, "mtl_phone_ctc_weight") and params.mtl_phone_ctc_weight > 0)
-        if inter:
-            raise NotImplementedError("emoasr_amd: intermediate-CTC branches are outside the HIP hot path")
-        self.inter_ctc_layer_id = 0
+        self.inter_ctc_layer_id = params.inter_ctc_layer_id if inter else 0
         self._owner = None  # set by ASR so encoder and decoder share one engine / arena
 
     def forward(self, xs, xlens):
-        eouts, elens = encoder_apply(self, xs, xlens)
-        return eouts, elens, None
+        return encoder_apply(self, xs, xlens)  # (eouts, elens, eouts_inter | None)

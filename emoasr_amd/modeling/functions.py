@@ -27,11 +27,16 @@ class _EncoderFn(torch.autograd.Function):
         eouts, elens_host, elens_dev, st = eng.forward(xs, xlens_host, training, stash=True)
         ctx.eng, ctx.st = eng, st
         ctx.mark_non_differentiable(elens_dev)
-        return eouts, elens_dev
+        inter = eng.eouts_inter
+        ctx.has_inter = inter is not None
+        if inter is None:
+            inter = eouts.new_empty(0)
+            ctx.mark_non_differentiable(inter)
+        return eouts, elens_dev, inter
 
     @staticmethod
-    def backward(ctx, deouts, _):
-        ctx.eng.backward(ctx.st, deouts.contiguous())
+    def backward(ctx, deouts, _, dinter):
+        ctx.eng.backward(ctx.st, deouts.contiguous(), dinter.contiguous() if ctx.has_inter else None)
         ctx.st = None
         return (None,) * (4 + len(ctx.eng.arena.params))
 
@@ -42,23 +47,27 @@ def encoder_apply(enc, xs, xlens):
     host = _host_list(xlens)
     if torch.is_grad_enabled():
         eng.step_count += 1
-        eouts, elens_dev = _EncoderFn.apply(eng, enc.training, xs, host, *eng.arena.params)
+        eouts, elens_dev, inter = _EncoderFn.apply(eng, enc.training, xs, host, *eng.arena.params)
+        inter = inter if eng.eouts_inter is not None else None
     else:
         eouts, _, elens_dev, _ = eng.forward(xs, host, enc.training, stash=False)
+        inter = eng.eouts_inter
     elens = torch.tensor([((v - 1) // 2 - 1) // 2 for v in host], dtype=torch.int64)
     if torch.is_tensor(xlens):
         elens = elens.to(xlens.device)
     eouts._emo_elens_dev = elens_dev
-    return eouts, elens
+    if inter is not None:
+        inter._emo_elens_dev = elens_dev
+    return eouts, elens, inter
 
 
 class _CTCLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, eouts, elens_dev, ys_host, ylens_host, blank, *params):
-        logits = eng.head_logits(eouts)
+    def forward(ctx, eng, eouts, elens_dev, ys_host, ylens_host, blank, head, *params):
+        logits = eng.head_logits(eouts, head)
         need = eouts.requires_grad or any(p.requires_grad for p in params)
         loss, cctx = eng.ctc_loss(logits, elens_dev, ys_host, ylens_host, blank, need)
-        ctx.eng, ctx.cctx, ctx.eouts = eng, cctx, eouts
+        ctx.eng, ctx.cctx, ctx.eouts, ctx.head = eng, cctx, eouts, head
         ctx.mark_non_differentiable(logits)
         return loss, logits
 
@@ -67,9 +76,80 @@ class _CTCLossFn(torch.autograd.Function):
         eng = ctx.eng
         gdev = gloss.to(torch.float32).reshape(1) if gloss.is_cuda else None  # no host sync
         dlogits = eng.ctc_grad(ctx.cctx, 1.0 if gdev is not None else float(gloss), gdev)
-        deouts = eng.head_backward(ctx.eouts, dlogits)
+        deouts = eng.head_backward(ctx.eouts, dlogits, ctx.head)
         ctx.cctx = None
-        return (None, deouts, None, None, None, None) + (None,) * len(eng.arena.params)
+        return (None, deouts, None, None, None, None, None) + (None,) * len(eng.arena.params)
+
+
+class _HeadFn(torch.autograd.Function):
+    """a vocabulary head on its own (logits = eouts W^T + b), for losses that are separate autograd nodes"""
+
+    @staticmethod
+    def forward(ctx, eng, eouts, head, *params):
+        ctx.eng, ctx.eouts, ctx.head = eng, eouts, head
+        return eng.head_logits(eouts, head)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        deouts = ctx.eng.head_backward(ctx.eouts, dlogits, ctx.head)
+        return (None, deouts, None) + (None,) * len(ctx.eng.arena.params)
+
+
+class _CTCLogitsFn(torch.autograd.Function):
+    """CTC loss of given logits (+ optionally the forced alignment read off the same lattices)"""
+
+    @staticmethod
+    def forward(ctx, eng, logits, elens_dev, ys_host, ylens_host, blank, want_aligns):
+        from .. import ops
+        loss, cctx = eng.ctc_loss(logits, elens_dev, ys_host, ylens_host, blank, True)
+        ctx.eng, ctx.cctx = eng, cctx
+        if want_aligns:
+            _, _, labels, elens, ylens, _, lp, alpha, beta, _ = cctx
+            aligns = ops.ctc_best_path(lp, alpha, beta, labels, elens, ylens, blank)
+        else:
+            aligns = torch.empty(0, dtype=torch.int32, device=logits.device)
+        ctx.mark_non_differentiable(aligns)
+        return loss, aligns
+
+    @staticmethod
+    def backward(ctx, gloss, _):
+        dlogits = ctx.eng.ctc_grad(ctx.cctx, 1.0, gloss.to(torch.float32).reshape(1))
+        ctx.cctx = None
+        return None, dlogits, None, None, None, None, None
+
+
+def head_apply(dec, eouts, head):
+    eng = _engine_of(dec)
+    return _HeadFn.apply(eng, eouts, head, *eng.arena.params)
+
+
+def ctc_from_logits_apply(dec, logits, eouts, elens, ys, ylens, want_aligns=False):
+    """-> (loss_ctc = sum_b nll_b / B, aligns int32 [B,T] | None)"""
+    eng = _engine_of(dec)
+    ys_host = ys.cpu() if torch.is_tensor(ys) else torch.as_tensor(ys)
+    loss, aligns = _CTCLogitsFn.apply(eng, logits, _elens_dev(eouts, elens), ys_host, _host_list(ylens), dec.blank_id,
+                                      want_aligns)
+    return loss, (aligns if want_aligns else None)
+
+
+def ctc_forced_align_apply(log_probs, elens, ys, ylens, blank):
+    """CTCForcedAligner.__call__ (ctc_aligner.py:139-221) on the CTC lattice kernels -> int64 [B,T] (device)"""
+    from .. import ops
+    dev = log_probs.device
+    lp_in = log_probs.contiguous()
+    B, T, V = lp_in.shape
+    ylens_host = _host_list(ylens)
+    Lmax = max(max(ylens_host), 1)
+    labels = torch.as_tensor(ys)[:, :Lmax].to(torch.int32)
+    if labels.shape[1] < Lmax:
+        labels = torch.nn.functional.pad(labels, (0, Lmax - labels.shape[1]))
+    labels = labels.contiguous().to(dev)
+    el = torch.as_tensor(elens).to(torch.int32).to(dev)
+    yl = torch.tensor(ylens_host, dtype=torch.int32).to(dev)
+    with ops.stream_scope():
+        lse = ops.row_lse(lp_in.view(B * T, V))
+        lp, alpha, beta, _ = ops.ctc_forward(lp_in, lse, labels, el, yl, blank)
+        return ops.ctc_best_path(lp, alpha, beta, labels, el, yl, blank).long()
 
 
 def _elens_dev(eouts, elens):
@@ -79,20 +159,20 @@ def _elens_dev(eouts, elens):
     return dev
 
 
-def ctc_head_apply(dec, eouts):
-    return _engine_of(dec).head_logits(eouts)
+def ctc_head_apply(dec, eouts, head="decoder.output"):
+    return _engine_of(dec).head_logits(eouts, head)
 
 
-def ctc_loss_apply(dec, eouts, elens, ys, ylens):
+def ctc_loss_apply(dec, eouts, elens, ys, ylens, head="decoder.output"):
     eng = _engine_of(dec)
     ys_host = ys.cpu() if torch.is_tensor(ys) else torch.as_tensor(ys)
-    return _CTCLossFn.apply(eng, eouts, _elens_dev(eouts, elens), ys_host, _host_list(ylens), dec.blank_id,
+    return _CTCLossFn.apply(eng, eouts, _elens_dev(eouts, elens), ys_host, _host_list(ylens), dec.blank_id, head,
                             *eng.arena.params)
 
 
 def ctc_greedy_apply(dec, eouts, elens):
     eng = _engine_of(dec)
-    logits = eng.head_logits(eouts)
+    logits = eng.head_logits(eouts, getattr(dec, "_prefix", "decoder") + ".output")
     best, hyp, hyplen = eng.greedy(logits, _elens_dev(eouts, elens), dec.blank_id)
     best_h, hyp_h, n_h = best.cpu(), hyp.cpu(), hyplen.cpu().tolist()  # one D2H per batch
     el = _host_list(elens)
@@ -106,45 +186,59 @@ def ctc_greedy_apply(dec, eouts, elens):
 # ---------------------------------------------------------------------------------------
 class _AttnDecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, training, eouts, elens_dev, ys_host, ylens_host, ys_in, ys_out, blank, *params):
+    def forward(ctx, eng, training, eouts, elens_dev, ys_host, ylens_host, ys_in, ys_out, blank, soft, kd, *params):
         logits, st = eng.dec_forward(eouts, elens_dev, ys_in, ylens_host, training, True)
-        loss_att, _ = eng.att_loss(logits, ys_out, ylens_host)
-        loss_ctc, cctx, loss = None, None, loss_att
+        if soft is None:
+            loss_att, _ = eng.att_loss(logits, ys_out, ylens_host)
+            loss_kd, loss = torch.zeros_like(loss_att), loss_att
+        else:  # label interpolation with the teacher's soft labels (decoders/transformer.py:117-126)
+            loss_kd, loss_att, _ = eng.att_kd_loss(logits, ys_out, ylens_host, soft)
+            loss = kd * loss_kd + (1 - kd) * loss_att
+        loss_ctc, cctx = None, None
+        ctx.soft, ctx.kd = soft, kd
         if eng.mtl_ctc > 0:
             ctc_logits = eng.head_logits(eouts, "decoder.ctc.output")
             loss_ctc, cctx = eng.ctc_loss(ctc_logits, elens_dev, ys_host, ylens_host, blank, True)
-            loss = loss_att + eng.mtl_ctc * loss_ctc
+            loss = loss + eng.mtl_ctc * loss_ctc
         else:
             loss_ctc = torch.zeros_like(loss_att)
         ctx.eng, ctx.st, ctx.cctx, ctx.eouts, ctx.logits = eng, st, cctx, eouts, logits
         ctx.ys_out, ctx.ylens_host = ys_out, ylens_host
         ctx.mark_non_differentiable(logits)
-        return loss, loss_att, loss_ctc, logits
+        return loss, loss_att, loss_ctc, logits, loss_kd
 
     @staticmethod
-    def backward(ctx, g_total, g_att, g_ctc, _):
+    def backward(ctx, g_total, g_att, g_ctc, _, g_kd):
         eng = ctx.eng
-        g_att_eff = (g_total + g_att).to(torch.float32).reshape(1)
-        _, dlogits = eng.att_loss(ctx.logits, ctx.ys_out, ctx.ylens_host, True, g_att_eff)
+        if ctx.soft is None:
+            g_att_eff = (g_total + g_att).to(torch.float32).reshape(1)
+            _, dlogits = eng.att_loss(ctx.logits, ctx.ys_out, ctx.ylens_host, True, g_att_eff)
+        else:
+            _, _, dlogits = eng.att_kd_loss(ctx.logits, ctx.ys_out, ctx.ylens_host, ctx.soft,
+                                            (g_total * ctx.kd + g_kd).to(torch.float32),
+                                            (g_total * (1 - ctx.kd) + g_att).to(torch.float32))
         deouts = eng.dec_backward(ctx.st, dlogits)
         if ctx.cctx is not None:
             g_ctc_eff = (g_total * eng.mtl_ctc + g_ctc).to(torch.float32).reshape(1)
             dcl = eng.ctc_grad(ctx.cctx, 1.0, g_ctc_eff)
             from .. import ops
             deouts = ops.add(deouts, eng.head_backward(ctx.eouts, dcl, "decoder.ctc.output"))
-        ctx.st = ctx.cctx = None
-        return (None, None, deouts, None, None, None, None, None, None) + (None,) * len(eng.arena.params)
+        ctx.st = ctx.cctx = ctx.soft = None
+        return (None, None, deouts, None, None, None, None, None, None, None, None) + (None,) * len(eng.arena.params)
 
 
-def attn_decoder_apply(dec, eouts, elens, ys, ylens, ys_in, ys_out):
+def attn_decoder_apply(dec, eouts, elens, ys, ylens, ys_in, ys_out, soft_labels=None, kd_weight=0.0):
     eng = _engine_of(dec)
     ylens_host = _host_list(ylens)
     L = max(ylens_host) + 1
     ys_host = ys.cpu() if torch.is_tensor(ys) else torch.as_tensor(ys)
     ys_in = (ys_in.cpu() if torch.is_tensor(ys_in) else torch.as_tensor(ys_in))[:, :L]
     ys_out = (ys_out.cpu() if torch.is_tensor(ys_out) else torch.as_tensor(ys_out))[:, :L]
+    soft = None
+    if soft_labels is not None:
+        soft = torch.as_tensor(soft_labels)[:, :L].to(device=eouts.device, dtype=torch.float32).contiguous()
     return _AttnDecoderFn.apply(eng, dec.training, eouts, _elens_dev(eouts, elens), ys_host, ylens_host, ys_in, ys_out,
-                                dec.blank_id, *eng.arena.params)
+                                dec.blank_id, soft, float(kd_weight), *eng.arena.params)
 
 
 def attn_decoder_logits(dec, eouts, elens, ys_in, ylens):
@@ -161,7 +255,11 @@ def attn_decoder_logits(dec, eouts, elens, ys_in, ylens):
 # ---------------------------------------------------------------------------------------
 class _RNNTFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, training, eouts, elens_dev, ys_host, ylens_host, ys_in, blank, *params):
+    def forward(ctx, eng, training, eouts, elens_dev, ys_host, ylens_host, ys_in, blank, kd, *params):
+        """kd = None | (soft f32 [B,L,V] on the device, kd_weight, reduce_main_loss_kd): word-level distillation
+        (rnn_transducer.py:127-141, criteria.py:218-247) of every lattice cell towards its label's soft target"""
+        from .. import ops
+        from ..criteria import rnnt_word_rows
         loss_rnnt, logits, st = eng.rnnt_forward(eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training)
         cctx, loss = None, loss_rnnt
         if eng.mtl_ctc > 0:
@@ -170,31 +268,50 @@ class _RNNTFn(torch.autograd.Function):
             loss = loss_rnnt + eng.mtl_ctc * loss_ctc
         else:
             loss_ctc = torch.zeros_like(loss_rnnt)
+        loss_kd = torch.zeros_like(loss_rnnt)
+        ctx.kd = None
+        if kd is not None:
+            soft, kd_w, reduce = kd
+            B, T, U, V = logits.shape
+            L = soft.shape[1]
+            src, w = rnnt_word_rows(B, T, U, L, elens_dev, ylens_host, logits.device)
+            rows, _ = ops.soft_ce(logits.view(B * T * U, V), soft.view(B * L, V), src, None, w, None, 0.0)
+            loss_kd = rows.sum()
+            loss = ((1 - kd_w) * loss if reduce else loss) + kd_w * loss_kd
+            ctx.kd = (soft, kd_w, (1 - kd_w) if reduce else 1.0, src, w)
         ctx.eng, ctx.st, ctx.cctx, ctx.eouts = eng, st, cctx, eouts
-        out_logits = logits.detach().clone() if False else logits
-        ctx.mark_non_differentiable(out_logits)
-        return loss, loss_rnnt, loss_ctc, out_logits
+        ctx.mark_non_differentiable(logits)
+        return loss, loss_rnnt, loss_ctc, logits, loss_kd
 
     @staticmethod
-    def backward(ctx, g_total, g_rnnt, g_ctc, _):
+    def backward(ctx, g_total, g_rnnt, g_ctc, _, g_kd):
+        from .. import ops
         eng = ctx.eng
-        deouts = eng.rnnt_backward(ctx.st, (g_total + g_rnnt).to(torch.float32).reshape(1))
+        main, extra = 1.0, None
+        if ctx.kd is not None:  # before rnnt_backward overwrites the logits with their gradient
+            soft, kd_w, main, src, w = ctx.kd
+            z = ctx.st.logits
+            B, T, U, V = z.shape
+            _, extra = ops.soft_ce(z.view(B * T * U, V), soft.view(-1, V), src, None,
+                                   w * (g_total * kd_w + g_kd).to(torch.float32), None, 0.0, want_grad=True)
+        deouts = eng.rnnt_backward(ctx.st, (g_total * main + g_rnnt).to(torch.float32).reshape(1), extra)
         if ctx.cctx is not None:
-            g_ctc_eff = (g_total * eng.mtl_ctc + g_ctc).to(torch.float32).reshape(1)
+            g_ctc_eff = (g_total * (main * eng.mtl_ctc) + g_ctc).to(torch.float32).reshape(1)
             dcl = eng.ctc_grad(ctx.cctx, 1.0, g_ctc_eff)
-            from .. import ops
             deouts = ops.add(deouts, eng.head_backward(ctx.eouts, dcl, "decoder.ctc.output"))
-        ctx.st = ctx.cctx = None
-        return (None, None, deouts, None, None, None, None, None) + (None,) * len(eng.arena.params)
+        ctx.st = ctx.cctx = ctx.kd = None
+        return (None, None, deouts, None, None, None, None, None, None) + (None,) * len(eng.arena.params)
 
 
-def rnnt_apply(dec, eouts, elens, ys, ylens, ys_in):
+def rnnt_apply(dec, eouts, elens, ys, ylens, ys_in, kd=None):
     eng = _engine_of(dec)
     ylens_host = _host_list(ylens)
     L = max(ylens_host)
     ys_host = (ys.cpu() if torch.is_tensor(ys) else torch.as_tensor(ys))[:, :L]
     ys_in = (ys_in.cpu() if torch.is_tensor(ys_in) else torch.as_tensor(ys_in))[:, : L + 1]
-    return _RNNTFn.apply(eng, dec.training, eouts, _elens_dev(eouts, elens), ys_host, ylens_host, ys_in, dec.blank_id,
+    if kd is not None:
+        kd = (torch.as_tensor(kd[0]).to(device=eouts.device, dtype=torch.float32).contiguous(), float(kd[1]), bool(kd[2]))
+    return _RNNTFn.apply(eng, dec.training, eouts, _elens_dev(eouts, elens), ys_host, ylens_host, ys_in, dec.blank_id, kd,
                          *eng.arena.params)
 
 

@@ -474,7 +474,8 @@ def ctc_forward(logits, lse, labels, elens, ylens, blank):
 
 def ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale, gscale_dev=None):
     B, T, V = logits.shape
-    grad = torch.empty_like(logits)
+    ld = logits.stride(1)  # rows of a ragged vocabulary are padded (engine.head_logits): keep that layout
+    grad = torch.empty_like(logits) if ld == V else torch.empty(B, T, ld, device=logits.device, dtype=logits.dtype)[..., :V]
     lib.call("emoasr_ctc_grad", dt(logits), B, T, V, labels.shape[1], _p(logits), logits.stride(1), _p(lse),
              _p(labels), _p(elens), _p(ylens), blank, _p(lp), _p(alpha), _p(beta), _p(nll), gscale, _p(gscale_dev),
              _p(grad),
@@ -518,6 +519,47 @@ def lsm_loss(logits, labels, w, lsm_prob, want_grad=False, gscale=1.0, gscale_de
     lib.call("emoasr_lsm_loss", dt(logits), M, V, _p(logits), ld, _p(labels), _p(w), lsm_prob, _p(loss), gscale,
              _p(gscale_dev), _p(grad), 0 if grad is None else grad.stride(0), _stream())
     return loss, grad
+
+
+# ---- knowledge distillation ---------------------------------------------------------------
+def soft_ce(logits, soft=None, src=None, hard=None, w_soft=None, w_hard=None, lsm_prob=0.0, lrow=None, want_grad=False,
+            gscale=1.0, gscale_dev=None, grad=None):
+    """logits [M,V]; soft f32 [N,V]; src/hard/lrow int32 [R]; w_* f32 [R] -> (loss rows f32 [R], grad [M,V] | None).
+    With `lrow` only the listed logits rows are touched: pass a zero-filled `grad`."""
+    M, V, ld = _rows(_chk(logits))
+    R = M if lrow is None else lrow.numel()
+    loss = torch.empty(R, device=logits.device, dtype=torch.float32)
+    if want_grad and grad is None:
+        grad = torch.zeros_like(logits) if lrow is not None else torch.empty_like(logits)
+    if soft is not None:
+        _chk(soft, torch.float32)
+        assert soft.shape[-1] == V and soft.is_contiguous()
+    lib.call("emoasr_soft_ce", dt(logits), R, V, _p(logits), ld, _p(lrow), _p(soft), V, _p(src), _p(hard), _p(w_soft),
+             _p(w_hard), lsm_prob, _p(loss), gscale, _p(gscale_dev), _p(grad) if want_grad else None,
+             grad.stride(-2) if want_grad else 0, _stream())
+    return loss, grad if want_grad else None
+
+
+def ctc_best_path(lp, alpha, beta, labels, elens, ylens, blank):
+    """lattices of ctc_forward [B,T,S] -> aligns int32 [B,T] (ctc_aligner.py:139-221)"""
+    B, T, S = lp.shape
+    aligns = torch.empty(B, T, device=lp.device, dtype=torch.int32)
+    lib.call("emoasr_ctc_best_path", B, T, labels.shape[1], _p(lp), _p(alpha), _p(beta), _p(labels), _p(elens),
+             _p(ylens), blank, _p(aligns), _stream())
+    return aligns
+
+
+LABEL_POSITIONS = {"all": 0, "left": 1, "mid": 2, "right": 3}
+
+
+def ctc_label_map(aligns, xlens, blank, position="all"):
+    """aligns int32 [B,T], xlens int32 [B] -> (label_map int32 [B,T] (-1: none), count int32 [B])"""
+    B, T = aligns.shape
+    lmap = torch.empty(B, T, device=aligns.device, dtype=torch.int32)
+    count = torch.empty(B, device=aligns.device, dtype=torch.int32)
+    lib.call("emoasr_ctc_label_map", B, T, _p(aligns), _p(xlens), blank, LABEL_POSITIONS[position], _p(lmap), _p(count),
+             _stream())
+    return lmap, count
 
 
 # ---- beam search -----------------------------------------------------------------------------

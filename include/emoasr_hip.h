@@ -288,6 +288,25 @@ int emoasr_lsm_loss(int dtype, int M, int V, const void* logits, long ld, const 
                     float lsm_prob, float* loss, float gscale, const float* gscale_dev, void* grad, long ldg,
                     void* stream);
 
+/* ---- knowledge distillation (asr/criteria.py:49-288, decoders/ctc_aligner.py:96-221) ---- */
+/* Soft-target cross-entropy rows (one kernel behind DistillLoss, CTCAlignDistillLoss, RNNTWordDistillLoss,
+ * RNNTAlignDistillLoss).  Row r reads logits row lrow[r] (lrow NULL: r), the dense f32 soft target
+ * soft[src[r], :V] (src NULL or src[r] < 0: no soft term) and the label-smoothed hard target of class hard[r]
+ * (hard NULL or < 0: none):  loss[r] = -(w_soft[r]*sum_v q_s[v] log p[v] + w_hard[r]*sum_v q_h[v] log p[v]);
+ * grad (may be NULL; rows indexed like logits) = gscale*[gscale_dev]*(w_soft*(p*sum(q_s) - q_s) + w_hard*(p - q_h)) */
+int emoasr_soft_ce(int dtype, int R, int V, const void* logits, long ld, const int* lrow, const float* soft, long lds,
+                   const int* src, const int* hard, const float* w_soft, const float* w_hard, float lsm_prob,
+                   float* loss, float gscale, const float* gscale_dev, void* grad, long ldg, void* stream);
+/* CTCForcedAligner.__call__ (ctc_aligner.py:139-221) on the lattices of emoasr_ctc_forward (same lp/alpha/beta
+ * [B,Tn,2*Lmax+1]): aligns[b,t] (int32 [B,Tn]) = token of the best state among those reachable from frame t-1's
+ * choice, 0 for t >= elens[b]. */
+int emoasr_ctc_best_path(int B, int Tn, int Lmax, const float* lp, const float* alpha, const float* beta,
+                         const int* labels, const int* elens, const int* ylens, int blank, int* aligns, void* stream);
+/* CTCAlignDistillLoss._frame_to_label_mapping (criteria.py:170-215): label_map[b,t] = index of the label that
+ * frame t is assigned to, or -1; position 0 "all", 1 "left", 2 "mid", 3 "right"; count[b] = frames mapped. */
+int emoasr_ctc_label_map(int B, int Tn, const int* aligns, const int* xlens, int blank, int position, int* label_map,
+                         int* count, void* stream);
+
 /* ---- joint CTC/attention beam search (decoders/transformer.py:161-294, ctc_score.py:13-85) ---- */
 /* out[m,v] = log_softmax(x[m,:V])[v] + mu*add[m,v]   (add may be NULL; f32 out) */
 int emoasr_log_softmax(int dtype, int M, int V, const void* x, long ldx, const float* add, long lda, float mu,

@@ -353,6 +353,201 @@ def run_rnnt_beam():
     np.savez_compressed(os.path.join(OUT, "rnntbeam_tiny.npz"), **out)
 
 
+KD_CTC_CASES = {
+    "ctc_all": dict(kd_weight=0.5, reduce_main_loss_kd=False),
+    "ctc_mid": dict(kd_weight=0.3, reduce_main_loss_kd=True, kd_ctc_soft_label_weight=0.6, kd_ctc_position="mid"),
+}
+KD_INTER_CASES = {
+    "inter": dict(mtl_inter_ctc_weight=0.3, inter_ctc_layer_id=1),
+    "inter_kd": dict(mtl_inter_ctc_weight=0.3, inter_ctc_layer_id=1, inter_kd_weight=0.5, kd_weight=0.5,
+                     reduce_main_loss_kd=True),
+    "inter_kd_noreduce": dict(mtl_inter_ctc_weight=0.3, inter_ctc_layer_id=2, inter_kd_weight=0.5,
+                              reduce_main_loss_kd=False),
+    "phone": dict(mtl_phone_ctc_weight=0.3, hie_mtl_phone=True, phone_vocab_size=12, inter_ctc_layer_id=1),
+    "phone_top": dict(mtl_phone_ctc_weight=0.2, hie_mtl_phone=False, phone_vocab_size=12, inter_ctc_layer_id=1),
+}
+KD_GRAD_KEYS = ["decoder.output.weight", "decoder.output.bias", "encoder.norm.weight", "encoder.conv.conv.0.weight",
+                "encoder.transformers.1.feed_forward.w2.weight", "encoder.transformers.0.self_attn.linear_q.weight"]
+
+
+def _soft_labels(seed, B, L, V, topk=5, lsm=0.1):
+    """soft labels shaped like datasets.create_soft_label (datasets.py:248-263): top-k teacher probabilities
+    scaled by 1-lsm, the remaining mass spread evenly"""
+    g = torch.Generator().manual_seed(seed)
+    soft = torch.full((B, L, V), lsm / (V - topk))
+    for b in range(B):
+        for i in range(L):
+            idx = torch.randperm(V, generator=g)[:topk]
+            pr = torch.softmax(2.0 * torch.randn(topk, generator=g), 0)
+            soft[b, i, idx] = pr * (1 - lsm)
+    return soft
+
+
+def run_kd():
+    """knowledge-distillation path -> kd_tiny.npz:
+    criteria.py losses + ctc_aligner.py on random inputs, and the CTC / Transformer decoders with
+    kd_weight > 0 on the l2_tiny / l3_tiny weights (loss, loss_dict, aligns, selected gradients,
+    the L2 norm of every gradient)."""
+    from asr.criteria import CTCAlignDistillLoss, DistillLoss, RNNTAlignDistillLoss, RNNTWordDistillLoss
+    from asr.modeling.decoders.ctc_aligner import CTCForcedAligner
+    out = {}
+    # ---- forced aligner + label mapping on random posteriors
+    g = torch.Generator().manual_seed(11)
+    B, T, V, L = 5, 23, 7, 6
+    logits = 3.0 * torch.randn(B, T, V, generator=g)
+    elens = torch.tensor([23, 19, 12, 7, 23])
+    ylens = torch.tensor([6, 4, 3, 1, 2])
+    ys = torch.randint(1, V, (B, L), generator=g)
+    ys[0, 2] = ys[0, 1]  # a repeated label: needs a blank in between
+    for b in range(B):
+        ys[b, ylens[b]:] = 0
+    aligns = CTCForcedAligner(blank_id=0)(torch.log_softmax(logits, -1), elens, ys, ylens)
+    out.update({"align/logits": logits.numpy(), "align/elens": elens.numpy(), "align/ys": ys.numpy(),
+                "align/ylens": ylens.numpy(), "align/aligns": aligns.numpy()})
+    for pos in ("all", "left", "mid", "right"):
+        fn = CTCAlignDistillLoss(vocab_size=V, position=pos)
+        maps = torch.full((B, T), -2, dtype=torch.long)
+        for b in range(B):
+            maps[b, :elens[b]] = fn._frame_to_label_mapping(aligns[b][:elens[b]].long(), int(elens[b]), int(ylens[b]))
+        out["align/map_" + pos] = maps.numpy()
+    # ---- the four distillation losses: values and logits gradients
+    soft = _soft_labels(3, B, L, V, topk=3)
+    for name, kw in (("cad_all", dict(soft_label_weight=1.0, position="all", lsm_prob=0.1)),
+                     ("cad_right", dict(soft_label_weight=0.4, position="right", lsm_prob=0.1)),
+                     ("cad_left_nonorm", dict(soft_label_weight=0.0, position="left", lsm_prob=0.2,
+                                              normalize_length=False, normalize_batch=False))):
+        z = logits.clone().requires_grad_(True)
+        loss = CTCAlignDistillLoss(vocab_size=V, blank_id=0, **kw)(z, ys, soft, aligns, elens, ylens)
+        loss.backward()
+        out[f"loss/{name}"] = loss.detach().numpy()
+        out[f"loss/{name}_grad"] = z.grad.numpy()
+    zl = (2.0 * torch.randn(B, L, V, generator=g))
+    for name, kw in (("distill", dict(soft_label_weight=0.3, lsm_prob=0.1)),
+                     ("distill_len", dict(soft_label_weight=0.7, lsm_prob=0.0, normalize_length=True,
+                                          normalize_batch=False))):
+        z = zl.clone().requires_grad_(True)
+        l, ls, lh = DistillLoss(vocab_size=V, **kw)(z, ys, soft, ylens)
+        l.backward()
+        out[f"loss/{name}"] = np.array([float(l), float(ls), float(lh)])
+        out[f"loss/{name}_grad"] = z.grad.numpy()
+    out["loss/dec_logits"] = zl.numpy()
+    out["loss/soft"] = soft.numpy()
+    Tr = 9
+    z4 = 2.0 * torch.randn(B, Tr, L + 1, V, generator=g)
+    xl4 = torch.tensor([9, 8, 6, 4, 9])
+    z = z4.clone().requires_grad_(True)
+    l = RNNTWordDistillLoss()(z, soft, xl4, ylens)
+    l.backward()
+    out["loss/rnnt_word"] = l.detach().numpy()
+    out["loss/rnnt_word_grad"] = z.grad.numpy()
+    al4 = torch.stack([torch.sort(torch.randint(0, int(xl4[b]), (L,), generator=g))[0] for b in range(B)])
+    z = z4.clone().requires_grad_(True)
+    l = RNNTAlignDistillLoss()(z, ys, soft, al4, xl4, ylens)
+    l.backward()
+    out["loss/rnnt_align"] = l.detach().numpy()
+    out["loss/rnnt_align_grad"] = z.grad.numpy()
+    out.update({"loss/rnnt_logits": z4.numpy(), "loss/rnnt_xlens": xl4.numpy(), "loss/rnnt_aligns": al4.numpy()})
+    # ---- CTC decoder with kd_weight > 0 on the l2_tiny weights
+    g2 = np.load(os.path.join(OUT, "l2_tiny.npz"))
+    sd2 = {k[3:]: torch.from_numpy(g2[k]) for k in g2.files if k.startswith("sd/")}
+    xs, xlens, ys2, ylens2, ys_in, ys_out = make_batch(1, COMMON["feat_dim"], COMMON["vocab_size"])
+    soft2 = _soft_labels(5, 4, ys2.shape[1], COMMON["vocab_size"])
+    out["model/soft_ctc"] = soft2.numpy()
+    for name, extra in KD_CTC_CASES.items():
+        model = ASR(make_params(dict(CONFIGS["l2_tiny"], **extra)), phase="train")
+        model.load_state_dict(sd2)
+        model.train()
+        loss, ld = model(xs, xlens, ys2, ylens2, ys_in, ys_out, soft_labels=soft2)
+        loss.backward()
+        out[f"model/{name}/loss"] = loss.detach().numpy()
+        for k, v in ld.items():
+            out[f"model/{name}/ld/{k}"] = v.detach().numpy()
+        grads = dict((n, p.grad) for n, p in model.named_parameters())
+        for k in KD_GRAD_KEYS:
+            out[f"model/{name}/grad/{k}"] = grads[k].numpy()
+        out[f"model/{name}/gnorms"] = np.array([float(v.norm()) for v in grads.values()])
+        with torch.no_grad():
+            model.load_state_dict(sd2)
+            eouts, elens2, _ = model.encoder(xs, xlens)
+            lg = model.decoder.output(eouts)
+            out[f"model/{name}/aligns"] = model.decoder.forced_aligner(torch.log_softmax(lg, -1), elens2, ys2,
+                                                                      ylens2).numpy()
+        print("kd", name, float(loss), {k: float(v) for k, v in ld.items()})
+    # ---- intermediate CTC (+ KD on it) and phone-level CTC (ctc.py:129-170), l2_tiny weights
+    gph = torch.Generator().manual_seed(21)
+    ps = torch.randint(1, 12, (4, 12), generator=gph)
+    plens = torch.tensor([12, 9, 7, 3])
+    for b in range(4):
+        ps[b, plens[b]:] = 0
+    out["model/ps"], out["model/plens"] = ps.numpy(), plens.numpy()
+    for name, extra in KD_INTER_CASES.items():
+        torch.manual_seed(31)
+        model = ASR(make_params(dict(CONFIGS["l2_tiny"], **extra)), phase="train")
+        missing = model.load_state_dict(sd2, strict=False)
+        for k in missing.missing_keys:  # the phone head is not part of l2_tiny: keep its seeded init
+            out[f"model/{name}/sd/{k}"] = model.state_dict()[k].clone().numpy()
+        model.train()
+        loss, ld = model(xs, xlens, ys2, ylens2, ys_in, ys_out, soft_labels=soft2, ps=ps, plens=plens)
+        loss.backward()
+        out[f"model/{name}/loss"] = loss.detach().numpy()
+        for k, v in ld.items():
+            out[f"model/{name}/ld/{k}"] = v.detach().numpy()
+        grads = dict((n, p.grad) for n, p in model.named_parameters())
+        for k in KD_GRAD_KEYS + [k for k in grads if "phone_output" in k]:
+            out[f"model/{name}/grad/{k}"] = grads[k].numpy()
+        out[f"model/{name}/gnorms"] = np.array([float(v.norm()) for v in grads.values()])
+        print("kd", name, float(loss), {k: float(v) for k, v in ld.items()})
+    # ---- Transformer decoder with kd_weight > 0 (DistillLoss on ys_out, aux CTC without KD) on l3_tiny
+    g3 = np.load(os.path.join(OUT, "l3_tiny.npz"))
+    sd3 = {k[3:]: torch.from_numpy(g3[k]) for k in g3.files if k.startswith("sd/") and not k.startswith("sd/lm.")}
+    sd3 = {k: v for k, v in sd3.items() if k.startswith("encoder.") or k.startswith("decoder.")}
+    soft3 = _soft_labels(6, 4, ys_out.shape[1], COMMON["vocab_size"])
+    out["model/soft_att"] = soft3.numpy()
+    model = ASR(make_params(dict(L3, kd_weight=0.4, reduce_main_loss_kd=False)), phase="train")
+    model.load_state_dict(sd3)
+    model.train()
+    loss, ld = model(xs, xlens, ys2, ylens2, ys_in, ys_out, soft_labels=soft3)
+    loss.backward()
+    out["model/att/loss"] = loss.detach().numpy()
+    for k, v in ld.items():
+        out[f"model/att/ld/{k}"] = v.detach().numpy()
+    grads = dict((n, p.grad) for n, p in model.named_parameters())
+    for k in ("decoder.output.weight", "decoder.embed.weight", "decoder.transformers.1.src_attn.linear_k.weight",
+              "encoder.norm.weight"):
+        out[f"model/att/grad/{k}"] = grads[k].numpy()
+    out["model/att/gnorms"] = np.array([float(v.norm()) for v in grads.values()])
+    print("kd att", float(loss), {k: float(v) for k, v in ld.items()})
+    # ---- RNN-T with word-level distillation (rnn_transducer.py:127-141) on the l4_tiny weights; the
+    # transducer loss itself is oracle.rnnt.rnnt_loss plugged in for the absent warp_rnnt, as in run_l4
+    sys.path.insert(0, "/root/repo")
+    from oracle import rnnt as orn
+    sys.modules["warp_rnnt"].rnnt_loss = orn.rnnt_loss
+    sys.modules["warp_rnnt"].__version__ = "oracle-restatement"
+    import asr.modeling.decoders.rnn_transducer as rt
+    rt.warp_rnnt = sys.modules["warp_rnnt"]
+    g4 = np.load(os.path.join(OUT, "l4_tiny.npz"))
+    sd4 = {k[3:]: torch.from_numpy(g4[k]) for k in g4.files if k.startswith("sd/")}
+    soft4 = _soft_labels(8, 4, ys2.shape[1], COMMON["vocab_size"])
+    out["model/soft_rnnt"] = soft4.numpy()
+    for name, extra in (("rnnt_word", dict(kd_weight=0.3, kd_type="word", reduce_main_loss_kd=False)),
+                        ("rnnt_word_reduce", dict(kd_weight=0.5, kd_type="word", reduce_main_loss_kd=True))):
+        model = ASR(make_params(dict(L4, **extra)), phase="train")
+        model.load_state_dict(sd4)
+        model.train()
+        loss, ld = model(xs, xlens, ys2, ylens2, ys_in, ys_out, soft_labels=soft4)
+        loss.backward()
+        out[f"model/{name}/loss"] = loss.detach().numpy()
+        for k, v in ld.items():
+            out[f"model/{name}/ld/{k}"] = v.detach().numpy()
+        grads = dict((n, p.grad) for n, p in model.named_parameters())
+        for k in ("decoder.output.weight", "decoder.w_dec.weight", "decoder.rnns.1.weight_hh_l0", "decoder.embed.weight",
+                  "encoder.norm.weight", "decoder.ctc.output.bias"):
+            out[f"model/{name}/grad/{k}"] = grads[k].numpy()
+        out[f"model/{name}/gnorms"] = np.array([float(v.norm()) for v in grads.values()])
+        print("kd", name, float(loss), {k: float(v) for k, v in ld.items()})
+    np.savez_compressed(os.path.join(OUT, "kd_tiny.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ctc", "l3", "l4"]
     if "ctc" in which:
@@ -364,6 +559,8 @@ if __name__ == "__main__":
         run_l4()
     if "hostio" in which:
         run_hostio()
+    if "kd" in which:  # needs l2_tiny.npz and l3_tiny.npz (reads their weights)
+        run_kd()
     if "rnntbeam" in which:  # needs l4_tiny.npz (reads its weights)
         run_rnnt_beam()
     if "ctcbeam" in which:  # needs l2_tiny.npz and l3_tiny.npz (reads their weights)

@@ -86,3 +86,32 @@ def load_rnnt_beam_golden():
             k += n
         out[bw] = per
     return out
+
+
+KD_CTC_CASES = {
+    "ctc_all": dict(kd_weight=0.5, reduce_main_loss_kd=False),
+    "ctc_mid": dict(kd_weight=0.3, reduce_main_loss_kd=True, kd_ctc_soft_label_weight=0.6, kd_ctc_position="mid"),
+}
+KD_INTER_CASES = {
+    "inter": dict(mtl_inter_ctc_weight=0.3, inter_ctc_layer_id=1),
+    "inter_kd": dict(mtl_inter_ctc_weight=0.3, inter_ctc_layer_id=1, inter_kd_weight=0.5, kd_weight=0.5,
+                     reduce_main_loss_kd=True),
+    "inter_kd_noreduce": dict(mtl_inter_ctc_weight=0.3, inter_ctc_layer_id=2, inter_kd_weight=0.5,
+                              reduce_main_loss_kd=False),
+    "phone": dict(mtl_phone_ctc_weight=0.3, hie_mtl_phone=True, phone_vocab_size=12, inter_ctc_layer_id=1),
+    "phone_top": dict(mtl_phone_ctc_weight=0.2, hie_mtl_phone=False, phone_vocab_size=12, inter_ctc_layer_id=1),
+}
+KD_RNNT_CASES = {"rnnt_word": dict(kd_weight=0.3, kd_type="word", reduce_main_loss_kd=False),
+                 "rnnt_word_reduce": dict(kd_weight=0.5, kd_type="word", reduce_main_loss_kd=True)}
+KD_ATT = dict(kd_weight=0.4, reduce_main_loss_kd=False)
+CAD_CASES = {"cad_all": dict(soft_label_weight=1.0, position="all", lsm_prob=0.1),
+             "cad_right": dict(soft_label_weight=0.4, position="right", lsm_prob=0.1),
+             "cad_left_nonorm": dict(soft_label_weight=0.0, position="left", lsm_prob=0.2, normalize_length=False,
+                                     normalize_batch=False)}
+DISTILL_CASES = {"distill": dict(soft_label_weight=0.3, lsm_prob=0.1),
+                 "distill_len": dict(soft_label_weight=0.7, lsm_prob=0.0, normalize_length=True, normalize_batch=False)}
+
+
+def load_kd_golden():
+    z = np.load(os.path.join(GOLDEN, "kd_tiny.npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
