@@ -8,6 +8,8 @@
 //                         (asr/modeling/decoders/ctc_aligner.py:139-221): per frame the arg-max of
 //                         alpha*beta over the lattice states reachable from the previous choice.
 //   emoasr_ctc_label_map  CTCAlignDistillLoss._frame_to_label_mapping (asr/criteria.py:170-215).
+//   emoasr_rnnt_best_path the alignment walk of RNNTForcedAligner.__call__
+//                         (asr/modeling/decoders/rnnt_aligner.py:158-198) over the transducer alpha+beta grid.
 #include "common.h"
 #include "../../include/emoasr_hip.h"
 
@@ -197,7 +199,38 @@ __global__ __launch_bounds__(256) void ctc_label_map_kernel(int Tn, const int* _
   if (threadIdx.x == 0) count[b] = total;
 }
 
+// One wave per utterance; lane 0 walks the lattice (rnnt_aligner.py:186-196): from (0,0), while t+1 < T and
+// u < U: move to the next frame if alpha+beta is larger there than one label up, else emit label u at frame t.
+// Labels not emitted before the last frame keep frame 0 (the reference's zero-initialised best_aligns).
+__global__ __launch_bounds__(64) void rnnt_best_path_kernel(int Tn, int U, const float* __restrict__ alpha,
+                                                            const float* __restrict__ beta,
+                                                            const int* __restrict__ elens,
+                                                            const int* __restrict__ ylens, int* __restrict__ aligns) {
+  const int b = blockIdx.x;
+  int* out = aligns + (long)b * (U - 1);
+  for (int i = threadIdx.x; i < U - 1; i += 64) out[i] = 0;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const int T = min(elens[b], Tn), Ub = min(ylens[b], U - 1);
+  const float* a = alpha + (long)b * Tn * U;
+  const float* bt = beta + (long)b * Tn * U;
+  int t = 0, u = 0;
+  while (t + 1 < T && u < Ub) {
+    const long down = (long)(t + 1) * U + u, right = (long)t * U + u + 1;
+    if (a[down] + bt[down] > a[right] + bt[right]) ++t;
+    else { out[u] = t; ++u; }
+  }
+}
+
 }  // namespace
+
+extern "C" int emoasr_rnnt_best_path(int B, int Tn, int U, const float* alpha, const float* beta, const int* elens,
+                                     const int* ylens, int* aligns, void* stream) {
+  if (B == 0 || U <= 1) return 0;
+  rnnt_best_path_kernel<<<B, 64, 0, (hipStream_t)stream>>>(Tn, U, alpha, beta, elens, ylens, aligns);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int emoasr_soft_ce(int dtype, int R, int V, const void* logits, long ld, const int* lrow,
                               const float* soft, long lds, const int* src, const int* hard, const float* w_soft,

@@ -985,14 +985,17 @@ class _RNNTMixin:
 
     def rnnt_backward(self, st, gscale_dev, extra_dlogits=None):
         """-> d_eouts [B,T,d]; accumulates decoder gradients (the logits buffer is overwritten by its gradient).
-        extra_dlogits [B*T*U,V]: gradient of another loss on the same logits (distillation), added in."""
+        extra_dlogits [B*T*U,V] (or (rows int64 [R], [R,V])): gradient of another loss on the same logits
+        (distillation), added in."""
         with ops.stream_scope():
             A, J, H = self.arena, self.r_J, self.r_H
             A.attach_grads()
             B, T, U = st.B, st.T, st.U
             dz = ops.rnnt_grad(st.logits, st.ctx, st.nll, st.labels, st.elens, st.ylens, st.blank, 1.0 / B, gscale_dev,
                                out=st.logits)
-            if extra_dlogits is not None:
+            if isinstance(extra_dlogits, tuple):  # (row indices, a few gradient rows)
+                dz.view(-1, dz.shape[-1]).index_add_(0, extra_dlogits[0], extra_dlogits[1])
+            elif extra_dlogits is not None:
                 ops.strided_copy(extra_dlogits.view(dz.shape), out=dz, accumulate=True)
             V = dz.shape[-1]
             dz2 = dz.view(B * T * U, V)

@@ -169,6 +169,7 @@ SIGNATURES = {
     "emoasr_soft_ce": [I, I, I, P, L, P, P, L, P, P, P, P, F, P, F, P, P, L, P],
     "emoasr_ctc_best_path": [I, I, I, P, P, P, P, P, P, I, P, P],
     "emoasr_ctc_label_map": [I, I, P, P, I, I, P, P, P],
+    "emoasr_rnnt_best_path": [I, I, I, P, P, P, P, P, P],
     "emoasr_log_softmax": [I, I, I, P, L, P, L, F, P, L, P],
     "emoasr_topk": [I, I, I, P, L, P, L, P, P, P, P],
     "emoasr_ctc_prefix_init": [I, I, P, I, P, P],

@@ -12,19 +12,14 @@ scores/logits/aligns (:339-346).
 import torch.nn as nn
 
 from ..functions import rnnt_apply, rnnt_beam_apply, rnnt_greedy_apply
+from ...criteria import RNNTAlignDistillLoss, RNNTWordDistillLoss
 from .ctc import CTCDecoder
+from .rnnt_aligner import RNNTForcedAligner
 
 
 class RNNTDecoder(nn.Module):
     def __init__(self, params, phase="train"):
         super().__init__()
-        if params.kd_weight > 0 and phase == "train":
-            self.kd_type = params.kd_type
-            self.reduce_main_loss_kd = params.reduce_main_loss_kd
-            if self.kd_type != "word":
-                # kd_type "align" needs RNNTForcedAligner (Numba CUDA kernels, rnnt_aligner.py:14-198); the loss
-                # itself exists (criteria.RNNTAlignDistillLoss)
-                raise NotImplementedError("emoasr_amd: RNN-T distillation is provided for kd_type 'word' only")
         self.dec_num_layers = params.dec_num_layers
         self.dec_hidden_size = params.dec_hidden_size
         self.eos_id = params.eos_id
@@ -43,13 +38,23 @@ class RNNTDecoder(nn.Module):
         self.output = nn.Linear(params.joint_hidden_size, params.vocab_size)
         if self.mtl_ctc_weight > 0:
             self.ctc = CTCDecoder(params, prefix="decoder.ctc")
+        if params.kd_weight > 0 and phase == "train":
+            self.kd_type = params.kd_type
+            self.reduce_main_loss_kd = params.reduce_main_loss_kd
+            if self.kd_type == "word":
+                self.transducer_kd_loss = RNNTWordDistillLoss()
+            elif self.kd_type == "align":
+                self.transducer_kd_loss = RNNTAlignDistillLoss()
+                self.forced_aligner = RNNTForcedAligner(blank_id=self.blank_id)
+            else:
+                raise NotImplementedError(f"emoasr_amd: unknown kd_type {self.kd_type!r}")
         self._owner = None
 
     def forward(self, eouts, elens, eouts_inter=None, ys=None, ylens=None, ys_in=None, ys_out=None,
                 soft_labels=None, ps=None, plens=None):
         kd = None
         if self.kd_weight > 0 and soft_labels is not None:
-            kd = (soft_labels, self.kd_weight, self.reduce_main_loss_kd)
+            kd = (soft_labels, self.kd_weight, self.reduce_main_loss_kd, self.kd_type)
         loss, loss_rnnt, loss_ctc, logits, loss_kd = rnnt_apply(self, eouts, elens, ys, ylens, ys_in, kd)
         loss_dict = {"loss_rnnt": loss_rnnt}
         if self.mtl_ctc_weight > 0:

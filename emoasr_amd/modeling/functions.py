@@ -271,14 +271,29 @@ class _RNNTFn(torch.autograd.Function):
         loss_kd = torch.zeros_like(loss_rnnt)
         ctx.kd = None
         if kd is not None:
-            soft, kd_w, reduce = kd
+            soft, kd_w, reduce, kd_type = kd
             B, T, U, V = logits.shape
             L = soft.shape[1]
-            src, w = rnnt_word_rows(B, T, U, L, elens_dev, ylens_host, logits.device)
-            rows, _ = ops.soft_ce(logits.view(B * T * U, V), soft.view(B * L, V), src, None, w, None, 0.0)
+            if kd_type == "word":
+                src, w = rnnt_word_rows(B, T, U, L, elens_dev, ylens_host, logits.device)
+                z, lrow = logits.view(B * T * U, V), None
+            else:
+                # "align" (rnn_transducer.py:131-135): forced alignment from the loss lattices, then
+                # RNNTAlignDistillLoss -- whose loop keeps only the LAST label of each utterance
+                # (criteria.py:271-281), i.e. one lattice cell per utterance
+                alpha, beta = st.ctx[3], st.ctx[4]
+                aligns = ops.rnnt_best_path(alpha, beta, st.elens, st.ylens)
+                bi = torch.arange(B, device=logits.device, dtype=torch.int32)
+                u = (st.ylens - 1).clamp(min=0)
+                t = aligns.gather(1, u.long()[:, None].clamp(max=max(aligns.shape[1] - 1, 0)))[:, 0]
+                lrow = ((bi * T + t) * U + u).long()
+                z = logits.view(B * T * U, V).index_select(0, lrow)  # [B,V], kept: the logits get overwritten
+                src = (bi * L + u).to(torch.int32)
+                w = (1.0 / B) / st.ylens.clamp(min=1).to(torch.float32)
+            rows, _ = ops.soft_ce(z, soft.view(B * L, V), src, None, w, None, 0.0)
             loss_kd = rows.sum()
             loss = ((1 - kd_w) * loss if reduce else loss) + kd_w * loss_kd
-            ctx.kd = (soft, kd_w, (1 - kd_w) if reduce else 1.0, src, w)
+            ctx.kd = (soft, kd_w, (1 - kd_w) if reduce else 1.0, src, w, z, lrow)
         ctx.eng, ctx.st, ctx.cctx, ctx.eouts = eng, st, cctx, eouts
         ctx.mark_non_differentiable(logits)
         return loss, loss_rnnt, loss_ctc, logits, loss_kd
@@ -289,11 +304,11 @@ class _RNNTFn(torch.autograd.Function):
         eng = ctx.eng
         main, extra = 1.0, None
         if ctx.kd is not None:  # before rnnt_backward overwrites the logits with their gradient
-            soft, kd_w, main, src, w = ctx.kd
-            z = ctx.st.logits
-            B, T, U, V = z.shape
-            _, extra = ops.soft_ce(z.view(B * T * U, V), soft.view(-1, V), src, None,
-                                   w * (g_total * kd_w + g_kd).to(torch.float32), None, 0.0, want_grad=True)
+            soft, kd_w, main, src, w, z, lrow = ctx.kd
+            V = z.shape[-1]
+            _, extra = ops.soft_ce(z, soft.view(-1, V), src, None, w * (g_total * kd_w + g_kd).to(torch.float32), None,
+                                   0.0, want_grad=True)
+            extra = extra if lrow is None else (lrow, extra)
         deouts = eng.rnnt_backward(ctx.st, (g_total * main + g_rnnt).to(torch.float32).reshape(1), extra)
         if ctx.cctx is not None:
             g_ctc_eff = (g_total * (main * eng.mtl_ctc) + g_ctc).to(torch.float32).reshape(1)
@@ -310,9 +325,27 @@ def rnnt_apply(dec, eouts, elens, ys, ylens, ys_in, kd=None):
     ys_host = (ys.cpu() if torch.is_tensor(ys) else torch.as_tensor(ys))[:, :L]
     ys_in = (ys_in.cpu() if torch.is_tensor(ys_in) else torch.as_tensor(ys_in))[:, : L + 1]
     if kd is not None:
-        kd = (torch.as_tensor(kd[0]).to(device=eouts.device, dtype=torch.float32).contiguous(), float(kd[1]), bool(kd[2]))
+        kd = (torch.as_tensor(kd[0]).to(device=eouts.device, dtype=torch.float32).contiguous(), float(kd[1]), bool(kd[2]),
+              kd[3])
     return _RNNTFn.apply(eng, dec.training, eouts, _elens_dev(eouts, elens), ys_host, ylens_host, ys_in, dec.blank_id, kd,
                          *eng.arena.params)
+
+
+def rnnt_forced_align_apply(log_probs, elens, ys, ylens, blank):
+    """RNNTForcedAligner.__call__ (rnnt_aligner.py:158-198) -> int32 [B,L] (device)"""
+    from .. import ops
+    dev = log_probs.device
+    z = log_probs.contiguous()
+    B, T, U, V = z.shape
+    labels = torch.as_tensor(ys)[:, : max(U - 1, 1)].to(torch.int32)
+    if labels.shape[1] < max(U - 1, 1):
+        labels = torch.nn.functional.pad(labels, (0, max(U - 1, 1) - labels.shape[1]))
+    labels = labels.contiguous().to(dev)
+    el = torch.as_tensor(elens).to(torch.int32).to(dev)
+    yl = torch.as_tensor(ylens).to(torch.int32).to(dev)
+    with ops.stream_scope():
+        (_, _, _, alpha, beta), _ = ops.rnnt_forward(z, labels, el, yl, blank)
+        return ops.rnnt_best_path(alpha, beta, el, yl)
 
 
 def rnnt_greedy_apply(dec, eouts, elens):

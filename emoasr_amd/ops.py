@@ -549,6 +549,14 @@ def ctc_best_path(lp, alpha, beta, labels, elens, ylens, blank):
     return aligns
 
 
+def rnnt_best_path(alpha, beta, elens, ylens):
+    """lattices of rnnt_forward f32 [B,T,U] -> aligns int32 [B,U-1] (rnnt_aligner.py:186-196)"""
+    B, T, U = alpha.shape
+    aligns = torch.zeros(B, max(U - 1, 0), device=alpha.device, dtype=torch.int32)
+    lib.call("emoasr_rnnt_best_path", B, T, U, _p(alpha), _p(beta), _p(elens), _p(ylens), _p(aligns), _stream())
+    return aligns
+
+
 LABEL_POSITIONS = {"all": 0, "left": 1, "mid": 2, "right": 3}
 
 

@@ -307,6 +307,12 @@ int emoasr_ctc_best_path(int B, int Tn, int Lmax, const float* lp, const float* 
 int emoasr_ctc_label_map(int B, int Tn, const int* aligns, const int* xlens, int blank, int position, int* label_map,
                          int* count, void* stream);
 
+/* RNNTForcedAligner.__call__ (decoders/rnnt_aligner.py:158-198) on the lattices of emoasr_rnnt_forward (alpha, beta
+ * f32 [B,Tn,U]): aligns (int32 [B,U-1]) = frame at which each label is emitted along the greedy alpha+beta walk;
+ * labels not reached before the last frame keep 0. */
+int emoasr_rnnt_best_path(int B, int Tn, int U, const float* alpha, const float* beta, const int* elens,
+                          const int* ylens, int* aligns, void* stream);
+
 /* ---- joint CTC/attention beam search (decoders/transformer.py:161-294, ctc_score.py:13-85) ---- */
 /* out[m,v] = log_softmax(x[m,:V])[v] + mu*add[m,v]   (add may be NULL; f32 out) */
 int emoasr_log_softmax(int dtype, int M, int V, const void* x, long ldx, const float* add, long lda, float mu,

@@ -270,3 +270,62 @@ def rnnt_decoder_forward_kd(sd, cfg, eouts, elens, ys, ylens, ys_in, soft_labels
         loss = loss + cfg.kd_weight * ld["loss_kd"]
     ld["loss_total"] = loss
     return loss, ld, logits
+
+
+def rnnt_forced_align(log_probs, elens, ys, ylens, blank=0):
+    """RNNTForcedAligner.__call__ (rnnt_aligner.py:158-198) -> int32 [B, maxU-1].
+
+    alpha[t,u] / beta[t,u]: the transducer forward / backward variables (rnnt_aligner.py:14-152, beta[T-1,U]
+    = the final blank); the walk starts at (0,0) and, while t+1 < T and u < U, moves down in time when
+    (alpha+beta)[t+1,u] > (alpha+beta)[t,u+1], else emits label u at frame t.  Labels not emitted before the
+    last frame keep 0.  PARITY UNPINNED for the lattice part: the reference's Numba CUDA kernels cannot run
+    here (numba absent); the recursion is the standard one also used by oracle.rnnt.rnnt_nll."""
+    B, Tm, Um, _ = log_probs.shape
+    out = torch.zeros(B, Um - 1, dtype=torch.int32)
+    lp = log_probs.double()
+    for b in range(B):
+        T, U = int(elens[b]), int(ylens[b])
+        lab = [int(v) for v in ys[b, :U]]
+        NEG = float("-inf")
+        alpha = torch.full((T, U + 1), NEG, dtype=torch.float64)
+        beta = torch.full((T, U + 1), NEG, dtype=torch.float64)
+        for t in range(T):
+            for u in range(U + 1):
+                if t == 0 and u == 0:
+                    alpha[0, 0] = 0.0
+                    continue
+                a = alpha[t - 1, u] + lp[b, t - 1, u, blank] if t > 0 else torch.tensor(NEG, dtype=torch.float64)
+                e = alpha[t, u - 1] + lp[b, t, u - 1, lab[u - 1]] if u > 0 else torch.tensor(NEG, dtype=torch.float64)
+                alpha[t, u] = torch.logaddexp(a, e)
+        for t in reversed(range(T)):
+            for u in reversed(range(U + 1)):
+                if t == T - 1 and u == U:
+                    beta[t, u] = lp[b, t, u, blank]
+                    continue
+                a = beta[t + 1, u] + lp[b, t, u, blank] if t < T - 1 else torch.tensor(NEG, dtype=torch.float64)
+                e = beta[t, u + 1] + lp[b, t, u, lab[u]] if u < U else torch.tensor(NEG, dtype=torch.float64)
+                beta[t, u] = torch.logaddexp(a, e)
+        post = alpha + beta
+        t = u = 0
+        while t + 1 < T and u < U:
+            if post[t + 1, u] > post[t, u + 1]:
+                t += 1
+            else:
+                out[b, u] = t
+                u += 1
+    return out
+
+
+def rnnt_decoder_forward_kd_align(sd, cfg, eouts, elens, ys, ylens, ys_in, soft_labels, prefix="decoder"):
+    """RNNTDecoder.forward with kd_type == "align" (rnn_transducer.py:127-141)"""
+    from .rnnt import rnnt_decoder_forward
+    loss, ld, logits = rnnt_decoder_forward(sd, cfg, eouts, elens, ys, ylens, ys_in, prefix)
+    ld = dict(ld)
+    aligns = rnnt_forced_align(torch.log_softmax(logits.detach(), -1), elens, ys, ylens, cfg.blank_id)
+    ld["loss_kd"] = rnnt_align_distill_loss(logits, ys, soft_labels, aligns, elens, ylens)
+    if cfg.reduce_main_loss_kd:
+        loss = (1 - cfg.kd_weight) * loss + cfg.kd_weight * ld["loss_kd"]
+    else:
+        loss = loss + cfg.kd_weight * ld["loss_kd"]
+    ld["loss_total"] = loss
+    return loss, ld, logits, aligns

@@ -63,5 +63,5 @@ def test_unbuilt_variants_fail_loudly():
     from tests.util import CONFIGS
     with pytest.raises(NotImplementedError):
         ASR(SimpleNamespace(**dict(CONFIGS["l2_tiny"], encoder_type="rnn")))
-    with pytest.raises(NotImplementedError):  # alignment-level RNN-T distillation needs the Numba aligner
-        ASR(SimpleNamespace(**dict(CONFIGS["l4_tiny"], kd_weight=0.5, kd_type="align", reduce_main_loss_kd=False)))
+    with pytest.raises(NotImplementedError):
+        ASR(SimpleNamespace(**dict(CONFIGS["l4_tiny"], kd_weight=0.5, kd_type="sequence", reduce_main_loss_kd=False)))

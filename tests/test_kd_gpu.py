@@ -195,6 +195,54 @@ def test_rnnt_decoder_with_word_kd(dev, dtype, case):
     _compare(model, loss, ld, g, case, dtype)
 
 
+def test_rnnt_forced_aligner(dev):
+    """HIP lattice + walk against the oracle restatement (the reference's Numba kernels cannot run here)"""
+    from emoasr_amd.modeling.decoders.rnnt_aligner import RNNTForcedAligner
+    from oracle import distill as od
+    gen = torch.Generator().manual_seed(4)
+    B, T, L, V = 5, 19, 6, 9
+    lp = torch.log_softmax(3.0 * torch.randn(B, T, L + 1, V, generator=gen), -1)
+    ys = torch.randint(1, V, (B, L), generator=gen)
+    elens, ylens = torch.tensor([19, 15, 9, 2, 1]), torch.tensor([6, 4, 6, 3, 2])
+    got = RNNTForcedAligner(blank_id=0)(lp.to(dev), elens, ys, ylens)
+    want = od.rnnt_forced_align(lp, elens, ys, ylens)
+    assert got.dtype == torch.int32 and torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_rnnt_decoder_with_align_kd(dev, dtype):
+    """kd_type 'align' (rnn_transducer.py:131-135) against the oracle composition on the l4_tiny weights"""
+    from oracle import distill as od
+    from oracle import model as om
+    g = load_kd_golden()
+    extra = dict(kd_weight=0.4, kd_type="align", reduce_main_loss_kd=True)
+    model, g4 = _model("l4_tiny", extra, dtype, dev, g, "none")
+    cfg, sd, _ = load_golden("l4_tiny")
+    cfg = SimpleNamespace(**dict(CONFIGS["l4_tiny"], **extra))
+    sd = {k: v.clone() for k, v in sd.items()}
+    params = {k: v for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    for v in params.values():
+        v.requires_grad_(True)
+    soft = g["model/soft_rnnt"]
+    eouts, elens = om.encoder_forward(sd, cfg, g4["xs"], g4["xlens"], training=True)
+    lref, ldref, _, aligns = od.rnnt_decoder_forward_kd_align(sd, cfg, eouts, elens, g4["ys"], g4["ylens"], g4["ys_in"], soft)
+    lref.backward()
+    model.train()
+    loss, ld = model(g4["xs"].to(dev), g4["xlens"], g4["ys"], g4["ylens"], g4["ys_in"], g4["ys_out"],
+                     soft_labels=soft.to(dev))
+    loss.backward()
+    ltol = 1e-3 if dtype == torch.float32 else 5e-2
+    assert sorted(ld) == sorted(ldref)
+    for k in ldref:
+        assert abs(ld[k].item() - float(ldref[k])) < ltol * abs(float(ldref[k])), (k, ld[k].item(), float(ldref[k]))
+    grads = {n: p.grad.float().cpu() for n, p in model.named_parameters()}
+    for name in ("decoder.output.weight", "decoder.w_dec.weight", "decoder.embed.weight", "encoder.norm.weight",
+                 "encoder.transformers.1.feed_forward.w2.weight"):
+        a, b = grads[name].flatten(), params[name].grad.flatten()
+        cos = torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)
+        assert cos > (0.9999 if dtype == torch.float32 else 0.97), (name, cos.item())
+
+
 def test_aux_ctc_greedy_uses_its_own_head(dev):
     """decode_ctc_weight == 1 short-circuits to greedy CTC on decoder.ctc.output (decoders/transformer.py:176-179)"""
     from oracle import model as om

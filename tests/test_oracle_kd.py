@@ -158,3 +158,29 @@ def test_rnnt_decoder_with_word_kd(case):
     for k in [k for k in g if k.startswith(f"model/{case}/grad/")]:
         name = k.split("/grad/")[1]
         assert (grads[name] - g[k]).abs().max() < 1e-4 * max(1.0, g[k].abs().max().item()), name
+
+
+def test_rnnt_forced_align_walk():
+    """the lattice part is unpinned (numba absent); the walk is checked on a case decidable by hand:
+    a sharply peaked posterior must reproduce the planted alignment, and labels left over when the last
+    frame is reached keep frame 0 (rnnt_aligner.py:186-196)."""
+    T, U, V = 6, 3, 5
+    labels = torch.tensor([[1, 2, 3]])
+    emit_at = [1, 1, 4]  # frame at which each label is emitted
+    z = torch.full((1, T, U + 1, V), -8.0)
+    u = 0
+    for t in range(T):
+        while u < U and emit_at[u] == t:
+            z[0, t, u, labels[0, u]] = 8.0
+            u += 1
+        z[0, t, u, 0] = 8.0
+    lp = torch.log_softmax(z, -1)
+    assert od.rnnt_forced_align(lp, [T], labels, [U]).tolist() == [emit_at]
+    # labels forced onto the last frame are never written by the walk
+    z2 = torch.full((1, T, U + 1, V), -8.0)
+    z2[0, :, 0, 0] = 8.0
+    z2[0, T - 1, 0, 1] = 9.0
+    z2[0, T - 1, 1, 2] = 9.0
+    z2[0, T - 1, 2, 3] = 9.0
+    z2[0, T - 1, 3, 0] = 9.0
+    assert od.rnnt_forced_align(torch.log_softmax(z2, -1), [T], labels, [U]).tolist() == [[0, 0, 0]]
