@@ -13,6 +13,7 @@ Reference behaviour being reproduced (file:line in /root/reference):
   CTC          asr/modeling/decoders/ctc.py:103-115,176-201
 """
 import math
+import weakref
 import os
 
 import torch
@@ -25,6 +26,23 @@ _ALIGN = 64  # arena slot alignment in elements (256 B in f32, 128 B in bf16)
 
 def _cfg(cfg, key, default=None):
     return getattr(cfg, key) if hasattr(cfg, key) else default
+
+
+_ARENAS = weakref.WeakSet()
+
+
+def arena_of(params):
+    """the live ParamArena that owns these parameter tensors (their .data are views of its flat buffer);
+    LookupError before the model has been bound on the device"""
+    params = list(params)
+    if params:
+        ptr = params[0].data_ptr()
+        for a in list(_ARENAS):
+            lo = a.flat.data_ptr()
+            if lo <= ptr < lo + a.size * 4 and a.bound():
+                return a
+    raise LookupError("emoasr_amd: these parameters are not bound to a device arena yet (move the model to the GPU and "
+                      "run model.engine() or one forward pass)")
 
 
 class ParamArena:
@@ -81,6 +99,7 @@ class ParamArena:
                 self.gviews[n] = self.grad[o:o + p.numel()].view(p.shape)
                 p.grad = self.gviews[n]
         self.refresh_shadow()
+        _ARENAS.add(self)
 
     def bound(self):
         return all(p.data_ptr() == self.pviews[n].data_ptr() for n, p in zip(self.names, self.params))

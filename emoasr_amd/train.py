@@ -89,3 +89,81 @@ class ArenaAdam:
         self._step = sd["_step"]
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
+
+
+def _world(group=None):
+    import torch.distributed as dist
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def train_step(model, optimizer, data, params, device, no_grad=False, empty_cache=False, group=None, sync=True):
+    """One micro-batch of asr/train_asr.py:35-97: forward, loss / accum_grad, backward; unless `no_grad`
+    (= still accumulating), clip to params.clip_grad_norm, skip the update on a NaN gradient norm, step,
+    zero_grad.  -> loss_dict of floats divided by accum_grad (`sync=False`: 0-dim device tensors, no
+    host synchronisation).
+
+    With `emoasr_amd.optimizers.Adam` underneath, norm / clip / NaN-skip / update are the fused HIP step
+    (no host round trip, so the reference's "do not update because of nan grad_norm" warning is not
+    logged); with any torch optimizer the reference's sequence runs literally.  One process per GPU: the
+    gradient arena is summed over the ranks once per optimizer step and scaled by 1/world, which is
+    nn.DataParallel's mean of replica losses (train_asr.py:67-71)."""
+    import math
+
+    from .optimizers import Adam as HipAdam
+    to = lambda k: data[k].to(device) if k in data else None
+    loss, loss_dict = model(xs=to("xs"), xlens=data["xlens"], ys=data["ys"], ylens=data["ylens"], ys_in=data["ys_in"],
+                            ys_out=data["ys_out"], soft_labels=to("soft_labels"), ps=data.get("ps"),
+                            plens=data.get("plens"))
+    accum = params.accum_grad
+    if sync:
+        loss_dict = {k: v.item() / accum for k, v in loss_dict.items()}
+    else:
+        loss_dict = {k: v.detach() / accum for k, v in loss_dict.items()}
+    (loss / accum).backward()
+    if not no_grad:
+        base = getattr(optimizer, "optimizer", optimizer)
+        world = _world(group)
+        if isinstance(base, HipAdam):
+            if world > 1:
+                allreduce_sum_(model.engine().arena.grad, group)
+            base.clip_grad_norm, base.grad_mult = params.clip_grad_norm, 1.0 / world
+            optimizer.step()
+        else:
+            if world > 1:
+                for p in model.parameters():
+                    if p.grad is not None:
+                        allreduce_sum_(p.grad, group)
+                        p.grad.div_(world)
+            grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), params.clip_grad_norm)
+            if math.isnan(grad_norm):
+                import logging
+                logging.warning("do not update because of nan grad_norm")
+            else:
+                optimizer.step()
+        optimizer.zero_grad()
+        if empty_cache:
+            torch.cuda.empty_cache()
+    return loss_dict
+
+
+def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False, group=None, log=None):
+    """One epoch of asr/train_asr.py:100-143: every accum_grad-th micro-batch steps the optimizer; the
+    running loss_dict sums are logged every params.log_step optimizer steps (the only host
+    synchronisation of the loop)."""
+    import logging
+    log = log or logging.info
+    optimizer.update_epoch()
+    step, sums = 0, {}
+    n_total = len(dataloader) // params.accum_grad if hasattr(dataloader, "__len__") else -1
+    for accum_step, data in enumerate(dataloader):
+        stepping = (accum_step + 1) % params.accum_grad == 0
+        loss_dict = train_step(model, optimizer, data, params, device, no_grad=not stepping,
+                               empty_cache=empty_cache and stepping, group=group, sync=False)
+        step += int(stepping)
+        for k, v in loss_dict.items():
+            sums[k] = sums[k] + v if k in sums else v
+        if stepping and step % params.log_step == 0:
+            detail = " ".join(f"{k}: {float(v) / params.log_step:.3f}" for k, v in sums.items())
+            log(f"epoch = {(epoch + 1):>2} step = {step:>6} / {n_total:>6} lr = {optimizer._lr:.5f} " + detail)
+            sums = {}
+    return step

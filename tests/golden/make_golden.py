@@ -320,8 +320,48 @@ def run_hostio():
         pack_cases.append(dict(xlens=xlens, ylens=ylens, max_xlens_batch=prm.max_xlens_batch,
                                max_ylens_batch=prm.max_ylens_batch, batch_size=prm.batch_size, min_batch_size=mbs,
                                batches=sorted(sampler.indices_batches)))
+    # ---- dataset items with phone targets and distillation soft labels (datasets.py:25-192,248-263):
+    # a tiny manifest + feature files + kd pickle written to a temp dir, read back by the reference
+    import pickle
+    import tempfile
+    from asr.datasets import ASRDataset
+    nrng = np.random.RandomState(5)
+    kd_case = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        rows, kd = [], {}
+        utts = [("sp0.9-utt-a", 7, [5, 9, 4]), ("utt-b", 5, [11, 3]), ("sp1.1-utt-c", 9, [6, 6, 8, 13])]
+        feats = {}
+        for uid, T, toks in utts:
+            x = nrng.randn(T, 4).astype(np.float32)
+            fp = os.path.join(tmp, uid + ".npy")
+            np.save(fp, x)
+            feats[uid] = x.tolist()
+            ph = [int(v) for v in nrng.randint(3, 9, size=len(toks) + 2)]
+            rows.append(dict(feat_path=fp, utt_id=uid, token_id=" ".join(map(str, toks)), text="t " + uid, xlen=T,
+                             ylen=len(toks), phone_token_id=" ".join(map(str, ph)), phone_text="p " + uid))
+            key = "-".join(uid.split("-")[1:]) if uid.startswith("sp") else uid
+            if uid != "utt-b":  # one utterance has no teacher output
+                kd[key] = [[(int(v), np.float32(pv)) for v, pv in zip(nrng.choice(16, 3, replace=False),
+                                                                        nrng.dirichlet(np.ones(3)) * 0.9)]
+                           for _ in toks]
+        import pandas as pd
+        tsv = os.path.join(tmp, "train.tsv")
+        pd.DataFrame(rows).to_csv(tsv, sep="\t", index=False)
+        kdp = os.path.join(tmp, "kd.pkl")
+        with open(kdp, "wb") as f:
+            pickle.dump(kd, f)
+        for dec in ("ctc", "transformer"):
+            prm = make_params(dict(feat_dim=4, num_framestacks=1, vocab_size=16, lsm_prob=0.1, eos_id=2, spec_augment=False,
+                                   mtl_phone_ctc_weight=0.3, phone_eos_id=1, kd_weight=0.5, kd_label_path=kdp,
+                                   decoder_type=dec))
+            dset = ASRDataset(prm, tsv, phase="train")
+            batch = ASRDataset.collate_fn([dset[i] for i in range(3)])
+            kd_case[dec] = {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        kd_case["rows"] = [dict(r, feat_path=os.path.basename(r["feat_path"])) for r in rows]
+        kd_case["feats"] = feats
+        kd_case["kd"] = {k: [[(v, float(p)) for v, p in pos] for pos in val] for k, val in kd.items()}
     with open(os.path.join(OUT, "hostio.json"), "w") as f:
-        json.dump(dict(wer=wer_cases, subwords=sw_cases, packing=pack_cases), f)
+        json.dump(dict(wer=wer_cases, subwords=sw_cases, packing=pack_cases, dataset_kd=kd_case), f)
     print("hostio:", len(wer_cases), "wer,", len(sw_cases), "subword,", len(pack_cases), "packing cases")
 
 
@@ -548,6 +588,61 @@ def run_kd():
     np.savez_compressed(os.path.join(OUT, "kd_tiny.npz"), **out)
 
 
+TRAIN_TRACE = dict(lr_schedule_type="noam", learning_rate=0.02, num_warmup_steps=4, accum_grad=2, clip_grad_norm=5.0,
+                   weight_decay=1e-6, log_step=100)
+
+
+def run_train_trace():
+    """the micro-batch / accumulate / clip / NaN-skip / noam sequence of asr/train_asr.py:35-97 with the
+    reference's ScheduledOptimizer (asr/optimizers.py) around torch.optim.Adam(lr=0, weight_decay) on the
+    l2_tiny weights: 12 optimizer steps x accum_grad 2 over three fixed batches -> train_trace.npz
+    (train_asr.py itself imports GitPython, which is absent: its train_step sequence is driven from here)."""
+    import math
+    from asr.optimizers import ScheduledOptimizer
+    g2 = np.load(os.path.join(OUT, "l2_tiny.npz"))
+    sd2 = {k[3:]: torch.from_numpy(g2[k]) for k in g2.files if k.startswith("sd/")}
+    params = make_params(dict(CONFIGS["l2_tiny"], **TRAIN_TRACE))
+    model = ASR(params, phase="train")
+    model.load_state_dict(sd2)
+    model.train()
+    optimizer = ScheduledOptimizer(torch.optim.Adam(model.parameters(), lr=0, weight_decay=params.weight_decay), params)
+    batches = [make_batch(seed, COMMON["feat_dim"], COMMON["vocab_size"]) for seed in (1, 2, 3)]
+    out = {}
+    for i, (xs, xlens, ys, ylens, ys_in, ys_out) in enumerate(batches):
+        out.update({f"batch{i}/xs": xs.numpy(), f"batch{i}/xlens": xlens.numpy(), f"batch{i}/ys": ys.numpy(),
+                    f"batch{i}/ylens": ylens.numpy(), f"batch{i}/ys_in": ys_in.numpy(), f"batch{i}/ys_out": ys_out.numpy()})
+    losses, lrs, gnorms = [], [], []
+    optimizer.update_epoch()
+    for micro in range(24):
+        xs, xlens, ys, ylens, ys_in, ys_out = batches[micro % 3]
+        loss, loss_dict = model(xs, xlens, ys, ylens, ys_in, ys_out)
+        losses.append(loss_dict["loss_total"].item() / params.accum_grad)
+        (loss / params.accum_grad).backward()
+        if (micro + 1) % params.accum_grad == 0:
+            grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), params.clip_grad_norm)
+            gnorms.append(float(grad_norm))
+            if not math.isnan(grad_norm):
+                optimizer.step()
+            optimizer.zero_grad()
+            lrs.append(optimizer._lr)
+    out["losses"], out["lrs"], out["gnorms"] = np.array(losses), np.array(lrs), np.array(gnorms)
+    sd_end = model.state_dict()
+    for k in ("decoder.output.weight", "encoder.norm.weight", "encoder.transformers.0.conv.batch_norm.running_var",
+              "encoder.transformers.1.self_attn.pos_bias_u", "encoder.conv.conv.0.weight",
+              "encoder.transformers.0.conv.batch_norm.num_batches_tracked"):
+        out["end/" + k] = sd_end[k].numpy()
+    osd = optimizer.state_dict()
+    names = [n for n, _ in model.named_parameters()]
+    idx = names.index("decoder.output.weight")
+    out["optim/_step"] = np.array(osd["_step"])
+    out["optim/_lr"] = np.array(osd["_lr"])
+    out["optim/exp_avg/decoder.output.weight"] = osd["optimizer"]["state"][idx]["exp_avg"].numpy()
+    out["optim/exp_avg_sq/decoder.output.weight"] = osd["optimizer"]["state"][idx]["exp_avg_sq"].numpy()
+    np.savez_compressed(os.path.join(OUT, "train_trace.npz"), **out)
+    print("train trace: losses", [round(v, 3) for v in losses[:4]], "...", [round(v, 3) for v in losses[-2:]],
+          "lrs", [round(v, 6) for v in lrs[:5]], "gnorms", [round(v, 2) for v in gnorms[:4]])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ctc", "l3", "l4"]
     if "ctc" in which:
@@ -559,6 +654,8 @@ if __name__ == "__main__":
         run_l4()
     if "hostio" in which:
         run_hostio()
+    if "traintrace" in which:  # needs l2_tiny.npz
+        run_train_trace()
     if "kd" in which:  # needs l2_tiny.npz and l3_tiny.npz (reads their weights)
         run_kd()
     if "rnntbeam" in which:  # needs l4_tiny.npz (reads its weights)

@@ -34,7 +34,8 @@ def test_dataset_collate_and_sampler(tmp_path):
     params = SimpleNamespace(feat_dim=6, num_framestacks=1, eos_id=2, max_xlens_batch=100, max_ylens_batch=7, batch_size=3)
     data = ds.ASRDataset(params, str(path))
     assert len(data) == 7
-    utt, x, xlen, y, ylen, text = data[2]
+    utt, x, xlen, y, ylen, text, p, plen, ptext, soft = data[2]  # the reference's 10-tuple (datasets.py:133)
+    assert p is None and plen is None and ptext is None and soft is None
     assert utt == "utt2" and x.shape == (34, 6) and xlen == 34 and ylen == 4 and text == "text 2"
     assert torch.equal(x, torch.from_numpy(np.load(rows[2][0])[:, :6]))
     sampler = ds.ASRBatchSampler(data, params)
@@ -60,7 +61,7 @@ def test_dataset_collate_and_sampler(tmp_path):
 def test_frame_stacking(tmp_path):
     path, rows = _write_corpus(tmp_path, n=1)
     data = ds.ASRDataset(SimpleNamespace(feat_dim=6, num_framestacks=3, eos_id=2), str(path))
-    _, x, xlen, _, _, _ = data[0]
+    _, x, xlen = data[0][:3]
     raw = np.load(rows[0][0])[:, :6]
     assert x.shape == (6, 18) and xlen == 6  # 20 frames -> 6 stacks of 3 (2 dropped)
     assert np.array_equal(x[1].numpy(), raw[3:6].reshape(-1))
@@ -145,3 +146,98 @@ def test_against_reference_known_answers():
         got = pack_batches(np.array(c["xlens"]), np.array(c["ylens"]), c["max_xlens_batch"], c["max_ylens_batch"],
                            c["batch_size"], c["min_batch_size"])
         assert sorted(got) == c["batches"], c
+
+
+def test_scheduled_optimizer_rates_and_state():
+    """asr/optimizers.py:45-117: the noam rates of the reference's 12-step trace (train_trace.npz), the
+    other two schedules by their formulas, and the state_dict round trip"""
+    import numpy as np
+    from types import SimpleNamespace
+    from emoasr_amd.optimizers import ScheduledOptimizer
+
+    class Dummy:
+        def __init__(self):
+            self.param_groups = [{"lr": 0.0}]
+            self.steps = 0
+
+        def step(self):
+            self.steps += 1
+
+        def zero_grad(self):
+            pass
+
+        def state_dict(self):
+            return {"steps": self.steps}
+
+        def load_state_dict(self, sd):
+            self.steps = sd["steps"]
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_trace.npz"))
+    prm = SimpleNamespace(lr_schedule_type="noam", learning_rate=0.02, num_warmup_steps=4, enc_hidden_size=128)
+    opt = ScheduledOptimizer(Dummy(), prm)
+    got = []
+    for _ in range(12):
+        opt.step()
+        got.append(opt.param_groups[0]["lr"])
+    assert np.allclose(got, z["lrs"], rtol=1e-12, atol=0)
+    sd = opt.state_dict()
+    assert sd["_step"] == 12 and sd["optimizer"] == {"steps": 12} and sd["num_warmup_steps"] == 4
+    opt2 = ScheduledOptimizer(Dummy(), prm)
+    opt2.load_state_dict(sd)
+    opt2.step()
+    opt.step()
+    assert opt2._lr == opt._lr and opt2.optimizer.steps == 13
+    ep = ScheduledOptimizer(Dummy(), SimpleNamespace(lr_schedule_type="epdecay", learning_rate=1.0, num_warmup_steps=2,
+                                                     lr_decay_start_epoch=2, lr_decay_rate=0.5))
+    rates = []
+    for _ in range(3):
+        ep.step()
+        rates.append(ep._lr)
+    assert rates == [0.5, 1.0, 1.0]
+    ep.update_epoch()
+    assert ep._lr == 1.0
+    ep.update_epoch()
+    assert ep._lr == 0.5 and ep.param_groups[0]["lr"] == 0.5
+    lin = ScheduledOptimizer(Dummy(), SimpleNamespace(lr_schedule_type="lindecay", learning_rate=1.0, warmup_proportion=0.2),
+                             num_total_steps=10)
+    rates = []
+    for _ in range(10):
+        lin.step()
+        rates.append(lin._lr)
+    assert np.allclose(rates, [0.5, 1.0, 0.875, 0.75, 0.625, 0.5, 0.375, 0.25, 0.125, 0.0])
+
+
+@pytest.mark.parametrize("decoder_type", ["ctc", "transformer"])
+def test_dataset_phone_targets_and_soft_labels(tmp_path, decoder_type):
+    """items + collate with phone targets and distillation soft labels (datasets.py:25-192,248-263) against
+    the batch the reference's ASRDataset built from the same manifest / features / kd pickle"""
+    import json
+    import pickle
+    import pandas as pd
+    with open(os.path.join(os.path.dirname(__file__), "golden", "hostio.json")) as f:
+        case = json.load(f)["dataset_kd"]
+    rows = []
+    for r in case["rows"]:
+        fp = str(tmp_path / r["feat_path"])
+        np.save(fp, np.array(case["feats"][r["utt_id"]], dtype=np.float32))
+        rows.append(dict(r, feat_path=fp))
+    tsv = str(tmp_path / "train.tsv")
+    pd.DataFrame(rows).to_csv(tsv, sep="\t", index=False)
+    kdp = str(tmp_path / "kd.pkl")
+    with open(kdp, "wb") as f:
+        pickle.dump({k: [[(int(v), np.float32(p)) for v, p in pos] for pos in val] for k, val in case["kd"].items()}, f)
+    prm = SimpleNamespace(feat_dim=4, num_framestacks=1, vocab_size=16, lsm_prob=0.1, eos_id=2, mtl_phone_ctc_weight=0.3,
+                          phone_eos_id=1, kd_weight=0.5, kd_label_path=kdp, decoder_type=decoder_type)
+    data = ds.ASRDataset(prm, tsv, phase="train")
+    batch = data.collate_fn([data[i] for i in range(3)])
+    want = case[decoder_type]
+    assert sorted(batch) == sorted(want)
+    for k, w in want.items():
+        got = batch[k].tolist() if torch.is_tensor(batch[k]) else batch[k]
+        if k in ("xs", "soft_labels"):
+            assert np.allclose(np.array(got), np.array(w), rtol=1e-6, atol=1e-7), k
+        else:
+            assert got == w, k
+    # test phase: neither phones nor soft labels are read
+    plain = ds.ASRDataset(prm, tsv, phase="test")
+    assert sorted(plain.collate_fn([plain[0]])) == ["texts", "utt_ids", "xlens", "xs", "ylens", "ys", "ys_in", "ys_out"]

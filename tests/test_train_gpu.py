@@ -1,0 +1,129 @@
+"""The training driver (train.train_step / train, optimizers.Adam + ScheduledOptimizer) against the 12-step
+trace the reference's own ScheduledOptimizer + torch.optim.Adam produced on the l2_tiny weights
+(tests/golden/train_trace.npz: accum_grad 2, clip 5.0 -- active at every step --, noam warm-up, weight decay).
+
+f32 mode; tolerances: learning rates exact, losses 2e-3 relative (12 steps of error amplification on top of the
+1e-3 single-step bar), final parameters 2e-3 of their range, Adam moments 1e-2."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import CONFIGS, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TRAIN_TRACE = dict(lr_schedule_type="noam", learning_rate=0.02, num_warmup_steps=4, accum_grad=2, clip_grad_norm=5.0,
+                   weight_decay=1e-6, log_step=3)
+
+
+def _trace():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_trace.npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def _data(t, i):
+    return {k: t[f"batch{i}/{k}"] for k in ("xs", "xlens", "ys", "ylens", "ys_in", "ys_out")}
+
+
+def _setup(dev, hip_adam=True):
+    from emoasr_amd.modeling.asr import ASR
+    from emoasr_amd.optimizers import Adam, ScheduledOptimizer
+    _, sd, _ = load_golden("l2_tiny")
+    params = SimpleNamespace(**dict(CONFIGS["l2_tiny"], **TRAIN_TRACE))
+    model = ASR(params, compute_dtype=torch.float32)
+    model.load_state_dict(sd)
+    # the reference's order: optimizer first, then model.to(device) (train_asr.py:228-246)
+    base = (Adam if hip_adam else torch.optim.Adam)(model.parameters(), lr=0, weight_decay=params.weight_decay)
+    optimizer = ScheduledOptimizer(base, params)
+    model.to(dev)
+    model.train()
+    return model, optimizer, params
+
+
+@pytest.mark.parametrize("hip_adam", [True, False], ids=["hip-adam", "torch-adam"])
+def test_twelve_step_trace(dev, hip_adam):
+    from emoasr_amd.train import train_step
+    t = _trace()
+    model, optimizer, params = _setup(dev, hip_adam)
+    if not hip_adam:  # torch.optim.Adam must see the arena-backed tensors: bind before its first step
+        model.engine()
+    optimizer.update_epoch()
+    losses, lrs = [], []
+    for micro in range(24):
+        stepping = (micro + 1) % params.accum_grad == 0
+        ld = train_step(model, optimizer, _data(t, micro % 3), params, dev, no_grad=not stepping)
+        assert set(ld) == {"loss_ctc", "loss_total"} and isinstance(ld["loss_total"], float)
+        losses.append(ld["loss_total"])
+        if stepping:
+            lrs.append(optimizer._lr)
+    assert np.allclose(lrs, t["lrs"].numpy(), rtol=1e-12, atol=0)
+    rel = np.abs(np.array(losses) - t["losses"].numpy()) / t["losses"].numpy()
+    assert rel.max() < 2e-3, rel
+    sd = model.state_dict()
+    for k in [k for k in t if k.startswith("end/")]:
+        want, got = t[k], sd[k[4:]].cpu()
+        if want.dtype.is_floating_point:
+            err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+            assert err < 2e-3, (k, err)
+        else:
+            assert torch.equal(got, want), k
+    osd = optimizer.state_dict()
+    assert osd["_step"] == int(t["optim/_step"]) and abs(osd["_lr"] - float(t["optim/_lr"])) < 1e-15
+    idx = [n for n, _ in model.named_parameters()].index("decoder.output.weight")
+    st = osd["optimizer"]["state"][idx]
+    assert int(st["step"]) == 12
+    for key in ("exp_avg", "exp_avg_sq"):
+        want = t[f"optim/{key}/decoder.output.weight"]
+        err = (st[key].cpu() - want).abs().max().item() / want.abs().max().item()
+        assert err < 1e-2, (key, err)
+
+
+def test_nan_gradient_skips_the_update_and_resume(dev):
+    """train_asr.py:88-89: a NaN gradient norm leaves parameters and moments untouched; then an optimizer
+    state_dict round trip through a fresh optimizer continues identically (asr/optimizers.py:99-117)"""
+    from emoasr_amd.optimizers import Adam, ScheduledOptimizer
+    from emoasr_amd.train import train_step
+    t = _trace()
+    model, optimizer, params = _setup(dev)
+    one = SimpleNamespace(**dict(vars(params), accum_grad=1))
+    train_step(model, optimizer, _data(t, 0), one, dev)
+    before = {k: v.clone() for k, v in model.state_dict().items() if v.dtype.is_floating_point and "running" not in k}
+    # poison the gradient of the next step
+    loss, _ = model(**{k: (v.to(dev) if k == "xs" else v) for k, v in _data(t, 1).items()})
+    loss.backward()
+    model.decoder.output.weight.grad[0, 0] = float("nan")
+    optimizer.optimizer.clip_grad_norm = one.clip_grad_norm
+    optimizer.step()
+    optimizer.zero_grad()
+    for k, v in before.items():
+        assert torch.equal(model.state_dict()[k], v), k
+    assert float(model.engine().arena.grad.abs().max()) == 0.0
+    # resume: same model weights, a NEW optimizer restored from the state dict, one more step each
+    sd_opt = optimizer.state_dict()
+    model2, optimizer2, _ = _setup(dev)
+    model2.load_state_dict(model.state_dict())
+    optimizer2.load_state_dict(sd_opt)
+    a = train_step(model, optimizer, _data(t, 2), one, dev)
+    b = train_step(model2, optimizer2, _data(t, 2), one, dev)
+    assert abs(a["loss_total"] - b["loss_total"]) < 1e-4 * abs(a["loss_total"])
+    assert optimizer2._step == optimizer._step and optimizer2._lr == optimizer._lr
+    # (atomically accumulated weight gradients make two runs differ in the last bits)
+    for (k, v), (_, w) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.allclose(v.float(), w.float(), rtol=1e-4, atol=1e-5), k
+
+
+def test_train_epoch_driver(dev):
+    from emoasr_amd.train import train
+    t = _trace()
+    model, optimizer, params = _setup(dev)
+    lines = []
+    steps = train(model, optimizer, [_data(t, i % 3) for i in range(12)], params, dev, epoch=0, log=lines.append)
+    assert steps == 6 and optimizer._epoch == 1 and optimizer._step == 6
+    assert len(lines) == 2 and "step =      3 /      6" in lines[0] and "loss_total:" in lines[0]
+    # the logged mean over 3 steps x 2 micro-batches equals the reference trace's
+    want = t["losses"][:6].sum().item() / 3
+    got = float(lines[0].split("loss_total: ")[1].split()[0])
+    assert abs(got - want) < 2e-3 * want + 1e-3, (got, want)
