@@ -360,8 +360,27 @@ def run_hostio():
         kd_case["rows"] = [dict(r, feat_path=os.path.basename(r["feat_path"])) for r in rows]
         kd_case["feats"] = feats
         kd_case["kd"] = {k: [[(v, float(p)) for v, p in pos] for pos in val] for k, val in kd.items()}
+    # ---- decode result rows (test_asr.py:96-117: strip <eos>, ids -> string, ids -> text through the vocab)
+    # for the greedy hypotheses the reference produced on l2_tiny (tests/golden/l2_tiny.npz)
+    from utils.converters import ints2str, strip_eos
+    g2 = np.load(os.path.join(OUT, "l2_tiny.npz"))
+    toks = ["<blank>", "<unk>", "<eos>"] + [("\u2581" if i % 3 == 0 else "") + "w%d" % i for i in range(3, 40)]
+    with tempfile.TemporaryDirectory() as tmp:
+        vp = os.path.join(tmp, "vocab.txt")
+        with open(vp, "w") as f:
+            for i, t in enumerate(toks):
+                f.write(f"{t} {i}\n")
+        vocab = Vocab(vp)
+        hyps, o = [], 0
+        for n in g2["eval/hyp_lens"].tolist():
+            hyps.append([int(v) for v in g2["eval/hyps"][o:o + n]])
+            o += n
+        hyps.append([2, 5, 2, 2])   # only <eos> around one token
+        hyps.append([])             # nothing decoded
+        row_case = dict(vocab=toks, hyps=hyps,
+                        rows=[[ints2str(strip_eos(h, 2)), vocab.ids2text(strip_eos(h, 2))] for h in hyps])
     with open(os.path.join(OUT, "hostio.json"), "w") as f:
-        json.dump(dict(wer=wer_cases, subwords=sw_cases, packing=pack_cases, dataset_kd=kd_case), f)
+        json.dump(dict(wer=wer_cases, subwords=sw_cases, packing=pack_cases, dataset_kd=kd_case, result_rows=row_case), f)
     print("hostio:", len(wer_cases), "wer,", len(sw_cases), "subword,", len(pack_cases), "packing cases")
 
 

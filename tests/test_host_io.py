@@ -241,3 +241,49 @@ def test_dataset_phone_targets_and_soft_labels(tmp_path, decoder_type):
     # test phase: neither phones nor soft labels are read
     plain = ds.ASRDataset(prm, tsv, phase="test")
     assert sorted(plain.collate_fn([plain[0]])) == ["texts", "utt_ids", "xlens", "xs", "ylens", "ys", "ys_in", "ys_out"]
+
+
+class _FakeModel:
+    """stands in for ASR.decode: returns the captured hypotheses, one utterance per call"""
+
+    def __init__(self, hyps):
+        self.hyps, self.calls = hyps, []
+
+    def decode(self, xs, xlens, beam_width, len_weight, lm=None, lm_weight=0, decode_ctc_weight=0, decode_phone=False):
+        i = len(self.calls)
+        self.calls.append((tuple(xs.shape), int(xlens[0]), beam_width, len_weight, lm_weight, decode_ctc_weight))
+        h = self.hyps[i]
+        return ([h] if h else []), [None], None, None
+
+
+def test_decode_driver_rows(tmp_path):
+    """test_asr.py:63-121 result rows against the strings the reference's Vocab / strip_eos / ints2str give
+    for the hypotheses it decoded on l2_tiny (+ an <eos>-only and an empty case)"""
+    import json
+    from emoasr_amd import decode as dec
+    with open(os.path.join(os.path.dirname(__file__), "golden", "hostio.json")) as f:
+        case = json.load(f)["result_rows"]
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("".join(f"{t} {i}\n" for i, t in enumerate(case["vocab"])))
+    vocab = ds.Vocab(str(vp))
+    loader = [{"utt_ids": [f"utt{i}"], "texts": [f"ref {i}"], "xs": torch.zeros(1, 10 + i, 4), "xlens": torch.tensor([10 + i])}
+              for i in range(len(case["hyps"]))]
+    model = _FakeModel(case["hyps"])
+    rows = dec.test(model, loader, vocab, 1, 0.0, 0.0, False, None, 0.0, "cpu")
+    assert len(rows) == len(case["hyps"])
+    for i, (row, (tok, text), hyp) in enumerate(zip(rows, case["rows"], case["hyps"])):
+        if hyp:
+            assert row == [f"utt{i}", tok, text, f"ref {i}"]
+        else:
+            assert row == [f"utt{i}", None, "", f"ref {i}"]  # "cannot decode"
+    assert model.calls[0] == ((1, 10, 4), 10, 1, 0.0, 0.0, 0.0)
+    # num_samples / sample_utt_id selection
+    assert len(dec.test(_FakeModel(case["hyps"]), loader, vocab, 1, 0, 0, False, None, 0, "cpu", num_samples=2)) == 2
+    only = dec.test(_FakeModel(case["hyps"][1:]), loader, vocab, 1, 0, 0, False, None, 0, "cpu", sample_utt_id="utt1")
+    assert [r[0] for r in only] == ["utt1"]
+    # result file: WER comment first, then the reference's four columns
+    wer, info = dec.save_results(rows, str(tmp_path / "result.tsv"))
+    lines = (tmp_path / "result.tsv").read_text().splitlines()
+    assert lines[0] == "# " + info and lines[1].split("\t") == ["utt_id", "token_id", "text", "reftext"]
+    assert info.startswith("WER: ") and len(lines) == 2 + len(rows)
+    assert dec.wavtime_of("spk-utt_0012300_0015800") == 3.5 and dec.wavtime_of("utt7") is None
