@@ -296,6 +296,15 @@ def l4_rnnt(dev, dtype, steps=5, warmup=2, n_dec=5):
         model.decode(x, l)
     torch.cuda.synchronize()
     out["greedy_rtf"] = (time.perf_counter() - t0) / (sum(l[0] for _, l in utts) * 0.010)
+    # alignment-length synchronous beam search (rnn_transducer.py:242-325), beam 4, on the two shortest picks
+    short = sorted(utts, key=lambda u: u[1][0])[:2]
+    model.decode(*short[0], beam_width=4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for x, l in short:
+        model.decode(x, l, beam_width=4)
+    torch.cuda.synchronize()
+    out["beam4_rtf"] = (time.perf_counter() - t0) / (sum(l[0] for _, l in short) * 0.010)
     return out
 
 
@@ -354,12 +363,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    # (EMOASR_BENCH_ONE_GPU=1 + EMOASR_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a 1-GPU box)
+    if os.environ.get("EMOASR_BENCH_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("EMOASR_DIST_BACKEND", "nccl")  # nccl = RCCL over xGMI
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from emoasr_amd import lib as emo_lib, ops
     from emoasr_amd.data import specaug_spans

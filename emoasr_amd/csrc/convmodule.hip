@@ -68,38 +68,39 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const
 
 // Merge of the per-block partials (Chan et al.): mean = sum_b s_b / M,
 // M2 = sum_b [ m2_b + n_b (s_b / n_b - mean)^2 ]; var = M2 / M (biased, used to normalise),
-// running_var gets the unbiased M2 / (M - 1) like nn.BatchNorm1d.  One block = 64 channels x 16
-// groups of partial blocks.
+// running_var gets the unbiased M2 / (M - 1) like nn.BatchNorm1d.  One block = 16 channels x 64
+// groups of partial blocks (16 blocks for C = 256: the partial table is walked in 7 steps, not 28).
+constexpr int BNF_CH = 16, BNF_G = 64;  // channels x groups of partial blocks per finalize block
 __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B, int Tn, int C, const float* __restrict__ part,
                                                                  float* __restrict__ mean, float* __restrict__ var,
                                                                  float* __restrict__ running_mean,
                                                                  float* __restrict__ running_var, float momentum,
                                                                  long long* __restrict__ num_batches_tracked) {
-  __shared__ float red[16][64];
-  __shared__ float mean_s[64];
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  __shared__ float red[BNF_G][BNF_CH];
+  __shared__ float mean_s[BNF_CH];
+  const int lane = threadIdx.x % BNF_CH, grp = threadIdx.x / BNF_CH;
+  const int c = blockIdx.x * BNF_CH + lane;
   const int nx = (Tn + DW_TT - 1) / DW_TT, nblk = B * nx;
   const float M = (float)B * Tn;
   float s = 0.f;
   if (c < C) {
-#pragma unroll 16
-    for (int k = grp; k < nblk; k += 16) s += part[(long)k * 2 * C + c];
+#pragma unroll 8
+    for (int k = grp; k < nblk; k += BNF_G) s += part[(long)k * 2 * C + c];
   }
   red[grp][lane] = s;
   __syncthreads();
   if (grp == 0) {
     float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) t += red[g][lane];
+    for (int g = 0; g < BNF_G; ++g) t += red[g][lane];
     mean_s[lane] = t / M;
   }
   __syncthreads();
   const float mu = mean_s[lane];
   float m2 = 0.f;
   if (c < C)
-#pragma unroll 16
-    for (int k = grp; k < nblk; k += 16) {
+#pragma unroll 8
+    for (int k = grp; k < nblk; k += BNF_G) {
       const int n = min(DW_TT, Tn - (k % nx) * DW_TT);
       const float d = part[(long)k * 2 * C + c] / n - mu;
       m2 += part[(long)k * 2 * C + C + c] + n * d * d;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B, int Tn, 
   if (grp == 0 && c < C) {
     float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) t += red[g][lane];
+    for (int g = 0; g < BNF_G; ++g) t += red[g][lane];
     mean[c] = mu;
     var[c] = t / M;
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
@@ -387,7 +388,7 @@ extern "C" int emoasr_bn_stats_finalize(int B, int Tn, int C, const float* part,
                                         float* running_mean, float* running_var, float momentum,
                                         long long* num_batches_tracked, void* stream) {
   EMO_CHECK(B * Tn > 0, "bn_stats_finalize: empty batch");
-  bn_stats_finalize_kernel<<<cdiv(C, 64), 1024, 0, (hipStream_t)stream>>>(B, Tn, C, part, mean, var, running_mean,
+  bn_stats_finalize_kernel<<<cdiv(C, BNF_CH), 1024, 0, (hipStream_t)stream>>>(B, Tn, C, part, mean, var, running_mean,
                                                                           running_var, momentum, num_batches_tracked);
   EMO_LAUNCH_CHECK();
   return 0;
