@@ -581,7 +581,11 @@ int launch_tn(TnArgs a, hipStream_t s) {
   // ~1.3 TB/s chip-wide, so more slices than that make the kernel atomic-bound.
   int splits = (int)((512 + tiles - 1) / tiles);
   const long out_bytes = (long)a.N1 * a.N2 * 4;
-  const int cap = (int)std::max(1L, (8L << 20) / out_bytes);
+  // ... unless the reduction is so long that the atomics stay below ~10 % of the product's own time
+  // (estimated at 300 TFLOP/s): the Conv2d weight gradient (K = B*T'*F2 ~ 130 k) wants 15 slices, not 3
+  const double est_s = 2.0 * a.N1 * a.N2 * (double)a.K / 300e12;
+  const long cap_work = (long)(0.25 * est_s * 1.3e12 / (double)out_bytes);
+  const int cap = (int)std::max(std::max(1L, (8L << 20) / out_bytes), cap_work);
   const int floor_splits = (int)std::min((long)splits, (128 + tiles - 1) / tiles);  // never starve the chip
   splits = std::max(floor_splits, std::min(splits, cap));
   splits = std::max(1, std::min(splits, nk / 4 > 0 ? nk / 4 : 1));
