@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int DW_TT = 32;    // output frames per block
+constexpr int DW_TT = 32;    // output frames per block (16: twice the blocks, measured slower -- more halo loads and partials)
 constexpr int DW_MAXK = 31;  // kernel taps (compile-time bound of the register window)
 constexpr int DW_WCHUNKS = 1; // time chunks per block in the weight-gradient kernel
 

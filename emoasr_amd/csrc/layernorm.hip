@@ -427,4 +427,4 @@ extern "C" int emoasr_layernorm_bwd_finalize(int n, const emoasr_ln_finalize_ite
   return 0;
 }
 
-extern "C" int emoasr_layernorm_bwd_scratch_floats(int N) { return LN_BWD8_MAXBLK * 2 * N; }
+extern "C" long emoasr_layernorm_bwd_scratch_floats(int N) { return (long)LN_BWD8_MAXBLK * 2 * N; }

@@ -28,7 +28,7 @@ class _Layout:
                     ("cv_h", (M, d)), ("g", (M, 2 * d)), ("gl", (M, d)), ("c", (M, d)), ("z", (M, d)), ("cv_y", (M, d)),
                     ("ff_h", (M, d)), ("ff_u", (M, F)), ("ff_a", (M, F)), ("ff_y", (M, d)), ("y", (M, d))]
         f_fields = [("ffm_mean", (M,)), ("ffm_rstd", (M,)), ("lse", (B, H, T)), ("at_mean", (M,)), ("at_rstd", (M,)),
-                    ("bmean", (d,)), ("bvar", (d,)), ("bn_part", (B * ((T + 31) // 32) * 2 * d,)),
+                    ("bmean", (d,)), ("bvar", (d,)), ("bn_part", (lib.size_query("emoasr_dwconv_stats_floats", B, T, d),)),
                     ("cv_mean", (M,)), ("cv_rstd", (M,)), ("ff_mean", (M,)), ("ff_rstd", (M,)),
                     ("fin_mean", (M,)), ("fin_rstd", (M,))]
         self.t, self.f = {}, {}

@@ -235,6 +235,21 @@ def call(name, *args):
         raise EmoasrHipError(f"{name} failed ({rc}): {load().emoasr_last_error().decode()}")
 
 
+_SIZE_FN = {}
+
+
+def size_query(name, *ints):
+    """scratch-size entry points (`long emoasr_*_floats(int, ...)`): the kernels' tiling constants live in
+    the library only, callers never restate them"""
+    fn = _SIZE_FN.get(name)
+    if fn is None:
+        fn = getattr(load(), name)
+        fn.restype = ctypes.c_long
+        fn.argtypes = [c_int] * len(ints)
+        _SIZE_FN[name] = fn
+    return int(fn(*[int(v) for v in ints]))
+
+
 def set_option(name, value):
     lib = load()
     if lib.emoasr_set_option(name.encode(), int(value)) != 0:

@@ -217,7 +217,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, branch=None, de
     dx = torch.empty_like(x)
     scratch = None
     if dgamma is not None or dbeta is not None:
-        scratch = torch.empty(1024 * 2 * N, device=x.device, dtype=torch.float32)  # emoasr_layernorm_bwd_scratch_floats(N)
+        scratch = torch.empty(lib.size_query("emoasr_layernorm_bwd_scratch_floats", N), device=x.device, dtype=torch.float32)
     if branch is None and deferred is None:
         lib.call("emoasr_layernorm_bwd", dt(x), M, N, _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
                  _p(dgamma), _p(dbeta), _p(scratch), _stream())
@@ -363,7 +363,7 @@ def dwconv_bn_stats_fwd(x, w, bias, running_mean=None, running_var=None, momentu
     -> (y, batch mean [C], biased batch var [C]); running stats / counter updated in place."""
     B, T, C = x.shape
     y = torch.empty_like(x)
-    part = torch.empty(B * ((T + 31) // 32) * 2 * C, device=x.device, dtype=torch.float32)  # emoasr_dwconv_stats_floats
+    part = torch.empty(lib.size_query("emoasr_dwconv_stats_floats", B, T, C), device=x.device, dtype=torch.float32)
     lib.call("emoasr_dwconv_fwd_stats", dt(x), B, T, C, w.shape[-1], _p(_chk(x)), _p(w), _p(bias), _p(y), _p(part),
              _stream())
     mean = torch.empty(C, device=x.device, dtype=torch.float32)
@@ -385,7 +385,8 @@ def dwconv_bwd_x(dy, w):
 def dwconv_bwd_w(dy, x, dw, dbias, accumulate=False):
     B, T, C = dy.shape
     K = dw.shape[-1]
-    scratch = torch.empty(B * ((T + 31) // 32) * (K + 1) * C, device=dy.device, dtype=torch.float32)
+    scratch = torch.empty(lib.size_query("emoasr_dwconv_bwd_w_scratch_floats", B, T, C, K), device=dy.device,
+                          dtype=torch.float32)
     lib.call("emoasr_dwconv_bwd_w", dt(dy), B, T, C, K, _p(dy), _p(x), _p(dw), _p(dbias),
              int(accumulate), _p(scratch), _stream())
 
@@ -410,7 +411,7 @@ def bn_swish_fwd(y, mean, var, gamma, beta, eps):
 def bn_swish_bwd(dz, y, mean, var, gamma, beta, eps, dgamma, dbeta):
     M, C, ld = _rows(_chk(y))
     dy = torch.empty_like(y)
-    scratch = torch.empty((M + 63) // 64 * 2 * C, device=y.device, dtype=torch.float32)  # emoasr_bn_swish_bwd_scratch_floats
+    scratch = torch.empty(lib.size_query("emoasr_bn_swish_bwd_scratch_floats", M, C), device=y.device, dtype=torch.float32)
     lib.call("emoasr_bn_swish_bwd", dt(y), M, C, _p(dz), _p(y), _p(mean), _p(var), _p(gamma), _p(beta), eps,
              _p(dy), _p(dgamma), _p(dbeta), _p(scratch), _stream())
     return dy

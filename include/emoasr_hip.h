@@ -122,7 +122,7 @@ int emoasr_layernorm_fwd(int dtype, int M, int N, const void* x, const float* ga
 int emoasr_layernorm_bwd(int dtype, int M, int N, const void* dy, const void* x, const float* gamma,
                          const float* mean, const float* rstd, const void* dres, void* dx,
                          float* dgamma, float* dbeta, float* scratch, void* stream);
-int emoasr_layernorm_bwd_scratch_floats(int N);
+long emoasr_layernorm_bwd_scratch_floats(int N);
 /* Extended form.  dy2 (optional) = dropout(dx * scale2; drop_p2, seed2), computed from the stored dx:
  * the gradient entering the next residual branch x + scale2 * dropout(f(x)) of the backward sweep, so
  * that branch needs no separate emoasr_scale_dropout pass (same mask index: row * N + col).
