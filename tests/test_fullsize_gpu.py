@@ -1,0 +1,160 @@
+"""Parity at BASELINE.json's full model size (L2: 23.5 M Conformer-CTC, d 256, 12 layers, V 10000).
+
+1. Against the oracle directly: a three-utterance batch is small enough for the CPU restatement to finish in
+   seconds at the FULL model size -- loss, logits, greedy ids, gradients (f32: 1e-3 as north_star states,
+   greedy ids bit-exact; bf16: loss 2e-2).
+2. Size-independent properties on a full bench-sized batch (about 27 k frames, bf16):
+   CTC logit gradients sum to zero over the vocabulary on valid frames and vanish on padded ones;
+   the backward pass is linear in the incoming loss gradient; eval-mode decoding of an equal-length batch
+   equals decoding each utterance alone; the counter-based dropout is reproducible for a given step."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+L2 = dict(input_layer="conv2d", feat_dim=80, num_framestacks=1, encoder_type="conformer", decoder_type="ctc",
+          pos_encode_type="rel", enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=12,
+          enc_intermediate_size=1024, dropout_enc_rate=0.0, dropout_attn_rate=0.0, vocab_size=10000, blank_id=0,
+          eos_id=2, kd_weight=0)
+
+
+def _model(dtype, dev, seed=0, **over):
+    from emoasr_amd.modeling.asr import ASR
+    torch.manual_seed(seed)
+    model = ASR(SimpleNamespace(**dict(L2, **over)), compute_dtype=dtype)
+    with torch.no_grad():  # spread the head so greedy decoding is not all blanks / ties
+        model.decoder.output.weight.mul_(3.0)
+        for n, p in model.named_parameters():
+            if "batch_norm" in n or ".norm" in n:
+                p.add_(0.05 * torch.randn_like(p))
+    return model.to(dev)
+
+
+def _batch(seed, xlens, V=10000):
+    g = torch.Generator().manual_seed(seed)
+    xlens = torch.tensor(xlens)
+    ylens = torch.clamp(xlens // 30, min=1)
+    B, T, L = len(xlens), int(xlens.max()), int(ylens.max())
+    xs = torch.randn(B, T, 80, generator=g)
+    ys = torch.randint(3, V, (B, L), generator=g)
+    for b in range(B):
+        xs[b, xlens[b]:] = 0
+        ys[b, ylens[b]:] = 2
+    return xs, xlens, ys, ylens
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_full_model_against_oracle(dev, dtype):
+    from oracle import model as om
+    model = _model(dtype, dev)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cfg = SimpleNamespace(**L2)
+    xs, xlens, ys, ylens = _batch(1, [403, 367, 298])
+    # ---- train mode (BatchNorm batch statistics), loss + gradients
+    params = {k: v for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    for v in params.values():
+        v.requires_grad_(True)
+    loss_ref, _, logits_ref = om.asr_ctc_forward(sd, cfg, xs, xlens, ys, ylens, training=True)
+    loss_ref.backward()
+    model.train()
+    loss, ld = model(xs.to(dev), xlens, ys, ylens, None, None)
+    loss.backward()
+    ltol = 1e-3 if dtype == torch.float32 else 2e-2
+    assert abs(loss.item() - loss_ref.item()) < ltol * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    grads = {n: p.grad.float().cpu() for n, p in model.named_parameters()}
+    for name in ("decoder.output.weight", "encoder.norm.weight", "encoder.transformers.11.feed_forward.w2.weight",
+                 "encoder.transformers.6.self_attn.linear_pos.weight", "encoder.transformers.0.conv.depthwise_conv.weight",
+                 "encoder.transformers.3.self_attn.pos_bias_u", "encoder.conv.conv.2.weight", "encoder.conv.conv.0.weight"):
+        a, b = grads[name].flatten(), params[name].grad.flatten()
+        cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
+        assert cos > (0.9995 if dtype == torch.float32 else 0.97), (name, cos)
+        if dtype == torch.float32:
+            assert abs(a.norm().item() / b.norm().item() - 1) < 5e-3, name
+    # ---- eval mode: logits + greedy ids (the reference's running statistics are untouched in `sd`)
+    with torch.no_grad():
+        sd_eval = {k: v.detach() for k, v in sd.items()}
+        eouts, elens = om.encoder_forward(sd_eval, cfg, xs, xlens)
+        logits_ref = om.ctc_decoder_forward(sd_eval, cfg, eouts, elens)
+        want, _ = om.ctc_greedy(logits_ref, elens, 0)
+    model.load_state_dict({k: v.detach() for k, v in sd.items()})  # undo the BatchNorm running-stat update
+    model.eval()
+    with torch.no_grad():
+        e2, el2, _ = model.encoder(xs.to(dev), xlens)
+        logits = model.decoder(e2, el2)
+    hyps, _, _, _ = model.decode(xs.to(dev), xlens)
+    rel = ((logits.float().cpu() - logits_ref).abs().max() / logits_ref.abs().max()).item()
+    assert rel < (1e-3 if dtype == torch.float32 else 6e-2), rel
+    if dtype == torch.float32:
+        assert hyps == want
+    else:
+        agree = sum(int(a == b) for h, w in zip(hyps, want) for a, b in zip(h, w)) / max(1, sum(len(w) for w in want))
+        assert agree > 0.8, agree
+
+
+def _bench_batch(seed=3):
+    # LibriSpeech-shaped, sorted by length, packed to ~27 k frames like the sampler does
+    g = torch.Generator().manual_seed(seed)
+    xlens = sorted(int(v) for v in torch.randint(1180, 1420, (21,), generator=g))
+    return _batch(seed, xlens)
+
+
+def test_ctc_gradient_rows_full_vocabulary(dev):
+    from emoasr_amd import ops
+    xs, xlens, ys, ylens = _bench_batch()
+    B = len(xlens)
+    elens = ((xlens - 1) // 2 - 1) // 2
+    T = int(elens.max())
+    logits = (2.0 * torch.randn(B, T, 10000, generator=torch.Generator().manual_seed(0))).to(torch.bfloat16).to(dev)
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    lse = ops.row_lse(logits.view(B * T, -1))
+    lp, alpha, beta, nll = ops.ctc_forward(logits, lse, i32(ys), i32(elens), i32(ylens), 0)
+    assert torch.isfinite(nll).all() and (nll > 0).all()
+    grad = ops.ctc_grad(logits, lse, i32(ys), i32(elens), i32(ylens), 0, lp, alpha, beta, nll, 1.0 / B).float()
+    rows = grad.sum(-1)
+    valid = torch.arange(T, device=dev)[None, :] < elens.to(dev)[:, None]
+    # softmax minus occupancy: both sum to one over the vocabulary (bf16 rounding of 10 k addends remains)
+    assert rows[valid].abs().max() < 2e-3 / B * 50, rows[valid].abs().max()
+    assert grad[~valid].abs().max() == 0
+    # the label occupancies of one utterance sum to its label count ... per frame: sum over non-blank = 1 - blank occupancy
+    occ = torch.softmax(logits.float(), -1) / B - grad
+    assert torch.allclose(occ[valid].sum(-1), torch.full_like(occ[valid].sum(-1), 1.0 / B), atol=2e-3 / B * 50)
+
+
+def test_backward_is_linear_in_the_loss_gradient(dev):
+    model = _model(torch.bfloat16, dev, dropout_enc_rate=0.1, dropout_attn_rate=0.1)
+    model.train()
+    eng = model.engine()
+    xs, xlens, ys, ylens = _bench_batch()
+    xs = xs.to(dev)
+
+    def grads(scale):
+        eng.step_count = 7  # same dropout masks for every run
+        model.zero_grad(set_to_none=False)
+        loss, _ = model(xs, xlens, ys, ylens, None, None)
+        (loss * scale).backward()
+        return loss.item(), eng.arena.grad.clone()
+
+    l1, g1 = grads(1.0)
+    l1b, g1b = grads(1.0)
+    l2, g2 = grads(-2.5)
+    assert l1 == l1b == l2  # counter-based dropout: the forward pass is reproducible bit for bit
+    # (weight gradients accumulate with float atomics: two identical runs differ in the last bits)
+    scale = g1.abs().max().item()
+    assert (g1 - g1b).abs().max().item() < 2e-3 * scale
+    assert (g2 + 2.5 * g1).abs().max().item() < 6e-3 * scale * 2.5
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+
+
+def test_equal_length_batch_decodes_like_single_utterances(dev):
+    model = _model(torch.bfloat16, dev)
+    model.eval()
+    xs, xlens, ys, ylens = _batch(5, [1217] * 6)
+    hyps, _, logits, aligns = model.decode(xs.to(dev), xlens)
+    for b in range(0, 6, 2):
+        h1, _, lg1, a1 = model.decode(xs[b:b + 1].to(dev), xlens[b:b + 1])
+        rel = ((lg1[0] - logits[b]).abs().max() / logits[b].abs().max()).item()
+        assert rel < 2e-2, rel  # different tile shapes -> different bf16 summation order
+        agree = sum(int(x == y) for x, y in zip(a1[0], aligns[b])) / len(aligns[b])
+        assert agree > 0.97, agree
