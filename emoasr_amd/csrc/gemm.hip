@@ -40,6 +40,26 @@ __device__ __forceinline__ int conv_k_off(const ConvGeom& g, int k) {
   return (kh * g.F1 + kw) * g.C + c;
 }
 
+// Data gradient of the same convolution as an implicit GEMM per output-parity class (AMODE == 2):
+// dy1[b, t1 = 2i+pt, f1 = 2j+pf, c] = relu'(y1) * sum_{taps (kh,kw) with kh = pt, kw = pf (mod 2)}
+//                                       sum_n dy2[b, i - kh/2, j - kw/2, n] * W[n, kh, kw, c]
+// rows  m = (b, i, j) of ONE class;  cols k = (tap, n);  A row base = dy2[b, i, j, :], a tap shifts it by
+// -(dh*F2 + dw)*C and is zero outside the output map;  B[k][c] = w2r[n][(kh*3+kw)*C + c] (k-major, ld 9C).
+// Every dy1 element belongs to exactly one class, so the four launches write dy1 once, with no im2col
+// buffer in between (the col2im path wrote and re-read B*T2*F2 x 9C values).
+struct DgradGeom {
+  int T1, F1, T2, F2, C;
+  int pt, pf, nI, nJ, ntap;
+  int dh[4], dw[4], wtap[4];  // per tap: source shift (dh, dw) and the tap's column offset inside a w2r row
+};
+__device__ __forceinline__ void dgrad_row(const DgradGeom& g, int m, int& b, int& i, int& j) {
+  const int per_b = g.nI * g.nJ;
+  b = m / per_b;
+  const int r = m - b * per_b;
+  i = r / g.nJ;
+  j = r - i * g.nJ;
+}
+
 int g_tr_read = 1;
 int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1;
 
@@ -59,6 +79,7 @@ struct NtArgs {
   void* C; long ldc;
   emoasr_epilogue_t ep;
   ConvGeom cg;
+  DgradGeom dg;
   int nh;  // batched: blockIdx.z = b * nh + h, two-level strides below (elements); 0 = not batched
   long sa_b, sa_h, sb_b, sb_h, sc_b, sc_h;
   int xcd;  // remap block ids so that each XCD works on a contiguous band of rows
@@ -138,6 +159,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A), rsB = make_rsrc(B);
   constexpr unsigned SZ = sizeof(T);
   unsigned a_off[A_IT]; bool a_ok[A_IT]; int a_lds[A_IT]; int a_kv[A_IT];
+  int a_i[A_IT], a_j[A_IT];  // AMODE == 2: position of the row inside its parity class
   unsigned b_off[B_IT]; bool b_ok[B_IT]; int b_lds[B_IT]; int b_kv[B_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
@@ -146,7 +168,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
     a_ok[i] = (m0 + r) < g.M;
     const int row = a_ok[i] ? (m0 + r) : 0;
     if constexpr (AMODE == 1) a_off[i] = (unsigned)(conv_row_base(g.cg, row) * SZ);
-    else a_off[i] = (unsigned)((long)row * g.lda * SZ);
+    else if constexpr (AMODE == 2) {
+      int bb, ii, jj;
+      dgrad_row(g.dg, row, bb, ii, jj);
+      a_i[i] = ii; a_j[i] = jj;
+      a_off[i] = (unsigned)((((long)bb * g.dg.T2 + ii) * g.dg.F2 + jj) * g.dg.C * SZ);  // may point one row past: guarded per tap
+    } else a_off[i] = (unsigned)((long)row * g.lda * SZ);
   }
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
@@ -169,20 +196,36 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   // cover the memory latency (the two-barrier loop waited on vmcnt(0) two thirds of the time).
   struct Stage { Vec16<T> a[A_IT], b[B_IT]; };
   auto load_tile = [&](Stage& r, int k0) {
+    // AMODE == 2: a k tile lies inside one tap (C % BK == 0), so the tap's shifts are block-uniform scalars
+    int tap = 0, tdh = 0, tdw = 0, tshift = 0, twoff = 0;
+    if constexpr (AMODE == 2) {
+      tap = min(k0 / g.dg.C, g.dg.ntap - 1);
+      tdh = g.dg.dh[tap]; tdw = g.dg.dw[tap];
+      tshift = (tdh * g.dg.F2 + tdw) * g.dg.C + tap * g.dg.C;  // subtracted from (row base + k)
+      twoff = g.dg.wtap[tap];
+    }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int k = k0 + a_kv[i];
       const bool ok = a_ok[i] && k < g.K;
       unsigned off;
+      bool okk = ok;
       if constexpr (AMODE == 1) off = a_off[i] + (unsigned)conv_k_off(g.cg, ok ? k : 0) * SZ;
-      else off = a_off[i] + (unsigned)k * SZ;
-      r.a[i] = buf_load16<T>(rsA, ok ? off : EMO_OOB);
+      else if constexpr (AMODE == 2) {
+        const int si = a_i[i] - tdh, sj = a_j[i] - tdw;
+        okk = ok && si >= 0 && si < g.dg.T2 && sj >= 0 && sj < g.dg.F2;
+        off = a_off[i] + (unsigned)((k - tshift) * (int)SZ);  // k - tap*C = channel n of the source row
+      } else off = a_off[i] + (unsigned)k * SZ;
+      r.a[i] = buf_load16<T>(rsA, okk ? off : EMO_OOB);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int k = k0 + b_kv[i];
       const bool ok = b_ok[i] && k < g.K;
-      const unsigned off = BKM ? b_off[i] + (unsigned)((long)k * g.ldb * SZ) : b_off[i] + (unsigned)k * SZ;
+      unsigned off;
+      if constexpr (AMODE == 2) {
+        off = b_off[i] + (unsigned)(((long)(k - tap * g.dg.C) * g.ldb + twoff) * SZ);
+      } else off = BKM ? b_off[i] + (unsigned)((long)k * g.ldb * SZ) : b_off[i] + (unsigned)k * SZ;
       r.b[i] = buf_load16<T>(rsB, ok ? off : EMO_OOB);
     }
   };
@@ -292,7 +335,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(&sc[lrow * EP_LD + ec + 4]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-      const long off = c_base + (long)row * g.ldc + col;
+      long off = c_base + (long)row * g.ldc + col;
+      if constexpr (AMODE == 2) {
+        int bb, ii, jj;
+        dgrad_row(g.dg, row, bb, ii, jj);
+        off = (((long)bb * g.dg.T1 + 2 * ii + g.dg.pt) * g.dg.F1 + 2 * jj + g.dg.pf) * g.dg.C + col;
+      }
       if (vec_ok) {
         if (ep.bias) {
           const f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.bias + col);
@@ -758,6 +806,38 @@ extern "C" int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const v
   a.ep = *ep;
   a.cg = ConvGeom{T1, F1, T2, F2, C};
   EMO_DISPATCH(dtype, return (launch_nt<T, 1>(a, (hipStream_t)stream)));
+}
+
+// dy1[b,t1,f1,c] = relu'(y1[b,t1,f1,c]) * sum_{kh,kw,n} dy2[b,(t1-kh)/2,(f1-kw)/2,n] * W[n,(kh,kw,c)]
+// (terms with odd / out-of-range source indices vanish): four implicit GEMMs, one per parity class of
+// (t1, f1), with K = 4C / 2C / 2C / C -- see DgradGeom.  w = the forward's [C, 9C] weight layout.
+extern "C" int emoasr_conv2_dgrad(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* w,
+                                  const void* y1, void* dy1, void* stream) {
+  EMO_CHECK(T1 >= 3 && F1 >= 3, "conv2_dgrad: input too small (T1=%d F1=%d)", T1, F1);
+  EMO_CHECK(C % 64 == 0, "conv2_dgrad: C must be a multiple of 64");
+  const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  for (int pt = 0; pt < 2; ++pt)
+    for (int pf = 0; pf < 2; ++pf) {
+      NtArgs a{};
+      DgradGeom& g = a.dg;
+      g.T1 = T1; g.F1 = F1; g.T2 = T2; g.F2 = F2; g.C = C; g.pt = pt; g.pf = pf;
+      g.nI = (T1 - pt + 1) / 2; g.nJ = (F1 - pf + 1) / 2;
+      g.ntap = 0;
+      for (int kh = pt; kh < 3; kh += 2)
+        for (int kw = pf; kw < 3; kw += 2) {
+          g.dh[g.ntap] = kh / 2; g.dw[g.ntap] = kw / 2; g.wtap[g.ntap] = (kh * 3 + kw) * C;
+          ++g.ntap;
+        }
+      if (g.nI <= 0 || g.nJ <= 0) continue;
+      a.M = B * g.nI * g.nJ; a.N = C; a.K = g.ntap * C;
+      a.A = dy2; a.lda = 0; a.B = w; a.ldb = 9 * C; a.C = dy1; a.ldc = C;
+      a.ep.alpha = 1.f; a.ep.dact_pre = y1; a.ep.dact = EMO_ACT_RELU; a.ep.res_scale = 1.f;
+      int rc = 1;
+      EMO_DISPATCH(dtype, rc = (g_tr_read ? launch_nt_<T, 2, true, true>(a, (hipStream_t)stream)
+                                          : launch_nt_<T, 2, true, false>(a, (hipStream_t)stream)));
+      if (rc) return rc;
+    }
+  return 0;
 }
 
 // dW[n, (kh,kw,c)] (+)= sum_{(b,t2,f2)} dy2[(b,t2,f2), n] * y1[b,2t2+kh,2f2+kw,c]

@@ -200,6 +200,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
         inter_on = (_cfg(cfg, "mtl_inter_ctc_weight", 0) or 0) > 0 or (_cfg(cfg, "mtl_phone_ctc_weight", 0) or 0) > 0
         self.inter_layer = int(cfg.inter_ctc_layer_id) if inter_on else 0
         self.eouts_inter = None
+        self._implicit_dgrad = os.environ.get("EMOASR_CONV2_DGRAD", "implicit") == "implicit"
         self.p_enc = float(_cfg(cfg, "dropout_enc_rate", 0.0))
         self.p_att = float(_cfg(cfg, "dropout_attn_rate", 0.0))
         self.dtype = compute_dtype
@@ -709,8 +710,11 @@ class CTCEngine(_DecoderMixinPlaceholder):
         dw2 = torch.zeros(C, 9 * C, device=dx.device, dtype=torch.float32)
         ops.conv2_wgrad(dy2, st.y1, dw2, dbias=A.g(pre + "conv.2.bias"), accumulate=True)
         ops.strided_copy(dw2.view(C, 3, 3, C).permute(0, 3, 1, 2), out=A.g(pre + "conv.2.weight"), accumulate=True)
-        dcol = ops.gemm_nn(dy2, st.w2r)
-        dy1 = ops.conv2_col2im(dcol, st.y1)
+        if self._implicit_dgrad:
+            dy1 = ops.conv2_dgrad(dy2, st.w2r, st.y1)  # four parity-class implicit GEMMs, no im2col buffer
+        else:
+            dcol = ops.gemm_nn(dy2, st.w2r)
+            dy1 = ops.conv2_col2im(dcol, st.y1)
         ops.conv1_wgrad(st.xs, dy1, A.g(pre + "conv.0.weight").view(C, 9), A.g(pre + "conv.0.bias"), accumulate=True)
 
     def head_backward(self, eouts, dlogits, head="decoder.output"):

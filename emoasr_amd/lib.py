@@ -136,6 +136,7 @@ SIGNATURES = {
     "emoasr_conv2_fwd": [I, I, I, I, I, P, P, P, POINTER(Epilogue), P],
     "emoasr_conv2_wgrad": [I, I, I, I, I, P, P, P, P, I, P],
     "emoasr_conv2_col2im": [I, I, I, I, I, P, P, P, P],
+    "emoasr_conv2_dgrad": [I, I, I, I, I, P, P, P, P, P],
     "emoasr_layernorm_fwd": [I, I, I, P, P, P, F, P, P, P, P],
     "emoasr_layernorm_bwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     "emoasr_layernorm_bwd_ex": [I, I, I, P, P, P, P, P, P, P, P, P, P, POINTER(LnBwdOpts), P],

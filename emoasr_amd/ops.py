@@ -189,6 +189,15 @@ def conv2_wgrad(dy2, y1, dw, dbias=None, accumulate=False):
              _p(dbias), int(accumulate), _stream())
 
 
+def conv2_dgrad(dy2, w, y1):
+    """dy2 [B,T2,F2,C] (or [B*T2*F2, C]), w [C, 9C] (conv2_fwd's layout), y1 [B,T1,F1,C] -> dy1 = relu'(y1) * conv2^T(dy2)"""
+    B, T1, F1, C = y1.shape
+    dy1 = torch.empty_like(y1)
+    lib.call("emoasr_conv2_dgrad", dt(y1), B, T1, F1, C, _p(_chk(dy2, y1.dtype)), _p(_chk(w, y1.dtype)), _p(y1), _p(dy1),
+             _stream())
+    return dy1
+
+
 def conv2_col2im(dcol, y1):
     B, T1, F1, C = y1.shape
     dy1 = torch.empty_like(y1)

@@ -110,6 +110,11 @@ int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const void* y1, co
 int emoasr_conv2_wgrad(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* y1,
                        float* dw, float* dbias, int accumulate, void* stream);
 /* dy1[b,t1,f1,c] = relu'(y1) * sum_{kh,kw} dcol[(b,t2,f2),(kh,kw,c)]  (col2im gather) */
+/* Data gradient of the same convolution without an im2col buffer (four implicit GEMMs, one per parity class of
+ * the output position): dy1[b,t1,f1,c] = relu'(y1[b,t1,f1,c]) * sum_{kh,kw,n} dy2[b,(t1-kh)/2,(f1-kw)/2,n]*w[n,(kh,kw,c)];
+ * w = the [C, 9C] layout of emoasr_conv2_fwd.  Replaces gemm_nn (dcol) + emoasr_conv2_col2im. */
+int emoasr_conv2_dgrad(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* w, const void* y1,
+                       void* dy1, void* stream);
 int emoasr_conv2_col2im(int dtype, int B, int T1, int F1, int C, const void* dcol, const void* y1,
                         void* dy1, void* stream);
 

@@ -150,9 +150,10 @@ def _conv2_weight_repack(w):  # (C, C, 3, 3) -> (C, (kh,kw,c))
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-def test_frontend(dev, dtype, tr_mode):
+@pytest.mark.parametrize("T,Fd", [(67, 80), (70, 83), (9, 7)], ids=["odd-T1", "even-T1-F1", "tiny"])
+def test_frontend(dev, dtype, tr_mode, T, Fd):
     from emoasr_amd import ops
-    B, T, Fd, C = 3, 67, 80, 128
+    B, C = 3, 128
     x = _rnd(dev, B, T, Fd)
     w1, b1 = _rnd(dev, C, 1, 3, 3, scale=0.3), _rnd(dev, C, scale=0.1)
     w2, b2 = _rnd(dev, C, C, 3, 3, scale=(9 * C) ** -0.5), _rnd(dev, C, scale=0.1)
@@ -183,6 +184,9 @@ def test_frontend(dev, dtype, tr_mode):
     # reference: grad wrt conv1 pre-relu output = y1_ref.grad * relu mask
     dy1_ref = (y1_ref.grad * (y1_ref > 0)).permute(0, 2, 3, 1)
     _close(dy1, dy1_ref, _tol(dtype, 1e-4, 3e-2), "col2im")
+    # the same gradient as four parity-class implicit GEMMs (no im2col buffer)
+    dy1_imp = ops.conv2_dgrad(dy2, w2p, y1)
+    _close(dy1_imp, dy1_ref, _tol(dtype, 1e-4, 3e-2), "conv2 implicit dgrad")
     dw1 = torch.empty(C, 9, device=dev)
     db1 = torch.empty(C, device=dev)
     ops.conv1_wgrad(x, dy1, dw1, db1)
