@@ -44,14 +44,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(int Tn, int F, int T1, i
 // (the f1 lanes of a channel group are adjacent lanes: 16-byte dy1 loads, 128-byte row segments, and a
 // 3-step shuffle folds them at the end).  The input rows of C1_SUB t1 rows are staged in LDS at a time.
 // One atomic per (block, output): large row chunks keep the same-address contention low.
-constexpr int C1_TROWS = 64;
+constexpr int C1_TROWS = 32;
 constexpr int C1_SUB = 8;
 constexpr int C1_FJ = 8;   // f1 positions per lane (8 lanes stride 8): F1 <= 64
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int Tn, int F, int T1, int F1, int C,
                                                           const float* __restrict__ x,
                                                           const T* __restrict__ dy1,
-                                                          float* __restrict__ dw, float* __restrict__ db) {
+                                                          float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float rows[];  // [2*C1_SUB+1][F]
   const int nchunk = (T1 + C1_TROWS - 1) / C1_TROWS;
   const int b = blockIdx.x / nchunk, tc = blockIdx.x % nchunk;
@@ -127,14 +127,38 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int Tn, int F, int T1,
 #pragma unroll
       for (int o = 1; o < 8; o <<= 1) acc[j][e] += __shfl_xor(acc[j][e], o, 64);
   }
+  // per-block partial sums [blk][C][10] (9 taps + bias): 260-way same-address float atomics cost more than
+  // the whole product; conv1_wgrad_reduce_kernel folds the partials
   if (cok && fl == 0) {
+    float* p = part + ((long)blockIdx.x * C + c) * 10;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
 #pragma unroll
-      for (int j = 0; j < 9; ++j) atomicAdd(&dw[(c + e) * 9 + j], acc[j][e]);
-      atomicAdd(&db[c + e], sb[e]);
+      for (int j = 0; j < 9; ++j) p[e * 10 + j] = acc[j][e];
+      p[e * 10 + 9] = sb[e];
     }
   }
+}
+
+// dw[c][j] (+)= sum_blk part[blk][c][j] (j < 9), db[c] (+)= sum_blk part[blk][c][9]
+__global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(int nblk, int C, const float* __restrict__ part,
+                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 int accumulate) {
+  __shared__ float red[4][64];
+  const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;  // 64 outputs x 4 slices of the partial list
+  const int i = blockIdx.x * 64 + li;                      // (c, j) flattened
+  float s = 0.f;
+  if (i < C * 10) {
+#pragma unroll 8
+    for (int k = sl; k < nblk; k += 4) s += part[(long)k * C * 10 + i];
+  }
+  red[sl][li] = s;
+  __syncthreads();
+  if (sl != 0 || i >= C * 10) return;
+  s = red[0][li] + red[1][li] + red[2][li] + red[3][li];
+  const int c = i / 10, j = i - c * 10;
+  float* o = j < 9 ? &dw[c * 9 + j] : &db[c];
+  *o = accumulate ? *o + s : s;
 }
 
 // dy1[b,t1,f1,c] = [y1 > 0] * sum over (kh,kw) with t1 = 2*t2+kh, f1 = 2*f2+kw of
@@ -193,23 +217,32 @@ extern "C" int emoasr_conv1_fwd(int dtype, int B, int Tn, int F, int C, const fl
   return 0;
 }
 
+extern "C" long emoasr_conv1_wgrad_scratch_floats(int B, int Tn, int C) {
+  const int T1 = (Tn - 3) / 2 + 1;
+  return (long)B * cdiv(T1 > 0 ? T1 : 1, C1_TROWS) * C * 10;
+}
+
 extern "C" int emoasr_conv1_wgrad(int dtype, int B, int Tn, int F, int C, const float* x, const void* dy1,
-                                  float* dw1, float* db1, int accumulate, void* stream) {
+                                  float* dw1, float* db1, int accumulate, float* scratch, void* stream) {
   EMO_CHECK(Tn >= 3 && F >= 3, "conv1_wgrad: input too small");
   EMO_CHECK(C <= 1024, "conv1_wgrad: C=%d > 1024", C);
   const int T1 = (Tn - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) {
-    hipMemsetAsync(dw1, 0, sizeof(float) * C * 9, s);
-    hipMemsetAsync(db1, 0, sizeof(float) * C, s);
+  if (B == 0) {
+    if (!accumulate) {
+      hipMemsetAsync(dw1, 0, sizeof(float) * C * 9, s);
+      hipMemsetAsync(db1, 0, sizeof(float) * C, s);
+    }
+    return 0;
   }
-  if (B == 0) return 0;
   EMO_CHECK(C % 8 == 0, "conv1_wgrad: C must be a multiple of 8");
   EMO_CHECK(F1 <= 8 * C1_FJ, "conv1_wgrad: F1=%d > %d", F1, 8 * C1_FJ);
+  EMO_CHECK(scratch, "conv1_wgrad: scratch of emoasr_conv1_wgrad_scratch_floats(B, T, C) floats required");
   const int nchunk = cdiv(T1, C1_TROWS);
   dim3 grid(B * nchunk, cdiv(C, 256));
   EMO_DISPATCH(dtype, (conv1_wgrad_kernel<T><<<grid, 256, (2 * C1_SUB + 1) * F * sizeof(float), s>>>(
-                          Tn, F, T1, F1, C, x, (const T*)dy1, dw1, db1)));
+                          Tn, F, T1, F1, C, x, (const T*)dy1, scratch)));
+  conv1_wgrad_reduce_kernel<<<cdiv(C * 10, 64), 256, 0, s>>>(B * nchunk, C, scratch, dw1, db1, accumulate);
   EMO_LAUNCH_CHECK();
   return 0;
 }

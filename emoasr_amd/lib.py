@@ -132,7 +132,7 @@ SIGNATURES = {
     "emoasr_gemm_tn_grouped": [I, I, POINTER(TnProblem), P],
     "emoasr_colsum": [I, I, I, P, L, P, F, I, P],
     "emoasr_conv1_fwd": [I, I, I, I, I, P, P, P, P, P],
-    "emoasr_conv1_wgrad": [I, I, I, I, I, P, P, P, P, I, P],
+    "emoasr_conv1_wgrad": [I, I, I, I, I, P, P, P, P, I, P, P],
     "emoasr_conv2_fwd": [I, I, I, I, I, P, P, P, POINTER(Epilogue), P],
     "emoasr_conv2_wgrad": [I, I, I, I, I, P, P, P, P, I, P],
     "emoasr_conv2_col2im": [I, I, I, I, I, P, P, P, P],

@@ -169,8 +169,9 @@ def conv1_fwd(x, w1, b1, dtype):
 def conv1_wgrad(x, dy1, dw1, db1, accumulate=False):
     B, T, F = x.shape
     C = dy1.shape[-1]
+    scratch = torch.empty(lib.size_query("emoasr_conv1_wgrad_scratch_floats", B, T, C), device=x.device, dtype=torch.float32)
     lib.call("emoasr_conv1_wgrad", dt(dy1), B, T, F, C, _p(x), _p(dy1), _p(dw1), _p(db1), int(accumulate),
-             _stream())
+             _p(scratch), _stream())
 
 
 def conv2_fwd(y1, w, **epi):

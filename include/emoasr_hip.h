@@ -100,9 +100,11 @@ int emoasr_colsum(int dtype, int M, int N, const void* X, long ldx, float* out, 
  * w1 f32 [C,9], b1 f32 [C]; ReLU fused. */
 int emoasr_conv1_fwd(int dtype, int B, int T, int F, int C, const float* x, const float* w1,
                      const float* b1, void* y1, void* stream);
-/* dw1[C,9], db1[C] (+)= from dy1 (gradient w.r.t. the pre-ReLU conv1 output) */
+/* dw1[C,9], db1[C] (+)= from dy1 (gradient w.r.t. the pre-ReLU conv1 output);
+ * scratch: emoasr_conv1_wgrad_scratch_floats(B, T, C) floats of per-block partial sums */
 int emoasr_conv1_wgrad(int dtype, int B, int T, int F, int C, const float* x, const void* dy1,
-                       float* dw1, float* db1, int accumulate, void* stream);
+                       float* dw1, float* db1, int accumulate, float* scratch, void* stream);
+long emoasr_conv1_wgrad_scratch_floats(int B, int T, int C);
 /* y2[(b,t2,f2), n] = epilogue(sum y1[b,2t2+kh,2f2+kw,c] * w[n,(kh,kw,c)])  (implicit GEMM) */
 int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const void* y1, const void* w, void* y2,
                      const emoasr_epilogue_t* ep, void* stream);
