@@ -18,6 +18,22 @@
 
 namespace {
 
+// log-space sums on the hardware exp2 / log2 units (v_exp_f32 / v_log_f32 through __expf / __logf): the
+// lattice recursions are one dependent chain per frame, and the accurate expf / logf / log1pf expansions
+// (~20 instructions each) were a large part of a step.  Absolute error ~1e-6 per step.  (A one-wave variant
+// with two states per lane and shuffles instead of LDS + barrier was measured no faster: the step is bound
+// by the dependent max / exp / log chain, ~0.33 us.)
+__device__ __forceinline__ float lat_add(float a, float b) {
+  const float m = fmaxf(a, b);
+  if (m == -INFINITY) return -INFINITY;
+  return m + __logf(1.f + __expf(-fabsf(a - b)));
+}
+__device__ __forceinline__ float lat_add3(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  if (m == -INFINITY) return -INFINITY;
+  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void row_lse_kernel(int V, const T* __restrict__ logits, long ld,
                                                       float* __restrict__ lse, int aligned) {
@@ -121,7 +137,7 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(int B, int Tn, int S,
       const float a0 = prev[s];
       const float a1 = fwd ? prev[s - 1] : prev[s + 1];
       const float a2 = skip ? (fwd ? prev[s - 2] : prev[s + 2]) : -INFINITY;
-      v = log_add3(a0, a1, a2) + e;
+      v = lat_add3(a0, a1, a2) + e;
     }
     if (s < S) { out[(long)t * S + s] = v; cur[s] = v; }
     __syncthreads();

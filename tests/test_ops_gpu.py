@@ -419,6 +419,35 @@ def test_ctc(dev, dtype, infeasible):
     _close(loss, ref.detach(), 1e-4, "loss")
 
 
+@pytest.mark.parametrize("L", [1, 31, 32, 63, 64, 90], ids=lambda v: f"L{v}")
+def test_ctc_lattice_label_lengths(dev, L):
+    """lattices of 3 .. 181 states (one to three waves per block) against torch's CTC loss, feasibility pattern
+    included"""
+    from emoasr_amd import ops
+    torch.manual_seed(L)
+    B, T, V = 5, 2 * L + 37, 23
+    elens = torch.tensor([T, T - 1, 2 * L + 1, T - 5, max(L, 1)], device=dev, dtype=torch.int32)
+    ylens = torch.tensor([L, max(L - 1, 0), L, max(L // 2, 1), max(L, 1)], device=dev, dtype=torch.int32)
+    labels = torch.randint(1, V, (B, L), device=dev, dtype=torch.int32)
+    if L >= 3:
+        labels[0, 2] = labels[0, 1]
+    logits = _rnd(dev, B, T, V, scale=2.0)
+    lse = ops.row_lse(logits.view(B * T, V))
+    nll_ref = F.ctc_loss(logits.transpose(0, 1).log_softmax(2), labels.long(), elens.long(), ylens.long(), blank=0,
+                         reduction="none", zero_infinity=False)
+    lp, alpha, beta, nll = ops.ctc_forward(logits, lse, labels, elens, ylens, 0)
+    fin = torch.isfinite(nll_ref)
+    assert torch.equal(torch.isfinite(nll), fin), (nll, nll_ref)
+    _close(nll[fin], nll_ref[fin], 1e-4, "nll")
+    # alpha and beta meet: for every frame, logsumexp_s(alpha + beta - lp) = -nll
+    for b in range(B):
+        if not bool(fin[b]):
+            continue
+        n, Sb = int(elens[b]), 2 * int(ylens[b]) + 1
+        tot = torch.logsumexp((alpha[b, :n, :Sb] + beta[b, :n, :Sb] - lp[b, :n, :Sb]).nan_to_num(nan=-float("inf")), -1)
+        assert (tot + nll[b]).abs().max() < 2e-3 * max(1.0, float(nll[b])), (b, (tot + nll[b]).abs().max())
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_ctc_greedy(dev, dtype):
     from itertools import groupby
