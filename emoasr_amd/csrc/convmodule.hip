@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(long n, int C, const 
 // rows r0 + lane_row + 8*it.  Pass 1 writes per-block partial sums [block][2][C] (no atomics, no
 // zeroing); pass 2 first folds the few partial rows for its channels (block-cooperatively through
 // LDS), then applies.
-constexpr int BN_SUM_ROWS = 64;  // rows per block of pass 1 (-> M/64 partial rows; 128: fewer, slower blocks; 32: pass 2 folds too many)
-constexpr int BN_APPLY_ROWS = 32; // rows per block of pass 2
+constexpr int BN_SUM_ROWS = 16;  // rows per block of pass 1 (-> M/16 partial rows, folded by bn_bwd_fold_kernel)
+constexpr int BN_APPLY_ROWS = 16; // rows per block of pass 3
 
 // pass 1: part[blk][c] = sum dbn, part[blk][C+c] = sum dbn*xhat   with dbn = dz * swish'(bn)
 template <typename T>
@@ -297,8 +297,32 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(int M, int C, const T*
     part[(long)blockIdx.y * 2 * C + C + cc] = b;
   }
 }
-// pass 2: dy = gamma*invstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat)); row block 0 also
-// adds dgamma / dbeta.
+// pass 2: tot[c] = mean(dbn), tot[C + c] = mean(dbn * xhat) from the partial rows (16 channels x 64 groups of
+// partial rows per block, like bn_stats_finalize_kernel); also dbeta += sum dbn, dgamma += sum dbn*xhat.
+__global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(int npart, int C, float inv_m, const float* __restrict__ part,
+                                                           float* __restrict__ tot, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+  __shared__ float red[2][64][16];
+  const int lane = threadIdx.x % 16, grp = threadIdx.x / 16;
+  const int c = blockIdx.x * 16 + lane;
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+#pragma unroll 8
+    for (int k = grp; k < npart; k += 64) { a += part[(long)k * 2 * C + c]; b += part[(long)k * 2 * C + C + c]; }
+  }
+  red[0][grp][lane] = a;
+  red[1][grp][lane] = b;
+  __syncthreads();
+  if (grp != 0 || c >= C) return;
+  a = 0.f; b = 0.f;
+#pragma unroll
+  for (int g = 0; g < 64; ++g) { a += red[0][g][lane]; b += red[1][g][lane]; }
+  if (dbeta) dbeta[c] += a;
+  if (dgamma) dgamma[c] += b;
+  tot[c] = a * inv_m;
+  tot[C + c] = b * inv_m;
+}
+// pass 3: dy = gamma*invstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat))
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int C, const T* __restrict__ dz,
                                                            const T* __restrict__ y,
@@ -306,25 +330,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int C, const T
                                                            const float* __restrict__ var,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps,
-                                                           const float* __restrict__ part, int npart,
-                                                           T* __restrict__ dy, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
-  __shared__ float tot[2][256];
-  {
-    const int cc = blockIdx.x * 256 + threadIdx.x;
-    float a = 0.f, b = 0.f;
-    if (cc < C) {
-#pragma unroll 8
-      for (int k = 0; k < npart; ++k) { a += part[(long)k * 2 * C + cc]; b += part[(long)k * 2 * C + C + cc]; }
-      if (blockIdx.y == 0) {
-        if (dbeta) dbeta[cc] += a;
-        if (dgamma) dgamma[cc] += b;
-      }
-    }
-    tot[0][threadIdx.x] = a / M;
-    tot[1][threadIdx.x] = b / M;
-  }
-  __syncthreads();
+                                                           const float* __restrict__ tot,
+                                                           T* __restrict__ dy) {
   const int hl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 256 + hl * 8;
   if (c >= C) return;
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int C, const T
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     mu[j] = mean[c + j]; is[j] = rsqrtf(var[c + j] + eps); g[j] = gamma[c + j]; bt[j] = beta[c + j];
-    m1[j] = tot[0][hl * 8 + j]; m2[j] = tot[1][hl * 8 + j];
+    m1[j] = tot[c + j]; m2[j] = tot[C + c + j];
   }
   const __amdgpu_buffer_rsrc_t rsy = make_rsrc(y), rsd = make_rsrc(dz);
   const int r0 = blockIdx.y * BN_APPLY_ROWS;
@@ -450,7 +457,7 @@ extern "C" int emoasr_bn_swish_fwd(int dtype, int M, int C, const void* y, const
   return 0;
 }
 
-extern "C" long emoasr_bn_swish_bwd_scratch_floats(int M, int C) { return (long)cdiv(M, BN_SUM_ROWS) * 2 * C; }
+extern "C" long emoasr_bn_swish_bwd_scratch_floats(int M, int C) { return ((long)cdiv(M, BN_SUM_ROWS) + 1) * 2 * C; }
 
 extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, const void* y,
                                    const float* mean, const float* var, const float* gamma,
@@ -465,9 +472,10 @@ extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, cons
   dim3 sgrid(cdiv(C, 256), npart);
   EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<sgrid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
                                                                   var, gamma, beta, eps, scratch)));
+  float* tot = scratch + (long)npart * 2 * C;
+  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta);
   EMO_DISPATCH(dtype, (bn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
-                                                                  var, gamma, beta, eps, scratch, npart, (T*)dy,
-                                                                  dgamma, dbeta)));
+                                                                  var, gamma, beta, eps, tot, (T*)dy)));
   EMO_LAUNCH_CHECK();
   return 0;
 }
