@@ -247,8 +247,12 @@ __device__ __forceinline__ void store_dT(T* dst, long ld, int r0, int rlimit, co
 // ====================================================================================
 // forward
 // ====================================================================================
-template <typename T, bool TR>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const emoasr_attn_t a) {
+// PF2: two prefetch register sets (a full tile of distance, ~390 registers: one wave per SIMD) for grids of
+// at most one block per CU; otherwise one set, refilled as soon as the score MFMAs have read it, and two
+// blocks per CU (bf16).  Measured at B 20, T' 340 (240 blocks): 36 us with two sets, 45 us with one; at 264
+// blocks the two-set kernel's second round of blocks costs 80 us against 62.
+template <typename T, bool TR, bool PF2>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fwd_kernel(const emoasr_attn_t a) {
   using M_ = Mma<T>;
   constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = AttnCfg<T>::LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -273,10 +277,72 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const emoasr_attn_t a) {
   zero16(o[0]); zero16(o[1]);
   int kend = hp.klen;
   if (a.causal) kend = min(kend, i0 + 32);
-  for (int j0 = 0; j0 < kend; j0 += 32) {
+
+  // Operand prefetch: the K / position-band fragments and the V rows of key tile j0+32 are loaded (bounds-
+  // checked buffer loads, no branches) as soon as tile j0's score MFMAs have read theirs, and fly during its
+  // skew, softmax and P.V.  With
+  // one wave per SIMD at the L2 batch size, loading each tile right where it was needed exposed two global
+  // round trips per tile.
+  constexpr int VEC = 16 / sizeof(T), PER_ROW = DK / VEC, VR = 32 * PER_ROW / 64;
+  struct Pre { typename M_::Frag kf[NK]; typename M_::Frag pf[2][NK]; Vec16<T> vr[VR]; };
+  const bool rel = hp.pos != nullptr;
+  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(hp.v);
+  auto fetch = [&](Pre& p, int j0) {
+    const bool live = j0 < kend;  // past the last tile: out-of-range offsets, no traffic
+    const int krow = j0 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+      p.kf[kk] = frag_global<T>((const T*)hp.k, a.ldk, krow, live && krow < a.Tk, kk, lane, nullptr);
+    if (rel) {
+      const int rbase = a.Tq - 32 - i0 + j0, rmax = 2 * a.Tq - 2;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int prow = clampi(rbase + 32 * ct + (lane & 31), 0, rmax);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+          p.pf[ct][kk] = frag_global<T>((const T*)hp.pos, a.ldp, prow, live, kk, lane, nullptr);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VR; ++i) {
+      const int v = lane + 64 * i, r = v / PER_ROW, piece = (v % PER_ROW) * VEC, row = j0 + r;
+      p.vr[i] = buf_load16<T>(rsV, live && row < a.Tk ? (unsigned)(((long)row * a.ldv + piece) * sizeof(T)) : EMO_OOB);
+    }
+  };
+  auto tile = [&](Pre& cur, Pre& nxt, int j0) {
+    if constexpr (PF2) fetch(nxt, j0 + 32);
+#pragma unroll
+    for (int i = 0; i < VR; ++i) {
+      const int v = lane + 64 * i;
+      store16(Vs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, cur.vr[i]);
+    }
+    // S^T = K . (Q+u)^T + skew(pos_band . (Q+v)^T)   (rows keys, cols queries; see score_tile)
     f32x16 s;
-    score_tile<T, true>(s, a, hp, i0, j0, qu, qv, nullptr, Gs, lane);
-    stage_rows<T, 32>(Vs, (const T*)hp.v, a.ldv, j0, 0, a.Tk, lane, nullptr);
+    zero16(s);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) s = M_::mma(cur.kf[kk], qu[kk], s);
+    if (rel) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x16 g;
+        zero16(g);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) g = M_::mma(cur.pf[ct][kk], qv[kk], g);  // g[c][i]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Gs[(32 * ct + c_row(r, lane)) * 32 + (lane & 31)] = g[r];
+      }
+    }
+    // one register set: every prefetched register has been consumed, refill them with tile j0+32
+    if constexpr (!PF2) fetch(cur, j0 + 32);
+    if (rel) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = c_row(r, lane), il = lane & 31;
+        s[r] += Gs[(31 - il + jl) * 32 + il];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     if (a.st && qval) {  // keep the scaled scores for the backward pass (32 queries contiguous per key row)
       float* srow = a.st + (((long)b * a.H + h) * a.Tk + j0) * a.ldst + qi;
 #pragma unroll
@@ -320,6 +386,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const emoasr_attn_t a) {
       for (int ks = 0; ks < NS; ++ks)
         o[dt] = M_::mma(chain_a<T, TR>(Vs, ks, 32 * dt, lane), chain_b<T>(s, ks), o[dt]);
     __builtin_amdgcn_wave_barrier();
+  };
+  if constexpr (PF2) {
+    Pre pa, pb;
+    fetch(pa, 0);
+    for (int j0 = 0; j0 < kend; j0 += 64) {
+      tile(pa, pb, j0);
+      if (j0 + 32 < kend) tile(pb, pa, j0 + 32);
+    }
+  } else {
+    Pre pc;
+    fetch(pc, 0);
+    for (int j0 = 0; j0 < kend; j0 += 32) tile(pc, pc, j0);
   }
   const float inv = l > 0.f ? 1.f / l : 0.f;
   store_dT<T>((T*)hp.out, a.ldo, i0, a.Tq, o, inv, lane);
@@ -1102,12 +1180,29 @@ int launch_fwd(const emoasr_attn_t& a, hipStream_t s) {
   constexpr int LD = AttnCfg<T>::LD;
   const int smem = 4 * (64 * 32 * 4 + 32 * LD * (int)sizeof(T));
   dim3 grid(cdiv(a.Tq, 128), a.H, a.B);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  const bool one_round = (long)grid.x * grid.y * grid.z <= n_cu;  // at most one block per CU: see attn_fwd_kernel
   if (g_tr) {
-    if (set_smem(attn_fwd_kernel<T, true>, smem)) return 1;
-    attn_fwd_kernel<T, true><<<grid, 256, smem, s>>>(a);
+    if (one_round) {
+      if (set_smem(attn_fwd_kernel<T, true, true>, smem)) return 1;
+      attn_fwd_kernel<T, true, true><<<grid, 256, smem, s>>>(a);
+    } else {
+      if (set_smem(attn_fwd_kernel<T, true, false>, smem)) return 1;
+      attn_fwd_kernel<T, true, false><<<grid, 256, smem, s>>>(a);
+    }
   } else {
-    if (set_smem(attn_fwd_kernel<T, false>, smem)) return 1;
-    attn_fwd_kernel<T, false><<<grid, 256, smem, s>>>(a);
+    if (one_round) {
+      if (set_smem(attn_fwd_kernel<T, false, true>, smem)) return 1;
+      attn_fwd_kernel<T, false, true><<<grid, 256, smem, s>>>(a);
+    } else {
+      if (set_smem(attn_fwd_kernel<T, false, false>, smem)) return 1;
+      attn_fwd_kernel<T, false, false><<<grid, 256, smem, s>>>(a);
+    }
   }
   EMO_LAUNCH_CHECK();
   return 0;
