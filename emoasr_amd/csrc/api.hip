@@ -16,6 +16,7 @@ void emo_set_error(const char* fmt, ...) {
 
 void emo_gemm_set_tr_read(int v);
 void emo_gemm_set_tile(int v);
+void emo_gemm_set_tn_group_blocks(int v);
 void emo_gemm_set_kb(int v);
 void emo_gemm_set_xcd(int v);
 void emo_attn_set_tr_read(int v);
@@ -29,6 +30,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
     return 0;
   }
   if (strcmp(name, "gemm_tile") == 0) { emo_gemm_set_tile(value); return 0; }
+  if (strcmp(name, "tn_group_blocks") == 0) { emo_gemm_set_tn_group_blocks(value); return 0; }
   if (strcmp(name, "gemm_kb") == 0) { emo_gemm_set_kb(value); return 0; }
   if (strcmp(name, "gemm_xcd") == 0) { emo_gemm_set_xcd(value); return 0; }
   emo_set_error("unknown option '%s'", name);

@@ -62,6 +62,7 @@ __device__ __forceinline__ void dgrad_row(const DgradGeom& g, int m, int& b, int
 
 int g_tr_read = 1;
 int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1;
+int g_tn_group_blocks = 0;  // override of a grouped TN launch's block budget (emoasr_set_option "tn_group_blocks"; 0 = auto)
 
 // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Reading
 // the linear id as (xcd, slot) makes XCD x work on ONE contiguous range of the logical block list, so
@@ -624,10 +625,11 @@ int launch_tn(TnArgs a, hipStream_t s) {
   const bool big = (long)cdiv(a.N1, 128) * cdiv(a.N2, 128) >= 32 && a.N1 >= 128 && a.N2 >= 128;
   const int bn = big ? 128 : 64;
   const long tiles = (long)cdiv(a.N1, bn) * cdiv(a.N2, bn);
-  // split-K: enough slices to put ~2 blocks on every CU with at least 4 k-tiles each, but keep
+  // split-K: as many slices as fit ONE round of resident blocks (rounding up past it leaves a mostly empty
+  // second round) with at least 4 k-tiles each, but keep
   // the f32 atomic traffic (output bytes x slices) around 8 MB: global float atomics run at
   // ~1.3 TB/s chip-wide, so more slices than that make the kernel atomic-bound.
-  int splits = (int)((512 + tiles - 1) / tiles);
+  int splits = (int)std::max(1L, (big ? 512 : 768) / tiles);  // one full round of resident blocks (2 / 3 per CU)
   const long out_bytes = (long)a.N1 * a.N2 * 4;
   // ... unless the reduction is so long that the atomics stay below ~10 % of the product's own time
   // (estimated at 300 TFLOP/s): the Conv2d weight gradient (K = B*T'*F2 ~ 130 k) wants 15 slices, not 3
@@ -665,6 +667,7 @@ int launch_tn(TnArgs a, hipStream_t s) {
 
 void emo_gemm_set_tr_read(int v) { g_tr_read = v; }
 void emo_gemm_set_tile(int v) { g_gemm_tile = v; }
+void emo_gemm_set_tn_group_blocks(int v) { g_tn_group_blocks = v > 0 ? v : 0; }
 void emo_gemm_set_kb(int v) { g_gemm_kb = v; }
 void emo_gemm_set_xcd(int v) { g_gemm_xcd = v; }
 
@@ -756,9 +759,12 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
               "gemm_tn_grouped: ragged N1 needs padded lda");
     tiles += (long)cdiv(q.N1, bt) * cdiv(q.N2, bt);
   }
-  // one split factor for the whole group: ~3 blocks per CU over all problems, at least 4 k-tiles per
-  // slice, and per problem no more f32 atomic traffic than ~8 MB (see launch_tn)
-  const int want = (int)std::max(1L, (768 + tiles - 1) / tiles);
+  // at least 4 k-tiles per slice, and per problem no more f32 atomic traffic than ~8 MB (see launch_tn)
+  // one split factor for the whole group, chosen so that the launch is ONE full round of resident blocks:
+  // a 128x128-tile block takes 80 KB of LDS (2 per CU), a 64x64 one 48 KB (3 per CU).  Rounding the block
+  // count up past that (768 blocks of the 128 tile = 1.5 rounds) measured 68 us against 52 us for 460.
+  const long slots = g_tn_group_blocks > 0 ? g_tn_group_blocks : (bt == 128 ? 512 : 768);
+  const int want = (int)std::max(1L, slots / tiles);
   int start = 0;
   for (int i = 0; i < n; ++i) {
     const emoasr_tn_problem_t& q = probs[i];
