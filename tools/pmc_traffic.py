@@ -10,7 +10,7 @@ def family(name):
     n = re.sub(r"\(anonymous namespace\)::", "", name)
     m = re.search(r"gemm_nt_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d)ELb(\d)", n)
     if m:
-        kind = "conv2_fwd" if m.group(4) == "1" else ("gemm_nn" if m.group(5) == "1" else "gemm_nt")
+        kind = {"1": "conv2_fwd", "2": "conv2_dgrad"}.get(m.group(4), "gemm_nn" if m.group(5) == "1" else "gemm_nt")
         return f"{kind}[{m.group(2)}x{m.group(3)}]"
     m = re.search(r"(gemm_tn_grouped_kernel|gemm_tn_kernel|attn_bwd_dq2_kernel|attn_fwd_kernel|ln_bwd8_kernel|ln_fwd_kernel)", n)
     if m:
