@@ -294,6 +294,21 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(int V, const T* __rest
   }
 }
 
+// out[0] = first i < n with x[i] != value (or -1), out[1] = x[that i] (or value): one wave, the transducer's
+// windowed greedy search reads both with a single 8-byte D2H copy.
+__global__ __launch_bounds__(64) void first_not_equal_kernel(int n, const int* __restrict__ x, int value,
+                                                             int* __restrict__ out) {
+  int best = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += 64)
+    if (x[i] != value) { best = i; break; }  // per lane: its first hit (lanes stride the array)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+  if (threadIdx.x == 0) {
+    out[0] = best == 0x7fffffff ? -1 : best;
+    out[1] = best == 0x7fffffff ? value : x[best];
+  }
+}
+
 inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
 }  // namespace
@@ -363,6 +378,12 @@ extern "C" int emoasr_rnnt_grad(int dtype, int B, int T_, int U, int V, int Lmax
   EMO_DISPATCH(dtype, (rnnt_grad_kernel<T><<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(
                           rows, T_, U, V, Lmax, (const T*)logits, lse, lpb, lpy, alpha, beta, labels, elens, ylens, nll,
                           blank, gscale, gscale_dev, (T*)dlogits)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int emoasr_first_not_equal(int n, const int* x, int value, int* out, void* stream) {
+  first_not_equal_kernel<<<1, 64, 0, (hipStream_t)stream>>>(n, x, value, out);
   EMO_LAUNCH_CHECK();
   return 0;
 }

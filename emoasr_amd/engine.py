@@ -1034,9 +1034,13 @@ class _RNNTMixin:
             self.rnnt_recurrency_bwd(st.rst, ddouts.view(U, B, H))
             return deouts
 
-    def rnnt_greedy(self, eouts, elens_host, blank, eos, max_seq_len=256):
-        """time-synchronous greedy search (rnn_transducer.py:194-240): one joint evaluation, one arg-max
-        and one 4-byte D2H per emitted symbol; the LSTM advances only on non-blank symbols."""
+    def rnnt_greedy(self, eouts, elens_host, blank, eos, max_seq_len=256, window=64):
+        """time-synchronous greedy search (rnn_transducer.py:194-240).  While the arg-max is blank the
+        prediction network does not move, so the frames t, t+1, ... can be scored against the SAME decoder
+        state in one batched joint + output GEMM: each round scores up to `window` frames, finds the first
+        non-blank one on the device and brings (index, token) back with one 8-byte copy -- one host round
+        trip per emitted label (plus one per all-blank window) instead of one per frame.  The sequence of
+        (frame, token) decisions is exactly the reference's."""
         with ops.stream_scope(), torch.no_grad():
             A, J = self.arena, self.r_J
             A.refresh_shadow()
@@ -1049,22 +1053,24 @@ class _RNNTMixin:
                 g = ops.gemm_nt(dout.view(1, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
                 hyp, align, t = [], [], 0
                 while t < T:
-                    h = ops.joint_tanh(e_all[t].view(1, 1, J), g.view(1, 1, J))
-                    logits = ops.gemm_nt(h.view(1, J), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
-                    tok = int(ops.argmax_rows(logits).item())
-                    align.append(tok)
-                    if tok == blank:
-                        t += 1
-                    else:
-                        hyp.append(tok)
-                        dout, state, _ = self.rnnt_recurrency(h2d_i32([[tok]], dev), state, False, False)
-                        g = ops.gemm_nt(dout.view(1, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
+                    n = min(window, T - t)
+                    h = ops.joint_tanh(e_all[t:t + n].view(1, n, J), g.view(1, 1, J))
+                    logits = ops.gemm_nt(h.view(n, J), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
+                    k, tok = ops.first_not_equal(ops.argmax_rows(logits), blank).tolist()
+                    if k < 0:  # every frame of the window is blank
+                        align += [blank] * n
+                        t += n
+                        continue
+                    align += [blank] * k + [tok]
+                    t += k  # the label is emitted AT frame t+k: the search stays on that frame
+                    hyp.append(tok)
+                    dout, state, _ = self.rnnt_recurrency(h2d_i32([[tok]], dev), state, False, False)
+                    g = ops.gemm_nt(dout.view(1, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
                     if len(hyp) > max_seq_len:
                         break
                 hyps.append(hyp)
                 aligns.append(align)
             return hyps, aligns
-
 
     def rnnt_beam_search(self, eouts, beam_width, blank, eos, num_expands=3):
         """alignment-length synchronous beam search for ONE utterance (rnn_transducer.py:242-325,348-359).

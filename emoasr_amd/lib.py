@@ -182,6 +182,7 @@ SIGNATURES = {
     "emoasr_rnnt_forward": [I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P],
     "emoasr_rnnt_grad": [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, F, P, P, P],
     "emoasr_argmax_rows": [I, I, I, P, L, P, P],
+    "emoasr_first_not_equal": [I, P, I, P, P],
     "emoasr_sqnorm": [L, P, P, P],
     "emoasr_adam_step": [L, P, P, P, P, F, F, F, F, F, I, P, F, F, P],
     "emoasr_specaug_apply": [I, I, I, P, P, I, I, P, P, P],

@@ -683,6 +683,13 @@ def argmax_rows(x):
     return out
 
 
+def first_not_equal(x, value):
+    """x int32 [n] -> int32 [2] = (first index with x != value or -1, x there or value)"""
+    out = torch.empty(2, device=x.device, dtype=torch.int32)
+    lib.call("emoasr_first_not_equal", x.numel(), _p(_chk(x, torch.int32)), int(value), _p(out), _stream())
+    return out
+
+
 # ---- optimizer -------------------------------------------------------------------------
 def sqnorm(x, out):
     lib.call("emoasr_sqnorm", x.numel(), _p(_chk(x, torch.float32)), _p(out), _stream())

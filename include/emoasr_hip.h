@@ -363,6 +363,9 @@ int emoasr_rnnt_grad(int dtype, int B, int T, int U, int V, int Lmax, const void
                      const float* gscale_dev, void* dlogits, void* stream);
 /* out[m] = argmax_v x[m,:V] (first maximum) */
 int emoasr_argmax_rows(int dtype, int M, int V, const void* x, long ldx, int* out, void* stream);
+/* out[0] = first i < n with x[i] != value (-1: none), out[1] = x[that i] (value: none) -- the windowed greedy
+ * transducer search (rnn_transducer.py:194-240) finds the next non-blank frame with one 8-byte D2H copy */
+int emoasr_first_not_equal(int n, const int* x, int value, int* out, void* stream);
 
 /* ---- one Conformer encoder layer, forward, sequenced on the host in C++ ---------
  * ConformerEncoderLayer.forward (asr/modeling/conformer.py:146-225) with relative-position attention:

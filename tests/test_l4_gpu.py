@@ -80,6 +80,19 @@ def test_greedy_decode_f32(dev):
     assert hyps2 == hyps and s2 is None and l2 is None and a2 is None  # decode() discards them (quirk 7)
 
 
+@pytest.mark.parametrize("window", [1, 3, 7, 64])
+def test_greedy_window_sizes(dev, window):
+    """the windowed search (frames scored in batches against an unchanged decoder state) takes the same
+    (frame, token) decisions for every window size -- window 1 is the reference's frame-by-frame loop"""
+    model, g = _build(torch.float32, dev)
+    model.eval()
+    with torch.no_grad():
+        eouts, elens, _ = model.encoder(g["xs"].to(dev), g["xlens"])
+        hyps, aligns = model.engine().rnnt_greedy(eouts, elens.tolist(), 0, 2, window=window)
+    assert hyps == split_ragged(g["eval/hyps"], g["eval/hyp_lens"])
+    assert aligns == split_ragged(g["eval/aligns"], g["eval/align_lens"])
+
+
 def test_beam_search_f32(dev):
     """ALSD beam search (rnn_transducer.py:242-325): the same hypotheses, in the same order, as the
     reference produced for the fitted l4_tiny weights (tests/golden/rnntbeam_tiny.npz)"""
