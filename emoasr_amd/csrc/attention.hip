@@ -1154,6 +1154,466 @@ __global__ __launch_bounds__(256) void attn_dbias_v_kernel(const emoasr_attn_t a
   a.dbias_v[col] += s;
 }
 
+// ====================================================================================
+// backward, single pass (round 2; bf16): one launch recomputes each score tile ONCE and produces dQ, dK, dV,
+// dbias_u and -- with relative positions -- the dS image the dpos pass reads.  Nothing else reaches HBM: no
+// P^T / dBD images, no follow-up GEMMs.
+//
+//   workgroup = FW waves = FW consecutive 32-key tiles of one (batch, head); it sweeps the query tiles i0 = 0, 32, ...
+//   * per wave, stationary in registers: K and V fragments of its key tile, K^T fragments (dQ operand), the dK^T / dV^T
+//     accumulators, per-key column sums of dS (dbias_u = sum_j colsum_j K_j);
+//   * per step, shared by the block through LDS (double buffered, ONE barrier per step): the (Q+u), (Q+v), dO tiles
+//     of the 32 queries and the union of the waves' position bands (32*FW + 32 rows of the projected table); they are
+//     fetched one step ahead into registers with bounds-checked buffer loads and written to LDS at the end of the step;
+//   * tile orientation as in the forward (rows = keys in registers, columns = queries on lanes): S^T = K (Q+u)^T +
+//     skew(band (Q+v)^T), dP^T = V dO^T; dQ^T += K^T dS^T + band^T unskew(dS^T) chains the accumulator straight into
+//     the next MFMA; dV^T += dO^T P and dK^T += (Q+u)^T dS sum over the query index, which sits on the lanes, so P and
+//     dS go through a 2.5 KB wave-private bf16 image (the same image feeds the un-skew);
+//   * the waves' dQ^T partials are summed with LDS float atomics into a [64 d][32 i] tile (two tiles, alternating), and
+//     the tile of the previous step is flushed with ONE set of global f32 atomics per block (rows of 64 d = 256 B);
+//   * dS (query-major, bf16) is stored for attn_bwd_dpos2_kernel, which walks its diagonals: dpos[r] = sum_{b,i}
+//     dS[b,i,i-(Tq-1)+r] (Q+v)[b,i].  dbias_v = colsum(dQ) - dbias_u comes out of the finalize pass.
+// ====================================================================================
+
+struct FusedWs {       // workspace carved by emoasr_attn_bwd_fused
+  float* dq32;         // f32 [B, Tq, H*DK]: dQ accumulator (zeroed by the prologue kernel)
+  void* dsq;           // T [B, H, Tq, ldds]: dS, query-major (relative positions only)
+  long ldds;
+  const void *qu, *qv; // T [B, Tq, ldqu]: Q + pos_bias_u, Q + pos_bias_v  (without biases: q itself, ldq)
+  long ldqu;
+};
+
+// prologue: delta[b,h,i] = dO.O, dense Q+u / Q+v, dq32 = 0.  8 lanes x 8 elements per (b,i,h) row.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t a, float* __restrict__ dq32,
+                                                            T* __restrict__ qu, T* __restrict__ qv) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = idx >> 3, total = (long)a.B * a.Tq * a.H;
+  const int d0 = (int)(idx & 7) * 8;
+  const bool ok = row < total;
+  const int h = ok ? (int)(row % a.H) : 0;
+  const long bt = ok ? row / a.H : 0;
+  float dv[8], ov[8];
+  load8<T>((const T*)a.dout + bt * a.ldo + h * DK + d0, dv);
+  load8<T>((const T*)a.out + bt * a.ldo + h * DK + d0, ov);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += dv[j] * ov[j];
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  if (!ok) return;
+  const int i = (int)(bt % a.Tq), b = (int)(bt / a.Tq);
+  if (d0 == 0) a.delta[((long)b * a.H + h) * a.Tq + i] = s;
+  const long o = (bt * a.H + h) * DK + d0;
+  *reinterpret_cast<f32x4*>(dq32 + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+  *reinterpret_cast<f32x4*>(dq32 + o + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (qu) {
+    float qx[8], u[8], v[8];
+    load8<T>((const T*)a.q + bt * a.ldq + h * DK + d0, qx);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { u[j] = qx[j] + a.bias_u[h * DK + d0 + j]; v[j] = qx[j] + a.bias_v[h * DK + d0 + j]; }
+    store8<T>(qu + o, u);
+    store8<T>(qv + o, v);
+  }
+}
+
+// FW = waves (key tiles) per workgroup: 4 (one workgroup per CU), or 2 with half the LDS (two workgroups per CU) when
+// the 4-wave grid would need a second, nearly empty round of workgroups
+template <typename T, int FW> struct FusedCfg {
+  static constexpr int LD = AttnCfg<T>::LD;
+  static constexpr int IMG = DqCfg<T>::IMG_LD;
+  // per wave: the dS image with 31 zero rows above and below it (the band un-skew reads key - 31 + query without a
+  // range test), then a region shared by the 64-row f32 skew tile (before the soft-max) and the P image (after it);
+  // the K tile is staged in the same region once, before the sweep
+  static constexpr int IMG_DS_ROWS = 31 + 32 + 32;  // (band column 63 is unused: its keys 32.. must read zeros too)
+  static constexpr int IMG_DS_BYTES = (IMG_DS_ROWS * IMG * (int)sizeof(T) + 15) / 16 * 16;
+  static constexpr int DQ_LD = 33;
+  static constexpr int GS_BYTES = 64 * DQ_LD * 4;  // >= 64 * 32 * 4: at the end of a step the region holds the wave's dQ^T slab
+  static constexpr int WAVE_BYTES = IMG_DS_BYTES + GS_BYTES;
+  static constexpr int BAND_ROWS = 32 * FW + 32;
+  static constexpr int stage_rows(bool rel) { return rel ? 96 + BAND_ROWS : 64; }
+  static constexpr int stage_bytes(bool rel) { return stage_rows(rel) * LD * (int)sizeof(T); }
+  static constexpr int smem_bytes(bool rel) { return stage_bytes(rel) + FW * WAVE_BYTES; }
+};
+
+// the workgroup barrier of the sweep: LDS traffic only (no vmcnt: the prefetch loads, the dS stores and the dQ
+// atomics stay in flight across it -- __syncthreads() would drain all three every step)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+template <typename T, bool TR, bool REL, int FW>
+__global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr_attn_t a, const FusedWs ws) {
+  using M_ = Mma<T>;
+  using C_ = FusedCfg<T, FW>;
+  constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = C_::LD, IMG = C_::IMG;
+  constexpr int VEC = 16 / sizeof(T), PER_ROW = DK / VEC;
+  constexpr int NTHR = 64 * FW;
+  constexpr int NROWS = C_::stage_rows(REL), NPIECE = NROWS * PER_ROW, PPT = NPIECE / NTHR;  // 16-byte pieces per thread
+  static_assert(NPIECE % NTHR == 0, "staging pieces must divide evenly");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31;
+  const int jblk = blockIdx.x * (32 * FW), h = blockIdx.y, b = blockIdx.z;
+  const HeadPtrs hp = head_ptrs<T>(a, b, h);
+  const int j0 = jblk + 32 * wave;
+  if (jblk >= hp.klen) {  // every key of this block is masked: its dK / dV rows are zero, nothing else to add
+    f32x16 z[2];
+    zero16(z[0]); zero16(z[1]);
+    store_dT<T>((T*)hp.dk, a.ldk, j0, a.Tk, z, 1.f, lane);
+    store_dT<T>((T*)hp.dv, a.ldv, j0, a.Tk, z, 1.f, lane);
+    return;
+  }
+  const bool live = j0 < hp.klen;  // a dead wave still stages, joins the barriers and flushes
+
+  T* stage0 = reinterpret_cast<T*>(smem);
+  char* mine = smem + C_::stage_bytes(REL) + wave * C_::WAVE_BYTES;
+  T* img_pad = reinterpret_cast<T*>(mine);           // [31 zero rows | 32 key rows | 31 zero rows][IMG]
+  T* img_ds = img_pad + 31 * IMG;
+  float* Gs = reinterpret_cast<float*>(mine + C_::IMG_DS_BYTES);  // [64 band rows][32 queries] f32 ...
+  T* img_p = reinterpret_cast<T*>(mine + C_::IMG_DS_BYTES);       // ... later the P image [32][IMG]
+  for (int i = lane; i < C_::IMG_DS_ROWS * IMG / 2; i += 64) reinterpret_cast<unsigned*>(img_pad)[i] = 0u;
+  // the four slab bases, for the flush (slab w = wave w's skew region)
+  const float* slab0 = reinterpret_cast<const float*>(smem + C_::stage_bytes(REL) + C_::IMG_DS_BYTES);
+  constexpr int SLAB_STRIDE = C_::WAVE_BYTES / 4;
+
+  // ---- per-(b,h) operand bases ----------------------------------------------------------------------------
+  const long ho = (long)h * DK;
+  const T* qu_base = (const T*)ws.qu + (long)b * a.Tq * ws.ldqu + ho;
+  const T* qv_base = REL ? (const T*)ws.qv + (long)b * a.Tq * ws.ldqu + ho : qu_base;
+  const __amdgpu_buffer_rsrc_t rsQu = make_rsrc(qu_base), rsQv = make_rsrc(qv_base), rsDo = make_rsrc(hp.dout),
+                               rsP = make_rsrc(REL ? hp.pos : hp.dout);
+  const int nstep = (a.Tq + 31) / 32;
+
+  // ---- one-step-ahead operand fetch (whole block) -----------------------------------------------------------
+  // stage rows: [0,32) Q+u, then (REL) [32,64) Q+v, [64,96) dO, [96,96+BAND_ROWS) band; (!REL) [32,64) dO
+  constexpr int RPP = NTHR / PER_ROW;  // stage rows covered by one piece index (32 or 16)
+  static_assert(32 % RPP == 0, "a piece index must stay inside one 32-row operand tile");
+  constexpr int NMAT = REL ? 3 : 2;  // 32-row tiles ahead of the band: Q+u, (Q+v,) dO
+  Vec16<T> pre[PPT];
+  float pre_lse, pre_del, nxt_lse = INFINITY, nxt_del = 0.f;
+  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(hp.lse), rsD = make_rsrc(hp.delta);
+  auto fetch = [&](const int step) {
+    const int i0 = step * 32;
+    const bool on = step < nstep;
+    const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
+    {
+      const unsigned o = on && i0 + il < a.Tq ? (unsigned)((i0 + il) * 4) : EMO_OOB;
+      pre_lse = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsL, o, 0, 0));
+      pre_del = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, o, 0, 0));
+    }
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int srow = p * RPP;  // first stage row of this piece index (compile-time after unrolling)
+      if (srow < 32 * NMAT) {
+        const int mat = srow / 32, i = i0 + srow % 32 + trow;
+        const bool ok = on && i < a.Tq;
+        if (mat == 0) pre[p] = buf_load16<T>(rsQu, ok ? (unsigned)(((long)i * ws.ldqu + piece) * sizeof(T)) : EMO_OOB);
+        else if (REL && mat == 1) pre[p] = buf_load16<T>(rsQv, ok ? (unsigned)(((long)i * ws.ldqu + piece) * sizeof(T)) : EMO_OOB);
+        else pre[p] = buf_load16<T>(rsDo, ok ? (unsigned)(((long)i * a.ldo + piece) * sizeof(T)) : EMO_OOB);
+      } else {
+        const int r = a.Tq - 32 - i0 + jblk + (srow - 32 * NMAT) + trow;
+        const bool ok = on && r >= 0 && r < 2 * a.Tq - 1;
+        pre[p] = buf_load16<T>(rsP, ok ? (unsigned)(((long)r * a.ldp + piece) * sizeof(T)) : EMO_OOB);
+      }
+    }
+  };
+  auto stash = [&]() {
+    T* st = stage0;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int pid = tid + NTHR * p;
+      store16(st + (pid / PER_ROW) * LD + (pid % PER_ROW) * VEC, pre[p]);
+    }
+    nxt_lse = pre_lse;
+    nxt_del = pre_del;
+  };
+
+  // ---- stationary operands of this wave's key tile ---------------------------------------------------------
+  const int kj_lane = j0 + il;
+  typename M_::Frag kfA[NK], vfA[NK], kT[2][NS];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    kfA[kk] = frag_global<T>((const T*)hp.k, a.ldk, kj_lane, live && kj_lane < a.Tk, kk, lane, nullptr);
+    vfA[kk] = frag_global<T>((const T*)hp.v, a.ldv, kj_lane, live && kj_lane < a.Tk, kk, lane, nullptr);
+  }
+  {
+    T* Ks = reinterpret_cast<T*>(Gs);  // [32][LD] in the wave's skew region
+    stage_rows<T, 32>(Ks, (const T*)hp.k, a.ldk, j0, 0, live ? a.Tk : 0, lane, nullptr);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) kT[dt][ks] = chain_a<T, TR>(Ks, ks, 32 * dt, lane);
+    __builtin_amdgcn_wave_barrier();
+  }
+  f32x16 dk[2], dv[2], csum;
+  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]); zero16(csum);
+  if (!live)  // a dead wave's slab stays zero for the whole sweep
+    for (int i = lane; i < 64 * C_::DQ_LD; i += 64) Gs[i] = 0.f;
+  // sum of the four waves' dQ^T slabs of the step that just ended -> global f32 accumulator (rows of 64 d = 256 B);
+  // wave w adds query rows w, w + FW, ...
+  auto flush = [&](const int ib) {
+#pragma unroll
+    for (int q = wave; q < 32; q += FW) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < FW; ++w) v += slab0[w * SLAB_STRIDE + lane * C_::DQ_LD + q];
+      if (ib + q < a.Tq) atomicAdd(ws.dq32 + ((long)b * a.Tq + ib + q) * (a.H * DK) + ho + lane, v);
+    }
+  };
+
+  fetch(0);
+  stash();
+  fetch(1);
+  __syncthreads();
+  const bool full_tile = j0 + 32 <= hp.klen;  // no masked key in this wave's tile
+  const float c_exp = a.scale * 1.4426950408889634f;
+
+  for (int step = 0; step < nstep; ++step) {
+    const int i0 = step * 32;
+    const T* st = stage0;
+    const T* Qus = st;
+    const T* Qvs = st + 32 * LD;
+    const T* dOs = st + (REL ? 64 : 32) * LD;
+    const T* Bs = st + (96 + 32 * wave) * LD;  // this wave's 64 band rows (REL)
+    if (live) {
+      const int qi = i0 + il;
+      const bool qval = qi < a.Tq;
+      // p = exp2(c_exp * s - lse * log2 e); rows without any valid key (lse = -inf) and padding queries get +inf -> p = 0
+      const float lse2 = (qval && nxt_lse != -INFINITY) ? nxt_lse * 1.4426950408889634f : INFINITY;
+      const float del_q = nxt_del;
+      const uint64_t drop_base = drop_index(a, b, h, qi, 0);
+      // S^T = K (Q+u)^T
+      f32x16 s;
+      zero16(s);
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) s = M_::mma(kfA[kk], M_::load_kc(Qus, LD, 0, kk * M_::KSTEP, lane), s);
+      if constexpr (REL) {
+        typename M_::Frag qv[NK];
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) qv[kk] = M_::load_kc(Qvs, LD, 0, kk * M_::KSTEP, lane);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          f32x16 g;
+          zero16(g);
+#pragma unroll
+          for (int kk = 0; kk < NK; ++kk)
+            g = M_::mma(M_::load_kc(Bs + 32 * ct * LD, LD, 0, kk * M_::KSTEP, lane), qv[kk], g);  // g[c][i]
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Gs[(32 * ct + c_row(r, lane)) * 32 + il] = g[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // element (key jl, query il) sits in band column c = 31 - il + jl
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += Gs[(31 - il + c_row(r, lane)) * 32 + il];
+        __builtin_amdgcn_wave_barrier();
+      }
+      // dP^T = V dO^T
+      f32x16 dp;
+      zero16(dp);
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) dp = M_::mma(vfA[kk], M_::load_kc(dOs, LD, 0, kk * M_::KSTEP, lane), dp);
+      f32x16 ds, dsc;
+      if (a.drop_p > 0.f) {
+        const float keep = 1.f / (1.f - a.drop_p);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dsc[r] = dropout_keep(a.seed, drop_base + (uint64_t)(j0 + c_row(r, lane)), a.drop_p) ? keep : 0.f;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsc[r] = 1.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = __builtin_amdgcn_exp2f(s[r] * c_exp - lse2);
+        if (!full_tile) p = (j0 + c_row(r, lane) >= hp.klen) ? 0.f : p;
+        ds[r] = p * (dp[r] * dsc[r] - del_q) * a.scale;
+        csum[r] += ds[r];
+        img_ds[c_row(r, lane) * IMG + il] = from_f32<T>(ds[r]);
+        img_p[c_row(r, lane) * IMG + il] = from_f32<T>(p * dsc[r]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (REL) {
+        // dS for the dpos pass: query-major rows, 4 consecutive keys (8 bytes) per store
+        if (qval) {
+          T* drow = (T*)ws.dsq + (((long)b * a.H + h) * a.Tq + qi) * ws.ldds + j0 + 4 * (lane >> 5);
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            bf16x4 v4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = (bf16)ds[4 * g4 + e];
+            *reinterpret_cast<bf16x4*>(drow + 8 * g4) = v4;
+          }
+        }
+      }
+      // dQ^T partial = K^T dS^T (+ band^T unskew(dS^T))
+      f32x16 dq[2];
+      zero16(dq[0]); zero16(dq[1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) dq[dt] = M_::mma(kT[dt][ks], chain_b<T>(ds, ks), dq[dt]);
+      if constexpr (REL) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          // dG^T[c][i] = dS^T[c - 31 + i][i] straight out of the zero-padded image, already in the chained operand's
+          // register order (element j of k step ks <-> accumulator register 8 ks + j)
+          typename M_::Frag dgf[NS];
+#pragma unroll
+          for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dgf[ks][j] = img_pad[(32 * ct + c_row(8 * ks + j, lane) + il) * IMG + il];
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < NS; ++ks)
+              dq[dt] = M_::mma(chain_a<T, TR>(Bs + 32 * ct * LD, ks, 32 * dt, lane), dgf[ks], dq[dt]);
+        }
+      }
+      // dV^T += dO^T P,  dK^T += (Q+u)^T dS   (sum over the query index: operands from the bf16 images)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+          dv[dt] = M_::mma(M_::template load_km<TR>(dOs, LD, ks * M_::KSTEP, 32 * dt, lane),
+                           M_::load_kc(img_p, IMG, 0, ks * M_::KSTEP, lane), dv[dt]);
+          dk[dt] = M_::mma(M_::template load_km<TR>(Qus, LD, ks * M_::KSTEP, 32 * dt, lane),
+                           M_::load_kc(img_ds, IMG, 0, ks * M_::KSTEP, lane), dk[dt]);
+        }
+      __builtin_amdgcn_wave_barrier();
+      // the P image (start of the skew region) has been consumed: the region now takes this wave's dQ^T slab
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Gs[(32 * dt + c_row(r, lane)) * C_::DQ_LD + il] = dq[dt][r];
+    }
+    lds_barrier();  // every wave has read the stage and written its slab
+    flush(i0);
+    stash();         // tiles of step+1 (fetched during the previous step)
+    fetch(step + 2);
+    lds_barrier();  // stage ready; every slab has been read: the skew regions may be written again
+  }
+  store_dT<T>((T*)hp.dk, a.ldk, j0, a.Tk, dk, 1.f, lane);  // (a dead wave stores zeros)
+  store_dT<T>((T*)hp.dv, a.ldv, j0, a.Tk, dv, 1.f, lane);
+  if (REL && live && a.dbias_u) {
+    // dbias_u[d] += sum_j colsum_j K[j][d]  (colsum_j = sum_i dS[i][j]);  dbias_v gets the negative: the finalize pass
+    // adds colsum(dQ) = dbias_u + dbias_v to it
+    float* cs = Gs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = csum[r];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (il == 0) cs[c_row(r, lane)] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+      const int kj = j0 + j;
+      acc += cs[j] * buf_load_f32<T>(rsK, kj < a.Tk ? (unsigned)(((long)kj * a.ldk + lane) * sizeof(T)) : EMO_OOB);
+    }
+    atomicAdd(&a.dbias_u[h * DK + lane], acc);
+    if (a.dbias_v) atomicAdd(&a.dbias_v[h * DK + lane], -acc);
+  }
+}
+
+// dpos[r, h*64+d] += sum_{b,i} dS[b,h,i, j = i-(Tq-1)+r] (Q+v)[b,i,h*64+d]: block = (32 table rows, head, batch chunk);
+// the waves take (batch, query tile) items round-robin, gather the diagonal band of dS (2-byte loads, consecutive lanes
+// = consecutive keys) as the A operand and (Q+v) as the B operand, and are reduced through LDS before one set of atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t a, const FusedWs ws, const int bchunk) {
+  using M_ = Mma<T>;
+  __shared__ float red[4 * 2 * 16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, hh = lane >> 5;
+  const int r0 = blockIdx.x * 32, h = blockIdx.y;
+  const int b_lo = blockIdx.z * bchunk, b_hi = min(a.B, b_lo + bchunk);
+  const int nit = (a.Tq + 31) / 32;
+  f32x16 acc[2];
+  zero16(acc[0]); zero16(acc[1]);
+  int item = wave;
+  for (int b = b_lo; b < b_hi; ++b) {
+    const int klen = a.klens ? min(a.klens[b], a.Tk) : a.Tk;
+    const __amdgpu_buffer_rsrc_t rsS = make_rsrc((const T*)ws.dsq + ((long)b * a.H + h) * a.Tq * ws.ldds);
+    const __amdgpu_buffer_rsrc_t rsQ = make_rsrc((const T*)ws.qv + (long)b * a.Tq * ws.ldqu + (long)h * DK);
+    for (; item < nit; item += 4) {
+      const int i0 = item * 32;
+      const int jmin = i0 - (a.Tq - 1) + r0, jmax = jmin + 62;
+      if (jmax < 0 || jmin >= klen) continue;
+      const int r = r0 + il;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fa, fb[2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int i = i0 + 16 * ks + 8 * hh + e;
+          const int j = i - (a.Tq - 1) + r;
+          const bool ok = i < a.Tq && j >= 0 && j < klen && r < 2 * a.Tq - 1;
+          fa[e] = (bf16)buf_load_f32<T>(rsS, ok ? (unsigned)(((long)i * ws.ldds + j) * sizeof(T)) : EMO_OOB);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            fb[dt][e] = (bf16)buf_load_f32<T>(rsQ, i < a.Tq ? (unsigned)(((long)i * ws.ldqu + 32 * dt + il) * sizeof(T)) : EMO_OOB);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[dt], acc[dt], 0, 0, 0);
+      }
+    }
+    item -= nit;
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave * 2 + dt) * 16 + r) * 64 + lane] = acc[dt][r];
+  __syncthreads();
+  // thread -> (dt, reg, lane) of the summed tile: 2048 values, 8 per thread
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = threadIdx.x + 256 * k, ln = idx & 63, rg = (idx >> 6) & 15, dt = idx >> 10;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[((w * 2 + dt) * 16 + rg) * 64 + ln];
+    const int row = r0 + c_row(rg, ln);
+    if (row < 2 * a.Tq - 1) atomicAdd(&a.dpos[(long)row * (a.H * DK) + h * DK + 32 * dt + (ln & 31)], v);
+  }
+}
+
+// dq (T, strided) = dq32; dbias_v[c] += sum over rows of dq32[:, c]  (optional).  Block = 64 rows x 256 columns.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_fin_kernel(const long rows, const int ncol, const float* __restrict__ dq32,
+                                                           T* __restrict__ dq, const long ldq,
+                                                           float* __restrict__ colsum_out) {
+  __shared__ float redsum[2048];
+  const int ngrp = ncol / 8, rpb = 256 / ngrp;  // column groups of 8, rows per pass
+  const int cg = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
+  if (colsum_out) {
+    for (int i = threadIdx.x; i < ncol; i += 256) redsum[i] = 0.f;
+    __syncthreads();
+  }
+  float cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+  const long row_lo = (long)blockIdx.x * 64, row_hi = min(rows, row_lo + 64);
+  if (rr < rpb) {
+    for (long row = row_lo + rr; row < row_hi; row += rpb) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(dq32 + row * ncol + cg * 8);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(dq32 + row * ncol + cg * 8 + 4);
+      float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[e] += o[e];
+      store8<T>(dq + row * ldq + cg * 8, o);
+    }
+  }
+  if (!colsum_out) return;
+  if (rr < rpb) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      __hip_atomic_fetch_add(&redsum[cg * 8 + e], cs[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ncol; i += 256) atomicAdd(&colsum_out[i], redsum[i]);
+}
+
 template <typename K>
 int set_smem(K kernel, int bytes) {
   if (bytes > 64 * 1024) {
@@ -1164,6 +1624,7 @@ int set_smem(K kernel, int bytes) {
 }
 
 int g_tr = 1;
+int g_fused_fw = 0;  // key tiles per workgroup of the single-pass backward (0 = by grid size; emoasr_set_option "attn_fw")
 
 int check_args(const emoasr_attn_t* a, int dtype) {
   EMO_CHECK(a->DK == DK, "attention: DK=%d unsupported (64 only)", a->DK);
@@ -1307,9 +1768,67 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
   return 0;
 }
 
+
+template <typename T>
+int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_t s) {
+  const bool rel = a.pos != nullptr;
+  const long nqd = (long)a.B * a.Tq * a.H * DK;
+  FusedWs ws{};
+  size_t off = 0;
+  auto carve = [&](size_t n) { char* p = mem + off; off += (n + 255) / 256 * 256; return p; };
+  ws.dq32 = reinterpret_cast<float*>(carve(nqd * 4));
+  T *qu = nullptr, *qv = nullptr;
+  if (rel) {
+    qu = reinterpret_cast<T*>(carve(nqd * sizeof(T)));
+    qv = reinterpret_cast<T*>(carve(nqd * sizeof(T)));
+    ws.ldds = (a.Tk + 31) / 32 * 32;
+    ws.dsq = carve((size_t)a.B * a.H * a.Tq * ws.ldds * sizeof(T));
+    ws.qu = qu; ws.qv = qv; ws.ldqu = (long)a.H * DK;
+  } else {
+    ws.qu = a.q; ws.qv = a.q; ws.ldqu = a.ldq;
+  }
+  EMO_CHECK(off <= bytes, "attn_bwd_fused: workspace too small (%zu < %zu bytes)", bytes, off);
+  const long rows = (long)a.B * a.Tq * a.H;
+  attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, ws.dq32, qu, qv);
+  // 4 key tiles per workgroup (one workgroup per CU) unless that grid spills into a second round of workgroups and the
+  // 2-tile grid (two workgroups per CU) does not
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  const long nb4 = (long)cdiv(a.Tk, 128) * a.H * a.B, nb2 = (long)cdiv(a.Tk, 64) * a.H * a.B;
+  const int fw = g_fused_fw ? g_fused_fw : ((nb4 > n_cu && nb2 <= 2 * n_cu) ? 2 : 4);
+#define EMO_FUSED_LAUNCH(REL_, FW_)                                                                \
+  do {                                                                                             \
+    const int smem = FusedCfg<T, FW_>::smem_bytes(REL_);                                           \
+    dim3 grid(cdiv(a.Tk, 32 * FW_), a.H, a.B);                                                     \
+    if (g_tr) { if (set_smem(attn_bwd_fused_kernel<T, true, REL_, FW_>, smem)) return 1;           \
+                attn_bwd_fused_kernel<T, true, REL_, FW_><<<grid, 64 * FW_, smem, s>>>(a, ws); }   \
+    else      { if (set_smem(attn_bwd_fused_kernel<T, false, REL_, FW_>, smem)) return 1;          \
+                attn_bwd_fused_kernel<T, false, REL_, FW_><<<grid, 64 * FW_, smem, s>>>(a, ws); }  \
+  } while (0)
+  if (rel) {
+    if (fw == 2) EMO_FUSED_LAUNCH(true, 2); else EMO_FUSED_LAUNCH(true, 4);
+    if (a.dpos) {
+      const int nchunk = a.B < 4 ? a.B : 4;
+      dim3 g2(cdiv(2 * a.Tq - 1, 32), a.H, nchunk);
+      attn_bwd_dpos2_kernel<T><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk));
+    }
+  } else {
+    if (fw == 2) EMO_FUSED_LAUNCH(false, 2); else EMO_FUSED_LAUNCH(false, 4);
+  }
+#undef EMO_FUSED_LAUNCH
+  attn_bwd_fin_kernel<T><<<cdiv((long)a.B * a.Tq, 64), 256, 0, s>>>((long)a.B * a.Tq, a.H * DK, ws.dq32, (T*)a.dq, a.ldq,
+                                                                 rel ? a.dbias_v : nullptr);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
 }  // namespace
 
 void emo_attn_set_tr_read(int v) { g_tr = v; }
+void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }
 
 extern "C" int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream) {
   if (check_args(a, dtype)) return 1;
@@ -1333,4 +1852,25 @@ extern "C" int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream) 
     return (launch_bwd_tr<T, false>(*a, (hipStream_t)stream));
   });
   return 0;
+}
+
+extern "C" size_t emoasr_attn_bwd_fused_ws_bytes(int dtype, int B, int H, int Tq, int Tk, int rel) {
+  const size_t esz = dtype == EMO_BF16 ? 2 : 4;
+  auto up = [](size_t n) { return (n + 255) / 256 * 256; };
+  const size_t nqd = (size_t)B * Tq * H * DK;
+  size_t n = up(nqd * 4);
+  if (rel) n += 2 * up(nqd * esz) + up((size_t)B * H * Tq * ((Tk + 31) / 32 * 32) * esz);
+  return n;
+}
+
+extern "C" int emoasr_attn_bwd_fused(int dtype, const emoasr_attn_t* a, void* ws, size_t ws_bytes, void* stream) {
+  if (check_args(a, dtype)) return 1;
+  EMO_CHECK(dtype == EMO_BF16, "attn_bwd_fused: bf16 only (f32 runs emoasr_attn_bwd)");
+  EMO_CHECK(!a->causal, "attn_bwd_fused: causal masks run emoasr_attn_bwd");
+  EMO_CHECK(a->dout && a->out && a->delta && a->dq && a->dk && a->dv && ws, "attn_bwd_fused: missing buffers");
+  EMO_CHECK(!a->pos || (a->bias_u && a->bias_v), "attn_bwd_fused: relative positions need both position biases");
+  EMO_CHECK((a->dbias_u != nullptr) == (a->dbias_v != nullptr), "attn_bwd_fused: dbias_u and dbias_v go together");
+  EMO_CHECK(a->H <= 32, "attn_bwd_fused: H=%d unsupported (at most 32 heads)", a->H);
+  if (a->B == 0 || a->Tq == 0) return 0;
+  return launch_bwd_fused<bf16>(*a, static_cast<char*>(ws), ws_bytes, (hipStream_t)stream);
 }

@@ -280,14 +280,12 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
-// returns 0.f (dropped) or 1/(1-p) (kept).  p == 0 -> always 1.
-__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
-  if (p <= 0.f) return 1.f;
-  // Three xorshift / 24-bit-multiply rounds over (idx, seed).  The masks are regenerated in every backward
-  // kernel, so this sits on the VALU critical path of the attention kernels: v_mul_u32_u24 issues at full
-  // rate where the 32-bit v_mul_lo_u32 of a classic avalanche hash is quarter rate.  The low 24 bits are
-  // the uniform (chi-square over 64 buckets of 4M consecutive indices: 66 +- 8 for 63 degrees of freedom;
-  // adjacent-index / row-stride / seed+1 correlations of the keep mask < 2e-3 -- tools/hash_check.py).
+// keep decision of element idx (p > 0): three xorshift / 24-bit-multiply rounds over (idx, seed).  The masks are
+// regenerated in every backward kernel, so this sits on the VALU critical path of the attention kernels:
+// v_mul_u32_u24 issues at full rate where the 32-bit v_mul_lo_u32 of a classic avalanche hash is quarter rate.  The
+// low 24 bits are the uniform (chi-square over 64 buckets of 4M consecutive indices: 66 +- 8 for 63 degrees of
+// freedom; adjacent-index / row-stride / seed+1 correlations of the keep mask < 2e-3 -- tools/hash_check.py).
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, float p) {
   const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
   uint32_t x = lo ^ (uint32_t)seed ^ __umul24(hi, 0x85EBCBu);
   x ^= x >> 16;
@@ -298,7 +296,12 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
   x = __umul24(x, 0x7FEB35u);
   x ^= x >> 12;
   const float u = (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f);
-  return u < p ? 0.f : 1.f / (1.f - p);
+  return !(u < p);
+}
+// returns 0.f (dropped) or 1/(1-p) (kept).  p == 0 -> always 1.
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
+  if (p <= 0.f) return 1.f;
+  return dropout_keep(seed, idx, p) ? 1.f / (1.f - p) : 0.f;
 }
 
 // ---------------------------------------------------------------------------

@@ -225,6 +225,8 @@ class CTCEngine(_DecoderMixinPlaceholder):
         self._side, self._inflight = None, []
         # keep the scaled scores S^T of the forward for the backward (1) or recompute them (0)
         self.attn_store_scores = os.environ.get("EMOASR_ATTN_STORED", "0") == "1"
+        # bf16 attention backward as ONE score recomputation (EMOASR_ATTN_FUSED=0: the materialised three-GEMM path)
+        self.attn_fused = os.environ.get("EMOASR_ATTN_FUSED", "1") != "0"
         self._bufs = {}
         self.seed = 0x5EED
         if _cfg(cfg, "decoder_type", "ctc") == "transformer":
@@ -236,7 +238,13 @@ class CTCEngine(_DecoderMixinPlaceholder):
     # ------------------------------------------------------------------ helpers
     def ensure_bound(self):
         if not self.arena.bound():
+            # the parameters were moved / re-created (model.cpu().cuda(), .to(dtype), load_state_dict on another
+            # device): re-home them and drop everything derived from the old arena's addresses
             self.arena = ParamArena(self.module, self.dtype)
+            self._layer_lo = None
+            self._layer_rt = None
+            self._bufs = {}
+            self._scratch_cache = {}
 
     def _pos_table(self, T, device, max_len=5000):
         """sinusoid table slice for T frames; the full table is built once (like the reference's
@@ -272,8 +280,8 @@ class CTCEngine(_DecoderMixinPlaceholder):
             return self._forward(xs, xlens_host, training, stash)
 
     def _forward(self, xs, xlens_host, training, stash):
+        self.ensure_bound()  # (may swap in a new arena: bind `A` only afterwards)
         A, d, dt = self.arena, self.d, self.dtype
-        self.ensure_bound()
         A.refresh_shadow()
         stash = training if stash is None else stash
         self._keep = stash
@@ -573,10 +581,15 @@ class CTCEngine(_DecoderMixinPlaceholder):
             gbu, gbv = A.g(name + ".pos_bias_u").view(-1), A.g(name + ".pos_bias_v").view(-1)
         else:
             dpos = bu = bv = gbu = gbv = None
-        scratch = self._scratch_for(B, H, T, T, qkv.dtype, qkv.device, pp is not None, elens, causal)
-        ops.attn_bwd(do.view(B, T, d), o, lse, q, k, v, H, scale, dq, dk, dv, pos=pp, bias_u=bu, bias_v=bv, klens=elens,
-                     causal=causal, drop_p=p_att, seed=s_att, dpos=dpos, dbias_u=gbu, dbias_v=gbv, scratch=scratch,
-                     st=sts)
+        if self.attn_fused and sts is None and ops.fused_attn_bwd_ok(q, pp, bu, bv, causal):
+            # single-pass backward (csrc/attention.hip: attn_bwd_fused_kernel): no P^T / dS^T / dBD images, no follow-up GEMMs
+            ops.attn_bwd(do.view(B, T, d), o, lse, q, k, v, H, scale, dq, dk, dv, pos=pp, bias_u=bu, bias_v=bv,
+                         klens=elens, drop_p=p_att, seed=s_att, dpos=dpos, dbias_u=gbu, dbias_v=gbv, materialise="fused")
+        else:
+            scratch = self._scratch_for(B, H, T, T, qkv.dtype, qkv.device, pp is not None, elens, causal)
+            ops.attn_bwd(do.view(B, T, d), o, lse, q, k, v, H, scale, dq, dk, dv, pos=pp, bias_u=bu, bias_v=bv,
+                         klens=elens, causal=causal, drop_p=p_att, seed=s_att, dpos=dpos, dbias_u=gbu, dbias_v=gbv,
+                         scratch=scratch, st=sts)
         if pp is not None:
             dpos_t = dpos if self.dtype == torch.float32 else ops.strided_copy(dpos, out_dtype=self.dtype)
             self._wgrad(dpos_t, pos_t, A.g(name + ".linear_pos.weight"))
@@ -868,9 +881,13 @@ class _DecoderMixin:
             do2 = self._lin_bwd(dyb, o2.view(B * L, dd), sa + ".linear_out.weight", sa + ".linear_out.bias", alpha)
             dq2 = torch.empty_like(q2)
             dkv = torch.empty_like(kv)
-            scratch = self._scratch_for(B, dh, L, T, q2.dtype, q2.device, False, st.elens, False)
-            ops.attn_bwd(do2.view(B, L, dd), o2, lse2, q2, kv[..., :dd], kv[..., dd:], dh, scale, dq2, dkv[..., :dd],
-                         dkv[..., dd:], klens=st.elens, drop_p=p_att, seed=s_att, scratch=scratch)
+            if self.attn_fused and ops.fused_attn_bwd_ok(q2, None, None, None, False):
+                ops.attn_bwd(do2.view(B, L, dd), o2, lse2, q2, kv[..., :dd], kv[..., dd:], dh, scale, dq2, dkv[..., :dd],
+                             dkv[..., dd:], klens=st.elens, drop_p=p_att, seed=s_att, materialise="fused")
+            else:
+                scratch = self._scratch_for(B, dh, L, T, q2.dtype, q2.device, False, st.elens, False)
+                ops.attn_bwd(do2.view(B, L, dd), o2, lse2, q2, kv[..., :dd], kv[..., dd:], dh, scale, dq2, dkv[..., :dd],
+                             dkv[..., dd:], klens=st.elens, drop_p=p_att, seed=s_att, scratch=scratch)
             dh2 = self._lin_bwd(dq2.view(B * L, dd), h2, sa + ".linear_q.weight", sa + ".linear_q.bias")
             dkv2 = dkv.view(B * T, 2 * dd)
             ops.gemm_tn(dkv2, st.mem2, out=A.g_span(sa + ".linear_k.weight", sa + ".linear_v.weight", (2 * dd, d)),

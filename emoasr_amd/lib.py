@@ -146,6 +146,7 @@ SIGNATURES = {
     "emoasr_bert_lm_infer": [I, I, POINTER(BertLayer), POINTER(BertInfer), P],
     "emoasr_attn_fwd": [I, POINTER(AttnArgs), P],
     "emoasr_attn_bwd": [I, POINTER(AttnArgs), P],
+    "emoasr_attn_bwd_fused": [I, POINTER(AttnArgs), P, ctypes.c_size_t, P],
     "emoasr_glu_fwd": [I, I, I, P, P, P],
     "emoasr_glu_bwd": [I, I, I, P, P, P, P],
     "emoasr_dwconv_fwd": [I, I, I, I, I, P, P, P, P, P],

@@ -313,13 +313,48 @@ class AttnScratch:
         self.dbias_part = torch.empty(B * ((Tq + 31) // 32), H, 2, 64, device=device, dtype=torch.float32)
 
 
+_FUSED_WS = {}
+
+
+def fused_attn_bwd_ok(q, pos, bias_u, bias_v, causal):
+    """can emoasr_attn_bwd_fused take this call? (bf16, no causal mask, relative positions with both biases or none)"""
+    return (q.dtype == torch.bfloat16 and not causal and (pos is None or (bias_u is not None and bias_v is not None))
+            and (pos is not None or (bias_u is None and bias_v is None)))
+
+
+def _fused_ws(device, nbytes):
+    """scratch of the single-pass attention backward: one buffer per device, grown on demand (no initialisation needed;
+    every call runs on the current stream, so calls never overlap)"""
+    w = _FUSED_WS.get(device)
+    if w is None or w.numel() < nbytes:
+        w = _FUSED_WS[device] = torch.empty(int(nbytes * 1.25) + 256, device=device, dtype=torch.uint8)
+    return w
+
+
 def attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=None, bias_u=None, bias_v=None, klens=None,
              causal=False, drop_p=0.0, seed=0, dpos=None, dbias_u=None, dbias_v=None, scratch=None,
              materialise=True, st=None):
     """dq/dk/dv are written (same strides as q/k/v); dpos/dbias_* are accumulated into.
+    materialise="fused": the single-pass kernel (bf16, no causal mask; see fused_attn_bwd_ok);
     materialise=True: dV/dK/dpos through batched GEMMs over stored P^T/dS^T (scratch is allocated
     here unless an AttnScratch for this shape/mask is passed); False: score-recompute kernels."""
     B, Tq, D = q.shape
+    if materialise == "fused":
+        assert fused_attn_bwd_ok(q, pos, bias_u, bias_v, causal)
+        a = _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, seed)
+        assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
+        assert dout.is_contiguous() and out.is_contiguous()
+        delta = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+        a.out, a.ldo, a.lse = out.data_ptr(), D, lse.data_ptr()
+        a.dout, a.delta = dout.data_ptr(), delta.data_ptr()
+        a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+        a.dpos = None if dpos is None else dpos.data_ptr()
+        a.dbias_u = None if dbias_u is None else dbias_u.data_ptr()
+        a.dbias_v = None if dbias_v is None else dbias_v.data_ptr()
+        nb = lib.size_query("emoasr_attn_bwd_fused_ws_bytes", dt(q), B, H, Tq, k.shape[1], int(pos is not None))
+        ws = _fused_ws(q.device, nb)
+        lib.call("emoasr_attn_bwd_fused", dt(q), byref(a), ws.data_ptr(), ws.numel(), _stream())
+        return
     a = _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, seed)
     assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
     assert dout.is_contiguous() and out.is_contiguous()

@@ -205,6 +205,14 @@ typedef struct {
 } emoasr_attn_t;
 int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream);
 int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream);
+/* Single-pass backward (bf16, no causal mask): every score tile is recomputed once; dQ, dK, dV, dbias_u/v and dpos come
+ * out of four launches (prologue: delta, Q+u, Q+v, zeroed dQ accumulator; main: one workgroup per (batch, head, 128 keys)
+ * sweeping the query tiles; dpos: diagonals of the stored dS; finalize: dQ f32 -> T and dbias_v).  Replaces the
+ * materialised mode of emoasr_attn_bwd (P^T / dS^T / dBD images + three GEMMs): same arguments, the pdT / dsT / dbd / cs /
+ * st / qu / qv / dbias_part fields are ignored.  `ws`: emoasr_attn_bwd_fused_ws_bytes(...) bytes of scratch, no
+ * initialisation needed.  Reference: transformer.py:73-94, conformer.py:77-95 (their autograd backward). */
+size_t emoasr_attn_bwd_fused_ws_bytes(int dtype, int B, int H, int Tq, int Tk, int rel);
+int emoasr_attn_bwd_fused(int dtype, const emoasr_attn_t* a, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Conformer convolution module (conformer.py:98-143) ---------------------- */
 /* out[M,C] = in[M,:C] * sigmoid(in[M,C:2C]) */
