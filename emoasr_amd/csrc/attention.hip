@@ -1169,24 +1169,27 @@ __global__ __launch_bounds__(256) void attn_dbias_v_kernel(const emoasr_attn_t a
 //     skew(band (Q+v)^T), dP^T = V dO^T; dQ^T += K^T dS^T + band^T unskew(dS^T) chains the accumulator straight into
 //     the next MFMA; dV^T += dO^T P and dK^T += (Q+u)^T dS sum over the query index, which sits on the lanes, so P and
 //     dS go through a 2.5 KB wave-private bf16 image (the same image feeds the un-skew);
-//   * the waves' dQ^T partials are summed with LDS float atomics into a [64 d][32 i] tile (two tiles, alternating), and
-//     the tile of the previous step is flushed with ONE set of global f32 atomics per block (rows of 64 d = 256 B);
+//   * each wave leaves its dQ^T partial in an LDS slab ([64 d][33] f32, in its skew region); after the barrier that ends
+//     the step the block sums the slabs and stores ONE f32 partial per (key block, query row) with plain 256-byte row
+//     stores (LDS float atomics measured ~170 cycles per wave-instruction, global float atomics would make dQ depend on
+//     arrival order: bf16 rounding flips of dQ then propagate through every layer below); the finalize pass adds the key
+//     blocks' partials in block order, so dQ is bit-reproducible;
 //   * dS (query-major, bf16) is stored for attn_bwd_dpos2_kernel, which walks its diagonals: dpos[r] = sum_{b,i}
 //     dS[b,i,i-(Tq-1)+r] (Q+v)[b,i].  dbias_v = colsum(dQ) - dbias_u comes out of the finalize pass.
 // ====================================================================================
 
 struct FusedWs {       // workspace carved by emoasr_attn_bwd_fused
-  float* dq32;         // f32 [B, Tq, H*DK]: dQ accumulator (zeroed by the prologue kernel)
+  float* dq32;         // f32 [key blocks][B, Tq, H*DK]: one dQ partial per key block, summed in block order by the finalize pass
+  long dq_slab;        // floats per key block
   void* dsq;           // T [B, H, Tq, ldds]: dS, query-major (relative positions only)
   long ldds;
   const void *qu, *qv; // T [B, Tq, ldqu]: Q + pos_bias_u, Q + pos_bias_v  (without biases: q itself, ldq)
   long ldqu;
 };
 
-// prologue: delta[b,h,i] = dO.O, dense Q+u / Q+v, dq32 = 0.  8 lanes x 8 elements per (b,i,h) row.
+// prologue: delta[b,h,i] = dO.O, dense Q+u / Q+v.  8 lanes x 8 elements per (b,i,h) row.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t a, float* __restrict__ dq32,
-                                                            T* __restrict__ qu, T* __restrict__ qv) {
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t a, T* __restrict__ qu, T* __restrict__ qv) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long row = idx >> 3, total = (long)a.B * a.Tq * a.H;
   const int d0 = (int)(idx & 7) * 8;
@@ -1204,8 +1207,6 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t 
   const int i = (int)(bt % a.Tq), b = (int)(bt / a.Tq);
   if (d0 == 0) a.delta[((long)b * a.H + h) * a.Tq + i] = s;
   const long o = (bt * a.H + h) * DK + d0;
-  *reinterpret_cast<f32x4*>(dq32 + o) = f32x4{0.f, 0.f, 0.f, 0.f};
-  *reinterpret_cast<f32x4*>(dq32 + o + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (qu) {
     float qx[8], u[8], v[8];
     load8<T>((const T*)a.q + bt * a.ldq + h * DK + d0, qx);
@@ -1350,18 +1351,18 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
   zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]); zero16(csum);
   if (!live)  // a dead wave's slab stays zero for the whole sweep
     for (int i = lane; i < 64 * C_::DQ_LD; i += 64) Gs[i] = 0.f;
-  // sum of the four waves' dQ^T slabs of the step that just ended -> global f32 accumulator (rows of 64 d = 256 B);
-  // wave w adds query rows w, w + FW, ...
+  // sum of the waves' dQ^T slabs of the step that just ended -> this key block's f32 partial (rows of 64 d = 256 B, plain
+  // stores: every (key block, query row) has exactly one writer, so dQ is bit-reproducible); wave w takes rows w, w + FW, ...
+  float* dq_part = ws.dq32 + (long)blockIdx.x * ws.dq_slab + (long)b * a.Tq * (a.H * DK) + ho + lane;
   auto flush = [&](const int ib) {
 #pragma unroll
     for (int q = wave; q < 32; q += FW) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < FW; ++w) v += slab0[w * SLAB_STRIDE + lane * C_::DQ_LD + q];
-      if (ib + q < a.Tq) atomicAdd(ws.dq32 + ((long)b * a.Tq + ib + q) * (a.H * DK) + ho + lane, v);
+      if (ib + q < a.Tq) dq_part[(long)(ib + q) * (a.H * DK)] = v;
     }
   };
-
   fetch(0);
   stash();
   fetch(1);
@@ -1578,10 +1579,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t
   }
 }
 
-// dq (T, strided) = dq32; dbias_v[c] += sum over rows of dq32[:, c]  (optional).  Block = 64 rows x 256 columns.
+// dq (T, strided) = sum over the utterance's live key blocks of their dQ partials (fixed order); dbias_v[c] += sum over
+// rows of dq[:, c]  (optional).  Block = 64 rows x ncol columns.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_fin_kernel(const long rows, const int ncol, const float* __restrict__ dq32,
-                                                           T* __restrict__ dq, const long ldq,
+                                                           const long slab, const int keys_per_block, const int Tq, const int Tk,
+                                                           const int* __restrict__ klens, T* __restrict__ dq, const long ldq,
                                                            float* __restrict__ colsum_out) {
   __shared__ float redsum[2048];
   const int ngrp = ncol / 8, rpb = 256 / ngrp;  // column groups of 8, rows per pass
@@ -1596,9 +1599,19 @@ __global__ __launch_bounds__(256) void attn_bwd_fin_kernel(const long rows, cons
   const long row_lo = (long)blockIdx.x * 64, row_hi = min(rows, row_lo + 64);
   if (rr < rpb) {
     for (long row = row_lo + rr; row < row_hi; row += rpb) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(dq32 + row * ncol + cg * 8);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(dq32 + row * ncol + cg * 8 + 4);
-      float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const int b = (int)(row / Tq);
+      const int klen = klens ? min(klens[b], Tk) : Tk;
+      const int nkb = (klen + keys_per_block - 1) / keys_per_block;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = 0.f;
+      for (int kb = 0; kb < nkb; ++kb) {
+        const float* src = dq32 + kb * slab + row * ncol + cg * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] += v0[e]; o[4 + e] += v1[e]; }
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) cs[e] += o[e];
       store8<T>(dq + row * ldq + cg * 8, o);
@@ -1776,7 +1789,8 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
   FusedWs ws{};
   size_t off = 0;
   auto carve = [&](size_t n) { char* p = mem + off; off += (n + 255) / 256 * 256; return p; };
-  ws.dq32 = reinterpret_cast<float*>(carve(nqd * 4));
+  ws.dq_slab = nqd;
+  ws.dq32 = reinterpret_cast<float*>(carve((size_t)nqd * 4 * cdiv(a.Tk, 64)));  // room for 64-key blocks (the finer grid)
   T *qu = nullptr, *qv = nullptr;
   if (rel) {
     qu = reinterpret_cast<T*>(carve(nqd * sizeof(T)));
@@ -1789,7 +1803,7 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
   }
   EMO_CHECK(off <= bytes, "attn_bwd_fused: workspace too small (%zu < %zu bytes)", bytes, off);
   const long rows = (long)a.B * a.Tq * a.H;
-  attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, ws.dq32, qu, qv);
+  attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, qu, qv);
   // 4 key tiles per workgroup (one workgroup per CU) unless that grid spills into a second round of workgroups and the
   // 2-tile grid (two workgroups per CU) does not
   static int n_cu = 0;
@@ -1820,8 +1834,8 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
     if (fw == 2) EMO_FUSED_LAUNCH(false, 2); else EMO_FUSED_LAUNCH(false, 4);
   }
 #undef EMO_FUSED_LAUNCH
-  attn_bwd_fin_kernel<T><<<cdiv((long)a.B * a.Tq, 64), 256, 0, s>>>((long)a.B * a.Tq, a.H * DK, ws.dq32, (T*)a.dq, a.ldq,
-                                                                 rel ? a.dbias_v : nullptr);
+  attn_bwd_fin_kernel<T><<<cdiv((long)a.B * a.Tq, 64), 256, 0, s>>>((long)a.B * a.Tq, a.H * DK, ws.dq32, ws.dq_slab, 32 * fw, a.Tq,
+                                                                 a.Tk, a.klens, (T*)a.dq, a.ldq, rel ? a.dbias_v : nullptr);
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -1858,7 +1872,7 @@ extern "C" size_t emoasr_attn_bwd_fused_ws_bytes(int dtype, int B, int H, int Tq
   const size_t esz = dtype == EMO_BF16 ? 2 : 4;
   auto up = [](size_t n) { return (n + 255) / 256 * 256; };
   const size_t nqd = (size_t)B * Tq * H * DK;
-  size_t n = up(nqd * 4);
+  size_t n = up(nqd * 4 * ((Tk + 63) / 64));
   if (rel) n += 2 * up(nqd * esz) + up((size_t)B * H * Tq * ((Tk + 31) / 32 * 32) * esz);
   return n;
 }

@@ -91,3 +91,147 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
   if (ffn_fwd(dtype, M, d, F, L->ff, io->cv_y, 0.5f, p_enc, io->seed[5], io->seed[6], io->ff, stream)) return 1;
   return emoasr_layernorm_fwd(dtype, M, d, io->ff.y, L->fin_ln_g, L->fin_ln_b, 1e-5f, io->y, io->fin_mean, io->fin_rstd, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of one Conformer layer (bf16, relative positions) as ONE crossing of the C ABI: the gradient kernels in
+// the order emoasr_amd/engine.py:_backward issues them (final LayerNorm, feed-forward, convolution module,
+// self-attention, macaron feed-forward; reference autograd of conformer.py:146-225), the layer's nine weight-gradient
+// products as one grouped launch, intermediates in one caller-provided workspace that the next layer reuses.
+// The LayerNorm dgamma / dbeta partial sums are left in `ln_part` for one emoasr_layernorm_bwd_finalize over the
+// whole sweep (slots: 0 final, 1 feed-forward, 2 convolution, 3 attention, 4 macaron).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct BwdLayout {
+  size_t off = 0;
+  size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; }
+};
+
+struct BwdBufs {
+  size_t dx1, dx2, dx3, dx4, pre1, pre2, pre3, pre4, dh, du_ff, du_ffm, dz, dc, dgl, dg, dout, dqkv, dpos_t;
+  size_t dpos, delta, bn_scr, dw_scr, attn_ws, attn_ws_bytes, total;
+};
+
+BwdBufs bwd_layout(int dtype, int B, int T, int d, int H, int F, int K) {
+  const size_t esz = dtype == EMO_BF16 ? 2 : 4, M = (size_t)B * T, R = 2 * (size_t)T - 1;
+  BwdLayout L;
+  BwdBufs b{};
+  b.dx1 = L.take(M * d * esz); b.dx2 = L.take(M * d * esz); b.dx3 = L.take(M * d * esz); b.dx4 = L.take(M * d * esz);
+  b.pre1 = L.take(M * d * esz); b.pre2 = L.take(M * d * esz); b.pre3 = L.take(M * d * esz); b.pre4 = L.take(M * d * esz);
+  b.dh = L.take(M * d * esz);
+  b.du_ff = L.take(M * F * esz); b.du_ffm = L.take(M * F * esz);
+  b.dz = L.take(M * d * esz); b.dc = L.take(M * d * esz); b.dgl = L.take(M * d * esz); b.dg = L.take(M * 2 * d * esz);
+  b.dout = L.take(M * d * esz); b.dqkv = L.take(M * 3 * d * esz); b.dpos_t = L.take(R * d * esz);
+  b.dpos = L.take(R * d * 4); b.delta = L.take((size_t)B * H * T * 4);
+  b.bn_scr = L.take((size_t)emoasr_bn_swish_bwd_scratch_floats((int)M, d) * 4);
+  b.dw_scr = L.take((size_t)emoasr_dwconv_bwd_w_scratch_floats(B, T, d, K) * 4);
+  b.attn_ws_bytes = emoasr_attn_bwd_fused_ws_bytes(dtype, B, H, T, T, 1);
+  b.attn_ws = L.take(b.attn_ws_bytes);
+  b.total = L.off;
+  return b;
+}
+
+}  // namespace
+
+extern "C" size_t emoasr_conformer_layer_bwd_ws_bytes(int dtype, int B, int T, int d, int H, int F, int K) {
+  return bwd_layout(dtype, B, T, d, H, F, K).total;
+}
+
+extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_layer_t* L, const emoasr_conformer_layer_t* G,
+                                          const emoasr_conformer_fwd_t* st, const emoasr_conformer_bwd_t* io, void* stream) {
+  EMO_CHECK(L && G && st && io && io->dy && io->dx && io->ws && io->ln_part, "conformer_layer_bwd: missing arguments");
+  EMO_CHECK(dtype == EMO_BF16, "conformer_layer_bwd: bf16 only (f32 is sequenced by the host)");
+  const int d = L->d, H = L->H, F = L->F, K = L->K, B = st->B, T = st->T, M = B * T, R = 2 * T - 1;
+  const BwdBufs bb = bwd_layout(dtype, B, T, d, H, F, K);
+  EMO_CHECK(io->ws_bytes >= bb.total, "conformer_layer_bwd: workspace %zu < %zu bytes", io->ws_bytes, bb.total);
+  char* ws = static_cast<char*>(io->ws);
+  const size_t esz = 2;
+  const float p = st->p_enc;
+  hipStream_t s = (hipStream_t)stream;
+  emoasr_tn_problem_t pr[EMOASR_TN_GROUP_MAX];
+  int npr = 0;
+  auto wgrad = [&](const void* dy, long lddy, int N1, const void* x, long ldx, int N2, int Kred, const void* gw, float alpha,
+                   const void* gb) {
+    pr[npr++] = emoasr_tn_problem_t{N1, N2, Kred, dy, lddy, x, ldx, (float*)gw, (long)N2, alpha, (float*)gb, alpha};
+  };
+  auto ln_bwd = [&](int slot, const void* dh, const void* x, const float* gamma, const float* mean, const float* rstd,
+                    const void* dres, void* dx, const void* ggam, const void* gbet, void* pre, float scale, uint64_t seed) {
+    emoasr_ln_bwd_opts_t o{};
+    if (pre && p > 0.f) { o.dy2 = pre; o.scale2 = scale; o.drop_p2 = p; o.seed2 = seed; }
+    o.defer_finalize = 1;
+    return emoasr_layernorm_bwd_ex(dtype, M, d, dh, x, gamma, mean, rstd, dres, dx, (float*)ggam, (float*)gbet,
+                                   io->ln_part + (long)slot * io->ln_part_stride, &o, stream);
+  };
+  // x + res_scale * drop(W2 act(W1 LN(x))): gradient chain of one feed-forward block.  dx_in: gradient at the block's
+  // output; pre_in: dropout(dx_in * res_scale) from the LayerNorm backward that produced dx_in (p > 0)
+  auto ffn_bwd = [&](const emoasr_ffn_params_t& P, const emoasr_ffn_params_t& Gp, const emoasr_ffn_stash_t& S, const void* x_in,
+                     const void* dx_in, const void* pre_in, void* du, uint64_t s_in) {
+    const void* dy = p > 0.f ? pre_in : dx_in;
+    const float alpha = p > 0.f ? 1.f : 0.5f;
+    wgrad(dy, d, d, S.a, F, F, M, Gp.w2, alpha, Gp.b2);
+    emoasr_epilogue_t e = plain_ep();
+    e.alpha = alpha; e.dact_pre = S.u; e.dact = EMOASR_ACT_SWISH; e.drop_p = p; e.seed = s_in;
+    if (emoasr_gemm_nn(dtype, M, F, d, dy, d, P.w2, F, du, F, &e, stream)) return 1;
+    wgrad(du, F, F, S.h, d, d, M, Gp.w1, 1.f, Gp.b1);
+    emoasr_epilogue_t e1 = plain_ep();
+    return emoasr_gemm_nn(dtype, M, d, F, du, F, P.w1, d, ws + bb.dh, d, &e1, stream);
+  };
+
+  // ---- final LayerNorm ------------------------------------------------------------------------------------------
+  if (ln_bwd(0, io->dy, st->ff.y, L->fin_ln_g, st->fin_mean, st->fin_rstd, nullptr, ws + bb.dx1, G->fin_ln_g, G->fin_ln_b,
+             ws + bb.pre1, 0.5f, st->seed[6])) return 1;
+  // ---- feed-forward -----------------------------------------------------------------------------------------------
+  if (ffn_bwd(L->ff, G->ff, st->ff, st->cv_y, ws + bb.dx1, ws + bb.pre1, ws + bb.du_ff, st->seed[5])) return 1;
+  if (ln_bwd(1, ws + bb.dh, st->cv_y, L->ff.ln_g, st->ff.mean, st->ff.rstd, ws + bb.dx1, ws + bb.dx2, G->ff.ln_g, G->ff.ln_b,
+             ws + bb.pre2, 1.f, st->seed[4])) return 1;
+  // ---- convolution module -----------------------------------------------------------------------------------------
+  {
+    const void* dy = p > 0.f ? ws + bb.pre2 : ws + bb.dx2;
+    wgrad(dy, d, d, st->z, d, d, M, G->pw2, 1.f, G->pw2_b);
+    emoasr_epilogue_t e = plain_ep();
+    if (emoasr_gemm_nn(dtype, M, d, d, dy, d, L->pw2, d, ws + bb.dz, d, &e, stream)) return 1;
+    if (emoasr_bn_swish_bwd(dtype, M, d, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f, ws + bb.dc,
+                            (float*)G->bn_g, (float*)G->bn_b, (float*)(ws + bb.bn_scr), stream)) return 1;
+    if (emoasr_dwconv_bwd_x(dtype, B, T, d, K, ws + bb.dc, L->dw_w, ws + bb.dgl, stream)) return 1;
+    if (emoasr_dwconv_bwd_w(dtype, B, T, d, K, ws + bb.dc, st->gl, (float*)G->dw_w, (float*)G->dw_b, 1,
+                            (float*)(ws + bb.dw_scr), stream)) return 1;
+    if (emoasr_glu_bwd(dtype, M, d, st->g, ws + bb.dgl, ws + bb.dg, stream)) return 1;
+    wgrad(ws + bb.dg, 2 * d, 2 * d, st->cv_h, d, d, M, G->pw1, 1.f, G->pw1_b);
+    if (emoasr_gemm_nn(dtype, M, d, 2 * d, ws + bb.dg, 2 * d, L->pw1, d, ws + bb.dh, d, &e, stream)) return 1;
+    if (ln_bwd(2, ws + bb.dh, st->at_y, L->cv_ln_g, st->cv_mean, st->cv_rstd, ws + bb.dx2, ws + bb.dx3, G->cv_ln_g, G->cv_ln_b,
+               ws + bb.pre3, 1.f, st->seed[3])) return 1;
+  }
+  // ---- relative-position self-attention -----------------------------------------------------------------------------
+  {
+    const void* dy = p > 0.f ? ws + bb.pre3 : ws + bb.dx3;
+    wgrad(dy, d, d, st->o, d, d, M, G->wout, 1.f, G->bout);
+    emoasr_epilogue_t e = plain_ep();
+    if (emoasr_gemm_nn(dtype, M, d, d, dy, d, L->wout, d, ws + bb.dout, d, &e, stream)) return 1;
+    hipMemsetAsync(ws + bb.dpos, 0, (size_t)R * d * 4, s);
+    emoasr_attn_t a{};
+    a.B = B; a.H = H; a.DK = d / H; a.Tq = T; a.Tk = T;
+    a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d; a.ldp = d;
+    a.q = st->qkv;
+    a.k = (const char*)st->qkv + (size_t)d * esz;
+    a.v = (const char*)st->qkv + (size_t)2 * d * esz;
+    a.pos = st->pp; a.bias_u = L->bias_u; a.bias_v = L->bias_v; a.klens = st->klens;
+    a.causal = 0; a.scale = 1.f / sqrtf((float)(d / H)); a.drop_p = st->p_att; a.seed = st->seed[2];
+    a.out = st->o; a.lse = st->lse;
+    a.dout = ws + bb.dout; a.delta = (float*)(ws + bb.delta);
+    a.dq = ws + bb.dqkv; a.dk = ws + bb.dqkv + (size_t)d * esz; a.dv = ws + bb.dqkv + (size_t)2 * d * esz;
+    a.dpos = (float*)(ws + bb.dpos); a.dbias_u = (float*)G->bias_u; a.dbias_v = (float*)G->bias_v;
+    if (emoasr_attn_bwd_fused(dtype, &a, ws + bb.attn_ws, bb.attn_ws_bytes, stream)) return 1;
+    if (emoasr_strided_copy(EMO_F32, dtype, ws + bb.dpos, ws + bb.dpos_t, 1, 1, 1, R * d, 0, 0, 0, 1, 0, stream)) return 1;
+    wgrad(ws + bb.dpos_t, d, d, st->pos_t, d, d, R, G->wpos, 1.f, nullptr);
+    wgrad(ws + bb.dqkv, 3 * d, 3 * d, st->at_h, d, d, M, G->wqkv, 1.f, G->bqkv);
+    if (emoasr_gemm_nn(dtype, M, d, 3 * d, ws + bb.dqkv, 3 * d, L->wqkv, d, ws + bb.dh, d, &e, stream)) return 1;
+    if (ln_bwd(3, ws + bb.dh, st->ffm.y, L->att_ln_g, st->at_mean, st->at_rstd, ws + bb.dx3, ws + bb.dx4, G->att_ln_g,
+               G->att_ln_b, ws + bb.pre4, 0.5f, st->seed[1])) return 1;
+  }
+  // ---- macaron feed-forward ---------------------------------------------------------------------------------------
+  if (ffn_bwd(L->ffm, G->ffm, st->ffm, st->x, ws + bb.dx4, ws + bb.pre4, ws + bb.du_ffm, st->seed[0])) return 1;
+  if (ln_bwd(4, ws + bb.dh, st->x, L->ffm.ln_g, st->ffm.mean, st->ffm.rstd, ws + bb.dx4, io->dx, G->ffm.ln_g, G->ffm.ln_b,
+             nullptr, 0.f, 0)) return 1;
+  // ---- the layer's weight gradients, one launch -----------------------------------------------------------------------
+  return emoasr_gemm_tn_grouped(dtype, npr, pr, stream);
+}

@@ -644,6 +644,15 @@ class CTCEngine(_DecoderMixinPlaceholder):
             self._ln_deferred = []
             self._join_side()
 
+    def _cpp_bwd_ok(self, st):
+        """the whole-layer C++ backward takes bf16 relative-position Conformer layers whose forward ran through the
+        C++ layer runtime (EMOASR_CPP_BWD=0: sequence the gradient kernels from here)"""
+        from .layer_rt import LayerStash
+        return (self._cpp_layers and self.conformer and self.rel and self.dtype == torch.bfloat16 and self.attn_fused
+                and not self._side_wgrads and os.environ.get("EMOASR_CPP_BWD", "1") != "0"
+                and bool(st.layers) and all(isinstance(s, LayerStash) and s.io is not None for s in st.layers)
+                and st.layers[0].io.training)
+
     def _backward(self, st, deouts, deouts_inter=None):
         A, d = self.arena, self.d
         A.attach_grads()
@@ -668,8 +677,25 @@ class CTCEngine(_DecoderMixinPlaceholder):
         inter = self.inter_layer if deouts_inter is not None else 0
         first = None if (self.conformer or inter == nl) else br(nl - 1, "ff")
         dx, pre = self._ln_bwd(deouts.reshape(M, d), st.x_final, "encoder.norm", st.fin_mean, st.fin_rstd, None, first)
+        cpp_bwd = self._cpp_bwd_ok(st)
+        if cpp_bwd:
+            from .layer_rt import LayerStash  # noqa: F401
+            lnf = ops.lib.size_query("emoasr_layernorm_bwd_scratch_floats", d)
+            ln_parts = torch.empty(nl, 5, lnf, device=dx.device, dtype=torch.float32)
+            dx_bufs = [torch.empty(M, d, device=dx.device, dtype=dx.dtype) for _ in range(2)]
         for li in reversed(range(nl)):
             name = f"encoder.transformers.{li}"
+            if cpp_bwd:
+                # one C-ABI call per layer (csrc/layer.hip: emoasr_conformer_layer_bwd), incl. its grouped weight gradients
+                if li + 1 == inter:
+                    dx, _ = self._ln_bwd(deouts_inter.reshape(M, d), st.x_inter, "encoder.norm", st.int_mean, st.int_rstd, dx)
+                out = dx_bufs[li & 1]
+                self._layer_rt.backward(li, st.layers[li], dx, out, ln_parts[li], self._ln_deferred)
+                dx = out
+                if self.grad_hook is not None and li + 1 <= (inter if inter > 0 else nl):
+                    ops.layernorm_bwd_finalize(self._ln_deferred)
+                    self.grad_hook(self._layer_offset(li))
+                continue
             s_ffm, s_att, s_conv, s_ff, s_fin = st.layers[li]
             if li + 1 == inter:
                 dx, _ = self._ln_bwd(deouts_inter.reshape(M, d), st.x_inter, "encoder.norm", st.int_mean, st.int_rstd, dx)

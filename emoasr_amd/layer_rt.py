@@ -53,10 +53,11 @@ class _Layout:
 class LayerStash:
     """What one layer's forward left behind; iterating yields the (s_ffm, s_att, s_conv, s_ff, s_fin) tuples
     engine._backward expects, with tensor views built on first use."""
-    __slots__ = ("wt", "wf", "lay", "x_in", "seeds", "_tup")
+    __slots__ = ("wt", "wf", "lay", "x_in", "seeds", "_tup", "io", "B", "T")
 
     def __init__(self, wt, wf, lay, x_in, seeds):
         self.wt, self.wf, self.lay, self.x_in, self.seeds, self._tup = wt, wf, lay, x_in, seeds, None
+        self.io = None  # the emoasr_conformer_fwd_t of the forward call (the C++ backward takes it as the stash)
 
     def tv(self, name):
         o, n, shape = self.lay.t[name]
@@ -94,7 +95,9 @@ class ConformerLayerRuntime:
     def __init__(self, eng):
         self.eng = eng
         self.params = {}    # layer index -> (lib.ConformerLayer, guard)
+        self.grads = {}     # layer index -> (lib.ConformerLayer of gradient pointers, guard)
         self.layouts = {}   # (B, T) -> _Layout
+        self.bwd_ws = None  # one backward workspace, shared by all layers (they run one after the other)
 
     def _layer_params(self, li):
         eng, A = self.eng, self.eng.arena
@@ -178,7 +181,66 @@ class ConformerLayerRuntime:
             io.cv_mean, io.cv_rstd = fb + f["cv_mean"][0] * 4, fb + f["cv_rstd"][0] * 4
             io.fin_mean, io.fin_rstd = fb + f["fin_mean"][0] * 4, fb + f["fin_rstd"][0] * 4
         lib.call("emoasr_conformer_layer_fwd", ops.dt(wt), ctypes.byref(L), ctypes.byref(io), ops._stream())
+        st.io, st.B, st.T = io, B, T
         return st
+
+    # ---------------------------------------------------------------------------------------------- backward
+    def _layer_grads(self, li):
+        """the layer struct again, every parameter pointer replaced by its f32 gradient's address"""
+        eng, A = self.eng, self.eng.arena
+        guard = A.grad.data_ptr()
+        hit = self.grads.get(li)
+        if hit is not None and hit[1] == guard:
+            return hit[0]
+        name = f"encoder.transformers.{li}"
+        d = eng.d
+        G = lib.ConformerLayer()
+
+        def gp(n):
+            return A.g(n).data_ptr()
+
+        def ffn(dst, pre, norm):
+            dst.ln_g, dst.ln_b = gp(norm + ".weight"), gp(norm + ".bias")
+            dst.w1, dst.b1, dst.w2, dst.b2 = gp(pre + ".w1.weight"), gp(pre + ".w1.bias"), gp(pre + ".w2.weight"), gp(pre + ".w2.bias")
+
+        ffn(G.ffm, name + ".feed_forward_macaron", name + ".norm_ff_macaron")
+        ffn(G.ff, name + ".feed_forward", name + ".norm_ff")
+        sa, cv, bn = name + ".self_attn", name + ".conv", name + ".conv.batch_norm"
+        G.att_ln_g, G.att_ln_b = gp(name + ".norm_self_attn.weight"), gp(name + ".norm_self_attn.bias")
+        G.wqkv = A.g_span(sa + ".linear_q.weight", sa + ".linear_v.weight", (3 * d, d)).data_ptr()
+        G.bqkv = A.g_span(sa + ".linear_q.bias", sa + ".linear_v.bias", (3 * d,)).data_ptr()
+        G.wpos = gp(sa + ".linear_pos.weight")
+        G.bias_u, G.bias_v = gp(sa + ".pos_bias_u"), gp(sa + ".pos_bias_v")
+        G.wout, G.bout = gp(sa + ".linear_out.weight"), gp(sa + ".linear_out.bias")
+        G.cv_ln_g, G.cv_ln_b = gp(name + ".norm_conv.weight"), gp(name + ".norm_conv.bias")
+        G.pw1, G.pw1_b = gp(cv + ".pointwise_conv1.weight"), gp(cv + ".pointwise_conv1.bias")
+        G.dw_w, G.dw_b = gp(cv + ".depthwise_conv.weight"), gp(cv + ".depthwise_conv.bias")
+        G.bn_g, G.bn_b = gp(bn + ".weight"), gp(bn + ".bias")
+        G.pw2, G.pw2_b = gp(cv + ".pointwise_conv2.weight"), gp(cv + ".pointwise_conv2.bias")
+        G.fin_ln_g, G.fin_ln_b = gp(name + ".norm_final.weight"), gp(name + ".norm_final.bias")
+        self.grads[li] = (G, guard)
+        return G
+
+    def backward(self, li, st, dy, dx, ln_part, deferred):
+        """one C-ABI call for the whole layer (csrc/layer.hip: emoasr_conformer_layer_bwd).  dy / dx: [M, d] gradient at
+        the layer's output / input (dx is written); ln_part: f32 [5, stride] scratch of this layer's LayerNorm partial
+        sums, recorded in `deferred` for ops.layernorm_bwd_finalize."""
+        eng, A = self.eng, self.eng.arena
+        L, G = self._layer_params(li), self._layer_grads(li)
+        B, T = st.B, st.T
+        nb = lib.size_query("emoasr_conformer_layer_bwd_ws_bytes", ops.dt(st.wt), B, T, eng.d, eng.h, L.F, L.K)
+        if self.bwd_ws is None or self.bwd_ws.numel() < nb:
+            self.bwd_ws = torch.empty(int(nb * 1.1) + 256, device=dy.device, dtype=torch.uint8)
+        io = lib.ConformerBwd()
+        io.dy, io.dx = dy.data_ptr(), dx.data_ptr()
+        io.ws, io.ws_bytes = self.bwd_ws.data_ptr(), self.bwd_ws.numel()
+        io.ln_part, io.ln_part_stride = ln_part.data_ptr(), ln_part.stride(0)
+        lib.call("emoasr_conformer_layer_bwd", ops.dt(st.wt), ctypes.byref(L), ctypes.byref(G), ctypes.byref(st.io),
+                 ctypes.byref(io), ops._stream())
+        name = f"encoder.transformers.{li}"
+        M = B * T
+        for k, norm in enumerate(("norm_final", "norm_ff", "norm_conv", "norm_self_attn", "norm_ff_macaron")):
+            deferred.append((M, eng.d, ln_part[k], A.g(f"{name}.{norm}.weight"), A.g(f"{name}.{norm}.bias")))
 
 
 def tb_prev(x, esz):

@@ -121,6 +121,11 @@ class ConformerFwd(Structure):
                 ("cv_mean", c_void_p), ("cv_rstd", c_void_p),
                 ("y", c_void_p), ("fin_mean", c_void_p), ("fin_rstd", c_void_p)]
 
+class ConformerBwd(Structure):
+    _fields_ = [("dy", c_void_p), ("dx", c_void_p), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t),
+                ("ln_part", c_void_p), ("ln_part_stride", c_long)]
+
+
 P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
 
 # name -> argtypes (every function returns int status); mirrors include/emoasr_hip.h
@@ -142,6 +147,8 @@ SIGNATURES = {
     "emoasr_layernorm_bwd_ex": [I, I, I, P, P, P, P, P, P, P, P, P, P, POINTER(LnBwdOpts), P],
     "emoasr_layernorm_bwd_finalize": [I, POINTER(LnFinalizeItem), P],
     "emoasr_conformer_layer_fwd": [I, POINTER(ConformerLayer), POINTER(ConformerFwd), P],
+    "emoasr_conformer_layer_bwd": [I, POINTER(ConformerLayer), POINTER(ConformerLayer), POINTER(ConformerFwd),
+                                   POINTER(ConformerBwd), P],
     "emoasr_transformer_decoder_infer": [I, I, POINTER(DecoderLayer), POINTER(DecoderInfer), P],
     "emoasr_bert_lm_infer": [I, I, POINTER(BertLayer), POINTER(BertInfer), P],
     "emoasr_attn_fwd": [I, POINTER(AttnArgs), P],

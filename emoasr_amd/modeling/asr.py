@@ -58,6 +58,8 @@ class ASR(nn.Module):
         if ys_in is not None:
             ys_in = ys_in[:, : int(max(ylens)) + 1]
             ys_out = ys_out[:, : int(max(ylens)) + 1]
+        if ps is not None:  # phone targets are trimmed to the batch like the word targets (asr.py:61-62)
+            ps = ps[:, : int(max(plens))]
         eouts, elens, eouts_inter = self.encoder(xs, xlens)
         loss, loss_dict, _ = self.decoder(eouts, elens, eouts_inter, ys, ylens, ys_in, ys_out, soft_labels, ps, plens)
         return loss, loss_dict

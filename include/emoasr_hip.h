@@ -424,6 +424,24 @@ typedef struct emoasr_conformer_fwd {
 } emoasr_conformer_fwd_t;
 int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* layer,
                                const emoasr_conformer_fwd_t* io, void* stream);
+/* Backward of the same layer (bf16; training-mode forward with stash) as one call: gradient kernels in the order the
+ * reference's autograd runs them (conformer.py:146-225 backwards), the layer's nine weight-gradient products as one grouped
+ * launch.  `grads`: the layer struct again with every parameter pointer replaced by the address of its f32 gradient
+ * (accumulated into; d/H/F/K and the running-statistics fields are ignored).  `st`: the emoasr_conformer_fwd_t the forward
+ * call was given (its buffers still intact).  dy / dx: gradient w.r.t. the layer's output / input, [B*T, d].
+ * ws: emoasr_conformer_layer_bwd_ws_bytes(...) bytes, no initialisation, reusable by the next layer's call.
+ * ln_part: 5 areas of emoasr_layernorm_bwd_scratch_floats(d) floats, ln_part_stride floats apart, that receive the
+ * dgamma / dbeta partial sums of the layer's LayerNorms (order: final, feed-forward, convolution, attention, macaron);
+ * the caller folds them with emoasr_layernorm_bwd_finalize (one launch for the whole backward sweep). */
+typedef struct emoasr_conformer_bwd {
+  const void* dy;
+  void* dx;
+  void* ws; size_t ws_bytes;
+  float* ln_part; long ln_part_stride;
+} emoasr_conformer_bwd_t;
+size_t emoasr_conformer_layer_bwd_ws_bytes(int dtype, int B, int T, int d, int H, int F, int K);
+int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_layer_t* layer, const emoasr_conformer_layer_t* grads,
+                               const emoasr_conformer_fwd_t* st, const emoasr_conformer_bwd_t* io, void* stream);
 
 /* ---- beam-search step runtime (inference): the Transformer decoder over the whole prefix and the
  * Transformer LM's next-token distribution, each as ONE call per output step ---------------------------

@@ -361,6 +361,47 @@ def test_attention_bwd_fused_vs_materialised(dev, case):
         _close(f[3], a[3], 3e-2, "dbias_v")
 
 
+def test_attention_bwd_fused_run_to_run(dev):
+    """Race screen at a training-batch shape (both workgroup sizes): dK and dV never leave their wave's registers, so they
+    must be bit-identical from run to run; dQ / dpos / dbias are sums of a few float atomics and may differ in the last bits."""
+    from emoasr_amd import lib, ops
+    H, dk = 4, 64
+    D = H * dk
+    B, T = 22, 320
+    dt_ = torch.bfloat16
+    kl = [T - 3 * i for i in range(B)]
+    klens = torch.tensor(kl, device=dev, dtype=torch.int32)
+    qkv = _rnd(dev, B, T, 3 * D, dtype=dt_)
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    pos = _rnd(dev, 2 * T - 1, D, dtype=dt_)
+    bu, bv = _rnd(dev, D, scale=0.5), _rnd(dev, D, scale=0.5)
+    scale = 1 / math.sqrt(dk)
+    out, lse = ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, drop_p=0.1, seed=5)
+    dout = _rnd(dev, B, T, D, dtype=dt_)
+    try:
+        for fw in (4, 2):
+            lib.set_option("attn_fw", fw)
+            first = None
+            for it in range(8):
+                dqkv = torch.full_like(qkv, float("nan"))
+                dpos = torch.zeros(2 * T - 1, D, device=dev)
+                dbu, dbv = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+                ops.attn_bwd(dout, out, lse, q, k, v, H, scale, dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:], pos=pos,
+                             bias_u=bu, bias_v=bv, klens=klens, drop_p=0.1, seed=5, dpos=dpos, dbias_u=dbu, dbias_v=dbv,
+                             materialise="fused")
+                cur = (dqkv.clone(), dpos, dbu, dbv)
+                assert torch.isfinite(cur[0].float()).all()
+                if first is None:
+                    first = cur
+                    continue
+                assert torch.equal(cur[0][..., D:], first[0][..., D:]), f"dK/dV differ between runs (fw={fw}, run {it})"
+                _close(cur[0][..., :D], first[0][..., :D], 1e-2, "dq run to run")
+                _close(cur[1], first[1], 1e-3, "dpos run to run")
+                _close(cur[2], first[2], 1e-3, "dbias_u run to run")
+    finally:
+        lib.set_option("attn_fw", 0)
+
+
 # ---------------------------------------------------------------- conv module
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_glu(dev, dtype):
