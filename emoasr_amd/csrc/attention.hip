@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(256) void attn_dbias_v_kernel(const emoasr_attn_t a
 //     arrival order: bf16 rounding flips of dQ then propagate through every layer below); the finalize pass adds the key
 //     blocks' partials in block order, so dQ is bit-reproducible;
 //   * dS (query-major, bf16) is stored for attn_bwd_dpos2_kernel, which walks its diagonals: dpos[r] = sum_{b,i}
-//     dS[b,i,i-(Tq-1)+r] (Q+v)[b,i].  dbias_v = colsum(dQ) - dbias_u comes out of the finalize pass.
+//     dS[b,i,i-(Tq-1)+r] (Q+v)[b,i].  dbias_v = colsum(dQ) - dbias_u: the flush also sums the dQ rows it stores.
 // ====================================================================================
 
 struct FusedWs {       // workspace carved by emoasr_attn_bwd_fused
@@ -1354,13 +1354,17 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
   // sum of the waves' dQ^T slabs of the step that just ended -> this key block's f32 partial (rows of 64 d = 256 B, plain
   // stores: every (key block, query row) has exactly one writer, so dQ is bit-reproducible); wave w takes rows w, w + FW, ...
   float* dq_part = ws.dq32 + (long)blockIdx.x * ws.dq_slab + (long)b * a.Tq * (a.H * DK) + ho + lane;
+  float dq_colsum = 0.f;  // sum over this wave's query rows of dQ[:, d = lane] (dbias_u + dbias_v = colsum(dQ))
   auto flush = [&](const int ib) {
 #pragma unroll
     for (int q = wave; q < 32; q += FW) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < FW; ++w) v += slab0[w * SLAB_STRIDE + lane * C_::DQ_LD + q];
-      if (ib + q < a.Tq) dq_part[(long)(ib + q) * (a.H * DK)] = v;
+      if (ib + q < a.Tq) {
+        dq_part[(long)(ib + q) * (a.H * DK)] = v;
+        dq_colsum += v;
+      }
     }
   };
   fetch(0);
@@ -1496,43 +1500,52 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
   }
   store_dT<T>((T*)hp.dk, a.ldk, j0, a.Tk, dk, 1.f, lane);  // (a dead wave stores zeros)
   store_dT<T>((T*)hp.dv, a.ldv, j0, a.Tk, dv, 1.f, lane);
-  if (REL && live && a.dbias_u) {
-    // dbias_u[d] += sum_j colsum_j K[j][d]  (colsum_j = sum_i dS[i][j]);  dbias_v gets the negative: the finalize pass
-    // adds colsum(dQ) = dbias_u + dbias_v to it
-    float* cs = Gs;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = csum[r];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (il == 0) cs[c_row(r, lane)] = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k);
+  if (REL && a.dbias_u) {
+    // dbias_u[d] += sum_j colsum_j K[j][d]  (colsum_j = sum_i dS[i][j]);  dbias_v[d] += colsum(dQ)[d] - that
     float acc = 0.f;
+    if (live) {
+      float* cs = Gs;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = csum[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (il == 0) cs[c_row(r, lane)] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k);
 #pragma unroll 8
-    for (int j = 0; j < 32; ++j) {
-      const int kj = j0 + j;
-      acc += cs[j] * buf_load_f32<T>(rsK, kj < a.Tk ? (unsigned)(((long)kj * a.ldk + lane) * sizeof(T)) : EMO_OOB);
+      for (int j = 0; j < 32; ++j) {
+        const int kj = j0 + j;
+        acc += cs[j] * buf_load_f32<T>(rsK, kj < a.Tk ? (unsigned)(((long)kj * a.ldk + lane) * sizeof(T)) : EMO_OOB);
+      }
+      atomicAdd(&a.dbias_u[h * DK + lane], acc);
     }
-    atomicAdd(&a.dbias_u[h * DK + lane], acc);
-    if (a.dbias_v) atomicAdd(&a.dbias_v[h * DK + lane], -acc);
+    atomicAdd(&a.dbias_v[h * DK + lane], dq_colsum - acc);
   }
 }
 
 // dpos[r, h*64+d] += sum_{b,i} dS[b,h,i, j = i-(Tq-1)+r] (Q+v)[b,i,h*64+d]: block = (32 table rows, head, batch chunk);
-// the waves take (batch, query tile) items round-robin, gather the diagonal band of dS (2-byte loads, consecutive lanes
-// = consecutive keys) as the A operand and (Q+v) as the B operand, and are reduced through LDS before one set of atomics.
-template <typename T>
+// the waves take the (batch, query tile) items whose diagonal band meets valid keys round-robin.  Per item: the band of
+// dS is gathered with 2-byte loads (consecutive lanes = consecutive keys) as the A operand, the 32x64 (Q+v) tile comes in
+// with 16-byte loads and goes through wave-private LDS (transposed reads) as the B operand; the next item's loads are in
+// flight while this one is multiplied.  Waves are reduced through LDS before one set of atomics (rows of 64 d).
+template <typename T, bool TR>
 __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t a, const FusedWs ws, const int bchunk) {
   using M_ = Mma<T>;
-  __shared__ float red[4 * 2 * 16 * 64];
+  constexpr int LD = AttnCfg<T>::LD, VEC = 16 / sizeof(T), PER_ROW = DK / VEC, QR = 32 * PER_ROW / 64;
+  constexpr int QS_BYTES = 32 * LD * (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) char smem[(4 * QS_BYTES > 4 * 2 * 16 * 64 * 4) ? 4 * QS_BYTES : 4 * 2 * 16 * 64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, hh = lane >> 5;
   const int r0 = blockIdx.x * 32, h = blockIdx.y;
   const int b_lo = blockIdx.z * bchunk, b_hi = min(a.B, b_lo + bchunk);
   const int nit = (a.Tq + 31) / 32;
+  const int r = r0 + il;
+  const bool rok = r < 2 * a.Tq - 1;
+  T* qs = reinterpret_cast<T*>(smem + wave * QS_BYTES);
   f32x16 acc[2];
   zero16(acc[0]); zero16(acc[1]);
+
   int item = wave;
   for (int b = b_lo; b < b_hi; ++b) {
     const int klen = a.klens ? min(a.klens[b], a.Tk) : a.Tk;
@@ -1540,32 +1553,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t
     const __amdgpu_buffer_rsrc_t rsQ = make_rsrc((const T*)ws.qv + (long)b * a.Tq * ws.ldqu + (long)h * DK);
     for (; item < nit; item += 4) {
       const int i0 = item * 32;
-      const int jmin = i0 - (a.Tq - 1) + r0, jmax = jmin + 62;
-      if (jmax < 0 || jmin >= klen) continue;
-      const int r = r0 + il;
+      const int jmin = i0 - (a.Tq - 1) + r0;
+      if (jmin + 62 < 0 || jmin >= klen) continue;
+      Vec16<T> xq[QR];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 fa, fb[2];
+      for (int k = 0; k < QR; ++k) {
+        const int p = lane + 64 * k, row = p / PER_ROW, piece = (p % PER_ROW) * VEC;
+        xq[k] = buf_load16<T>(rsQ, i0 + row < a.Tq ? (unsigned)(((i0 + row) * (int)ws.ldqu + piece) * (int)sizeof(T)) : EMO_OOB);
+      }
+      typename M_::Frag fa[2];
+      // element (i, r) of the band sits at dS[i][j = i - (Tq-1) + r]: element offset i * (ldds + 1) + r - (Tq-1)
+      const int base = (i0 + 8 * hh) * ((int)ws.ldds + 1) + r - (a.Tq - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int i = i0 + 16 * ks + 8 * hh + e;
           const int j = i - (a.Tq - 1) + r;
-          const bool ok = i < a.Tq && j >= 0 && j < klen && r < 2 * a.Tq - 1;
-          fa[e] = (bf16)buf_load_f32<T>(rsS, ok ? (unsigned)(((long)i * ws.ldds + j) * sizeof(T)) : EMO_OOB);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-            fb[dt][e] = (bf16)buf_load_f32<T>(rsQ, i < a.Tq ? (unsigned)(((long)i * ws.ldqu + 32 * dt + il) * sizeof(T)) : EMO_OOB);
+          const bool ok = rok && i < a.Tq && j >= 0 && j < klen;
+          const float v = buf_load_f32<T>(rsS, ok ? (unsigned)((base + (16 * ks + e) * ((int)ws.ldds + 1)) * (int)sizeof(T)) : EMO_OOB);
+          if constexpr (sizeof(T) == 2) fa[ks][e] = (bf16)v;
         }
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[dt], acc[dt], 0, 0, 0);
+      for (int k = 0; k < QR; ++k) {
+        const int p = lane + 64 * k;
+        store16(qs + (p / PER_ROW) * LD + (p % PER_ROW) * VEC, xq[k]);
       }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          acc[dt] = M_::mma(fa[ks], M_::template load_km<TR>(qs, LD, 16 * ks, 32 * dt, lane), acc[dt]);
+      __builtin_amdgcn_wave_barrier();
     }
     item -= nit;
   }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[((wave * 2 + dt) * 16 + r) * 64 + lane] = acc[dt][r];
+    for (int rg = 0; rg < 16; ++rg) red[((wave * 2 + dt) * 16 + rg) * 64 + lane] = acc[dt][rg];
   __syncthreads();
   // thread -> (dt, reg, lane) of the summed tile: 2048 values, 8 per thread
 #pragma unroll
@@ -1579,52 +1608,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t
   }
 }
 
-// dq (T, strided) = sum over the utterance's live key blocks of their dQ partials (fixed order); dbias_v[c] += sum over
-// rows of dq[:, c]  (optional).  Block = 64 rows x ncol columns.
+// dq (T, strided) = sum over the utterance's live key blocks of their dQ partials, in block order (bit-reproducible).
+// Block = 16 rows x ncol columns; the slab loads of a row are issued together (out-of-range blocks: no traffic).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_fin_kernel(const long rows, const int ncol, const float* __restrict__ dq32,
                                                            const long slab, const int keys_per_block, const int Tq, const int Tk,
-                                                           const int* __restrict__ klens, T* __restrict__ dq, const long ldq,
-                                                           float* __restrict__ colsum_out) {
-  __shared__ float redsum[2048];
+                                                           const int* __restrict__ klens, T* __restrict__ dq, const long ldq) {
   const int ngrp = ncol / 8, rpb = 256 / ngrp;  // column groups of 8, rows per pass
   const int cg = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
-  if (colsum_out) {
-    for (int i = threadIdx.x; i < ncol; i += 256) redsum[i] = 0.f;
-    __syncthreads();
-  }
-  float cs[8];
+  if (rr >= rpb) return;
+  const long row_lo = (long)blockIdx.x * 16, row_hi = min(rows, row_lo + 16);
+  for (long row = row_lo + rr; row < row_hi; row += rpb) {
+    const int b = (int)(row / Tq);
+    const int klen = klens ? min(klens[b], Tk) : Tk;
+    const int nkb = (klen + keys_per_block - 1) / keys_per_block;
+    float o[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
-  const long row_lo = (long)blockIdx.x * 64, row_hi = min(rows, row_lo + 64);
-  if (rr < rpb) {
-    for (long row = row_lo + rr; row < row_hi; row += rpb) {
-      const int b = (int)(row / Tq);
-      const int klen = klens ? min(klens[b], Tk) : Tk;
-      const int nkb = (klen + keys_per_block - 1) / keys_per_block;
-      float o[8];
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    const int nkb_max = (Tk + keys_per_block - 1) / keys_per_block;  // uniform loop bound
+    for (int kb0 = 0; kb0 < nkb_max; kb0 += 4) {
+      f32x4 v[4][2];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = 0.f;
-      for (int kb = 0; kb < nkb; ++kb) {
-        const float* src = dq32 + kb * slab + row * ncol + cg * 8;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] += v0[e]; o[4 + e] += v1[e]; }
+      for (int u = 0; u < 4; ++u) {
+        const bool on = kb0 + u < nkb;  // (nkb varies with the row's utterance: a per-lane predicate, not a branch)
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(dq32 + (long)(kb0 + u) * slab);  // wave-uniform base
+        const unsigned off = (unsigned)((row * ncol + cg * 8) * 4);
+        v[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, on ? off : EMO_OOB, 0, 0));
+        v[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, on ? off + 16u : EMO_OOB, 0, 0));
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) cs[e] += o[e];
-      store8<T>(dq + row * ldq + cg * 8, o);
-    }
-  }
-  if (!colsum_out) return;
-  if (rr < rpb) {
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      __hip_atomic_fetch_add(&redsum[cg * 8 + e], cs[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int e = 0; e < 4; ++e) { o[e] += v[u][0][e]; o[4 + e] += v[u][1][e]; }
+    }
+    store8<T>(dq + row * ldq + cg * 8, o);
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < ncol; i += 256) atomicAdd(&colsum_out[i], redsum[i]);
 }
 
 template <typename K>
@@ -1828,14 +1846,15 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
     if (a.dpos) {
       const int nchunk = a.B < 4 ? a.B : 4;
       dim3 g2(cdiv(2 * a.Tq - 1, 32), a.H, nchunk);
-      attn_bwd_dpos2_kernel<T><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk));
+      if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk));
+      else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk));
     }
   } else {
     if (fw == 2) EMO_FUSED_LAUNCH(false, 2); else EMO_FUSED_LAUNCH(false, 4);
   }
 #undef EMO_FUSED_LAUNCH
-  attn_bwd_fin_kernel<T><<<cdiv((long)a.B * a.Tq, 64), 256, 0, s>>>((long)a.B * a.Tq, a.H * DK, ws.dq32, ws.dq_slab, 32 * fw, a.Tq,
-                                                                 a.Tk, a.klens, (T*)a.dq, a.ldq, rel ? a.dbias_v : nullptr);
+  attn_bwd_fin_kernel<T><<<cdiv((long)a.B * a.Tq, 16), 256, 0, s>>>((long)a.B * a.Tq, a.H * DK, ws.dq32, ws.dq_slab, 32 * fw, a.Tq,
+                                                                 a.Tk, a.klens, (T*)a.dq, a.ldq);
   EMO_LAUNCH_CHECK();
   return 0;
 }
