@@ -46,24 +46,21 @@ def fwd_flops_per_utt(T, F=1024, V=10000, d=256, layers=12):
     return conv1 + conv2 + lin + layers * layer + head
 
 
-def pmc_traffic(entry):
-    """HBM bytes per call of a C-ABI entry point from the committed PMC passes (profiles/r01_pmc_traffic.json:
-    FETCH_SIZE x 2 + WRITE_SIZE per kernel family, separate --pmc runs of this bench; tools/pmc_traffic.py).
-    None when the file is absent or the entry's kernels are not mapped."""
-    fam = {"emoasr_gemm_nn": ("gemm_nn[",), "emoasr_gemm_nt": ("gemm_nt[",),
-           "emoasr_gemm_tn_grouped": ("gemm_tn_grouped_kernel",),
-           "emoasr_attn_bwd": ("attn_bwd_dq2_kernel", "attn_delta_kernel", "gemm_nn_batched[", "attn_dbias_reduce_kernel"),
-           "emoasr_attn_fwd": ("attn_fwd_kernel",)}.get(entry)
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if fam is None or not os.path.exists(path):
+def pmc_kernel(kernel, key):
+    """per-launch figure of one kernel from the committed PMC passes of this bench (separate rocprofv3 --pmc runs,
+    summarised by tools/pmc_summary.py into profiles/r02_pmc.json): key = "traffic_bytes" (FETCH_SIZE x 2 + WRITE_SIZE, the
+    gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md) or "mfma_util" (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CU
+    cycles the kernel was resident)).  None when the file or the kernel is absent."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if not os.path.exists(path):
         return None
     with open(path) as f:
-        fams = json.load(f)["families"]
-    hit = {k: v for k, v in fams.items() if k.startswith(fam)}
-    if not hit:
+        fams = json.load(f).get("kernels", {})
+    hit = [v for k, v in fams.items() if kernel in k]
+    if not hit or key not in hit[0]:
         return None
-    lead = max(v["launches"] for v in hit.values()) if entry.startswith("emoasr_attn") else sum(v["launches"] for v in hit.values())
-    return sum(v["traffic_bytes_per_launch"] * v["launches"] for v in hit.values()) / lead
+    n = sum(v["launches"] for v in hit)
+    return sum(v[key] * v["launches"] for v in hit) / max(n, 1)
 
 
 class CallTimer:
@@ -136,8 +133,10 @@ def make_batches(rank, world, need, dev, seed=0):
     return out
 
 
-def cpu_baseline(model, max_seconds=25.0):
-    """CPU oracle (fp32, torch eager on the host cores): fwd + bwd of one 4-utterance L2 batch."""
+def cpu_baseline(model, max_seconds=14.0):
+    """CPU oracle (oracle/model.py, fp32 torch eager on the host cores), bounded samples of the same workload:
+    all threads -- fwd + bwd of one 4-utterance L2 batch (the headline `value`); one thread (the reference's RTF protocol,
+    asr/test_asr.py:227) -- fwd + bwd of one 640-frame utterance and greedy CTC decoding of two utterances."""
     from oracle import model as om
     cfg = SimpleNamespace(**dict(L2, dropout_enc_rate=0.0, dropout_attn_rate=0.0))
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -149,48 +148,92 @@ def cpu_baseline(model, max_seconds=25.0):
     ys = torch.randint(3, 10000, (4, 40), generator=g)
     for b in range(4):
         xs[b, xlens[b]:] = 0
-    steps, t_total = 0, 0.0
-    for i in range(6):
+
+    def train_rate(xs_, xl_, ys_, yl_, budget, max_steps):
+        steps, t_total = 0, 0.0
+        for i in range(max_steps + 1):
+            t0 = time.perf_counter()
+            loss, _, _ = om.asr_ctc_forward(sd, cfg, xs_, xl_, ys_, yl_, training=True)
+            loss.backward()
+            for p in params:
+                p.grad = None
+            dt = time.perf_counter() - t0
+            if i == 0 and max_steps > 1:
+                continue  # warm-up
+            steps += 1
+            t_total += dt
+            if t_total > budget:
+                break
+        return int(xl_.sum()) * steps / t_total, steps, t_total
+
+    nthr = torch.get_num_threads()
+    rate, steps, t_total = train_rate(xs, xlens, ys, ylens, max_seconds, 5)
+    out = dict(value=rate, unit="frames/s", cores=nthr, kind="port",
+               sample=f"{steps} fwd+bwd steps of one L2 batch (4 utts, xlens 1200/1037/911/640, fp32, dropout 0, "
+                      f"no optimizer step) in {t_total:.1f}s on {nthr} threads")
+    torch.set_num_threads(1)
+    try:
+        r1, s1, t1 = train_rate(xs[3:4, :640], xlens[3:4], ys[3:4, :20], ylens[3:4], 6.0, 1)
+        out["value_1thread"] = r1
+        out["sample_1thread"] = f"{s1} fwd+bwd step(s) of one 640-frame utterance in {t1:.1f}s on 1 thread"
         t0 = time.perf_counter()
-        loss, _, _ = om.asr_ctc_forward(sd, cfg, xs, xlens, ys, ylens, training=True)
-        loss.backward()
-        for p in params:
-            p.grad = None
-        dt = time.perf_counter() - t0
-        if i == 0:
-            continue  # warm-up
-        steps += 1
-        t_total += dt
-        if t_total > max_seconds:
-            break
-    frames = int(xlens.sum()) * steps
-    return dict(value=frames / t_total, unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{steps} fwd+bwd steps of one L2 batch (4 utts, xlens 1200/1037/911/640, fp32, dropout 0, "
-                       f"no optimizer step) in {t_total:.1f}s")
+        with torch.no_grad():
+            for b in (2, 3):
+                om.asr_ctc_greedy(sd, cfg, xs[b:b + 1, : int(xlens[b])], xlens[b:b + 1])
+        out["decode_rtf_1thread"] = (time.perf_counter() - t0) / (float(xlens[2] + xlens[3]) * 0.010)
+    finally:
+        torch.set_num_threads(nthr)
+    return out
 
 
-def decode_rtf(model, dev, n_utts=20, repeats=3):
-    """greedy CTC decode, batch 1 (reference protocol, asr/test_asr.py:226-263): wall / audio seconds"""
+class _NpyLoader:
+    """the reference's decode-time data path: TSV manifest + one .npy feature file per utterance, batch size 1, read from
+    disk on every pass (asr/datasets.py:25-177 via emoasr_amd.datasets.ASRDataset)"""
+
+    def __init__(self, ds):
+        self.ds = ds
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __iter__(self):
+        for i in range(len(self.ds)):
+            yield self.ds.collate_fn([self.ds[i]])
+
+
+def rtf_fixture(tmpdir, n_utts, seed, feat_dim=80):
+    """n_utts synthetic LibriSpeech-length utterances as .npy files + manifest + vocabulary -> (loader, vocab, ylens)"""
     from emoasr_amd.data import libri_shaped_lengths
-    xlens, _ = libri_shaped_lengths(2000, 0)
-    rs = np.random.RandomState(1)
+    from emoasr_amd.datasets import ASRDataset, Vocab
+    xlens, ylens = libri_shaped_lengths(2000, 0)
+    rs = np.random.RandomState(seed)
     pick = rs.choice(len(xlens), n_utts, replace=False)
-    utts = [torch.randn(1, int(xlens[i]), 80).to(dev) for i in pick]
-    lens = [[int(xlens[i])] for i in pick]
+    os.makedirs(tmpdir, exist_ok=True)
+    lines = ["feat_path\tutt_id\ttoken_id\ttext\txlen\tylen"]
+    for k, i in enumerate(pick):
+        fp = os.path.join(tmpdir, f"utt{k}.npy")
+        np.save(fp, rs.randn(int(xlens[i]), feat_dim).astype(np.float32))
+        lines.append(f"{fp}\tutt{k}\t3 4 5\tref\t{int(xlens[i])}\t{int(ylens[i])}")
+    tsv = os.path.join(tmpdir, "test.tsv")
+    with open(tsv, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    vp = os.path.join(tmpdir, "vocab.txt")
+    with open(vp, "w") as f:
+        f.write("<blank> 0\n<unk> 1\n<eos> 2\n" + "".join(f"\u2581w{i} {i}\n" for i in range(3, 10000)))
+    ds = ASRDataset(SimpleNamespace(feat_dim=feat_dim, eos_id=2), tsv, phase="test")
+    return _NpyLoader(ds), Vocab(vp), [int(ylens[i]) for i in pick]
+
+
+def decode_rtf(model, dev, tmpdir):
+    """greedy CTC decode with the reference's RTF protocol (asr/test_asr.py:226-263 = emoasr_amd.decode.measure_rtf): 20
+    utterances, batch 1, feature files read from disk inside the timed region, mean of 5 repeats"""
+    from emoasr_amd import decode as dec
+    loader, vocab, _ = rtf_fixture(os.path.join(tmpdir, "greedy"), 20, 1)
     model.eval()
-    for x, l in zip(utts[:3], lens[:3]):
-        model.decode(x, l)
-    torch.cuda.synchronize()
-    audio = sum(l[0] for l in lens) * 0.010
-    best = 1e9
-    for _ in range(repeats):
-        t0 = time.perf_counter()
-        for x, l in zip(utts, lens):
-            model.decode(x, l)
-        torch.cuda.synchronize()
-        best = min(best, (time.perf_counter() - t0) / audio)
+    dec.test(model, loader, vocab, 1, 0.0, 0.0, False, None, 0.0, dev, num_samples=3)  # warm-up
+    _, rtf = dec.measure_rtf(model, loader, vocab, 1, 0.0, 0.0, False, None, 0.0, dev, num_samples=20, num_repeats=5)
     model.train()
-    return best
+    return rtf
 
 
 def logmel_rate(dev, batch_xlens, repeats=3):
@@ -315,37 +358,85 @@ LM12 = dict(lm_type="transformer", vocab_size=10000, hidden_size=256, num_layers
             intermediate_size=1024, max_seq_len=256)
 
 
-def decode_rtf_l33(dev, dtype, n_utts=5):
-    """config 4 (`L3-3`): joint CTC+attention beam 10 with Transformer-LM shallow fusion, batch 1.
-    Random-init weights never emit <eos>, so every utterance is decoded for exactly
-    ylen+1 = round(xlen/30)+1 output steps with a full beam (max_decode_ylen is set per utterance):
-    the per-step work of a real decode of that length, without early termination."""
-    import math
-    from emoasr_amd.data import libri_shaped_lengths
+def decode_rtf_l33(dev, dtype, tmpdir, n_utts=20, repeats=5, out_steps=36):  # noqa: C901
+    """config 4 (`L3-3`): joint CTC+attention beam 10 with Transformer-LM shallow fusion, batch 1, the reference's RTF
+    protocol (20 utterances x 5 repeats, feature files read inside the timed region; emoasr_amd.decode.measure_rtf).
+    Random-init weights never emit <eos>, so every utterance is decoded for exactly `out_steps` output steps with a full
+    beam (36 = mean of round(xlen / 30) + 1 over the set): the per-step work of a real decode, without early termination."""
+    import logging
+    from emoasr_amd import decode as dec
     from emoasr_amd.modeling.asr import ASR
     from emoasr_amd.modeling.lm import LM
+    logging.disable(logging.WARNING)  # ("cannot decode": no hypothesis ever ends with <eos> here, by construction)
     torch.manual_seed(1)
     model = ASR(SimpleNamespace(**L3), compute_dtype=dtype).to(dev).eval()
     lm = LM(SimpleNamespace(**LM12), compute_dtype=dtype).to(dev).eval()
-    xlens, _ = libri_shaped_lengths(2000, 0)
-    rs = np.random.RandomState(2)
-    pick = rs.choice(len(xlens), n_utts, replace=False)
-    utts = [(torch.randn(1, int(xlens[i]), 80).to(dev), [int(xlens[i])]) for i in pick]
-    kw = dict(beam_width=10, len_weight=0.0, lm=lm, lm_weight=0.3, decode_ctc_weight=0.3)
+    loader, vocab, _ = rtf_fixture(os.path.join(tmpdir, "l33"), n_utts, 2)
     model.decoder.max_decode_ylen = 8
-    model.decode(*utts[0], **kw)
+    dec.test(model, loader, vocab, 10, 0.0, 0.3, False, lm, 0.3, dev, num_samples=2)  # warm-up
+    model.decoder.max_decode_ylen = out_steps
+    runtime, rtf = dec.measure_rtf(model, loader, vocab, 10, 0.0, 0.3, False, lm, 0.3, dev, num_samples=n_utts,
+                                   num_repeats=repeats)
+    logging.disable(logging.NOTSET)
+    return dict(rtf=rtf, out_steps=out_steps, ms_per_step=1e3 * runtime / out_steps, utts=n_utts, repeats=repeats, beam=10,
+                lm_weight=0.3, decode_ctc_weight=0.3, forced_steps=True)
+
+
+def parity_mode(dev, batches, steps=4, warmup=2):
+    """the f32 (parity) mode on the same workload: training frames/s with exact-f32 MFMA, and the measured distance of the
+    bf16 engine from it on one full-size batch (same weights, dropout 0): relative loss error, max logits error over the
+    logits' range, greedy token agreement.  The f32 engine is what tests/ hold to the oracle at 1e-3 / bit-exact ids."""
+    from emoasr_amd.modeling.asr import ASR
+    from emoasr_amd.train import ArenaAdam, noam_lr
+    torch.manual_seed(0)
+    m32 = ASR(SimpleNamespace(**L2), compute_dtype=torch.float32).to(dev).train()
+    opt = ArenaAdam(m32.engine().arena, lambda s: noam_lr(OPT["lr"], L2["enc_hidden_size"], OPT["warmup"], s),
+                    weight_decay=OPT["weight_decay"], clip_grad_norm=OPT["clip_grad_norm"])
+
+    def step(bt):
+        loss, _ = m32(bt.xs, bt.xlens, bt.ys, bt.ylens, None, None)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    for bt in batches[:warmup]:
+        step(bt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps = []
-    for x, l in utts:
-        model.decoder.max_decode_ylen = max(1, round(l[0] / 30.0)) + 1
-        steps.append(model.decoder.max_decode_ylen)
-        model.decode(x, l, **kw)
+    for bt in batches[warmup:warmup + steps]:
+        step(bt)
     torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    audio = sum(l[0] for _, l in utts) * 0.010
-    return dict(rtf=wall / audio, mean_out_steps=float(np.mean(steps)), ms_per_step=1e3 * wall / sum(steps), utts=n_utts,
-                beam=10, lm_weight=0.3, decode_ctc_weight=0.3, forced_steps=True)
+    el = time.perf_counter() - t0
+    out = {"f32_frames_per_s": sum(sum(b.xlens) for b in batches[warmup:warmup + steps]) / el, "f32_ms_per_step": 1e3 * el / steps}
+    # bf16 vs f32 on identical weights and inputs, no dropout
+    cfg0 = dict(L2, dropout_enc_rate=0.0, dropout_attn_rate=0.0)
+    torch.manual_seed(0)
+    a32 = ASR(SimpleNamespace(**cfg0), compute_dtype=torch.float32)
+    sd = {k: v.clone() for k, v in a32.state_dict().items()}
+    a16 = ASR(SimpleNamespace(**cfg0), compute_dtype=torch.bfloat16)
+    a16.load_state_dict(sd)
+    a32, a16 = a32.to(dev).eval(), a16.to(dev).eval()
+    bt = batches[0]
+    res = []
+    with torch.no_grad():
+        for m in (a32, a16):
+            eouts, elens, _ = m.encoder(bt.xs, bt.xlens)
+            logits = m.decoder(eouts, elens).float()
+            loss, _ = m(bt.xs, bt.xlens, bt.ys, bt.ylens, None, None)
+            hyps = m.decode(bt.xs, bt.xlens)[0]
+            res.append((float(loss), logits, hyps, [int(e) for e in elens]))
+    (l32, z32, h32, el32), (l16, z16, h16, _) = res
+    mask = torch.zeros(z32.shape[:2], dtype=torch.bool, device=dev)
+    for b, e in enumerate(el32):
+        mask[b, :e] = True
+    a1 = z32.argmax(-1)[mask]
+    a2 = z16.argmax(-1)[mask]
+    out["bf16_vs_f32"] = {"loss_rel": abs(l16 - l32) / abs(l32),
+                          "logits_rel": float((z16 - z32)[mask].abs().max() / (z32[mask].max() - z32[mask].min())),
+                          "greedy_frame_agreement": float((a1 == a2).float().mean()),
+                          "greedy_hyp_exact": float(np.mean([x == y for x, y in zip(h32, h16)])),
+                          "batch": f"B={len(bt.xlens)}, {sum(bt.xlens)} frames, random-init weights, dropout 0"}
+    return out
 
 
 def main():
@@ -425,7 +516,7 @@ def main():
     # warm-up; the last warm-up step is instrumented per entry point to find the dominant kernel family
     breakdown = None
     for i in range(args.warmup):
-        if i == args.warmup - 1:
+        if i == args.warmup - 1 and args.breakdown:
             with CallTimer(emo_lib) as ct:
                 ct.attn_pairs = attn_pairs(batches[i])
                 step(batches[i])
@@ -434,19 +525,26 @@ def main():
             step(batches[i])
     # the roofline object is about ONE kernel family: composite entry points (a whole layer's ~24 kernels behind
     # one C-ABI call) are not candidates
-    composite = {"emoasr_conformer_layer_fwd"}
-    cand = [k for k in (breakdown or {}) if k not in composite]
-    dominant = max(cand, key=lambda k: breakdown[k]["ms"]) if cand else "emoasr_gemm_nn"
+    # the roofline object is about ONE kernel: the single-pass attention backward (the largest single kernel of the step,
+    # profiles/r02_*_kernel_stats.csv).  It runs behind the composite layer call, so it is timed inside the library with HIP
+    # events on its launch stream (emoasr_timer_read) over exactly the timed region.
+    dominant = "attn_bwd_fused_kernel"
     sync()
     frames = sum(sum(b.xlens) for b in batches[args.warmup:])
-    with CallTimer(emo_lib, names={dominant}) as ct:
-        t0 = time.perf_counter()
-        for bt in batches[args.warmup:]:
-            ct.attn_pairs = attn_pairs(bt)
-            loss = step(bt)
-        sync()
-        elapsed = time.perf_counter() - t0
-    dom = ct.summary().get(dominant, dict(calls=0, ms=0.0, flops=0.0))
+    emo_lib.set_option("timers", 1)
+    emo_lib.timer_read(dominant)
+    t0 = time.perf_counter()
+    pairs = 0.0
+    for bt in batches[args.warmup:]:
+        pairs += attn_pairs(bt)
+        loss = step(bt)
+    sync()
+    elapsed = time.perf_counter() - t0
+    emo_lib.set_option("timers", 0)
+    dcalls, dms = emo_lib.timer_read(dominant)
+    # algorithmic work of the kernel: seven 2*DK-flop products per valid (query, key, head) pair -- Q K^T, Q pos^T, dO V^T,
+    # dV, dK, dQ from K, dQ from pos (the dpos product lives in attn_bwd_dpos2_kernel)
+    dom = dict(calls=dcalls, ms=dms, flops=7 * 2.0 * 64 * L2["enc_num_attention_heads"] * pairs * L2["enc_num_layers"])
     tt = torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64)
     if world > 1:
         tmax = tt.clone()
@@ -473,9 +571,10 @@ def main():
         if dom["calls"] and dom["flops"]:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             res["roofline"] = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[args.dtype],
-                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": pmc_traffic(dominant),
+                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype],
+                               "traffic": pmc_kernel(dominant, "traffic_bytes"), "mfma_util": pmc_kernel(dominant, "mfma_util"),
                                "launches": dom["calls"], "avg_us": 1e3 * dom["ms"] / dom["calls"],
-                               "share_of_step": dom["ms"] * 1e-3 / elapsed}
+                               "flop_per_launch": dom["flops"] / dom["calls"], "share_of_step": dom["ms"] * 1e-3 / elapsed}
         else:
             res["roofline"] = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": None, "traffic": None, "launches": dom["calls"],
@@ -488,12 +587,37 @@ def main():
                       file=sys.stderr)
             print(f"  total instrumented GPU time {tot:.2f} ms (one step, B={len(batches[args.warmup - 1].xlens)})", file=sys.stderr)
         if world == 1 and not args.no_decode:
-            res["decode_rtf"] = decode_rtf(model, dev)
-            res["decode_rtf_batch32"] = decode_rtf_batched(model, dev)
+            import tempfile
+            with tempfile.TemporaryDirectory() as tmpdir:
+                res["decode_rtf"] = decode_rtf(model, dev, tmpdir)
+                res["decode_rtf_batch32"] = decode_rtf_batched(model, dev)
+                res["decode_l33"] = decode_rtf_l33(dev, dtype, tmpdir)
+            # log-mel in the loop: the same steps starting from raw 16 kHz audio (fbank kernel -> SpecAugment -> model)
+            from emoasr_amd.features import LogMel
             fb = logmel_rate(dev, batches[-1].xlens)
-            res["logmel"] = {"frames_per_s": fb, "train_frames_per_s_with_logmel": 1.0 / (1.0 / value + 1.0 / fb)}
-            res["decode_l33"] = decode_rtf_l33(dev, dtype)
+            lmel = LogMel(dev)
+            g = torch.Generator().manual_seed(9)
+            sub = batches[args.warmup:args.warmup + 6]
+            wavs = [[(0.05 * torch.randn(160 * (t - 1) + 400, generator=g)).to(dev) for t in bt.xlens] for bt in sub]
+
+            def wav_step(bt, ws_):
+                xs = torch.zeros_like(bt.xs)
+                for b, w in enumerate(ws_):
+                    f = lmel(w)
+                    xs[b, : f.shape[0]] = f[: xs.shape[1]]
+                return step(SimpleNamespace(xs=xs, xlens=bt.xlens, ys=bt.ys, ylens=bt.ylens))
+
+            wav_step(sub[0], wavs[0])
+            sync()
+            t0 = time.perf_counter()
+            for bt, ws_ in zip(sub[1:], wavs[1:]):
+                wav_step(bt, ws_)
+            sync()
+            res["logmel"] = {"frames_per_s": fb, "train_frames_per_s_with_logmel":
+                             sum(sum(b.xlens) for b in sub[1:]) / (time.perf_counter() - t0), "steps": len(sub) - 1}
             res["l4_rnnt"] = l4_rnnt(dev, dtype)
+            if args.dtype == "bf16":
+                res.update(parity_mode(dev, batches))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(res), flush=True)

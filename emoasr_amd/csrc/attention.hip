@@ -1533,19 +1533,18 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
 template <typename T, bool TR>
 __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t a, const FusedWs ws, const int bchunk) {
   using M_ = Mma<T>;
+  constexpr int RT = 2;  // 32-row table tiles per block: the staged (Q+v) tile is multiplied into both
   constexpr int LD = AttnCfg<T>::LD, VEC = 16 / sizeof(T), PER_ROW = DK / VEC, QR = 32 * PER_ROW / 64;
-  constexpr int QS_BYTES = 32 * LD * (int)sizeof(T);
-  __shared__ __attribute__((aligned(16))) char smem[(4 * QS_BYTES > 4 * 2 * 16 * 64 * 4) ? 4 * QS_BYTES : 4 * 2 * 16 * 64 * 4];
+  constexpr int QS_BYTES = 32 * LD * (int)sizeof(T), RED_BYTES = 4 * RT * 2 * 16 * 64 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[(4 * QS_BYTES > RED_BYTES) ? 4 * QS_BYTES : RED_BYTES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, hh = lane >> 5;
-  const int r0 = blockIdx.x * 32, h = blockIdx.y;
+  const int r0 = blockIdx.x * (32 * RT), h = blockIdx.y;
   const int b_lo = blockIdx.z * bchunk, b_hi = min(a.B, b_lo + bchunk);
   const int nit = (a.Tq + 31) / 32;
-  const int r = r0 + il;
-  const bool rok = r < 2 * a.Tq - 1;
   T* qs = reinterpret_cast<T*>(smem + wave * QS_BYTES);
-  f32x16 acc[2];
-  zero16(acc[0]); zero16(acc[1]);
-
+  f32x16 acc[RT][2];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) { zero16(acc[t][0]); zero16(acc[t][1]); }
   int item = wave;
   for (int b = b_lo; b < b_hi; ++b) {
     const int klen = a.klens ? min(a.klens[b], a.Tk) : a.Tk;
@@ -1553,27 +1552,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t
     const __amdgpu_buffer_rsrc_t rsQ = make_rsrc((const T*)ws.qv + (long)b * a.Tq * ws.ldqu + (long)h * DK);
     for (; item < nit; item += 4) {
       const int i0 = item * 32;
-      const int jmin = i0 - (a.Tq - 1) + r0;
-      if (jmin + 62 < 0 || jmin >= klen) continue;
+      const int jmin = i0 - (a.Tq - 1) + r0;  // keys of the block's band: jmin .. jmin + 32 RT + 30
+      if (jmin + 32 * RT + 30 < 0 || jmin >= klen) continue;
       Vec16<T> xq[QR];
 #pragma unroll
       for (int k = 0; k < QR; ++k) {
         const int p = lane + 64 * k, row = p / PER_ROW, piece = (p % PER_ROW) * VEC;
         xq[k] = buf_load16<T>(rsQ, i0 + row < a.Tq ? (unsigned)(((i0 + row) * (int)ws.ldqu + piece) * (int)sizeof(T)) : EMO_OOB);
       }
-      typename M_::Frag fa[2];
       // element (i, r) of the band sits at dS[i][j = i - (Tq-1) + r]: element offset i * (ldds + 1) + r - (Tq-1)
-      const int base = (i0 + 8 * hh) * ((int)ws.ldds + 1) + r - (a.Tq - 1);
+      typename M_::Frag fa[RT][2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int t = 0; t < RT; ++t) {
+        const int r = r0 + 32 * t + il;
+        const int base = (i0 + 8 * hh) * ((int)ws.ldds + 1) + r - (a.Tq - 1);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int i = i0 + 16 * ks + 8 * hh + e;
-          const int j = i - (a.Tq - 1) + r;
-          const bool ok = rok && i < a.Tq && j >= 0 && j < klen;
-          const float v = buf_load_f32<T>(rsS, ok ? (unsigned)((base + (16 * ks + e) * ((int)ws.ldds + 1)) * (int)sizeof(T)) : EMO_OOB);
-          if constexpr (sizeof(T) == 2) fa[ks][e] = (bf16)v;
-        }
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int i = i0 + 16 * ks + 8 * hh + e;
+            const int j = i - (a.Tq - 1) + r;
+            const bool ok = r < 2 * a.Tq - 1 && i < a.Tq && j >= 0 && j < klen;
+            const float v = buf_load_f32<T>(rsS, ok ? (unsigned)((base + (16 * ks + e) * ((int)ws.ldds + 1)) * (int)sizeof(T)) : EMO_OOB);
+            if constexpr (sizeof(T) == 2) fa[t][ks][e] = (bf16)v;
+          }
+      }
 #pragma unroll
       for (int k = 0; k < QR; ++k) {
         const int p = lane + 64 * k;
@@ -1583,8 +1586,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          acc[dt] = M_::mma(fa[ks], M_::template load_km<TR>(qs, LD, 16 * ks, 32 * dt, lane), acc[dt]);
+        for (int dt = 0; dt < 2; ++dt) {
+          const typename M_::Frag fb = M_::template load_km<TR>(qs, LD, 16 * ks, 32 * dt, lane);
+#pragma unroll
+          for (int t = 0; t < RT; ++t) acc[t][dt] = M_::mma(fa[t][ks], fb, acc[t][dt]);
+        }
       __builtin_amdgcn_wave_barrier();
     }
     item -= nit;
@@ -1592,18 +1598,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int rg = 0; rg < 16; ++rg) red[((wave * 2 + dt) * 16 + rg) * 64 + lane] = acc[dt][rg];
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) red[(((wave * RT + t) * 2 + dt) * 16 + rg) * 64 + lane] = acc[t][dt][rg];
   __syncthreads();
-  // thread -> (dt, reg, lane) of the summed tile: 2048 values, 8 per thread
+  // thread -> (tile, dt, reg, lane) of the summed tiles: RT * 2048 values, RT * 8 per thread
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int idx = threadIdx.x + 256 * k, ln = idx & 63, rg = (idx >> 6) & 15, dt = idx >> 10;
+  for (int k = 0; k < RT * 8; ++k) {
+    const int idx = threadIdx.x + 256 * k, ln = idx & 63, rg = (idx >> 6) & 15, dt = (idx >> 10) & 1, t = idx >> 11;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += red[((w * 2 + dt) * 16 + rg) * 64 + ln];
-    const int row = r0 + c_row(rg, ln);
+    for (int w = 0; w < 4; ++w) v += red[(((w * RT + t) * 2 + dt) * 16 + rg) * 64 + ln];
+    const int row = r0 + 32 * t + c_row(rg, ln);
     if (row < 2 * a.Tq - 1) atomicAdd(&a.dpos[(long)row * (a.H * DK) + h * DK + 32 * dt + (ln & 31)], v);
   }
 }
@@ -1679,6 +1687,7 @@ int launch_fwd(const emoasr_attn_t& a, hipStream_t s) {
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
   }
   const bool one_round = (long)grid.x * grid.y * grid.z <= n_cu;  // at most one block per CU: see attn_fwd_kernel
+  emo_timer_begin(EMO_TIMER_ATTN_FWD, s);
   if (g_tr) {
     if (one_round) {
       if (set_smem(attn_fwd_kernel<T, true, true>, smem)) return 1;
@@ -1696,6 +1705,7 @@ int launch_fwd(const emoasr_attn_t& a, hipStream_t s) {
       attn_fwd_kernel<T, false, false><<<grid, 256, smem, s>>>(a);
     }
   }
+  emo_timer_end(EMO_TIMER_ATTN_FWD, s);
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -1841,16 +1851,21 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
     else      { if (set_smem(attn_bwd_fused_kernel<T, false, REL_, FW_>, smem)) return 1;          \
                 attn_bwd_fused_kernel<T, false, REL_, FW_><<<grid, 64 * FW_, smem, s>>>(a, ws); }  \
   } while (0)
+  emo_timer_begin(EMO_TIMER_ATTN_BWD_MAIN, s);
   if (rel) {
     if (fw == 2) EMO_FUSED_LAUNCH(true, 2); else EMO_FUSED_LAUNCH(true, 4);
+    emo_timer_end(EMO_TIMER_ATTN_BWD_MAIN, s);
     if (a.dpos) {
-      const int nchunk = a.B < 4 ? a.B : 4;
-      dim3 g2(cdiv(2 * a.Tq - 1, 32), a.H, nchunk);
+      const int nchunk = a.B < 8 ? a.B : 8;
+      dim3 g2(cdiv(2 * a.Tq - 1, 64), a.H, nchunk);
+      emo_timer_begin(EMO_TIMER_ATTN_BWD_DPOS, s);
       if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk));
       else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk));
+      emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, s);
     }
   } else {
     if (fw == 2) EMO_FUSED_LAUNCH(false, 2); else EMO_FUSED_LAUNCH(false, 4);
+    emo_timer_end(EMO_TIMER_ATTN_BWD_MAIN, s);
   }
 #undef EMO_FUSED_LAUNCH
   attn_bwd_fin_kernel<T><<<cdiv((long)a.B * a.Tq, 16), 256, 0, s>>>((long)a.B * a.Tq, a.H * DK, ws.dq32, ws.dq_slab, 32 * fw, a.Tq,

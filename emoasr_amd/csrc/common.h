@@ -343,6 +343,12 @@ void emo_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// HIP-event timers around selected kernels (api.hip; read with emoasr_timer_read, enabled by option "timers")
+enum { EMO_TIMER_ATTN_BWD_MAIN = 0, EMO_TIMER_ATTN_BWD_DPOS = 1, EMO_TIMER_ATTN_FWD = 2, EMO_TIMER_TN_GROUPED = 3,
+       EMO_TIMER_COUNT = 4 };
+void emo_timer_begin(int id, hipStream_t s);
+void emo_timer_end(int id, hipStream_t s);
+
 enum { EMO_F32 = 0, EMO_BF16 = 1 };
 #define EMO_DISPATCH(dtype, ...)                                        \
   do {                                                                  \

@@ -781,6 +781,7 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   }
   G.start[n] = start;
   hipStream_t s = (hipStream_t)stream;
+  emo_timer_begin(EMO_TIMER_TN_GROUPED, s);
   if (dtype == EMO_BF16) {
     if (bt == 128) {
       if (g_tr_read) gemm_tn_grouped_kernel<bf16, true, 2, 128><<<start, 256, 0, s>>>(G);
@@ -796,6 +797,7 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
     emo_set_error("bad dtype %d", dtype);
     return 1;
   }
+  emo_timer_end(EMO_TIMER_TN_GROUPED, s);
   EMO_LAUNCH_CHECK();
   return 0;
 }

@@ -79,14 +79,19 @@ def measure_rtf(model, dataloader, vocab, beam_width, len_weight, decode_ctc_wei
                 eos_id=2, num_samples=20, num_repeats=5, wavtime_factor=1000.0, frame_seconds=0.010):
     """test_asr.py:226-263 -> (mean runtime per utterance [s], mean RTF).  The device is synchronised before
     each clock read, so asynchronous launches are inside the measured time."""
-    data_list = list(dataloader)
-    frames = {d["utt_ids"][0]: int(d["xlens"][0]) for d in data_list}
+    frames = {}
+
+    def recording(loader):  # the loader is walked INSIDE the timed region, feature loading included (test_asr.py:231-240)
+        for d in loader:
+            frames[d["utt_ids"][0]] = int(d["xlens"][0])
+            yield d
+
     runtimes, rtfs = [], []
     for j in range(num_repeats):
         torch.cuda.synchronize()
         t0 = time.time()
-        rows = test(model, data_list, vocab, beam_width, len_weight, decode_ctc_weight, decode_phone, lm, lm_weight, device,
-                    eos_id=eos_id, num_samples=num_samples)
+        rows = test(model, recording(dataloader), vocab, beam_width, len_weight, decode_ctc_weight, decode_phone, lm, lm_weight,
+                    device, eos_id=eos_id, num_samples=num_samples)
         torch.cuda.synchronize()
         runtime = time.time() - t0
         wavtime = 0.0

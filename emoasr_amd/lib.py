@@ -260,6 +260,17 @@ def size_query(name, *ints):
     return int(fn(*[int(v) for v in ints]))
 
 
+def timer_read(name, reset=True):
+    """(launches, summed ms) of a kernel timed inside the library (emoasr_timer_read; option "timers" enables recording)"""
+    lib = load()
+    calls, ms = c_int(0), ctypes.c_double(0.0)
+    lib.emoasr_timer_read.argtypes = [c_char_p, POINTER(c_int), POINTER(ctypes.c_double), c_int]
+    lib.emoasr_timer_read.restype = c_int
+    if lib.emoasr_timer_read(name.encode(), ctypes.byref(calls), ctypes.byref(ms), int(reset)) != 0:
+        raise EmoasrHipError(lib.emoasr_last_error().decode())
+    return calls.value, ms.value
+
+
 def set_option(name, value):
     lib = load()
     if lib.emoasr_set_option(name.encode(), int(value)) != 0:

@@ -31,8 +31,15 @@ enum { EMOASR_ACT_NONE = 0, EMOASR_ACT_RELU = 1, EMOASR_ACT_SWISH = 2 };
 
 const char* emoasr_last_error(void);
 int emoasr_version(void);
-/* options: "tr_read" (1 = ds_read_b64_tr_b16 operand reads, 0 = scalar fallback) */
+/* options: "tr_read" (1 = ds_read_b64_tr_b16 operand reads, 0 = scalar fallback); tuning: "gemm_tile", "gemm_kb",
+ * "gemm_xcd", "tn_group_blocks", "attn_fw" (key tiles per workgroup of the single-pass attention backward: 2, 4, 0 = auto);
+ * "timers" (see emoasr_timer_read) */
 int emoasr_set_option(const char* name, int value);
+/* Device time of selected kernels that sit behind composite entry points, measured with HIP events on the launch stream
+ * while emoasr_set_option("timers", 1) is in effect.  name: "attn_bwd_fused_kernel", "attn_bwd_dpos2_kernel",
+ * "attn_fwd_kernel", "gemm_tn_grouped_kernel".  -> number of launches recorded and their summed milliseconds
+ * (synchronises on the recorded events); reset != 0 clears the record.  bench.py's roofline object reads this. */
+int emoasr_timer_read(const char* name, int* calls, double* ms, int reset);
 
 /* GEMM epilogue, applied in this order to v = alpha*acc + bias[col]:
  *   pre_out[row,col] = v            (if pre_out)

@@ -663,10 +663,14 @@ def run_train_trace():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ctc", "l3", "l4"]
+    which = sys.argv[1:] or ["ctc", "ctcabs", "l3", "l4"]
     if "ctc" in which:
         for name, cfg in CONFIGS.items():
             run_ctc(name, cfg)
+    if "ctcabs" in which:
+        # Conformer with ABSOLUTE positions: the layer runs convolution BEFORE self-attention and uses the plain
+        # MultiHeadedAttention (conformer.py:209-219), the encoder adds the absolute table (encoders/transformer.py:96-99)
+        run_ctc("l2abs_tiny", dict(CONFIGS["l2_tiny"], pos_encode_type="abs"))
     if "l3" in which:
         run_l3()
     if "l4" in which:

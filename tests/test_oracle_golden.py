@@ -11,7 +11,7 @@ def _rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
-@pytest.mark.parametrize("name", ["l2_tiny", "l1_tiny"])
+@pytest.mark.parametrize("name", ["l2_tiny", "l1_tiny", "l2abs_tiny"])
 def test_eval_forward_and_greedy(name):
     cfg, sd, g = load_golden(name)
     with torch.no_grad():
@@ -26,7 +26,7 @@ def test_eval_forward_and_greedy(name):
     assert sum(aligns, []) == g["eval/aligns"].tolist()
 
 
-@pytest.mark.parametrize("name", ["l2_tiny", "l1_tiny"])
+@pytest.mark.parametrize("name", ["l2_tiny", "l1_tiny", "l2abs_tiny"])
 def test_train_loss_and_grads(name):
     cfg, sd, g = load_golden(name)
     sd = {k: v.clone() for k, v in sd.items()}

@@ -14,6 +14,7 @@ COMMON = dict(input_layer="conv2d", feat_dim=40, num_framestacks=1, enc_hidden_s
 CONFIGS = {
     "l2_tiny": dict(COMMON, encoder_type="conformer", decoder_type="ctc", pos_encode_type="rel"),
     "l1_tiny": dict(COMMON, encoder_type="transformer", decoder_type="ctc"),
+    "l2abs_tiny": dict(COMMON, encoder_type="conformer", decoder_type="ctc", pos_encode_type="abs"),
 }
 
 
