@@ -128,3 +128,31 @@ def test_bucketed_overlap_allreduce_equals_one_allreduce(tmp_path):
     got = torch.load(out)
     assert got["same"] and got["done"] == 10_000
     assert got["n_async"] == 2  # [7000,10000) and [3000,7000): the 500/1000/100/1-element pieces were merged
+
+
+def _bf16_bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emoasr_amd.train import GradBuckets, allreduce_sum_
+    g = torch.Generator().manual_seed(200 + rank)
+    flat = torch.randn(6_000, generator=g)
+    ref = flat.clone()
+    allreduce_sum_(ref)
+    buckets = GradBuckets(flat, min_elems=1000, comm_dtype=torch.bfloat16)
+    for lo in (4_000, 1_500):
+        buckets.ready(lo)
+    buckets.finish()
+    if rank == 0:
+        torch.save({"err": float((flat - ref).abs().max()), "scale": float(ref.abs().max()), "dtype": str(flat.dtype)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bf16_gradient_buckets(tmp_path):
+    """comm_dtype=bf16: half the bytes on the wire, the f32 arena receives the widened sums (bf16 rounding of the operands
+    and of the sum: 2^-8 relative)"""
+    world, out = 2, str(tmp_path / "b16.pt")
+    mp.spawn(_bf16_bucket_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = torch.load(out)
+    assert got["dtype"] == "torch.float32" and got["err"] < 2e-2 * got["scale"]

@@ -12,7 +12,7 @@ for n1, n2 in shapes:
     a = torch.randn(M, n1, device=dev).to(dt); b = torch.randn(M, n2, device=dev).to(dt)
     probs.append((a, b, torch.zeros(n1, n2, device=dev), 1.0, torch.zeros(n1, device=dev), 1.0))
 fl = sum(2.0 * M * n1 * n2 for n1, n2 in shapes)
-for blocks in (256, 384, 512, 640, 768, 1024, 1536):
+for blocks in (96, 128, 192, 256, 384, 512, 768):
     lib.set_option("tn_group_blocks", blocks)
     for _ in range(5): ops.gemm_tn_grouped(probs)
     torch.cuda.synchronize()
