@@ -21,6 +21,7 @@ void emo_gemm_set_kb(int v);
 void emo_gemm_set_xcd(int v);
 void emo_attn_set_tr_read(int v);
 void emo_attn_set_fw(int v);
+void emo_layer_set_ffn_fused(int v);
 
 // ---- kernel timers: HIP-event pairs around selected launches, on the stream they are launched on -----------------------
 // (bench.py's roofline object needs the live device time of ONE kernel that sits behind a composite entry point;
@@ -80,6 +81,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "gemm_xcd") == 0) { emo_gemm_set_xcd(value); return 0; }
   if (strcmp(name, "attn_fw") == 0) { emo_attn_set_fw(value); return 0; }
   if (strcmp(name, "timers") == 0) { g_timers_on = value; return 0; }
+  if (strcmp(name, "ffn_fused") == 0) { emo_layer_set_ffn_fused(value); return 0; }
   emo_set_error("unknown option '%s'", name);
   return 1;
 }

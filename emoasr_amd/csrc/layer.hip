@@ -17,8 +17,14 @@ emoasr_epilogue_t plain_ep() {
 }
 
 // x + res_scale * drop(W2 act(W1 LN(x) + b1) + b2)
+int g_ffn_fused = 0;  // bf16, d = 256: the feed-forward block as ONE launch (csrc/ffn.hip) -- measured slower than LayerNorm +
+                      // two GEMMs at the L2 batch size (87 vs 40 us, see ffn.hip), so off unless emoasr_set_option("ffn_fused", 1)
+
 int ffn_fwd(int dtype, int M, int d, int F, const emoasr_ffn_params_t& p, const void* x, float res_scale,
             float p_enc, uint64_t s_in, uint64_t s_out, const emoasr_ffn_stash_t& st, void* stream) {
+  if (g_ffn_fused && dtype == EMO_BF16 && d == 256 && F % 256 == 0)
+    return emoasr_ffn_fwd(dtype, M, d, F, x, p.ln_g, p.ln_b, 1e-5f, p.w1, p.b1, p.w2, p.b2, EMOASR_ACT_SWISH, res_scale, p_enc,
+                          s_in, s_out, st.h, st.mean, st.rstd, st.u, st.a, st.y, stream);
   if (emoasr_layernorm_fwd(dtype, M, d, x, p.ln_g, p.ln_b, 1e-5f, st.h, st.mean, st.rstd, stream)) return 1;
   emoasr_epilogue_t e1 = plain_ep();
   e1.bias = p.b1; e1.act = EMOASR_ACT_SWISH; e1.pre_out = st.u; e1.drop_p = p_enc; e1.seed = s_in;
@@ -29,6 +35,8 @@ int ffn_fwd(int dtype, int M, int d, int F, const emoasr_ffn_params_t& p, const 
 }
 
 }  // namespace
+
+void emo_layer_set_ffn_fused(int v) { g_ffn_fused = v; }
 
 extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* L,
                                           const emoasr_conformer_fwd_t* io, void* stream) {

@@ -146,6 +146,7 @@ SIGNATURES = {
     "emoasr_layernorm_bwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     "emoasr_layernorm_bwd_ex": [I, I, I, P, P, P, P, P, P, P, P, P, P, POINTER(LnBwdOpts), P],
     "emoasr_layernorm_bwd_finalize": [I, POINTER(LnFinalizeItem), P],
+    "emoasr_ffn_fwd": [I, I, I, I, P, P, P, F, P, P, P, P, I, F, F, U64, U64, P, P, P, P, P, P, P],
     "emoasr_conformer_layer_fwd": [I, POINTER(ConformerLayer), POINTER(ConformerFwd), P],
     "emoasr_conformer_layer_bwd": [I, POINTER(ConformerLayer), POINTER(ConformerLayer), POINTER(ConformerFwd),
                                    POINTER(ConformerBwd), P],
