@@ -2,7 +2,8 @@
 
 1. Against the oracle directly: a three-utterance batch is small enough for the CPU restatement to finish in
    seconds at the FULL model size -- loss, logits, greedy ids, gradients (f32: 1e-3 as north_star states,
-   greedy ids bit-exact; bf16: loss 2e-2).
+   greedy ids bit-exact; bf16: loss 2e-3, logits 3e-2 of range, gradient cosines 0.995, greedy agreement 0.9 -- the
+   measured values, printed by the test, are 2.0e-4 / 1.25e-2 / >= 0.999 / 0.957).
 2. Size-independent properties on a full bench-sized batch (about 27 k frames, bf16):
    CTC logit gradients sum to zero over the vocabulary on valid frames and vanish on padded ones;
    the backward pass is linear in the incoming loss gradient; eval-mode decoding of an equal-length batch
@@ -61,7 +62,8 @@ def test_full_model_against_oracle(dev, dtype):
     model.train()
     loss, ld = model(xs.to(dev), xlens, ys, ylens, None, None)
     loss.backward()
-    ltol = 1e-3 if dtype == torch.float32 else 2e-2
+    ltol = 1e-3 if dtype == torch.float32 else 2e-3  # bf16 measured 2.0e-4 (round 2)
+    print(f"[measured {dtype}] loss rel err {abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()):.2e}")
     assert abs(loss.item() - loss_ref.item()) < ltol * abs(loss_ref.item()), (loss.item(), loss_ref.item())
     grads = {n: p.grad.float().cpu() for n, p in model.named_parameters()}
     for name in ("decoder.output.weight", "encoder.norm.weight", "encoder.transformers.11.feed_forward.w2.weight",
@@ -69,7 +71,8 @@ def test_full_model_against_oracle(dev, dtype):
                  "encoder.transformers.3.self_attn.pos_bias_u", "encoder.conv.conv.2.weight", "encoder.conv.conv.0.weight"):
         a, b = grads[name].flatten(), params[name].grad.flatten()
         cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
-        assert cos > (0.9995 if dtype == torch.float32 else 0.97), (name, cos)
+        print(f"[measured {dtype}] grad cosine {name}: {cos:.5f}")
+        assert cos > (0.9995 if dtype == torch.float32 else 0.995), (name, cos)  # bf16 measured >= 0.9990
         if dtype == torch.float32:
             assert abs(a.norm().item() / b.norm().item() - 1) < 5e-3, name
     # ---- eval mode: logits + greedy ids (the reference's running statistics are untouched in `sd`)
@@ -85,12 +88,14 @@ def test_full_model_against_oracle(dev, dtype):
         logits = model.decoder(e2, el2)
     hyps, _, _, _ = model.decode(xs.to(dev), xlens)
     rel = ((logits.float().cpu() - logits_ref).abs().max() / logits_ref.abs().max()).item()
-    assert rel < (1e-3 if dtype == torch.float32 else 6e-2), rel
+    print(f"[measured {dtype}] logits rel err {rel:.2e}")
+    assert rel < (1e-3 if dtype == torch.float32 else 3e-2), rel  # bf16 measured 1.25e-2 of the logits' range
     if dtype == torch.float32:
         assert hyps == want
     else:
         agree = sum(int(a == b) for h, w in zip(hyps, want) for a, b in zip(h, w)) / max(1, sum(len(w) for w in want))
-        assert agree > 0.8, agree
+        print(f"[measured {dtype}] greedy agreement {agree:.4f}")
+        assert agree > 0.9, agree  # bf16 measured 0.957 (random-init weights: many near-ties)
 
 
 def _bench_batch(seed=3):
