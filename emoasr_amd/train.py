@@ -104,7 +104,8 @@ def _world(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
-def train_step(model, optimizer, data, params, device, no_grad=False, empty_cache=False, group=None, sync=True):
+def train_step(model, optimizer, data, params, device, no_grad=False, empty_cache=False, group=None, sync=True,
+               specaug=None):
     """One micro-batch of asr/train_asr.py:35-97: forward, loss / accum_grad, backward; unless `no_grad`
     (= still accumulating), clip to params.clip_grad_norm, skip the update on a NaN gradient norm, step,
     zero_grad.  -> loss_dict of floats divided by accum_grad (`sync=False`: 0-dim device tensors, no
@@ -114,12 +115,18 @@ def train_step(model, optimizer, data, params, device, no_grad=False, empty_cach
     (no host round trip, so the reference's "do not update because of nan grad_norm" warning is not
     logged); with any torch optimizer the reference's sequence runs literally.  One process per GPU: the
     gradient arena is summed over the ranks once per optimizer step and scaled by 1/world, which is
-    nn.DataParallel's mean of replica losses (train_asr.py:67-71)."""
+    nn.DataParallel's mean of replica losses (train_asr.py:67-71).
+
+    `specaug`: a data.SpecAugment; the batch is masked on the device before the forward (the reference masks each
+    utterance in its data loader, asr/datasets.py:94-95)."""
     import math
 
     from .optimizers import Adam as HipAdam
     to = lambda k: data[k].to(device) if k in data else None
-    loss, loss_dict = model(xs=to("xs"), xlens=data["xlens"], ys=data["ys"], ylens=data["ylens"], ys_in=data["ys_in"],
+    xs = to("xs")
+    if specaug is not None:
+        xs = specaug(xs.float(), data["xlens"])
+    loss, loss_dict = model(xs=xs, xlens=data["xlens"], ys=data["ys"], ylens=data["ylens"], ys_in=data["ys_in"],
                             ys_out=data["ys_out"], soft_labels=to("soft_labels"), ps=data.get("ps"),
                             plens=data.get("plens"))
     world = _world(group)
@@ -170,11 +177,15 @@ def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False
     log = log or logging.info
     optimizer.update_epoch()
     step, sums = 0, {}
+    specaug = None
+    if getattr(params, "spec_augment", False):  # asr/datasets.py:37-38
+        from .data import SpecAugment
+        specaug = SpecAugment(params)
     n_total = len(dataloader) // params.accum_grad if hasattr(dataloader, "__len__") else -1
     for accum_step, data in enumerate(dataloader):
         stepping = (accum_step + 1) % params.accum_grad == 0
         loss_dict = train_step(model, optimizer, data, params, device, no_grad=not stepping,
-                               empty_cache=empty_cache and stepping, group=group, sync=False)
+                               empty_cache=empty_cache and stepping, group=group, sync=False, specaug=specaug)
         step += int(stepping)
         for k, v in loss_dict.items():
             sums[k] = sums[k] + v if k in sums else v

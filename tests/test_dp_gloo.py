@@ -100,6 +100,43 @@ def test_sampler_rule_and_specaug_spans():
     assert (sp[:, 2:, 1] - sp[:, 2:, 0] < 40).all()
 
 
+def test_adaptive_specaug_follows_the_reference_draws():
+    """asr/spec_augment.py:63-95 with max_mask_time_ratio / num_masks_time_ratio, restated literally on a numpy array and
+    compared with the bands data.SpecAugment samples from identically seeded generators."""
+    import random
+    from types import SimpleNamespace
+
+    import numpy as np
+    from emoasr_amd.data import SpecAugment
+    P = SimpleNamespace(max_mask_freq=30, num_masks_freq=2, max_mask_time_ratio=0.05, num_masks_time_ratio=0.01,
+                        replace_with_zero=True)
+    xlens = [1234, 310, 777]
+    aug = SpecAugment(P, np_rng=np.random.RandomState(5), py_rng=random.Random(5))
+    sp = aug.spans(xlens, 80)
+    assert sp.shape == (3, 2 + 20, 2)
+    np_rng, py_rng = np.random.RandomState(5), random.Random(5)
+    for b, xlen in enumerate(xlens):
+        x = np.ones((xlen, 80), np.float32)
+        for f, w in np_rng.randint(0, 30, size=(2, 2)):
+            f0 = py_rng.randrange(0, 80 - f)
+            if f:
+                x[:, f0:f0 + w] = 0
+        mmt, nmt = min(20, round(xlen * 0.05)), min(20, round(xlen * 0.01))
+        assert nmt == [12, 3, 8][b] and mmt == [20, 16, 20][b]
+        for t, w in np_rng.randint(0, mmt, size=(nmt, 2)):
+            t0 = py_rng.randrange(0, xlen - t)
+            if t:
+                x[t0:t0 + w] = 0
+        got = np.ones((xlen, 80), np.float32)
+        for m, (lo, hi) in enumerate(sp[b]):
+            if m < 2:
+                got[:, lo:hi] = 0
+            else:
+                got[lo:hi] = 0
+        assert (got == x).all()
+        assert (sp[b, 2 + nmt:] == 0).all()
+
+
 def _bucket_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -639,6 +639,35 @@ def test_specaug_cmvn(dev):
     _close(ops.cmvn(x.clone(), mean, std), (x - mean) / std, 1e-6, "cmvn")
 
 
+@pytest.mark.parametrize("zero", [True, False], ids=["zero", "mean"])
+def test_adaptive_specaug_on_device(dev, zero):
+    """data.SpecAugment (adaptive variant: up to 20 time bands per utterance) on a padded batch == its bands applied with
+    numpy slicing, asr/spec_augment.py:39-95"""
+    import random
+    from types import SimpleNamespace
+
+    import numpy as np
+    from emoasr_amd.data import SpecAugment
+    P = SimpleNamespace(max_mask_freq=30, num_masks_freq=2, max_mask_time_ratio=0.05, num_masks_time_ratio=0.01,
+                        replace_with_zero=zero)
+    xlens = [900, 640, 333]
+    x = _rnd(dev, 3, 900, 80) + 0.3
+    for b, n in enumerate(xlens):
+        x[b, n:] = 0
+    bands = SpecAugment(P, np_rng=np.random.RandomState(7), py_rng=random.Random(7)).spans(xlens, 80)
+    got = SpecAugment(P, np_rng=np.random.RandomState(7), py_rng=random.Random(7))(x.clone(), xlens)
+    ref = x.clone()
+    for b, n in enumerate(xlens):
+        fill = 0.0 if zero else x[b, :n].mean().item()
+        for m, (lo, hi) in enumerate(bands[b]):
+            if m < 2:
+                ref[b, :n, lo:hi] = fill
+            else:
+                ref[b, lo:min(hi, n)] = fill
+    assert (bands[:, 2:, 1] > bands[:, 2:, 0]).sum() >= 12
+    _close(got, ref, 1e-6, "adaptive specaug")
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_gemm_tn_grouped(dev, dtype, tr_mode):
     """grouped weight-gradient launch == the same products one by one (f32 accumulate + colsum)"""
