@@ -665,6 +665,10 @@ int launch_tn(TnArgs a, hipStream_t s) {
 
 }  // namespace
 
+int emo_conv_big_enabled();
+int emo_conv2_fwd_big(int B, int T1, int F1, int C, const void* y1, const void* w, void* y2, const float* bias,
+                      int relu, hipStream_t s);
+
 void emo_gemm_set_tr_read(int v) { g_tr_read = v; }
 void emo_gemm_set_tile(int v) { g_gemm_tile = v; }
 void emo_gemm_set_tn_group_blocks(int v) { g_tn_group_blocks = v > 0 ? v : 0; }
@@ -809,6 +813,10 @@ extern "C" int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const v
   EMO_CHECK(T1 >= 3 && F1 >= 3, "conv2: input too small (T1=%d F1=%d)", T1, F1);
   const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
   EMO_CHECK(C % 32 == 0, "conv2: C must be a multiple of 32");
+  // bias (+ ReLU) only, bf16, C % 256 == 0: the large-tile kernel (gemm_big.hip)
+  if (dtype == EMO_BF16 && C % 256 == 0 && emo_conv_big_enabled() && ep->alpha == 1.f && !ep->residual && !ep->dact_pre &&
+      !ep->pre_out && ep->drop_p == 0.f && !ep->out_f32 && (ep->act == EMO_ACT_NONE || ep->act == EMO_ACT_RELU))
+    return emo_conv2_fwd_big(B, T1, F1, C, y1, w, y2, ep->bias, ep->act == EMO_ACT_RELU, (hipStream_t)stream);
   NtArgs a{};
   a.M = B * T2 * F2; a.N = C; a.K = 9 * C; a.A = y1; a.lda = 0; a.B = w; a.ldb = 9 * C; a.C = y2; a.ldc = C;
   a.ep = *ep;

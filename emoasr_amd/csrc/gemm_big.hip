@@ -1,0 +1,476 @@
+// Large-tile bf16 MFMA GEMM for the one compute-bound product family of the encoder: the Conv2d(256 -> 256, k3, s2)
+// of the subsampling front-end (asr/modeling/encoders/conv.py:9-19) -- forward, data gradient and weight gradient are
+// each ~157 GFLOP per 27 k-frame batch (M = B*T2*F2 ~ 133 k rows, K = 9*256, N = 256), 13 % of the step when run on
+// the 128x64-tile kernel of gemm.hip (LDS-read-bound at ~20 % of the MFMA peak).
+//
+//   big_nt : C[M,N] = epilogue(A[M,K] . B[N,K]^T), A plain / gathered through the conv geometry (forward) / gathered
+//            per output-parity class (data gradient; all four classes in one launch)
+//
+// Structure (one workgroup per CU):
+//   * 512 threads = 8 waves as 2 (M) x 4 (N); block tile BM x 256 with BM = 256 / 192 / 128 chosen by the host so that
+//     the tile count fills whole rounds of the 256 CUs; wave tile (BM/2) x 64 of 16x16x32 MFMAs (128 accumulator
+//     registers at BM = 256).  Per k-tile and wave: (BM/2 + 64) * 128 B of LDS reads for BM/2 * 64 * 64 * 2 flop.
+//   * k-tiles of 64; LDS rings of three A stages (BM x 128 B each) and two B stages (256 x 128 B): 160 KB at BM = 256,
+//     filled by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass): each wave-instruction
+//     lands 8 rows x 128 B.
+//     The image is lane-linear, so the bank swizzle is applied on the SOURCE side: the 16-byte chunk a lane fetches is
+//     chunk ^ ((row >> 1) & 7), and fragment reads (ds_read_b128, 16 rows x 16 B per 16-lane group) use the same XOR:
+//     conflict-free for the 16x16x32 operand shape.
+//   * one raw s_barrier per k-tile and a counted vmcnt wait (the newest A tile stays in flight across it); DMA pieces
+//     are issued between the MFMA groups of the running tile, fragment reads one 8-MFMA step ahead of their use.
+//   * measured at M = 130 663 (MI355X, HIP-graph timed): forward 141 us = 1.09 PFLOP/s (the 128x64 kernel: 290-317 us);
+//     timing ablations of that launch: MFMAs alone 91-95 us (1.65 PFLOP/s: the ceiling of 2 rounds of 256-row tiles at the
+//     sustained matrix clock), + fragment reads 104, + barrier 109-112, + DMA 141-146.
+//   * out-of-range rows / taps use the buffer descriptor's bounds check (offset 0xFFFFFFFF -> zeros land in LDS).
+//   * operands are multiplied as D^T = B . A^T, so a lane ends up with 4 CONSECUTIVE output columns of one row; the
+//     epilogue packs them to 8 bytes, transposes 16-row slabs through wave-private LDS and stores full 128-byte rows.
+#include <algorithm>
+#include "mma.h"
+#include "../../include/emoasr_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+struct BigConv {   // forward gather: see ConvGeom in gemm.hip
+  int T1, F1, T2, F2, C;
+};
+struct BigDgrad {  // data gradient, one entry per output-parity class (pt, pf)
+  int T1, F1, T2, F2, C;
+  int ncls;
+  int tile0[5];            // first tile of each class
+  int pt[4], pf[4], nI[4], nJ[4], ntap[4], M[4];
+  int dh[4][4], dw[4][4], wtap[4][4];
+};
+struct BigArgs {
+  int M, N, K;
+  const void* A; long lda;
+  const void* B; long ldb;
+  void* C; long ldc;
+  const float* bias;
+  int relu;
+  const void* dmask;  // data gradient only, optional: multiply by (dmask[same offset as C] > 0)  (ReLU backward)
+  int tiles_m, tiles_n;
+  int korder;  // gathered modes: 1 = channel chunk outermost, taps innermost; 0 = tap-major
+  BigConv cg;
+  BigDgrad dg;
+};
+
+__device__ __forceinline__ int xcd_remap_big(int pid, int nblk) {
+  const int per = nblk / 8, rem = nblk - per * 8;
+  const int x = pid % 8, slot = pid / 8;
+  return x * per + min(x, rem) + slot;
+}
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_ptr)lds, 16, voff, soff, 0, 0);
+}
+
+// AMODE 0: plain row-major A.  1: Conv2d forward gather.  2: Conv2d data gradient (parity classes).
+template <int TMW, int AMODE>
+__global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
+  constexpr int BM = TMW * 32, BN = 256;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int A_PCS = BM / 64, B_PCS = BN / 64;  // 1-KiB pieces (8 rows x 128 B) per wave and tile
+  constexpr int EP_LD = 144;                       // bytes per row of the wave-private transpose slab (128 + 16)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  // XCD-contiguous tile ranges (neighbouring row tiles share the convolution's halo rows in one L2); not for the data
+  // gradient, whose tiles are ordered heaviest class first for the dispatcher
+  const int bid = AMODE == 2 ? (int)blockIdx.x : xcd_remap_big(blockIdx.x, gridDim.x);
+
+  // ---- which tile -----------------------------------------------------------------------------------
+  int cls = 0, tm, tn;
+  int M = g.M;
+  if constexpr (AMODE == 2) {
+    const int t = bid / g.tiles_n;
+    tn = bid - t * g.tiles_n;
+    while (cls + 1 < g.dg.ncls && t >= g.dg.tile0[cls + 1]) ++cls;
+    tm = t - g.dg.tile0[cls];
+    M = g.dg.M[cls];
+  } else {
+    tm = bid / g.tiles_n;
+    tn = bid - tm * g.tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- DMA source offsets (bytes; per lane one row of each of its pieces) ------------------------------
+  const int sub = lane >> 3, pc = lane & 7;
+  unsigned a_off[A_PCS], b_off[B_PCS];
+  unsigned a_tapmask = 0;  // AMODE 2: 4 bits per piece, bit (dh*2 + dw) = that shifted source row exists
+  const char* a_base = static_cast<const char*>(g.A);
+#pragma unroll
+  for (int i = 0; i < A_PCS; ++i) {
+    const int row = (wave + 8 * i) * 8 + sub;
+    const unsigned ch = (unsigned)(pc ^ ((row >> 1) & 7)) * 16u;
+    const int grow = m0 + row;
+    const bool ok = grow < M;
+    const int r = ok ? grow : 0;
+    if constexpr (AMODE == 1) {
+      const int per_b = g.cg.T2 * g.cg.F2;
+      const int b = r / per_b, q = r - b * per_b;
+      const int t2 = q / g.cg.F2, f2 = q - t2 * g.cg.F2;
+      a_off[i] = ok ? (unsigned)(((((long)b * g.cg.T1 + 2 * t2) * g.cg.F1 + 2 * f2) * g.cg.C) * 2) + ch : EMO_OOB;
+    } else if constexpr (AMODE == 2) {
+      const int per_b = g.dg.nI[cls] * g.dg.nJ[cls];
+      const int b = r / per_b, q = r - b * per_b;
+      const int ii = q / g.dg.nJ[cls], jj = q - ii * g.dg.nJ[cls];
+      // offsets are relative to dy2 - (F2 + 1) * C elements, so that the tap shifts (dh, dw in {0, 1}) are non-negative
+      a_off[i] = (unsigned)(((((long)b * g.dg.T2 + ii) * g.dg.F2 + jj) * g.dg.C) * 2) + ch;
+      unsigned msk = 0;
+#pragma unroll
+      for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+          const int si = ii - dh, sj = jj - dw;
+          if (ok && si >= 0 && si < g.dg.T2 && sj >= 0 && sj < g.dg.F2) msk |= 1u << (dh * 2 + dw);
+        }
+      a_tapmask |= msk << (4 * i);
+    } else {
+      a_off[i] = ok ? (unsigned)((long)r * g.lda * 2) + ch : EMO_OOB;
+    }
+  }
+  if constexpr (AMODE == 2) a_base -= (long)(g.dg.F2 + 1) * g.dg.C * 2;
+#pragma unroll
+  for (int i = 0; i < B_PCS; ++i) {
+    const int row = (wave + 8 * i) * 8 + sub;
+    const unsigned ch = (unsigned)(pc ^ ((row >> 1) & 7)) * 16u;
+    const int n = n0 + row;
+    b_off[i] = n < g.N ? (unsigned)((long)n * g.ldb * 2) + ch : EMO_OOB;
+  }
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a_base), rsB = make_rsrc(g.B);
+
+  const int cpt = (AMODE == 0) ? 1 : (AMODE == 1 ? g.cg.C : g.dg.C) / 64;  // k-tiles per tap
+  const int nk = (AMODE == 2) ? g.dg.ntap[cls] * cpt : g.K / 64;
+
+  // Staging rings.  The B operand (the weight: 1.2 MB, re-read by every tile) always hits the L2; the A operand streams
+  // from HBM / Infinity Cache with ~2 us of latency under load, more than one k-tile of MFMA work (~1.5 us).  With two
+  // symmetric stages the wait for the LAST piece of the next tile was exposed in every k-tile (measured: MFMA + fragment
+  // reads + barrier alone 109 us, DMA alone 63 us, together 146 us).  So the 160 KB of LDS are split unevenly: B two stages
+  // (tile kt + 1 in flight), A THREE stages (tiles kt + 1 and kt + 2 in flight).  Within an iteration the B pieces are
+  // issued before the A pieces, so that the counted wait at the top of the next iteration, vmcnt(A_PCS), retires
+  // everything but the newest A tile.
+  // k order of the gathered modes: channel chunk outermost, taps innermost (neighbouring taps read nearly the same input
+  // rows, so their re-reads follow the first touch by one to three k-tiles and hit the XCD's L2: fabric reads of the
+  // forward 621 -> 337 MB).
+  auto tile_offsets = [&](int kt, unsigned& sA, unsigned& sB, int& tapbit) {
+    tapbit = 0;
+    if constexpr (AMODE == 1) {
+      const int kc = g.korder ? kt / 9 : kt % cpt, tap = g.korder ? kt - kc * 9 : kt / cpt;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      sA = (unsigned)(((kh * g.cg.F1 + kw) * g.cg.C + kc * 64) * 2);
+      sB = (unsigned)((tap * g.cg.C + kc * 64) * 2);
+    } else if constexpr (AMODE == 2) {
+      const int ntap = g.dg.ntap[cls];
+      const int kc = g.korder ? kt / ntap : kt % cpt, tap = g.korder ? kt - kc * ntap : kt / cpt;
+      const int dh = g.dg.dh[cls][tap], dw = g.dg.dw[cls][tap];
+      sA = (unsigned)((((1 - dh) * g.dg.F2 + (1 - dw)) * g.dg.C + kc * 64) * 2);
+      sB = (unsigned)((g.dg.wtap[cls][tap] + kc * 64) * 2);
+      tapbit = dh * 2 + dw;
+    } else {
+      sA = sB = (unsigned)kt * 128u;
+    }
+  };
+  constexpr int A_RING = 3 * A_BYTES;  // B ring starts here
+  unsigned ia_s = 0, ib_s = 0;         // scalar source offsets of the tiles being issued
+  int ia_tapbit = 0;
+  char* ia_dst = smem;                 // this wave's first piece of the A / B stage being filled
+  char* ib_dst = smem;
+  auto setup_a = [&](int kt) {
+    unsigned dummy; 
+    tile_offsets(kt, ia_s, dummy, ia_tapbit);
+    ia_dst = smem + (kt % 3) * A_BYTES + wave * 1024;
+  };
+  auto setup_b = [&](int kt) {
+    unsigned dummy;
+    int tb;
+    tile_offsets(kt, dummy, ib_s, tb);
+    ib_dst = smem + A_RING + (kt & 1) * B_BYTES + wave * 1024;
+  };
+  auto issue_a = [&](const int p) __attribute__((always_inline)) {
+    unsigned v = a_off[p];
+    if constexpr (AMODE == 2) v = ((a_tapmask >> (4 * p + ia_tapbit)) & 1u) ? v : EMO_OOB;
+    dma16(rsA, ia_dst + p * 8192, v, ia_s);
+  };
+  auto issue_b = [&](const int p) __attribute__((always_inline)) { dma16(rsB, ib_dst + p * 8192, b_off[p], ib_s); };
+  constexpr int N_PCS = A_PCS + B_PCS;
+
+  // ---- fragment read offsets -----------------------------------------------------------------------
+  // lane -> row (lane & 15) of a 16-row group, logical chunk ks*4 + (lane >> 4), swizzled by ((row >> 1) & 7);
+  // group bases are multiples of 16 rows, so the XOR term depends on the lane only
+  const int frow = lane & 15;
+  const unsigned fsw = (unsigned)((lane >> 1) & 7);
+  unsigned fch[2];
+  fch[0] = (((unsigned)(lane >> 4)) ^ fsw) * 16u;
+  fch[1] = (((unsigned)(4 + (lane >> 4))) ^ fsw) * 16u;
+  const unsigned a_frag0 = (unsigned)((wr * (BM / 2) + frow) * 128);
+  const unsigned b_frag0 = (unsigned)(A_RING + (wc * 64 + frow) * 128);
+
+  f32x4 acc[TMW][4];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: A(0), B(0), then A(1) -- the one group that may stay in flight across the first wait
+  setup_a(0);
+#pragma unroll
+  for (int p = 0; p < A_PCS; ++p) issue_a(p);
+  setup_b(0);
+#pragma unroll
+  for (int p = 0; p < B_PCS; ++p) issue_b(p);
+  if (nk > 1) {
+    setup_a(1);
+#pragma unroll
+    for (int p = 0; p < A_PCS; ++p) issue_a(p);
+  }
+  // MFMA groups (ks, i) per k-tile: 2 * TMW; piece p (B pieces first) goes out after group p * (2 * TMW - 2) / N_PCS
+  constexpr int GROUPS = 2 * TMW;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      if constexpr (A_PCS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (A_PCS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const bool more_b = kt + 1 < nk, more_a = kt + 2 < nk;
+    if (more_b) setup_b(kt + 1);
+    if (more_a) setup_a(kt + 2);
+    const char* sta = smem + (kt % 3) * A_BYTES;
+    const char* stb = smem + (kt & 1) * B_BYTES;
+    // Fragment reads run one step ahead of the MFMAs that use them: a step = one pair of 16-row A groups against the
+    // four B groups of one 32-deep k slice (8 MFMAs); while it runs, the next pair (and, towards the end of slice 0,
+    // slice 1's B groups) is read into the other register set, so no MFMA waits on a read issued just before it.
+    constexpr int PAIRS = TMW / 2, STEPS = 2 * PAIRS;
+    bf16x8 bq[2][4], aq[2][2];
+    auto ld_b = [&](int ks, int j) { return *reinterpret_cast<const bf16x8*>(stb + b_frag0 + j * 2048 + fch[ks]); };
+    auto ld_a = [&](int ks, int i) { return *reinterpret_cast<const bf16x8*>(sta + a_frag0 + i * 2048 + fch[ks]); };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bq[0][j] = ld_b(0, j);
+    aq[0][0] = ld_a(0, 0);
+    aq[0][1] = ld_a(0, 1);
+#pragma unroll
+    for (int sidx = 0; sidx < STEPS; ++sidx) {
+      const int ks = sidx / PAIRS, pr = sidx % PAIRS;
+      if (sidx + 1 < STEPS) {
+        const int ks1 = (sidx + 1) / PAIRS, pr1 = (sidx + 1) % PAIRS;
+        aq[(sidx + 1) & 1][0] = ld_a(ks1, 2 * pr1);
+        aq[(sidx + 1) & 1][1] = ld_a(ks1, 2 * pr1 + 1);
+      }
+      if (PAIRS >= 2 && sidx == PAIRS - 2) { bq[1][0] = ld_b(1, 0); bq[1][1] = ld_b(1, 1); }
+      if (PAIRS >= 2 && sidx == PAIRS - 1) { bq[1][2] = ld_b(1, 2); bq[1][3] = ld_b(1, 3); }
+      __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these reads to just before their first use
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[2 * pr + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][j], aq[sidx & 1][i], acc[2 * pr + i][j], 0, 0, 0);
+        const int grp = ks * TMW + 2 * pr + i;
+#pragma unroll
+        for (int p = 0; p < N_PCS; ++p)
+          if (grp == (p * (GROUPS - 2)) / N_PCS) {
+            if (p < B_PCS) { if (more_b) issue_b(p); }
+            else { if (more_a) issue_a(p - B_PCS); }
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------
+  // acc[i][j][r] = C[m = group i, row lane & 15][n = group j, col 4 * (lane >> 4) + r]
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // every wave is done with the staging buffers
+  char* slab = smem + wave * (16 * EP_LD);
+  const int ncol0 = n0 + wc * 64;
+  f32x4 bias4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g.bias) bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + ncol0 + j * 16 + 4 * (lane >> 4));
+  }
+  bf16* Cp = static_cast<bf16*>(g.C);
+  const bf16* Dm = static_cast<const bf16*>(g.dmask);
+  // output offsets of this lane's 2 * TMW row segments; the ReLU-mask loads of all of them go out together, before the
+  // transposes (one dependent load per store would cost 2 * TMW memory round trips per tile)
+  long offs[TMW][2];
+  bf16x8 dm[TMW][2];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int id = lane + 64 * hh, row = id >> 3, cc = id & 7;
+      const int grow = m0 + wr * (BM / 2) + i * 16 + row;
+      long off = -1;
+      if (grow < M) {
+        if constexpr (AMODE == 2) {
+          const int per_b = g.dg.nI[cls] * g.dg.nJ[cls];
+          const int b = grow / per_b, q = grow - b * per_b;
+          const int ii = q / g.dg.nJ[cls], jj = q - ii * g.dg.nJ[cls];
+          off = ((((long)b * g.dg.T1 + 2 * ii + g.dg.pt[cls]) * g.dg.F1 + 2 * jj + g.dg.pf[cls]) * g.dg.C) + ncol0 + cc * 8;
+        } else {
+          off = (long)grow * g.ldc + ncol0 + cc * 8;
+        }
+      }
+      offs[i][hh] = off;
+      if (AMODE == 2 && Dm) dm[i][hh] = *reinterpret_cast<const bf16x8*>(Dm + (off >= 0 ? off : 0));
+    }
+#pragma unroll
+  for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bias4[j][r];
+        if (g.relu) v = fmaxf(v, 0.f);
+        h[r] = (bf16)v;
+      }
+      *reinterpret_cast<bf16x4*>(slab + frow * EP_LD + (j * 16 + 4 * (lane >> 4)) * 2) = h;
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int id = lane + 64 * hh, row = id >> 3, cc = id & 7;
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(slab + row * EP_LD + cc * 16);
+      if (offs[i][hh] >= 0) {
+        if (AMODE == 2 && Dm) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (float)dm[i][hh][e] > 0.f ? v[e] : (bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(Cp + offs[i][hh]) = v;
+      }
+    }
+  }
+}
+
+int g_conv_big = 1;
+
+inline int pick_bm(long M, int n_cu) {
+  // the tile height that wastes the fewest CU-rounds: efficiency = M / (rounds * n_cu * BM)
+  int best = 256;
+  double best_eff = 0.0;
+  for (int bm : {256, 192, 128}) {
+    const long tiles = (M + bm - 1) / bm;
+    const long rounds = (tiles + n_cu - 1) / n_cu;
+    // a taller tile amortises the 256 weight rows it stages over more output rows
+    const double eff = (double)M / ((double)rounds * n_cu * bm) * (bm == 256 ? 1.0 : bm == 192 ? 0.96 : 0.88);
+    if (eff > best_eff) { best_eff = eff; best = bm; }
+  }
+  return best;
+}
+
+int n_cu_cached() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceProp_t p;
+    n = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int TMW, int AMODE>
+int launch_big_t(const BigArgs& a, int tiles, hipStream_t s) {
+  constexpr int bytes = (3 * TMW * 32 + 2 * 256) * 128;  // A ring of three stages + B ring of two
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)big_nt_kernel<TMW, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { emo_set_error("hipFuncSetAttribute(%d): %s", bytes, hipGetErrorString(e)); return 1; }
+    attr_done = true;
+  }
+  big_nt_kernel<TMW, AMODE><<<tiles, 512, bytes, s>>>(a);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int AMODE>
+int launch_big_bm(const BigArgs& a, int bm, int tiles, hipStream_t s) {
+  if (bm == 256) return launch_big_t<8, AMODE>(a, tiles, s);
+  if (bm == 192) return launch_big_t<6, AMODE>(a, tiles, s);
+  return launch_big_t<4, AMODE>(a, tiles, s);
+}
+
+int g_big_bm = 0;  // tuning override
+int g_big_korder = 1;
+
+}  // namespace
+
+void emo_gemm_set_conv_big(int v) { g_conv_big = v; }
+void emo_gemm_set_big_bm(int v) { g_big_bm = v; }
+void emo_gemm_set_big_korder(int v) { g_big_korder = v; }
+int emo_conv_big_enabled() { return g_conv_big; }
+
+// C[M,N] (bf16) = relu?(A[M,K] . B[N,K]^T + bias): N % 256 == 0, K % 64 == 0, 16-byte aligned rows.
+extern "C" int emoasr_gemm_nt_big(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                                  void* C, long ldc, const float* bias, int relu, void* stream) {
+  EMO_CHECK(dtype == EMO_BF16, "gemm_nt_big: bf16 only");
+  EMO_CHECK(M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 64 == 0, "gemm_nt_big: needs N %% 256 == 0, K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+  EMO_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "gemm_nt_big: leading dimensions must be multiples of 8");
+  EMO_CHECK((long)M * lda * 2 < (1L << 32) && (long)N * ldb * 2 < (1L << 32), "gemm_nt_big: operands must be < 4 GiB");
+  BigArgs a{};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.bias = bias; a.relu = relu;
+  const int bm = g_big_bm ? g_big_bm : pick_bm(M, n_cu_cached());
+  a.tiles_m = cdiv(M, bm); a.tiles_n = N / 256;
+  return launch_big_bm<0>(a, bm, a.tiles_m * a.tiles_n, (hipStream_t)stream);
+}
+
+// Conv2d forward through the large-tile kernel; called by emoasr_conv2_fwd (gemm.hip) for bf16, C % 256 == 0.
+int emo_conv2_fwd_big(int B, int T1, int F1, int C, const void* y1, const void* w, void* y2, const float* bias,
+                      int relu, hipStream_t s) {
+  const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  EMO_CHECK((long)B * T1 * F1 * C * 2 < (1L << 32), "conv2: input must be < 4 GiB");
+  BigArgs a{};
+  a.M = B * T2 * F2; a.N = C; a.K = 9 * C; a.A = y1; a.B = w; a.ldb = 9 * C; a.C = y2; a.ldc = C;
+  a.bias = bias; a.relu = relu;
+  a.cg = BigConv{T1, F1, T2, F2, C};
+  a.korder = g_big_korder;
+  const int bm = g_big_bm ? g_big_bm : pick_bm(a.M, n_cu_cached());
+  a.tiles_m = cdiv(a.M, bm); a.tiles_n = C / 256;
+  return launch_big_bm<1>(a, bm, a.tiles_m * a.tiles_n, s);
+}
+
+// dy1[b,t1,f1,c] = relu'(y1[b,t1,f1,c]) * sum_{kh,kw,n} dy2[b,(t1-kh)/2,(f1-kw)/2,n] * W[n,c,kh,kw]: the four output-parity
+// classes (DgradGeom in gemm.hip) as ONE launch, heaviest class first.  wt: the weight as [c][kh][kw][n] (k-contiguous for
+// every tap), i.e. conv.2.weight.permute(1, 2, 3, 0).
+extern "C" int emoasr_conv2_dgrad_kc(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* wt,
+                                     const void* y1, void* dy1, void* stream) {
+  EMO_CHECK(dtype == EMO_BF16, "conv2_dgrad_kc: bf16 only");
+  EMO_CHECK(T1 >= 3 && F1 >= 3, "conv2_dgrad_kc: input too small (T1=%d F1=%d)", T1, F1);
+  EMO_CHECK(C % 256 == 0, "conv2_dgrad_kc: C must be a multiple of 256");
+  const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  EMO_CHECK((long)B * T1 * F1 * C * 2 < (1L << 32), "conv2_dgrad_kc: tensors must be < 4 GiB");
+  BigArgs a{};
+  a.korder = g_big_korder;
+  a.N = C; a.K = 4 * C; a.A = dy2; a.B = wt; a.ldb = 9 * C; a.C = dy1; a.ldc = C; a.dmask = y1;
+  BigDgrad& g = a.dg;
+  g.T1 = T1; g.F1 = F1; g.T2 = T2; g.F2 = F2; g.C = C;
+  long rows = 0;
+  for (int pt = 0; pt < 2; ++pt)
+    for (int pf = 0; pf < 2; ++pf) {
+      const int nI = (T1 - pt + 1) / 2, nJ = (F1 - pf + 1) / 2;
+      if (nI <= 0 || nJ <= 0) continue;
+      const int c = g.ncls++;
+      g.pt[c] = pt; g.pf[c] = pf; g.nI[c] = nI; g.nJ[c] = nJ; g.M[c] = B * nI * nJ;
+      g.ntap[c] = 0;
+      for (int kh = pt; kh < 3; kh += 2)
+        for (int kw = pf; kw < 3; kw += 2) {
+          const int t = g.ntap[c]++;
+          g.dh[c][t] = kh / 2; g.dw[c][t] = kw / 2; g.wtap[c][t] = (kh * 3 + kw) * C;
+        }
+      rows += (long)g.M[c] * g.ntap[c];
+    }
+  // tile height from the work-weighted row count (a 4-tap tile runs 4x as long as a 1-tap tile)
+  const int bm = g_big_bm ? g_big_bm : pick_bm(rows / 4, n_cu_cached());
+  int t0 = 0;
+  for (int c = 0; c < g.ncls; ++c) { g.tile0[c] = t0; t0 += cdiv(g.M[c], bm); }
+  g.tile0[g.ncls] = t0;
+  a.tiles_m = t0; a.tiles_n = C / 256;
+  return launch_big_bm<2>(a, bm, t0 * a.tiles_n, (hipStream_t)stream);
+}

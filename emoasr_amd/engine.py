@@ -201,6 +201,10 @@ class CTCEngine(_DecoderMixinPlaceholder):
         self.inter_layer = int(cfg.inter_ctc_layer_id) if inter_on else 0
         self.eouts_inter = None
         self._implicit_dgrad = os.environ.get("EMOASR_CONV2_DGRAD", "implicit") == "implicit"
+        self._conv_big = os.environ.get("EMOASR_CONV_BIG", "1") != "0"  # A/B switch of csrc/gemm_big.hip (process-wide)
+        if not self._conv_big:
+            from . import lib as _lib
+            _lib.set_option("conv_big", 0)
         self.p_enc = float(_cfg(cfg, "dropout_enc_rate", 0.0))
         self.p_att = float(_cfg(cfg, "dropout_attn_rate", 0.0))
         self.dtype = compute_dtype
@@ -749,7 +753,11 @@ class CTCEngine(_DecoderMixinPlaceholder):
         dw2 = torch.zeros(C, 9 * C, device=dx.device, dtype=torch.float32)
         ops.conv2_wgrad(dy2, st.y1, dw2, dbias=A.g(pre + "conv.2.bias"), accumulate=True)
         ops.strided_copy(dw2.view(C, 3, 3, C).permute(0, 3, 1, 2), out=A.g(pre + "conv.2.weight"), accumulate=True)
-        if self._implicit_dgrad:
+        if self._implicit_dgrad and dy2.dtype == torch.bfloat16 and C % 256 == 0 and self._conv_big:
+            # all four parity classes in one launch of the large-tile kernel; it wants the weight as [c, kh, kw, n]
+            wt = ops.strided_copy(A.p(pre + "conv.2.weight").permute(1, 2, 3, 0), out_dtype=dy2.dtype).view(C, 9 * C)
+            dy1 = ops.conv2_dgrad_kc(dy2, wt, st.y1)
+        elif self._implicit_dgrad:
             dy1 = ops.conv2_dgrad(dy2, st.w2r, st.y1)  # four parity-class implicit GEMMs, no im2col buffer
         else:
             dcol = ops.gemm_nn(dy2, st.w2r)

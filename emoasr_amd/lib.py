@@ -142,6 +142,8 @@ SIGNATURES = {
     "emoasr_conv2_wgrad": [I, I, I, I, I, P, P, P, P, I, P],
     "emoasr_conv2_col2im": [I, I, I, I, I, P, P, P, P],
     "emoasr_conv2_dgrad": [I, I, I, I, I, P, P, P, P, P],
+    "emoasr_conv2_dgrad_kc": [I, I, I, I, I, P, P, P, P, P],
+    "emoasr_gemm_nt_big": [I, I, I, I, P, L, P, L, P, L, P, I, P],
     "emoasr_layernorm_fwd": [I, I, I, P, P, P, F, P, P, P, P],
     "emoasr_layernorm_bwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     "emoasr_layernorm_bwd_ex": [I, I, I, P, P, P, P, P, P, P, P, P, P, POINTER(LnBwdOpts), P],

@@ -199,6 +199,27 @@ def conv2_dgrad(dy2, w, y1):
     return dy1
 
 
+def conv2_dgrad_kc(dy2, wt, y1):
+    """as conv2_dgrad on the large-tile kernel: wt [C, 9C] = conv.2.weight.permute(1, 2, 3, 0) (c, kh, kw, n); bf16, C % 256 == 0"""
+    B, T1, F1, C = y1.shape
+    dy1 = torch.empty_like(y1)
+    lib.call("emoasr_conv2_dgrad_kc", dt(y1), B, T1, F1, C, _p(_chk(dy2, y1.dtype)), _p(_chk(wt, y1.dtype)), _p(y1), _p(dy1),
+             _stream())
+    return dy1
+
+
+def gemm_nt_big(a, b, out=None, bias=None, relu=False):
+    """out[M,N] = relu?(a[M,K] @ b[N,K]^T + bias) on the large-tile kernel (bf16, N % 256 == 0, K % 64 == 0)"""
+    M, K, lda = _rows(_chk(a, torch.bfloat16))
+    N, Kb, ldb = _rows(_chk(b, a.dtype))
+    assert K == Kb, (a.shape, b.shape)
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=a.dtype)
+    lib.call("emoasr_gemm_nt_big", dt(a), M, N, K, _p(a), lda, _p(b), ldb, _p(out), out.stride(0), _p(bias), int(relu),
+             _stream())
+    return out
+
+
 def conv2_col2im(dcol, y1):
     B, T1, F1, C = y1.shape
     dy1 = torch.empty_like(y1)

@@ -126,6 +126,15 @@ int emoasr_conv2_dgrad(int dtype, int B, int T1, int F1, int C, const void* dy2,
                        void* dy1, void* stream);
 int emoasr_conv2_col2im(int dtype, int B, int T1, int F1, int C, const void* dcol, const void* y1,
                         void* dy1, void* stream);
+/* The same data gradient on the large-tile kernel (csrc/gemm_big.hip; bf16, C % 256 == 0): all four parity classes in ONE
+ * launch.  wt = the weight laid out [c][kh][kw][n] (conv.2.weight.permute(1,2,3,0)), so that every tap's reduction over the
+ * output channels n is contiguous. */
+int emoasr_conv2_dgrad_kc(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* wt, const void* y1,
+                          void* dy1, void* stream);
+/* Large-tile NT product for long, wide shapes (bf16; N % 256 == 0, K % 64 == 0): C = relu?(A . B^T + bias).  The kernel
+ * behind emoasr_conv2_fwd / _dgrad_kc on a plain row-major A (nn.Linear with >= 256 outputs over >= 10^5 rows). */
+int emoasr_gemm_nt_big(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                       const float* bias, int relu, void* stream);
 
 /* ---- LayerNorm (nn.LayerNorm call sites: conformer.py:183-187,
  * encoders/transformer.py:73, transformer.py:140-141,178-180) ------------------ */

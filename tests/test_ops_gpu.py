@@ -194,6 +194,68 @@ def test_frontend(dev, dtype, tr_mode, T, Fd):
     _close(db1, b1r.grad, _tol(dtype, 1e-4, 3e-2), "conv1 bgrad")
 
 
+@pytest.mark.parametrize("bm", [0, 256, 192, 128])
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 128), (257, 512, 64), (5000, 256, 2304), (31, 256, 192)])
+def test_gemm_nt_big(dev, bm, M, N, K):
+    """large-tile NT kernel (LDS-DMA staging, swizzled images, transposed accumulators) against f32 matmul of the same
+    bf16 operands, every tile height, ragged last tiles"""
+    from emoasr_amd import lib, ops
+    a = _rnd(dev, M, K + 8, dtype=torch.bfloat16)[:, :K]  # lda != K
+    b = _rnd(dev, N, K, dtype=torch.bfloat16, scale=K ** -0.5)
+    bias = _rnd(dev, N, scale=0.5)
+    lib.set_option("big_bm", bm)
+    try:
+        for relu in (False, True):
+            out = ops.gemm_nt_big(a, b, bias=bias, relu=relu)
+            ref = a.float() @ b.float().t() + bias
+            _close(out, F.relu(ref) if relu else ref, 1e-2, f"gemm_nt_big relu={relu}")
+        out = ops.gemm_nt_big(a, b)
+        _close(out, a.float() @ b.float().t(), 1e-2, "gemm_nt_big plain")
+    finally:
+        lib.set_option("big_bm", 0)
+
+
+@pytest.mark.parametrize("bm", [0, 256, 192, 128])
+@pytest.mark.parametrize("B,T,Fd", [(3, 67, 80), (2, 70, 83), (5, 9, 7), (2, 300, 80)], ids=["odd", "even", "tiny", "long"])
+def test_conv2_large_tile_kernels(dev, bm, B, T, Fd):
+    """Conv2d(256 -> 256, k3, s2) forward and data gradient on the large-tile kernel == torch conv2d autograd, and the
+    forward == the 128x64-tile implicit GEMM it replaces up to bf16 output rounding"""
+    from emoasr_amd import lib, ops
+    C = 256
+    dtype = torch.bfloat16
+    x = _rnd(dev, B, T, Fd)
+    w1, b1 = _rnd(dev, C, 1, 3, 3, scale=0.3), _rnd(dev, C, scale=0.1)
+    w2, b2 = _rnd(dev, C, C, 3, 3, scale=(9 * C) ** -0.5), _rnd(dev, C, scale=0.1)
+    y1 = ops.conv1_fwd(x, w1.reshape(C, 9).contiguous(), b1, dtype)
+    y1r = y1.float().permute(0, 3, 1, 2).clone().requires_grad_(True)   # the SAME bf16 input for the reference
+    w2b = w2.to(dtype)
+    y2_ref = F.relu(F.conv2d(y1r, w2b.float(), b2, stride=2))
+    g = torch.randn_like(y2_ref)
+    y2_ref.backward(g)
+    w2p = _conv2_weight_repack(w2b)
+    lib.set_option("big_bm", bm)
+    try:
+        y2 = ops.conv2_fwd(y1, w2p, bias=b2, act=ops.ACT_RELU)
+        lib.set_option("conv_big", 0)
+        y2_old = ops.conv2_fwd(y1, w2p, bias=b2, act=ops.ACT_RELU)
+        lib.set_option("conv_big", 1)
+        _close(y2, y2_ref.permute(0, 2, 3, 1), 1e-2, "conv2 big")
+        _close(y2, y2_old, 1e-2, "conv2 big vs 128x64")
+        dy2 = (g.permute(0, 2, 3, 1) * (y2_ref.permute(0, 2, 3, 1) > 0)).contiguous().to(dtype)
+        wt = w2b.permute(1, 2, 3, 0).reshape(C, 9 * C).contiguous()
+        dy1 = ops.conv2_dgrad_kc(dy2, wt, y1)
+        # the reference consumes the same bf16 dy2
+        y1r.grad = None
+        y2_ref2 = F.conv2d(y1r, w2b.float(), b2, stride=2)
+        y2_ref2.backward(dy2.float().permute(0, 3, 1, 2))
+        dy1_ref = (y1r.grad * (y1r > 0)).permute(0, 2, 3, 1)
+        _close(dy1, dy1_ref, 1.5e-2, "conv2 big dgrad")
+        _close(dy1, ops.conv2_dgrad(dy2, w2p, y1), 1.5e-2, "conv2 big dgrad vs parity-class launches")
+    finally:
+        lib.set_option("big_bm", 0)
+        lib.set_option("conv_big", 1)
+
+
 # ---------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("N,eps", [(256, 1e-5), (256, 1e-12), (64, 1e-5), (1024, 1e-5)])
