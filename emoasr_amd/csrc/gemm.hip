@@ -666,6 +666,9 @@ int launch_tn(TnArgs a, hipStream_t s) {
 }  // namespace
 
 int emo_conv_big_enabled();
+bool emo_gemm_nt_big_wants(int M, int N, int K, long lda, long ldb, long ldc, const emoasr_epilogue_t& ep);
+int emo_gemm_nt_big_ep(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                       const emoasr_epilogue_t& ep, hipStream_t s);
 int emo_conv2_fwd_big(int B, int T1, int F1, int C, const void* y1, const void* w, void* y2, const float* bias,
                       int relu, hipStream_t s);
 
@@ -688,6 +691,9 @@ extern "C" int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, lon
   NtArgs a{};
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   if (ep) a.ep = *ep; else { a.ep = emoasr_epilogue_t{}; a.ep.alpha = 1.f; }
+  // wide bf16 products over many rows (q/k/v, feed-forward w1, pointwise conv 1): the large-tile kernel of gemm_big.hip
+  if (dtype == EMO_BF16 && emo_gemm_nt_big_wants(M, N, K, lda, ldb, ldc, a.ep))
+    return emo_gemm_nt_big_ep(M, N, K, A, lda, B, ldb, C, ldc, a.ep, (hipStream_t)stream);
   EMO_DISPATCH(dtype, return (launch_nt<T, 0>(a, (hipStream_t)stream)));
 }
 

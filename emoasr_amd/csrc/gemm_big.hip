@@ -49,6 +49,7 @@ struct BigArgs {
   void* C; long ldc;
   const float* bias;
   int relu;
+  emoasr_epilogue_t ep;  // AMODE 0 only: the general epilogue of emoasr_gemm_nt (no residual / dact_pre / f32 output)
   const void* dmask;  // data gradient only, optional: multiply by (dmask[same offset as C] > 0)  (ReLU backward)
   int tiles_m, tiles_n;
   int korder;  // gathered modes: 1 = channel chunk outermost, taps innermost; 0 = tap-major
@@ -285,8 +286,54 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
   // acc[i][j][r] = C[m = group i, row lane & 15][n = group j, col 4 * (lane >> 4) + r]
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // every wave is done with the staging buffers
-  char* slab = smem + wave * (16 * EP_LD);
   const int ncol0 = n0 + wc * 64;
+  if constexpr (AMODE == 0) {
+    // general epilogue, in the order and precision of gemm_nt_kernel's: alpha, bias, pre_out, activation, dropout (mask
+    // indexed by row * N + col).  16-row slabs go through wave-private LDS as f32 (row stride 68 floats), then every lane
+    // owns 8 consecutive columns of a row.
+    constexpr int FLD = 68;
+    float* fslab = reinterpret_cast<float*>(smem) + wave * (16 * FLD);
+    const emoasr_epilogue_t& ep = g.ep;
+    bf16* Cp = static_cast<bf16*>(g.C);
+    bf16* pre_out = static_cast<bf16*>(ep.pre_out);
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(fslab + frow * FLD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int id = lane + 64 * hh, row = id >> 3, cc = id & 7;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(fslab + row * FLD + cc * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(fslab + row * FLD + cc * 8 + 4);
+        const int grow = m0 + wr * (BM / 2) + i * 16 + row;
+        const int col = ncol0 + cc * 8;
+        if (grow < M) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+          if (ep.bias) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.bias + col);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(ep.bias + col + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = ep.alpha * v[e] + b0[e]; v[4 + e] = ep.alpha * v[4 + e] + b1[e]; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
+          }
+          const long off = (long)grow * g.ldc + col;
+          if (pre_out) store8<bf16>(pre_out + off, v);
+          act_vec<8>(ep.act, v);
+          if (ep.drop_p > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= dropout_scale(ep.seed, (uint64_t)grow * (uint64_t)g.N + col + e, ep.drop_p);
+          }
+          store8<bf16>(Cp + off, v);
+        }
+      }
+    }
+    return;
+  }
+  char* slab = smem + wave * (16 * EP_LD);
   f32x4 bias4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -406,6 +453,30 @@ void emo_gemm_set_big_bm(int v) { g_big_bm = v; }
 void emo_gemm_set_big_korder(int v) { g_big_korder = v; }
 int emo_conv_big_enabled() { return g_conv_big; }
 
+// Measured in the L2 training step (M ~ 7 k rows): with the q/k/v, feed-forward w1 and pointwise-conv-1 products
+// (165 - 220 tiles of 128 x 256) on this kernel the step took 9.72 ms against 9.66 ms without -- those launches are
+// latency-bound either way -- so only products of at least two full rounds of tiles are taken.
+int g_big_min_tiles = 512;
+
+// Does the large-tile kernel take this emoasr_gemm_nt call?  (bf16 product, full 256-column tiles, 64-deep k-tiles, an
+// epilogue without residual / saved-activation / f32 output, and enough 128-row tiles to occupy most CUs.)
+bool emo_gemm_nt_big_wants(int M, int N, int K, long lda, long ldb, long ldc, const emoasr_epilogue_t& ep) {
+  if (!g_conv_big || N % 256 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) return false;
+  if (ep.residual || ep.dact_pre || ep.out_f32) return false;
+  if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldb * 2 >= (1L << 32)) return false;
+  return (long)cdiv(M, 128) * (N / 256) >= g_big_min_tiles;
+}
+int emo_gemm_nt_big_ep(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                       const emoasr_epilogue_t& ep, hipStream_t s) {
+  BigArgs a{};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.ep = ep;
+  const int bm = g_big_bm ? g_big_bm : pick_bm(M, n_cu_cached());
+  a.tiles_m = cdiv(M, bm); a.tiles_n = N / 256;
+  return launch_big_bm<0>(a, bm, a.tiles_m * a.tiles_n, s);
+}
+void emo_gemm_set_big_min_tiles(int v) { g_big_min_tiles = v; }
+
 // C[M,N] (bf16) = relu?(A[M,K] . B[N,K]^T + bias): N % 256 == 0, K % 64 == 0, 16-byte aligned rows.
 extern "C" int emoasr_gemm_nt_big(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                                   void* C, long ldc, const float* bias, int relu, void* stream) {
@@ -413,12 +484,9 @@ extern "C" int emoasr_gemm_nt_big(int dtype, int M, int N, int K, const void* A,
   EMO_CHECK(M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 64 == 0, "gemm_nt_big: needs N %% 256 == 0, K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
   EMO_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "gemm_nt_big: leading dimensions must be multiples of 8");
   EMO_CHECK((long)M * lda * 2 < (1L << 32) && (long)N * ldb * 2 < (1L << 32), "gemm_nt_big: operands must be < 4 GiB");
-  BigArgs a{};
-  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
-  a.bias = bias; a.relu = relu;
-  const int bm = g_big_bm ? g_big_bm : pick_bm(M, n_cu_cached());
-  a.tiles_m = cdiv(M, bm); a.tiles_n = N / 256;
-  return launch_big_bm<0>(a, bm, a.tiles_m * a.tiles_n, (hipStream_t)stream);
+  emoasr_epilogue_t ep{};
+  ep.alpha = 1.f; ep.bias = bias; ep.act = relu ? EMO_ACT_RELU : EMO_ACT_NONE; ep.res_scale = 1.f;
+  return emo_gemm_nt_big_ep(M, N, K, A, lda, B, ldb, C, ldc, ep, (hipStream_t)stream);
 }
 
 // Conv2d forward through the large-tile kernel; called by emoasr_conv2_fwd (gemm.hip) for bf16, C % 256 == 0.

@@ -205,6 +205,9 @@ class CTCEngine(_DecoderMixinPlaceholder):
         if not self._conv_big:
             from . import lib as _lib
             _lib.set_option("conv_big", 0)
+        if os.environ.get("EMOASR_BIG_MIN_TILES"):
+            from . import lib as _lib
+            _lib.set_option("big_min_tiles", int(os.environ["EMOASR_BIG_MIN_TILES"]))
         self.p_enc = float(_cfg(cfg, "dropout_enc_rate", 0.0))
         self.p_att = float(_cfg(cfg, "dropout_attn_rate", 0.0))
         self.dtype = compute_dtype

@@ -215,6 +215,33 @@ def test_gemm_nt_big(dev, bm, M, N, K):
         lib.set_option("big_bm", 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 512, 256), (7029, 1024, 256), (333, 768, 128)])
+def test_gemm_nt_dispatch_to_large_tile_kernel(dev, M, N, K):
+    """emoasr_gemm_nt hands wide bf16 products to the large-tile kernel; its epilogue (alpha, bias, saved pre-activation,
+    Swish, dropout) must equal the 128x64 kernel's: identical dropout masks, values up to the accumulation order"""
+    from emoasr_amd import lib, ops
+    a = _rnd(dev, M, K, dtype=torch.bfloat16)
+    b = _rnd(dev, N, K, dtype=torch.bfloat16, scale=K ** -0.5)
+    bias = _rnd(dev, N, scale=0.5)
+    outs = []
+    try:
+        for big in (1, 0):
+            lib.set_option("conv_big", big)
+            lib.set_option("big_min_tiles", 1)
+            pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            y = ops.gemm_nt(a, b, bias=bias, alpha=0.5, act=ops.ACT_SWISH, pre_out=pre, drop_p=0.1, seed=77)
+            outs.append((y, pre, ops.gemm_nt(a, b)))
+    finally:
+        lib.set_option("conv_big", 1)
+        lib.set_option("big_min_tiles", 512)
+    (y1, p1, r1), (y0, p0, r0) = outs
+    assert torch.equal(y1 == 0, y0 == 0), "dropout masks differ"
+    _close(p1, 0.5 * (a.float() @ b.float().t()) + bias, 1e-2, "pre-activation")
+    _close(p1, p0, 1e-2, "pre-activation vs 128x64")
+    _close(y1, y0, 1e-2, "swish + dropout vs 128x64")
+    _close(r1, r0, 1e-2, "plain")
+
+
 @pytest.mark.parametrize("bm", [0, 256, 192, 128])
 @pytest.mark.parametrize("B,T,Fd", [(3, 67, 80), (2, 70, 83), (5, 9, 7), (2, 300, 80)], ids=["odd", "even", "tiny", "long"])
 def test_conv2_large_tile_kernels(dev, bm, B, T, Fd):

@@ -45,7 +45,7 @@ dw = torch.zeros(C, 9 * C, device=dev)
 us = graph_time(lambda: ops.conv2_wgrad(dy2, y1, dw, accumulate=True), n=5)
 print(f"conv2 wgrad tn         : {us:7.1f} us  {flop / us / 1e6:6.0f} TF/s", flush=True)
 # plain product of the same size
-for (m, n, k) in [(136800, 256, 2304), (136800, 256, 256), (7029, 1024, 256), (7029, 256, 1024)]:
+for (m, n, k) in [(136800, 256, 2304), (7029, 1024, 256), (7029, 768, 256), (7029, 512, 256), (5000, 1024, 256), (9000, 512, 256)]:
     a = torch.randn(m, k, device=dev).to(dt)
     b = (torch.randn(n, k, device=dev) * k ** -0.5).to(dt)
     f = 2.0 * m * n * k
