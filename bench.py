@@ -284,7 +284,7 @@ L4 = dict(L2, decoder_type="rnn_transducer", vocab_size=1000, embedding_size=256
 
 def l4_rnnt(dev, dtype, steps=5, warmup=2, n_dec=5):
     """config 5 (`L4`): RNN-T (Conformer) 26 M -- training frames/s (fwd + transducer lattice + bwd + Adam on
-    LibriSpeech-shaped batches, 12 000-frame budget: the joint logits are [B,T',U+1,1000]) and streaming greedy
+    LibriSpeech-shaped batches at the standard 30 000-frame budget: the joint logits [B,T',U+1,1000] are ~0.9 GB in bf16) and streaming greedy
     decode RTF at batch 1 (decode steps capped by the model's own max-symbols rule)."""
     from emoasr_amd.data import libri_shaped_lengths, pack_batches
     from emoasr_amd.modeling.asr import ASR
@@ -295,7 +295,7 @@ def l4_rnnt(dev, dtype, steps=5, warmup=2, n_dec=5):
     opt = ArenaAdam(eng.arena, lambda s: noam_lr(OPT["lr"], 256, OPT["warmup"], s), weight_decay=OPT["weight_decay"],
                     clip_grad_norm=OPT["clip_grad_norm"])
     xlens, ylens = libri_shaped_lengths(2000, 0)
-    batches = pack_batches(xlens, ylens, 12000, 1200, 50, 1)
+    batches = pack_batches(xlens, ylens, 30000, 3000, 50, 1)  # the standard sampler budget (asr/datasets.py:159-213)
     rs = random.Random(3)
     rs.shuffle(batches)
     g = torch.Generator().manual_seed(5)

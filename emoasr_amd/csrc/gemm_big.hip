@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(fslab + row * FLD + cc * 8 + 4);
         const int grow = m0 + wr * (BM / 2) + i * 16 + row;
         const int col = ncol0 + cc * 8;
-        if (grow < M) {
+        if (grow < M && col < g.N) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
@@ -461,10 +461,10 @@ int g_big_min_tiles = 512;
 // Does the large-tile kernel take this emoasr_gemm_nt call?  (bf16 product, full 256-column tiles, 64-deep k-tiles, an
 // epilogue without residual / saved-activation / f32 output, and enough 128-row tiles to occupy most CUs.)
 bool emo_gemm_nt_big_wants(int M, int N, int K, long lda, long ldb, long ldc, const emoasr_epilogue_t& ep) {
-  if (!g_conv_big || N % 256 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) return false;
+  if (!g_conv_big || N % 8 != 0 || N < 256 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) return false;
   if (ep.residual || ep.dact_pre || ep.out_f32) return false;
   if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldb * 2 >= (1L << 32)) return false;
-  return (long)cdiv(M, 128) * (N / 256) >= g_big_min_tiles;
+  return (long)cdiv(M, 128) * cdiv(N, 256) >= g_big_min_tiles;
 }
 int emo_gemm_nt_big_ep(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                        const emoasr_epilogue_t& ep, hipStream_t s) {
@@ -472,16 +472,16 @@ int emo_gemm_nt_big_ep(int M, int N, int K, const void* A, long lda, const void*
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.ep = ep;
   const int bm = g_big_bm ? g_big_bm : pick_bm(M, n_cu_cached());
-  a.tiles_m = cdiv(M, bm); a.tiles_n = N / 256;
+  a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(N, 256);
   return launch_big_bm<0>(a, bm, a.tiles_m * a.tiles_n, s);
 }
 void emo_gemm_set_big_min_tiles(int v) { g_big_min_tiles = v; }
 
-// C[M,N] (bf16) = relu?(A[M,K] . B[N,K]^T + bias): N % 256 == 0, K % 64 == 0, 16-byte aligned rows.
+// C[M,N] (bf16) = relu?(A[M,K] . B[N,K]^T + bias): N % 8 == 0, K % 64 == 0, 16-byte aligned rows.
 extern "C" int emoasr_gemm_nt_big(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                                   void* C, long ldc, const float* bias, int relu, void* stream) {
   EMO_CHECK(dtype == EMO_BF16, "gemm_nt_big: bf16 only");
-  EMO_CHECK(M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 64 == 0, "gemm_nt_big: needs N %% 256 == 0, K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+  EMO_CHECK(M > 0 && N > 0 && N % 8 == 0 && K > 0 && K % 64 == 0, "gemm_nt_big: needs N %% 8 == 0, K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
   EMO_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "gemm_nt_big: leading dimensions must be multiples of 8");
   EMO_CHECK((long)M * lda * 2 < (1L << 32) && (long)N * ldb * 2 < (1L << 32), "gemm_nt_big: operands must be < 4 GiB");
   emoasr_epilogue_t ep{};

@@ -209,7 +209,7 @@ def conv2_dgrad_kc(dy2, wt, y1):
 
 
 def gemm_nt_big(a, b, out=None, bias=None, relu=False):
-    """out[M,N] = relu?(a[M,K] @ b[N,K]^T + bias) on the large-tile kernel (bf16, N % 256 == 0, K % 64 == 0)"""
+    """out[M,N] = relu?(a[M,K] @ b[N,K]^T + bias) on the large-tile kernel (bf16, N % 8 == 0, K % 64 == 0)"""
     M, K, lda = _rows(_chk(a, torch.bfloat16))
     N, Kb, ldb = _rows(_chk(b, a.dtype))
     assert K == Kb, (a.shape, b.shape)

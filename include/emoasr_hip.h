@@ -131,7 +131,7 @@ int emoasr_conv2_col2im(int dtype, int B, int T1, int F1, int C, const void* dco
  * output channels n is contiguous. */
 int emoasr_conv2_dgrad_kc(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* wt, const void* y1,
                           void* dy1, void* stream);
-/* Large-tile NT product for long, wide shapes (bf16; N % 256 == 0, K % 64 == 0): C = relu?(A . B^T + bias).  The kernel
+/* Large-tile NT product for long, wide shapes (bf16; N % 8 == 0, K % 64 == 0): C = relu?(A . B^T + bias).  The kernel
  * behind emoasr_conv2_fwd / _dgrad_kc on a plain row-major A (nn.Linear with >= 256 outputs over >= 10^5 rows). */
 int emoasr_gemm_nt_big(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                        const float* bias, int relu, void* stream);

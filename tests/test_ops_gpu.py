@@ -195,7 +195,7 @@ def test_frontend(dev, dtype, tr_mode, T, Fd):
 
 
 @pytest.mark.parametrize("bm", [0, 256, 192, 128])
-@pytest.mark.parametrize("M,N,K", [(1000, 256, 128), (257, 512, 64), (5000, 256, 2304), (31, 256, 192)])
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 128), (257, 512, 64), (5000, 256, 2304), (31, 256, 192), (3000, 1000, 512)])
 def test_gemm_nt_big(dev, bm, M, N, K):
     """large-tile NT kernel (LDS-DMA staging, swizzled images, transposed accumulators) against f32 matmul of the same
     bf16 operands, every tile height, ragged last tiles"""
@@ -215,7 +215,7 @@ def test_gemm_nt_big(dev, bm, M, N, K):
         lib.set_option("big_bm", 0)
 
 
-@pytest.mark.parametrize("M,N,K", [(700, 512, 256), (7029, 1024, 256), (333, 768, 128)])
+@pytest.mark.parametrize("M,N,K", [(700, 512, 256), (7029, 1024, 256), (333, 768, 128), (2000, 1000, 512)])
 def test_gemm_nt_dispatch_to_large_tile_kernel(dev, M, N, K):
     """emoasr_gemm_nt hands wide bf16 products to the large-tile kernel; its epilogue (alpha, bias, saved pre-activation,
     Swish, dropout) must equal the 128x64 kernel's: identical dropout masks, values up to the accumulation order"""
