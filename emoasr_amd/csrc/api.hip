@@ -23,6 +23,8 @@ void emo_gemm_set_conv_big(int v);
 void emo_gemm_set_big_bm(int v);
 void emo_gemm_set_big_korder(int v);
 void emo_gemm_set_big_min_tiles(int v);
+void emo_conv_set_dwconv_lds(int v);
+void emo_layer_set_conv_fused(int v);
 void emo_attn_set_tr_read(int v);
 void emo_attn_set_fw(int v);
 void emo_layer_set_ffn_fused(int v);
@@ -87,6 +89,8 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "big_bm") == 0) { emo_gemm_set_big_bm(value); return 0; }
   if (strcmp(name, "big_korder") == 0) { emo_gemm_set_big_korder(value); return 0; }
   if (strcmp(name, "big_min_tiles") == 0) { emo_gemm_set_big_min_tiles(value); return 0; }
+  if (strcmp(name, "dwconv_lds") == 0) { emo_conv_set_dwconv_lds(value); return 0; }
+  if (strcmp(name, "conv_fused") == 0) { emo_layer_set_conv_fused(value); return 0; }
   if (strcmp(name, "attn_fw") == 0) { emo_attn_set_fw(value); return 0; }
   if (strcmp(name, "timers") == 0) { g_timers_on = value; return 0; }
   if (strcmp(name, "ffn_fused") == 0) { emo_layer_set_ffn_fused(value); return 0; }

@@ -364,10 +364,25 @@ inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 8192 ? 8
 
 }  // namespace
 
+// convfused.hip: the same stencil with the time tile staged through LDS by 16-byte loads (bf16; bit-identical results)
+int emo_dwconv_lds(int B, int Tn, int C, int K, const void* x, const float* w, const float* bias, void* y, int flip,
+                   float* part, hipStream_t s);
+static int g_dwconv_lds = 1;
+void emo_conv_set_dwconv_lds(int v) { g_dwconv_lds = v; }
+static bool use_lds(int dtype, int Tn, int C) {
+  return g_dwconv_lds && dtype == EMO_BF16 && C % 8 == 0 && (long)Tn * C * 2 < (1L << 32);
+}
+int emo_dwconv_bwd_w_reduce(int nblk, int C, int K, const float* part, float* dw, float* dbias, hipStream_t s) {
+  dwconv_bwd_w_reduce_kernel<<<cdiv((K + 1) * C, 64), 256, 0, s>>>(nblk, C, K, part, dw, dbias);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int emoasr_dwconv_fwd(int dtype, int B, int Tn, int C, int K, const void* x, const float* w,
                                  const float* bias, void* y, void* stream) {
   EMO_CHECK(K <= DW_MAXK && (K & 1), "dwconv: K=%d unsupported (odd, <= %d)", K, DW_MAXK);
   if (B * Tn == 0) return 0;
+  if (use_lds(dtype, Tn, C)) return emo_dwconv_lds(B, Tn, C, K, x, w, bias, y, 0, nullptr, (hipStream_t)stream);
   dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
   EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)x, w,
                                                                               bias, (T*)y, 0, nullptr)));
@@ -384,6 +399,7 @@ extern "C" int emoasr_dwconv_fwd_stats(int dtype, int B, int Tn, int C, int K, c
                                        const float* bias, void* y, float* part, void* stream) {
   EMO_CHECK(K <= DW_MAXK && (K & 1), "dwconv: K=%d unsupported", K);
   EMO_CHECK(part != nullptr && B * Tn > 0, "dwconv_fwd_stats: needs a non-empty batch and the partials buffer");
+  if (use_lds(dtype, Tn, C)) return emo_dwconv_lds(B, Tn, C, K, x, w, bias, y, 0, part, (hipStream_t)stream);
   dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
   EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)x, w,
                                                                               bias, (T*)y, 0, part)));
@@ -404,6 +420,7 @@ extern "C" int emoasr_dwconv_bwd_x(int dtype, int B, int Tn, int C, int K, const
                                    void* dx, void* stream) {
   EMO_CHECK(K <= DW_MAXK && (K & 1), "dwconv: K=%d unsupported", K);
   if (B * Tn == 0) return 0;
+  if (use_lds(dtype, Tn, C)) return emo_dwconv_lds(B, Tn, C, K, dy, w, nullptr, dx, 1, nullptr, (hipStream_t)stream);
   dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
   EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)dy, w,
                                                                               nullptr, (T*)dx, 1, nullptr)));
@@ -458,6 +475,26 @@ extern "C" int emoasr_bn_swish_fwd(int dtype, int M, int C, const void* y, const
 }
 
 extern "C" long emoasr_bn_swish_bwd_scratch_floats(int M, int C) { return ((long)cdiv(M, BN_SUM_ROWS) + 1) * 2 * C; }
+
+// Passes 1 and 2 only (partial sums + fold): leaves tot[2][C] = (mean(dbn), mean(dbn * xhat)) at
+// scratch + cdiv(M, 16) * 2 * C and accumulates dgamma / dbeta; the apply pass is then part of emoasr_conv_bwd_fused.
+extern "C" int emoasr_bn_swish_bwd_sums(int dtype, int M, int C, const void* dz, const void* y, const float* mean,
+                                        const float* var, const float* gamma, const float* beta, float eps,
+                                        float* dgamma, float* dbeta, float* scratch, float** tot_out, void* stream) {
+  EMO_CHECK(M > 0, "bn_swish_bwd_sums: empty batch");
+  hipStream_t s = (hipStream_t)stream;
+  EMO_CHECK(C % 8 == 0, "bn_swish_bwd_sums: C=%d must be a multiple of 8", C);
+  EMO_CHECK((long)M * C * (dtype == EMO_BF16 ? 2 : 4) < (1L << 32), "bn_swish_bwd_sums: activation larger than 4 GiB");
+  const int npart = cdiv(M, BN_SUM_ROWS);
+  dim3 sgrid(cdiv(C, 256), npart);
+  EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<sgrid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
+                                                                  var, gamma, beta, eps, scratch)));
+  float* tot = scratch + (long)npart * 2 * C;
+  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta);
+  if (tot_out) *tot_out = tot;
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, const void* y,
                                    const float* mean, const float* var, const float* gamma,

@@ -20,6 +20,9 @@ emoasr_epilogue_t plain_ep() {
 int g_ffn_fused = 0;  // bf16, d = 256: the feed-forward block as ONE launch (csrc/ffn.hip) -- measured slower than LayerNorm +
                       // two GEMMs at the L2 batch size (87 vs 40 us, see ffn.hip), so off unless emoasr_set_option("ffn_fused", 1)
 
+int g_conv_fused = 1;  // bf16: the fused convolution-module kernels of csrc/convfused.hip (bit-identical to the separate launches)
+bool conv_fused_ok(int dtype, int d) { return g_conv_fused && dtype == EMO_BF16 && d % 8 == 0; }
+
 int ffn_fwd(int dtype, int M, int d, int F, const emoasr_ffn_params_t& p, const void* x, float res_scale,
             float p_enc, uint64_t s_in, uint64_t s_out, const emoasr_ffn_stash_t& st, void* stream) {
   if (g_ffn_fused && dtype == EMO_BF16 && d == 256 && F % 256 == 0)
@@ -37,6 +40,7 @@ int ffn_fwd(int dtype, int M, int d, int F, const emoasr_ffn_params_t& p, const 
 }  // namespace
 
 void emo_layer_set_ffn_fused(int v) { g_ffn_fused = v; }
+void emo_layer_set_conv_fused(int v) { g_conv_fused = v; }
 
 extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* L,
                                           const emoasr_conformer_fwd_t* io, void* stream) {
@@ -79,14 +83,22 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
     emoasr_epilogue_t e = plain_ep();
     e.bias = L->pw1_b;
     if (emoasr_gemm_nt(dtype, M, 2 * d, d, io->cv_h, d, L->pw1, d, io->g, 2 * d, &e, stream)) return 1;
-    if (emoasr_glu_fwd(dtype, M, d, io->g, io->gl, stream)) return 1;
+    // bf16: GLU + depthwise convolution (+ BatchNorm partial statistics) in one launch, the GLU output never stored
+    const bool fused = conv_fused_ok(dtype, d);
+    if (!fused && emoasr_glu_fwd(dtype, M, d, io->g, io->gl, stream)) return 1;
     const float *bmean = L->bn_rm, *bvar = L->bn_rv;
     if (io->training) {
       EMO_CHECK(io->bn_part && io->bmean && io->bvar, "conformer_layer_fwd: training needs the BatchNorm buffers");
-      if (emoasr_dwconv_fwd_stats(dtype, B, T, d, L->K, io->gl, L->dw_w, L->dw_b, io->c, io->bn_part, stream)) return 1;
+      if (fused) {
+        if (emoasr_glu_dwconv_fwd(dtype, B, T, d, L->K, io->g, L->dw_w, L->dw_b, io->c, io->bn_part, stream)) return 1;
+      } else if (emoasr_dwconv_fwd_stats(dtype, B, T, d, L->K, io->gl, L->dw_w, L->dw_b, io->c, io->bn_part, stream)) {
+        return 1;
+      }
       if (emoasr_bn_stats_finalize(B, T, d, io->bn_part, io->bmean, io->bvar, L->bn_rm, L->bn_rv, 0.1f, L->bn_nbt, stream))
         return 1;
       bmean = io->bmean; bvar = io->bvar;
+    } else if (fused) {
+      if (emoasr_glu_dwconv_fwd(dtype, B, T, d, L->K, io->g, L->dw_w, L->dw_b, io->c, nullptr, stream)) return 1;
     } else if (emoasr_dwconv_fwd(dtype, B, T, d, L->K, io->gl, L->dw_w, L->dw_b, io->c, stream)) {
       return 1;
     }
@@ -198,12 +210,22 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     wgrad(dy, d, d, st->z, d, d, M, G->pw2, 1.f, G->pw2_b);
     emoasr_epilogue_t e = plain_ep();
     if (emoasr_gemm_nn(dtype, M, d, d, dy, d, L->pw2, d, ws + bb.dz, d, &e, stream)) return 1;
-    if (emoasr_bn_swish_bwd(dtype, M, d, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f, ws + bb.dc,
-                            (float*)G->bn_g, (float*)G->bn_b, (float*)(ws + bb.bn_scr), stream)) return 1;
-    if (emoasr_dwconv_bwd_x(dtype, B, T, d, K, ws + bb.dc, L->dw_w, ws + bb.dgl, stream)) return 1;
-    if (emoasr_dwconv_bwd_w(dtype, B, T, d, K, ws + bb.dc, st->gl, (float*)G->dw_w, (float*)G->dw_b, 1,
-                            (float*)(ws + bb.dw_scr), stream)) return 1;
-    if (emoasr_glu_bwd(dtype, M, d, st->g, ws + bb.dgl, ws + bb.dg, stream)) return 1;
+    if (conv_fused_ok(dtype, d)) {
+      // BatchNorm sums + fold, then ONE launch for BatchNorm/Swish apply -> depthwise data gradient -> GLU backward and the
+      // depthwise weight-gradient partials (the GLU output is recomputed from g)
+      float* tot = nullptr;
+      if (emoasr_bn_swish_bwd_sums(dtype, M, d, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f,
+                                   (float*)G->bn_g, (float*)G->bn_b, (float*)(ws + bb.bn_scr), &tot, stream)) return 1;
+      if (emoasr_conv_bwd_fused(dtype, B, T, d, K, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f, tot, st->g,
+                                L->dw_w, ws + bb.dg, (float*)G->dw_w, (float*)G->dw_b, (float*)(ws + bb.dw_scr), stream)) return 1;
+    } else {
+      if (emoasr_bn_swish_bwd(dtype, M, d, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f, ws + bb.dc,
+                              (float*)G->bn_g, (float*)G->bn_b, (float*)(ws + bb.bn_scr), stream)) return 1;
+      if (emoasr_dwconv_bwd_x(dtype, B, T, d, K, ws + bb.dc, L->dw_w, ws + bb.dgl, stream)) return 1;
+      if (emoasr_dwconv_bwd_w(dtype, B, T, d, K, ws + bb.dc, st->gl, (float*)G->dw_w, (float*)G->dw_b, 1,
+                              (float*)(ws + bb.dw_scr), stream)) return 1;
+      if (emoasr_glu_bwd(dtype, M, d, st->g, ws + bb.dgl, ws + bb.dg, stream)) return 1;
+    }
     wgrad(ws + bb.dg, 2 * d, 2 * d, st->cv_h, d, d, M, G->pw1, 1.f, G->pw1_b);
     if (emoasr_gemm_nn(dtype, M, d, 2 * d, ws + bb.dg, 2 * d, L->pw1, d, ws + bb.dh, d, &e, stream)) return 1;
     if (ln_bwd(2, ws + bb.dh, st->at_y, L->cv_ln_g, st->cv_mean, st->cv_rstd, ws + bb.dx2, ws + bb.dx3, G->cv_ln_g, G->cv_ln_b,

@@ -201,6 +201,11 @@ class CTCEngine(_DecoderMixinPlaceholder):
         self.inter_layer = int(cfg.inter_ctc_layer_id) if inter_on else 0
         self.eouts_inter = None
         self._implicit_dgrad = os.environ.get("EMOASR_CONV2_DGRAD", "implicit") == "implicit"
+        self._conv_fused = os.environ.get("EMOASR_CONV_FUSED", "1") != "0"  # csrc/convfused.hip (bit-identical; A/B switch)
+        if not self._conv_fused:
+            from . import lib as _lib
+            _lib.set_option("conv_fused", 0)
+            _lib.set_option("dwconv_lds", 0)
         self._conv_big = os.environ.get("EMOASR_CONV_BIG", "1") != "0"  # A/B switch of csrc/gemm_big.hip (process-wide)
         if not self._conv_big:
             from . import lib as _lib
@@ -403,12 +408,16 @@ class CTCEngine(_DecoderMixinPlaceholder):
         A, d = self.arena, self.d
         h, mean, rstd = ops.layernorm_fwd(x, A.p(norm_name + ".weight"), A.p(norm_name + ".bias"), 1e-5, self._keep)
         g = ops.gemm_nt(h, A.w(name + ".pointwise_conv1.weight", (2 * d, d)), bias=A.p(name + ".pointwise_conv1.bias"))
-        gl = ops.glu_fwd(g)
         wd = A.p(name + ".depthwise_conv.weight")
         bn = name + ".batch_norm"
         rm, rv = self._buffers(bn + ".running_mean"), self._buffers(bn + ".running_var")
         wdk, bd = wd.view(d, wd.shape[-1]), A.p(name + ".depthwise_conv.bias")
-        if training:  # batch statistics come out of the conv kernel (per-block partials + one merge)
+        fused = self._conv_fused and g.dtype == torch.bfloat16  # GLU inside the convolution's staging pass (convfused.hip)
+        gl = None if fused else ops.glu_fwd(g)
+        if fused:
+            c, bmean, bvar = ops.glu_dwconv_fwd(g, B, T, wdk, bd, rm, rv, 0.1, self._buffers(bn + ".num_batches_tracked"),
+                                                training)
+        elif training:  # batch statistics come out of the conv kernel (per-block partials + one merge)
             c, bmean, bvar = ops.dwconv_bn_stats_fwd(gl.view(B, T, d), wdk, bd, rm, rv, 0.1,
                                                      self._buffers(bn + ".num_batches_tracked"))
         else:
@@ -626,14 +635,19 @@ class CTCEngine(_DecoderMixinPlaceholder):
         dy, alpha = self._branch_grad(dx, 1.0, self.p_enc, s_out, pre)
         dz = self._lin_bwd(dy, z, name + ".pointwise_conv2.weight", name + ".pointwise_conv2.bias", alpha)
         bn = name + ".batch_norm"
-        dc = ops.bn_swish_bwd(dz, c, bmean, bvar, A.p(bn + ".weight"), A.p(bn + ".bias"), 1e-5, A.g(bn + ".weight"),
-                              A.g(bn + ".bias"))
         wd = A.p(name + ".depthwise_conv.weight")
         K = wd.shape[-1]
-        dgl = ops.dwconv_bwd_x(dc.view(B, T, d), wd.view(d, K))
-        ops.dwconv_bwd_w(dc.view(B, T, d), gl.view(B, T, d), A.g(name + ".depthwise_conv.weight").view(d, K),
-                         A.g(name + ".depthwise_conv.bias"), accumulate=True)
-        dg = ops.glu_bwd(g, dgl.view(B * T, d))
+        if self._conv_fused and g.dtype == torch.bfloat16:
+            dg = ops.conv_bwd_fused(dz, c, bmean, bvar, A.p(bn + ".weight"), A.p(bn + ".bias"), 1e-5, A.g(bn + ".weight"),
+                                    A.g(bn + ".bias"), g, wd.view(d, K), A.g(name + ".depthwise_conv.weight").view(d, K),
+                                    A.g(name + ".depthwise_conv.bias"), B, T)
+        else:
+            dc = ops.bn_swish_bwd(dz, c, bmean, bvar, A.p(bn + ".weight"), A.p(bn + ".bias"), 1e-5, A.g(bn + ".weight"),
+                                  A.g(bn + ".bias"))
+            dgl = ops.dwconv_bwd_x(dc.view(B, T, d), wd.view(d, K))
+            ops.dwconv_bwd_w(dc.view(B, T, d), gl.view(B, T, d), A.g(name + ".depthwise_conv.weight").view(d, K),
+                             A.g(name + ".depthwise_conv.bias"), accumulate=True)
+            dg = ops.glu_bwd(g, dgl.view(B * T, d))
         dh = self._lin_bwd(dg, h, name + ".pointwise_conv1.weight", name + ".pointwise_conv1.bias")
         r = self._ln_bwd(dh, x, norm_name, mean, rstd, dx, nxt)
         return r if nxt is not None else r[0]

@@ -167,6 +167,9 @@ SIGNATURES = {
     "emoasr_bn_stats": [I, I, I, P, P, P, P, P, F, P],
     "emoasr_bn_swish_fwd": [I, I, I, P, P, P, P, P, F, P, P],
     "emoasr_bn_swish_bwd": [I, I, I, P, P, P, P, P, P, F, P, P, P, P, P],
+    "emoasr_glu_dwconv_fwd": [I, I, I, I, I, P, P, P, P, P, P],
+    "emoasr_bn_swish_bwd_sums": [I, I, I, P, P, P, P, P, P, F, P, P, P, P, P],
+    "emoasr_conv_bwd_fused": [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P],
     "emoasr_strided_copy": [I, I, P, P, I, I, I, I, L, L, L, L, I, P],
     "emoasr_scale_dropout": [I, L, P, P, F, F, U64, P],
     "emoasr_posenc": [I, I, I, I, P, P, F, F, U64, P, P],

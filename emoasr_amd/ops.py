@@ -458,6 +458,44 @@ def dwconv_bn_stats_fwd(x, w, bias, running_mean=None, running_var=None, momentu
     return y, mean, var
 
 
+def glu_dwconv_fwd(g, B, T, w, bias, running_mean=None, running_var=None, momentum=0.1, num_batches_tracked=None,
+                   training=True):
+    """c = depthwise_conv(GLU(g)) in one launch (bf16; g [B*T, 2C]); training: + the BatchNorm batch statistics of c
+    -> (c [B,T,C], mean, var) like dwconv_bn_stats_fwd, else (c, running_mean, running_var)."""
+    C = g.shape[-1] // 2
+    c = torch.empty(B, T, C, device=g.device, dtype=g.dtype)
+    if not training:
+        lib.call("emoasr_glu_dwconv_fwd", dt(g), B, T, C, w.shape[-1], _p(_chk(g)), _p(w), _p(bias), _p(c), None, _stream())
+        return c, running_mean, running_var
+    part = torch.empty(lib.size_query("emoasr_dwconv_stats_floats", B, T, C), device=g.device, dtype=torch.float32)
+    lib.call("emoasr_glu_dwconv_fwd", dt(g), B, T, C, w.shape[-1], _p(_chk(g)), _p(w), _p(bias), _p(c), _p(part), _stream())
+    mean = torch.empty(C, device=g.device, dtype=torch.float32)
+    var = torch.empty(C, device=g.device, dtype=torch.float32)
+    if num_batches_tracked is not None:
+        _chk(num_batches_tracked, torch.int64)
+    lib.call("emoasr_bn_stats_finalize", B, T, C, _p(part), _p(mean), _p(var), _p(running_mean), _p(running_var),
+             momentum, _p(num_batches_tracked), _stream())
+    return c, mean, var
+
+
+def conv_bwd_fused(ds, c, mean, var, gamma, beta, eps, dgamma, dbeta, g, w, dw, dbias, B, T):
+    """backward of GLU -> depthwise conv -> BatchNorm(training) -> Swish in three launches (bf16): BatchNorm sums + fold,
+    then apply / depthwise data gradient / GLU backward / depthwise weight-gradient partials fused, then their fold.
+    ds: gradient w.r.t. the Swish output [B*T, C]; c: the convolution's output; g: the GLU input [B*T, 2C] -> dg."""
+    import ctypes
+    M, C, _ = _rows(_chk(c))
+    K = w.shape[-1]
+    scr = torch.empty(lib.size_query("emoasr_bn_swish_bwd_scratch_floats", M, C), device=c.device, dtype=torch.float32)
+    tot = ctypes.c_void_p()
+    lib.call("emoasr_bn_swish_bwd_sums", dt(c), M, C, _p(_chk(ds, c.dtype)), _p(c), _p(mean), _p(var), _p(gamma), _p(beta),
+             eps, _p(dgamma), _p(dbeta), _p(scr), ctypes.byref(tot), _stream())
+    dg = torch.empty_like(g)
+    wscr = torch.empty(lib.size_query("emoasr_dwconv_bwd_w_scratch_floats", B, T, C, K), device=c.device, dtype=torch.float32)
+    lib.call("emoasr_conv_bwd_fused", dt(c), B, T, C, K, _p(ds), _p(c), _p(mean), _p(var), _p(gamma), _p(beta), eps, tot,
+             _p(_chk(g, c.dtype)), _p(w), _p(dg), _p(dw), _p(dbias), _p(wscr), _stream())
+    return dg
+
+
 def dwconv_bwd_x(dy, w):
     B, T, C = dy.shape
     dx = torch.empty_like(dy)

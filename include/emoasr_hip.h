@@ -269,6 +269,23 @@ long emoasr_bn_swish_bwd_scratch_floats(int M, int C);
 int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, const void* y, const float* mean,
                         const float* var, const float* gamma, const float* beta, float eps, void* dy,
                         float* dgamma, float* dbeta, float* scratch, void* stream);
+/* ---- fused convolution-module kernels (csrc/convfused.hip; bf16, K <= 31, C % 8 == 0): bit-identical to the separate
+ * launches they replace (every intermediate is rounded to bf16 at the same point).
+ * emoasr_glu_dwconv_fwd: c = depthwise_conv(GLU(g)), g [B*T, 2C]; part (may be NULL) receives the per-block BatchNorm
+ *   partial statistics of emoasr_dwconv_fwd_stats.  conformer.py:126-131.
+ * emoasr_bn_swish_bwd_sums: passes 1-2 of emoasr_bn_swish_bwd (dgamma / dbeta accumulated; *tot_out = the [2][C] means
+ *   inside `scratch`).
+ * emoasr_conv_bwd_fused: given those means, ds (gradient w.r.t. the Swish output), cv (the depthwise convolution's output)
+ *   and g -> dg [B*T, 2C] (BatchNorm/Swish backward, depthwise data gradient, GLU backward) and dw [C,K] / dbias [C]
+ *   accumulated (the GLU output is recomputed from g).  scratch: emoasr_dwconv_bwd_w_scratch_floats() floats. */
+int emoasr_glu_dwconv_fwd(int dtype, int B, int Tn, int C, int K, const void* g, const float* w, const float* bias, void* c,
+                          float* part, void* stream);
+int emoasr_bn_swish_bwd_sums(int dtype, int M, int C, const void* dz, const void* y, const float* mean, const float* var,
+                             const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta, float* scratch,
+                             float** tot_out, void* stream);
+int emoasr_conv_bwd_fused(int dtype, int B, int Tn, int C, int K, const void* ds, const void* cv, const float* mean,
+                          const float* var, const float* gamma, const float* beta, float eps, const float* tot, const void* g,
+                          const float* w, void* dg, float* dw, float* dbias, float* scratch, void* stream);
 
 /* ---- element-wise / layout helpers ------------------------------------------ */
 /* out (contiguous [d0,d1,d2,d3], dtype_out) (+)= in[strides s0..s3 (elements), dtype_in] */

@@ -283,6 +283,55 @@ def test_conv2_large_tile_kernels(dev, bm, B, T, Fd):
         lib.set_option("conv_big", 1)
 
 
+@pytest.mark.parametrize("B,T,C,K", [(3, 70, 256, 31), (2, 33, 256, 15), (2, 20, 144, 31), (1, 100, 512, 7), (4, 320, 256, 31)])
+def test_fused_conv_module_kernels_are_bit_identical(dev, B, T, C, K):
+    """csrc/convfused.hip against the separate launches it replaces (bf16): the LDS-staged depthwise convolution, GLU fused
+    into it, and BatchNorm/Swish apply -> depthwise data gradient -> GLU backward + weight-gradient partials in one launch.
+    Every intermediate is rounded at the same point, so all outputs must be EQUAL, not close."""
+    from emoasr_amd import lib, ops
+    dt_ = torch.bfloat16
+    g = _rnd(dev, B * T, 2 * C, dtype=dt_)
+    w, bias = _rnd(dev, C, K, scale=K ** -0.5), _rnd(dev, C, scale=0.1)
+    gamma, beta = 1 + 0.1 * _rnd(dev, C), 0.1 * _rnd(dev, C)
+    ds = _rnd(dev, B * T, C, dtype=dt_)
+    nbt = torch.zeros((), device=dev, dtype=torch.int64)
+
+    def unfused():
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        gl = ops.glu_fwd(g)
+        c, mean, var = ops.dwconv_bn_stats_fwd(gl.view(B, T, C), w, bias, rm, rv, 0.1, nbt.clone())
+        c_eval = ops.dwconv_fwd(gl.view(B, T, C), w, bias)
+        dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dc = ops.bn_swish_bwd(ds, c.view(B * T, C), mean, var, gamma, beta, 1e-5, dgam, dbet)
+        dgl = ops.dwconv_bwd_x(dc.view(B, T, C), w)
+        dw, db = torch.zeros(C, K, device=dev), torch.zeros(C, device=dev)
+        ops.dwconv_bwd_w(dc.view(B, T, C), gl.view(B, T, C), dw, db, accumulate=True)
+        dg = ops.glu_bwd(g, dgl.view(B * T, C))
+        return dict(c=c, mean=mean, var=var, rm=rm, rv=rv, c_eval=c_eval, dgam=dgam, dbet=dbet, dw=dw, db=db, dg=dg, dgl=dgl)
+
+    def fused():
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        c, mean, var = ops.glu_dwconv_fwd(g, B, T, w, bias, rm, rv, 0.1, nbt.clone(), True)
+        c_eval = ops.glu_dwconv_fwd(g, B, T, w, bias, rm, rv, training=False)[0]
+        dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dw, db = torch.zeros(C, K, device=dev), torch.zeros(C, device=dev)
+        dg = ops.conv_bwd_fused(ds, c.view(B * T, C), mean, var, gamma, beta, 1e-5, dgam, dbet, g, w, dw, db, B, T)
+        return dict(c=c, mean=mean, var=var, rm=rm, rv=rv, c_eval=c_eval, dgam=dgam, dbet=dbet, dw=dw, db=db, dg=dg)
+
+    try:
+        lib.set_option("dwconv_lds", 0)
+        ref = unfused()          # the round-1 kernels
+        lib.set_option("dwconv_lds", 1)
+        lds = unfused()          # same sequence, LDS-staged stencils
+        got = fused()
+    finally:
+        lib.set_option("dwconv_lds", 1)
+    for k, v in ref.items():
+        assert torch.equal(lds[k], v), f"LDS-staged dwconv: {k} differs"
+        if k in got:
+            assert torch.equal(got[k], v), f"fused: {k} differs (max {(got[k].float() - v.float()).abs().max().item():.3e})"
+
+
 # ---------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("N,eps", [(256, 1e-5), (256, 1e-12), (64, 1e-5), (1024, 1e-5)])
