@@ -79,6 +79,14 @@ class DecoderInfer(Structure):
                 ("ln_out", LnP), ("out", Lin), ("logits_last", c_void_p), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t)]
 
 
+class DecoderStep(Structure):
+    _fields_ = [("nb", c_int), ("Lmax", c_int), ("T", c_int), ("dd", c_int), ("H", c_int), ("F", c_int), ("V", c_int),
+                ("ids", c_void_p), ("pos", c_void_p), ("klens", c_void_p),
+                ("embed", c_void_p), ("pe", c_void_p), ("emb_scale", c_float),
+                ("kmem", c_void_p), ("kv", POINTER(c_void_p)), ("kcache", c_void_p), ("vcache", c_void_p),
+                ("ln_out", LnP), ("out", Lin), ("logits_last", c_void_p), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t)]
+
+
 class BertLayer(Structure):
     _fields_ = [("qkv", Lin), ("attn_out", Lin), ("ln_attn", LnP), ("inter", Lin), ("out", Lin), ("ln_out", LnP)]
 
@@ -88,6 +96,31 @@ class BertInfer(Structure):
                 ("ids", c_void_p), ("word_emb", c_void_p), ("pe", c_void_p), ("ln_emb", LnP), ("klens", c_void_p),
                 ("transform", Lin), ("ln_transform", LnP), ("out_bias", c_void_p), ("logp", c_void_p),
                 ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t)]
+
+
+class BertStep(Structure):
+    _fields_ = [("nb", c_int), ("Lmax", c_int), ("d", c_int), ("H", c_int), ("F", c_int), ("V", c_int),
+                ("ids", c_void_p), ("pos", c_void_p), ("klens", c_void_p),
+                ("word_emb", c_void_p), ("pe", c_void_p), ("ln_emb", LnP), ("kcache", c_void_p), ("vcache", c_void_p),
+                ("transform", Lin), ("ln_transform", LnP), ("out_bias", c_void_p), ("logp", c_void_p),
+                ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t)]
+
+
+class BeamUpdate(Structure):
+    _fields_ = [("bw", c_int), ("cw", c_int), ("eos", c_int), ("one_minus_lam", c_float), ("lam", c_float), ("mu", c_float),
+                ("len_weight", ctypes.c_double), ("vals", c_void_p), ("cands", c_void_p), ("lm_at", c_void_p), ("psi", c_void_p),
+                ("score", c_void_p), ("score_ctc", c_void_p),
+                ("n_ids", c_void_p), ("n_parent", c_void_p), ("n_pcand", c_void_p), ("n_last", c_void_p),
+                ("n_outlen", c_void_p), ("n_klens", c_void_p), ("hist_parent", c_void_p), ("hist_token", c_void_p),
+                ("res_score", c_void_p), ("res_step", c_void_p), ("res_parent", c_void_p), ("state", c_void_p)]
+
+
+class JointStep(Structure):
+    _fields_ = [("dec_nl", c_int), ("dec_layers", POINTER(DecoderLayer)), ("dec", DecoderStep),
+                ("lm_nl", c_int), ("lm_layers", POINTER(BertLayer)), ("lm", BertStep),
+                ("dec_k_prev", c_void_p), ("dec_v_prev", c_void_p), ("lm_k_prev", c_void_p), ("lm_v_prev", c_void_p),
+                ("parent", c_void_p), ("scores_pre", c_void_p), ("ctc_x", c_void_p), ("T", c_int), ("blank", c_int),
+                ("states_prev", c_void_p), ("states_cur", c_void_p), ("upd", BeamUpdate)]
 
 
 class FfnParams(Structure):
@@ -154,6 +187,14 @@ SIGNATURES = {
                                    POINTER(ConformerBwd), P],
     "emoasr_transformer_decoder_infer": [I, I, POINTER(DecoderLayer), POINTER(DecoderInfer), P],
     "emoasr_bert_lm_infer": [I, I, POINTER(BertLayer), POINTER(BertInfer), P],
+    "emoasr_transformer_decoder_step": [I, I, POINTER(DecoderLayer), POINTER(DecoderStep), P],
+    "emoasr_bert_lm_step": [I, I, POINTER(BertLayer), POINTER(BertStep), P],
+    "emoasr_beam_cache_gather": [I, I, I, I, I, P, P, P, P, P, P, P],
+    "emoasr_beam_update": [POINTER(BeamUpdate), P],
+    "emoasr_joint_beam_step": [I, POINTER(JointStep), P, P],
+    "emoasr_joint_beam_step_parts": [I, POINTER(JointStep), I, P],
+    "emoasr_joint_beam_graph_build": [I, POINTER(JointStep), I, I, P],
+    "emoasr_joint_beam_graph_launch": [I, I, P],
     "emoasr_attn_fwd": [I, POINTER(AttnArgs), P],
     "emoasr_attn_bwd": [I, POINTER(AttnArgs), P],
     "emoasr_attn_bwd_fused": [I, POINTER(AttnArgs), P, ctypes.c_size_t, P],

@@ -27,6 +27,13 @@ def joint_beam_search(dec, eouts, elens, beam_width, len_weight=0, lm=None, lm_w
     eng = _engine_of(dec)
     assert eouts.shape[0] == 1, "beam search decodes one utterance at a time (decoders/transformer.py:181)"
     V, eos, blank = dec.vocab_size, dec.eos_id, dec.blank_id
+    # the whole step on the device (K / V caches, device-side bookkeeping: one C-ABI call and one flag per step);
+    # EMOASR_DEVICE_BEAM=0 keeps the host bookkeeping below (same results)
+    if (os.environ.get("EMOASR_DEVICE_BEAM", "1") != "0" and os.environ.get("EMOASR_CPP_DECODE", "1") != "0"
+            and beam_width <= 32 and min(V, int(beam_width * CTC_BEAM_WIDTH_RATIO)) <= 32
+            and (lm is None or lm_weight <= 0 or hasattr(lm, "predict_device"))):
+        from .beam_search_device import joint_beam_search_device
+        return joint_beam_search_device(dec, eouts, elens, beam_width, len_weight, lm, lm_weight, decode_ctc_weight)
     dev = eouts.device
     T = eouts.shape[1]
     use_ctc = decode_ctc_weight > 0

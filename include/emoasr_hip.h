@@ -532,6 +532,81 @@ int emoasr_transformer_decoder_infer(int dtype, int nl, const emoasr_decoder_lay
 int emoasr_bert_lm_infer(int dtype, int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_infer_t* io,
                          void* stream);
 
+/* ---- the same two networks one POSITION at a time, with self-attention K / V caches, and the beam bookkeeping on the
+ * device (csrc/decode_rt.hip): a step is a fixed launch sequence without host input, so it can be captured in a HIP graph.
+ * Caches: compute dtype [nl][nb][Lmax][d] (K and V separately).  `pos` (device int) = position of the token in `ids`
+ * (prefix length - 1); klens (device int32 [nb]) = pos + 1.  emoasr_beam_cache_gather re-orders the caches of a new step's
+ * hypotheses by their parent: dst[l][b][t < pos] = src[l][parent[b]][t]. */
+typedef struct emoasr_decoder_step {
+  int nb, Lmax, T, dd, H, F, V;
+  const int* ids; const int* pos; const int* klens;
+  const void* embed; const float* pe; float emb_scale;
+  const int* kmem; const void* const* kv;       /* as in emoasr_decoder_infer_t */
+  void* kcache; void* vcache;
+  emoasr_lnp_t ln_out; emoasr_lin_t out;
+  void* logits_last;                             /* [nb, V] compute dtype */
+  void* ws; size_t ws_bytes;                     /* emoasr_decode_step_ws_bytes() */
+} emoasr_decoder_step_t;
+typedef struct emoasr_bert_step {
+  int nb, Lmax, d, H, F, V;
+  const int* ids; const int* pos; const int* klens;
+  const void* word_emb; const float* pe; emoasr_lnp_t ln_emb;
+  void* kcache; void* vcache;
+  emoasr_lin_t transform; emoasr_lnp_t ln_transform; const float* out_bias;
+  float* logp;                                   /* f32 [nb, V] log-probabilities of the next token */
+  void* ws; size_t ws_bytes;
+} emoasr_bert_step_t;
+size_t emoasr_decode_step_ws_bytes(int dtype, int nb, int d, int H, int F, int V);
+int emoasr_transformer_decoder_step(int dtype, int nl, const emoasr_decoder_layer_t* layers, const emoasr_decoder_step_t* io,
+                                    void* stream);
+int emoasr_bert_lm_step(int dtype, int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_step_t* io, void* stream);
+int emoasr_beam_cache_gather(int dtype, int nl, int nb, int Lmax, int d, const void* src_k, const void* src_v, void* dst_k,
+                             void* dst_v, const int* parent, const int* pos, void* stream);
+/* Beam bookkeeping of one output step (decoders/transformer.py:215-290) for up to 32 beams x 32 candidates, one workgroup:
+ * candidate scores in numpy-float32 arithmetic, accumulated hypothesis scores in double (Python float), stable orders,
+ * <eos> -> result (score + len_weight * len(hyp incl. sos/eos); empty hypotheses dropped), the rest -> the next step's
+ * beams.  All arrays live on the device; `state` carries pos / n_alive / n_results / done between steps (done: the kernel
+ * returns immediately, so replaying a captured step past the end is harmless).  hist_parent / hist_token [max_steps][bw]
+ * record the surviving beams of every step (the host rebuilds the token sequences once, at the end). */
+typedef struct emoasr_beam_state { int pos, n_alive, n_results, done; } emoasr_beam_state_t;
+typedef struct emoasr_beam_update {
+  int bw, cw, eos;
+  float one_minus_lam, lam, mu;                  /* f32(1 - ctc_weight), f32(ctc_weight), f32(lm_weight) */
+  double len_weight;
+  const float* vals; const int* cands;           /* [bw, cw] top candidates of scores_att(+lm) per beam */
+  const float* lm_at;                            /* [bw, cw] LM log-probs at the candidates, or NULL */
+  const float* psi;                              /* [bw, cw] CTC prefix scores, or NULL (no CTC term) */
+  double* score; float* score_ctc;               /* [bw] current beams; overwritten with the next step's */
+  int *n_ids, *n_parent, *n_pcand, *n_last, *n_outlen, *n_klens;   /* [bw] inputs of the next step */
+  int *hist_parent, *hist_token;
+  double* res_score; int* res_step; int* res_parent;               /* [bw] finished hypotheses */
+  emoasr_beam_state_t* state;
+} emoasr_beam_update_t;
+int emoasr_beam_update(const emoasr_beam_update_t* u, void* stream);
+/* One whole output step (cache gather, decoder step, LM step on `side_stream` when given, log-softmax + LM fusion, top-cw,
+ * CTC prefix scores, beam update) from one call.  parent / pcand / last / out_len of the CURRENT beams are upd.n_parent /
+ * n_pcand / n_last / n_outlen as the previous step's update left them; *_prev are the previous step's caches and CTC scorer
+ * states [bw, cw, T, 2] (before the first step: the initial state at [0, 0]).  lm_nl == 0: no LM; upd.psi == NULL: no CTC. */
+typedef struct emoasr_joint_step {
+  int dec_nl; const emoasr_decoder_layer_t* dec_layers; emoasr_decoder_step_t dec;
+  int lm_nl; const emoasr_bert_layer_t* lm_layers; emoasr_bert_step_t lm;
+  const void *dec_k_prev, *dec_v_prev, *lm_k_prev, *lm_v_prev;
+  const int* parent;
+  float* scores_pre;                               /* f32 [bw, V] */
+  const float* ctc_x; int T; int blank;            /* CTC log-probs f32 [T, V] */
+  const float* states_prev; float* states_cur;
+  emoasr_beam_update_t upd;
+} emoasr_joint_step_t;
+int emoasr_joint_beam_step(int dtype, const emoasr_joint_step_t* js, void* stream, void* side_stream);
+/* Parts of the step on ONE stream (mask: 1 = decoder chain incl. its cache gather, 2 = LM chain, 4 = scoring tail), and the
+ * parts as HIP graphs: build captures part 0 / 1 / 2 (decoder / LM / tail) of slot 0 / 1 (even / odd steps), or updates the
+ * instantiated graph with a new utterance's pointers; launch replays it.  The caller orders the three launches of a step
+ * with events: the two chains on two streams, the tail after both (~185 kernels per ~0.1 ms of host time, against
+ * ~1.1 ms for launching them one by one). */
+int emoasr_joint_beam_step_parts(int dtype, const emoasr_joint_step_t* js, int parts, void* stream);
+int emoasr_joint_beam_graph_build(int dtype, const emoasr_joint_step_t* js, int slot, int part, void* stream);
+int emoasr_joint_beam_graph_launch(int slot, int part, void* stream);
+
 /* ---- optimizer (asr/train_asr.py:84-92, torch.optim.Adam semantics) ---------- */
 /* out[0] += sum x^2 */
 int emoasr_sqnorm(long n, const float* x, float* out, void* stream);

@@ -171,3 +171,38 @@ def test_joint_beam_search_bf16_runs(dev):
     hyps, scores, _, _ = model.decode(g["xs"][:1, :n].to(dev), g["xlens"][:1], lm=lm, **DECODE_SETTINGS[2])
     ref = g["decode/2/0/scores"].numpy()
     assert len(hyps) >= 1 and abs(scores[0] - ref[0]) < 0.05 * abs(ref[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_device_beam_search_equals_host_bookkeeping(dev, dtype, monkeypatch):
+    """the device-resident search (K / V caches, one position per step, emoasr_beam_update) against the host bookkeeping
+    over whole-prefix recomputation: same hypotheses in the same order, scores to the last bits of the f32 candidate
+    arithmetic, for all four score combinations, with and without a length bonus; and the device path is the one taken"""
+    from emoasr_amd.modeling import beam_search_device as bsd
+    from emoasr_amd.modeling.lm import LM
+    model, g = _build(dtype, dev)
+    model.eval()
+    lm = LM(SimpleNamespace(**LM_CFG), compute_dtype=dtype)
+    lm.load_state_dict(lm_state(g))
+    lm = lm.to(dev).eval()
+    calls = []
+    orig = bsd.joint_beam_search_device
+    monkeypatch.setattr(bsd, "joint_beam_search_device", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    for si, st in enumerate(DECODE_SETTINGS):
+        for lw in (0.0, 0.3):
+            kw = dict(st, len_weight=lw)
+            for b in range(2):
+                n = int(g["xlens"][b])
+                x, xl = g["xs"][b:b + 1, :n].to(dev), g["xlens"][b:b + 1]
+                monkeypatch.setenv("EMOASR_DEVICE_BEAM", "1")
+                k0 = len(calls)
+                hyps, scores, _, _ = model.decode(x, xl, lm=lm, **kw)
+                assert len(calls) == k0 + 1, "device path not taken"
+                monkeypatch.setenv("EMOASR_DEVICE_BEAM", "0")
+                hyps_h, scores_h, _, _ = model.decode(x, xl, lm=lm, **kw)
+                assert len(calls) == k0 + 1
+                if dtype == torch.float32:
+                    assert hyps == hyps_h, (si, lw, b, hyps, hyps_h)
+                    assert max(abs(a - c) for a, c in zip(scores, scores_h)) < 1e-4, (scores, scores_h)
+                else:  # bf16: cached K / V and recomputed prefixes round alike, but near-ties may still flip
+                    assert hyps[0] == hyps_h[0] and abs(scores[0] - scores_h[0]) < 2e-2 * abs(scores_h[0]) + 1e-3
