@@ -185,6 +185,18 @@ __global__ __launch_bounds__(256) void cache_gather_kernel(int nl, int nb, int L
     reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[i];
 }
 
+int g_decode_fused = 0;  // bf16: LayerNorm / residual / cache-append folded into rowlin + attn_step (csrc/rowlin.hip): 8 / 5
+                         // launches per decoder / LM layer instead of 12 / 8 -- measured SLOWER (0.74 vs 0.68 ms per step: a
+                         // rowlin launch with a LayerNorm inside takes 8 us against 4.7 + 4.5 for GEMM + LayerNorm, and the
+                         // single-query attention 5.5 us), so off unless emoasr_set_option("decode_fused", 1)
+
+// y = act(LN?(x) . W^T + b) (+ r | LN(r)) for the step's <= 16 rows (bf16)
+int rl(int M, int N, int K, const void* x, const emoasr_lnp_t* lna, const emoasr_lin_t& l, int act, const void* res,
+       const emoasr_lnp_t* lnr, void* y, int out_f32, void* stream) {
+  return emoasr_rowlin(M, N, K, x, K, lna ? lna->g : nullptr, lna ? lna->b : nullptr, 1e-12f, l.w, l.b, act, res, N,
+                       lnr ? lnr->g : nullptr, lnr ? lnr->b : nullptr, 1e-12f, y, out_f32, N, stream);
+}
+
 int attn_cached(int dtype, int nb, int Lmax, int d, int H, const void* qkv, const void* kc, const void* vc, const int* klens,
                 void* o, float* lse, void* stream) {
   emoasr_attn_t a{};
@@ -197,6 +209,8 @@ int attn_cached(int dtype, int nb, int Lmax, int d, int H, const void* qkv, cons
 }
 
 }  // namespace
+
+void emo_decode_set_fused(int v) { g_decode_fused = v; }
 
 extern "C" size_t emoasr_decode_step_ws_bytes(int dtype, int nb, int d, int H, int F, int V) {
   const size_t esz = dtype == EMO_BF16 ? 2 : 4;
@@ -235,6 +249,32 @@ extern "C" int emoasr_transformer_decoder_step(int dtype, int nl, const emoasr_d
   EMO_DISPATCH(dtype, (step_embed_kernel<T><<<cdiv(nb * dd, 256), 256, 0, s>>>(nb, dd, io->ids, (const T*)io->embed, io->pe,
                                                                                 io->emb_scale, io->pos, (T*)x)));
   const size_t layer_bytes = (size_t)nb * Lmax * dd * esz;
+  if (g_decode_fused && dtype == EMO_BF16 && nb <= 16 && dd <= 1024 && F <= 1024 && dd % 32 == 0 && F % 32 == 0 && (dd / H) % 8 == 0) {
+    // 8 launches per layer instead of 12: LayerNorms inside the following projection, cache append inside the attention
+    for (int li = 0; li < nl; ++li) {
+      const emoasr_decoder_layer_t& Ly = layers[li];
+      char* kc = (char*)io->kcache + li * layer_bytes;
+      char* vc = (char*)io->vcache + li * layer_bytes;
+      if (rl(nb, 3 * dd, dd, x, &Ly.ln1, Ly.qkv, EMOASR_ACT_NONE, nullptr, nullptr, qkv, 0, stream)) return 1;
+      if (emoasr_attn_step(nb, dd, H, Lmax, qkv, kc, vc, io->pos, o, stream)) return 1;
+      if (rl(nb, dd, dd, o, nullptr, Ly.out, EMOASR_ACT_NONE, x, nullptr, x2, 0, stream)) return 1;
+      if (rl(nb, dd, dd, x2, &Ly.ln2, Ly.q2, EMOASR_ACT_NONE, nullptr, nullptr, q, 0, stream)) return 1;
+      {
+        emoasr_attn_t a{};
+        a.B = nb; a.H = H; a.DK = dd / H; a.Tq = 1; a.Tk = T;
+        a.ldq = dd; a.ldk = a.ldv = 2 * dd; a.ldo = dd;
+        a.q = q; a.k = io->kv[li]; a.v = (const char*)io->kv[li] + (size_t)dd * esz;
+        a.klens = io->kmem; a.scale = 1.f / sqrtf((float)(dd / H));
+        a.out = o; a.lse = lse;
+        if (emoasr_attn_fwd(dtype, &a, stream)) return 1;
+      }
+      if (rl(nb, dd, dd, o, nullptr, Ly.out2, EMOASR_ACT_NONE, x2, nullptr, x, 0, stream)) return 1;
+      if (rl(nb, F, dd, x, &Ly.ln3, Ly.w1, EMOASR_ACT_RELU, nullptr, nullptr, act, 0, stream)) return 1;
+      if (rl(nb, dd, F, act, nullptr, Ly.w2, EMOASR_ACT_NONE, x, nullptr, x2, 0, stream)) return 1;
+      void* t = x; x = x2; x2 = t;
+    }
+    return rl(nb, io->V, dd, x, &io->ln_out, io->out, EMOASR_ACT_NONE, nullptr, nullptr, io->logits_last, 0, stream);
+  }
   for (int li = 0; li < nl; ++li) {
     const emoasr_decoder_layer_t& Ly = layers[li];
     char* kc = (char*)io->kcache + li * layer_bytes;
@@ -286,8 +326,31 @@ extern "C" int emoasr_bert_lm_step(int dtype, int nl, const emoasr_bert_layer_t*
   EMO_CHECK(ws.ok, "bert_lm_step: scratch too small (%zu bytes given)", io->ws_bytes);
   EMO_DISPATCH(dtype, (step_embed_kernel<T><<<cdiv(nb * d, 256), 256, 0, s>>>(nb, d, io->ids, (const T*)io->word_emb, io->pe, 1.f,
                                                                               io->pos, (T*)y)));
-  if (emoasr_layernorm_fwd(dtype, nb, d, y, io->ln_emb.g, io->ln_emb.b, 1e-12f, x, nullptr, nullptr, stream)) return 1;
   const size_t layer_bytes = (size_t)nb * Lmax * d * esz;
+  if (g_decode_fused && dtype == EMO_BF16 && nb <= 16 && d <= 1024 && F <= 1024 && d % 32 == 0 && F % 32 == 0 && (d / H) % 8 == 0) {
+    // post-LN blocks, 5 launches per layer instead of 8: `y` holds the block's pre-LayerNorm output and `pend` the
+    // LayerNorm still to be applied to it -- inside the next projection (A operand) and inside the next residual add
+    const emoasr_lnp_t* pend = &io->ln_emb;
+    void* ycur = y;   // embeddings, not yet normalised
+    void* yalt = x;
+    for (int li = 0; li < nl; ++li) {
+      const emoasr_bert_layer_t& Ly = layers[li];
+      char* kc = (char*)io->kcache + li * layer_bytes;
+      char* vc = (char*)io->vcache + li * layer_bytes;
+      if (rl(nb, 3 * d, d, ycur, pend, Ly.qkv, EMOASR_ACT_NONE, nullptr, nullptr, qkv, 0, stream)) return 1;
+      if (emoasr_attn_step(nb, d, H, Lmax, qkv, kc, vc, io->pos, o, stream)) return 1;
+      if (rl(nb, d, d, o, nullptr, Ly.attn_out, EMOASR_ACT_NONE, ycur, pend, yalt, 0, stream)) return 1;       // y1
+      if (rl(nb, F, d, yalt, &Ly.ln_attn, Ly.inter, 3 /* GELU */, nullptr, nullptr, act, 0, stream)) return 1;
+      if (rl(nb, d, F, act, nullptr, Ly.out, EMOASR_ACT_NONE, yalt, &Ly.ln_attn, ycur, 0, stream)) return 1;  // y2
+      pend = &Ly.ln_out;
+    }
+    if (rl(nb, d, d, ycur, pend, io->transform, 3, nullptr, nullptr, t1, 0, stream)) return 1;
+    emoasr_lin_t tied{io->word_emb, io->out_bias};
+    if (io->raw_logits) return rl(nb, V, d, t1, &io->ln_transform, tied, EMOASR_ACT_NONE, nullptr, nullptr, io->logp, 1, stream);
+    if (rl(nb, V, d, t1, &io->ln_transform, tied, EMOASR_ACT_NONE, nullptr, nullptr, logits, 1, stream)) return 1;
+    return emoasr_log_softmax(EMO_F32, nb, V, logits, V, nullptr, 0, 0.f, io->logp, V, stream);
+  }
+  if (emoasr_layernorm_fwd(dtype, nb, d, y, io->ln_emb.g, io->ln_emb.b, 1e-12f, x, nullptr, nullptr, stream)) return 1;
   for (int li = 0; li < nl; ++li) {
     const emoasr_bert_layer_t& Ly = layers[li];
     char* kc = (char*)io->kcache + li * layer_bytes;
@@ -305,6 +368,7 @@ extern "C" int emoasr_bert_lm_step(int dtype, int nl, const emoasr_bert_layer_t*
   if (emoasr_layernorm_fwd(dtype, nb, d, t1, io->ln_transform.g, io->ln_transform.b, 1e-12f, t2, nullptr, nullptr, stream))
     return 1;
   emoasr_lin_t tied{io->word_emb, io->out_bias};
+  if (io->raw_logits) return linear(dtype, nb, V, d, t2, d, tied, io->logp, EMOASR_ACT_NONE, nullptr, stream, 1);
   if (linear(dtype, nb, V, d, t2, d, tied, logits, EMOASR_ACT_NONE, nullptr, stream, 1)) return 1;
   EMO_LAUNCH_CHECK();
   return emoasr_log_softmax(EMO_F32, nb, V, logits, V, nullptr, 0, 0.f, io->logp, V, stream);
@@ -445,11 +509,20 @@ extern "C" int emoasr_joint_beam_step_parts(int dtype, const emoasr_joint_step_t
   if (parts & 4) {
     // scores_att (+ mu * lm: the reference adds the LM term in place, so it is inside scores_att when the CTC re-scoring
     // adds it again -- see modeling/beam_search.py)
-    if (emoasr_log_softmax(dtype, bw, V, d.logits_last, V, use_lm ? l.logp : nullptr, V, js->upd.mu, js->scores_pre, V, s)) return 1;
     const emoasr_beam_update_t& u = js->upd;
-    const bool want_aux = use_lm && u.lm_at != nullptr;
-    if (emoasr_topk(bw, V, u.cw, js->scores_pre, V, want_aux ? l.logp : nullptr, V, (float*)u.vals, (int*)u.cands,
-                    want_aux ? (float*)u.lm_at : nullptr, s)) return 1;
+    if (use_lm && l.raw_logits) {
+      // one launch: both log-softmaxes, the fusion and the candidate selection (the LM step left its raw logits in l.logp)
+      if (emoasr_beam_scores_topk(dtype, bw, V, u.cw, d.logits_last, V, l.logp, V, js->upd.mu, (float*)u.vals, (int*)u.cands,
+                                  (float*)u.lm_at, s)) return 1;
+    } else if (!use_lm) {
+      if (emoasr_beam_scores_topk(dtype, bw, V, u.cw, d.logits_last, V, nullptr, 0, 0.f, (float*)u.vals, (int*)u.cands, nullptr,
+                                  s)) return 1;
+    } else {
+      if (emoasr_log_softmax(dtype, bw, V, d.logits_last, V, l.logp, V, js->upd.mu, js->scores_pre, V, s)) return 1;
+      const bool want_aux = u.lm_at != nullptr;
+      if (emoasr_topk(bw, V, u.cw, js->scores_pre, V, want_aux ? l.logp : nullptr, V, (float*)u.vals, (int*)u.cands,
+                      want_aux ? (float*)u.lm_at : nullptr, s)) return 1;
+    }
     if (u.psi) {
       if (emoasr_ctc_prefix_score(bw, js->T, V, u.cw, js->ctc_x, js->states_prev, u.cw, js->parent, u.n_pcand, nullptr, u.n_last,
                                   u.n_outlen, u.cands, js->blank, u.eos, (float*)u.psi, js->states_cur, s)) return 1;

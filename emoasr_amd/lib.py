@@ -102,7 +102,7 @@ class BertStep(Structure):
     _fields_ = [("nb", c_int), ("Lmax", c_int), ("d", c_int), ("H", c_int), ("F", c_int), ("V", c_int),
                 ("ids", c_void_p), ("pos", c_void_p), ("klens", c_void_p),
                 ("word_emb", c_void_p), ("pe", c_void_p), ("ln_emb", LnP), ("kcache", c_void_p), ("vcache", c_void_p),
-                ("transform", Lin), ("ln_transform", LnP), ("out_bias", c_void_p), ("logp", c_void_p),
+                ("transform", Lin), ("ln_transform", LnP), ("out_bias", c_void_p), ("logp", c_void_p), ("raw_logits", c_int),
                 ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t)]
 
 
@@ -191,6 +191,9 @@ SIGNATURES = {
     "emoasr_bert_lm_step": [I, I, POINTER(BertLayer), POINTER(BertStep), P],
     "emoasr_beam_cache_gather": [I, I, I, I, I, P, P, P, P, P, P, P],
     "emoasr_beam_update": [POINTER(BeamUpdate), P],
+    "emoasr_beam_scores_topk": [I, I, I, I, P, L, P, L, F, P, P, P, P],
+    "emoasr_rowlin": [I, I, I, P, L, P, P, F, P, P, I, P, L, P, P, F, P, I, L, P],
+    "emoasr_attn_step": [I, I, I, I, P, P, P, P, P, P],
     "emoasr_joint_beam_step": [I, POINTER(JointStep), P, P],
     "emoasr_joint_beam_step_parts": [I, POINTER(JointStep), I, P],
     "emoasr_joint_beam_graph_build": [I, POINTER(JointStep), I, I, P],

@@ -10,6 +10,7 @@ flag back:
   * the token sequences are rebuilt once, at the end, from the per-step (parent, token) history.
 """
 import ctypes
+import gc
 import math
 import os
 import time
@@ -66,6 +67,8 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
     Lmax = max_steps + 1
     A = eng.arena
     timing = os.environ.get("EMOASR_BEAM_TIMING") == "1"
+    if os.environ.get("EMOASR_DECODE_FUSED"):   # A/B switch of csrc/rowlin.hip inside the cached steps
+        lib.set_option("decode_fused", int(os.environ["EMOASR_DECODE_FUSED"]))
     if timing:
         torch.cuda.synchronize()
         t_start = time.perf_counter()
@@ -144,6 +147,7 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
                 _lin(l.transform, LA.w(cp + "transform.dense.weight"), LA.p(cp + "transform.dense.bias"))
                 _ln(l.ln_transform, LA.p(cp + "transform.LayerNorm.weight"), LA.p(cp + "transform.LayerNorm.bias"))
                 l.out_bias, l.logp = LA.p(cp + "bias").data_ptr(), Bf.lm_logp.data_ptr()
+                l.raw_logits = 1   # the scoring kernel does both log-softmaxes (emoasr_beam_scores_topk)
                 l.ws, l.ws_bytes = ws_lm.data_ptr(), ws_lm.numel()
                 js.lm_k_prev, js.lm_v_prev = Bf.lm_k[prev].data_ptr(), Bf.lm_v[prev].data_ptr()
             js.parent, js.scores_pre = Bf.parent.data_ptr(), Bf.scores_pre.data_ptr()
@@ -195,6 +199,10 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
         ev = torch.cuda.Event()
         ev_tail, ev_lm = torch.cuda.Event(), torch.cuda.Event()
         pending = False
+        # a generation-2 garbage collection in the middle of the loop stalls a 0.65 ms step for 10-15 ms (measured: one or
+        # two per utterance); the loop allocates next to nothing, so collection simply waits until it is over
+        gc_was_on = gc.isenabled()
+        gc.disable()
         for i in range(max_steps):
             if use_graph:
                 k = i & 1
@@ -217,6 +225,8 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
             ev.record(main)
             pending = True
         main.synchronize()
+        if gc_was_on:
+            gc.enable()
         Bf.state_host.copy_(Bf.state)
         n_done = int(Bf.state_host[0])               # effective steps (pos advances only while the search is live)
         if side is not None:

@@ -832,3 +832,26 @@ def fbank(wav, frame_len, frame_shift, n_fft, n_mel, preemph, window, mel_fb):
     lib.call("emoasr_fbank", _p(wav), n, frame_len, frame_shift, n_fft, n_mel, preemph, _p(window), _p(mel_fb),
              _p(feats), T, _stream())
     return feats
+
+
+# ---- small-M decode-step kernels (csrc/rowlin.hip) -------------------------------------------------------------------
+def rowlin(x, w, bias=None, act=ACT_NONE, ln_a=None, res=None, ln_r=None, out_f32=False, eps=1e-12):
+    """y[M <= 16, N] = act(LN_a?(x) @ w^T + bias) (+ res | LN_r(res)); bf16; ln_a / ln_r = (gamma, beta)"""
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    ga, ba = ln_a if ln_a is not None else (None, None)
+    gr, br = ln_r if ln_r is not None else (None, None)
+    lib.call("emoasr_rowlin", M, N, K, _p(_chk(x, torch.bfloat16)), x.stride(0), _p(ga), _p(ba), eps, _p(_chk(w, torch.bfloat16)),
+             _p(bias), act, _p(res), 0 if res is None else res.stride(0), _p(gr), _p(br), eps, _p(y), int(out_f32), N, _stream())
+    return y
+
+
+def attn_step(qkv, kcache, vcache, pos, H):
+    """single-query attention of every row of qkv [nb, 3d] against its cache [nb, Lmax, d]; appends k, v at *pos (device int)"""
+    nb, d3 = qkv.shape
+    d = d3 // 3
+    out = torch.empty(nb, d, device=qkv.device, dtype=qkv.dtype)
+    lib.call("emoasr_attn_step", nb, d, H, kcache.shape[1], _p(_chk(qkv, torch.bfloat16)), _p(kcache), _p(vcache), _p(pos), _p(out),
+             _stream())
+    return out

@@ -369,6 +369,11 @@ int emoasr_log_softmax(int dtype, int M, int V, const void* x, long ldx, const f
  * indices into aux_out */
 int emoasr_topk(int M, int V, int k, const float* x, long ldx, const float* aux, long ldaux, float* vals,
                 int* idx, float* aux_out, void* stream);
+/* log_softmax(dec row) + mu * log_softmax(lm row) and its k largest entries in one launch (the beam search needs nothing
+ * else of the score rows): vals / idx as emoasr_topk, lm_at = log_softmax(lm)[idx].  dec: compute dtype [M, V]; lm: f32 raw
+ * logits [M, V] or NULL. */
+int emoasr_beam_scores_topk(int dtype, int M, int V, int k, const void* dec, long ldd, const float* lm, long ldl, float mu,
+                            float* vals, int* idx, float* lm_at, void* stream);
 /* CTCPrefixScorer.initial_state: r f32 [T,2] from the CTC log-probs x f32 [T,V] */
 int emoasr_ctc_prefix_init(int T, int V, const float* x, int blank, float* r, void* stream);
 /* CTCPrefixScorer.__call__ for nb beams x cw candidates.  Beam m's previous state is
@@ -554,12 +559,21 @@ typedef struct emoasr_bert_step {
   void* kcache; void* vcache;
   emoasr_lin_t transform; emoasr_lnp_t ln_transform; const float* out_bias;
   float* logp;                                   /* f32 [nb, V] log-probabilities of the next token */
+  int raw_logits;                                /* 1: leave the raw logits in logp (no log-softmax) */
   void* ws; size_t ws_bytes;
 } emoasr_bert_step_t;
 size_t emoasr_decode_step_ws_bytes(int dtype, int nb, int d, int H, int F, int V);
 int emoasr_transformer_decoder_step(int dtype, int nl, const emoasr_decoder_layer_t* layers, const emoasr_decoder_step_t* io,
                                     void* stream);
 int emoasr_bert_lm_step(int dtype, int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_step_t* io, void* stream);
+/* Small-M pieces of those steps (csrc/rowlin.hip; bf16): y[M <= 16, N] = act(LN?(x) . W^T + bias) (+ res | LayerNorm(res)) with the
+ * LayerNorms computed inside the kernel, and single-query attention of row b of qkv [nb, 3d] against the caches, appending
+ * the new key / value at *pos first. */
+int emoasr_rowlin(int M, int N, int K, const void* x, long ldx, const float* lna_g, const float* lna_b, float lna_eps,
+                  const void* w, const float* bias, int act, const void* res, long ldres, const float* lnr_g,
+                  const float* lnr_b, float lnr_eps, void* y, int out_f32, long ldy, void* stream);
+int emoasr_attn_step(int nb, int d, int H, int Lmax, const void* qkv, void* kcache, void* vcache, const int* pos, void* out,
+                     void* stream);
 int emoasr_beam_cache_gather(int dtype, int nl, int nb, int Lmax, int d, const void* src_k, const void* src_v, void* dst_k,
                              void* dst_v, const int* parent, const int* pos, void* stream);
 /* Beam bookkeeping of one output step (decoders/transformer.py:215-290) for up to 32 beams x 32 candidates, one workgroup:

@@ -875,3 +875,47 @@ def test_layernorm_bwd_branch_and_deferred(dev, dtype):
     _close(db1, db0, 1e-5, "deferred dbeta")
     _close(dg2, dg0, 1e-5, "second deferred item")
     assert deferred == [] and dx2.shape == dx0.shape
+
+
+@pytest.mark.parametrize("M,N,K", [(10, 768, 256), (10, 256, 1024), (1, 10000, 256), (16, 1024, 256), (7, 40, 64)])
+def test_rowlin_small_m_linear(dev, M, N, K):
+    """csrc/rowlin.hip: linear layers of the cached decode steps with the LayerNorms folded in, against torch"""
+    from emoasr_amd import ops
+    bf = torch.bfloat16
+    x = _rnd(dev, M, K, dtype=bf)
+    w = _rnd(dev, N, K, dtype=bf, scale=K ** -0.5)
+    b = _rnd(dev, N, scale=0.3)
+    ga, ba = 1 + 0.1 * _rnd(dev, K), 0.1 * _rnd(dev, K)
+    gr, br = 1 + 0.1 * _rnd(dev, N), 0.1 * _rnd(dev, N)
+    res = _rnd(dev, M, N, dtype=bf)
+    xf, wf = x.float(), w.float()
+    ln = lambda t, g, bb: F.layer_norm(t, t.shape[-1:], g, bb, 1e-12)
+    _close(ops.rowlin(x, w, b), xf @ wf.t() + b, 1.5e-2, "plain")
+    _close(ops.rowlin(x, w, b, act=ops.ACT_RELU, res=res), F.relu(xf @ wf.t() + b) + res.float(), 1.5e-2, "relu + residual")
+    h = ln(xf, ga, ba).to(bf).float()
+    _close(ops.rowlin(x, w, b, act=ops.ACT_GELU, ln_a=(ga, ba)), F.gelu(h @ wf.t() + b), 1.5e-2, "LN prologue + gelu")
+    if N <= 1024:
+        want = xf @ wf.t() + b + ln(res.float(), gr, br).to(bf).float()
+        _close(ops.rowlin(x, w, b, res=res, ln_r=(gr, br)), want, 1.5e-2, "residual = LayerNorm(res)")
+    _close(ops.rowlin(x, w, None, ln_a=(ga, ba), out_f32=True), h @ wf.t(), 1.5e-2, "f32 out")
+
+
+@pytest.mark.parametrize("pos", [0, 5, 40, 63])
+def test_attn_step_single_query_with_cache_append(dev, pos):
+    from emoasr_amd import ops
+    bf = torch.bfloat16
+    nb, d, H, Lmax = 10, 256, 4, 64
+    qkv = _rnd(dev, nb, 3 * d, dtype=bf)
+    kc, vc = _rnd(dev, nb, Lmax, d, dtype=bf), _rnd(dev, nb, Lmax, d, dtype=bf)
+    kc0, vc0 = kc.clone(), vc.clone()
+    p = torch.tensor([pos], device=dev, dtype=torch.int32)
+    out = ops.attn_step(qkv, kc, vc, p, H)
+    assert torch.equal(kc[:, pos], qkv[:, d:2 * d]) and torch.equal(vc[:, pos], qkv[:, 2 * d:])
+    keep = torch.ones(Lmax, dtype=torch.bool, device=dev)
+    keep[pos] = False
+    assert torch.equal(kc[:, keep], kc0[:, keep]) and torch.equal(vc[:, keep], vc0[:, keep])
+    q = qkv[:, :d].float().view(nb, H, 1, d // H)
+    k = kc[:, :pos + 1].float().view(nb, pos + 1, H, d // H).transpose(1, 2)
+    v = vc[:, :pos + 1].float().view(nb, pos + 1, H, d // H).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / (d // H) ** 0.5, -1) @ v).transpose(1, 2).reshape(nb, d)
+    _close(out, ref, 1.5e-2, "attn_step")
