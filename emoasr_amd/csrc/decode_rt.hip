@@ -4,6 +4,7 @@
 // minus the work the beam search never uses (logits of earlier positions, K/V of the unchanged memory).
 // Reference: decoders/transformer.py:148-159 + transformer.py:156-198; lm/modeling/transformer.py:62-77.
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/emoasr_hip.h"
 
@@ -468,6 +469,13 @@ __global__ __launch_bounds__(256) void beam_update_kernel(emoasr_beam_update_t u
   st->n_results = nres;
   st->done = (nres >= bw || a == 0) ? 1 : 0;
   st->pos = pos + 1;
+  if (u.host_mirror) {   // the host's view of the search: written last, `pos` after the rest
+    volatile int* hm = u.host_mirror;
+    hm[1] = a; hm[2] = nres; hm[3] = st->done;
+    __threadfence_system();
+    hm[0] = pos + 1;
+    __threadfence_system();
+  }
 }
 
 }  // namespace
@@ -576,6 +584,8 @@ extern "C" int emoasr_joint_beam_graph_build(int dtype, const emoasr_joint_step_
   if (e != hipSuccess || !graph) { emo_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return 1; }
   hipGraphExec_t& ex = g_beam_exec[slot * 3 + part];
   bool ok = false;
+  static const bool no_update = getenv("EMOASR_GRAPH_NO_UPDATE") != nullptr;
+  if (ex && no_update) { hipGraphExecDestroy(ex); ex = nullptr; }
   if (ex) {
     hipGraphNode_t bad = nullptr;
     hipGraphExecUpdateResult res;

@@ -112,7 +112,8 @@ class BeamUpdate(Structure):
                 ("score", c_void_p), ("score_ctc", c_void_p),
                 ("n_ids", c_void_p), ("n_parent", c_void_p), ("n_pcand", c_void_p), ("n_last", c_void_p),
                 ("n_outlen", c_void_p), ("n_klens", c_void_p), ("hist_parent", c_void_p), ("hist_token", c_void_p),
-                ("res_score", c_void_p), ("res_step", c_void_p), ("res_parent", c_void_p), ("state", c_void_p)]
+                ("res_score", c_void_p), ("res_step", c_void_p), ("res_parent", c_void_p), ("state", c_void_p),
+                ("host_mirror", c_void_p)]
 
 
 class JointStep(Structure):

@@ -169,6 +169,7 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
             u.hist_parent, u.hist_token = Bf.hist_parent.data_ptr(), Bf.hist_token.data_ptr()
             u.res_score, u.res_step, u.res_parent = Bf.res_score.data_ptr(), Bf.res_step.data_ptr(), Bf.res_parent.data_ptr()
             u.state = Bf.state.data_ptr()
+            u.host_mirror = Bf.state_host.data_ptr()   # pinned: the kernel writes it, the host polls it (no copy engine)
             steps.append(js)
         side = None
         if use_lm:
@@ -196,39 +197,58 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
                     lib.call("emoasr_joint_beam_graph_build", dt_code, ctypes.byref(steps[k]), k, part, main_p)
         # Steps are issued one ahead of the flag they depend on: a step launched after the search has finished changes
         # nothing (emoasr_beam_update returns at once), and the GPU never waits for the host's round trip.
-        ev = torch.cuda.Event()
         ev_tail, ev_lm = torch.cuda.Event(), torch.cuda.Event()
-        pending = False
-        # a generation-2 garbage collection in the middle of the loop stalls a 0.65 ms step for 10-15 ms (measured: one or
-        # two per utterance); the loop allocates next to nothing, so collection simply waits until it is over
+        two_streams = os.environ.get("EMOASR_BEAM_TWO_STREAMS", "1") != "0"
+        mirror = Bf.state_host.numpy()               # [pos, n_alive, n_results, done], written by emoasr_beam_update
+        mirror[:] = (0, 1, 0, 0)
+        # a generation-2 garbage collection in the middle of the loop stalls a 0.65 ms step for 10-15 ms; the loop allocates
+        # next to nothing, so collection simply waits until it is over
         gc_was_on = gc.isenabled()
         gc.disable()
+        dbg = os.environ.get("EMOASR_BEAM_STEP_TIMING") == "1"
+        t_l = t_s = 0.0
+        worst = (0.0, -1, "")
         for i in range(max_steps):
+            if dbg:
+                _t0 = time.perf_counter()
             if use_graph:
                 k = i & 1
-                if use_lm:   # the LM chain on the side stream, concurrent with the decoder chain
+                if use_lm and two_streams:   # the LM chain on the side stream, concurrent with the decoder chain
                     ev_tail.record(main)             # the previous step's tail (ids / parent / pos) is complete
                     side.wait_event(ev_tail)
                     lib.call("emoasr_joint_beam_graph_launch", k, 1, side_p)
                     ev_lm.record(side)
+                elif use_lm:
+                    lib.call("emoasr_joint_beam_graph_launch", k, 1, main_p)
                 lib.call("emoasr_joint_beam_graph_launch", k, 0, main_p)
-                if use_lm:
+                if use_lm and two_streams:
                     main.wait_event(ev_lm)
                 lib.call("emoasr_joint_beam_graph_launch", k, 2, main_p)
             else:
                 lib.call("emoasr_joint_beam_step", dt_code, ctypes.byref(steps[i & 1]), main_p, side_p)
-            if pending:
-                ev.synchronize()                     # the state after step i - 1
-                if int(Bf.state_host[3]):
+            if dbg:
+                _t1 = time.perf_counter()
+            # Steps are issued one ahead of the flag they depend on (a step launched after the search has finished changes
+            # nothing: emoasr_beam_update returns at once), so the GPU never waits for the host.  The state of step i - 1
+            # arrives in pinned memory by the kernel's own store; polling it involves no copy engine and no event.
+            if i >= 1:
+                while mirror[0] < i and not mirror[3]:
+                    pass
+                if mirror[3]:
                     break
-            Bf.state_host.copy_(Bf.state, non_blocking=True)
-            ev.record(main)
-            pending = True
+            if dbg:
+                _t2 = time.perf_counter()
+                t_l += _t1 - _t0; t_s += _t2 - _t1
+                if _t1 - _t0 > worst[0]:
+                    worst = (_t1 - _t0, i, "launch")
+                if _t2 - _t1 > worst[0]:
+                    worst = (_t2 - _t1, i, "sync")
         main.synchronize()
+        if dbg:
+            print(f"   host: launches {1e3 * t_l:.2f} ms, waits {1e3 * t_s:.2f} ms, worst {1e3 * worst[0]:.2f} ms at step {worst[1]} ({worst[2]})", flush=True)
         if gc_was_on:
             gc.enable()
-        Bf.state_host.copy_(Bf.state)
-        n_done = int(Bf.state_host[0])               # effective steps (pos advances only while the search is live)
+        n_done = int(mirror[0])                      # effective steps (pos advances only while the search is live)
         if side is not None:
             main.wait_stream(side)
         if timing:
@@ -237,7 +257,7 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
             print(f"[beam timing] T' {T}: setup {1e3 * (t_loop - t_start):.2f} ms, {n_done} steps {1e3 * (t_end - t_loop):.2f} ms "
                   f"({1e3 * (t_end - t_loop) / max(n_done, 1):.3f} ms/step)", flush=True)
         # ---- results: token sequences from the (parent, token) history ----
-        n_res = int(Bf.state_host[2])
+        n_res = int(mirror[2])
         hp, ht = Bf.hist_parent[:n_done].cpu().numpy(), Bf.hist_token[:n_done].cpu().numpy()
         rs, rstep, rpar = Bf.res_score[:n_res].cpu().numpy(), Bf.res_step[:n_res].cpu().numpy(), Bf.res_parent[:n_res].cpu().numpy()
     caller.wait_stream(bstream)

@@ -595,6 +595,8 @@ typedef struct emoasr_beam_update {
   int *hist_parent, *hist_token;
   double* res_score; int* res_step; int* res_parent;               /* [bw] finished hypotheses */
   emoasr_beam_state_t* state;
+  int* host_mirror;                              /* optional: pinned host memory (device-visible) that receives a copy of `state`
+                                                  * at the end of every live step -- the host polls it instead of copying */
 } emoasr_beam_update_t;
 int emoasr_beam_update(const emoasr_beam_update_t* u, void* stream);
 /* One whole output step (cache gather, decoder step, LM step on `side_stream` when given, log-softmax + LM fusion, top-cw,
