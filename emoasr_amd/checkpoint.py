@@ -102,12 +102,18 @@ def load_optimizer_state_dict(opt, sd):
     above); returns the schedule fields (_epoch, base_lr, num_warmup_steps) for the caller's lr_fn"""
     arena = opt.arena
     st = sd["optimizer"]["state"]
-    assert len(st) in (0, len(arena.names)), "optimizer state does not match the model's parameter list"
+    n_params = len(arena.module_order)
+    bad = [i for i in st if not (isinstance(i, int) and 0 <= i < n_params)]
+    assert not bad, f"optimizer state holds entries for parameters the model does not have: {bad[:5]}"
+    # torch.optim.Adam creates state only for parameters that ever received a gradient (a frozen or unused head has none):
+    # missing entries start from zero moments, which is what torch does at their first gradient.  (The fused step updates the
+    # whole arena every step, so from here on they also see weight decay and moment decay like every other parameter.)
     opt.m.zero_()
     opt.v.zero_()
     for i, n in enumerate(arena.module_order):
         if i in st:
             o, v = arena.offsets[n], arena.pviews[n]
+            assert tuple(st[i]["exp_avg"].shape) == tuple(v.shape), f"optimizer state of {n}: shape {tuple(st[i]['exp_avg'].shape)}"
             opt.m[o:o + v.numel()].view(v.shape).copy_(st[i]["exp_avg"])
             opt.v[o:o + v.numel()].view(v.shape).copy_(st[i]["exp_avg_sq"])
     opt._step = int(sd["_step"])

@@ -35,11 +35,14 @@ __global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p
                                                    float* __restrict__ m, float* __restrict__ v, float lr,
                                                    float beta1, float beta2, float eps, float wd, float bc1,
                                                    float bc2_sqrt, const float* __restrict__ gnorm_sq,
-                                                   float clip, float grad_mult) {
+                                                   float clip, float grad_mult, int* __restrict__ skipped) {
   float mult = grad_mult;
   if (gnorm_sq) {
     const float nsq = *gnorm_sq * grad_mult * grad_mult;
-    if (!isfinite(nsq)) return;  // NaN / Inf gradient: skip the step (train_asr.py:88-89)
+    if (!isfinite(nsq)) {  // NaN / Inf gradient: skip the step (train_asr.py:88-89) and count it for the host's counters
+      if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+      return;
+    }
     if (clip > 0.f) {
       const float c = clip / (sqrtf(nsq) + 1e-6f);
       if (c < 1.f) mult *= c;
@@ -69,15 +72,24 @@ extern "C" int emoasr_sqnorm(long n, const float* x, float* out, void* stream) {
   return 0;
 }
 
+extern "C" int emoasr_adam_step_ex(long n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, int step, const float* gnorm_sq, float clip,
+                                   float grad_mult, int* skipped, void* stream);
 extern "C" int emoasr_adam_step(long n, float* p, const float* g, float* m, float* v, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, int step,
                                 const float* gnorm_sq, float clip, float grad_mult, void* stream) {
+  return emoasr_adam_step_ex(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq, clip, grad_mult, nullptr, stream);
+}
+
+extern "C" int emoasr_adam_step_ex(long n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, int step, const float* gnorm_sq, float clip,
+                                   float grad_mult, int* skipped, void* stream) {
   if (n == 0) return 0;
   EMO_CHECK(step >= 1, "adam: step must be >= 1");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
   adam_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay,
-                                                          bc1, sqrtf(bc2), gnorm_sq, clip, grad_mult);
+                                                          bc1, sqrtf(bc2), gnorm_sq, clip, grad_mult, skipped);
   EMO_LAUNCH_CHECK();
   return 0;
 }

@@ -244,6 +244,7 @@ SIGNATURES = {
     "emoasr_first_not_equal": [I, P, I, P, P],
     "emoasr_sqnorm": [L, P, P, P],
     "emoasr_adam_step": [L, P, P, P, P, F, F, F, F, F, I, P, F, F, P],
+    "emoasr_adam_step_ex": [L, P, P, P, P, F, F, F, F, F, I, P, F, F, P, P],
     "emoasr_specaug_apply": [I, I, I, P, P, I, I, P, P, P],
     "emoasr_fbank": [P, L, I, I, I, I, F, P, P, P, I, P],
     "emoasr_cmvn": [I, I, P, P, P, P],

@@ -806,9 +806,9 @@ def sqnorm(x, out):
     lib.call("emoasr_sqnorm", x.numel(), _p(_chk(x, torch.float32)), _p(out), _stream())
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq=None, clip=0.0, grad_mult=1.0):
-    lib.call("emoasr_adam_step", p.numel(), _p(p), _p(g), _p(m), _p(v), lr, beta1, beta2, eps, weight_decay,
-             step, _p(gnorm_sq), clip, grad_mult, _stream())
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq=None, clip=0.0, grad_mult=1.0, skipped=None):
+    lib.call("emoasr_adam_step_ex", p.numel(), _p(p), _p(g), _p(m), _p(v), lr, beta1, beta2, eps, weight_decay,
+             step, _p(gnorm_sq), clip, grad_mult, _p(skipped), _stream())
 
 
 # ---- features --------------------------------------------------------------------------

@@ -64,6 +64,11 @@ class Adam:
         if self._core is not None or self._can_bind():
             self._bind().zero_grad()
 
+    def fold_skipped(self):
+        """-> number of updates the fused kernel skipped (NaN / Inf gradient norm) since the last call; the step counter
+        behind the bias correction is corrected by it (one host synchronisation)"""
+        return self._core.fold_skipped() if self._core is not None else 0
+
     def _can_bind(self):
         from .engine import arena_of
         try:
@@ -150,6 +155,7 @@ class ScheduledOptimizer:
         self.optimizer.step()
 
     def update_epoch(self):
+        self.fold_skipped()
         self._epoch += 1
         if self.schedule_type == "epdecay" and self._epoch >= self.lr_decay_start_epoch:
             new_lr = self._lr * self.lr_decay_rate
@@ -160,7 +166,19 @@ class ScheduledOptimizer:
     def zero_grad(self):
         self.optimizer.zero_grad()
 
+    def fold_skipped(self):
+        """Take the updates that the fused Adam kernel skipped on the device (NaN / Inf gradient norm) out of the schedule
+        position: the reference never calls step() for them (train_asr.py:88-91).  One host synchronisation; called at every
+        epoch boundary and before the state is saved."""
+        base = getattr(self.optimizer, "fold_skipped", None)
+        n = base() if base is not None else 0
+        if n:
+            logging.warning(f"{n:d} update(s) skipped because of nan grad_norm")
+            self._step -= n
+        return n
+
     def state_dict(self):
+        self.fold_skipped()
         return {"_step": self._step, "_epoch": self._epoch, "base_lr": self.base_lr, "_lr": self._lr,
                 "num_warmup_steps": self.num_warmup_steps, "num_total_steps": self.num_total_steps,
                 "optimizer": self.optimizer.state_dict()}

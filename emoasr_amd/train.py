@@ -71,6 +71,7 @@ class ArenaAdam:
         self.m = torch.zeros_like(arena.flat)
         self.v = torch.zeros_like(arena.flat)
         self.nsq = torch.zeros(1, device=arena.flat.device, dtype=torch.float32)
+        self.skipped = torch.zeros(1, device=arena.flat.device, dtype=torch.int32)  # steps the kernel skipped (NaN / Inf norm)
         self._step = 0
         self.lr = 0.0
 
@@ -88,9 +89,21 @@ class ArenaAdam:
         from . import ops
         ops.sqnorm(self.arena.grad, self.nsq)
         ops.adam_step(self.arena.flat, self.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.wd, self._step, gnorm_sq=self.nsq, clip=self.clip, grad_mult=grad_mult)
+                      self.eps, self.wd, self._step, gnorm_sq=self.nsq, clip=self.clip, grad_mult=grad_mult,
+                      skipped=self.skipped)
+
+    def fold_skipped(self):
+        """Host synchronisation point: take the steps the kernel skipped since the last call out of the step counter
+        (train_asr.py:88-91 does not call optimizer.step() on a NaN gradient norm, so neither the bias correction nor a
+        schedule position advance) -> number of skipped steps."""
+        n = int(self.skipped.item())
+        if n:
+            self._step -= n
+            self.skipped.zero_()
+        return n
 
     def state_dict(self):
+        self.fold_skipped()
         return {"_step": self._step, "m": self.m, "v": self.v, "lr": self.lr}
 
     def load_state_dict(self, sd):

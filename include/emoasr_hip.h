@@ -632,6 +632,12 @@ int emoasr_sqnorm(long n, const float* x, float* out, void* stream);
 int emoasr_adam_step(long n, float* p, const float* g, float* m, float* v, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step, const float* gnorm_sq,
                      float clip, float grad_mult, void* stream);
+/* the same; a skipped step also increments *skipped (device int, may be NULL): the host subtracts it from its step
+ * counters at its next synchronisation point, so that the schedule position and the bias correction follow the number of
+ * updates actually applied, as in the reference (which does not call optimizer.step() on a NaN norm) */
+int emoasr_adam_step_ex(long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, const float* gnorm_sq, float clip, float grad_mult, int* skipped,
+                        void* stream);
 
 /* ---- on-GPU features --------------------------------------------------------- */
 /* SpecAugment (asr/spec_augment.py:39-95): zero (or fill) bands.  spans int32

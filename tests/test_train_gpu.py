@@ -101,8 +101,14 @@ def test_nan_gradient_skips_the_update_and_resume(dev):
     for k, v in before.items():
         assert torch.equal(model.state_dict()[k], v), k
     assert float(model.engine().arena.grad.abs().max()) == 0.0
-    # resume: same model weights, a NEW optimizer restored from the state dict, one more step each
+    # the skipped update does not advance the schedule position or Adam's step count (the reference never calls
+    # optimizer.step() on a NaN norm): both follow at the next host synchronisation point (state_dict / update_epoch)
+    assert optimizer._step == 2                      # host counter, not yet corrected
     sd_opt = optimizer.state_dict()
+    assert optimizer._step == 1 and sd_opt["_step"] == 1
+    assert optimizer.optimizer._core._step == 1 and int(optimizer.optimizer._core.skipped.item()) == 0
+    assert {int(v["step"]) for v in sd_opt["optimizer"]["state"].values()} == {1}
+    # resume: same model weights, a NEW optimizer restored from the state dict, one more step each
     model2, optimizer2, _ = _setup(dev)
     model2.load_state_dict(model.state_dict())
     optimizer2.load_state_dict(sd_opt)
@@ -127,3 +133,35 @@ def test_train_epoch_driver(dev):
     want = t["losses"][:6].sum().item() / 3
     got = float(lines[0].split("loss_total: ")[1].split()[0])
     assert abs(got - want) < 2e-3 * want + 1e-3, (got, want)
+
+
+def test_partial_optimizer_state_resumes_with_zero_moments(dev):
+    """a reference optim.ep{N} written by torch.optim.Adam has no entry for parameters that never received a gradient;
+    those resume from zero moments (asr/optimizers.py:110-117 + torch.optim.Adam.load_state_dict semantics)"""
+    from emoasr_amd import checkpoint
+    from emoasr_amd.train import train_step
+    t = _trace()
+    model, optimizer, params = _setup(dev)
+    one = SimpleNamespace(**dict(vars(params), accum_grad=1))
+    train_step(model, optimizer, _data(t, 0), one, dev)
+    sd = optimizer.state_dict()
+    full = sd["optimizer"]["state"]
+    dropped = sorted(full)[-3:]
+    sd["optimizer"]["state"] = {k: v for k, v in full.items() if k not in dropped}
+    model2, optimizer2, _ = _setup(dev)
+    model2.load_state_dict(model.state_dict())
+    model2.engine().ensure_bound()              # the arena exists, so the state is applied at once
+    optimizer2.load_state_dict(sd)
+    core, arena = optimizer2.optimizer._bind(), model2.engine().arena
+    for i, n in enumerate(arena.module_order):
+        o, v = arena.offsets[n], arena.pviews[n]
+        m = core.m[o:o + v.numel()]
+        if i in dropped:
+            assert float(m.abs().max()) == 0.0, n
+        else:
+            assert torch.equal(m.view(v.shape).cpu(), full[i]["exp_avg"]), n
+    bad = dict(sd["optimizer"]["state"])
+    bad[10 ** 6] = full[0]
+    sd["optimizer"]["state"] = bad
+    with pytest.raises(AssertionError):
+        checkpoint.load_optimizer_state_dict(core, {"optimizer": sd["optimizer"], "_step": 1})
