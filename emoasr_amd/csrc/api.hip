@@ -26,6 +26,7 @@ void emo_gemm_set_big_min_tiles(int v);
 void emo_conv_set_dwconv_lds(int v);
 void emo_layer_set_conv_fused(int v);
 void emo_decode_set_fused(int v);
+void emo_decode_set_wg(int v);
 void emo_attn_set_tr_read(int v);
 void emo_attn_set_fw(int v);
 void emo_layer_set_ffn_fused(int v);
@@ -93,6 +94,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "dwconv_lds") == 0) { emo_conv_set_dwconv_lds(value); return 0; }
   if (strcmp(name, "conv_fused") == 0) { emo_layer_set_conv_fused(value); return 0; }
   if (strcmp(name, "decode_fused") == 0) { emo_decode_set_fused(value); return 0; }
+  if (strcmp(name, "decode_wg") == 0) { emo_decode_set_wg(value); return 0; }
   if (strcmp(name, "attn_fw") == 0) { emo_attn_set_fw(value); return 0; }
   if (strcmp(name, "timers") == 0) { g_timers_on = value; return 0; }
   if (strcmp(name, "ffn_fused") == 0) { emo_layer_set_ffn_fused(value); return 0; }

@@ -186,6 +186,14 @@ __global__ __launch_bounds__(256) void cache_gather_kernel(int nl, int nb, int L
     reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[i];
 }
 
+}  // namespace
+// csrc/decode_wg.hip: the whole stack of either network for one step in ONE single-workgroup launch (bf16)
+bool emo_decode_wg_ok(int dtype, int nb, int nl, int max_layers, int d, int H, int F);
+int emo_bert_lm_step_wg(int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_step_t* io, void* out_hidden, hipStream_t s);
+int emo_transformer_decoder_step_wg(int nl, const emoasr_decoder_layer_t* layers, const emoasr_decoder_step_t* io, void* out_x,
+                                    hipStream_t s);
+namespace {
+
 int g_decode_fused = 0;  // bf16: LayerNorm / residual / cache-append folded into rowlin + attn_step (csrc/rowlin.hip): 8 / 5
                          // launches per decoder / LM layer instead of 12 / 8 -- measured SLOWER (0.74 vs 0.68 ms per step: a
                          // rowlin launch with a LayerNorm inside takes 8 us against 4.7 + 4.5 for GEMM + LayerNorm, and the
@@ -247,6 +255,11 @@ extern "C" int emoasr_transformer_decoder_step(int dtype, int nl, const emoasr_d
   void* act = ws.take((size_t)nb * F * esz);
   float* lse = (float*)ws.take((size_t)nb * H * 4);
   EMO_CHECK(ws.ok, "decoder_step: scratch too small (%zu bytes given)", io->ws_bytes);
+  if (emo_decode_wg_ok(dtype, nb, nl, 8, dd, H, F)) {
+    // the whole stack in one single-workgroup launch, then the final LayerNorm + vocabulary projection across the chip
+    if (emo_transformer_decoder_step_wg(nl, layers, io, x, s)) return 1;
+    return rl(nb, io->V, dd, x, &io->ln_out, io->out, EMOASR_ACT_NONE, nullptr, nullptr, io->logits_last, 0, stream);
+  }
   EMO_DISPATCH(dtype, (step_embed_kernel<T><<<cdiv(nb * dd, 256), 256, 0, s>>>(nb, dd, io->ids, (const T*)io->embed, io->pe,
                                                                                 io->emb_scale, io->pos, (T*)x)));
   const size_t layer_bytes = (size_t)nb * Lmax * dd * esz;
@@ -325,6 +338,13 @@ extern "C" int emoasr_bert_lm_step(int dtype, int nl, const emoasr_bert_layer_t*
   void* t2 = ws.take((size_t)nb * d * esz);
   float* logits = (float*)ws.take((size_t)nb * V * 4);
   EMO_CHECK(ws.ok, "bert_lm_step: scratch too small (%zu bytes given)", io->ws_bytes);
+  if (emo_decode_wg_ok(dtype, nb, nl, 12, d, H, F)) {
+    if (emo_bert_lm_step_wg(nl, layers, io, t1, s)) return 1;
+    emoasr_lin_t tied_wg{io->word_emb, io->out_bias};
+    if (io->raw_logits) return rl(nb, V, d, t1, &io->ln_transform, tied_wg, EMOASR_ACT_NONE, nullptr, nullptr, io->logp, 1, stream);
+    if (rl(nb, V, d, t1, &io->ln_transform, tied_wg, EMOASR_ACT_NONE, nullptr, nullptr, logits, 1, stream)) return 1;
+    return emoasr_log_softmax(EMO_F32, nb, V, logits, V, nullptr, 0, 0.f, io->logp, V, stream);
+  }
   EMO_DISPATCH(dtype, (step_embed_kernel<T><<<cdiv(nb * d, 256), 256, 0, s>>>(nb, d, io->ids, (const T*)io->word_emb, io->pe, 1.f,
                                                                               io->pos, (T*)y)));
   const size_t layer_bytes = (size_t)nb * Lmax * d * esz;
