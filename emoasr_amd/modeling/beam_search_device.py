@@ -184,6 +184,7 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
             torch.cuda.synchronize()
             t_loop = time.perf_counter()
         main_p, side_p = main.cuda_stream, (side.cuda_stream if side is not None else None)
+        t_loop0 = time.perf_counter()
         use_graph = os.environ.get("EMOASR_BEAM_GRAPH", "1") != "0"
         if use_graph:
             if not getattr(eng, "_beam_graph_warm", False):
@@ -251,6 +252,10 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
         if gc_was_on:
             gc.enable()
         n_done = int(mirror[0])                      # effective steps (pos advances only while the search is live)
+        stats = getattr(eng, "_beam_stats", None)    # running totals for bench.py: steps and wall time of the search loops
+        if stats is None:
+            stats = eng._beam_stats = {"steps": 0, "loop_s": 0.0, "utts": 0}
+        stats["steps"] += n_done; stats["loop_s"] += time.perf_counter() - t_loop0; stats["utts"] += 1
         if side is not None:
             main.wait_stream(side)
         if timing:
