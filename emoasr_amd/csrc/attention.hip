@@ -1188,9 +1188,13 @@ struct FusedWs {       // workspace carved by emoasr_attn_bwd_fused
 };
 
 // prologue: delta[b,h,i] = dO.O, dense Q+u / Q+v.  8 lanes x 8 elements per (b,i,h) row.
+// zero / zn: optional f32 buffer cleared on the side (the position-table gradient that attn_bwd_dpos2_kernel accumulates into:
+// saves the separate memset launch of the per-layer backward)
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t a, T* __restrict__ qu, T* __restrict__ qv) {
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t a, T* __restrict__ qu, T* __restrict__ qv,
+                                                            float* __restrict__ zero, const long zn) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  for (long i = idx; i < zn; i += (long)gridDim.x * 256) zero[i] = 0.f;
   const long row = idx >> 3, total = (long)a.B * a.Tq * a.H;
   const int d0 = (int)(idx & 7) * 8;
   const bool ok = row < total;
@@ -1621,7 +1625,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_fin_kernel(const long rows, const int ncol, const float* __restrict__ dq32,
                                                            const long slab, const int keys_per_block, const int Tq, const int Tk,
-                                                           const int* __restrict__ klens, T* __restrict__ dq, const long ldq) {
+                                                           const int* __restrict__ klens, T* __restrict__ dq, const long ldq,
+                                                           const float* __restrict__ cast_src, T* __restrict__ cast_dst,
+                                                           const long cast_n) {
+  // on the side: the finished f32 position-table gradient rounded to the compute dtype for its weight-gradient product
+  // (this launch follows attn_bwd_dpos2_kernel; saves the separate cast launch of the per-layer backward)
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < cast_n; i += (long)gridDim.x * 256) cast_dst[i] = from_f32<T>(cast_src[i]);
   const int ngrp = ncol / 8, rpb = 256 / ngrp;  // column groups of 8, rows per pass
   const int cg = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
   if (rr >= rpb) return;
@@ -1810,6 +1819,9 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
 }
 
 
+struct FusedExtras { float* zero; long zero_n; const float* cast_src; void* cast_dst; long cast_n; };
+FusedExtras g_fused_extras{};
+
 template <typename T>
 int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_t s) {
   const bool rel = a.pos != nullptr;
@@ -1831,7 +1843,9 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
   }
   EMO_CHECK(off <= bytes, "attn_bwd_fused: workspace too small (%zu < %zu bytes)", bytes, off);
   const long rows = (long)a.B * a.Tq * a.H;
-  attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, qu, qv);
+  const FusedExtras fx = g_fused_extras;
+  g_fused_extras = FusedExtras{};
+  attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, qu, qv, fx.zero, fx.zero_n);
   // 4 key tiles per workgroup (one workgroup per CU) unless that grid spills into a second round of workgroups and the
   // 2-tile grid (two workgroups per CU) does not
   static int n_cu = 0;
@@ -1869,11 +1883,17 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
   }
 #undef EMO_FUSED_LAUNCH
   attn_bwd_fin_kernel<T><<<cdiv((long)a.B * a.Tq, 16), 256, 0, s>>>((long)a.B * a.Tq, a.H * DK, ws.dq32, ws.dq_slab, 32 * fw, a.Tq,
-                                                                 a.Tk, a.klens, (T*)a.dq, a.ldq);
+                                                                 a.Tk, a.klens, (T*)a.dq, a.ldq, fx.cast_src, (T*)fx.cast_dst, fx.cast_n);
   EMO_LAUNCH_CHECK();
   return 0;
 }
 }  // namespace
+
+// One-shot side jobs for the NEXT emoasr_attn_bwd_fused call of this thread's library state (csrc/layer.hip): clear `zero`
+// (zn floats) in the prologue launch, and write cast_dst = compute-dtype(cast_src) (cn values) in the finalize launch.
+void emo_attn_bwd_fused_extras(float* zero, long zn, const float* cast_src, void* cast_dst, long cn) {
+  g_fused_extras = FusedExtras{zero, zn, cast_src, cast_dst, cn};
+}
 
 void emo_attn_set_tr_read(int v) { g_tr = v; }
 void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }

@@ -7,6 +7,8 @@
 #include "common.h"
 #include "../../include/emoasr_hip.h"
 
+void emo_attn_bwd_fused_extras(float* zero, long zn, const float* cast_src, void* cast_dst, long cn);  // csrc/attention.hip
+
 namespace {
 
 emoasr_epilogue_t plain_ep() {
@@ -237,7 +239,6 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     wgrad(dy, d, d, st->o, d, d, M, G->wout, 1.f, G->bout);
     emoasr_epilogue_t e = plain_ep();
     if (emoasr_gemm_nn(dtype, M, d, d, dy, d, L->wout, d, ws + bb.dout, d, &e, stream)) return 1;
-    hipMemsetAsync(ws + bb.dpos, 0, (size_t)R * d * 4, s);
     emoasr_attn_t a{};
     a.B = B; a.H = H; a.DK = d / H; a.Tq = T; a.Tk = T;
     a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d; a.ldp = d;
@@ -250,8 +251,10 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     a.dout = ws + bb.dout; a.delta = (float*)(ws + bb.delta);
     a.dq = ws + bb.dqkv; a.dk = ws + bb.dqkv + (size_t)d * esz; a.dv = ws + bb.dqkv + (size_t)2 * d * esz;
     a.dpos = (float*)(ws + bb.dpos); a.dbias_u = (float*)G->bias_u; a.dbias_v = (float*)G->bias_v;
+    // the position-table gradient is cleared by the attention backward's prologue launch and rounded to the compute dtype
+    // by its finalize launch (two launches less per layer than a memset + a cast)
+    emo_attn_bwd_fused_extras((float*)(ws + bb.dpos), (long)R * d, (const float*)(ws + bb.dpos), ws + bb.dpos_t, (long)R * d);
     if (emoasr_attn_bwd_fused(dtype, &a, ws + bb.attn_ws, bb.attn_ws_bytes, stream)) return 1;
-    if (emoasr_strided_copy(EMO_F32, dtype, ws + bb.dpos, ws + bb.dpos_t, 1, 1, 1, R * d, 0, 0, 0, 1, 0, stream)) return 1;
     wgrad(ws + bb.dpos_t, d, d, st->pos_t, d, d, R, G->wpos, 1.f, nullptr);
     wgrad(ws + bb.dqkv, 3 * d, 3 * d, st->at_h, d, d, M, G->wqkv, 1.f, G->bqkv);
     if (emoasr_gemm_nn(dtype, M, d, 3 * d, ws + bb.dqkv, 3 * d, L->wqkv, d, ws + bb.dh, d, &e, stream)) return 1;
