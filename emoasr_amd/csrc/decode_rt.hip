@@ -587,6 +587,8 @@ extern "C" int emoasr_joint_beam_step(int dtype, const emoasr_joint_step_t* js, 
 // the even / odd steps differ in which cache and scorer-state buffers are "previous" and "current"); for the next utterance
 // the same topology is re-captured with the new pointers and the instantiated graph is updated in place
 // (hipGraphExecUpdate), which is far cheaper than a new instantiation.  emoasr_joint_beam_graph_launch replays it.
+// (One search at a time per process -- the reference decodes one utterance at a time, decoders/transformer.py:181 -- so the
+// instantiated graphs live in six process-wide slots.)
 namespace {
 hipGraphExec_t g_beam_exec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [slot][part: decoder, LM, tail]
 }
