@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O3 tools/micro/one_wg_bw.hip -o tools/micro/one_wg_bw   (result: profiles/r02_one_wg_bw.txt)
 // How fast can ONE workgroup (1024 threads) stream a weight set?  (sizing of a single-workgroup decode-step kernel)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
