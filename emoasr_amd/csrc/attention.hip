@@ -1185,6 +1185,7 @@ struct FusedWs {       // workspace carved by emoasr_attn_bwd_fused
   long ldds;
   const void *qu, *qv; // T [B, Tq, ldqu]: Q + pos_bias_u, Q + pos_bias_v  (without biases: q itself, ldq)
   long ldqu;
+  unsigned long long* stamp;  // -DEMO_ATTN_STAMP builds only: s_memtime of wave 0 of workgroup (0,0,0) at 13 points per step
 };
 
 // prologue: delta[b,h,i] = dO.O, dense Q+u / Q+v.  8 lanes x 8 elements per (b,i,h) row.
@@ -1231,14 +1232,28 @@ template <typename T, int FW> struct FusedCfg {
   // the K tile is staged in the same region once, before the sweep
   static constexpr int IMG_DS_ROWS = 31 + 32 + 32;  // (band column 63 is unused: its keys 32.. must read zeros too)
   static constexpr int IMG_DS_BYTES = (IMG_DS_ROWS * IMG * (int)sizeof(T) + 15) / 16 * 16;
-  static constexpr int DQ_LD = 33;
-  static constexpr int GS_BYTES = 64 * DQ_LD * 4;  // >= 64 * 32 * 4: at the end of a step the region holds the wave's dQ^T slab
+  // at the end of a step the region holds the wave's dQ slab, query-major: [32 queries][DQ_LD floats] (64 d + 4 of padding).
+  // A lane owns 4 consecutive d of one query after the chained products (accumulator rows r & 3), so the slab is written
+  // with 16-byte stores and flushed with 16-byte reads / global stores (the d-major slab took 32 + 32 scalar LDS accesses and
+  // 16 four-byte global stores per lane and step: 3.9 k of the step's 11.6 k cycles, in-kernel stamps)
+  static constexpr int DQ_LD = 68;
+  static constexpr int GS_BYTES = 32 * DQ_LD * 4;  // >= 64 * 32 * 4 (the f32 skew tile before the soft-max)
   static constexpr int WAVE_BYTES = IMG_DS_BYTES + GS_BYTES;
   static constexpr int BAND_ROWS = 32 * FW + 32;
   static constexpr int stage_rows(bool rel) { return rel ? 96 + BAND_ROWS : 64; }
   static constexpr int stage_bytes(bool rel) { return stage_rows(rel) * LD * (int)sizeof(T); }
   static constexpr int smem_bytes(bool rel) { return stage_bytes(rel) + FW * WAVE_BYTES; }
 };
+
+#ifdef EMO_ATTN_STAMP
+#define EMO_STAMP(k)                                                                                          \
+  do {                                                                                                        \
+    if (ws.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)               \
+      ws.stamp[step * 13 + (k)] = __builtin_amdgcn_s_memtime();                                               \
+  } while (0)
+#else
+#define EMO_STAMP(k) do {} while (0)
+#endif
 
 // the workgroup barrier of the sweep: LDS traffic only (no vmcnt: the prefetch loads, the dS stores and the dQ
 // atomics stay in flight across it -- __syncthreads() would drain all three every step)
@@ -1354,20 +1369,28 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
   f32x16 dk[2], dv[2], csum;
   zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]); zero16(csum);
   if (!live)  // a dead wave's slab stays zero for the whole sweep
-    for (int i = lane; i < 64 * C_::DQ_LD; i += 64) Gs[i] = 0.f;
+    for (int i = lane; i < 32 * C_::DQ_LD; i += 64) Gs[i] = 0.f;
   // sum of the waves' dQ^T slabs of the step that just ended -> this key block's f32 partial (rows of 64 d = 256 B, plain
   // stores: every (key block, query row) has exactly one writer, so dQ is bit-reproducible); wave w takes rows w, w + FW, ...
-  float* dq_part = ws.dq32 + (long)blockIdx.x * ws.dq_slab + (long)b * a.Tq * (a.H * DK) + ho + lane;
-  float dq_colsum = 0.f;  // sum over this wave's query rows of dQ[:, d = lane] (dbias_u + dbias_v = colsum(dQ))
+  // flush lane map: 4 query rows per pass (lane >> 4), 4 consecutive d per lane (lane & 15)
+  const int f_row = lane >> 4, f_d = 4 * (lane & 15);
+  float* dq_part = ws.dq32 + (long)blockIdx.x * ws.dq_slab + (long)b * a.Tq * (a.H * DK) + ho + f_d;
+  f32x4 dq_colsum4 = f32x4{0.f, 0.f, 0.f, 0.f};  // sum over this lane's query rows of dQ[:, f_d .. f_d + 3]
   auto flush = [&](const int ib) {
 #pragma unroll
-    for (int q = wave; q < 32; q += FW) {
-      float v = 0.f;
+    for (int q0 = 4 * wave; q0 < 32; q0 += 4 * FW) {
+      const int q = q0 + f_row;
+      f32x4 v = *reinterpret_cast<const f32x4*>(slab0 + q * C_::DQ_LD + f_d);
 #pragma unroll
-      for (int w = 0; w < FW; ++w) v += slab0[w * SLAB_STRIDE + lane * C_::DQ_LD + q];
+      for (int w = 1; w < FW; ++w) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(slab0 + w * SLAB_STRIDE + q * C_::DQ_LD + f_d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += o[e];
+      }
       if (ib + q < a.Tq) {
-        dq_part[(long)(ib + q) * (a.H * DK)] = v;
-        dq_colsum += v;
+        *reinterpret_cast<f32x4*>(dq_part + (long)(ib + q) * (a.H * DK)) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dq_colsum4[e] += v[e];
       }
     }
   };
@@ -1385,6 +1408,7 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
     const T* Qvs = st + 32 * LD;
     const T* dOs = st + (REL ? 64 : 32) * LD;
     const T* Bs = st + (96 + 32 * wave) * LD;  // this wave's 64 band rows (REL)
+    EMO_STAMP(0);
     if (live) {
       const int qi = i0 + il;
       const bool qval = qi < a.Tq;
@@ -1417,11 +1441,14 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
         for (int r = 0; r < 16; ++r) s[r] += Gs[(31 - il + c_row(r, lane)) * 32 + il];
         __builtin_amdgcn_wave_barrier();
       }
+      EMO_STAMP(1);
       // dP^T = V dO^T
       f32x16 dp;
       zero16(dp);
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) dp = M_::mma(vfA[kk], M_::load_kc(dOs, LD, 0, kk * M_::KSTEP, lane), dp);
+      EMO_STAMP(2);
+      // (placing these ~300 VALU instructions ahead of the MFMA chains above moved their 1.5 k cycles, it did not hide them)
       f32x16 ds, dsc;
       if (a.drop_p > 0.f) {
         const float keep = 1.f / (1.f - a.drop_p);
@@ -1442,6 +1469,7 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
         img_p[c_row(r, lane) * IMG + il] = from_f32<T>(p * dsc[r]);
       }
       __builtin_amdgcn_wave_barrier();
+      EMO_STAMP(3);
       if constexpr (REL) {
         // dS for the dpos pass: query-major rows, 4 consecutive keys (8 bytes) per store
         if (qval) {
@@ -1455,6 +1483,7 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
           }
         }
       }
+      EMO_STAMP(4);
       // dQ^T partial = K^T dS^T (+ band^T unskew(dS^T))
       f32x16 dq[2];
       zero16(dq[0]); zero16(dq[1]);
@@ -1479,6 +1508,7 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
               dq[dt] = M_::mma(chain_a<T, TR>(Bs + 32 * ct * LD, ks, 32 * dt, lane), dgf[ks], dq[dt]);
         }
       }
+      EMO_STAMP(5);
       // dV^T += dO^T P,  dK^T += (Q+u)^T dS   (sum over the query index: operands from the bf16 images)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -1490,17 +1520,26 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
                            M_::load_kc(img_ds, IMG, 0, ks * M_::KSTEP, lane), dk[dt]);
         }
       __builtin_amdgcn_wave_barrier();
+      EMO_STAMP(6);
       // the P image (start of the skew region) has been consumed: the region now takes this wave's dQ^T slab
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Gs[(32 * dt + c_row(r, lane)) * C_::DQ_LD + il] = dq[dt][r];
+        for (int g4 = 0; g4 < 4; ++g4)   // accumulator rows 4 g4 .. 4 g4 + 3 = d 32 dt + 8 g4 + 4 (lane >> 5) + 0 .. 3 of query il
+          *reinterpret_cast<f32x4*>(Gs + il * C_::DQ_LD + 32 * dt + 8 * g4 + 4 * (lane >> 5)) =
+              f32x4{dq[dt][4 * g4], dq[dt][4 * g4 + 1], dq[dt][4 * g4 + 2], dq[dt][4 * g4 + 3]};
     }
+    EMO_STAMP(7);
     lds_barrier();  // every wave has read the stage and written its slab
+    EMO_STAMP(8);
     flush(i0);
+    EMO_STAMP(9);
     stash();         // tiles of step+1 (fetched during the previous step)
+    EMO_STAMP(10);
     fetch(step + 2);
+    EMO_STAMP(11);
     lds_barrier();  // stage ready; every slab has been read: the skew regions may be written again
+    EMO_STAMP(12);
   }
   store_dT<T>((T*)hp.dk, a.ldk, j0, a.Tk, dk, 1.f, lane);  // (a dead wave stores zeros)
   store_dT<T>((T*)hp.dv, a.ldv, j0, a.Tk, dv, 1.f, lane);
@@ -1524,6 +1563,18 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
         acc += cs[j] * buf_load_f32<T>(rsK, kj < a.Tk ? (unsigned)(((long)kj * a.ldk + lane) * sizeof(T)) : EMO_OOB);
       }
       atomicAdd(&a.dbias_u[h * DK + lane], acc);
+    }
+    // colsum(dQ)[d = lane]: fold the four row groups of the flush map, then pick component lane & 3 of lane (lane >> 2)'s sums
+    float dq_colsum = 0.f;
+    {
+      f32x4 t = dq_colsum4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { t[e] += __shfl_xor(t[e], 16, 64); t[e] += __shfl_xor(t[e], 32, 64); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ve = __shfl(t[e], lane >> 2, 64);
+        if ((lane & 3) == e) dq_colsum = ve;
+      }
     }
     atomicAdd(&a.dbias_v[h * DK + lane], dq_colsum - acc);
   }
@@ -1845,6 +1896,12 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
   const long rows = (long)a.B * a.Tq * a.H;
   const FusedExtras fx = g_fused_extras;
   g_fused_extras = FusedExtras{};
+#ifdef EMO_ATTN_STAMP
+  static unsigned long long* d_stamp = nullptr;
+  static int stamp_calls = 0;
+  if (!d_stamp) hipMalloc(&d_stamp, 64 * 13 * 8);
+  ws.stamp = stamp_calls++ == 0 ? d_stamp : nullptr;   // the first (eager) call only: later calls may be under stream capture
+#endif
   attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, qu, qv, fx.zero, fx.zero_n);
   // 4 key tiles per workgroup (one workgroup per CU) unless that grid spills into a second round of workgroups and the
   // 2-tile grid (two workgroups per CU) does not
@@ -1884,6 +1941,26 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
 #undef EMO_FUSED_LAUNCH
   attn_bwd_fin_kernel<T><<<cdiv((long)a.B * a.Tq, 16), 256, 0, s>>>((long)a.B * a.Tq, a.H * DK, ws.dq32, ws.dq_slab, 32 * fw, a.Tq,
                                                                  a.Tk, a.klens, (T*)a.dq, a.ldq, fx.cast_src, (T*)fx.cast_dst, fx.cast_n);
+#ifdef EMO_ATTN_STAMP
+  {  // debug builds: per-phase cycle counts of the main kernel's first workgroup (wave 0), averaged over the sweep
+    static int printed = 0;
+    if (printed < 1) {
+      ++printed;
+      unsigned long long h[64 * 13];
+      hipStreamSynchronize(s);
+      hipMemcpy(h, ws.stamp, sizeof(h), hipMemcpyDeviceToHost);
+      const int ns = (a.Tq + 31) / 32 < 64 ? (a.Tq + 31) / 32 : 64;
+      double acc[13] = {0};
+      for (int st = 1; st < ns; ++st)
+        for (int k = 1; k < 13; ++k) acc[k] += (double)(h[st * 13 + k] - h[st * 13 + k - 1]);
+      fprintf(stderr, "[attn stamp] B %d T %d fw %d: per step (cycles):", a.B, a.Tq, fw);
+      const char* nm[13] = {"", "S+band", "dP", "drop+exp+img", "dS store", "dQ", "dV+dK", "slab", "barrier1", "flush", "stash", "fetch", "barrier2"};
+      double tot = 0;
+      for (int k = 1; k < 13; ++k) { fprintf(stderr, " %s %.0f", nm[k], acc[k] / (ns - 1)); tot += acc[k] / (ns - 1); }
+      fprintf(stderr, " | total %.0f\n", tot);
+    }
+  }
+#endif
   EMO_LAUNCH_CHECK();
   return 0;
 }
