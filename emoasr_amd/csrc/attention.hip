@@ -214,8 +214,10 @@ __device__ __forceinline__ void score_tile(f32x16& acc, const emoasr_attn_t& a, 
   __builtin_amdgcn_wave_barrier();
 }
 
+// element index of the attention-dropout mask: rows of an EVEN stride, so that keys 2m and 2m + 1 of a row are one hash pair
+// (common.h: dropout_keep2)
 __device__ __forceinline__ uint64_t drop_index(const emoasr_attn_t& a, int b, int h, int i, int j) {
-  return (((uint64_t)b * a.H + h) * a.Tq + i) * (uint64_t)a.Tk + j;
+  return (((uint64_t)b * a.H + h) * a.Tq + i) * (uint64_t)((a.Tk + 1) & ~1) + j;
 }
 
 // write a [64 d][32 cols] transposed accumulator pair (rows d in registers, col = row index
@@ -375,9 +377,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
     if (a.drop_p > 0.f) {
+      // accumulator rows 4 g .. 4 g + 3 are keys j0 + 8 g + 4 (lane >> 5) + 0 .. 3: two hash pairs (row base and j0 are even)
+      const float keep = 1.f / (1.f - a.drop_p);
+      const uint32_t thr = dropout_thr(a.drop_p);
+      const uint64_t dbase = drop_index(a, b, h, qi, j0 + 4 * (lane >> 5));
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        s[r] *= dropout_scale(a.seed, drop_index(a, b, h, qi, j0 + c_row(r, lane)), a.drop_p);
+      for (int g = 0; g < 4; ++g) {
+        const uint64_t pr = (dbase + (uint64_t)(8 * g)) >> 1;
+        bool k0, k1, k2, k3;
+        dropout_keep2(a.seed, pr, thr, k0, k1);
+        dropout_keep2(a.seed, pr + 1, thr, k2, k3);
+        s[4 * g] *= k0 ? keep : 0.f; s[4 * g + 1] *= k1 ? keep : 0.f;
+        s[4 * g + 2] *= k2 ? keep : 0.f; s[4 * g + 3] *= k3 ? keep : 0.f;
+      }
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1452,9 +1464,17 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
       f32x16 ds, dsc;
       if (a.drop_p > 0.f) {
         const float keep = 1.f / (1.f - a.drop_p);
+        const uint32_t thr = dropout_thr(a.drop_p);
+        // accumulator rows 4 g .. 4 g + 3 are keys j0 + 8 g + 4 (lane >> 5) + 0 .. 3: two hash pairs (drop_base, j0 even)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          dsc[r] = dropout_keep(a.seed, drop_base + (uint64_t)(j0 + c_row(r, lane)), a.drop_p) ? keep : 0.f;
+        for (int g = 0; g < 4; ++g) {
+          const uint64_t pr = (drop_base + (uint64_t)(j0 + 8 * g + 4 * (lane >> 5))) >> 1;
+          bool k0, k1, k2, k3;
+          dropout_keep2(a.seed, pr, thr, k0, k1);
+          dropout_keep2(a.seed, pr + 1, thr, k2, k3);
+          dsc[4 * g] = k0 ? keep : 0.f; dsc[4 * g + 1] = k1 ? keep : 0.f;
+          dsc[4 * g + 2] = k2 ? keep : 0.f; dsc[4 * g + 3] = k3 ? keep : 0.f;
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dsc[r] = 1.f;

@@ -280,13 +280,17 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
-// keep decision of element idx (p > 0): three xorshift / 24-bit-multiply rounds over (idx, seed).  The masks are
-// regenerated in every backward kernel, so this sits on the VALU critical path of the attention kernels:
-// v_mul_u32_u24 issues at full rate where the 32-bit v_mul_lo_u32 of a classic avalanche hash is quarter rate.  The
-// low 24 bits are the uniform (chi-square over 64 buckets of 4M consecutive indices: 66 +- 8 for 63 degrees of
-// freedom; adjacent-index / row-stride / seed+1 correlations of the keep mask < 2e-3 -- tools/hash_check.py).
-__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, float p) {
-  const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+// keep decision of element idx (p > 0).  Elements are hashed in PAIRS: four xorshift / 24-bit-multiply rounds over
+// (idx >> 1, seed) give the 24-bit uniform of the even element, one more round gives the odd element's -- a kernel that walks
+// consecutive elements (the attention tiles: 16 per lane and step) pays 9 integer operations per decision instead of 17, and
+// the compare is against an integer threshold (no conversion).  The masks are regenerated in every backward kernel, so this
+// sits on the VALU critical path of the attention kernels (1.4 k of 9 k cycles per step before pairing, in-kernel stamps):
+// v_mul_u32_u24 issues at full rate where the 32-bit v_mul_lo_u32 of a classic avalanche hash is quarter rate.
+// Statistics (tools/hash_check.py, numpy restatement): chi-square over 64 buckets of 4M consecutive indices 57-96 for 63
+// degrees of freedom for both elements of a pair; adjacent-index / row-stride / seed+1 / within-pair correlations of the keep
+// mask < 3e-3.
+__device__ __forceinline__ uint32_t dropout_hash(uint64_t seed, uint64_t pair) {
+  const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
   uint32_t x = lo ^ (uint32_t)seed ^ __umul24(hi, 0x85EBCBu);
   x ^= x >> 16;
   x = __umul24(x, 0x9E3779u) ^ (uint32_t)(seed >> 32);
@@ -295,8 +299,24 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, float 
   x ^= x >> 15;
   x = __umul24(x, 0x7FEB35u);
   x ^= x >> 12;
-  const float u = (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f);
-  return !(u < p);
+  return x;
+}
+__device__ __forceinline__ uint32_t dropout_second(uint32_t x) {
+  const uint32_t y = __umul24(x ^ (x >> 11), 0x9E3779u);
+  return y ^ (y >> 14);
+}
+// keep <=> (24-bit uniform) >= thr, i.e. u24 * 2^-24 >= p exactly
+__device__ __forceinline__ uint32_t dropout_thr(float p) { return (uint32_t)ceilf(p * 16777216.f); }
+// the two elements 2 * pair and 2 * pair + 1
+__device__ __forceinline__ void dropout_keep2(uint64_t seed, uint64_t pair, uint32_t thr, bool& k0, bool& k1) {
+  const uint32_t x = dropout_hash(seed, pair);
+  k0 = (x & 0xFFFFFFu) >= thr;
+  k1 = (dropout_second(x) & 0xFFFFFFu) >= thr;
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, float p) {
+  const uint32_t x = dropout_hash(seed, idx >> 1);
+  const uint32_t u = ((idx & 1) ? dropout_second(x) : x) & 0xFFFFFFu;
+  return u >= dropout_thr(p);
 }
 // returns 0.f (dropped) or 1/(1-p) (kept).  p == 0 -> always 1.
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
