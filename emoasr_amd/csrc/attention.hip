@@ -214,6 +214,17 @@ __device__ __forceinline__ void score_tile(f32x16& acc, const emoasr_attn_t& a, 
   __builtin_amdgcn_wave_barrier();
 }
 
+#ifdef EMO_ATTN_STAMP
+__device__ unsigned long long g_fwd_stamps[64 * 8];
+#define EMO_FSTAMP(k)                                                                                                   \
+  do {                                                                                                                  \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && j0 / 32 < 64)                       \
+      g_fwd_stamps[(j0 / 32) * 8 + (k)] = __builtin_amdgcn_s_memtime();                                                 \
+  } while (0)
+#else
+#define EMO_FSTAMP(k) do {} while (0)
+#endif
+
 // element index of the attention-dropout mask: rows of an EVEN stride, so that keys 2m and 2m + 1 of a row are one hash pair
 // (common.h: dropout_keep2)
 __device__ __forceinline__ uint64_t drop_index(const emoasr_attn_t& a, int b, int h, int i, int j) {
@@ -312,7 +323,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
     }
   };
   auto tile = [&](Pre& cur, Pre& nxt, int j0) {
+    EMO_FSTAMP(0);
     if constexpr (PF2) fetch(nxt, j0 + 32);
+    EMO_FSTAMP(1);
 #pragma unroll
     for (int i = 0; i < VR; ++i) {
       const int v = lane + 64 * i;
@@ -334,8 +347,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
         for (int r = 0; r < 16; ++r) Gs[(32 * ct + c_row(r, lane)) * 32 + (lane & 31)] = g[r];
       }
     }
+    EMO_FSTAMP(2);
     // one register set: every prefetched register has been consumed, refill them with tile j0+32
     if constexpr (!PF2) fetch(cur, j0 + 32);
+    EMO_FSTAMP(3);
     if (rel) {
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -353,13 +368,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
         if (j0 + kl < a.Tk) srow[(long)kl * a.ldst] = s[r] * a.scale;
       }
     }
+    EMO_FSTAMP(4);
     float mt = -INFINITY;
+    if (j0 + 32 <= hp.klen && !a.causal) {  // (wave-uniform) a tile without masked keys: no per-element range tests
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kj = j0 + c_row(r, lane);
-      const bool masked = kj >= hp.klen || (a.causal && kj > qi);
-      s[r] = masked ? -INFINITY : s[r] * a.scale;
-      mt = fmaxf(mt, s[r]);
+      for (int r = 0; r < 16; ++r) {
+        s[r] *= a.scale;
+        mt = fmaxf(mt, s[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kj = j0 + c_row(r, lane);
+        const bool masked = kj >= hp.klen || (a.causal && kj > qi);
+        s[r] = masked ? -INFINITY : s[r] * a.scale;
+        mt = fmaxf(mt, s[r]);
+      }
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float mn = fmaxf(m, mt);
@@ -392,12 +416,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
       }
     }
     __builtin_amdgcn_wave_barrier();
+    EMO_FSTAMP(5);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int ks = 0; ks < NS; ++ks)
         o[dt] = M_::mma(chain_a<T, TR>(Vs, ks, 32 * dt, lane), chain_b<T>(s, ks), o[dt]);
     __builtin_amdgcn_wave_barrier();
+    EMO_FSTAMP(6);
   };
   if constexpr (PF2) {
     Pre pa, pb;
@@ -1786,6 +1812,25 @@ int launch_fwd(const emoasr_attn_t& a, hipStream_t s) {
     }
   }
   emo_timer_end(EMO_TIMER_ATTN_FWD, s);
+#ifdef EMO_ATTN_STAMP
+  {  // debug builds: per-phase cycle counts of the first workgroup's wave 0, averaged over the key tiles (first call only)
+    static int calls = 0;
+    if (calls++ == 0 && sizeof(T) == 2) {
+      unsigned long long h[64 * 8];
+      hipStreamSynchronize(s);
+      hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fwd_stamps), sizeof(h));
+      const int nt = (a.Tk + 31) / 32 < 64 ? (a.Tk + 31) / 32 : 64;
+      double acc[8] = {0};
+      for (int t = 1; t < nt - 1; ++t)
+        for (int k = 1; k < 7; ++k) acc[k] += (double)(h[t * 8 + k] - h[t * 8 + k - 1]);
+      const char* nm[7] = {"", "fetch(PF2)", "V stash + S + band MFMA + Gs write", "fetch(!PF2)", "skew read + st", "softmax + dropout", "P.V"};
+      fprintf(stderr, "[attn fwd stamp] B %d T %d one_round %d: per key tile (cycles):", a.B, a.Tq, (int)one_round);
+      double tot = 0;
+      for (int k = 1; k < 7; ++k) { fprintf(stderr, " %s %.0f |", nm[k], acc[k] / (nt - 2)); tot += acc[k] / (nt - 2); }
+      fprintf(stderr, " total %.0f\n", tot);
+    }
+  }
+#endif
   EMO_LAUNCH_CHECK();
   return 0;
 }
