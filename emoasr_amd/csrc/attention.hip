@@ -1265,11 +1265,13 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t 
 template <typename T, int FW> struct FusedCfg {
   static constexpr int LD = AttnCfg<T>::LD;
   static constexpr int IMG = DqCfg<T>::IMG_LD;
-  // per wave: the dS image with 31 zero rows above and below it (the band un-skew reads key - 31 + query without a
-  // range test), then a region shared by the 64-row f32 skew tile (before the soft-max) and the P image (after it);
-  // the K tile is staged in the same region once, before the sweep
-  static constexpr int IMG_DS_ROWS = 31 + 32 + 32;  // (band column 63 is unused: its keys 32.. must read zeros too)
-  static constexpr int IMG_DS_BYTES = (IMG_DS_ROWS * IMG * (int)sizeof(T) + 15) / 16 * 16;
+  // per wave: the dS image [32 keys][IMG] (dK product), the same values once more as the band gradient dG[query][band column
+  // c = key - query + 31] ([32][LDG], k-contiguous B operand of the band part of dQ; the entries a lane never writes -- keys
+  // outside the tile -- are zeroed once), then a region shared by the 64-row f32 skew tile (before the soft-max) and the P image
+  // (after it); the K tile is staged in the same region once, before the sweep.  (dG used to be gathered out of a zero-padded dS
+  // image: 32 two-byte LDS reads + 16 packs per lane and step against 16 more two-byte writes + 4 sixteen-byte reads.)
+  static constexpr int LDG = 72;
+  static constexpr int IMG_DS_BYTES = (32 * IMG + 32 * LDG) * (int)sizeof(T);
   // at the end of a step the region holds the wave's dQ slab, query-major: [32 queries][DQ_LD floats] (64 d + 4 of padding).
   // A lane owns 4 consecutive d of one query after the chained products (accumulator rows r & 3), so the slab is written
   // with 16-byte stores and flushed with 16-byte reads / global stores (the d-major slab took 32 + 32 scalar LDS accesses and
@@ -1325,11 +1327,11 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
 
   T* stage0 = reinterpret_cast<T*>(smem);
   char* mine = smem + C_::stage_bytes(REL) + wave * C_::WAVE_BYTES;
-  T* img_pad = reinterpret_cast<T*>(mine);           // [31 zero rows | 32 key rows | 31 zero rows][IMG]
-  T* img_ds = img_pad + 31 * IMG;
+  T* img_ds = reinterpret_cast<T*>(mine);            // [32 keys][IMG]
+  T* img_g = img_ds + 32 * IMG;                      // [32 queries][LDG]
   float* Gs = reinterpret_cast<float*>(mine + C_::IMG_DS_BYTES);  // [64 band rows][32 queries] f32 ...
   T* img_p = reinterpret_cast<T*>(mine + C_::IMG_DS_BYTES);       // ... later the P image [32][IMG]
-  for (int i = lane; i < C_::IMG_DS_ROWS * IMG / 2; i += 64) reinterpret_cast<unsigned*>(img_pad)[i] = 0u;
+  for (int i = lane; i < C_::IMG_DS_BYTES / 4; i += 64) reinterpret_cast<unsigned*>(img_ds)[i] = 0u;
   // the four slab bases, for the flush (slab w = wave w's skew region)
   const float* slab0 = reinterpret_cast<const float*>(smem + C_::stage_bytes(REL) + C_::IMG_DS_BYTES);
   constexpr int SLAB_STRIDE = C_::WAVE_BYTES / 4;
@@ -1454,37 +1456,56 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
       const float lse2 = (qval && nxt_lse != -INFINITY) ? nxt_lse * 1.4426950408889634f : INFINITY;
       const float del_q = nxt_del;
       const uint64_t drop_base = drop_index(a, b, h, qi, 0);
-      // S^T = K (Q+u)^T
-      f32x16 s;
-      zero16(s);
+      // S^T = K (Q+u)^T, band G^T = band (Q+v)^T, dP^T = V dO^T.  One wave per SIMD: nothing hides an LDS round trip or a
+      // dependent MFMA, so every operand fragment of the phase is requested first and the four accumulation chains are
+      // interleaved (each MFMA waited for the read issued right before it and for its predecessor in the chain otherwise)
+      typename M_::Frag fq[NK], fo[NK], fv[NK], fb0[NK], fb1[NK];
 #pragma unroll
-      for (int kk = 0; kk < NK; ++kk) s = M_::mma(kfA[kk], M_::load_kc(Qus, LD, 0, kk * M_::KSTEP, lane), s);
+      for (int kk = 0; kk < NK; ++kk) fq[kk] = M_::load_kc(Qus, LD, 0, kk * M_::KSTEP, lane);
       if constexpr (REL) {
-        typename M_::Frag qv[NK];
 #pragma unroll
-        for (int kk = 0; kk < NK; ++kk) qv[kk] = M_::load_kc(Qvs, LD, 0, kk * M_::KSTEP, lane);
+        for (int kk = 0; kk < NK; ++kk) {
+          fv[kk] = M_::load_kc(Qvs, LD, 0, kk * M_::KSTEP, lane);
+          fb0[kk] = M_::load_kc(Bs, LD, 0, kk * M_::KSTEP, lane);
+          fb1[kk] = M_::load_kc(Bs + 32 * LD, LD, 0, kk * M_::KSTEP, lane);
+        }
+      }
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          f32x16 g;
-          zero16(g);
+      for (int kk = 0; kk < NK; ++kk) fo[kk] = M_::load_kc(dOs, LD, 0, kk * M_::KSTEP, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 s, dp;
+      zero16(s); zero16(dp);
+      if constexpr (REL) {
+        f32x16 g0, g1;
+        zero16(g0); zero16(g1);
 #pragma unroll
-          for (int kk = 0; kk < NK; ++kk)
-            g = M_::mma(M_::load_kc(Bs + 32 * ct * LD, LD, 0, kk * M_::KSTEP, lane), qv[kk], g);  // g[c][i]
+        for (int kk = 0; kk < NK; ++kk) {
+          s = M_::mma(kfA[kk], fq[kk], s);
+          g0 = M_::mma(fb0[kk], fv[kk], g0);  // g[c][i]
+          g1 = M_::mma(fb1[kk], fv[kk], g1);
+          dp = M_::mma(vfA[kk], fo[kk], dp);
+        }
+        // (the optimiser sinks the S chain below the skew writes, into the shadow of their LDS round trip: pinning it up here with
+        // an empty asm was measured 85 cycles per step slower)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) Gs[(32 * ct + c_row(r, lane)) * 32 + il] = g[r];
+        for (int r = 0; r < 16; ++r) {
+          Gs[c_row(r, lane) * 32 + il] = g0[r];
+          Gs[(32 + c_row(r, lane)) * 32 + il] = g1[r];
         }
         __builtin_amdgcn_wave_barrier();
         // element (key jl, query il) sits in band column c = 31 - il + jl
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] += Gs[(31 - il + c_row(r, lane)) * 32 + il];
         __builtin_amdgcn_wave_barrier();
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          s = M_::mma(kfA[kk], fq[kk], s);
+          dp = M_::mma(vfA[kk], fo[kk], dp);
+        }
       }
       EMO_STAMP(1);
-      // dP^T = V dO^T
-      f32x16 dp;
-      zero16(dp);
-#pragma unroll
-      for (int kk = 0; kk < NK; ++kk) dp = M_::mma(vfA[kk], M_::load_kc(dOs, LD, 0, kk * M_::KSTEP, lane), dp);
       EMO_STAMP(2);
       // (placing these ~300 VALU instructions ahead of the MFMA chains above moved their 1.5 k cycles, it did not hide them)
       f32x16 ds, dsc;
@@ -1512,6 +1533,7 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
         ds[r] = p * (dp[r] * dsc[r] - del_q) * a.scale;
         csum[r] += ds[r];
         img_ds[c_row(r, lane) * IMG + il] = from_f32<T>(ds[r]);
+        if constexpr (REL) img_g[il * (C_::LDG - 1) + c_row(r, lane) + 31] = from_f32<T>(ds[r]);  // [il][key - il + 31]
         img_p[c_row(r, lane) * IMG + il] = from_f32<T>(p * dsc[r]);
       }
       __builtin_amdgcn_wave_barrier();
@@ -1530,40 +1552,58 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
         }
       }
       EMO_STAMP(4);
-      // dQ^T partial = K^T dS^T (+ band^T unskew(dS^T))
+      // dQ^T partial = K^T dS^T (+ band^T unskew(dS^T));  dV^T += dO^T P,  dK^T += (Q+u)^T dS (sum over the query index:
+      // operands from the bf16 images).  Reads first, as above: the band rows and the un-skewed dS ahead of the four register-
+      // operand MFMAs, the dV / dK operands ahead of the band MFMAs.
+      typename M_::Frag dgf[2][NS], fba[2][2][NS];
+      if constexpr (REL) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int ks = 0; ks < NS; ++ks) {
+            dgf[ct][ks] = M_::load_kc(img_g, C_::LDG, 0, 32 * ct + ks * M_::KSTEP, lane);  // dG^T[c][i], c contiguous
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+              fba[ct][dt][ks] = M_::template load_km<TR>(Bs + 32 * ct * LD, LD, ks * M_::KSTEP, 32 * dt, lane);
+          }
+      }
+      typename M_::Frag dsf[NS];
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) dsf[ks] = chain_b<T>(ds, ks);
+      __builtin_amdgcn_sched_barrier(0);
       f32x16 dq[2];
       zero16(dq[0]); zero16(dq[1]);
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int ks = 0; ks < NS; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < NS; ++ks) dq[dt] = M_::mma(kT[dt][ks], chain_b<T>(ds, ks), dq[dt]);
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = M_::mma(kT[dt][ks], dsf[ks], dq[dt]);
+      typename M_::Frag fdo[2][NS], fqu[2][NS], fp[NS], fd[NS];
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          fdo[dt][ks] = M_::template load_km<TR>(dOs, LD, ks * M_::KSTEP, 32 * dt, lane);
+          fqu[dt][ks] = M_::template load_km<TR>(Qus, LD, ks * M_::KSTEP, 32 * dt, lane);
+        }
+        fp[ks] = M_::load_kc(img_p, IMG, 0, ks * M_::KSTEP, lane);
+        fd[ks] = M_::load_kc(img_ds, IMG, 0, ks * M_::KSTEP, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (REL) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          // dG^T[c][i] = dS^T[c - 31 + i][i] straight out of the zero-padded image, already in the chained operand's
-          // register order (element j of k step ks <-> accumulator register 8 ks + j)
-          typename M_::Frag dgf[NS];
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
           for (int ks = 0; ks < NS; ++ks)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dgf[ks][j] = img_pad[(32 * ct + c_row(8 * ks + j, lane) + il) * IMG + il];
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int ks = 0; ks < NS; ++ks)
-              dq[dt] = M_::mma(chain_a<T, TR>(Bs + 32 * ct * LD, ks, 32 * dt, lane), dgf[ks], dq[dt]);
-        }
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = M_::mma(fba[ct][dt][ks], dgf[ct][ks], dq[dt]);
       }
       EMO_STAMP(5);
-      // dV^T += dO^T P,  dK^T += (Q+u)^T dS   (sum over the query index: operands from the bf16 images)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int ks = 0; ks < NS; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < NS; ++ks) {
-          dv[dt] = M_::mma(M_::template load_km<TR>(dOs, LD, ks * M_::KSTEP, 32 * dt, lane),
-                           M_::load_kc(img_p, IMG, 0, ks * M_::KSTEP, lane), dv[dt]);
-          dk[dt] = M_::mma(M_::template load_km<TR>(Qus, LD, ks * M_::KSTEP, 32 * dt, lane),
-                           M_::load_kc(img_ds, IMG, 0, ks * M_::KSTEP, lane), dk[dt]);
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = M_::mma(fdo[dt][ks], fp[ks], dv[dt]);
+          dk[dt] = M_::mma(fqu[dt][ks], fd[ks], dk[dt]);
         }
       __builtin_amdgcn_wave_barrier();
       EMO_STAMP(6);
