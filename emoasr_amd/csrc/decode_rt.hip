@@ -190,6 +190,11 @@ __global__ __launch_bounds__(256) void cache_gather_kernel(int nl, int nb, int L
 // csrc/decode_wg.hip: the whole stack of either network for one step in ONE single-workgroup launch (bf16)
 bool emo_decode_wg_ok(int dtype, int nb, int nl, int max_layers, int d, int H, int F);
 int emo_bert_lm_step_wg(int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_step_t* io, void* out_hidden, hipStream_t s);
+// csrc/decode_coop.hip: the same in one launch of 16 cooperating workgroups with grid barriers between the stages (bf16)
+bool emo_decode_coop_ok(int dtype, int nb, int nl, int max_layers, int d, int H, int F, int T);
+int emo_bert_lm_step_coop(int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_step_t* io, void* out_hidden, hipStream_t s);
+int emo_transformer_decoder_step_coop(int nl, const emoasr_decoder_layer_t* layers, const emoasr_decoder_step_t* io, void* out_x,
+                                      hipStream_t s);
 int emo_transformer_decoder_step_wg(int nl, const emoasr_decoder_layer_t* layers, const emoasr_decoder_step_t* io, void* out_x,
                                     hipStream_t s);
 namespace {
@@ -255,6 +260,11 @@ extern "C" int emoasr_transformer_decoder_step(int dtype, int nl, const emoasr_d
   void* act = ws.take((size_t)nb * F * esz);
   float* lse = (float*)ws.take((size_t)nb * H * 4);
   EMO_CHECK(ws.ok, "decoder_step: scratch too small (%zu bytes given)", io->ws_bytes);
+  if (emo_decode_coop_ok(dtype, nb, nl, 8, dd, H, F, T)) {
+    // the whole stack in one launch of 16 cooperating workgroups, then the final LayerNorm + vocabulary projection across the chip
+    if (emo_transformer_decoder_step_coop(nl, layers, io, x, s)) return 1;
+    return rl(nb, io->V, dd, x, &io->ln_out, io->out, EMOASR_ACT_NONE, nullptr, nullptr, io->logits_last, 0, stream);
+  }
   if (emo_decode_wg_ok(dtype, nb, nl, 8, dd, H, F)) {
     // the whole stack in one single-workgroup launch, then the final LayerNorm + vocabulary projection across the chip
     if (emo_transformer_decoder_step_wg(nl, layers, io, x, s)) return 1;
@@ -338,6 +348,13 @@ extern "C" int emoasr_bert_lm_step(int dtype, int nl, const emoasr_bert_layer_t*
   void* t2 = ws.take((size_t)nb * d * esz);
   float* logits = (float*)ws.take((size_t)nb * V * 4);
   EMO_CHECK(ws.ok, "bert_lm_step: scratch too small (%zu bytes given)", io->ws_bytes);
+  if (emo_decode_coop_ok(dtype, nb, nl, 12, d, H, F, 0)) {
+    if (emo_bert_lm_step_coop(nl, layers, io, t1, s)) return 1;
+    emoasr_lin_t tied_co{io->word_emb, io->out_bias};
+    if (io->raw_logits) return rl(nb, V, d, t1, &io->ln_transform, tied_co, EMOASR_ACT_NONE, nullptr, nullptr, io->logp, 1, stream);
+    if (rl(nb, V, d, t1, &io->ln_transform, tied_co, EMOASR_ACT_NONE, nullptr, nullptr, logits, 1, stream)) return 1;
+    return emoasr_log_softmax(EMO_F32, nb, V, logits, V, nullptr, 0, 0.f, io->logp, V, stream);
+  }
   if (emo_decode_wg_ok(dtype, nb, nl, 12, d, H, F)) {
     if (emo_bert_lm_step_wg(nl, layers, io, t1, s)) return 1;
     emoasr_lin_t tied_wg{io->word_emb, io->out_bias};

@@ -178,6 +178,21 @@ __global__ __launch_bounds__(256) void topk_kernel(int V, int k, const float* __
   }
 }
 
+#define EMO_DPP_I(old_, v_, ctrl_, rmask_) __builtin_amdgcn_update_dpp((old_), (v_), (ctrl_), (rmask_), 0xf, false)
+// wave-wide max / min through DPP moves: quad swaps, half-row and row mirrors, the GFX9 row broadcasts; the result of lane 63
+__device__ __forceinline__ float topk_wave_max(float v) {
+#define EMO_STEP(ctrl_, rm_) v = fmaxf(v, __builtin_bit_cast(float, EMO_DPP_I(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl_, rm_)))
+  EMO_STEP(0xB1, 0xf); EMO_STEP(0x4E, 0xf); EMO_STEP(0x141, 0xf); EMO_STEP(0x140, 0xf); EMO_STEP(0x142, 0xa); EMO_STEP(0x143, 0xc);
+#undef EMO_STEP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int topk_wave_min(int v) {
+#define EMO_STEP(ctrl_, rm_) v = min(v, EMO_DPP_I(v, v, ctrl_, rm_))
+  EMO_STEP(0xB1, 0xf); EMO_STEP(0x4E, 0xf); EMO_STEP(0x141, 0xf); EMO_STEP(0x140, 0xf); EMO_STEP(0x142, 0xa); EMO_STEP(0x143, 0xc);
+#undef EMO_STEP
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 // log-softmax of the decoder row + mu * log-softmax of the LM row + top-k, one launch, one workgroup of 1024 threads per
 // hypothesis (the beam search never needs the full score rows: three launches and ~130 us per step become one of ~20 us).
 //   s[v] = (dec[v] - lse(dec)) + mu * (lm[v] - lse(lm));  vals / idx = the k largest s (ties -> lowest index);
@@ -228,13 +243,10 @@ __global__ __launch_bounds__(1024) void beam_scores_topk_kernel(int V, int k, co
     if (r > lb) { lb = r; li = v; }   // ascending v: ties keep the lower index
   }
   for (int j = 0; j < k; ++j) {
-    float best = lb; int bi = li;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
+    // wave winner: the maximum, then the lowest index among the lanes that hold it (two DPP reductions of ~7 short instructions
+    // each; the shuffle form was 12 dependent ds_bpermutes per round, most of the kernel's 47 us at k = 15)
+    float best = topk_wave_max(lb);
+    int bi = topk_wave_min(lb == best ? li : 0x7fffffff);
     const int par = j & 1;
     if (lane == 0) { redv[par][wave] = best; redi[par][wave] = bi; }
     __syncthreads();
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(64) void ctc_prefix_kernel(int Tn, int V, int cw, c
     __builtin_amdgcn_wave_barrier();
     const int n = min(64, Tn - t0);
     for (int i = 0; i < n; ++i) {
-      const float rn_prev = __shfl(v, 0, 64);
+      const float rn_prev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));  // (v_readlane: a few cycles; __shfl = ds_bpermute, ~100, on the recurrence's critical path)
       const float phi = s_phi[i], xt = s_x[i];
       const float a = lane == 0 ? phi : (lane == 1 ? phi + xt : rn_prev);
       const float bb = lane == 0 ? xt : (lane == 1 ? 0.f : s_xb[i]);
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(64) void ctc_prefix_kernel(int Tn, int V, int cw, c
     if (t < Tn) { r[2 * t] = s_rn[lane]; r[2 * t + 1] = s_rb[lane]; }
     __builtin_amdgcn_wave_barrier();
   }
-  float psi = __shfl(v, 1, 64);
+  float psi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 1));
   if (lane == 0) {
     if (tok == eos) psi = np_logaddexp(rp[2 * (Tn - 1)], rp[2 * (Tn - 1) + 1]);
     if (tok == blank) psi = EMO_LOG0;

@@ -52,6 +52,9 @@ class _Buffers:
         self.state_host = torch.zeros(4, dtype=torch.int32).pin_memory()
 
 
+_yield = os.sched_yield if os.environ.get("EMOASR_BEAM_YIELD", "1") != "0" else (lambda: None)
+
+
 def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=None, lm_weight=0, decode_ctc_weight=0):
     eng = _engine_of(dec)
     assert eouts.shape[0] == 1, "beam search decodes one utterance at a time (decoders/transformer.py:181)"
@@ -69,6 +72,8 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
     timing = os.environ.get("EMOASR_BEAM_TIMING") == "1"
     if os.environ.get("EMOASR_DECODE_WG"):      # A/B switch of csrc/decode_wg.hip (one launch per network and step)
         lib.set_option("decode_wg", int(os.environ["EMOASR_DECODE_WG"]))
+    if os.environ.get("EMOASR_DECODE_COOP"):    # A/B switch of csrc/decode_coop.hip (one cooperative launch per network and step)
+        lib.set_option("decode_coop", int(os.environ["EMOASR_DECODE_COOP"]))
     if os.environ.get("EMOASR_DECODE_FUSED"):   # A/B switch of csrc/rowlin.hip inside the cached steps
         lib.set_option("decode_fused", int(os.environ["EMOASR_DECODE_FUSED"]))
     if timing:
@@ -198,6 +203,8 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
             for k in (0, 1):
                 for part in ((0, 1, 2) if use_lm else (0, 2)):
                     lib.call("emoasr_joint_beam_graph_build", dt_code, ctypes.byref(steps[k]), k, part, main_p)
+            if timing:
+                print(f"[beam timing] graph build / update {1e3 * (time.perf_counter() - t_loop0):.2f} ms", flush=True)
         # Steps are issued one ahead of the flag they depend on: a step launched after the search has finished changes
         # nothing (emoasr_beam_update returns at once), and the GPU never waits for the host's round trip.
         ev_tail, ev_lm = torch.cuda.Event(), torch.cuda.Event()
@@ -236,7 +243,7 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
             # arrives in pinned memory by the kernel's own store; polling it involves no copy engine and no event.
             if i >= 1:
                 while mirror[0] < i and not mirror[3]:
-                    pass
+                    _yield()   # the runtime's own threads (signal handling, graph bookkeeping) may share this core
                 if mirror[3]:
                     break
             if dbg:
@@ -247,6 +254,9 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
                 if _t2 - _t1 > worst[0]:
                     worst = (_t2 - _t1, i, "sync")
         main.synchronize()
+        if lib.size_query("emoasr_decode_coop_status") != 0:
+            raise RuntimeError("decode_coop: a grid barrier gave up waiting (csrc/decode_coop.hip); emoasr_set_option('decode_coop', 0) "
+                               "selects the launch chain")
         if dbg:
             print(f"   host: launches {1e3 * t_l:.2f} ms, waits {1e3 * t_s:.2f} ms, worst {1e3 * worst[0]:.2f} ms at step {worst[1]} ({worst[2]})", flush=True)
         if gc_was_on:

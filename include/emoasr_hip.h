@@ -574,6 +574,10 @@ int emoasr_rowlin(int M, int N, int K, const void* x, long ldx, const float* lna
                   const float* lnr_b, float lnr_eps, void* y, int out_f32, long ldy, void* stream);
 int emoasr_attn_step(int nb, int d, int H, int Lmax, const void* qkv, void* kcache, void* vcache, const int* pos, void* out,
                      void* stream);
+/* The steps run as one cooperative launch per network (csrc/decode_coop.hip, option "decode_coop", bf16, <= 16 hypotheses): 0 when
+ * none of its grid barriers ever gave up waiting, 1 otherwise (results of that step are then undefined), -1 on a runtime error.
+ * Synchronises the device. */
+long emoasr_decode_coop_status(void);
 int emoasr_beam_cache_gather(int dtype, int nl, int nb, int Lmax, int d, const void* src_k, const void* src_v, void* dst_k,
                              void* dst_v, const int* parent, const int* pos, void* stream);
 /* Beam bookkeeping of one output step (decoders/transformer.py:215-290) for up to 32 beams x 32 candidates, one workgroup:

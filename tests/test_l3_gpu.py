@@ -208,11 +208,12 @@ def test_device_beam_search_equals_host_bookkeeping(dev, dtype, monkeypatch):
                     assert hyps[0] == hyps_h[0] and abs(scores[0] - scores_h[0]) < 2e-2 * abs(scores_h[0]) + 1e-3
 
 
-@pytest.mark.parametrize("option", ["decode_wg", "decode_fused"])
+@pytest.mark.parametrize("option", ["decode_coop", "decode_wg", "decode_fused"])
 def test_alternative_decode_step_kernels_agree(dev, option):
-    """the two measured-and-not-kept forms of the cached decode steps (csrc/decode_wg.hip: one workgroup per network;
-    csrc/rowlin.hip: LayerNorm / cache append folded into small-M kernels) give the same best hypothesis as the default
-    launch chain (bf16: scores to 2 %)"""
+    """the forms of the cached decode steps -- csrc/decode_coop.hip (the default: one launch of 16 cooperating workgroups per
+    network, grid barriers between the stages), and the two measured-and-not-kept ones, csrc/decode_wg.hip (one workgroup per
+    network) and csrc/rowlin.hip (LayerNorm / cache append folded into small-M kernels) -- give the same best hypothesis as the
+    plain launch chain (bf16: scores to 2 %)"""
     from emoasr_amd import lib
     from emoasr_amd.modeling.lm import LM
     model, g = _build(torch.bfloat16, dev)
@@ -220,12 +221,18 @@ def test_alternative_decode_step_kernels_agree(dev, option):
     lm = LM(SimpleNamespace(**LM_CFG), compute_dtype=torch.bfloat16)
     lm.load_state_dict(lm_state(g))
     lm = lm.to(dev).eval()
-    n = int(g["xlens"][0])
-    x, xl = g["xs"][:1, :n].to(dev), g["xlens"][:1]
-    ref_h, ref_s, _, _ = model.decode(x, xl, lm=lm, **DECODE_SETTINGS[2])
     try:
-        lib.set_option(option, 1)
-        hyps, scores, _, _ = model.decode(x, xl, lm=lm, **DECODE_SETTINGS[2])
+        for u in range(min(3, len(g["xlens"]))):
+            n = int(g["xlens"][u])
+            x, xl = g["xs"][u:u + 1, :n].to(dev), g["xlens"][u:u + 1]
+            lib.set_option("decode_coop", 0)
+            ref_h, ref_s, _, _ = model.decode(x, xl, lm=lm, **DECODE_SETTINGS[2])
+            lib.set_option(option, 1)
+            hyps, scores, _, _ = model.decode(x, xl, lm=lm, **DECODE_SETTINGS[2])
+            if option != "decode_coop":
+                lib.set_option(option, 0)
+            assert lib.size_query("emoasr_decode_coop_status") == 0
+            assert hyps[0] == ref_h[0] and abs(scores[0] - ref_s[0]) < 2e-2 * abs(ref_s[0]) + 1e-3, (u, hyps[0], ref_h[0], scores[0], ref_s[0])
     finally:
         lib.set_option(option, 0)
-    assert hyps[0] == ref_h[0] and abs(scores[0] - ref_s[0]) < 2e-2 * abs(ref_s[0]) + 1e-3, (hyps[0], ref_h[0], scores[0], ref_s[0])
+        lib.set_option("decode_coop", 1)
