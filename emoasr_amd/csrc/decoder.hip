@@ -203,20 +203,37 @@ template <typename T>
 __global__ __launch_bounds__(1024) void beam_scores_topk_kernel(int V, int k, const T* __restrict__ dec, long ldd,
                                                                 const float* __restrict__ lm, long ldl, float mu,
                                                                 float* __restrict__ vals, int* __restrict__ idx,
-                                                                float* __restrict__ lm_at) {
-  extern __shared__ float sbuf[];      // [V] scores
-  __shared__ float redv[2][16];
-  __shared__ int redi[2][16];
+                                                                float* __restrict__ lm_at, int lm_lds) {
+  extern __shared__ float sbuf[];      // [V] the decoder row (f32), later the scores | [16][k] x 2 survivors | (lm_lds) [V] the LM row
   __shared__ float red4[4][16];
   const long m = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T* drow = dec + m * ldd;
   const float* lrow = lm ? lm + m * ldl : nullptr;
+  // Both rows go to LDS first, four strided elements of each per thread and trip (8 loads in flight): read where they are used,
+  // inside three loops of ~V / 1024 dependent trips each, the rows cost ~30 global round trips -- most of the kernel's 41 us.
+  // A thread only ever reads back the elements it staged itself (v = tid mod 1024), so no barrier is needed.
+  float* slm = (lrow && lm_lds) ? sbuf + V + 32 * k : nullptr;
+  for (int v0 = tid; v0 < V; v0 += 4096) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = v0 + 1024 * u;
+      a[u] = v < V ? to_f32(drow[v]) : 0.f;
+      b[u] = (slm && v < V) ? lrow[v] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = v0 + 1024 * u;
+      if (v < V) { sbuf[v] = a[u]; if (slm) slm[v] = b[u]; }
+    }
+  }
+  const float* lsrc = slm ? slm : lrow;   // (LM row too long for LDS: read from global memory as before)
   // ---- the two log-sum-exps ----
   float mxd = -INFINITY, mxl = -INFINITY;
   for (int v = tid; v < V; v += 1024) {
-    mxd = fmaxf(mxd, to_f32(drow[v]));
-    if (lrow) mxl = fmaxf(mxl, lrow[v]);
+    mxd = fmaxf(mxd, sbuf[v]);
+    if (lrow) mxl = fmaxf(mxl, lsrc[v]);
   }
   for (int o = 32; o > 0; o >>= 1) { mxd = fmaxf(mxd, __shfl_xor(mxd, o)); mxl = fmaxf(mxl, __shfl_xor(mxl, o)); }
   if (lane == 0) { red4[0][wave] = mxd; red4[1][wave] = mxl; }
@@ -225,8 +242,8 @@ __global__ __launch_bounds__(1024) void beam_scores_topk_kernel(int V, int k, co
   for (int w = 1; w < 16; ++w) { mxd = fmaxf(mxd, red4[0][w]); mxl = fmaxf(mxl, red4[1][w]); }
   float sd = 0.f, sl = 0.f;
   for (int v = tid; v < V; v += 1024) {
-    sd += expf(to_f32(drow[v]) - mxd);
-    if (lrow) sl += expf(lrow[v] - mxl);
+    sd += expf(sbuf[v] - mxd);
+    if (lrow) sl += expf(lsrc[v] - mxl);
   }
   for (int o = 32; o > 0; o >>= 1) { sd += __shfl_xor(sd, o); sl += __shfl_xor(sl, o); }
   if (lane == 0) { red4[2][wave] = sd; red4[3][wave] = sl; }
@@ -234,40 +251,105 @@ __global__ __launch_bounds__(1024) void beam_scores_topk_kernel(int V, int k, co
   sd = 0.f; sl = 0.f;
   for (int w = 0; w < 16; ++w) { sd += red4[2][w]; sl += red4[3][w]; }
   const float lsed = mxd + logf(sd), lsel = lrow ? mxl + logf(sl) : 0.f;
-  // ---- scores into LDS; local best of this thread's elements ----
+  // ---- scores; local best of this thread's elements ----
+  // Two levels, so that a round costs no workgroup barrier: every wave selects the k best of its own lanes' elements (a round = two
+  // DPP reductions -- the maximum, then the lowest index among the lanes that hold it -- and a rescan of the lanes' elements),
+  // then wave 0 merges the 16 x k survivors the same way.  The elements being rescanned sit in REGISTERS (V <= 16 K, k <= 32;
+  // beyond that the LDS copies are walked): a rescan loop over LDS with a run-time trip count waits ~130 cycles per element for
+  // one useful lane, which -- not the reductions, the barrier or the global loads -- was 2 us per round (42 us at k = 15).
+  constexpr int NE = 16, NM = 8;
+  const bool e_regs = V <= NE * 1024;
   float lb = -INFINITY; int li = 0x7fffffff;
-  for (int v = tid; v < V; v += 1024) {
-    float r = to_f32(drow[v]) - lsed;
-    if (lrow) r += mu * (lrow[v] - lsel);
-    sbuf[v] = r;
-    if (r > lb) { lb = r; li = v; }   // ascending v: ties keep the lower index
+  float e[NE];
+  if (e_regs) {
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int v = tid + 1024 * u;
+      e[u] = -INFINITY;
+      if (v < V) {
+        float r = sbuf[v] - lsed;
+        if (lrow) r += mu * (lsrc[v] - lsel);
+        e[u] = r;
+        if (r > lb) { lb = r; li = v; }   // ascending v: ties keep the lower index
+      }
+    }
+  } else {
+    for (int v = tid; v < V; v += 1024) {
+      float r = sbuf[v] - lsed;
+      if (lrow) r += mu * (lsrc[v] - lsel);
+      sbuf[v] = r;
+      if (r > lb) { lb = r; li = v; }
+    }
   }
+  float* cand_v = sbuf + V;                              // [16][k] survivors of the waves (dynamic LDS after the score row)
+  int* cand_i = reinterpret_cast<int*>(cand_v + 16 * k);
   for (int j = 0; j < k; ++j) {
-    // wave winner: the maximum, then the lowest index among the lanes that hold it (two DPP reductions of ~7 short instructions
-    // each; the shuffle form was 12 dependent ds_bpermutes per round, most of the kernel's 47 us at k = 15)
-    float best = topk_wave_max(lb);
-    int bi = topk_wave_min(lb == best ? li : 0x7fffffff);
-    const int par = j & 1;
-    if (lane == 0) { redv[par][wave] = best; redi[par][wave] = bi; }
-    __syncthreads();
-    best = redv[par][0]; bi = redi[par][0];
-    for (int w = 1; w < 16; ++w) {
-      const float ob = redv[par][w];
-      const int oi = redi[par][w];
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    if (bi == 0x7fffffff) bi = 0;
-    if (tid == 0) {
-      vals[m * k + j] = best;
-      idx[m * k + j] = bi;
-      if (lm_at) lm_at[m * k + j] = lrow ? lrow[bi] - lsel : 0.f;
-    }
-    if ((bi & 1023) == tid) {   // the owner: drop the winner, rescan its own elements
+    const float best = topk_wave_max(lb);
+    const int bi = topk_wave_min(lb == best ? li : 0x7fffffff);
+    if (lane == 0) { cand_v[wave * k + j] = best; cand_i[wave * k + j] = bi; }
+    if (e_regs) {   // every lane: drop the winner if it is mine, take the best of what is left
+      lb = -INFINITY; li = 0x7fffffff;
+#pragma unroll
+      for (int u = 0; u < NE; ++u) {
+        if (tid + 1024 * u == bi) e[u] = -INFINITY;
+        if (e[u] > lb) { lb = e[u]; li = tid + 1024 * u; }
+      }
+    } else if (bi != 0x7fffffff && (bi & 1023) == tid) {
       sbuf[bi] = -INFINITY;
       lb = -INFINITY; li = 0x7fffffff;
       for (int v = tid; v < V; v += 1024) {
         const float c = sbuf[v];
         if (c > lb) { lb = c; li = v; }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // lane owns survivors lane, lane + 64, ... of the 16 k (indices are unique; -inf / 0x7fffffff entries are never picked)
+    const int n = 16 * k;
+    const bool m_regs = n <= NM * 64;
+    float cv[NM]; int ci[NM];
+#pragma unroll
+    for (int u = 0; u < NM; ++u) {
+      const int c = lane + 64 * u;
+      cv[u] = (m_regs && c < n) ? cand_v[c] : -INFINITY;
+      ci[u] = (m_regs && c < n) ? cand_i[c] : 0x7fffffff;
+    }
+    float mb = -INFINITY; int mi = 0x7fffffff;
+    auto rescan = [&]() {
+      mb = -INFINITY; mi = 0x7fffffff;
+      if (m_regs) {
+#pragma unroll
+        for (int u = 0; u < NM; ++u)
+          if (cv[u] > mb || (cv[u] == mb && ci[u] < mi)) { mb = cv[u]; mi = ci[u]; }
+      } else {
+        for (int c = lane; c < n; c += 64) {
+          const float xv = cand_v[c];
+          const int xi = cand_i[c];
+          if (xv > mb || (xv == mb && xi < mi)) { mb = xv; mi = xi; }
+        }
+      }
+    };
+    rescan();
+    for (int j = 0; j < k; ++j) {
+      const float best = topk_wave_max(mb);
+      int bi = topk_wave_min(mb == best ? mi : 0x7fffffff);
+      if (bi != 0x7fffffff) {
+        if (m_regs) {
+#pragma unroll
+          for (int u = 0; u < NM; ++u)
+            if (ci[u] == bi) { cv[u] = -INFINITY; ci[u] = 0x7fffffff; }
+        } else {
+          for (int c = lane; c < n; c += 64)
+            if (cand_i[c] == bi) { cand_v[c] = -INFINITY; cand_i[c] = 0x7fffffff; }
+        }
+        rescan();
+      }
+      if (bi == 0x7fffffff) bi = 0;
+      if (lane == 0) {
+        vals[m * k + j] = best;
+        idx[m * k + j] = bi;
+        if (lm_at) lm_at[m * k + j] = lrow ? lsrc[bi] - lsel : 0.f;   // (from the LDS copy: a global load here was a round trip per round)
       }
     }
   }
@@ -294,7 +376,7 @@ __global__ __launch_bounds__(64) void ctc_prefix_kernel(int Tn, int V, int cw, c
                                                         const int* __restrict__ last, const int* __restrict__ out_len,
                                                         const int* __restrict__ cands, int blank, int eos,
                                                         float* __restrict__ log_psi, float* __restrict__ states) {
-  __shared__ float s_phi[64], s_x[64], s_xb[64], s_rn[64], s_rb[64];
+  __shared__ float s_rn[64], s_rb[64];
   const int m = blockIdx.x / cw, c = blockIdx.x % cw, lane = threadIdx.x;
   const float* rp = prev_states ? prev_states + ((long)parent[m] * cw_prev + pcand[m]) * Tn * 2 : init_state;
   const int tok = cands[m * cw + c];
@@ -316,19 +398,23 @@ __global__ __launch_bounds__(64) void ctc_prefix_kernel(int Tn, int V, int cw, c
   float v = lane == 2 ? EMO_LOG0 : v0;  // rn = psi = v0, rb = LOG_0
   for (int t0 = start; t0 < Tn; t0 += 64) {
     const int t = t0 + lane;
+    // lane i keeps frame t0 + i's inputs in registers; the recurrence lanes fetch them with v_readlane (the LDS copies they used
+    // to read cost a ~130-cycle round trip per frame on top of the dependent exp / log chain: 53 us at T' 285)
+    float my_phi = 0.f, my_x = 0.f, my_xb = 0.f;
     if (t < Tn) {
       const float pn = rp[2 * (t - 1)], pb = rp[2 * (t - 1) + 1];
-      s_phi[lane] = same ? pb : np_logaddexp(pn, pb);
-      s_x[lane] = x[(long)t * V + tok];
-      s_xb[lane] = x[(long)t * V + blank];
+      my_phi = same ? pb : np_logaddexp(pn, pb);
+      my_x = x[(long)t * V + tok];
+      my_xb = x[(long)t * V + blank];
     }
-    __builtin_amdgcn_wave_barrier();
     const int n = min(64, Tn - t0);
     for (int i = 0; i < n; ++i) {
-      const float rn_prev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));  // (v_readlane: a few cycles; __shfl = ds_bpermute, ~100, on the recurrence's critical path)
-      const float phi = s_phi[i], xt = s_x[i];
+      const float rn_prev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+      const float phi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_phi), i));
+      const float xt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_x), i));
+      const float xbl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_xb), i));
       const float a = lane == 0 ? phi : (lane == 1 ? phi + xt : rn_prev);
-      const float bb = lane == 0 ? xt : (lane == 1 ? 0.f : s_xb[i]);
+      const float bb = lane == 0 ? xt : (lane == 1 ? 0.f : xbl);
       if (lane < 3) {
         // same formula as np_logaddexp with the hardware exp / log (v_exp_f32, v_log_f32): |error| < 1e-7 in
         // absolute terms per step against scores of magnitude 10..100 (the library expf / log1pf pair is ~4x
@@ -390,14 +476,16 @@ extern "C" int emoasr_beam_scores_topk(int dtype, int M, int V, int k, const voi
                                        float mu, float* vals, int* idx, float* lm_at, void* stream) {
   if (M == 0) return 0;
   EMO_CHECK(k >= 1 && k <= V, "beam_scores_topk: k=%d V=%d", k, V);
-  EMO_CHECK((size_t)V * 4 <= 150 * 1024, "beam_scores_topk: V=%d too large for an LDS row", V);
-  const int bytes = V * 4;
+  int bytes = V * 4 + 16 * k * 8;   // the score row + the 16 waves' k survivors (value, index)
+  EMO_CHECK((size_t)bytes <= 150 * 1024, "beam_scores_topk: V=%d, k=%d too large for the LDS plan", V, k);
+  const int lm_lds = lm && (size_t)bytes + (size_t)V * 4 <= 150 * 1024;   // the LM row staged in LDS as well
+  if (lm_lds) bytes += V * 4;
   if (dtype == EMO_BF16) {
     if (bytes > 60 * 1024) hipFuncSetAttribute((const void*)beam_scores_topk_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    beam_scores_topk_kernel<bf16><<<M, 1024, bytes, (hipStream_t)stream>>>(V, k, (const bf16*)dec, ldd, lm, ldl, mu, vals, idx, lm_at);
+    beam_scores_topk_kernel<bf16><<<M, 1024, bytes, (hipStream_t)stream>>>(V, k, (const bf16*)dec, ldd, lm, ldl, mu, vals, idx, lm_at, lm_lds);
   } else if (dtype == EMO_F32) {
     if (bytes > 60 * 1024) hipFuncSetAttribute((const void*)beam_scores_topk_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    beam_scores_topk_kernel<float><<<M, 1024, bytes, (hipStream_t)stream>>>(V, k, (const float*)dec, ldd, lm, ldl, mu, vals, idx, lm_at);
+    beam_scores_topk_kernel<float><<<M, 1024, bytes, (hipStream_t)stream>>>(V, k, (const float*)dec, ldd, lm, ldl, mu, vals, idx, lm_at, lm_lds);
   } else {
     emo_set_error("bad dtype %d", dtype);
     return 1;
