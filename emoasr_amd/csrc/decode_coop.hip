@@ -12,15 +12,16 @@
 // 32-deep weight fragments of a stage, requested BEFORE the barrier that precedes the stage.
 //
 // MEASURED (MI355X, beam 10, d 256, F 1024 / 2048, rocprofv3, both chains running concurrently): LM stack 351 us per step (the
-// launch chain: ~500), decoder stack 339 us (~375); search step 0.68 -> 0.52 ms.  In-kernel stamps (-DEMO_COOP_STAMP) of the LM
-// stack, per layer: barriers 5 x ~3 us (gather 0.4, release fence 1.0, add 0.2, wait 1.2, acquire fence 0.3), QKV stage 5.9 us
-// (of which LayerNorm 2.6), attention 7 (q load 1.2, one 64-key pass 5), out-projection 3, FFN 6 + 4.3.  What it took to get
-// there: 512 instead of 1024 threads (at 128 registers the kernels spilled, and a spill reloaded after the barrier's cache
-// invalidate is a memory round trip), per-stage index arithmetic kept out of the layer loop's preheader (EMO_FRESH), the layers'
-// parameter pointers in LDS instead of the kernel-argument segment, release / acquire fences instead of two full fences per
-// barrier (480 -> 351 us together); DPP instead of shuffle reductions changed little.  Every phase runs ~3x longer than its
-// instruction latencies add up to -- the device clocks down with 32 of 256 CUs busy -- so the remaining lever is fewer stages,
-// not faster ones.
+// launch chain: ~500), decoder stack 339 us (~375); search step 0.68 -> 0.52 ms.  In-kernel stamps (-DEMO_COOP_STAMP; s_memtime
+// ticks at the 2.39 GHz shader clock, tools/micro/clock_probe.hip) of the LM stack, per layer: barriers 5 x 2.0 us (gather 0.25,
+// release fence 0.65, add 0.1, wait 0.8, acquire fence 0.2), QKV stage 3.8 us (of which LayerNorm 1.6), attention 4.5 (q load 0.8,
+// one 64-key pass 3.2), out-projection 1.9, FFN 3.8 + 2.75: ~27 us per layer.  What it took to get there: 512 instead of 1024
+// threads (at 128 registers the kernels spilled, and a spill reloaded after the barrier's cache invalidate is a memory round
+// trip), per-stage index arithmetic kept out of the layer loop's preheader (EMO_FRESH), the layers' parameter pointers in LDS
+// instead of the kernel-argument segment, release / acquire fences instead of two full fences per barrier (480 -> 351 us
+// together); DPP instead of shuffle reductions changed little.  A stage is a handful of dependent memory round trips (~0.8 us each
+// after the invalidate) and dependent-instruction chains (5.75 cycles per dependent VALU op) on a nearly idle chip: the remaining
+// lever is fewer stages, not faster ones.
 //
 //   linear stage  : all activation rows [16][K] -> LDS (every workgroup; LayerNorm recomputed by each, one wave per row);
 //                   workgroup g owns the 16-column strips g, g + 16, ...; its 16 waves split (strip, k step) units, one 16x16x32
