@@ -919,3 +919,39 @@ def test_attn_step_single_query_with_cache_append(dev, pos):
     v = vc[:, :pos + 1].float().view(nb, pos + 1, H, d // H).transpose(1, 2)
     ref = (torch.softmax(q @ k.transpose(-1, -2) / (d // H) ** 0.5, -1) @ v).transpose(1, 2).reshape(nb, d)
     _close(out, ref, 1.5e-2, "attn_step")
+
+
+@pytest.mark.parametrize("V,k,use_lm", [(10000, 15, True), (10000, 15, False), (40, 6, True), (20000, 15, True), (10000, 40, True),
+                                        (5000, 1, True)])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_beam_scores_topk(dev, dtype, V, k, use_lm):
+    """log-softmax(decoder row) + mu * log-softmax(LM row) + top-k (csrc/decoder.hip): the register-resident two-level selection,
+    its LDS fallbacks (rows longer than 16 K, more than 32 candidates), and the tie rule (lowest index first)"""
+    from emoasr_amd import lib, ops
+    M, mu = 7, 0.3
+    dec = _rnd(dev, M, V, dtype=dtype, scale=3.0)
+    dec[:, 5] = dec[:, 3]                      # exact ties inside a row
+    dec[2, :] = 0.0                            # a whole row of ties: indices 0 .. k - 1 in order
+    lm = _rnd(dev, M, V, scale=2.0)
+    lm[:, 5] = lm[:, 3]
+    lm[2, :] = 0.0
+    vals = torch.empty(M, k, device=dev)
+    idx = torch.empty(M, k, device=dev, dtype=torch.int32)
+    at = torch.empty(M, k, device=dev)
+    lib.call("emoasr_beam_scores_topk", ops.dt(dec), M, V, k, dec.data_ptr(), V, lm.data_ptr() if use_lm else None, V, mu,
+             vals.data_ptr(), idx.data_ptr(), at.data_ptr(), ops._stream())
+    s = torch.log_softmax(dec.float(), -1)
+    llm = torch.log_softmax(lm, -1)
+    if use_lm:
+        s = s + mu * llm
+    # reference order: value descending, index ascending among equals (a stable sort of the negated scores)
+    order = torch.sort(-s, dim=-1, stable=True).indices[:, :k]
+    ref = torch.gather(s, 1, order)
+    _close(vals, ref, 1e-5, "vals")
+    got = torch.gather(s, 1, idx.long())
+    _close(got, ref, 1e-5, "scores at the returned indices")
+    assert (idx[2].cpu() == torch.arange(k, dtype=torch.int32)).all(), idx[2]
+    for m in range(M):                          # no duplicates
+        assert len(set(idx[m].tolist())) == k
+    if use_lm:
+        _close(at, torch.gather(llm, 1, idx.long()), 1e-5, "lm_at")
