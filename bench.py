@@ -457,6 +457,11 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point GPU time table to stderr")
     args = ap.parse_args()
 
+    # the intra-op CPU pool must fit the container's CPU quota, or the kernel throttles the whole process -- the launching and
+    # polling thread included -- for tens of milliseconds at a time (emoasr_amd/hostenv.py)
+    from emoasr_amd.hostenv import respect_cpu_quota
+    respect_cpu_quota()
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -39,6 +39,8 @@ def test_step(model, data, beam_width, len_weight, decode_ctc_weight, decode_pho
 def test(model, dataloader, vocab, beam_width, len_weight, decode_ctc_weight, decode_phone, lm, lm_weight, device,
          eos_id=2, num_samples=-1, sample_utt_id=None, nbest=False):
     """test_asr.py:63-121 -> rows.  An utterance without any hypothesis gives token_id None and an empty text."""
+    from .hostenv import respect_cpu_quota
+    respect_cpu_quota()   # (an oversized CPU pool under a cgroup quota freezes the decoding thread for 20-50 ms at a time)
     rows = []
     n = len(dataloader) if hasattr(dataloader, "__len__") else -1
     for i, data in enumerate(dataloader):

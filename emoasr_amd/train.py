@@ -187,6 +187,8 @@ def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False
     running loss_dict sums are logged every params.log_step optimizer steps (the only host
     synchronisation of the loop)."""
     import logging
+    from .hostenv import respect_cpu_quota
+    respect_cpu_quota()   # (an oversized CPU pool under a cgroup quota freezes the launching thread for 20-50 ms at a time)
     log = log or logging.info
     optimizer.update_epoch()
     step, sums = 0, {}

@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import bench
+from emoasr_amd.hostenv import respect_cpu_quota
+if __import__('os').environ.get('EMOASR_NO_QUOTA') != '1':
+    respect_cpu_quota()
 
 dev = torch.device("cuda:0")
 for mode in os.environ.get("MODES", "1,0").split(","):
