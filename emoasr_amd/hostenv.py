@@ -48,7 +48,10 @@ def respect_cpu_quota(reserve=4):
     q = cpu_quota()
     have = min(torch.get_num_threads(), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
     if q is not None:
-        want = max(1, min(have, q - reserve if q > reserve else 1))
+        # one process per GPU: the ranks of this node share the quota
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+        share = max(1, q // max(1, local))
+        want = max(1, min(have, share - reserve if share > 2 * reserve else max(1, share // 2)))
         if want < torch.get_num_threads():
             torch.set_num_threads(want)
     return torch.get_num_threads()
