@@ -190,7 +190,10 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
             t_loop = time.perf_counter()
         main_p, side_p = main.cuda_stream, (side.cuda_stream if side is not None else None)
         t_loop0 = time.perf_counter()
-        use_graph = os.environ.get("EMOASR_BEAM_GRAPH", "1") != "0"
+        # HIP graphs pay off for the launch chains (~185 kernels per step); with the cooperative step kernels a step is ~25 launches
+        # and plain launches are ~3 % faster (no graph boundaries: 0.476-0.607 against 0.494-0.625 ms per step over T' 190-600)
+        g_env = os.environ.get("EMOASR_BEAM_GRAPH", "auto")
+        use_graph = (os.environ.get("EMOASR_DECODE_COOP", "1") == "0") if g_env == "auto" else g_env != "0"
         if use_graph:
             if not getattr(eng, "_beam_graph_warm", False):
                 # first use in this process: one eager pass with the search marked finished, so that every kernel's lazy

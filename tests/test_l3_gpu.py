@@ -195,6 +195,7 @@ def test_device_beam_search_equals_host_bookkeeping(dev, dtype, monkeypatch):
                 n = int(g["xlens"][b])
                 x, xl = g["xs"][b:b + 1, :n].to(dev), g["xlens"][b:b + 1]
                 monkeypatch.setenv("EMOASR_DEVICE_BEAM", "1")
+                monkeypatch.setenv("EMOASR_BEAM_GRAPH", "1" if b == 0 else "0")   # the step as HIP graphs / as plain launches
                 k0 = len(calls)
                 hyps, scores, _, _ = model.decode(x, xl, lm=lm, **kw)
                 assert len(calls) == k0 + 1, "device path not taken"
