@@ -186,7 +186,7 @@ __device__ __forceinline__ Plan make_plan(int N, int K, int g, int wave) {
 }
 constexpr int C_OPT = 1024 / CT;   // outputs per thread of a linear stage (at most 4 strips x 256 per workgroup)
 struct WFrag { bf16x8 w[C_UPW]; float bias[C_OPT]; };
-struct LnFrag { float g[C_MAXD / 64], b[C_MAXD / 64]; };
+template <int NV> struct LnFragT { float g[NV], b[NV]; };   // NV = d / 64 values per lane (4 where d <= 256 is known, else 8)
 
 // a pointer read from LDS is uniform but sits in a vector register: buffer descriptors want it in scalar ones
 template <typename P>
@@ -216,12 +216,13 @@ __device__ __forceinline__ void wprefetch(WFrag& f, const emoasr_lin_t& L, int N
   }
 }
 // likewise the LayerNorm parameters of the rows a stage normalises: lane owns columns lane, lane + 64, ...
-__device__ __forceinline__ void lnprefetch(LnFrag& f, const emoasr_lnp_t& ln, int d, int tid) {
+template <int NV>
+__device__ __forceinline__ void lnprefetch(LnFragT<NV>& f, const emoasr_lnp_t& ln, int d, int tid) {
   EMO_FRESH(tid);
   const int lane = tid & 63;
   const __amdgpu_buffer_rsrc_t rsg = make_rsrc(uniform_ptr(ln.g)), rsb = make_rsrc(uniform_ptr(ln.b));
 #pragma unroll
-  for (int i = 0; i < C_MAXD / 64; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int k = lane + 64 * i;
     f.g[i] = buf_load_f32<float>(rsg, k < d ? (unsigned)(k * 4) : EMO_OOB);
     f.b[i] = buf_load_f32<float>(rsb, k < d ? (unsigned)(k * 4) : EMO_OOB);
@@ -280,14 +281,15 @@ __device__ __forceinline__ void load_rows(bf16* rows, const bf16* src, int ncols
   }
 }
 // rows[r][0..d) <- LayerNorm(rows[r][0..d)), 16 / CW rows per wave (eps 1e-12, as both networks use); the caller synchronises
-__device__ __forceinline__ void ln_rows(bf16* rows, int d, const LnFrag& P, int tid) {
+template <int NV>
+__device__ __forceinline__ void ln_rows(bf16* rows, int d, const LnFragT<NV>& P, int tid) {
   EMO_FRESH(tid);
   const int wave = tid >> 6, lane = tid & 63;
   for (int r = wave; r < 16; r += CW) {
-    float v[C_MAXD / 64];
+    float v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < C_MAXD / 64; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int k = lane + 64 * i;
       v[i] = k < d ? (float)rows[r * C_LD + k] : 0.f;
       s += v[i];
@@ -295,13 +297,13 @@ __device__ __forceinline__ void ln_rows(bf16* rows, int d, const LnFrag& P, int 
     const float mean = wave_sum(s) / d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < C_MAXD / 64; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const float dl = lane + 64 * i < d ? v[i] - mean : 0.f;
       q += dl * dl;
     }
     const float rstd = rsqrtf(wave_sum(q) / d + 1e-12f);
 #pragma unroll
-    for (int i = 0; i < C_MAXD / 64; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int k = lane + 64 * i;
       if (k < d) rows[r * C_LD + k] = (bf16)((v[i] - mean) * rstd * P.g[i] + P.b[i]);
     }
@@ -402,7 +404,102 @@ __device__ void coop_self_attention(const bf16* qkv, int nb, int d, int H, int L
   }
 }
 
+// ---- projection + self-attention in one stage (no grid barrier between them) ------------------------------------------------------
+// Workgroup g takes head g % H (CG / H workgroups per head): each of them computes that head's q | k | v columns for all 16 rows
+// -- 3 dk / 16 strips, a wave owns one or two whole strips over every k step, so no cross-wave sum -- into LDS, and then attends
+// for the hypotheses b = g / H, g / H + CG / H, ...  The head's new key / value rows come from LDS, the older ones from the caches;
+// the first workgroup of a head appends the new rows to the caches for the later steps.  The projection is computed CG / H times
+// over, which costs less than the barrier and the q round trip it replaces (2.8 us per layer).
+constexpr int C_QKS = 8;   // k steps of the projection (d <= 256)
+constexpr int C_QPRE = 4;  // ... of which this many (first strip) are requested ahead of the barrier
+struct QFrag { bf16x8 w[2][C_QKS]; float bias[2]; };
+__host__ __device__ inline bool qkv_merge_ok(int d, int H) {
+  const int dk = d / H;
+  return CG % H == 0 && dk % 16 == 0 && 3 * dk / 16 <= 2 * CW && d / 32 <= C_QKS && dk <= 64;
+}
+// part 0: the first C_QPRE k steps of the wave's first strip (requested ahead of the barrier); part 1: the rest, requested at the
+// start of the stage -- its round trip hides behind the LayerNorm -- so that only 16 registers of fragments live across the
+// barrier (all 64 did not fit next to the LM kernel's other state: 28 were spilled and reloaded, a memory round trip each, right
+// before their MFMAs)
+__device__ __forceinline__ void qprefetch(QFrag& f, const emoasr_lin_t& L, int d, int H, int g, int tid, int part) {
+  EMO_FRESH(tid);
+  const int wave = tid >> 6, lane = tid & 63, dk = d / H, h = g % H, spp = dk / 16, nstr = 3 * spp, ksteps = d / 32;
+  const void* Lw = uniform_ptr(L.w);
+  const float* Lb = uniform_ptr(L.b);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(Lw), rsb = make_rsrc(Lb);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int st = wave + CW * i;
+    const bool ok = st < nstr;
+    const int col = (st / spp) * d + h * dk + (st % spp) * 16 + (lane & 15);
+    const unsigned woff = (unsigned)(((long)(ok ? col : 0) * d + 8 * (lane >> 4)) * 2);
+#pragma unroll
+    for (int ks = 0; ks < C_QKS; ++ks) {
+      const bool early = i == 0 && ks < C_QPRE;   // part 0: the first k steps of the first strip
+      if (early == (part == 0)) f.w[i][ks] = buf_load16<bf16>(rsw, (ok && ks < ksteps) ? woff + (unsigned)(64 * ks) : EMO_OOB).v;
+    }
+    if (part == 1) f.bias[i] = buf_load_f32<float>(rsb, (ok && Lb) ? (unsigned)(col * 4) : EMO_OOB);
+  }
+}
+// rows: the normalised input rows [16][C_LD]; hq: [16][3 dk + 8] bf16 scratch (the `red` buffer); out: O rows [16][d] in global memory
+__device__ void qkv_attn_stage(const QFrag& f, const bf16* rows, bf16* hq, int nb, int d, int H, int Lmax, bf16* kc, bf16* vc, int pos,
+                               bf16* out, int g, int tid, float* wscr) {
+  EMO_FRESH(tid);
+  const int wave = tid >> 6, lane = tid & 63, dk = d / H, h = g % H, slot = g / H, wph = CG / H;
+  const int spp = dk / 16, nstr = 3 * spp, ksteps = d / 32, ldh = 3 * dk + 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int st = wave + CW * i;
+    if (st < nstr) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bf16* xrow = rows + (lane & 15) * C_LD + 8 * (lane >> 4);
+#pragma unroll
+      for (int ks = 0; ks < C_QKS; ++ks)
+        if (ks < ksteps) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xrow + 32 * ks), f.w[i][ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hq[(4 * (lane >> 4) + r) * ldh + st * 16 + (lane & 15)] = (bf16)(acc[r] + f.bias[i]);   // [q | k | v] of the head
+    }
+  }
+  __syncthreads();
+  if (slot == 0)   // the new key / value rows of this head -> caches (read by the later steps)
+    for (int i = tid; i < nb * dk; i += CT) {
+      const int m = i / dk, c = i - m * dk;
+      kc[((long)m * Lmax + pos) * d + h * dk + c] = hq[m * ldh + dk + c];
+      vc[((long)m * Lmax + pos) * d + h * dk + c] = hq[m * ldh + 2 * dk + c];
+    }
+  float* q = wscr + wave * 192;
+  float* prob = q + 128;
+  const float scale = 1.f / sqrtf((float)dk);
+  for (int b = slot + wph * wave; b < nb; b += wph * CW) {
+    for (int c = lane; c < dk; c += 64) q[c] = (float)hq[b * ldh + c];
+    float m_run = -INFINITY, l_run = 0.f, a0 = 0.f, a1 = 0.f;
+    const bf16* kb = kc + (long)b * Lmax * d + h * dk;
+    const bf16* vb = vc + (long)b * Lmax * d + h * dk;
+    for (int t0 = 0; t0 < pos; t0 += 64) {   // the cached keys 0 .. pos - 1
+      float m, l, o0, o1;
+      attend64(q, dk, kb + (long)t0 * d, d, vb + (long)t0 * d, d, min(64, pos - t0), scale, prob, lane, m, l, o0, o1);
+      const float mn = fmaxf(m_run, m), ca = __expf(m_run - mn), cb = __expf(m - mn);
+      l_run = l_run * ca + l * cb; a0 = a0 * ca + o0 * cb; a1 = a1 * ca + o1 * cb;
+      m_run = mn;
+    }
+    {  // the new key (position pos) out of LDS
+      const float sn = wave_sum(lane < dk ? q[lane] * (float)hq[b * ldh + dk + lane] : 0.f) * scale;
+      const float mn = fmaxf(m_run, sn), ca = __expf(m_run - mn), cb = __expf(sn - mn);
+      const float v0 = 2 * lane < dk ? (float)hq[b * ldh + 2 * dk + 2 * lane] : 0.f;
+      const float v1 = 2 * lane < dk ? (float)hq[b * ldh + 2 * dk + 2 * lane + 1] : 0.f;
+      l_run = l_run * ca + cb; a0 = a0 * ca + v0 * cb; a1 = a1 * ca + v1 * cb;
+    }
+    const float inv = 1.f / l_run;
+    if (2 * lane < dk) {
+      out[(long)b * d + h * dk + 2 * lane] = (bf16)(a0 * inv);
+      out[(long)b * d + h * dk + 2 * lane + 1] = (bf16)(a1 * inv);
+    }
+  }
+  __syncthreads();   // hq (= red) and the rows may be rewritten
+}
+
 // ---- the Transformer LM stack ----------------------------------------------------------------------------------------------------
+template <bool MERGED>
 __global__ __launch_bounds__(CT) void lm_step_coop_kernel(const LmCoopArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 rows[16 * C_LD];
   __shared__ float red[4096];
@@ -415,7 +512,7 @@ __global__ __launch_bounds__(CT) void lm_step_coop_kernel(const LmCoopArgs a) {
   bar_init(bar, B.counter, B.err, &s_base);
   bar.chain = 1;
   WFrag wf;
-  LnFrag lf;
+  LnFragT<MERGED ? 4 : C_MAXD / 64> lf;   // (the merged stage implies d <= 256)
   ResFrag rf;
   // the layers' parameter pointers -> LDS once: read from the kernel-argument segment where they are needed, every stage began
   // with a scalar load that the previous barrier's invalidate had turned into a memory round trip
@@ -423,36 +520,46 @@ __global__ __launch_bounds__(CT) void lm_step_coop_kernel(const LmCoopArgs a) {
   for (int i = tid; i < (int)(sizeof(emoasr_bert_layer_t) / 4) * a.nl; i += CT)
     reinterpret_cast<unsigned*>(s_layers)[i] = reinterpret_cast<const unsigned*>(a.layers)[i];
   __syncthreads();
-  wprefetch(wf, s_layers[0].qkv, 3 * d, d, g, tid);
-  lnprefetch(lf, a.ln_emb, d, tid);
+  constexpr bool merged = MERGED;   // projection + self-attention in one stage (the host checks qkv_merge_ok)
+  QFrag qf;
   // embeddings (word + position / token-type) -> rows; rows >= nb are zero
   for (int i = tid; i < 16 * d; i += CT) {
     const int m = i / d, c = i - m * d;
     rows[m * C_LD + c] = m < nb ? (bf16)((float)a.word_emb[(long)a.ids[m] * d + c] + a.pe[(long)pos * d + c]) : (bf16)0.f;
   }
   __syncthreads();
+  if constexpr (merged) qprefetch(qf, s_layers[0].qkv, d, a.H, g, tid, 0);
+  else wprefetch(wf, s_layers[0].qkv, 3 * d, d, g, tid);
+  lnprefetch(lf, a.ln_emb, d, tid);
   const long layer_elems = (long)nb * a.Lmax * d;
   for (int li = 0; li < a.nl; ++li) {
     const emoasr_bert_layer_t& Ly = s_layers[li];
     bf16* kc = a.kcache + li * layer_elems;
     bf16* vc = a.vcache + li * layer_elems;
     // S1: x = LN(rows) (the previous block's output LayerNorm / the embedding LayerNorm); q | k | v = x . Wqkv^T + b
+    if constexpr (merged) qprefetch(qf, Ly.qkv, d, a.H, g, tid, 1);
     ln_rows(rows, d, lf, tid);
     __syncthreads();
     CSTAMP(bar, 16);
     if (g == 0) store_rows(B.X, rows, d, tid);
-    coop_linear(wf, rows, 3 * d, d, g, tid, red, [&](int m, int n, float v, int) {
-      if (n < d) B.QKV[(long)m * 3 * d + n] = (bf16)v;
-      else if (m < nb) {
-        if (n < 2 * d) kc[((long)m * a.Lmax + pos) * d + n - d] = (bf16)v;
-        else vc[((long)m * a.Lmax + pos) * d + n - 2 * d] = (bf16)v;
-      }
-    });
-    CSTAMP(bar, 17);
-    wprefetch(wf, Ly.attn_out, d, d, g, tid);
-    grid_sync(bar, 21);
-    // S2: attention over keys 0 .. pos
-    coop_self_attention(B.QKV, nb, d, a.H, a.Lmax, kc, vc, pos, B.O, g, tid, wscr, bar);
+    if constexpr (merged) {
+      // S1 + S2: the head's q | k | v and its attention over keys 0 .. pos, no barrier in between
+      qkv_attn_stage(qf, rows, reinterpret_cast<bf16*>(red), nb, d, a.H, a.Lmax, kc, vc, pos, B.O, g, tid, wscr);
+      wprefetch(wf, Ly.attn_out, d, d, g, tid);
+    } else {
+      coop_linear(wf, rows, 3 * d, d, g, tid, red, [&](int m, int n, float v, int) {
+        if (n < d) B.QKV[(long)m * 3 * d + n] = (bf16)v;
+        else if (m < nb) {
+          if (n < 2 * d) kc[((long)m * a.Lmax + pos) * d + n - d] = (bf16)v;
+          else vc[((long)m * a.Lmax + pos) * d + n - 2 * d] = (bf16)v;
+        }
+      });
+      CSTAMP(bar, 17);
+      wprefetch(wf, Ly.attn_out, d, d, g, tid);
+      grid_sync(bar, 21);
+      // S2: attention over keys 0 .. pos
+      coop_self_attention(B.QKV, nb, d, a.H, a.Lmax, kc, vc, pos, B.O, g, tid, wscr, bar);
+    }
     lnprefetch(lf, Ly.ln_attn, d, tid);
     grid_sync(bar, 22);
     // S3: y = o . Wout^T + b + x
@@ -482,8 +589,12 @@ __global__ __launch_bounds__(CT) void lm_step_coop_kernel(const LmCoopArgs a) {
     load_rows(rows, B.ACT, F, tid);
     __syncthreads();
     coop_linear(wf, rows, d, F, g, tid, red, [&](int m, int n, float v, int o) { B.Y[(long)m * d + n] = (bf16)(v + rf.v[o]); });
-    if (li + 1 < a.nl) wprefetch(wf, s_layers[li + 1].qkv, 3 * d, d, g, tid);
-    else wprefetch(wf, a.transform, d, d, g, tid);
+    if (li + 1 < a.nl) {
+      if constexpr (merged) qprefetch(qf, s_layers[li + 1].qkv, d, a.H, g, tid, 0);
+      else wprefetch(wf, s_layers[li + 1].qkv, 3 * d, d, g, tid);
+    } else {
+      wprefetch(wf, a.transform, d, d, g, tid);
+    }
     grid_sync(bar, 25);
     load_rows(rows, B.Y, d, tid);
     __syncthreads();
@@ -498,6 +609,7 @@ __global__ __launch_bounds__(CT) void lm_step_coop_kernel(const LmCoopArgs a) {
 }
 
 // ---- the Transformer decoder stack ------------------------------------------------------------------------------------------------
+template <bool MERGED>
 __global__ __launch_bounds__(CT) void dec_step_coop_kernel(const DecCoopArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 rows[16 * C_LD];
   __shared__ float red[4096];
@@ -509,7 +621,7 @@ __global__ __launch_bounds__(CT) void dec_step_coop_kernel(const DecCoopArgs a) 
   Bar bar;
   bar_init(bar, B.counter, B.err, &s_base);
   WFrag wf;
-  LnFrag lf;
+  LnFragT<MERGED ? 4 : C_MAXD / 64> lf;   // (the merged stage implies d <= 256)
   ResFrag rf;
   __shared__ emoasr_decoder_layer_t s_layers[8];   // (see lm_step_coop_kernel)
   __shared__ const void* s_kv[8];
@@ -517,7 +629,10 @@ __global__ __launch_bounds__(CT) void dec_step_coop_kernel(const DecCoopArgs a) 
     reinterpret_cast<unsigned*>(s_layers)[i] = reinterpret_cast<const unsigned*>(a.layers)[i];
   if (tid < a.nl) s_kv[tid] = a.kv[tid];
   __syncthreads();
-  wprefetch(wf, s_layers[0].qkv, 3 * d, d, g, tid);
+  constexpr bool merged = MERGED;   // projection + self-attention in one stage (the host checks qkv_merge_ok)
+  QFrag qf;
+  if constexpr (merged) qprefetch(qf, s_layers[0].qkv, d, H, g, tid, 0);
+  else wprefetch(wf, s_layers[0].qkv, 3 * d, d, g, tid);
   lnprefetch(lf, s_layers[0].ln1, d, tid);
   // the residual stream X lives in global memory; every workgroup builds the embedded rows for itself, workgroup 0 publishes them
   for (int i = tid; i < 16 * d; i += CT) {
@@ -533,19 +648,26 @@ __global__ __launch_bounds__(CT) void dec_step_coop_kernel(const DecCoopArgs a) 
     bf16* kc = a.kcache + li * layer_elems;
     bf16* vc = a.vcache + li * layer_elems;
     // S1: h = LN1(x); q | k | v
+    if constexpr (merged) qprefetch(qf, Ly.qkv, d, H, g, tid, 1);
     ln_rows(rows, d, lf, tid);
     __syncthreads();
-    coop_linear(wf, rows, 3 * d, d, g, tid, red, [&](int m, int n, float v, int) {
-      if (n < d) B.QKV[(long)m * 3 * d + n] = (bf16)v;
-      else if (m < nb) {
-        if (n < 2 * d) kc[((long)m * a.Lmax + pos) * d + n - d] = (bf16)v;
-        else vc[((long)m * a.Lmax + pos) * d + n - 2 * d] = (bf16)v;
-      }
-    });
-    wprefetch(wf, Ly.out, d, d, g, tid);
-    grid_sync(bar);
-    // S2: masked self-attention over the cached prefix
-    coop_self_attention(B.QKV, nb, d, H, a.Lmax, kc, vc, pos, B.O, g, tid, wscr, bar);
+    if constexpr (merged) {
+      // S1 + S2: the head's q | k | v and its masked self-attention over the cached prefix, no barrier in between
+      qkv_attn_stage(qf, rows, reinterpret_cast<bf16*>(red), nb, d, H, a.Lmax, kc, vc, pos, B.O, g, tid, wscr);
+      wprefetch(wf, Ly.out, d, d, g, tid);
+    } else {
+      coop_linear(wf, rows, 3 * d, d, g, tid, red, [&](int m, int n, float v, int) {
+        if (n < d) B.QKV[(long)m * 3 * d + n] = (bf16)v;
+        else if (m < nb) {
+          if (n < 2 * d) kc[((long)m * a.Lmax + pos) * d + n - d] = (bf16)v;
+          else vc[((long)m * a.Lmax + pos) * d + n - 2 * d] = (bf16)v;
+        }
+      });
+      wprefetch(wf, Ly.out, d, d, g, tid);
+      grid_sync(bar);
+      // S2: masked self-attention over the cached prefix
+      coop_self_attention(B.QKV, nb, d, H, a.Lmax, kc, vc, pos, B.O, g, tid, wscr, bar);
+    }
     lnprefetch(lf, Ly.ln2, d, tid);
     grid_sync(bar);
     // S3: x += o . Wout^T + b   (each element of X is read and written by the same thread)
@@ -650,7 +772,8 @@ __global__ __launch_bounds__(CT) void dec_step_coop_kernel(const DecCoopArgs a) 
       if (li + 1 == a.nl && m < nb) a.out_x[(long)m * d + n] = ov;
     });
     if (li + 1 < a.nl) {
-      wprefetch(wf, s_layers[li + 1].qkv, 3 * d, d, g, tid);
+      if constexpr (merged) qprefetch(qf, s_layers[li + 1].qkv, d, H, g, tid, 0);
+      else wprefetch(wf, s_layers[li + 1].qkv, 3 * d, d, g, tid);
       grid_sync(bar);
       load_rows(rows, B.X, d, tid);
       __syncthreads();
@@ -659,6 +782,9 @@ __global__ __launch_bounds__(CT) void dec_step_coop_kernel(const DecCoopArgs a) 
 }
 
 int g_decode_coop = 1;
+int g_coop_merge = 1;   // projection + self-attention in one stage where the shapes allow: bit 0 the decoder stack (339 -> 322 us),
+                        // bit 1 the LM stack (351 -> 351 us: the later arrival of 15 of the 16 weight fragments and the four-fold
+                        // projection eat the barrier it saves; off) -- option "decode_coop_merge"
 
 // device scratch of the two chains (0: decoder, 1: LM), allocated on first use -- which must not be inside a stream capture: the
 // search's eager warm-up pass (modeling/beam_search_device.py) comes first
@@ -697,6 +823,7 @@ bool plan_ok(int N, int K) {
 }  // namespace
 
 void emo_decode_set_coop(int v) { g_decode_coop = v; }
+void emo_decode_set_coop_merge(int v) { g_coop_merge = v; }
 
 // Can the cooperative kernels take this step?  (bf16, <= 16 hypotheses, <= 12 / 8 layers, shapes that fit the plans)
 bool emo_decode_coop_ok(int dtype, int nb, int nl, int max_layers, int d, int H, int F, int T) {
@@ -715,7 +842,8 @@ int emo_bert_lm_step_coop(int nl, const emoasr_bert_layer_t* layers, const emoas
   a.kcache = (bf16*)io->kcache; a.vcache = (bf16*)io->vcache; a.transform = io->transform; a.out_hidden = (bf16*)out_hidden;
   a.B = *B;
   for (int i = 0; i < nl; ++i) a.layers[i] = layers[i];
-  lm_step_coop_kernel<<<CG, CT, 0, s>>>(a);
+  if ((g_coop_merge & 2) && qkv_merge_ok(a.d, a.H)) lm_step_coop_kernel<true><<<CG, CT, 0, s>>>(a);
+  else lm_step_coop_kernel<false><<<CG, CT, 0, s>>>(a);
   EMO_LAUNCH_CHECK();
 #ifdef EMO_COOP_STAMP
   {  // debug builds: the first (eager) launch's stamps of workgroup 0: mean ticks from the previous stamp, by stamp id
@@ -751,7 +879,8 @@ int emo_transformer_decoder_step_coop(int nl, const emoasr_decoder_layer_t* laye
   a.kcache = (bf16*)io->kcache; a.vcache = (bf16*)io->vcache; a.kmem = io->kmem; a.out_x = (bf16*)out_x;
   a.B = *B;
   for (int i = 0; i < nl; ++i) { a.layers[i] = layers[i]; a.kv[i] = io->kv[i]; }
-  dec_step_coop_kernel<<<CG, CT, 0, s>>>(a);
+  if ((g_coop_merge & 1) && qkv_merge_ok(a.d, a.H)) dec_step_coop_kernel<true><<<CG, CT, 0, s>>>(a);
+  else dec_step_coop_kernel<false><<<CG, CT, 0, s>>>(a);
   EMO_LAUNCH_CHECK();
   return 0;
 }

@@ -209,7 +209,7 @@ def test_device_beam_search_equals_host_bookkeeping(dev, dtype, monkeypatch):
                     assert hyps[0] == hyps_h[0] and abs(scores[0] - scores_h[0]) < 2e-2 * abs(scores_h[0]) + 1e-3
 
 
-@pytest.mark.parametrize("option", ["decode_coop", "decode_wg", "decode_fused"])
+@pytest.mark.parametrize("option", ["decode_coop", "decode_coop_merge3", "decode_coop_merge0", "decode_wg", "decode_fused"])
 def test_alternative_decode_step_kernels_agree(dev, option):
     """the forms of the cached decode steps -- csrc/decode_coop.hip (the default: one launch of 16 cooperating workgroups per
     network, grid barriers between the stages), and the two measured-and-not-kept ones, csrc/decode_wg.hip (one workgroup per
@@ -228,12 +228,18 @@ def test_alternative_decode_step_kernels_agree(dev, option):
             x, xl = g["xs"][u:u + 1, :n].to(dev), g["xlens"][u:u + 1]
             lib.set_option("decode_coop", 0)
             ref_h, ref_s, _, _ = model.decode(x, xl, lm=lm, **DECODE_SETTINGS[2])
-            lib.set_option(option, 1)
+            if option.startswith("decode_coop_merge"):   # projection + self-attention as one stage in both / in neither stack
+                lib.set_option("decode_coop", 1)
+                lib.set_option("decode_coop_merge", int(option[-1]))
+            else:
+                lib.set_option(option, 1)
             hyps, scores, _, _ = model.decode(x, xl, lm=lm, **DECODE_SETTINGS[2])
-            if option != "decode_coop":
+            if not option.startswith("decode_coop"):
                 lib.set_option(option, 0)
             assert lib.size_query("emoasr_decode_coop_status") == 0
             assert hyps[0] == ref_h[0] and abs(scores[0] - ref_s[0]) < 2e-2 * abs(ref_s[0]) + 1e-3, (u, hyps[0], ref_h[0], scores[0], ref_s[0])
     finally:
-        lib.set_option(option, 0)
+        if not option.startswith("decode_coop"):
+            lib.set_option(option, 0)
         lib.set_option("decode_coop", 1)
+        lib.set_option("decode_coop_merge", 1)
