@@ -108,6 +108,17 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, EMO_DPP_F(v, v, 0x143, 0xc));
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// sum over the lane's HALF of the wave (lanes 0-31 / 32-63), both halves at once
+__device__ __forceinline__ float half_sum(float v, int lane) {
+  v += EMO_DPP_F(0.f, v, 0xB1, 0xf);
+  v += EMO_DPP_F(0.f, v, 0x4E, 0xf);
+  v += EMO_DPP_F(0.f, v, 0x141, 0xf);
+  v += EMO_DPP_F(0.f, v, 0x140, 0xf);
+  v += EMO_DPP_F(0.f, v, 0x142, 0xa);   // rows 1, 3 now hold the sums of lanes 0-31 / 32-63
+  const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+  const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  return lane < 32 ? lo : hi;
+}
 __device__ __forceinline__ float gelu_(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 // Thread-index arithmetic of a stage is recomputed where the stage runs: hoisted out of the layer loop (it is loop-invariant) the
@@ -280,33 +291,44 @@ __device__ __forceinline__ void load_rows(bf16* rows, const bf16* src, int ncols
     *reinterpret_cast<bf16x8*>(rows + m * C_LD + c) = *reinterpret_cast<const bf16x8*>(src + (long)m * ncols + c);
   }
 }
-// rows[r][0..d) <- LayerNorm(rows[r][0..d)), 16 / CW rows per wave (eps 1e-12, as both networks use); the caller synchronises
+// rows[r][0..d) <- LayerNorm(rows[r][0..d)), one row per HALF-wave (CW = 8: all 16 rows in one pass; two rows per wave one after
+// the other cost 1.6 us per LayerNorm), a lane owns columns hl, hl + 32, ... (eps 1e-12, as both networks use); the caller
+// synchronises.  P: gamma / beta of columns lane + 64 i as lnprefetch left them -- a half's lane hl needs hl + 32 j, which the lane
+// itself (j even) or its partner in the other half (j odd) holds: fetched with one cross-half swap per value.
 template <int NV>
 __device__ __forceinline__ void ln_rows(bf16* rows, int d, const LnFragT<NV>& P, int tid) {
   EMO_FRESH(tid);
-  const int wave = tid >> 6, lane = tid & 63;
-  for (int r = wave; r < 16; r += CW) {
-    float v[NV];
-    float s = 0.f;
+  static_assert(CW == 8, "one row per half-wave covers 16 rows with 8 waves");
+  const int wave = tid >> 6, lane = tid & 63, hl = lane & 31, half = lane >> 5;
+  const int r = 2 * wave + half;
+  float v[2 * NV], gg[2 * NV], bb[2 * NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int k = lane + 64 * i;
-      v[i] = k < d ? (float)rows[r * C_LD + k] : 0.f;
-      s += v[i];
-    }
-    const float mean = wave_sum(s) / d;
-    float q = 0.f;
+  for (int i = 0; i < NV; ++i) {
+    // columns 64 i + hl (held by lane hl) and 64 i + 32 + hl (held by lane 32 + hl): both halves need both
+    const float g_own = P.g[i], b_own = P.b[i];
+    const float g_oth = __shfl_xor(g_own, 32), b_oth = __shfl_xor(b_own, 32);
+    gg[2 * i] = half ? g_oth : g_own;      bb[2 * i] = half ? b_oth : b_own;
+    gg[2 * i + 1] = half ? g_own : g_oth;  bb[2 * i + 1] = half ? b_own : b_oth;
+  }
+  float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const float dl = lane + 64 * i < d ? v[i] - mean : 0.f;
-      q += dl * dl;
-    }
-    const float rstd = rsqrtf(wave_sum(q) / d + 1e-12f);
+  for (int j = 0; j < 2 * NV; ++j) {
+    const int k = hl + 32 * j;
+    v[j] = k < d ? (float)rows[r * C_LD + k] : 0.f;
+    s += v[j];
+  }
+  const float mean = half_sum(s, lane) / d;
+  float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int k = lane + 64 * i;
-      if (k < d) rows[r * C_LD + k] = (bf16)((v[i] - mean) * rstd * P.g[i] + P.b[i]);
-    }
+  for (int j = 0; j < 2 * NV; ++j) {
+    const float dl = hl + 32 * j < d ? v[j] - mean : 0.f;
+    q += dl * dl;
+  }
+  const float rstd = rsqrtf(half_sum(q, lane) / d + 1e-12f);
+#pragma unroll
+  for (int j = 0; j < 2 * NV; ++j) {
+    const int k = hl + 32 * j;
+    if (k < d) rows[r * C_LD + k] = (bf16)((v[j] - mean) * rstd * gg[j] + bb[j]);
   }
 }
 // rows -> dst[16][d] (workgroup 0 publishes the normalised rows: the post-LN blocks add them back two stages later)
