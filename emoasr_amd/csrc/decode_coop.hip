@@ -12,7 +12,8 @@
 // 32-deep weight fragments of a stage, requested BEFORE the barrier that precedes the stage.
 //
 // MEASURED (MI355X, beam 10, d 256, F 1024 / 2048, rocprofv3, both chains running concurrently): LM stack 351 us per step (the
-// launch chain: ~500), decoder stack 339 us (~375); search step 0.68 -> 0.52 ms.  In-kernel stamps (-DEMO_COOP_STAMP; s_memtime
+// launch chain: ~500), decoder stack 339 us (~375; 312 with its projection + self-attention merged); search step 0.68 -> 0.47-0.58
+// ms over T' 190-600.  In-kernel stamps (-DEMO_COOP_STAMP; s_memtime
 // ticks at the 2.39 GHz shader clock, tools/micro/clock_probe.hip) of the LM stack, per layer: barriers 5 x 2.0 us (gather 0.25,
 // release fence 0.65, add 0.1, wait 0.8, acquire fence 0.2), QKV stage 3.8 us (of which LayerNorm 1.6), attention 4.5 (q load 0.8,
 // one 64-key pass 3.2), out-projection 1.9, FFN 3.8 + 2.75: ~27 us per layer.  What it took to get there: 512 instead of 1024
