@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libemoasr_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "elementwise.hip", "convmodule.hip",
-           "subsample.hip", "ctc.hip", "attention.hip", "optim.hip", "feats.hip", "decoder.hip", "rnnt.hip", "layer.hip", "decode_rt.hip", "distill.hip", "ffn.hip", "gemm_big.hip", "convfused.hip", "rowlin.hip", "decode_wg.hip", "decode_coop.hip"]
+           "subsample.hip", "ctc.hip", "attention.hip", "optim.hip", "feats.hip", "decoder.hip", "rnnt.hip", "layer.hip", "decode_rt.hip", "distill.hip", "ffn.hip", "gemm_big.hip", "convfused.hip", "rowlin.hip", "decode_wg.hip", "decode_coop.hip", "lstm_coop.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-Wno-comment",
          "-ffp-contract=off"]
 

@@ -28,6 +28,7 @@ void emo_layer_set_conv_fused(int v);
 void emo_decode_set_fused(int v);
 void emo_decode_set_wg(int v);
 void emo_decode_set_coop(int v);
+void emo_lstm_set_coop(int v);
 void emo_decode_set_coop_merge(int v);
 void emo_attn_set_tr_read(int v);
 void emo_attn_set_fw(int v);
@@ -98,6 +99,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "decode_fused") == 0) { emo_decode_set_fused(value); return 0; }
   if (strcmp(name, "decode_wg") == 0) { emo_decode_set_wg(value); return 0; }
   if (strcmp(name, "decode_coop") == 0) { emo_decode_set_coop(value); return 0; }
+  if (strcmp(name, "lstm_coop") == 0) { emo_lstm_set_coop(value); return 0; }
   if (strcmp(name, "decode_coop_merge") == 0) { emo_decode_set_coop_merge(value); return 0; }
   if (strcmp(name, "attn_fw") == 0) { emo_attn_set_fw(value); return 0; }
   if (strcmp(name, "timers") == 0) { g_timers_on = value; return 0; }

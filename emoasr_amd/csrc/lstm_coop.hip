@@ -1,0 +1,199 @@
+// The prediction network's LSTM recurrence (config 5, bf16) as ONE cooperative launch per layer and direction instead of two
+// launches (recurrent GEMM + cell) per label position: H / 16 co-resident workgroups, each the owner of 16 hidden units for the whole
+// sequence -- its 64 rows of W_hh (the four gates of its units) stay in LDS, its cell states in registers -- meet at a grid barrier
+// once per position (the scheme of csrc/decode_coop.hip).
+//
+// Why: at the standard batch (36 utterances, ~80 label positions, H 512, 2 layers) the recurrence is ~640 dependent launches of
+// 3-14 us per step (profiles/r02_l4_kernel_stats.csv: recurrent GEMMs 1.17 + 2.18 ms, cells 0.30 + 0.47 ms of a 17.6 ms step),
+// each a [36 x 512] x [512 x 2048] product that no tiling can make efficient; per position the chip needs one barrier, one read of
+// h_{u-1} (36 KB per workgroup) and 24-32 MFMAs per wave.
+//
+//   forward, position u : h_{u-1} [B][H] -> LDS; gates[m][4][16 own units] = h_{u-1} . W_own^T (16x16x32 MFMAs: a wave takes one
+//                         gate and two 16-row tiles) + pre[u] (the input projection, requested before the barrier); the cell on
+//                         one thread per (row, unit) pair, c in registers; h_u, c_u and the activated gates written out
+//   backward, position u: cell backward for the own units (dc in registers); dgates -> global (the weight-gradient GEMMs run over
+//                         the whole sequence afterwards) and LDS; partial dh_{u-1}[m][all H] = dgates_own [B x 64] . W_own [64 x H]
+//                         as f32 per workgroup; after the barrier every workgroup sums the H / 16 partials of its own 16 columns
+//                         in workgroup order (bit-reproducible; no float atomics)
+//
+// Numerics: the gate pre-activations are rounded to bf16 before the cell and dh_{u-1} is formed in f32 from the partials, as the
+// launch chain's GEMM outputs were / were not; the k order of the products differs from the GEMM kernels', so results agree with
+// the chain to bf16 rounding, not bit for bit (tests/test_l4_gpu.py covers both paths against the oracle).
+//
+// Reference: decoders/rnn_transducer.py:96-135 (nn.LSTM prediction network), torch LSTM gate order i, f, g, o.
+#include <math.h>
+#include "common.h"
+#include "../../include/emoasr_hip.h"
+
+namespace {
+
+constexpr int LT = 512;          // threads per workgroup (8 waves)
+constexpr int LW = LT / 64;
+constexpr int L_MAXB = 64;       // rows (sequences) per batch: four 16-row MFMA tiles
+constexpr int L_MAXH = 512;
+
+#define EMO_FRESH(x) asm volatile("" : "+v"(x))
+
+struct LBar { unsigned* counter; int* err; unsigned base, n, G; };
+__device__ void lbar_init(LBar& b, unsigned* counter, int* err, unsigned G, unsigned* s_base) {
+  if (threadIdx.x == 0) {
+    const unsigned v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_base = v - v % G;   // (see decode_coop.hip: launches are stream-ordered and perform whole barriers)
+  }
+  __syncthreads();
+  b.counter = counter; b.err = err; b.base = *s_base; b.n = 0; b.G = G;
+}
+__device__ void lgrid_sync(LBar& b) {
+  ++b.n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(b.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = b.base + b.G * b.n;
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(b.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 22)) { *b.err = 1; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float rbf(float x) { return (float)(bf16)x; }   // round to bf16 and back
+
+struct LstmFwdArgs {
+  int U, B, H;
+  const bf16* pre;     // [U][B][4H] input projection + biases
+  const bf16* w_hh;    // [4H][H]
+  const bf16* h0;      // [B][H] or null
+  const float* c0;     // [B][H] or null
+  bf16* hseq;          // [U][B][H]
+  float* cseq;         // [U][B][H]
+  bf16* gact;          // [U][B][4H] activated gates
+  unsigned* counter; int* err;
+};
+
+// LDS: Ws [64][H + 8] | hs [64][H + 8] | gat [4][64][17] f32
+__global__ __launch_bounds__(LT) void lstm_seq_fwd_kernel(const LstmFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned s_base;
+  const int H = a.H, B = a.B, ld = H + 8, g = blockIdx.x, G = gridDim.x;
+  bf16* Ws = reinterpret_cast<bf16*>(smem);
+  bf16* hs = Ws + 64 * ld;
+  float* gat = reinterpret_cast<float*>(hs + 64 * ld);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  LBar bar;
+  lbar_init(bar, a.counter, a.err, (unsigned)G, &s_base);
+  // the four gates' rows of the own 16 units: Ws[gate * 16 + j] = w_hh[gate * H + 16 g + j]
+  for (int i = tid; i < 64 * (H / 8); i += LT) {
+    const int r = i / (H / 8), c = (i - r * (H / 8)) * 8;
+    *reinterpret_cast<bf16x8*>(Ws + r * ld + c) = *reinterpret_cast<const bf16x8*>(a.w_hh + ((long)(r >> 4) * H + 16 * g + (r & 15)) * H + c);
+  }
+  for (int i = tid; i < 64 * ld / 2; i += LT) reinterpret_cast<unsigned*>(hs)[i] = 0u;   // rows >= B stay zero
+  __syncthreads();
+  // this thread's two (row, unit) pairs: p = tid, tid + 512 -> m = p >> 4, n = p & 15
+  float c_reg[2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int p = tid + LT * o, m = p >> 4, n = p & 15;
+    c_reg[o] = (a.c0 && m < B) ? a.c0[(long)m * H + 16 * g + n] : 0.f;
+  }
+  const int gate = wave & 3, mt0 = 2 * (wave >> 2);
+  for (int u = 0; u < a.U; ++u) {
+    int t = tid;
+    EMO_FRESH(t);
+    // the input projection of this position for the own pairs (independent of the recurrence: before the wait)
+    float pv[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int p = t + LT * o, m = p >> 4, n = p & 15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pv[o][q] = m < B ? (float)a.pre[((long)u * B + m) * 4 * H + q * H + 16 * g + n] : 0.f;
+    }
+    const bf16* hprev = u > 0 ? a.hseq + (long)(u - 1) * B * H : a.h0;
+    if (u > 0) lgrid_sync(bar);   // h_{u-1} complete on every workgroup
+    if (hprev) {
+      for (int i = t; i < B * (H / 8); i += LT) {
+        const int m = i / (H / 8), c = (i - m * (H / 8)) * 8;
+        *reinterpret_cast<bf16x8*>(hs + m * ld + c) = *reinterpret_cast<const bf16x8*>(hprev + (long)m * H + c);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int mt = mt0 + mi;
+        if (16 * mt < B) {
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          const bf16* xrow = hs + (16 * mt + (lane & 15)) * ld + 8 * (lane >> 4);
+          const bf16* wrow = Ws + (16 * gate + (lane & 15)) * ld + 8 * (lane >> 4);
+          for (int ks = 0; ks < H / 32; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xrow + 32 * ks),
+                                                          *reinterpret_cast<const bf16x8*>(wrow + 32 * ks), acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gat[(gate * 64 + 16 * mt + 4 * (lane >> 4) + r) * 17 + (lane & 15)] = acc[r];
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int p = t + LT * o, m = p >> 4, n = p & 15;
+      if (m < B) {
+        float z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z[q] = rbf(pv[o][q] + (hprev ? gat[(q * 64 + m) * 17 + n] : 0.f));   // the chain's GEMM output was bf16
+        const float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), gg = tanhf(z[2]), og = sigmoidf_(z[3]);
+        const float cn = fg * c_reg[o] + ig * gg;
+        c_reg[o] = cn;
+        const long row = (long)u * B + m;
+        a.cseq[row * H + 16 * g + n] = cn;
+        a.hseq[row * H + 16 * g + n] = (bf16)(og * tanhf(cn));
+        bf16* ga = a.gact + row * 4 * H + 16 * g + n;
+        ga[0] = (bf16)ig; ga[H] = (bf16)fg; ga[2 * H] = (bf16)gg; ga[3 * H] = (bf16)og;
+      }
+    }
+  }
+}
+
+unsigned* lstm_counter(int which, int** err) {
+  static unsigned* buf = nullptr;
+  if (!buf) {
+    if (hipMalloc(&buf, 1024) != hipSuccess || hipMemset(buf, 0, 1024) != hipSuccess) return nullptr;
+  }
+  *err = reinterpret_cast<int*>(buf) + 128;
+  return buf + 16 * which;
+}
+
+int g_lstm_coop = 1;
+
+}  // namespace
+
+void emo_lstm_set_coop(int v) { g_lstm_coop = v; }
+
+// Can the cooperative recurrence take this layer?  (bf16, B <= 64, H a multiple of 32 up to 512)
+extern "C" int emoasr_lstm_seq_supported(int dtype, int B, int H) {
+  return g_lstm_coop && dtype == EMO_BF16 && B >= 1 && B <= L_MAXB && H % 32 == 0 && H >= 32 && H <= L_MAXH;
+}
+
+// hseq[u], cseq[u], gact[u] for u = 0 .. U - 1 from pre[u] = x_u . W_ih^T + b (bf16 [U][B][4H]) and the recurrent weights
+extern "C" int emoasr_lstm_seq_fwd(int dtype, int U, int B, int H, const void* pre, const void* w_hh, const void* h0, const float* c0,
+                                   void* hseq, float* cseq, void* gact, void* stream) {
+  EMO_CHECK(emoasr_lstm_seq_supported(dtype, B, H), "lstm_seq_fwd: unsupported shape (dtype %d, B %d, H %d)", dtype, B, H);
+  if (U == 0) return 0;
+  LstmFwdArgs a{};
+  a.U = U; a.B = B; a.H = H;
+  a.pre = (const bf16*)pre; a.w_hh = (const bf16*)w_hh; a.h0 = (const bf16*)h0; a.c0 = c0;
+  a.hseq = (bf16*)hseq; a.cseq = cseq; a.gact = (bf16*)gact;
+  a.counter = lstm_counter(0, &a.err);
+  EMO_CHECK(a.counter, "lstm_seq_fwd: counter allocation failed");
+  const size_t smem = (size_t)2 * 64 * (H + 8) * 2 + 4 * 64 * 17 * 4;
+  static size_t set_bytes = 0;
+  if (smem > set_bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    EMO_CHECK(e == hipSuccess, "lstm_seq_fwd: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
+    set_bytes = smem;
+  }
+  lstm_seq_fwd_kernel<<<H / 16, LT, smem, (hipStream_t)stream>>>(a);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}

@@ -1002,10 +1002,15 @@ class _RNNTMixin:
             gact = torch.empty(U, B, 4 * H, device=dev, dtype=x.dtype)
             h_prev = state[0][l] if state is not None else None
             c_prev = state[1][l] if state is not None else None
-            for u in range(U):
-                gates = pre[u] if h_prev is None else ops.gemm_nt(h_prev, w_hh, residual=pre[u], res_scale=1.0)
-                ops.lstm_cell_fwd(gates, c_prev, hseq[u], cseq[u], gact[u])
-                h_prev, c_prev = hseq[u], cseq[u]
+            if U > 1 and ops.lstm_seq_supported(x, B, H):
+                # the whole recurrence in one cooperative launch (csrc/lstm_coop.hip) instead of 2 launches per position
+                ops.lstm_seq_fwd(pre, w_hh, h_prev, c_prev, hseq, cseq, gact)
+                h_prev, c_prev = hseq[U - 1], cseq[U - 1]
+            else:
+                for u in range(U):
+                    gates = pre[u] if h_prev is None else ops.gemm_nt(h_prev, w_hh, residual=pre[u], res_scale=1.0)
+                    ops.lstm_cell_fwd(gates, c_prev, hseq[u], cseq[u], gact[u])
+                    h_prev, c_prev = hseq[u], cseq[u]
             new_h.append(h_prev)
             new_c.append(c_prev)
             s_do = self._seed(7010 + l)

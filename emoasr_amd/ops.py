@@ -743,6 +743,17 @@ def lstm_cell_fwd(gates_pre, c_prev, h_out, c_out, gates_act):
              _p(c_out), _p(gates_act), _stream())
 
 
+def lstm_seq_supported(x, B, H):
+    """does the cooperative whole-sequence recurrence (csrc/lstm_coop.hip) take this layer?"""
+    return lib.size_query("emoasr_lstm_seq_supported", dt(x), B, H) == 1
+
+
+def lstm_seq_fwd(pre, w_hh, h0, c0, hseq, cseq, gact):
+    """pre [U,B,4H] (input projection + biases) -> hseq [U,B,H], cseq f32 [U,B,H], gact [U,B,4H] in one launch"""
+    U, B, H4 = pre.shape
+    lib.call("emoasr_lstm_seq_fwd", dt(pre), U, B, H4 // 4, _p(pre), _p(w_hh), _p(h0), _p(c0), _p(hseq), _p(cseq), _p(gact), _stream())
+
+
 def lstm_cell_bwd(dh_out, dh_rec, dc, gates_act, c_prev, c, dgates_pre):
     B, H4 = gates_act.shape
     lib.call("emoasr_lstm_cell_bwd", dt(gates_act), B, H4 // 4, _p(dh_out), dh_out.stride(0), _p(dh_rec), _p(dc),

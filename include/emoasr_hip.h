@@ -394,6 +394,12 @@ int emoasr_lstm_cell_fwd(int dtype, int B, int H, const void* gates_pre, const f
 int emoasr_lstm_cell_bwd(int dtype, int B, int H, const void* dh_out, long lddh, const void* dh_rec, float* dc,
                          const void* gates_act, const float* c_prev, const float* c, void* dgates_pre,
                          void* stream);
+/* The whole recurrence of one LSTM layer in one cooperative launch (csrc/lstm_coop.hip; bf16, B <= 64, H % 32 == 0, H <= 512):
+ * pre [U][B][4H] = x . W_ih^T + b_ih + b_hh, w_hh [4H][H]; outputs hseq [U][B][H], cseq f32 [U][B][H], gact [U][B][4H] (activated
+ * i | f | g | o).  h0 / c0 may be NULL (zeros).  emoasr_lstm_seq_supported() -> 1 if this shape runs here (option "lstm_coop"). */
+int emoasr_lstm_seq_supported(int dtype, int B, int H);
+int emoasr_lstm_seq_fwd(int dtype, int U, int B, int H, const void* pre, const void* w_hh, const void* h0, const float* c0,
+                        void* hseq, float* cseq, void* gact, void* stream);
 /* joint network: h[b,t,u,:] = tanh(e[b,t,:] + g[b,u,:]) ; reductions of d(pre-tanh) back to de / dg */
 int emoasr_joint_tanh(int dtype, int B, int T, int U, int J, const void* e, const void* g, void* h, void* stream);
 int emoasr_joint_reduce(int dtype, int B, int T, int U, int J, const void* d, void* de, void* dg, void* stream);

@@ -955,3 +955,30 @@ def test_beam_scores_topk(dev, dtype, V, k, use_lm):
         assert len(set(idx[m].tolist())) == k
     if use_lm:
         _close(at, torch.gather(llm, 1, idx.long()), 1e-5, "lm_at")
+
+
+@pytest.mark.parametrize("U,B,H,with_state", [(9, 36, 512, False), (5, 50, 512, True), (7, 4, 128, False), (3, 17, 256, True)])
+def test_lstm_seq_cooperative_matches_the_step_chain(dev, U, B, H, with_state):
+    """csrc/lstm_coop.hip (one cooperative launch for the whole recurrence of a layer) against the per-position chain
+    gemm_nt + lstm_cell_fwd: same h / c / activated gates to bf16 rounding"""
+    from emoasr_amd import ops
+    dt_ = torch.bfloat16
+    pre = _rnd(dev, U, B, 4 * H, dtype=dt_, scale=1.0)
+    w_hh = _rnd(dev, 4 * H, H, dtype=dt_, scale=H ** -0.5)
+    h0 = _rnd(dev, B, H, dtype=dt_, scale=0.5) if with_state else None
+    c0 = _rnd(dev, B, H, scale=0.5) if with_state else None
+    assert ops.lstm_seq_supported(pre, B, H)
+    hseq = torch.empty(U, B, H, device=dev, dtype=dt_)
+    cseq = torch.empty(U, B, H, device=dev)
+    gact = torch.empty(U, B, 4 * H, device=dev, dtype=dt_)
+    ops.lstm_seq_fwd(pre, w_hh, h0, c0, hseq, cseq, gact)
+    h_ref = torch.empty_like(hseq); c_ref = torch.empty_like(cseq); g_ref = torch.empty_like(gact)
+    hp, cp = h0, c0
+    for u in range(U):
+        gates = pre[u] if hp is None else ops.gemm_nt(hp, w_hh, residual=pre[u], res_scale=1.0)
+        ops.lstm_cell_fwd(gates, cp, h_ref[u], c_ref[u], g_ref[u])
+        hp, cp = h_ref[u], c_ref[u]
+    torch.cuda.synchronize()
+    _close(hseq, h_ref, 3e-2, "hseq")
+    _close(cseq, c_ref, 3e-2, "cseq")
+    _close(gact, g_ref, 3e-2, "gact")
