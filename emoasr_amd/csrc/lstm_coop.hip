@@ -155,6 +155,110 @@ __global__ __launch_bounds__(LT) void lstm_seq_fwd_kernel(const LstmFwdArgs a) {
   }
 }
 
+struct LstmBwdArgs {
+  int U, B, H;
+  const bf16* dh_seq;   // [U][B][H] gradient from above (dropout already applied)
+  const bf16* gact;     // [U][B][4H]
+  const float* cseq;    // [U][B][H]
+  const float* c0;      // [B][H] or null
+  const bf16* w_hh;     // [4H][H]
+  bf16* dgp;            // [U][B][4H] out: gradient w.r.t. the gate pre-activations
+  float* part;          // [2][G][64][H] f32 scratch: every workgroup's contribution to dh_{u-1}
+  unsigned* counter; int* err;
+};
+
+// LDS: WT [H][72] (the own 64 gate rows of W_hh, transposed: WT[n][k] = w_hh[row(k)][n]) | dg [64][72] (the own dgates of the position)
+__global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned s_base;
+  const int H = a.H, B = a.B, g = blockIdx.x, G = gridDim.x;
+  constexpr int LDK = 72;
+  bf16* WT = reinterpret_cast<bf16*>(smem);
+  bf16* dg = WT + H * LDK;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  LBar bar;
+  lbar_init(bar, a.counter, a.err, (unsigned)G, &s_base);
+  for (int i = tid; i < 64 * H; i += LT) {   // k = gate * 16 + j <-> row gate * H + 16 g + j
+    const int k = i / H, n = i - k * H;
+    WT[n * LDK + k] = a.w_hh[((long)(k >> 4) * H + 16 * g + (k & 15)) * H + n];
+  }
+  for (int i = tid; i < 64 * LDK / 2; i += LT) reinterpret_cast<unsigned*>(dg)[i] = 0u;   // rows >= B stay zero
+  __syncthreads();
+  float dc_reg[2] = {0.f, 0.f};
+  const long slab = (long)64 * H;   // one workgroup's partial
+  for (int u = a.U - 1; u >= 0; --u) {
+    int t = tid;
+    EMO_FRESH(t);
+    // everything of this position that does not depend on the recurrence: before the wait
+    float dho[2], gv[2][4], cu[2], cp[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int p = t + LT * o, m = p >> 4, n = p & 15;
+      const long row = (long)u * B + m, col = 16 * g + n;
+      const bool ok = m < B;
+      dho[o] = ok ? (float)a.dh_seq[row * H + col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gv[o][q] = ok ? (float)a.gact[row * 4 * H + q * H + col] : 0.f;
+      cu[o] = ok ? a.cseq[row * H + col] : 0.f;
+      cp[o] = !ok ? 0.f : (u > 0 ? a.cseq[(row - B) * H + col] : (a.c0 ? a.c0[(long)m * H + col] : 0.f));
+    }
+    const bool rec = u < a.U - 1;   // position u + 1 contributed to dh_u
+    if (rec) lgrid_sync(bar);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int p = t + LT * o, m = p >> 4, n = p & 15;
+      if (m < B) {
+        float dh = dho[o];
+        if (rec) {   // the workgroups' partials of the own column, in workgroup order
+          const float* src = a.part + ((long)((u + 1) & 1) * G) * slab + (long)m * H + 16 * g + n;
+          float acc = 0.f;
+          for (int w0 = 0; w0 < G; w0 += 8) {
+            float pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = w0 + e < G ? src[(long)(w0 + e) * slab] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += pv[e];
+          }
+          dh += acc;
+        }
+        const float ig = gv[o][0], fg = gv[o][1], gg = gv[o][2], og = gv[o][3];
+        const float tc = tanhf(cu[o]);
+        const float dct = dc_reg[o] + dh * og * (1.f - tc * tc);
+        const bf16 d0 = (bf16)(dct * gg * ig * (1.f - ig)), d1 = (bf16)(dct * cp[o] * fg * (1.f - fg));
+        const bf16 d2 = (bf16)(dct * ig * (1.f - gg * gg)), d3 = (bf16)(dh * tc * og * (1.f - og));
+        dc_reg[o] = dct * fg;
+        bf16* dst = a.dgp + ((long)u * B + m) * 4 * H + 16 * g + n;
+        dst[0] = d0; dst[H] = d1; dst[2 * H] = d2; dst[3 * H] = d3;
+        dg[m * LDK + n] = d0; dg[m * LDK + 16 + n] = d1; dg[m * LDK + 32 + n] = d2; dg[m * LDK + 48 + n] = d3;
+      }
+    }
+    if (u > 0) {
+      __syncthreads();
+      // partial dh_{u-1}[m][:] = dg [B x 64] . W_own [64 x H]: column strips of 16 dealt to the waves
+      float* dstp = a.part + ((long)(u & 1) * G + g) * slab;
+      const int MT = (B + 15) / 16;
+      for (int st = wave; st < H / 16; st += LW) {
+        bf16x8 wf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(WT + (16 * st + (lane & 15)) * LDK + 32 * ks + 8 * (lane >> 4));
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(dg + (16 * mt + (lane & 15)) * LDK + 32 * ks + 8 * (lane >> 4)),
+                                                          wf[ks], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 16 * mt + 4 * (lane >> 4) + r;
+            if (m < B) dstp[(long)m * H + 16 * st + (lane & 15)] = acc[r];
+          }
+        }
+      }
+      __syncthreads();   // dg is rewritten by the next position
+    }
+  }
+}
+
 unsigned* lstm_counter(int which, int** err) {
   static unsigned* buf = nullptr;
   if (!buf) {
@@ -196,4 +300,41 @@ extern "C" int emoasr_lstm_seq_fwd(int dtype, int U, int B, int H, const void* p
   lstm_seq_fwd_kernel<<<H / 16, LT, smem, (hipStream_t)stream>>>(a);
   EMO_LAUNCH_CHECK();
   return 0;
+}
+
+// scratch of emoasr_lstm_seq_bwd: [2][H / 16][64][H] f32
+extern "C" long emoasr_lstm_seq_bwd_ws_bytes(int B, int H) { return (long)2 * (H / 16) * 64 * H * 4; }
+
+// dgp[u] (gradient w.r.t. the gate pre-activations, [U][B][4H]) for u = U - 1 .. 0 from dh_seq (gradient w.r.t. the layer's
+// outputs), the stored activated gates and cell states; the weight / input gradients follow from dgp as before
+extern "C" int emoasr_lstm_seq_bwd(int dtype, int U, int B, int H, const void* dh_seq, const void* gact, const float* cseq,
+                                   const float* c0, const void* w_hh, void* dgp, void* ws, long ws_bytes, void* stream) {
+  EMO_CHECK(emoasr_lstm_seq_supported(dtype, B, H), "lstm_seq_bwd: unsupported shape (dtype %d, B %d, H %d)", dtype, B, H);
+  EMO_CHECK(ws && ws_bytes >= emoasr_lstm_seq_bwd_ws_bytes(B, H), "lstm_seq_bwd: scratch too small");
+  if (U == 0) return 0;
+  LstmBwdArgs a{};
+  a.U = U; a.B = B; a.H = H;
+  a.dh_seq = (const bf16*)dh_seq; a.gact = (const bf16*)gact; a.cseq = cseq; a.c0 = c0; a.w_hh = (const bf16*)w_hh;
+  a.dgp = (bf16*)dgp; a.part = (float*)ws;
+  a.counter = lstm_counter(1, &a.err);
+  EMO_CHECK(a.counter, "lstm_seq_bwd: counter allocation failed");
+  const size_t smem = (size_t)(H + 64) * 72 * 2;
+  static size_t set_bytes = 0;
+  if (smem > set_bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    EMO_CHECK(e == hipSuccess, "lstm_seq_bwd: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
+    set_bytes = smem;
+  }
+  lstm_seq_bwd_kernel<<<H / 16, LT, smem, (hipStream_t)stream>>>(a);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+// error flag of the recurrence kernels' barriers (a wait that gave up): 0 = fine.  Synchronises the device.
+extern "C" long emoasr_lstm_coop_status(void) {
+  int* err = nullptr;
+  if (!lstm_counter(0, &err)) return -1;
+  int e = 0;
+  if (hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return e;
 }

@@ -1035,12 +1035,16 @@ class _RNNTMixin:
             w_ih, w_hh = A.w(name + ".weight_ih_l0"), A.w(name + ".weight_hh_l0")
             dh_seq = ops.scale_dropout(dy, 1.0, st.p, s_do) if st.p > 0 else dy
             dgp = torch.empty(U, B, 4 * H, device=dy.device, dtype=dy.dtype)
-            dc = torch.zeros(B, H, device=dy.device, dtype=torch.float32)
-            dh_rec = None
-            for u in reversed(range(U)):
-                ops.lstm_cell_bwd(dh_seq[u], dh_rec, dc, gact[u], cseq[u - 1] if u > 0 else c0, cseq[u], dgp[u])
-                if u > 0 or h0 is not None:
-                    dh_rec = ops.gemm_nn(dgp[u], w_hh)
+            if U > 1 and ops.lstm_seq_supported(dh_seq, B, H):
+                # the whole backward recurrence in one cooperative launch (csrc/lstm_coop.hip)
+                ops.lstm_seq_bwd(dh_seq.contiguous(), gact, cseq, c0, w_hh, dgp)
+            else:
+                dc = torch.zeros(B, H, device=dy.device, dtype=torch.float32)
+                dh_rec = None
+                for u in reversed(range(U)):
+                    ops.lstm_cell_bwd(dh_seq[u], dh_rec, dc, gact[u], cseq[u - 1] if u > 0 else c0, cseq[u], dgp[u])
+                    if u > 0 or h0 is not None:
+                        dh_rec = ops.gemm_nn(dgp[u], w_hh)
             nin = x_in.shape[-1]
             dgp2 = dgp.view(U * B, 4 * H)
             ops.gemm_tn(dgp2, x_in.reshape(U * B, nin), out=A.g(name + ".weight_ih_l0"), accumulate=True,

@@ -237,6 +237,7 @@ SIGNATURES = {
     "emoasr_lstm_cell_fwd": [I, I, I, P, P, P, L, P, P, P],
     "emoasr_lstm_cell_bwd": [I, I, I, P, L, P, P, P, P, P, P, P],
     "emoasr_lstm_seq_fwd": [I, I, I, I, P, P, P, P, P, P, P, P],
+    "emoasr_lstm_seq_bwd": [I, I, I, I, P, P, P, P, P, P, P, L, P],
     "emoasr_joint_tanh": [I, I, I, I, I, P, P, P, P],
     "emoasr_joint_reduce": [I, I, I, I, I, P, P, P, P],
     "emoasr_rnnt_forward": [I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P],

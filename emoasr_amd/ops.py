@@ -754,6 +754,21 @@ def lstm_seq_fwd(pre, w_hh, h0, c0, hseq, cseq, gact):
     lib.call("emoasr_lstm_seq_fwd", dt(pre), U, B, H4 // 4, _p(pre), _p(w_hh), _p(h0), _p(c0), _p(hseq), _p(cseq), _p(gact), _stream())
 
 
+_lstm_ws = {}
+
+
+def lstm_seq_bwd(dh_seq, gact, cseq, c0, w_hh, dgp):
+    """dh_seq [U,B,H] (gradient w.r.t. the layer outputs) -> dgp [U,B,4H] (w.r.t. the gate pre-activations) in one launch"""
+    U, B, H = dh_seq.shape
+    need = lib.size_query("emoasr_lstm_seq_bwd_ws_bytes", B, H)
+    key = (dh_seq.device, need)
+    ws = _lstm_ws.get(key)
+    if ws is None:
+        ws = _lstm_ws[key] = torch.empty(need, device=dh_seq.device, dtype=torch.uint8)
+    lib.call("emoasr_lstm_seq_bwd", dt(dh_seq), U, B, H, _p(dh_seq), _p(gact), _p(cseq), _p(c0), _p(w_hh), _p(dgp), _p(ws), need,
+             _stream())
+
+
 def lstm_cell_bwd(dh_out, dh_rec, dc, gates_act, c_prev, c, dgates_pre):
     B, H4 = gates_act.shape
     lib.call("emoasr_lstm_cell_bwd", dt(gates_act), B, H4 // 4, _p(dh_out), dh_out.stride(0), _p(dh_rec), _p(dc),

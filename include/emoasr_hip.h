@@ -400,6 +400,13 @@ int emoasr_lstm_cell_bwd(int dtype, int B, int H, const void* dh_out, long lddh,
 int emoasr_lstm_seq_supported(int dtype, int B, int H);
 int emoasr_lstm_seq_fwd(int dtype, int U, int B, int H, const void* pre, const void* w_hh, const void* h0, const float* c0,
                         void* hseq, float* cseq, void* gact, void* stream);
+/* ... and backward: dgp [U][B][4H] (gradient w.r.t. the gate pre-activations) from dh_seq [U][B][H] (gradient w.r.t. the outputs),
+ * the stored gact / cseq and c0 (may be NULL); ws: emoasr_lstm_seq_bwd_ws_bytes(B, H) bytes of scratch.
+ * emoasr_lstm_coop_status(): 0 unless a grid barrier of these kernels ever gave up waiting (synchronises the device). */
+long emoasr_lstm_seq_bwd_ws_bytes(int B, int H);
+int emoasr_lstm_seq_bwd(int dtype, int U, int B, int H, const void* dh_seq, const void* gact, const float* cseq, const float* c0,
+                        const void* w_hh, void* dgp, void* ws, long ws_bytes, void* stream);
+long emoasr_lstm_coop_status(void);
 /* joint network: h[b,t,u,:] = tanh(e[b,t,:] + g[b,u,:]) ; reductions of d(pre-tanh) back to de / dg */
 int emoasr_joint_tanh(int dtype, int B, int T, int U, int J, const void* e, const void* g, void* h, void* stream);
 int emoasr_joint_reduce(int dtype, int B, int T, int U, int J, const void* d, void* de, void* dg, void* stream);

@@ -982,3 +982,28 @@ def test_lstm_seq_cooperative_matches_the_step_chain(dev, U, B, H, with_state):
     _close(hseq, h_ref, 3e-2, "hseq")
     _close(cseq, c_ref, 3e-2, "cseq")
     _close(gact, g_ref, 3e-2, "gact")
+
+
+@pytest.mark.parametrize("U,B,H,with_c0", [(9, 36, 512, False), (5, 50, 512, True), (7, 4, 128, False), (3, 17, 256, True)])
+def test_lstm_seq_backward_cooperative_matches_the_step_chain(dev, U, B, H, with_c0):
+    """the backward recurrence of csrc/lstm_coop.hip against the per-position chain lstm_cell_bwd + gemm_nn"""
+    from emoasr_amd import lib, ops
+    dt_ = torch.bfloat16
+    gact = torch.sigmoid(_rnd(dev, U, B, 4 * H)).to(dt_)
+    gact[:, :, 2 * H:3 * H] = torch.tanh(_rnd(dev, U, B, H)).to(dt_)
+    cseq = _rnd(dev, U, B, H, scale=0.7)
+    c0 = _rnd(dev, B, H, scale=0.7) if with_c0 else None
+    dh_seq = _rnd(dev, U, B, H, dtype=dt_, scale=0.5)
+    w_hh = _rnd(dev, 4 * H, H, dtype=dt_, scale=H ** -0.5)
+    dgp = torch.empty(U, B, 4 * H, device=dev, dtype=dt_)
+    ops.lstm_seq_bwd(dh_seq, gact, cseq, c0, w_hh, dgp)
+    assert lib.size_query("emoasr_lstm_coop_status") == 0
+    ref = torch.empty_like(dgp)
+    dc = torch.zeros(B, H, device=dev)
+    dh_rec = None
+    for u in reversed(range(U)):
+        ops.lstm_cell_bwd(dh_seq[u], dh_rec, dc, gact[u], cseq[u - 1] if u > 0 else c0, cseq[u], ref[u])
+        if u > 0:
+            dh_rec = ops.gemm_nn(ref[u], w_hh)
+    torch.cuda.synchronize()
+    _close(dgp, ref, 3e-2, "dgp")
