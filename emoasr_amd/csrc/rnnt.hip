@@ -290,8 +290,16 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(long rows, int Tn, int U
   const int Tb = min(elens[b], Tn), Ub = ylens[b];
   T* dr = dz + row * V;
   const float nl = nll[b];
+  constexpr int VEC = 16 / sizeof(T);
+  const bool vec = V % VEC == 0;   // rows are 16-byte aligned: 16 bytes per load / store instead of one value
   if (t >= Tb || u > Ub || !isfinite(nl)) {
-    for (int v = lane; v < V; v += 64) dr[v] = from_f32<T>(0.f);
+    if (vec) {
+      Vec16<T> zv;
+      zv.zero();
+      for (int v0 = lane * VEC; v0 < V; v0 += 64 * VEC) store16(dr + v0, zv);
+    } else {
+      for (int v = lane; v < V; v += 64) dr[v] = from_f32<T>(0.f);
+    }
     return;
   }
   const float gs = gscale_dev ? gscale * gscale_dev[0] : gscale;
@@ -304,6 +312,23 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(long rows, int Tn, int U
   const float occ = gb + gy;
   const float l = lse[row];
   const T* zr = z + row * V;
+  if (vec) {
+#pragma unroll 2
+    for (int v0 = lane * VEC; v0 < V; v0 += 64 * VEC) {
+      const Vec16<T> q = load16(zr + v0);
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int v = v0 + e;
+        float g = __expf(q.get(e) - l) * occ;
+        if (v == blank) g -= gb;
+        if (v == y) g -= gy;
+        o.set(e, g * gs);
+      }
+      store16(dr + v0, o);
+    }
+    return;
+  }
   for (int v = lane; v < V; v += 64) {
     float g = __expf(to_f32(zr[v]) - l) * occ;
     if (v == blank) g -= gb;
