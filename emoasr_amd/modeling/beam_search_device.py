@@ -257,7 +257,7 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
                 if _t2 - _t1 > worst[0]:
                     worst = (_t2 - _t1, i, "sync")
         main.synchronize()
-        if lib.size_query("emoasr_decode_coop_status") != 0:
+        if lib.size_query("emoasr_decode_coop_status") > 0:
             raise RuntimeError("decode_coop: a grid barrier gave up waiting (csrc/decode_coop.hip); emoasr_set_option('decode_coop', 0) "
                                "selects the launch chain")
         if dbg:

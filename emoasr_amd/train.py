@@ -205,6 +205,10 @@ def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False
         for k, v in loss_dict.items():
             sums[k] = sums[k] + v if k in sums else v
         if stepping and step % params.log_step == 0:
+            from . import lib
+            if lib.size_query("emoasr_lstm_coop_status") > 0:   # (this is the loop's host synchronisation point anyway; -1: no device)
+                raise RuntimeError("lstm_coop: a grid barrier gave up waiting (csrc/lstm_coop.hip); emoasr_set_option('lstm_coop', 0) "
+                                   "selects the per-position launch chain")
             detail = " ".join(f"{k}: {float(v) / params.log_step:.3f}" for k, v in sums.items())
             log(f"epoch = {(epoch + 1):>2} step = {step:>6} / {n_total:>6} lr = {optimizer._lr:.5f} " + detail)
             sums = {}
