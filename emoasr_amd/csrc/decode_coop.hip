@@ -6,7 +6,7 @@
 // INSIDE a launch -- every workgroup publishes its slice of the activations, one device-scope atomic add on a monotonic counter,
 // a polling load, then 8 KB of activation rows read back -- measures 2.1 us for 16 workgroups on an otherwise idle device
 // (tools/micro/grid_barrier.hip, profiles/r02_grid_barrier.txt: 1.8 / 2.1 / 2.8 / 4.4 us at 8 / 16 / 32 / 64 workgroups), and
-// fusing LayerNorm, the cache append and the residual adds into the neighbouring stages leaves 5 (LM) / 8 (decoder) boundaries per
+// fusing LayerNorm, the cache append and the residual adds into the neighbouring stages leaves 5 (LM) / 8 (decoder; 7 with its projection and self-attention as one stage, see qkv_attn_stage) boundaries per
 // layer instead of 8 / 12 launches.  The single-workgroup attempt (csrc/decode_wg.hip) had no boundaries at all but paid a global
 // round trip per stage on one CU and could not stream the weights; here 16 workgroups x 8 waves each own up to four 16-column x
 // 32-deep weight fragments of a stage, requested BEFORE the barrier that precedes the stage.
