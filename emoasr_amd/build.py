@@ -11,7 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libemoasr_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "elementwise.hip", "convmodule.hip",
-           "subsample.hip", "ctc.hip", "attention.hip", "optim.hip", "feats.hip", "decoder.hip", "rnnt.hip", "layer.hip", "decode_rt.hip", "distill.hip", "ffn.hip", "gemm_big.hip", "convfused.hip", "rowlin.hip", "decode_wg.hip", "decode_coop.hip", "lstm_coop.hip"]
+           "subsample.hip", "ctc.hip", "attention.hip", "optim.hip", "feats.hip", "decoder.hip", "rnnt.hip", "layer.hip", "decode_rt.hip", "distill.hip", "gemm_big.hip", "convfused.hip", "rowlin.hip", "decode_coop.hip", "lstm_coop.hip"]
+# measured-slower variants kept reproducible: linked in only when EMOASR_EXPERIMENTAL=1 is set at build time
+EXPERIMENTAL = ["experimental/ffn.hip", "experimental/decode_wg.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-Wno-comment",
          "-ffp-contract=off"]
 
@@ -26,28 +28,39 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in ("common.h", "mma.h")]
     headers.append(os.path.join(HERE, "..", "include", "emoasr_hip.h"))
+    experimental = os.environ.get("EMOASR_EXPERIMENTAL", "0") == "1"
+    sources = SOURCES + (EXPERIMENTAL if experimental else [])
+    flags = FLAGS + (["-DEMOASR_EXPERIMENTAL"] if experimental else [])
+    # a flavour change (default <-> experimental) rebuilds everything: the flag changes code in several units
+    stamp = os.path.join(objdir, "flavour")
+    flavour = "experimental" if experimental else "default"
+    if not os.path.exists(stamp) or open(stamp).read() != flavour:
+        force = True
+    obj_of = lambda src: os.path.join(objdir, src.replace("/", "_").replace(".hip", ".o"))
     jobs = []
-    for src in SOURCES:
+    for src in sources:
         s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        o = obj_of(src)
         if force or _newer(s, o) or any(_newer(h, o) for h in headers):
             jobs.append((s, o))
 
     def cc(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + flags + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [obj_of(s) for s in sources]
     if jobs or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(flavour)
     return LIB
 
 

@@ -26,7 +26,9 @@ void emo_gemm_set_big_min_tiles(int v);
 void emo_conv_set_dwconv_lds(int v);
 void emo_layer_set_conv_fused(int v);
 void emo_decode_set_fused(int v);
+#ifdef EMOASR_EXPERIMENTAL
 void emo_decode_set_wg(int v);
+#endif
 void emo_decode_set_coop(int v);
 void emo_lstm_set_coop(int v);
 void emo_decode_set_coop_merge(int v);
@@ -80,6 +82,13 @@ extern "C" int emoasr_timer_read(const char* name, int* calls, double* ms, int r
 
 extern "C" const char* emoasr_last_error(void) { return g_err; }
 extern "C" int emoasr_version(void) { return 1; }
+extern "C" int emoasr_experimental(void) {
+#ifdef EMOASR_EXPERIMENTAL
+  return 1;
+#else
+  return 0;
+#endif
+}
 extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "tr_read") == 0) {
     emo_gemm_set_tr_read(value);
@@ -96,14 +105,22 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "big_min_tiles") == 0) { emo_gemm_set_big_min_tiles(value); return 0; }
   if (strcmp(name, "dwconv_lds") == 0) { emo_conv_set_dwconv_lds(value); return 0; }
   if (strcmp(name, "conv_fused") == 0) { emo_layer_set_conv_fused(value); return 0; }
+#ifdef EMOASR_EXPERIMENTAL
   if (strcmp(name, "decode_fused") == 0) { emo_decode_set_fused(value); return 0; }
   if (strcmp(name, "decode_wg") == 0) { emo_decode_set_wg(value); return 0; }
+  if (strcmp(name, "ffn_fused") == 0) { emo_layer_set_ffn_fused(value); return 0; }
+#else
+  if (strcmp(name, "decode_fused") == 0 || strcmp(name, "decode_wg") == 0 || strcmp(name, "ffn_fused") == 0) {
+    if (value == 0) return 0;
+    emo_set_error("option '%s' needs a library built with EMOASR_EXPERIMENTAL=1 (measured-slower variants, csrc/experimental/)", name);
+    return 1;
+  }
+#endif
   if (strcmp(name, "decode_coop") == 0) { emo_decode_set_coop(value); return 0; }
   if (strcmp(name, "lstm_coop") == 0) { emo_lstm_set_coop(value); return 0; }
   if (strcmp(name, "decode_coop_merge") == 0) { emo_decode_set_coop_merge(value); return 0; }
   if (strcmp(name, "attn_fw") == 0) { emo_attn_set_fw(value); return 0; }
   if (strcmp(name, "timers") == 0) { g_timers_on = value; return 0; }
-  if (strcmp(name, "ffn_fused") == 0) { emo_layer_set_ffn_fused(value); return 0; }
   emo_set_error("unknown option '%s'", name);
   return 1;
 }

@@ -848,9 +848,28 @@ bool plan_ok(int N, int K) {
 void emo_decode_set_coop(int v) { g_decode_coop = v; }
 void emo_decode_set_coop_merge(int v) { g_coop_merge = v; }
 
+// The kernels are launched with <<<>>> (they are replayed from HIP graphs), so the co-residency of the CG workgroups their grid
+// barrier assumes is verified once here: occupancy x compute units >= CG for all four instantiations.
+static bool coop_resident() {
+  static int cached = -1;
+  if (cached < 0) {
+    int dev = 0, cus = 0;
+    bool ok = hipGetDevice(&dev) == hipSuccess &&
+              hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+    const void* ks[4] = {(const void*)lm_step_coop_kernel<true>, (const void*)lm_step_coop_kernel<false>,
+                         (const void*)dec_step_coop_kernel<true>, (const void*)dec_step_coop_kernel<false>};
+    for (int i = 0; ok && i < 4; ++i) {
+      int per_cu = 0;
+      ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ks[i], CT, 0) == hipSuccess && (long)per_cu * cus >= CG;
+    }
+    cached = ok ? 1 : 0;
+  }
+  return cached == 1;
+}
+
 // Can the cooperative kernels take this step?  (bf16, <= 16 hypotheses, <= 12 / 8 layers, shapes that fit the plans)
 bool emo_decode_coop_ok(int dtype, int nb, int nl, int max_layers, int d, int H, int F, int T) {
-  return g_decode_coop && dtype == EMO_BF16 && nb >= 1 && nb <= 16 && nl >= 1 && nl <= max_layers && d <= C_MAXD && F <= C_MAXF &&
+  return g_decode_coop && coop_resident() && dtype == EMO_BF16 && nb >= 1 && nb <= 16 && nl >= 1 && nl <= max_layers && d <= C_MAXD && F <= C_MAXF &&
          d % H == 0 && (d / H) % 8 == 0 && d / H <= 64 && nb * H <= C_MAXPAIR && (T + 63) / 64 <= C_MAXCHUNK && plan_ok(3 * d, d) &&
          plan_ok(d, d) && plan_ok(F, d) && plan_ok(d, F);
 }

@@ -187,16 +187,22 @@ __global__ __launch_bounds__(256) void cache_gather_kernel(int nl, int nb, int L
 }
 
 }  // namespace
-// csrc/decode_wg.hip: the whole stack of either network for one step in ONE single-workgroup launch (bf16)
+#ifdef EMOASR_EXPERIMENTAL
+// csrc/experimental/decode_wg.hip (opt-in build, measured slower): the whole stack of either network for one step in ONE
+// single-workgroup launch (bf16)
 bool emo_decode_wg_ok(int dtype, int nb, int nl, int max_layers, int d, int H, int F);
 int emo_bert_lm_step_wg(int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_step_t* io, void* out_hidden, hipStream_t s);
+int emo_transformer_decoder_step_wg(int nl, const emoasr_decoder_layer_t* layers, const emoasr_decoder_step_t* io, void* out_x,
+                                    hipStream_t s);
+constexpr bool kExperimental = true;
+#else
+constexpr bool kExperimental = false;   // the measured-slower variants are compiled only with EMOASR_EXPERIMENTAL=1 (build.py)
+#endif
 // csrc/decode_coop.hip: the same in one launch of 16 cooperating workgroups with grid barriers between the stages (bf16)
 bool emo_decode_coop_ok(int dtype, int nb, int nl, int max_layers, int d, int H, int F, int T);
 int emo_bert_lm_step_coop(int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_step_t* io, void* out_hidden, hipStream_t s);
 int emo_transformer_decoder_step_coop(int nl, const emoasr_decoder_layer_t* layers, const emoasr_decoder_step_t* io, void* out_x,
                                       hipStream_t s);
-int emo_transformer_decoder_step_wg(int nl, const emoasr_decoder_layer_t* layers, const emoasr_decoder_step_t* io, void* out_x,
-                                    hipStream_t s);
 namespace {
 
 int g_decode_fused = 0;  // bf16: LayerNorm / residual / cache-append folded into rowlin + attn_step (csrc/rowlin.hip): 8 / 5
@@ -265,15 +271,17 @@ extern "C" int emoasr_transformer_decoder_step(int dtype, int nl, const emoasr_d
     if (emo_transformer_decoder_step_coop(nl, layers, io, x, s)) return 1;
     return rl(nb, io->V, dd, x, &io->ln_out, io->out, EMOASR_ACT_NONE, nullptr, nullptr, io->logits_last, 0, stream);
   }
+#ifdef EMOASR_EXPERIMENTAL
   if (emo_decode_wg_ok(dtype, nb, nl, 8, dd, H, F)) {
     // the whole stack in one single-workgroup launch, then the final LayerNorm + vocabulary projection across the chip
     if (emo_transformer_decoder_step_wg(nl, layers, io, x, s)) return 1;
     return rl(nb, io->V, dd, x, &io->ln_out, io->out, EMOASR_ACT_NONE, nullptr, nullptr, io->logits_last, 0, stream);
   }
+#endif
   EMO_DISPATCH(dtype, (step_embed_kernel<T><<<cdiv(nb * dd, 256), 256, 0, s>>>(nb, dd, io->ids, (const T*)io->embed, io->pe,
                                                                                 io->emb_scale, io->pos, (T*)x)));
   const size_t layer_bytes = (size_t)nb * Lmax * dd * esz;
-  if (g_decode_fused && dtype == EMO_BF16 && nb <= 16 && dd <= 1024 && F <= 1024 && dd % 32 == 0 && F % 32 == 0 && (dd / H) % 8 == 0) {
+  if (kExperimental && g_decode_fused && dtype == EMO_BF16 && nb <= 16 && dd <= 1024 && F <= 1024 && dd % 32 == 0 && F % 32 == 0 && (dd / H) % 8 == 0) {
     // 8 launches per layer instead of 12: LayerNorms inside the following projection, cache append inside the attention
     for (int li = 0; li < nl; ++li) {
       const emoasr_decoder_layer_t& Ly = layers[li];
@@ -355,6 +363,7 @@ extern "C" int emoasr_bert_lm_step(int dtype, int nl, const emoasr_bert_layer_t*
     if (rl(nb, V, d, t1, &io->ln_transform, tied_co, EMOASR_ACT_NONE, nullptr, nullptr, logits, 1, stream)) return 1;
     return emoasr_log_softmax(EMO_F32, nb, V, logits, V, nullptr, 0, 0.f, io->logp, V, stream);
   }
+#ifdef EMOASR_EXPERIMENTAL
   if (emo_decode_wg_ok(dtype, nb, nl, 12, d, H, F)) {
     if (emo_bert_lm_step_wg(nl, layers, io, t1, s)) return 1;
     emoasr_lin_t tied_wg{io->word_emb, io->out_bias};
@@ -362,10 +371,11 @@ extern "C" int emoasr_bert_lm_step(int dtype, int nl, const emoasr_bert_layer_t*
     if (rl(nb, V, d, t1, &io->ln_transform, tied_wg, EMOASR_ACT_NONE, nullptr, nullptr, logits, 1, stream)) return 1;
     return emoasr_log_softmax(EMO_F32, nb, V, logits, V, nullptr, 0, 0.f, io->logp, V, stream);
   }
+#endif
   EMO_DISPATCH(dtype, (step_embed_kernel<T><<<cdiv(nb * d, 256), 256, 0, s>>>(nb, d, io->ids, (const T*)io->word_emb, io->pe, 1.f,
                                                                               io->pos, (T*)y)));
   const size_t layer_bytes = (size_t)nb * Lmax * d * esz;
-  if (g_decode_fused && dtype == EMO_BF16 && nb <= 16 && d <= 1024 && F <= 1024 && d % 32 == 0 && F % 32 == 0 && (d / H) % 8 == 0) {
+  if (kExperimental && g_decode_fused && dtype == EMO_BF16 && nb <= 16 && d <= 1024 && F <= 1024 && d % 32 == 0 && F % 32 == 0 && (d / H) % 8 == 0) {
     // post-LN blocks, 5 launches per layer instead of 8: `y` holds the block's pre-LayerNorm output and `pend` the
     // LayerNorm still to be applied to it -- inside the next projection (A operand) and inside the next residual add
     const emoasr_lnp_t* pend = &io->ln_emb;

@@ -28,8 +28,8 @@
 // Reference: decoders/transformer.py:148-159 + transformer.py:156-198 (pre-LN decoder layer, ReLU);
 // lm/modeling/transformer.py:62-77 over modeling_bert.py:159-303,360-436 (post-LN block, GELU).
 #include <math.h>
-#include "common.h"
-#include "../../include/emoasr_hip.h"
+#include "../common.h"
+#include "../../../include/emoasr_hip.h"
 
 namespace {
 

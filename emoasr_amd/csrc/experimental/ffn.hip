@@ -26,8 +26,8 @@
 // GEMMs run three workgroups per CU on all CUs and hide exactly that.  The kernel is kept as the tested reference point
 // for a version with LDS-DMA staging and more rows per weight byte.
 #include <type_traits>
-#include "mma.h"
-#include "../../include/emoasr_hip.h"
+#include "../mma.h"
+#include "../../../include/emoasr_hip.h"
 
 namespace {
 

@@ -19,17 +19,20 @@ emoasr_epilogue_t plain_ep() {
 }
 
 // x + res_scale * drop(W2 act(W1 LN(x) + b1) + b2)
-int g_ffn_fused = 0;  // bf16, d = 256: the feed-forward block as ONE launch (csrc/ffn.hip) -- measured slower than LayerNorm +
-                      // two GEMMs at the L2 batch size (87 vs 40 us, see ffn.hip), so off unless emoasr_set_option("ffn_fused", 1)
+int g_ffn_fused = 0;  // bf16, d = 256: the feed-forward block as ONE launch (csrc/experimental/ffn.hip, EMOASR_EXPERIMENTAL builds
+                      // only) -- measured slower than LayerNorm + two GEMMs at the L2 batch size (87 vs 40 us, see ffn.hip), so
+                      // off unless emoasr_set_option("ffn_fused", 1)
 
 int g_conv_fused = 1;  // bf16: the fused convolution-module kernels of csrc/convfused.hip (bit-identical to the separate launches)
 bool conv_fused_ok(int dtype, int d) { return g_conv_fused && dtype == EMO_BF16 && d % 8 == 0; }
 
 int ffn_fwd(int dtype, int M, int d, int F, const emoasr_ffn_params_t& p, const void* x, float res_scale,
             float p_enc, uint64_t s_in, uint64_t s_out, const emoasr_ffn_stash_t& st, void* stream) {
+#ifdef EMOASR_EXPERIMENTAL
   if (g_ffn_fused && dtype == EMO_BF16 && d == 256 && F % 256 == 0)
     return emoasr_ffn_fwd(dtype, M, d, F, x, p.ln_g, p.ln_b, 1e-5f, p.w1, p.b1, p.w2, p.b2, EMOASR_ACT_SWISH, res_scale, p_enc,
                           s_in, s_out, st.h, st.mean, st.rstd, st.u, st.a, st.y, stream);
+#endif
   if (emoasr_layernorm_fwd(dtype, M, d, x, p.ln_g, p.ln_b, 1e-5f, st.h, st.mean, st.rstd, stream)) return 1;
   emoasr_epilogue_t e1 = plain_ep();
   e1.bias = p.b1; e1.act = EMOASR_ACT_SWISH; e1.pre_out = st.u; e1.drop_p = p_enc; e1.seed = s_in;

@@ -39,15 +39,16 @@ constexpr int L_MAXH = 512;
 
 #define EMO_FRESH(x) asm volatile("" : "+v"(x))
 
+// The barrier's base (the counter value when the launch starts) is a KERNEL ARGUMENT kept by the host (lstm_base below): the
+// counter is shared by every layer / model / hidden size of the process and G = H / 16 varies (2 .. 32, not always a power of
+// two), so it cannot be recovered on the device as "the counter rounded down to a multiple of G".  Every launch performs exactly
+// U - 1 whole barriers -- a workgroup whose wait gave up has still added its arrival -- so the host's running sum stays exact.
 struct LBar { unsigned* counter; int* err; unsigned base, n, G; };
-__device__ void lbar_init(LBar& b, unsigned* counter, int* err, unsigned G, unsigned* s_base) {
-  if (threadIdx.x == 0) {
-    const unsigned v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_base = v - v % G;   // (see decode_coop.hip: launches are stream-ordered and perform whole barriers)
-  }
-  __syncthreads();
-  b.counter = counter; b.err = err; b.base = *s_base; b.n = 0; b.G = G;
+__device__ void lbar_init(LBar& b, unsigned* counter, int* err, unsigned G, unsigned base) {
+  b.counter = counter; b.err = err; b.base = base; b.n = 0; b.G = G;
 }
+// a barrier of this launch (or an earlier one that nobody has reported yet) gave up: the outputs cannot be trusted
+__device__ bool lbar_failed(const LBar& b) { return __hip_atomic_load(b.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 __device__ void lgrid_sync(LBar& b) {
   ++b.n;
   __syncthreads();
@@ -76,20 +77,19 @@ struct LstmFwdArgs {
   bf16* hseq;          // [U][B][H]
   float* cseq;         // [U][B][H]
   bf16* gact;          // [U][B][4H] activated gates
-  unsigned* counter; int* err;
+  unsigned* counter; int* err; unsigned base;
 };
 
 // LDS: Ws [64][H + 8] | hs [64][H + 8] | gat [4][64][17] f32
 __global__ __launch_bounds__(LT) void lstm_seq_fwd_kernel(const LstmFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ unsigned s_base;
   const int H = a.H, B = a.B, ld = H + 8, g = blockIdx.x, G = gridDim.x;
   bf16* Ws = reinterpret_cast<bf16*>(smem);
   bf16* hs = Ws + 64 * ld;
   float* gat = reinterpret_cast<float*>(hs + 64 * ld);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   LBar bar;
-  lbar_init(bar, a.counter, a.err, (unsigned)G, &s_base);
+  lbar_init(bar, a.counter, a.err, (unsigned)G, a.base);
   // the four gates' rows of the own 16 units: Ws[gate * 16 + j] = w_hh[gate * H + 16 g + j]
   for (int i = tid; i < 64 * (H / 8); i += LT) {
     const int r = i / (H / 8), c = (i - r * (H / 8)) * 8;
@@ -158,6 +158,12 @@ __global__ __launch_bounds__(LT) void lstm_seq_fwd_kernel(const LstmFwdArgs a) {
       }
     }
   }
+  // a wait that gave up read a half-written h_{u-1}: poison the own slice of the outputs so that the loss / gradient norm turns
+  // NaN and the optimizer's NaN skip drops the step (the host reports the flag at its next synchronisation point)
+  if (lbar_failed(bar)) {
+    const float qnan = __builtin_nanf("");
+    for (long i = threadIdx.x; i < (long)a.U * B * 16; i += LT) a.hseq[(i >> 4) * H + 16 * g + (i & 15)] = (bf16)qnan;
+  }
 }
 
 struct LstmBwdArgs {
@@ -169,20 +175,19 @@ struct LstmBwdArgs {
   const bf16* w_hh;     // [4H][H]
   bf16* dgp;            // [U][B][4H] out: gradient w.r.t. the gate pre-activations
   float* part;          // [2][G][64][H] f32 scratch: every workgroup's contribution to dh_{u-1}
-  unsigned* counter; int* err;
+  unsigned* counter; int* err; unsigned base;
 };
 
 // LDS: WT [H][72] (the own 64 gate rows of W_hh, transposed: WT[n][k] = w_hh[row(k)][n]) | dg [64][72] (the own dgates of the position)
 __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ unsigned s_base;
   const int H = a.H, B = a.B, g = blockIdx.x, G = gridDim.x;
   constexpr int LDK = 72;
   bf16* WT = reinterpret_cast<bf16*>(smem);
   bf16* dg = WT + H * LDK;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   LBar bar;
-  lbar_init(bar, a.counter, a.err, (unsigned)G, &s_base);
+  lbar_init(bar, a.counter, a.err, (unsigned)G, a.base);
   for (int i = tid; i < 64 * H; i += LT) {   // k = gate * 16 + j <-> row gate * H + 16 g + j
     const int k = i / H, n = i - k * H;
     WT[n * LDK + k] = a.w_hh[((long)(k >> 4) * H + 16 * g + (k & 15)) * H + n];
@@ -262,6 +267,13 @@ __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
       __syncthreads();   // dg is rewritten by the next position
     }
   }
+  if (lbar_failed(bar)) {   // (see the forward kernel)
+    const float qnan = __builtin_nanf("");
+    for (long i = threadIdx.x; i < (long)a.U * B * 64; i += LT) {
+      const long row = i >> 6; const int k = (int)(i & 63);
+      a.dgp[row * 4 * H + (long)(k >> 4) * H + 16 * g + (k & 15)] = (bf16)qnan;
+    }
+  }
 }
 
 unsigned* lstm_counter(int which, int** err) {
@@ -274,6 +286,24 @@ unsigned* lstm_counter(int which, int** err) {
 }
 
 int g_lstm_coop = 1;
+
+// counter value at the start of the next launch, per counter (0 forward, 1 backward); launches are stream-ordered
+unsigned g_lstm_base[2] = {0u, 0u};
+unsigned lstm_base(int which, int G, int U) {
+  const unsigned b = g_lstm_base[which];
+  g_lstm_base[which] += (unsigned)G * (unsigned)(U - 1);
+  return b;
+}
+
+// The kernels are launched with <<<>>>, so the co-residency of their G workgroups is verified here instead (once per kernel and
+// LDS size): the grid barrier would otherwise spin until its bail-out.
+bool lstm_fits(const void* kernel, size_t smem, int G) {
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, LT, smem) != hipSuccess) return false;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return false;
+  return (long)per_cu * cus >= G;
+}
 
 }  // namespace
 
@@ -300,8 +330,11 @@ extern "C" int emoasr_lstm_seq_fwd(int dtype, int U, int B, int H, const void* p
   if (smem > set_bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     EMO_CHECK(e == hipSuccess, "lstm_seq_fwd: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
+    EMO_CHECK(lstm_fits((const void*)lstm_seq_fwd_kernel, smem, L_MAXH / 16), "lstm_seq_fwd: the device cannot hold %d workgroups at once",
+              L_MAXH / 16);
     set_bytes = smem;
   }
+  a.base = lstm_base(0, H / 16, U);
   lstm_seq_fwd_kernel<<<H / 16, LT, smem, (hipStream_t)stream>>>(a);
   EMO_LAUNCH_CHECK();
   return 0;
@@ -328,18 +361,27 @@ extern "C" int emoasr_lstm_seq_bwd(int dtype, int U, int B, int H, const void* d
   if (smem > set_bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     EMO_CHECK(e == hipSuccess, "lstm_seq_bwd: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
+    EMO_CHECK(lstm_fits((const void*)lstm_seq_bwd_kernel, smem, L_MAXH / 16), "lstm_seq_bwd: the device cannot hold %d workgroups at once",
+              L_MAXH / 16);
     set_bytes = smem;
   }
+  a.base = lstm_base(1, H / 16, U);
   lstm_seq_bwd_kernel<<<H / 16, LT, smem, (hipStream_t)stream>>>(a);
   EMO_LAUNCH_CHECK();
   return 0;
 }
 
-// error flag of the recurrence kernels' barriers (a wait that gave up): 0 = fine.  Synchronises the device.
+// error flag of the recurrence kernels' barriers (a wait that gave up): 0 = fine.  Synchronises the device; a reported
+// failure is cleared (flag and both counters back to zero), so the launches that follow start from a clean state.
 extern "C" long emoasr_lstm_coop_status(void) {
   int* err = nullptr;
-  if (!lstm_counter(0, &err)) return -1;
+  unsigned* c = lstm_counter(0, &err);
+  if (!c) return -1;
   int e = 0;
   if (hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (e) {
+    if (hipDeviceSynchronize() != hipSuccess || hipMemset(c, 0, 1024) != hipSuccess) return -1;
+    g_lstm_base[0] = g_lstm_base[1] = 0u;
+  }
   return e;
 }

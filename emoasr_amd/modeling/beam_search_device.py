@@ -23,6 +23,8 @@ from ..decode_rt import DecoderStepRuntime, LMStepRuntime, _lin, _ln
 from ..engine import h2d_i32
 from .functions import _engine_of
 
+_STEP_DEADLINE_S = 30.0   # a search step takes ~0.5 ms; this only bounds the wait for a launch that will never report
+
 CTC_BEAM_WIDTH_RATIO = 1.5
 
 
@@ -221,49 +223,59 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
         dbg = os.environ.get("EMOASR_BEAM_STEP_TIMING") == "1"
         t_l = t_s = 0.0
         worst = (0.0, -1, "")
-        for i in range(max_steps):
-            if dbg:
-                _t0 = time.perf_counter()
-            if use_graph:
-                k = i & 1
-                if use_lm and two_streams:   # the LM chain on the side stream, concurrent with the decoder chain
-                    ev_tail.record(main)             # the previous step's tail (ids / parent / pos) is complete
-                    side.wait_event(ev_tail)
-                    lib.call("emoasr_joint_beam_graph_launch", k, 1, side_p)
-                    ev_lm.record(side)
-                elif use_lm:
-                    lib.call("emoasr_joint_beam_graph_launch", k, 1, main_p)
-                lib.call("emoasr_joint_beam_graph_launch", k, 0, main_p)
-                if use_lm and two_streams:
-                    main.wait_event(ev_lm)
-                lib.call("emoasr_joint_beam_graph_launch", k, 2, main_p)
-            else:
-                lib.call("emoasr_joint_beam_step", dt_code, ctypes.byref(steps[i & 1]), main_p, side_p)
-            if dbg:
-                _t1 = time.perf_counter()
-            # Steps are issued one ahead of the flag they depend on (a step launched after the search has finished changes
-            # nothing: emoasr_beam_update returns at once), so the GPU never waits for the host.  The state of step i - 1
-            # arrives in pinned memory by the kernel's own store; polling it involves no copy engine and no event.
-            if i >= 1:
-                while mirror[0] < i and not mirror[3]:
-                    _yield()   # the runtime's own threads (signal handling, graph bookkeeping) may share this core
-                if mirror[3]:
-                    break
-            if dbg:
-                _t2 = time.perf_counter()
-                t_l += _t1 - _t0; t_s += _t2 - _t1
-                if _t1 - _t0 > worst[0]:
-                    worst = (_t1 - _t0, i, "launch")
-                if _t2 - _t1 > worst[0]:
-                    worst = (_t2 - _t1, i, "sync")
-        main.synchronize()
-        if lib.size_query("emoasr_decode_coop_status") > 0:
-            raise RuntimeError("decode_coop: a grid barrier gave up waiting (csrc/decode_coop.hip); emoasr_set_option('decode_coop', 0) "
-                               "selects the launch chain")
+        try:
+            for i in range(max_steps):
+                if dbg:
+                    _t0 = time.perf_counter()
+                if use_graph:
+                    k = i & 1
+                    if use_lm and two_streams:   # the LM chain on the side stream, concurrent with the decoder chain
+                        ev_tail.record(main)             # the previous step's tail (ids / parent / pos) is complete
+                        side.wait_event(ev_tail)
+                        lib.call("emoasr_joint_beam_graph_launch", k, 1, side_p)
+                        ev_lm.record(side)
+                    elif use_lm:
+                        lib.call("emoasr_joint_beam_graph_launch", k, 1, main_p)
+                    lib.call("emoasr_joint_beam_graph_launch", k, 0, main_p)
+                    if use_lm and two_streams:
+                        main.wait_event(ev_lm)
+                    lib.call("emoasr_joint_beam_graph_launch", k, 2, main_p)
+                else:
+                    lib.call("emoasr_joint_beam_step", dt_code, ctypes.byref(steps[i & 1]), main_p, side_p)
+                if dbg:
+                    _t1 = time.perf_counter()
+                # Steps are issued one ahead of the flag they depend on (a step launched after the search has finished changes
+                # nothing: emoasr_beam_update returns at once), so the GPU never waits for the host.  The state of step i - 1
+                # arrives in pinned memory by the kernel's own store; polling it involves no copy engine and no event.
+                if i >= 1:
+                    spins, t_wait = 0, None
+                    while mirror[0] < i and not mirror[3]:
+                        _yield()   # the runtime's own threads (signal handling, graph bookkeeping) may share this core
+                        spins += 1
+                        if spins & 0xFFF == 0:   # a lost launch / a faulted device must surface, not spin forever
+                            now = time.perf_counter()
+                            t_wait = now if t_wait is None else t_wait
+                            if now - t_wait > _STEP_DEADLINE_S:
+                                raise RuntimeError(f"beam search: step {i - 1} did not report within {_STEP_DEADLINE_S:.0f} s "
+                                                   f"(stream idle: {main.query()}; last library error: {lib.load().emoasr_last_error().decode()!r})")
+                    if mirror[3]:
+                        break
+                if dbg:
+                    _t2 = time.perf_counter()
+                    t_l += _t1 - _t0; t_s += _t2 - _t1
+                    if _t1 - _t0 > worst[0]:
+                        worst = (_t1 - _t0, i, "launch")
+                    if _t2 - _t1 > worst[0]:
+                        worst = (_t2 - _t1, i, "sync")
+            main.synchronize()
+            if lib.size_query("emoasr_decode_coop_status") > 0:
+                raise RuntimeError("decode_coop: a grid barrier gave up waiting (csrc/decode_coop.hip); emoasr_set_option('decode_coop', 0) "
+                                   "selects the launch chain")
+        finally:
+            if gc_was_on:   # (also on an exception: the collector must not stay off for the rest of the process)
+                gc.enable()
         if dbg:
             print(f"   host: launches {1e3 * t_l:.2f} ms, waits {1e3 * t_s:.2f} ms, worst {1e3 * worst[0]:.2f} ms at step {worst[1]} ({worst[2]})", flush=True)
-        if gc_was_on:
-            gc.enable()
         n_done = int(mirror[0])                      # effective steps (pos advances only while the search is live)
         stats = getattr(eng, "_beam_stats", None)    # running totals for bench.py: steps and wall time of the search loops
         if stats is None:

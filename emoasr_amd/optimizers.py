@@ -32,6 +32,7 @@ class Adam:
         self._pending = None  # a state dict loaded before the arena exists
         self.clip_grad_norm = 0.0  # set by train_step (the reference clips outside the optimizer)
         self.grad_mult = 1.0
+        self._unclaimed = 0  # skipped updates already folded out of the core's counter, not yet out of a scheduler's
 
     # -- binding ---------------------------------------------------------------------------
     def _bind(self):
@@ -66,8 +67,17 @@ class Adam:
 
     def fold_skipped(self):
         """-> number of updates the fused kernel skipped (NaN / Inf gradient norm) since the last call; the step counter
-        behind the bias correction is corrected by it (one host synchronisation)"""
-        return self._core.fold_skipped() if self._core is not None else 0
+        behind the bias correction is corrected by it (one host synchronisation).  The count is also kept pending for the
+        scheduler that wraps this optimizer (take_skipped), whoever triggered the fold."""
+        n = self._core.fold_skipped() if self._core is not None else 0
+        self._unclaimed += n
+        return n
+
+    def take_skipped(self):
+        """fold, then hand over (and forget) every skipped update no scheduler has been told about yet"""
+        self.fold_skipped()
+        n, self._unclaimed = self._unclaimed, 0
+        return n
 
     def _can_bind(self):
         from .engine import arena_of
@@ -101,67 +111,78 @@ class Adam:
         checkpoint.load_optimizer_state_dict(self._core, {"optimizer": sd, "_step": max(steps) if steps else 0})
 
 
+def _warmup_ramp(peak, warm, step):
+    return (peak / max(1.0, warm)) * step
+
+
+# schedule name -> rate(sched, step) for step >= 1 (asr/optimizers.py:47-75); `sched` carries the constants
+_SCHEDULES = {
+    # Vaswani et al.: peak * d^-0.5 * min(step^-0.5, step * warm^-1.5)
+    "noam": lambda o, t: o.base_lr * o.model_dim ** (-0.5) * min(t ** (-0.5), t * o.num_warmup_steps ** (-1.5)),
+    # linear ramp, then flat (the per-epoch decay happens in update_epoch)
+    "epdecay": lambda o, t: _warmup_ramp(o.base_lr, o.num_warmup_steps, t) if t <= o.num_warmup_steps else o.base_lr,
+    # linear ramp, then a straight line to zero at num_total_steps (transformers.get_linear_schedule_with_warmup)
+    "lindecay": lambda o, t: _warmup_ramp(o.base_lr, o.num_warmup_steps, t) if t <= o.num_warmup_steps else
+    o.base_lr * max(0.0, float(o.num_total_steps - t) / float(max(1.0, o.num_total_steps - o.num_warmup_steps))),
+}
+
+# the checkpoint boundary: keys of the reference's `optim.ep{N}` files (asr/optimizers.py:99-108), in their order
+_CKPT_KEYS = ("_step", "_epoch", "base_lr", "_lr", "num_warmup_steps", "num_total_steps")
+
+
 class ScheduledOptimizer:
-    """learning-rate schedules of asr/optimizers.py:45-97 ("noam", "epdecay", "lindecay"); the rate is written
-    into the wrapped optimizer's param groups before every step"""
+    """Learning-rate schedules of asr/optimizers.py:45-97 ("noam", "epdecay", "lindecay") around a wrapped optimizer:
+    before every step the rate for the new schedule position is written into the optimizer's parameter groups.
+
+    Attribute names (`_step`, `_epoch`, `_lr`, `base_lr`, ...) and the state_dict layout are the reference's (they are
+    what its checkpoints and its training log read); the schedules themselves are table entries (_SCHEDULES)."""
 
     def __init__(self, optimizer, params, num_total_steps=None):
+        has_steps, has_prop = hasattr(params, "num_warmup_steps"), hasattr(params, "warmup_proportion")
+        assert has_steps != has_prop, "give exactly one of num_warmup_steps / warmup_proportion"
         self.optimizer = optimizer
         self.schedule_type = params.lr_schedule_type
-        self._step = 0
-        self._epoch = 0
         self.base_lr = params.learning_rate
         self.num_total_steps = num_total_steps
-        assert hasattr(params, "num_warmup_steps") ^ hasattr(params, "warmup_proportion")
-        if hasattr(params, "warmup_proportion"):
-            self.num_warmup_steps = int(num_total_steps * params.warmup_proportion)
-            logging.info(f"warmup #steps: {self.num_warmup_steps:d}")
-        else:
-            self.num_warmup_steps = params.num_warmup_steps
+        self.num_warmup_steps = int(num_total_steps * params.warmup_proportion) if has_prop else params.num_warmup_steps
+        self._step = self._epoch = 0
         self._lr = 0
-        logging.info(f"lr scheduling type: {self.schedule_type}")
-        if self.schedule_type == "epdecay":
-            self.lr_decay_start_epoch = params.lr_decay_start_epoch
-            self.lr_decay_rate = params.lr_decay_rate
-        elif self.schedule_type == "noam":
-            self.model_dim = params.enc_hidden_size if hasattr(params, "enc_hidden_size") else params.hidden_size
+        if self.schedule_type == "noam":
+            self.model_dim = getattr(params, "enc_hidden_size", None) or params.hidden_size
+        elif self.schedule_type == "epdecay":
+            self.lr_decay_start_epoch, self.lr_decay_rate = params.lr_decay_start_epoch, params.lr_decay_rate
+        logging.info(f"lr scheduling type: {self.schedule_type}" + (f", warmup #steps: {self.num_warmup_steps:d}" if has_prop else ""))
 
     @property
     def param_groups(self):
         return self.optimizer.param_groups
 
-    def _set_lr(self, lr):
-        for group in self.optimizer.param_groups:
-            group["lr"] = lr
+    def _publish(self, lr):
+        """make `lr` the rate of every parameter group (skipped when it did not change)"""
+        if lr != self._lr:
+            for group in self.optimizer.param_groups:
+                group["lr"] = lr
+        self._lr = lr
 
     def rate(self, step):
-        warm = self.num_warmup_steps
-        if self.schedule_type == "noam":
-            return self.base_lr * self.model_dim ** (-0.5) * min(step ** (-0.5), step * warm ** (-1.5))
-        if step <= warm:  # epdecay / lindecay: linear warm-up
-            return (self.base_lr / max(1.0, warm)) * step
-        if self.schedule_type == "epdecay":
-            return self.base_lr
-        if self.schedule_type == "lindecay":
-            return self.base_lr * max(0.0, float(self.num_total_steps - step) / float(max(1.0, self.num_total_steps - warm)))
-        return None
+        """learning rate at schedule position `step`; None for an unknown schedule (as the reference leaves it).  Positions
+        below 1 (every update so far was skipped and folded out) are clamped: noam's step^-0.5 has no value at 0."""
+        fn = _SCHEDULES.get(self.schedule_type)
+        return fn(self, max(int(step), 1)) if fn is not None else None
 
     def step(self):
         self._step += 1
-        new_lr = self.rate(self._step)
-        if new_lr != self._lr:
-            self._set_lr(new_lr)
-        self._lr = new_lr
+        self._publish(self.rate(self._step))
         self.optimizer.step()
 
     def update_epoch(self):
         self.fold_skipped()
         self._epoch += 1
         if self.schedule_type == "epdecay" and self._epoch >= self.lr_decay_start_epoch:
-            new_lr = self._lr * self.lr_decay_rate
-            self._set_lr(new_lr)
-            logging.info(f"learning rate decreased: {self._lr:.6f} -> {new_lr:.6f}")
-            self._lr = new_lr
+            decayed = self._lr * self.lr_decay_rate
+            logging.info(f"learning rate decreased: {self._lr:.6f} -> {decayed:.6f}")
+            self._lr = None  # force the write: the epoch decay applies even when the product equals the old rate
+            self._publish(decayed)
 
     def zero_grad(self):
         self.optimizer.zero_grad()
@@ -169,27 +190,29 @@ class ScheduledOptimizer:
     def fold_skipped(self):
         """Take the updates that the fused Adam kernel skipped on the device (NaN / Inf gradient norm) out of the schedule
         position: the reference never calls step() for them (train_asr.py:88-91).  One host synchronisation; called at every
-        epoch boundary and before the state is saved."""
-        base = getattr(self.optimizer, "fold_skipped", None)
-        n = base() if base is not None else 0
+        epoch boundary, at the training loop's log-step synchronisation and before the state is saved.  The wrapped Adam
+        keeps a pending count, so skips it folded on its own (a direct Adam.state_dict()) reach the schedule here too."""
+        take = getattr(self.optimizer, "take_skipped", None)
+        n = take() if take is not None else 0
         if n:
             logging.warning(f"{n:d} update(s) skipped because of nan grad_norm")
-            self._step -= n
+            self._step = max(self._step - n, 0)
         return n
 
     def state_dict(self):
         self.fold_skipped()
-        return {"_step": self._step, "_epoch": self._epoch, "base_lr": self.base_lr, "_lr": self._lr,
-                "num_warmup_steps": self.num_warmup_steps, "num_total_steps": self.num_total_steps,
-                "optimizer": self.optimizer.state_dict()}
+        out = {k: getattr(self, k) for k in _CKPT_KEYS}
+        out["optimizer"] = self.optimizer.state_dict()
+        return out
 
     def load_state_dict(self, state_dict):
-        for key, value in state_dict.items():
-            if key == "optimizer":
-                self.optimizer.load_state_dict(value)
-            elif key == "num_total_steps" and value is not None:
-                assert self.num_total_steps == value
-            else:
+        inner = state_dict.get("optimizer")
+        if inner is not None:
+            self.optimizer.load_state_dict(inner)
+        total = state_dict.get("num_total_steps")
+        assert total is None or total == self.num_total_steps, (total, self.num_total_steps)
+        for key, value in state_dict.items():  # (unknown keys become attributes, as the reference's loop does)
+            if key not in ("optimizer", "num_total_steps"):
                 setattr(self, key, value)
 
 

@@ -117,6 +117,16 @@ def _world(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def rank_dropout_seed(model, group=None):
+    """Offset the engine's dropout seed by this process's rank (idempotent).  Call it once the process group exists and
+    before the first training forward; train_step / train do."""
+    import torch.distributed as dist
+    eng = model.engine() if hasattr(model, "engine") else None
+    if eng is not None and _world(group) > 1 and not getattr(eng, "_seed_ranked", False):
+        eng.seed += 7919 * dist.get_rank(group)
+        eng._seed_ranked = True
+
+
 def train_step(model, optimizer, data, params, device, no_grad=False, empty_cache=False, group=None, sync=True,
                specaug=None):
     """One micro-batch of asr/train_asr.py:35-97: forward, loss / accum_grad, backward; unless `no_grad`
@@ -139,18 +149,15 @@ def train_step(model, optimizer, data, params, device, no_grad=False, empty_cach
     xs = to("xs")
     if specaug is not None:
         xs = specaug(xs.float(), data["xlens"])
-    loss, loss_dict = model(xs=xs, xlens=data["xlens"], ys=data["ys"], ylens=data["ylens"], ys_in=data["ys_in"],
-                            ys_out=data["ys_out"], soft_labels=to("soft_labels"), ps=data.get("ps"),
-                            plens=data.get("plens"))
     world = _world(group)
     if world > 1:
         # one process per GPU: every replica gets its own dropout stream (masks are a pure hash of seed / site / element
-        # index; identical seeds would drop identical positions on all ranks, unlike nn.DataParallel's replicas)
-        import torch.distributed as dist
-        eng = model.engine() if hasattr(model, "engine") else None
-        if eng is not None and not getattr(eng, "_seed_ranked", False):
-            eng.seed += 7919 * dist.get_rank(group)
-            eng._seed_ranked = True
+        # index; identical seeds would drop identical positions on all ranks, unlike nn.DataParallel's replicas).  Applied
+        # BEFORE the first forward, once per engine.
+        rank_dropout_seed(model, group)
+    loss, loss_dict = model(xs=xs, xlens=data["xlens"], ys=data["ys"], ylens=data["ylens"], ys_in=data["ys_in"],
+                            ys_out=data["ys_out"], soft_labels=to("soft_labels"), ps=data.get("ps"),
+                            plens=data.get("plens"))
     accum = params.accum_grad
     if sync:
         loss_dict = {k: v.item() / accum for k, v in loss_dict.items()}
@@ -209,6 +216,8 @@ def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False
             if lib.size_query("emoasr_lstm_coop_status") > 0:   # (this is the loop's host synchronisation point anyway; -1: no device)
                 raise RuntimeError("lstm_coop: a grid barrier gave up waiting (csrc/lstm_coop.hip); emoasr_set_option('lstm_coop', 0) "
                                    "selects the per-position launch chain")
+            if hasattr(optimizer, "fold_skipped"):   # skipped (NaN) updates leave the schedule position here, not only at epoch ends
+                optimizer.fold_skipped()
             detail = " ".join(f"{k}: {float(v) / params.log_step:.3f}" for k, v in sums.items())
             log(f"epoch = {(epoch + 1):>2} step = {step:>6} / {n_total:>6} lr = {optimizer._lr:.5f} " + detail)
             sums = {}

@@ -217,6 +217,8 @@ def test_alternative_decode_step_kernels_agree(dev, option):
     plain launch chain (bf16: scores to 2 %)"""
     from emoasr_amd import lib
     from emoasr_amd.modeling.lm import LM
+    if option in ("decode_wg", "decode_fused") and not lib.experimental():
+        pytest.skip("measured-slower variant: only in a library built with EMOASR_EXPERIMENTAL=1")
     model, g = _build(torch.bfloat16, dev)
     model.eval()
     lm = LM(SimpleNamespace(**LM_CFG), compute_dtype=torch.bfloat16)

@@ -358,8 +358,10 @@ def test_layernorm(dev, dtype, N, eps):
 @pytest.mark.parametrize("drop", [0.0, 0.1])
 @pytest.mark.parametrize("M,F", [(333, 1024), (64, 256), (7029, 1024)])
 def test_ffn_fwd_fused_is_bit_identical_to_layernorm_plus_two_gemms(dev, M, F, drop, act):
-    """csrc/ffn.hip keeps every accumulation order and every rounding point of the unfused path"""
-    from emoasr_amd import ops
+    """csrc/experimental/ffn.hip keeps every accumulation order and every rounding point of the unfused path"""
+    from emoasr_amd import lib, ops
+    if not lib.experimental():
+        pytest.skip("measured-slower variant: only in a library built with EMOASR_EXPERIMENTAL=1")
     d, dt_ = 256, torch.bfloat16
     A = ops.ACT_SWISH if act == "swish" else ops.ACT_RELU
     x = _rnd(dev, M, d, dtype=dt_)
