@@ -845,6 +845,7 @@ bool plan_ok(int N, int K) {
 
 }  // namespace
 
+static long g_coop_launches[2] = {0, 0};
 void emo_decode_set_coop(int v) { g_decode_coop = v; }
 void emo_decode_set_coop_merge(int v) { g_coop_merge = v; }
 
@@ -887,6 +888,7 @@ int emo_bert_lm_step_coop(int nl, const emoasr_bert_layer_t* layers, const emoas
   if ((g_coop_merge & 2) && qkv_merge_ok(a.d, a.H)) lm_step_coop_kernel<true><<<CG, CT, 0, s>>>(a);
   else lm_step_coop_kernel<false><<<CG, CT, 0, s>>>(a);
   EMO_LAUNCH_CHECK();
+  ++g_coop_launches[1];
 #ifdef EMO_COOP_STAMP
   {  // debug builds: the first (eager) launch's stamps of workgroup 0: mean ticks from the previous stamp, by stamp id
     static int calls = 0;
@@ -924,8 +926,13 @@ int emo_transformer_decoder_step_coop(int nl, const emoasr_decoder_layer_t* laye
   if ((g_coop_merge & 1) && qkv_merge_ok(a.d, a.H)) dec_step_coop_kernel<true><<<CG, CT, 0, s>>>(a);
   else dec_step_coop_kernel<false><<<CG, CT, 0, s>>>(a);
   EMO_LAUNCH_CHECK();
+  ++g_coop_launches[0];
   return 0;
 }
+
+// how many times the cooperative kernels were enqueued or captured into a graph (chain 0 decoder, 1 LM) since the library was
+// loaded: lets a test assert that a search really took this path
+extern "C" long emoasr_decode_coop_launches(int chain) { return chain == 0 || chain == 1 ? g_coop_launches[chain] : -1; }
 
 // error flag of the barriers (a wait that gave up): 0 = fine.  Synchronises the device.
 extern "C" long emoasr_decode_coop_status(void) {

@@ -4,6 +4,7 @@
 // Reference: ConformerEncoderLayer.forward, asr/modeling/conformer.py:146-225 (macaron FFN, rel-pos
 // MHA, convolution module, FFN, final LayerNorm; residual scales 0.5 / 1 / 1 / 0.5).
 #include <math.h>
+#include <algorithm>
 #include "common.h"
 #include "../../include/emoasr_hip.h"
 
@@ -42,6 +43,35 @@ int ffn_fwd(int dtype, int M, int d, int F, const emoasr_ffn_params_t& p, const 
   return emoasr_gemm_nt(dtype, M, d, F, st.a, F, p.w2, F, st.y, d, &e2, stream);
 }
 
+// The stacked micro-batches of a call (include/emoasr_hip.h: emoasr_segments_t) with their offsets: first row, first row of
+// the relative-position table, first utterance, first float of the BatchNorm partial-sum area.
+struct SegView {
+  int n = 0, Btot = 0;
+  int B[EMOASR_MAX_SEGMENTS], T[EMOASR_MAX_SEGMENTS], b0[EMOASR_MAX_SEGMENTS];
+  long row[EMOASR_MAX_SEGMENTS + 1], prow[EMOASR_MAX_SEGMENTS + 1], part[EMOASR_MAX_SEGMENTS + 1];
+  long M() const { return row[n]; }
+  long R() const { return prow[n]; }
+};
+
+bool seg_view(const emoasr_conformer_fwd_t* io, int d, SegView* v) {
+  const emoasr_segments_t& s = io->seg;
+  if (s.n < 0 || s.n > EMOASR_MAX_SEGMENTS) return false;
+  v->n = s.n > 0 ? s.n : 1;
+  v->row[0] = v->prow[0] = v->part[0] = 0;
+  v->Btot = 0;
+  for (int i = 0; i < v->n; ++i) {
+    v->B[i] = s.n > 0 ? s.B[i] : io->B;
+    v->T[i] = s.n > 0 ? s.T[i] : io->T;
+    if (v->B[i] <= 0 || v->T[i] <= 0) return false;
+    v->b0[i] = v->Btot;
+    v->Btot += v->B[i];
+    v->row[i + 1] = v->row[i] + (long)v->B[i] * v->T[i];
+    v->prow[i + 1] = v->prow[i] + 2L * v->T[i] - 1;
+    v->part[i + 1] = v->part[i] + emoasr_dwconv_stats_floats(v->B[i], v->T[i], d);
+  }
+  return true;
+}
+
 }  // namespace
 
 void emo_layer_set_ffn_fused(int v) { g_ffn_fused = v; }
@@ -50,8 +80,11 @@ void emo_layer_set_conv_fused(int v) { g_conv_fused = v; }
 extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* L,
                                           const emoasr_conformer_fwd_t* io, void* stream) {
   EMO_CHECK(L && io && io->x && io->pos_t, "conformer_layer_fwd: missing arguments");
-  const int d = L->d, H = L->H, F = L->F, B = io->B, T = io->T, M = B * T;
-  EMO_CHECK(d > 0 && H > 0 && d % H == 0 && M > 0, "conformer_layer_fwd: bad dims d=%d H=%d B=%d T=%d", d, H, B, T);
+  const int d = L->d, H = L->H, F = L->F;
+  EMO_CHECK(d > 0 && H > 0 && d % H == 0, "conformer_layer_fwd: bad dims d=%d H=%d", d, H);
+  SegView sv;
+  EMO_CHECK(seg_view(io, d, &sv), "conformer_layer_fwd: bad batch / segment shapes (B=%d T=%d segments=%d)", io->B, io->T, io->seg.n);
+  const int M = (int)sv.M(), R = (int)sv.R();
   const size_t esz = dtype == EMO_BF16 ? 2 : 4;
   const float p_enc = io->p_enc;
   // ---- macaron feed-forward ---------------------------------------------------------------------
@@ -65,17 +98,23 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
     e.bias = L->bqkv;
     if (emoasr_gemm_nt(dtype, M, 3 * d, d, io->at_h, d, L->wqkv, d, io->qkv, 3 * d, &e, stream)) return 1;
     emoasr_epilogue_t ep = plain_ep();
-    if (emoasr_gemm_nt(dtype, 2 * T - 1, d, d, io->pos_t, d, L->wpos, d, io->pp, d, &ep, stream)) return 1;
-    emoasr_attn_t a{};
-    a.B = B; a.H = H; a.DK = d / H; a.Tq = T; a.Tk = T;
-    a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d; a.ldp = d;
-    a.q = io->qkv;
-    a.k = (const char*)io->qkv + (size_t)d * esz;
-    a.v = (const char*)io->qkv + (size_t)2 * d * esz;
-    a.pos = io->pp; a.bias_u = L->bias_u; a.bias_v = L->bias_v; a.klens = io->klens;
-    a.causal = 0; a.scale = 1.f / sqrtf((float)(d / H)); a.drop_p = io->p_att; a.seed = io->seed[2];
-    a.out = io->o; a.lse = io->lse;
-    if (emoasr_attn_fwd(dtype, &a, stream)) return 1;
+    if (emoasr_gemm_nt(dtype, R, d, d, io->pos_t, d, L->wpos, d, io->pp, d, &ep, stream)) return 1;
+    for (int si = 0; si < sv.n; ++si) {   // attention is per utterance: one launch per stacked micro-batch
+      const size_t ro = (size_t)sv.row[si];
+      const char* qkv = (const char*)io->qkv + ro * 3 * d * esz;
+      emoasr_attn_t a{};
+      a.B = sv.B[si]; a.H = H; a.DK = d / H; a.Tq = sv.T[si]; a.Tk = sv.T[si];
+      a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d; a.ldp = d;
+      a.q = qkv;
+      a.k = qkv + (size_t)d * esz;
+      a.v = qkv + (size_t)2 * d * esz;
+      a.pos = (const char*)io->pp + (size_t)sv.prow[si] * d * esz;
+      a.bias_u = L->bias_u; a.bias_v = L->bias_v; a.klens = io->klens ? io->klens + sv.b0[si] : nullptr;
+      a.causal = 0; a.scale = 1.f / sqrtf((float)(d / H)); a.drop_p = io->p_att;
+      a.seed = io->seed[2] + 0x9E3779B97F4A7C15ull * (uint64_t)si;   // (the mask index restarts in every segment)
+      a.out = (char*)io->o + ro * d * esz; a.lse = io->lse + ro * H;
+      if (emoasr_attn_fwd(dtype, &a, stream)) return 1;
+    }
     emoasr_epilogue_t eo = plain_ep();
     eo.bias = L->bout; eo.residual = x1; eo.ldr = d; eo.drop_p = p_enc; eo.seed = io->seed[3];
     if (emoasr_gemm_nt(dtype, M, d, d, io->o, d, L->wout, d, io->at_y, d, &eo, stream)) return 1;
@@ -91,23 +130,33 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
     // bf16: GLU + depthwise convolution (+ BatchNorm partial statistics) in one launch, the GLU output never stored
     const bool fused = conv_fused_ok(dtype, d);
     if (!fused && emoasr_glu_fwd(dtype, M, d, io->g, io->gl, stream)) return 1;
-    const float *bmean = L->bn_rm, *bvar = L->bn_rv;
-    if (io->training) {
-      EMO_CHECK(io->bn_part && io->bmean && io->bvar, "conformer_layer_fwd: training needs the BatchNorm buffers");
-      if (fused) {
-        if (emoasr_glu_dwconv_fwd(dtype, B, T, d, L->K, io->g, L->dw_w, L->dw_b, io->c, io->bn_part, stream)) return 1;
-      } else if (emoasr_dwconv_fwd_stats(dtype, B, T, d, L->K, io->gl, L->dw_w, L->dw_b, io->c, io->bn_part, stream)) {
+    if (io->training) EMO_CHECK(io->bn_part && io->bmean && io->bvar, "conformer_layer_fwd: training needs the BatchNorm buffers");
+    for (int si = 0; si < sv.n; ++si) {   // each micro-batch: its own zero padding, its own batch statistics
+      const size_t ro = (size_t)sv.row[si];
+      const int B = sv.B[si], T = sv.T[si];
+      const char* g = (const char*)io->g + ro * 2 * d * esz;
+      const char* gl = io->gl ? (const char*)io->gl + ro * d * esz : nullptr;
+      char* c = (char*)io->c + ro * d * esz;
+      const float *bmean = L->bn_rm, *bvar = L->bn_rv;
+      if (io->training) {
+        float* part = io->bn_part + sv.part[si];
+        if (fused) {
+          if (emoasr_glu_dwconv_fwd(dtype, B, T, d, L->K, g, L->dw_w, L->dw_b, c, part, stream)) return 1;
+        } else if (emoasr_dwconv_fwd_stats(dtype, B, T, d, L->K, gl, L->dw_w, L->dw_b, c, part, stream)) {
+          return 1;
+        }
+        // (the running statistics move once per micro-batch, in order, as in the separate passes)
+        if (emoasr_bn_stats_finalize(B, T, d, part, io->bmean + (size_t)si * d, io->bvar + (size_t)si * d, L->bn_rm, L->bn_rv, 0.1f,
+                                     L->bn_nbt, stream))
+          return 1;
+        bmean = io->bmean + (size_t)si * d; bvar = io->bvar + (size_t)si * d;
+      } else if (fused) {
+        if (emoasr_glu_dwconv_fwd(dtype, B, T, d, L->K, g, L->dw_w, L->dw_b, c, nullptr, stream)) return 1;
+      } else if (emoasr_dwconv_fwd(dtype, B, T, d, L->K, gl, L->dw_w, L->dw_b, c, stream)) {
         return 1;
       }
-      if (emoasr_bn_stats_finalize(B, T, d, io->bn_part, io->bmean, io->bvar, L->bn_rm, L->bn_rv, 0.1f, L->bn_nbt, stream))
-        return 1;
-      bmean = io->bmean; bvar = io->bvar;
-    } else if (fused) {
-      if (emoasr_glu_dwconv_fwd(dtype, B, T, d, L->K, io->g, L->dw_w, L->dw_b, io->c, nullptr, stream)) return 1;
-    } else if (emoasr_dwconv_fwd(dtype, B, T, d, L->K, io->gl, L->dw_w, L->dw_b, io->c, stream)) {
-      return 1;
+      if (emoasr_bn_swish_fwd(dtype, B * T, d, c, bmean, bvar, L->bn_g, L->bn_b, 1e-5f, (char*)io->z + ro * d * esz, stream)) return 1;
     }
-    if (emoasr_bn_swish_fwd(dtype, M, d, io->c, bmean, bvar, L->bn_g, L->bn_b, 1e-5f, io->z, stream)) return 1;
     emoasr_epilogue_t eo = plain_ep();
     eo.bias = L->pw2_b; eo.residual = x2; eo.ldr = d; eo.drop_p = p_enc; eo.seed = io->seed[4];
     if (emoasr_gemm_nt(dtype, M, d, d, io->z, d, L->pw2, d, io->cv_y, d, &eo, stream)) return 1;
@@ -137,8 +186,8 @@ struct BwdBufs {
   size_t dpos, delta, bn_scr, dw_scr, attn_ws, attn_ws_bytes, total;
 };
 
-BwdBufs bwd_layout(int dtype, int B, int T, int d, int H, int F, int K) {
-  const size_t esz = dtype == EMO_BF16 ? 2 : 4, M = (size_t)B * T, R = 2 * (size_t)T - 1;
+BwdBufs bwd_layout(int dtype, const SegView& sv, int d, int H, int F, int K) {
+  const size_t esz = dtype == EMO_BF16 ? 2 : 4, M = (size_t)sv.M(), R = (size_t)sv.R();
   BwdLayout L;
   BwdBufs b{};
   b.dx1 = L.take(M * d * esz); b.dx2 = L.take(M * d * esz); b.dx3 = L.take(M * d * esz); b.dx4 = L.take(M * d * esz);
@@ -147,10 +196,17 @@ BwdBufs bwd_layout(int dtype, int B, int T, int d, int H, int F, int K) {
   b.du_ff = L.take(M * F * esz); b.du_ffm = L.take(M * F * esz);
   b.dz = L.take(M * d * esz); b.dc = L.take(M * d * esz); b.dgl = L.take(M * d * esz); b.dg = L.take(M * 2 * d * esz);
   b.dout = L.take(M * d * esz); b.dqkv = L.take(M * 3 * d * esz); b.dpos_t = L.take(R * d * esz);
-  b.dpos = L.take(R * d * 4); b.delta = L.take((size_t)B * H * T * 4);
-  b.bn_scr = L.take((size_t)emoasr_bn_swish_bwd_scratch_floats((int)M, d) * 4);
-  b.dw_scr = L.take((size_t)emoasr_dwconv_bwd_w_scratch_floats(B, T, d, K) * 4);
-  b.attn_ws_bytes = emoasr_attn_bwd_fused_ws_bytes(dtype, B, H, T, T, 1);
+  b.dpos = L.take(R * d * 4); b.delta = L.take(M * H * 4);
+  // per-segment scratch is reused by the segments one after the other: sized for the largest
+  size_t bn_scr = 0, dw_scr = 0, attn_ws = 0;
+  for (int i = 0; i < sv.n; ++i) {
+    bn_scr = std::max(bn_scr, (size_t)emoasr_bn_swish_bwd_scratch_floats(sv.B[i] * sv.T[i], d) * 4);
+    dw_scr = std::max(dw_scr, (size_t)emoasr_dwconv_bwd_w_scratch_floats(sv.B[i], sv.T[i], d, K) * 4);
+    attn_ws = std::max(attn_ws, emoasr_attn_bwd_fused_ws_bytes(dtype, sv.B[i], H, sv.T[i], sv.T[i], 1));
+  }
+  b.bn_scr = L.take(bn_scr);
+  b.dw_scr = L.take(dw_scr);
+  b.attn_ws_bytes = attn_ws;
   b.attn_ws = L.take(b.attn_ws_bytes);
   b.total = L.off;
   return b;
@@ -158,16 +214,30 @@ BwdBufs bwd_layout(int dtype, int B, int T, int d, int H, int F, int K) {
 
 }  // namespace
 
+extern "C" size_t emoasr_conformer_layer_bwd_ws_bytes_seg(int dtype, const emoasr_segments_t* seg, int d, int H, int F, int K) {
+  emoasr_conformer_fwd_t io{};
+  if (!seg) return 0;
+  io.seg = *seg;
+  SegView sv;
+  if (seg->n < 1 || !seg_view(&io, d, &sv)) return 0;
+  return bwd_layout(dtype, sv, d, H, F, K).total;
+}
+
 extern "C" size_t emoasr_conformer_layer_bwd_ws_bytes(int dtype, int B, int T, int d, int H, int F, int K) {
-  return bwd_layout(dtype, B, T, d, H, F, K).total;
+  emoasr_segments_t seg{};
+  seg.n = 1; seg.B[0] = B; seg.T[0] = T;
+  return emoasr_conformer_layer_bwd_ws_bytes_seg(dtype, &seg, d, H, F, K);
 }
 
 extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_layer_t* L, const emoasr_conformer_layer_t* G,
                                           const emoasr_conformer_fwd_t* st, const emoasr_conformer_bwd_t* io, void* stream) {
   EMO_CHECK(L && G && st && io && io->dy && io->dx && io->ws && io->ln_part, "conformer_layer_bwd: missing arguments");
   EMO_CHECK(dtype == EMO_BF16, "conformer_layer_bwd: bf16 only (f32 is sequenced by the host)");
-  const int d = L->d, H = L->H, F = L->F, K = L->K, B = st->B, T = st->T, M = B * T, R = 2 * T - 1;
-  const BwdBufs bb = bwd_layout(dtype, B, T, d, H, F, K);
+  const int d = L->d, H = L->H, F = L->F, K = L->K;
+  SegView sv;
+  EMO_CHECK(seg_view(st, d, &sv), "conformer_layer_bwd: bad batch / segment shapes");
+  const int M = (int)sv.M(), R = (int)sv.R();
+  const BwdBufs bb = bwd_layout(dtype, sv, d, H, F, K);
   EMO_CHECK(io->ws_bytes >= bb.total, "conformer_layer_bwd: workspace %zu < %zu bytes", io->ws_bytes, bb.total);
   char* ws = static_cast<char*>(io->ws);
   const size_t esz = 2;
@@ -218,17 +288,29 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     if (conv_fused_ok(dtype, d)) {
       // BatchNorm sums + fold, then ONE launch for BatchNorm/Swish apply -> depthwise data gradient -> GLU backward and the
       // depthwise weight-gradient partials (the GLU output is recomputed from g)
-      float* tot = nullptr;
-      if (emoasr_bn_swish_bwd_sums(dtype, M, d, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f,
-                                   (float*)G->bn_g, (float*)G->bn_b, (float*)(ws + bb.bn_scr), &tot, stream)) return 1;
-      if (emoasr_conv_bwd_fused(dtype, B, T, d, K, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f, tot, st->g,
-                                L->dw_w, ws + bb.dg, (float*)G->dw_w, (float*)G->dw_b, (float*)(ws + bb.dw_scr), stream)) return 1;
+      for (int si = 0; si < sv.n; ++si) {   // per micro-batch: its own batch statistics and zero padding; scratch reused in order
+        const size_t ro = (size_t)sv.row[si];
+        const float *bmean = st->bmean + (size_t)si * d, *bvar = st->bvar + (size_t)si * d;
+        const char* c = (const char*)st->c + ro * d * esz;
+        float* tot = nullptr;
+        if (emoasr_bn_swish_bwd_sums(dtype, sv.B[si] * sv.T[si], d, ws + bb.dz + ro * d * esz, c, bmean, bvar, L->bn_g, L->bn_b, 1e-5f,
+                                     (float*)G->bn_g, (float*)G->bn_b, (float*)(ws + bb.bn_scr), &tot, stream)) return 1;
+        if (emoasr_conv_bwd_fused(dtype, sv.B[si], sv.T[si], d, K, ws + bb.dz + ro * d * esz, c, bmean, bvar, L->bn_g, L->bn_b, 1e-5f,
+                                  tot, (const char*)st->g + ro * 2 * d * esz, L->dw_w, ws + bb.dg + ro * 2 * d * esz, (float*)G->dw_w,
+                                  (float*)G->dw_b, (float*)(ws + bb.dw_scr), stream)) return 1;
+      }
     } else {
-      if (emoasr_bn_swish_bwd(dtype, M, d, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f, ws + bb.dc,
-                              (float*)G->bn_g, (float*)G->bn_b, (float*)(ws + bb.bn_scr), stream)) return 1;
-      if (emoasr_dwconv_bwd_x(dtype, B, T, d, K, ws + bb.dc, L->dw_w, ws + bb.dgl, stream)) return 1;
-      if (emoasr_dwconv_bwd_w(dtype, B, T, d, K, ws + bb.dc, st->gl, (float*)G->dw_w, (float*)G->dw_b, 1,
-                              (float*)(ws + bb.dw_scr), stream)) return 1;
+      for (int si = 0; si < sv.n; ++si) {
+        const size_t ro = (size_t)sv.row[si];
+        const int B = sv.B[si], T = sv.T[si];
+        const float *bmean = st->bmean + (size_t)si * d, *bvar = st->bvar + (size_t)si * d;
+        if (emoasr_bn_swish_bwd(dtype, B * T, d, ws + bb.dz + ro * d * esz, (const char*)st->c + ro * d * esz, bmean, bvar, L->bn_g,
+                                L->bn_b, 1e-5f, ws + bb.dc + ro * d * esz, (float*)G->bn_g, (float*)G->bn_b,
+                                (float*)(ws + bb.bn_scr), stream)) return 1;
+        if (emoasr_dwconv_bwd_x(dtype, B, T, d, K, ws + bb.dc + ro * d * esz, L->dw_w, ws + bb.dgl + ro * d * esz, stream)) return 1;
+        if (emoasr_dwconv_bwd_w(dtype, B, T, d, K, ws + bb.dc + ro * d * esz, (const char*)st->gl + ro * d * esz, (float*)G->dw_w,
+                                (float*)G->dw_b, 1, (float*)(ws + bb.dw_scr), stream)) return 1;
+      }
       if (emoasr_glu_bwd(dtype, M, d, st->g, ws + bb.dgl, ws + bb.dg, stream)) return 1;
     }
     wgrad(ws + bb.dg, 2 * d, 2 * d, st->cv_h, d, d, M, G->pw1, 1.f, G->pw1_b);
@@ -242,22 +324,31 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     wgrad(dy, d, d, st->o, d, d, M, G->wout, 1.f, G->bout);
     emoasr_epilogue_t e = plain_ep();
     if (emoasr_gemm_nn(dtype, M, d, d, dy, d, L->wout, d, ws + bb.dout, d, &e, stream)) return 1;
-    emoasr_attn_t a{};
-    a.B = B; a.H = H; a.DK = d / H; a.Tq = T; a.Tk = T;
-    a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d; a.ldp = d;
-    a.q = st->qkv;
-    a.k = (const char*)st->qkv + (size_t)d * esz;
-    a.v = (const char*)st->qkv + (size_t)2 * d * esz;
-    a.pos = st->pp; a.bias_u = L->bias_u; a.bias_v = L->bias_v; a.klens = st->klens;
-    a.causal = 0; a.scale = 1.f / sqrtf((float)(d / H)); a.drop_p = st->p_att; a.seed = st->seed[2];
-    a.out = st->o; a.lse = st->lse;
-    a.dout = ws + bb.dout; a.delta = (float*)(ws + bb.delta);
-    a.dq = ws + bb.dqkv; a.dk = ws + bb.dqkv + (size_t)d * esz; a.dv = ws + bb.dqkv + (size_t)2 * d * esz;
-    a.dpos = (float*)(ws + bb.dpos); a.dbias_u = (float*)G->bias_u; a.dbias_v = (float*)G->bias_v;
-    // the position-table gradient is cleared by the attention backward's prologue launch and rounded to the compute dtype
-    // by its finalize launch (two launches less per layer than a memset + a cast)
-    emo_attn_bwd_fused_extras((float*)(ws + bb.dpos), (long)R * d, (const float*)(ws + bb.dpos), ws + bb.dpos_t, (long)R * d);
-    if (emoasr_attn_bwd_fused(dtype, &a, ws + bb.attn_ws, bb.attn_ws_bytes, stream)) return 1;
+    for (int si = 0; si < sv.n; ++si) {   // per micro-batch (the fused kernel's workspace is reused in order)
+      const size_t ro = (size_t)sv.row[si], po = (size_t)sv.prow[si];
+      const long Rs = 2L * sv.T[si] - 1;
+      const char* qkv = (const char*)st->qkv + ro * 3 * d * esz;
+      char* dqkv = ws + bb.dqkv + ro * 3 * d * esz;
+      emoasr_attn_t a{};
+      a.B = sv.B[si]; a.H = H; a.DK = d / H; a.Tq = sv.T[si]; a.Tk = sv.T[si];
+      a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d; a.ldp = d;
+      a.q = qkv;
+      a.k = qkv + (size_t)d * esz;
+      a.v = qkv + (size_t)2 * d * esz;
+      a.pos = (const char*)st->pp + po * d * esz; a.bias_u = L->bias_u; a.bias_v = L->bias_v;
+      a.klens = st->klens ? st->klens + sv.b0[si] : nullptr;
+      a.causal = 0; a.scale = 1.f / sqrtf((float)(d / H)); a.drop_p = st->p_att;
+      a.seed = st->seed[2] + 0x9E3779B97F4A7C15ull * (uint64_t)si;   // (as the forward)
+      a.out = (char*)st->o + ro * d * esz; a.lse = st->lse + ro * H;
+      a.dout = ws + bb.dout + ro * d * esz; a.delta = (float*)(ws + bb.delta) + ro * H;
+      a.dq = dqkv; a.dk = dqkv + (size_t)d * esz; a.dv = dqkv + (size_t)2 * d * esz;
+      float* dpos = (float*)(ws + bb.dpos) + po * d;
+      a.dpos = dpos; a.dbias_u = (float*)G->bias_u; a.dbias_v = (float*)G->bias_v;
+      // the position-table gradient is cleared by the attention backward's prologue launch and rounded to the compute dtype
+      // by its finalize launch (two launches less per layer than a memset + a cast)
+      emo_attn_bwd_fused_extras(dpos, Rs * d, dpos, ws + bb.dpos_t + po * d * esz, Rs * d);
+      if (emoasr_attn_bwd_fused(dtype, &a, ws + bb.attn_ws, bb.attn_ws_bytes, stream)) return 1;
+    }
     wgrad(ws + bb.dpos_t, d, d, st->pos_t, d, d, R, G->wpos, 1.f, nullptr);
     wgrad(ws + bb.dqkv, 3 * d, 3 * d, st->at_h, d, d, M, G->wqkv, 1.f, G->bqkv);
     if (emoasr_gemm_nn(dtype, M, d, 3 * d, ws + bb.dqkv, 3 * d, L->wqkv, d, ws + bb.dh, d, &e, stream)) return 1;

@@ -7,8 +7,13 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(long n, const float* __restrict__ x, float* out) {
+// Bit-reproducible: every block leaves its partial in `part`, the block that arrives last (a ticket counter) adds them up in block
+// order.  Data-parallel replicas clip by this norm: with per-block float atomics on `out` two ranks holding the SAME reduced
+// gradient got norms that differed in the last bits, and their parameters drifted apart (tests/test_00_dp_two_process_gpu.py).
+__global__ __launch_bounds__(256) void sqnorm_kernel(long n, const float* __restrict__ x, float* out, float* __restrict__ part,
+                                                     unsigned* __restrict__ ticket) {
   __shared__ float red[16];
+  __shared__ int s_last;
   float s = 0.f;
   const long n4 = n / 4;
   // four independent 16-byte loads in flight per thread (one per iteration left the kernel latency-bound
@@ -28,7 +33,22 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(long n, const float* __rest
   if (blockIdx.x == 0)
     for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += x[i] * x[i];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = s;
+    __threadfence();
+    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  float t = 0.f;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();   // (red is reused)
+  t = block_sum(t, red);
+  if (threadIdx.x == 0) {
+    *out += t;
+    *ticket = 0u;
+  }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g,
@@ -66,8 +86,14 @@ inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 4096 ? 4
 extern "C" int emoasr_sqnorm(long n, const float* x, float* out, void* stream) {
   if (n == 0) return 0;
   EMO_CHECK(((uintptr_t)x & 15) == 0, "sqnorm: buffer must be 16-byte aligned");
-  // at most 1024 blocks: every block ends in one f32 atomic on the same address (8192 of them cost more than the read)
-  sqnorm_kernel<<<std::min(ew_grid(n / 4 + 1), 1024), 256, 0, (hipStream_t)stream>>>(n, x, out);
+  // at most 1024 blocks, each leaving one partial sum; calls are stream-ordered (one scratch per process)
+  static float* scratch = nullptr;
+  if (!scratch) {
+    EMO_CHECK(hipMalloc(&scratch, 1025 * sizeof(float)) == hipSuccess && hipMemset(scratch, 0, 1025 * sizeof(float)) == hipSuccess,
+              "sqnorm: scratch allocation failed");
+  }
+  sqnorm_kernel<<<std::min(ew_grid(n / 4 + 1), 1024), 256, 0, (hipStream_t)stream>>>(n, x, out, scratch,
+                                                                                     reinterpret_cast<unsigned*>(scratch + 1024));
   EMO_LAUNCH_CHECK();
   return 0;
 }

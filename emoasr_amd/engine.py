@@ -492,6 +492,155 @@ class CTCEngine(_DecoderMixinPlaceholder):
         best, hyp, hyplen = ops.ctc_greedy(logits, elens, blank)
         return best, hyp, hyplen
 
+    # ------------------------------------------------------------------ stacked micro-batches
+    def stacked_ok(self):
+        """can ctc_train_stacked take this model?  (bf16 relative-position Conformer + plain CTC head, the layer runtime and
+        the single-pass attention backward on, no intermediate / distillation branches)"""
+        cfg = self.cfg
+        return (self.conformer and self.rel and self.dtype == torch.bfloat16 and self._cpp_layers and self.attn_fused
+                and not self.attn_store_scores and not self._side_wgrads and self.inter_layer == 0
+                and _cfg(cfg, "decoder_type", "ctc") == "ctc" and not (_cfg(cfg, "kd_weight", 0) or 0) > 0
+                and os.environ.get("EMOASR_CPP_BWD", "1") != "0" and self._implicit_dgrad and self._conv_big
+                and self.d % 256 == 0 and os.environ.get("EMOASR_STACKED", "1") != "0")
+
+    def ctc_train_stacked(self, batches, blank, scales=None, head="decoder.output"):
+        """Forward + CTC loss + backward of several micro-batches in ONE stacked pass (asr/train_asr.py:106-128 runs them one
+        after the other and sums their gradients: `accum_grad`).  Rows of all micro-batches are concatenated for every row-wise
+        kernel (Linear / LayerNorm / pointwise convolutions / vocabulary head); attention, the depthwise convolution's padding
+        and the BatchNorm statistics stay per micro-batch (include/emoasr_hip.h: emoasr_segments_t), so the result is the sum
+        of the separate passes' gradients up to summation order.
+
+        batches: [(xs f32 [B,T,F] on the device, xlens, ys (host int tensor [B,L]), ylens), ...] (at most lib.MAX_SEGMENTS)
+        scales:  weight of every micro-batch's loss in the gradient (default 1 / len(batches) = loss / accum_grad)
+        -> losses f32 [n] (device): loss_s = sum_b nll_b / B_s, infeasible utterances zeroed, as nn.CTCLoss(zero_infinity)
+        Parameter gradients are ACCUMULATED into the gradient arena (p.grad)."""
+        assert self.stacked_ok(), "ctc_train_stacked: unsupported configuration (see stacked_ok)"
+        self._defer_wgrads = self._group_wgrads
+        try:
+            with ops.stream_scope():
+                return self._ctc_train_stacked(batches, blank, scales, head)
+        finally:
+            self._defer_wgrads = False
+            self._wq = []
+            self._ln_deferred = []
+
+    def _ctc_train_stacked(self, batches, blank, scales, head):
+        from . import lib
+        self.ensure_bound()
+        A, d, dt = self.arena, self.d, self.dtype
+        A.refresh_shadow()
+        A.attach_grads()
+        self.step_count += 1
+        self._keep = True
+        n = len(batches)
+        assert 1 <= n <= lib.MAX_SEGMENTS
+        scales = [1.0 / n] * n if scales is None else [float(v) for v in scales]
+        dev = batches[0][0].device
+        p_enc, p_att = self.p_enc, self.p_att
+        pre = "encoder.conv."
+        C = d
+        # ---- Conv2d subsampling per micro-batch (its own padded length), outputs stacked row-wise ----------------
+        w1 = A.p(pre + "conv.0.weight").view(C, 9)
+        w2r = ops.strided_copy(A.p(pre + "conv.2.weight").permute(0, 2, 3, 1), out_dtype=dt).view(C, 9 * C)
+        y1s, segs, xlens_all = [], [], []
+        for xs, xlens, _, _ in batches:
+            B, T, Fd = xs.shape
+            T1, F1 = (T - 3) // 2 + 1, (Fd - 3) // 2 + 1
+            T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+            segs.append((B, T2))
+            xlens_all += [int(v) for v in xlens]
+        rows = [0]
+        for b, t in segs:
+            rows.append(rows[-1] + b * t)
+        M = rows[-1]
+        y2 = torch.empty(M, F2 * C, device=dev, dtype=dt)
+        for k, (xs, _, _, _) in enumerate(batches):
+            y1 = ops.conv1_fwd(xs, w1, A.p(pre + "conv.0.bias"), dt)
+            ops.conv2_fwd(y1, w2r, out=y2[rows[k]:rows[k + 1]], bias=A.p(pre + "conv.2.bias"), act=ACT_RELU)
+            y1s.append(y1)
+        wl = A.p(pre + "output.weight")  # [d, C*F2] channel-major -> [d, F2*C]
+        wlr = ops.strided_copy(wl.view(d, C, F2).permute(0, 2, 1), out_dtype=dt).view(d, F2 * C)
+        x = ops.gemm_nt(y2, wlr, bias=A.p(pre + "output.bias"))
+        elens_host = [((v - 1) // 2 - 1) // 2 for v in xlens_all]
+        elens = h2d_i32(elens_host, dev)
+        s_pe = self._seed(1)
+        x = ops.posenc(x.view(1, M, d), None, math.sqrt(d), p_enc, s_pe).view(M, d)
+        # every micro-batch has its own relative-position table (rows <-> rel = T-1 ... -(T-1)), dropped out independently
+        tab = torch.cat([self._pos_table(t, dev) for _, t in segs], 0)
+        pos_t = ops.strided_copy(tab, out_dtype=dt)
+        if p_enc > 0:
+            pos_t = ops.scale_dropout(pos_t, 1.0, p_enc, self._seed(2))
+        # ---- encoder layers: one C-ABI call each over the stacked rows ------------------------------------------------
+        if self._layer_rt is None:
+            from .layer_rt import ConformerLayerRuntime
+            self._layer_rt = ConformerLayerRuntime(self)
+        Btot, Tmax = sum(b for b, _ in segs), max(t for _, t in segs)
+        cur, layers = x, []
+        for li in range(self.nl):
+            cur = self._layer_rt.forward(li, cur, Btot, Tmax, elens, pos_t, p_enc, p_att, True, True, segs=tuple(segs))
+            layers.append(cur)
+        x_final = cur.tv("y")
+        eouts, fin_mean, fin_rstd = ops.layernorm_fwd(x_final, A.p("encoder.norm.weight"), A.p("encoder.norm.bias"), 1e-12, True)
+        # ---- vocabulary head over all rows; CTC lattices per micro-batch -----------------------------------------------
+        w = A.w(head + ".weight")
+        V = w.shape[0]
+        assert V % 8 == 0, "ctc_train_stacked: vocabulary must be a multiple of 8"
+        logits = ops.gemm_nt(eouts, w, bias=A.p(head + ".bias"))
+        lse = ops.row_lse(logits)
+        dlogits = torch.empty_like(logits)
+        losses = []
+        b0 = 0
+        for k, (_, _, ys, ylens) in enumerate(batches):
+            B, T2 = segs[k]
+            ylens_h = [int(v) for v in ylens]
+            Lmax = max(max(ylens_h), 1)
+            labels = torch.as_tensor(ys)[:, :Lmax].to(torch.int32)
+            if labels.shape[1] < Lmax:
+                labels = torch.nn.functional.pad(labels, (0, Lmax - labels.shape[1]))
+            labels = h2d_i32(labels.contiguous(), dev)
+            yl = h2d_i32(ylens_h, dev)
+            el = elens[b0:b0 + B]
+            lg = logits[rows[k]:rows[k + 1]].view(B, T2, V)
+            lp, alpha, beta, nll = ops.ctc_forward(lg, lse[rows[k]:rows[k + 1]], labels, el, yl, blank)
+            losses.append(torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll)).sum() / B)
+            ops.ctc_grad(lg, lse[rows[k]:rows[k + 1]], labels, el, yl, blank, lp, alpha, beta, nll, scales[k] / B,
+                         out=dlogits[rows[k]:rows[k + 1]].view(B, T2, V))
+            b0 += B
+        # ---- backward ------------------------------------------------------------------------------------------------
+        deouts = self._lin_bwd(dlogits, eouts, head + ".weight", head + ".bias")
+        if self.grad_hook is not None:   # the head's gradients are final
+            self._flush_wgrads()
+            self.grad_hook(A.offsets[head + ".weight"])
+        dx, _ = self._ln_bwd(deouts, x_final, "encoder.norm", fin_mean, fin_rstd, None, None)
+        lnf = ops.lib.size_query("emoasr_layernorm_bwd_scratch_floats", d)
+        ln_parts = torch.empty(self.nl, 5, lnf, device=dev, dtype=torch.float32)
+        dx_bufs = [torch.empty(M, d, device=dev, dtype=dt) for _ in range(2)]
+        for li in reversed(range(self.nl)):
+            out = dx_bufs[li & 1]
+            self._layer_rt.backward(li, layers[li], dx, out, ln_parts[li], self._ln_deferred)
+            dx = out
+            if self.grad_hook is not None:
+                self._flush_wgrads()
+                ops.layernorm_bwd_finalize(self._ln_deferred)
+                self.grad_hook(self._layer_offset(li))
+        self._flush_wgrads()
+        ops.layernorm_bwd_finalize(self._ln_deferred)
+        # positional scaling, Linear (all rows at once), then the two convolutions per micro-batch
+        dlin = ops.scale_dropout(dx, math.sqrt(d), p_enc, s_pe)
+        dwl = torch.zeros(d, F2 * C, device=dev, dtype=torch.float32)  # (f, c) order
+        ops.gemm_tn(dlin, y2, out=dwl, accumulate=True, colsum=A.g(pre + "output.bias"))
+        ops.strided_copy(dwl.view(d, F2, C).permute(0, 2, 1), out=A.g(pre + "output.weight").view(d, C, F2), accumulate=True)
+        dy2 = ops.gemm_nn(dlin, wlr, dact_pre=y2, dact=ACT_RELU)
+        dw2 = torch.zeros(C, 9 * C, device=dev, dtype=torch.float32)
+        wt = ops.strided_copy(A.p(pre + "conv.2.weight").permute(1, 2, 3, 0), out_dtype=dt).view(C, 9 * C)
+        for k, (xs, _, _, _) in enumerate(batches):
+            dy2_k = dy2[rows[k]:rows[k + 1]].view(-1, C)
+            ops.conv2_wgrad(dy2_k, y1s[k], dw2, dbias=A.g(pre + "conv.2.bias"), accumulate=True)
+            dy1 = ops.conv2_dgrad_kc(dy2_k, wt, y1s[k])
+            ops.conv1_wgrad(xs, dy1, A.g(pre + "conv.0.weight").view(C, 9), A.g(pre + "conv.0.bias"), accumulate=True)
+        ops.strided_copy(dw2.view(C, 3, 3, C).permute(0, 3, 1, 2), out=A.g(pre + "conv.2.weight"), accumulate=True)
+        return torch.stack(losses)
+
     # ------------------------------------------------------------------ backward
     def _lin_bwd(self, dy, x_in, wname, bname, alpha=1.0, **epi):
         """gradients of y = x_in @ W^T + b given dy (already including any dropout mask);

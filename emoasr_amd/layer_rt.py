@@ -19,16 +19,26 @@ def _round(n, a):
 
 
 class _Layout:
-    """offsets (in elements) of every forward intermediate of one layer for a (B, T) shape"""
+    """offsets (in elements) of every forward intermediate of one layer for a (B, T) shape, or for a tuple of stacked
+    micro-batches `segs` = ((B_0, T_0), (B_1, T_1), ...) whose rows are concatenated (emoasr_segments_t)"""
 
-    def __init__(self, B, T, d, H, F):
-        M, R = B * T, 2 * T - 1
+    def __init__(self, B, T, d, H, F, segs=None):
+        self.segs = segs
+        if segs is None:
+            M, R = B * T, 2 * T - 1
+            qkv_shape, o_shape, lse_shape, nstat = (B, T, 3 * d), (B, T, d), (B, H, T), 1
+            npart = lib.size_query("emoasr_dwconv_stats_floats", B, T, d)
+        else:
+            M, R = sum(b * t for b, t in segs), sum(2 * t - 1 for _, t in segs)
+            qkv_shape, o_shape, lse_shape, nstat = (M, 3 * d), (M, d), (H * M,), len(segs)
+            npart = sum(lib.size_query("emoasr_dwconv_stats_floats", b, t, d) for b, t in segs)
+        self.M, self.R = M, R
         t_fields = [("ffm_h", (M, d)), ("ffm_u", (M, F)), ("ffm_a", (M, F)), ("ffm_y", (M, d)),
-                    ("at_h", (M, d)), ("qkv", (B, T, 3 * d)), ("pp", (R, d)), ("o", (B, T, d)), ("at_y", (M, d)),
+                    ("at_h", (M, d)), ("qkv", qkv_shape), ("pp", (R, d)), ("o", o_shape), ("at_y", (M, d)),
                     ("cv_h", (M, d)), ("g", (M, 2 * d)), ("gl", (M, d)), ("c", (M, d)), ("z", (M, d)), ("cv_y", (M, d)),
                     ("ff_h", (M, d)), ("ff_u", (M, F)), ("ff_a", (M, F)), ("ff_y", (M, d)), ("y", (M, d))]
-        f_fields = [("ffm_mean", (M,)), ("ffm_rstd", (M,)), ("lse", (B, H, T)), ("at_mean", (M,)), ("at_rstd", (M,)),
-                    ("bmean", (d,)), ("bvar", (d,)), ("bn_part", (lib.size_query("emoasr_dwconv_stats_floats", B, T, d),)),
+        f_fields = [("ffm_mean", (M,)), ("ffm_rstd", (M,)), ("lse", lse_shape), ("at_mean", (M,)), ("at_rstd", (M,)),
+                    ("bmean", (nstat * d,)), ("bvar", (nstat * d,)), ("bn_part", (npart,)),
                     ("cv_mean", (M,)), ("cv_rstd", (M,)), ("ff_mean", (M,)), ("ff_rstd", (M,)),
                     ("fin_mean", (M,)), ("fin_rstd", (M,))]
         self.t, self.f = {}, {}
@@ -75,6 +85,8 @@ class LayerStash:
         return x
 
     def __iter__(self):
+        if self.lay.segs is not None:
+            raise RuntimeError("a stacked layer pass is differentiated by emoasr_conformer_layer_bwd only (no per-kernel path)")
         if self._tup is None:
             tv, fv, s = self.tv, self.fv, self.seeds
             x0 = self.input()
@@ -142,15 +154,18 @@ class ConformerLayerRuntime:
         self.params[li] = (L, guard)
         return L
 
-    def forward(self, li, x, B, T, elens, pos_t, p_enc, p_att, training, keep):
-        """x: tensor [B*T, d] or the previous layer's LayerStash.  -> LayerStash (its tv("y") is the output)"""
+    def forward(self, li, x, B, T, elens, pos_t, p_enc, p_att, training, keep, segs=None):
+        """x: tensor [B*T, d] or the previous layer's LayerStash.  -> LayerStash (its tv("y") is the output).
+        segs: ((B_0, T_0), ...) -- stacked micro-batches (x has sum B_s T_s rows, pos_t the segments' tables back to back,
+        elens all utterances in order); B / T are then the totals / maximum."""
         eng = self.eng
         L = self._layer_params(li)
-        lay = self.layouts.get((B, T))
+        key = (B, T) if segs is None else tuple(segs)
+        lay = self.layouts.get(key)
         if lay is None:
             if len(self.layouts) > 64:
                 self.layouts.clear()
-            lay = self.layouts[(B, T)] = _Layout(B, T, eng.d, eng.h, L.F)
+            lay = self.layouts[key] = _Layout(B, T, eng.d, eng.h, L.F, segs)
         dev = pos_t.device
         wt = torch.empty(lay.nt, device=dev, dtype=eng.dtype)
         wf = torch.empty(lay.nf, device=dev, dtype=torch.float32)
@@ -162,6 +177,11 @@ class ConformerLayerRuntime:
         t, f = lay.t, lay.f
         io = lib.ConformerFwd()
         io.B, io.T = B, T
+        if segs is not None:
+            assert len(segs) <= lib.MAX_SEGMENTS, f"at most {lib.MAX_SEGMENTS} stacked micro-batches"
+            io.seg.n = len(segs)
+            for k, (b, t) in enumerate(segs):
+                io.seg.B[k], io.seg.T[k] = b, t
         io.x = tb_prev(x, esz)
         io.pos_t, io.klens = pos_t.data_ptr(), elens.data_ptr()
         io.training, io.p_enc, io.p_att = int(training), p_enc, p_att
@@ -228,7 +248,10 @@ class ConformerLayerRuntime:
         eng, A = self.eng, self.eng.arena
         L, G = self._layer_params(li), self._layer_grads(li)
         B, T = st.B, st.T
-        nb = lib.size_query("emoasr_conformer_layer_bwd_ws_bytes", ops.dt(st.wt), B, T, eng.d, eng.h, L.F, L.K)
+        if st.lay.segs is None:
+            nb = lib.size_query("emoasr_conformer_layer_bwd_ws_bytes", ops.dt(st.wt), B, T, eng.d, eng.h, L.F, L.K)
+        else:
+            nb = lib.ws_bytes_seg(ops.dt(st.wt), st.io.seg, eng.d, eng.h, L.F, L.K)
         if self.bwd_ws is None or self.bwd_ws.numel() < nb:
             self.bwd_ws = torch.empty(int(nb * 1.1) + 256, device=dy.device, dtype=torch.uint8)
         io = lib.ConformerBwd()
@@ -238,7 +261,7 @@ class ConformerLayerRuntime:
         lib.call("emoasr_conformer_layer_bwd", ops.dt(st.wt), ctypes.byref(L), ctypes.byref(G), ctypes.byref(st.io),
                  ctypes.byref(io), ops._stream())
         name = f"encoder.transformers.{li}"
-        M = B * T
+        M = st.lay.M
         for k, norm in enumerate(("norm_final", "norm_ff", "norm_conv", "norm_self_attn", "norm_ff_macaron")):
             deferred.append((M, eng.d, ln_part[k], A.g(f"{name}.{norm}.weight"), A.g(f"{name}.{norm}.bias")))
 

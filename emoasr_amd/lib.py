@@ -144,6 +144,13 @@ class FfnStash(Structure):
                 ("rstd", c_void_p)]
 
 
+MAX_SEGMENTS = 8
+
+
+class Segments(Structure):
+    _fields_ = [("n", c_int), ("B", c_int * MAX_SEGMENTS), ("T", c_int * MAX_SEGMENTS)]
+
+
 class ConformerFwd(Structure):
     _fields_ = [("B", c_int), ("T", c_int), ("x", c_void_p), ("pos_t", c_void_p), ("klens", c_void_p),
                 ("training", c_int), ("p_enc", c_float), ("p_att", c_float), ("seed", c_uint64 * 7),
@@ -153,7 +160,7 @@ class ConformerFwd(Structure):
                 ("cv_h", c_void_p), ("g", c_void_p), ("gl", c_void_p), ("c", c_void_p), ("z", c_void_p),
                 ("cv_y", c_void_p), ("bmean", c_void_p), ("bvar", c_void_p), ("bn_part", c_void_p),
                 ("cv_mean", c_void_p), ("cv_rstd", c_void_p),
-                ("y", c_void_p), ("fin_mean", c_void_p), ("fin_rstd", c_void_p)]
+                ("y", c_void_p), ("fin_mean", c_void_p), ("fin_rstd", c_void_p), ("seg", Segments)]
 
 class ConformerBwd(Structure):
     _fields_ = [("dy", c_void_p), ("dx", c_void_p), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t),
@@ -322,6 +329,17 @@ def size_query(name, *ints):
         fn.argtypes = [c_int] * len(ints)
         _SIZE_FN[name] = fn
     return int(fn(*[int(v) for v in ints]))
+
+
+def ws_bytes_seg(dtype_code, seg, d, H, F, K):
+    """emoasr_conformer_layer_bwd_ws_bytes_seg: backward workspace of a layer pass over stacked micro-batches"""
+    fn = load().emoasr_conformer_layer_bwd_ws_bytes_seg
+    fn.restype = ctypes.c_size_t
+    fn.argtypes = [c_int, POINTER(Segments), c_int, c_int, c_int, c_int]
+    n = int(fn(dtype_code, ctypes.byref(seg), d, H, F, K))
+    if n == 0:
+        raise EmoasrHipError("emoasr_conformer_layer_bwd_ws_bytes_seg: bad segment description")
+    return n
 
 
 def timer_read(name, reset=True):

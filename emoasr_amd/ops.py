@@ -174,10 +174,14 @@ def conv1_wgrad(x, dy1, dw1, db1, accumulate=False):
              _p(scratch), _stream())
 
 
-def conv2_fwd(y1, w, **epi):
+def conv2_fwd(y1, w, out=None, **epi):
     B, T1, F1, C = y1.shape
     T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
-    y2 = torch.empty(B, T2, F2, C, device=y1.device, dtype=y1.dtype)
+    if out is None:
+        y2 = torch.empty(B, T2, F2, C, device=y1.device, dtype=y1.dtype)
+    else:  # (a contiguous slice of a larger buffer: the stacked micro-batches of engine.ctc_train_stacked)
+        assert out.is_contiguous() and out.numel() == B * T2 * F2 * C and out.dtype == y1.dtype
+        y2 = out.view(B, T2, F2, C)
     ep = make_epilogue(**epi)
     lib.call("emoasr_conv2_fwd", dt(y1), B, T1, F1, C, _p(y1), _p(_chk(w, y1.dtype)), _p(y2), byref(ep),
              _stream())
@@ -594,10 +598,14 @@ def ctc_forward(logits, lse, labels, elens, ylens, blank):
     return lp, alpha, beta, nll
 
 
-def ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale, gscale_dev=None):
+def ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale, gscale_dev=None, out=None):
     B, T, V = logits.shape
     ld = logits.stride(1)  # rows of a ragged vocabulary are padded (engine.head_logits): keep that layout
-    grad = torch.empty_like(logits) if ld == V else torch.empty(B, T, ld, device=logits.device, dtype=logits.dtype)[..., :V]
+    if out is not None:
+        assert out.shape == logits.shape and out.dtype == logits.dtype and out.stride(2) == 1
+        grad = out
+    else:
+        grad = torch.empty_like(logits) if ld == V else torch.empty(B, T, ld, device=logits.device, dtype=logits.dtype)[..., :V]
     lib.call("emoasr_ctc_grad", dt(logits), B, T, V, labels.shape[1], _p(logits), logits.stride(1), _p(lse),
              _p(labels), _p(elens), _p(ylens), blank, _p(lp), _p(alpha), _p(beta), _p(nll), gscale, _p(gscale_dev),
              _p(grad),

@@ -463,11 +463,24 @@ typedef struct emoasr_ffn_stash {
   void *h, *u, *a, *y;               /* LN out [M,d], pre-activation [M,F] (optional), activation [M,F], block output [M,d] */
   float *mean, *rstd;
 } emoasr_ffn_stash_t;
+/* Stacked micro-batches ("segments"): the reference accumulates gradients over `accum_grad` independent forward /
+ * backward passes (asr/train_asr.py:106-128).  Here up to EMOASR_MAX_SEGMENTS of those micro-batches go through a layer
+ * TOGETHER: their rows are concatenated (segment s = B[s] utterances padded to T[s] frames; M = sum B[s] T[s] rows), so every
+ * row-wise kernel -- the projections, LayerNorms, the vocabulary head -- runs once over all of them, while attention stays per
+ * utterance, the depthwise convolution sees each segment's own zero padding and BatchNorm takes its batch statistics PER
+ * SEGMENT and updates the running statistics once per segment, in order -- the arithmetic of the separate passes.
+ * n = 0 (or 1 with B[0], T[0]): one dense batch. */
+#define EMOASR_MAX_SEGMENTS 8
+typedef struct emoasr_segments {
+  int n;
+  int B[EMOASR_MAX_SEGMENTS], T[EMOASR_MAX_SEGMENTS];
+} emoasr_segments_t;
 typedef struct emoasr_conformer_fwd {
-  int B, T;
-  const void* x;                     /* [B*T, d] */
-  const void* pos_t;                 /* [2T-1, d] relative position table (after dropout), compute dtype */
-  const int* klens;                  /* int32 [B] valid frames */
+  int B, T;                          /* dense batch; with seg.n > 1: B = sum seg.B, T = max seg.T (informative) */
+  const void* x;                     /* [M, d], M = B*T or the stacked row count */
+  const void* pos_t;                 /* [2T-1, d] relative position table (after dropout), compute dtype; stacked: the
+                                      * segments' tables one after the other, sum (2 T[s] - 1) rows */
+  const int* klens;                  /* int32 [B] valid frames (stacked: all segments' utterances in order) */
   int training;                      /* batch statistics + running-stat update in BatchNorm */
   float p_enc, p_att;
   uint64_t seed[7];
@@ -475,6 +488,9 @@ typedef struct emoasr_conformer_fwd {
   void *at_h, *qkv, *pp, *o, *at_y; float *lse, *at_mean, *at_rstd;
   void *cv_h, *g, *gl, *c, *z, *cv_y; float *bmean, *bvar, *bn_part, *cv_mean, *cv_rstd;
   void* y; float *fin_mean, *fin_rstd;
+  emoasr_segments_t seg;             /* stacked micro-batches; lse is [H * M]: segment s at H * (its first row), laid out
+                                      * [B[s], H, T[s]]; bmean / bvar are [n, d]; bn_part holds the segments' partial-sum
+                                      * areas (emoasr_dwconv_stats_floats(B[s], T[s], d) floats each) back to back */
 } emoasr_conformer_fwd_t;
 int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* layer,
                                const emoasr_conformer_fwd_t* io, void* stream);
@@ -507,6 +523,7 @@ typedef struct emoasr_conformer_bwd {
   float* ln_part; long ln_part_stride;
 } emoasr_conformer_bwd_t;
 size_t emoasr_conformer_layer_bwd_ws_bytes(int dtype, int B, int T, int d, int H, int F, int K);
+size_t emoasr_conformer_layer_bwd_ws_bytes_seg(int dtype, const emoasr_segments_t* seg, int d, int H, int F, int K);
 int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_layer_t* layer, const emoasr_conformer_layer_t* grads,
                                const emoasr_conformer_fwd_t* st, const emoasr_conformer_bwd_t* io, void* stream);
 
@@ -598,6 +615,8 @@ int emoasr_attn_step(int nb, int d, int H, int Lmax, const void* qkv, void* kcac
  * none of its grid barriers ever gave up waiting, 1 otherwise (results of that step are then undefined), -1 on a runtime error.
  * Synchronises the device. */
 long emoasr_decode_coop_status(void);
+/* times the cooperative step kernel of a chain (0 decoder, 1 LM) was enqueued or captured since the library was loaded */
+long emoasr_decode_coop_launches(int chain);
 int emoasr_beam_cache_gather(int dtype, int nl, int nb, int Lmax, int d, const void* src_k, const void* src_v, void* dst_k,
                              void* dst_v, const int* parent, const int* pos, void* stream);
 /* Beam bookkeeping of one output step (decoders/transformer.py:215-290) for up to 32 beams x 32 candidates, one workgroup:

@@ -71,6 +71,38 @@ def test_l3_joint_beam_search_full_size(dev):
         assert abs(a - b) < 1e-3 * abs(b) + 2e-3, (scores, want_scores)
 
 
+def test_l3_joint_beam_search_full_size_bf16_cooperative_kernels(dev):
+    """The configuration bench.py times for config 4 -- bf16, beam 10, 12-layer LM, so the cached steps run as the
+    cooperative launches of csrc/decode_coop.hip (one 16-workgroup launch per network, 42 / 61 grid barriers) -- against the
+    f32 CPU oracle at full size, on the same sharpened weights as the f32 test above.
+    bf16 contract: the SAME ten hypotheses in the same order, every score within 1 % + 0.05 of the
+    oracle's (measured: 0.2 %); the cooperative path taken by both networks and none of its barriers timed out."""
+    from emoasr_amd import lib
+    from oracle import decoder as od, model as om
+    model, lm = _l3(torch.bfloat16)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    lsd = {k: v.detach().clone() for k, v in lm.state_dict().items()}
+    cfg = SimpleNamespace(**L3)
+    g = torch.Generator().manual_seed(1)
+    xs, xlens = torch.randn(1, 1200, 80, generator=g), torch.tensor([1200])
+    with torch.no_grad():
+        eouts, elens = om.encoder_forward(sd, cfg, xs, xlens)
+        want, want_scores = od.joint_beam_search(sd, cfg, eouts, elens, 10, 0.0, (lsd, SimpleNamespace(**LM12)), 0.3, 0.3)
+    assert len(want) == 10 and max(len(h) for h in want) >= 5, [len(h) for h in want]
+    model, lm = model.to(dev).eval(), lm.to(dev).eval()
+    before = [lib.size_query("emoasr_decode_coop_launches", c) for c in (0, 1)]
+    hyps, scores, _, _ = model.decode(xs.to(dev), xlens, beam_width=10, len_weight=0.0, lm=lm, lm_weight=0.3,
+                                      decode_ctc_weight=0.3)
+    after = [lib.size_query("emoasr_decode_coop_launches", c) for c in (0, 1)]
+    assert after[0] > before[0] and after[1] > before[1], ("the cooperative step kernels were not used", before, after)
+    assert lib.size_query("emoasr_decode_coop_status") == 0
+    print("bf16 coop search: hyps equal", hyps == want, "max rel score err",
+          max(abs(a - b) / abs(b) for a, b in zip(scores, want_scores)) if len(scores) == len(want_scores) else None)
+    assert hyps == want, (hyps, want)
+    for a, b in zip(scores, want_scores):
+        assert abs(a - b) < 1e-2 * abs(b) + 5e-2, (scores, want_scores)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_l3_teacher_forced_loss_and_grads_full_size(dev, dtype):
     from oracle import decoder as od, model as om

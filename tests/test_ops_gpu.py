@@ -986,6 +986,40 @@ def test_lstm_seq_cooperative_matches_the_step_chain(dev, U, B, H, with_state):
     _close(gact, g_ref, 3e-2, "gact")
 
 
+def test_lstm_seq_cooperative_survives_changing_grid_sizes(dev):
+    """The grid barrier's base is tracked by the host per launch (csrc/lstm_coop.hip: lstm_base), so launches whose workgroup
+    counts G = H / 16 differ may follow each other in any order: H = 128 with U = 4 leaves the shared counter at 24, which is
+    not a multiple of the next launch's G = 32 (the round-2 kernels derived the base as counter - counter % G and released the
+    first barrier of that launch after 8 of 32 arrivals); H = 320 gives a G that is not a power of two."""
+    from emoasr_amd import lib, ops
+    dt_ = torch.bfloat16
+
+    def run(U, B, H):
+        pre = _rnd(dev, U, B, 4 * H, dtype=dt_, scale=1.0)
+        w_hh = _rnd(dev, 4 * H, H, dtype=dt_, scale=H ** -0.5)
+        hseq = torch.empty(U, B, H, device=dev, dtype=dt_)
+        cseq = torch.empty(U, B, H, device=dev)
+        gact = torch.empty(U, B, 4 * H, device=dev, dtype=dt_)
+        ops.lstm_seq_fwd(pre, w_hh, None, None, hseq, cseq, gact)
+        h_ref = torch.empty_like(hseq); c_ref = torch.empty_like(cseq); g_ref = torch.empty_like(gact)
+        hp, cp = None, None
+        for u in range(U):
+            gates = pre[u] if hp is None else ops.gemm_nt(hp, w_hh, residual=pre[u], res_scale=1.0)
+            ops.lstm_cell_fwd(gates, cp, h_ref[u], c_ref[u], g_ref[u])
+            hp, cp = h_ref[u], c_ref[u]
+        torch.cuda.synchronize()
+        _close(hseq, h_ref, 3e-2, f"hseq H={H} U={U}")
+        # backward on the same shapes
+        dh_seq = _rnd(dev, U, B, H, dtype=dt_, scale=0.5)
+        dgp = torch.empty(U, B, 4 * H, device=dev, dtype=dt_)
+        ops.lstm_seq_bwd(dh_seq, gact, cseq, None, w_hh, dgp)
+        assert torch.isfinite(dgp.float()).all()
+
+    for U, B, H in [(4, 36, 128), (9, 36, 512), (6, 20, 320), (3, 36, 512), (5, 8, 96), (7, 36, 512)]:
+        run(U, B, H)
+        assert lib.size_query("emoasr_lstm_coop_status") == 0, (U, B, H)
+
+
 @pytest.mark.parametrize("U,B,H,with_c0", [(9, 36, 512, False), (5, 50, 512, True), (7, 4, 128, False), (3, 17, 256, True)])
 def test_lstm_seq_backward_cooperative_matches_the_step_chain(dev, U, B, H, with_c0):
     """the backward recurrence of csrc/lstm_coop.hip against the per-position chain lstm_cell_bwd + gemm_nn"""
