@@ -452,6 +452,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--accum", type=int, default=5,
+                    help="micro-batches per optimizer step (the reference trains with accum_grad: 5, asr/correct/exps/csj/asr.yaml:52, "
+                         "asr/train_asr.py:106-128); a `step` of this benchmark is one optimizer step = this many micro-batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point GPU time table to stderr")
@@ -491,7 +494,9 @@ def main():
     eng.seed = 1234 + rank  # per-replica dropout streams
     opt = ArenaAdam(eng.arena, lambda s: noam_lr(OPT["lr"], L2["enc_hidden_size"], OPT["warmup"], s),
                     weight_decay=OPT["weight_decay"], clip_grad_norm=OPT["clip_grad_norm"])
-    batches = make_batches(rank, world, args.warmup + args.steps, dev)
+    accum = max(1, args.accum)
+    micro = make_batches(rank, world, (args.warmup + args.steps) * accum, dev)
+    batches = [micro[i * accum:(i + 1) * accum] for i in range(args.warmup + args.steps)]   # one entry = one optimizer step
     np_rng, py_rng = np.random.RandomState(rank), random.Random(rank)
 
     buckets = None
@@ -500,14 +505,25 @@ def main():
         buckets = GradBuckets(eng.arena.grad)
         eng.grad_hook = buckets.ready
 
-    def step(bt):
-        xs = bt.xs.clone()
-        spans = h2d_i32(specaug_spans(bt.xlens, 80, np_rng=np_rng, py_rng=py_rng), dev)
-        xl = h2d_i32(bt.xlens, dev)
-        ops.specaug_apply(xs, spans, 2, 2, xl)
-        loss, _ = model(xs, bt.xlens, bt.ys, bt.ylens, None, None)
+    stacked = accum > 1 and dtype == torch.bfloat16 and eng.stacked_ok()
+
+    def step(group):
+        """one optimizer step: `accum` micro-batches (SpecAugment on the device each), gradients of loss / accum summed -- through
+        the engine together when it can stack them (engine.ctc_train_stacked), else one after the other --, all-reduce, Adam"""
+        datas = []
+        for bt in group:
+            xs = bt.xs.clone()
+            spans = h2d_i32(specaug_spans(bt.xlens, 80, np_rng=np_rng, py_rng=py_rng), dev)
+            xl = h2d_i32(bt.xlens, dev)
+            ops.specaug_apply(xs, spans, 2, 2, xl)
+            datas.append((xs, bt.xlens, bt.ys, bt.ylens))
         opt.zero_grad()
-        loss.backward()
+        if stacked:
+            loss = eng.ctc_train_stacked(datas, L2["blank_id"]).mean()
+        else:
+            for xs, xlens, ys, ylens in datas:
+                loss, _ = model(xs, xlens, ys, ylens, None, None)
+                (loss / accum).backward()
         if buckets is not None:
             buckets.finish()   # the tail ranges went out during the backward sweep (train.GradBuckets)
         elif world > 1:
@@ -515,8 +531,8 @@ def main():
         opt.step(grad_mult=1.0 / world)
         return loss
 
-    def attn_pairs(bt):
-        sub = [((t - 3) // 2 + 1 - 3) // 2 + 1 for t in bt.xlens]  # Conv2dEncoder: two stride-2 3x3 convs
+    def attn_pairs(group):
+        sub = [((t - 3) // 2 + 1 - 3) // 2 + 1 for bt in group for t in bt.xlens]  # Conv2dEncoder: two stride-2 3x3 convs
         return float(sum(t * t for t in sub))
 
     def sync():
@@ -542,7 +558,7 @@ def main():
     # events on its launch stream (emoasr_timer_read) over exactly the timed region.
     dominant = "attn_bwd_fused_kernel"
     sync()
-    frames = sum(sum(b.xlens) for b in batches[args.warmup:])
+    frames = sum(sum(b.xlens) for grp in batches[args.warmup:] for b in grp)
     emo_lib.set_option("timers", 1)
     emo_lib.timer_read(dominant)
     t0 = time.perf_counter()
@@ -573,11 +589,14 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "CTC(Conformer) 23M `L2`, bf16, SpecAugment on-GPU, synthetic LibriSpeech-shaped "
                                    "batches (2000 utts, lognormal lengths, ASRBatchSampler packing 30000 frames/50 utts "
-                                   "per GPU), fwd+bwd+all-reduce+clip+Adam, dropout 0.1",
+                                   f"per GPU), one step = accum_grad {accum} micro-batches (the reference's accum_grad: 5, "
+                                   "asr/train_asr.py:106-128" + (", stacked through the engine in one pass" if stacked else "") +
+                                   ") fwd+bwd, then all-reduce+clip+Adam; dropout 0.1",
+                       "accum_grad": accum, "stacked_micro_batches": bool(stacked),
                        "params_M": sum(p.numel() for p in model.parameters()) / 1e6,
                        "parallelism": f"dp{world}", "final_loss": float(loss.detach())},
         }
-        mean_T = frames / world / args.steps / max(1, np.mean([len(b.xlens) for b in batches[args.warmup:]]))
+        mean_T = frames / world / args.steps / accum / max(1, np.mean([len(b.xlens) for grp in batches[args.warmup:] for b in grp]))
         train_flops = 3.0 * fwd_flops_per_utt(int(mean_T)) / max(mean_T, 1) * frames
         res["model_mfma_frac"] = train_flops / elapsed / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12 * world)
         if dom["calls"] and dom["flops"]:
@@ -597,7 +616,7 @@ def main():
                 tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
                 print(f"  {k:28s} calls {v['calls']:5d}  {v['ms']:9.3f} ms  {100 * v['ms'] / tot:5.1f}%  {tf:7.1f} TF/s",
                       file=sys.stderr)
-            print(f"  total instrumented GPU time {tot:.2f} ms (one step, B={len(batches[args.warmup - 1].xlens)})", file=sys.stderr)
+            print(f"  total instrumented GPU time {tot:.2f} ms (one step, {accum} micro-batches)", file=sys.stderr)
         if world == 1 and not args.no_decode:
             import tempfile
             with tempfile.TemporaryDirectory() as tmpdir:
@@ -606,30 +625,34 @@ def main():
                 res["decode_l33"] = decode_rtf_l33(dev, dtype, tmpdir)
             # log-mel in the loop: the same steps starting from raw 16 kHz audio (fbank kernel -> SpecAugment -> model)
             from emoasr_amd.features import LogMel
-            fb = logmel_rate(dev, batches[-1].xlens)
+            fb = logmel_rate(dev, batches[-1][-1].xlens)
             lmel = LogMel(dev)
             g = torch.Generator().manual_seed(9)
-            sub = batches[args.warmup:args.warmup + 6]
-            wavs = [[(0.05 * torch.randn(160 * (t - 1) + 400, generator=g)).to(dev) for t in bt.xlens] for bt in sub]
+            sub = batches[args.warmup:args.warmup + 3]
+            wavs = [[[(0.05 * torch.randn(160 * (t - 1) + 400, generator=g)).to(dev) for t in bt.xlens] for bt in grp] for grp in sub]
 
-            def wav_step(bt, ws_):
-                xs = torch.zeros_like(bt.xs)
-                for b, w in enumerate(ws_):
-                    f = lmel(w)
-                    xs[b, : f.shape[0]] = f[: xs.shape[1]]
-                return step(SimpleNamespace(xs=xs, xlens=bt.xlens, ys=bt.ys, ylens=bt.ylens))
+            def wav_step(grp, ws_grp):
+                feats = []
+                for bt, ws_ in zip(grp, ws_grp):
+                    xs = torch.zeros_like(bt.xs)
+                    for b, w in enumerate(ws_):
+                        f = lmel(w)
+                        xs[b, : f.shape[0]] = f[: xs.shape[1]]
+                    feats.append(SimpleNamespace(xs=xs, xlens=bt.xlens, ys=bt.ys, ylens=bt.ylens))
+                return step(feats)
 
             wav_step(sub[0], wavs[0])
             sync()
             t0 = time.perf_counter()
-            for bt, ws_ in zip(sub[1:], wavs[1:]):
-                wav_step(bt, ws_)
+            for grp, ws_grp in zip(sub[1:], wavs[1:]):
+                wav_step(grp, ws_grp)
             sync()
             res["logmel"] = {"frames_per_s": fb, "train_frames_per_s_with_logmel":
-                             sum(sum(b.xlens) for b in sub[1:]) / (time.perf_counter() - t0), "steps": len(sub) - 1}
+                             sum(sum(b.xlens) for grp in sub[1:] for b in grp) / (time.perf_counter() - t0),
+                             "steps": len(sub) - 1}
             res["l4_rnnt"] = l4_rnnt(dev, dtype)
             if args.dtype == "bf16":
-                res.update(parity_mode(dev, batches))
+                res.update(parity_mode(dev, [b for grp in batches for b in grp]))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(res), flush=True)

@@ -25,6 +25,7 @@ void emo_gemm_set_big_korder(int v);
 void emo_gemm_set_big_min_tiles(int v);
 void emo_conv_set_dwconv_lds(int v);
 void emo_layer_set_conv_fused(int v);
+void emo_layer_set_stack_launch(int v);
 void emo_decode_set_fused(int v);
 #ifdef EMOASR_EXPERIMENTAL
 void emo_decode_set_wg(int v);
@@ -105,6 +106,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "big_min_tiles") == 0) { emo_gemm_set_big_min_tiles(value); return 0; }
   if (strcmp(name, "dwconv_lds") == 0) { emo_conv_set_dwconv_lds(value); return 0; }
   if (strcmp(name, "conv_fused") == 0) { emo_layer_set_conv_fused(value); return 0; }
+  if (strcmp(name, "stack_launch") == 0) { emo_layer_set_stack_launch(value); return 0; }
 #ifdef EMOASR_EXPERIMENTAL
   if (strcmp(name, "decode_fused") == 0) { emo_decode_set_fused(value); return 0; }
   if (strcmp(name, "decode_wg") == 0) { emo_decode_set_wg(value); return 0; }

@@ -153,6 +153,44 @@ __device__ __forceinline__ HeadPtrs head_ptrs(const emoasr_attn_t& a, int b, int
   return p;
 }
 
+// Stacked micro-batches (emoasr_attn_t::nseg > 1): a workgroup first turns the launch's arguments into those of ITS segment --
+// base pointers moved to the segment's first row / table row, B / Tq / Tk its own, the utterance index made local, the dropout
+// seed offset -- and everything below runs as for a dense batch.  All of it is wave-uniform (scalar registers).
+// (The tables are indexed dynamically only in the KERNEL ARGUMENT -- constant memory; the private copy that seg_apply edits
+// is touched through fixed fields only, so it stays in scalar registers instead of scratch.)
+struct SegRef { int s, b0, nb, T; long row, prow; };
+__device__ __forceinline__ SegRef seg_ref(const emoasr_attn_t& karg, int s) {
+  return SegRef{s, karg.seg_b0[s], karg.seg_b0[s + 1] - karg.seg_b0[s], karg.seg_T[s], karg.seg_row[s], karg.seg_prow[s]};
+}
+__device__ __forceinline__ SegRef seg_of_utt(const emoasr_attn_t& karg, int b) {
+  int s = 0;
+  for (int k = 1; k < EMOASR_MAX_SEGMENTS; ++k) s += (k < karg.nseg && b >= karg.seg_b0[k]) ? 1 : 0;
+  return seg_ref(karg, s);
+}
+__device__ __forceinline__ SegRef seg_of_row(const emoasr_attn_t& karg, long row) {
+  int s = 0;
+  for (int k = 1; k < EMOASR_MAX_SEGMENTS; ++k) s += (k < karg.nseg && row >= karg.seg_row[k]) ? 1 : 0;
+  return seg_ref(karg, s);
+}
+template <typename T>
+__device__ __forceinline__ void seg_apply(emoasr_attn_t& a, const SegRef& g) {
+  const long r = g.row;
+  a.q = (const T*)a.q + r * a.ldq; a.k = (const T*)a.k + r * a.ldk; a.v = (const T*)a.v + r * a.ldv;
+  if (a.out) a.out = (T*)a.out + r * a.ldo;
+  if (a.dout) a.dout = (const T*)a.dout + r * a.ldo;
+  if (a.dq) a.dq = (T*)a.dq + r * a.ldq;
+  if (a.dk) a.dk = (T*)a.dk + r * a.ldk;
+  if (a.dv) a.dv = (T*)a.dv + r * a.ldv;
+  if (a.pos) a.pos = (const T*)a.pos + g.prow * a.ldp;
+  if (a.dpos) a.dpos += g.prow * (long)(a.H * DK);
+  a.lse += r * a.H;
+  if (a.delta) a.delta += r * a.H;
+  if (a.klens) a.klens += g.b0;
+  a.B = g.nb;
+  a.Tq = a.Tk = g.T;
+  a.seed += 0x9E3779B97F4A7C15ull * (uint64_t)g.s;
+}
+
 // ------------------------------------------------------------------------------------
 // Score tile.  `row_*` fragments index the tile's rows, `col_*` its columns:
 //   SWAPPED  (forward, dq):   rows = keys j0.., cols = queries i0..   (row side = K / band)
@@ -265,12 +303,19 @@ __device__ __forceinline__ void store_dT(T* dst, long ld, int r0, int rlimit, co
 // blocks per CU (bf16).  Measured at B 20, T' 340 (240 blocks): 36 us with two sets, 45 us with one; at 264
 // blocks the two-set kernel's second round of blocks costs 80 us against 62.
 template <typename T, bool TR, bool PF2>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fwd_kernel(const emoasr_attn_t a) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fwd_kernel(const emoasr_attn_t a_in) {
   using M_ = Mma<T>;
   constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = AttnCfg<T>::LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+  emoasr_attn_t a = a_in;
+  int b = blockIdx.z;
+  if (a_in.nseg > 1) {
+    const SegRef g = seg_of_utt(a_in, b);
+    seg_apply<T>(a, g);
+    b -= g.b0;
+  }
+  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y;
   if (i0 >= a.Tq) return;
   constexpr int WAVE_BYTES = 64 * 32 * 4 + 32 * LD * (int)sizeof(T);
   float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
@@ -1231,10 +1276,10 @@ struct FusedWs {       // workspace carved by emoasr_attn_bwd_fused
 // saves the separate memset launch of the per-layer backward)
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t a, T* __restrict__ qu, T* __restrict__ qv,
-                                                            float* __restrict__ zero, const long zn) {
+                                                            float* __restrict__ zero, const long zn, const long nrows) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   for (long i = idx; i < zn; i += (long)gridDim.x * 256) zero[i] = 0.f;
-  const long row = idx >> 3, total = (long)a.B * a.Tq * a.H;
+  const long row = idx >> 3, total = nrows * a.H;   // nrows = B * Tq, or all stacked rows
   const int d0 = (int)(idx & 7) * 8;
   const bool ok = row < total;
   const int h = ok ? (int)(row % a.H) : 0;
@@ -1247,8 +1292,17 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t 
   for (int j = 0; j < 8; ++j) s += dv[j] * ov[j];
   s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
   if (!ok) return;
-  const int i = (int)(bt % a.Tq), b = (int)(bt / a.Tq);
-  if (d0 == 0) a.delta[((long)b * a.H + h) * a.Tq + i] = s;
+  if (d0 == 0) {
+    if (a.nseg > 1) {   // delta of segment s: [utterances, H, T_s] at H * (its first row)
+      const SegRef g = seg_of_row(a, bt);
+      const long loc = bt - g.row;
+      const int i = (int)(loc % g.T), b = (int)(loc / g.T);
+      a.delta[g.row * a.H + ((long)b * a.H + h) * g.T + i] = s;
+    } else {
+      const int i = (int)(bt % a.Tq), b = (int)(bt / a.Tq);
+      a.delta[((long)b * a.H + h) * a.Tq + i] = s;
+    }
+  }
   const long o = (bt * a.H + h) * DK + d0;
   if (qu) {
     float qx[8], u[8], v[8];
@@ -1303,7 +1357,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <typename T, bool TR, bool REL, int FW>
-__global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr_attn_t a, const FusedWs ws) {
+__global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr_attn_t a_in, const FusedWs ws_in) {
   using M_ = Mma<T>;
   using C_ = FusedCfg<T, FW>;
   constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = C_::LD, IMG = C_::IMG;
@@ -1313,7 +1367,20 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
   static_assert(NPIECE % NTHR == 0, "staging pieces must divide evenly");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31;
-  const int jblk = blockIdx.x * (32 * FW), h = blockIdx.y, b = blockIdx.z;
+  emoasr_attn_t a = a_in;
+  FusedWs ws = ws_in;
+  int b = blockIdx.z;
+  if (a_in.nseg > 1) {   // stacked micro-batches: this workgroup's segment (the scratch images are stacked like the rows)
+    const SegRef g = seg_of_utt(a_in, b);
+    seg_apply<T>(a, g);
+    b -= g.b0;
+    ws.qu = (const T*)ws.qu + g.row * ws.ldqu;
+    ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
+    ws.dq32 += g.row * (long)(a.H * DK);
+    if (ws.dsq) ws.dsq = (T*)ws.dsq + g.row * a.H * ws.ldds;
+  }
+  const int jblk = blockIdx.x * (32 * FW), h = blockIdx.y;
+  if (jblk >= a.Tk) return;   // (a shorter segment of a stacked launch: the grid follows the longest)
   const HeadPtrs hp = head_ptrs<T>(a, b, h);
   const int j0 = jblk + 32 * wave;
   if (jblk >= hp.klen) {  // every key of this block is masked: its dK / dV rows are zero, nothing else to add
@@ -1672,15 +1739,29 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
 // with 16-byte loads and goes through wave-private LDS (transposed reads) as the B operand; the next item's loads are in
 // flight while this one is multiplied.  Waves are reduced through LDS before one set of atomics (rows of 64 d).
 template <typename T, bool TR>
-__global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t a, const FusedWs ws, const int bchunk) {
+__global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int bchunk_in,
+                                                             const int nchunk) {
   using M_ = Mma<T>;
   constexpr int RT = 2;  // 32-row table tiles per block: the staged (Q+v) tile is multiplied into both
   constexpr int LD = AttnCfg<T>::LD, VEC = 16 / sizeof(T), PER_ROW = DK / VEC, QR = 32 * PER_ROW / 64;
   constexpr int QS_BYTES = 32 * LD * (int)sizeof(T), RED_BYTES = 4 * RT * 2 * 16 * 64 * 4;
   __shared__ __attribute__((aligned(16))) char smem[(4 * QS_BYTES > RED_BYTES) ? 4 * QS_BYTES : RED_BYTES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, hh = lane >> 5;
+  emoasr_attn_t a = a_in;
+  FusedWs ws = ws_in;
+  int bchunk = bchunk_in, zc = blockIdx.z;
+  if (a_in.nseg > 1) {   // stacked micro-batches: blockIdx.z = segment * nchunk + batch chunk; every segment has its own table
+    const int sgi = blockIdx.z / nchunk;
+    zc = blockIdx.z - sgi * nchunk;
+    const SegRef g = seg_ref(a_in, sgi);
+    seg_apply<T>(a, g);
+    ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
+    ws.dsq = (T*)ws.dsq + g.row * a.H * ws.ldds;
+    bchunk = (a.B + nchunk - 1) / nchunk;
+  }
   const int r0 = blockIdx.x * (32 * RT), h = blockIdx.y;
-  const int b_lo = blockIdx.z * bchunk, b_hi = min(a.B, b_lo + bchunk);
+  if (r0 >= 2 * a.Tq - 1) return;
+  const int b_lo = zc * bchunk, b_hi = min(a.B, b_lo + bchunk);
   const int nit = (a.Tq + 31) / 32;
   T* qs = reinterpret_cast<T*>(smem + wave * QS_BYTES);
   f32x16 acc[RT][2];
@@ -1759,12 +1840,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t
 
 // dq (T, strided) = sum over the utterance's live key blocks of their dQ partials, in block order (bit-reproducible).
 // Block = 16 rows x ncol columns; the slab loads of a row are issued together (out-of-range blocks: no traffic).
+struct FinSegs { int n; int b0[EMOASR_MAX_SEGMENTS + 1], T[EMOASR_MAX_SEGMENTS]; long row[EMOASR_MAX_SEGMENTS + 1]; };
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_fin_kernel(const long rows, const int ncol, const float* __restrict__ dq32,
                                                            const long slab, const int keys_per_block, const int Tq, const int Tk,
                                                            const int* __restrict__ klens, T* __restrict__ dq, const long ldq,
                                                            const float* __restrict__ cast_src, T* __restrict__ cast_dst,
-                                                           const long cast_n) {
+                                                           const long cast_n, const FinSegs sg) {
   // on the side: the finished f32 position-table gradient rounded to the compute dtype for its weight-gradient product
   // (this launch follows attn_bwd_dpos2_kernel; saves the separate cast launch of the per-layer backward)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < cast_n; i += (long)gridDim.x * 256) cast_dst[i] = from_f32<T>(cast_src[i]);
@@ -1773,8 +1855,14 @@ __global__ __launch_bounds__(256) void attn_bwd_fin_kernel(const long rows, cons
   if (rr >= rpb) return;
   const long row_lo = (long)blockIdx.x * 16, row_hi = min(rows, row_lo + 16);
   for (long row = row_lo + rr; row < row_hi; row += rpb) {
-    const int b = (int)(row / Tq);
-    const int klen = klens ? min(klens[b], Tk) : Tk;
+    int b = (int)(row / Tq), tk = Tk;
+    if (sg.n > 1) {   // stacked micro-batches: the row's segment gives its utterance and padded length
+      int si = 0;
+      for (int k = 1; k < EMOASR_MAX_SEGMENTS; ++k) si += (k < sg.n && row >= sg.row[k]) ? 1 : 0;
+      tk = sg.T[si];
+      b = sg.b0[si] + (int)((row - sg.row[si]) / tk);
+    }
+    const int klen = klens ? min(klens[b], tk) : tk;
     const int nkb = (klen + keys_per_block - 1) / keys_per_block;
     float o[8];
 #pragma unroll
@@ -1818,6 +1906,20 @@ int check_args(const emoasr_attn_t* a, int dtype) {
             "attention: row strides must be multiples of %d elements", vec);
   EMO_CHECK(!a->pos || (a->Tq == a->Tk && a->ldp % vec == 0), "attention: relative positions need Tq == Tk");
   EMO_CHECK(!(a->pos && a->causal), "attention: causal + relative positions unsupported");
+  if (a->nseg > 1) {   // stacked micro-batches
+    EMO_CHECK(a->nseg <= EMOASR_MAX_SEGMENTS && a->Tq == a->Tk && !a->causal && !a->st && !a->pdT,
+              "attention: stacked segments need self-attention without causal mask / stored scores / materialised scratch");
+    EMO_CHECK(a->seg_b0[0] == 0 && a->seg_row[0] == 0 && a->seg_b0[a->nseg] == a->B, "attention: bad segment table");
+    int tmax = 0;
+    for (int k = 0; k < a->nseg; ++k) {
+      const int nb = a->seg_b0[k + 1] - a->seg_b0[k];
+      EMO_CHECK(nb > 0 && a->seg_T[k] > 0 && a->seg_row[k + 1] == a->seg_row[k] + (long)nb * a->seg_T[k] &&
+                    (!a->pos || a->seg_prow[k + 1] == a->seg_prow[k] + 2L * a->seg_T[k] - 1),
+                "attention: bad segment %d", k);
+      tmax = std::max(tmax, a->seg_T[k]);
+    }
+    EMO_CHECK(tmax == a->Tq, "attention: Tq must be the longest segment (%d != %d)", a->Tq, tmax);
+  }
   return 0;
 }
 
@@ -1825,7 +1927,7 @@ template <typename T>
 int launch_fwd(const emoasr_attn_t& a, hipStream_t s) {
   constexpr int LD = AttnCfg<T>::LD;
   const int smem = 4 * (64 * 32 * 4 + 32 * LD * (int)sizeof(T));
-  dim3 grid(cdiv(a.Tq, 128), a.H, a.B);
+  dim3 grid(cdiv(a.Tq, 128), a.H, a.B);   // (stacked micro-batches: Tq = the longest segment, B = all utterances)
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -1981,7 +2083,8 @@ FusedExtras g_fused_extras{};
 template <typename T>
 int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_t s) {
   const bool rel = a.pos != nullptr;
-  const long nqd = (long)a.B * a.Tq * a.H * DK;
+  const long nrows = a.nseg > 1 ? a.seg_row[a.nseg] : (long)a.B * a.Tq;   // stacked micro-batches: all segments' rows
+  const long nqd = nrows * a.H * DK;
   FusedWs ws{};
   size_t off = 0;
   auto carve = [&](size_t n) { char* p = mem + off; off += (n + 255) / 256 * 256; return p; };
@@ -1992,13 +2095,13 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
     qu = reinterpret_cast<T*>(carve(nqd * sizeof(T)));
     qv = reinterpret_cast<T*>(carve(nqd * sizeof(T)));
     ws.ldds = (a.Tk + 31) / 32 * 32;
-    ws.dsq = carve((size_t)a.B * a.H * a.Tq * ws.ldds * sizeof(T));
+    ws.dsq = carve((size_t)nrows * a.H * ws.ldds * sizeof(T));
     ws.qu = qu; ws.qv = qv; ws.ldqu = (long)a.H * DK;
   } else {
     ws.qu = a.q; ws.qv = a.q; ws.ldqu = a.ldq;
   }
   EMO_CHECK(off <= bytes, "attn_bwd_fused: workspace too small (%zu < %zu bytes)", bytes, off);
-  const long rows = (long)a.B * a.Tq * a.H;
+  const long rows = nrows * a.H;
   const FusedExtras fx = g_fused_extras;
   g_fused_extras = FusedExtras{};
 #ifdef EMO_ATTN_STAMP
@@ -2007,7 +2110,7 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
   if (!d_stamp) hipMalloc(&d_stamp, 64 * 13 * 8);
   ws.stamp = stamp_calls++ == 0 ? d_stamp : nullptr;   // the first (eager) call only: later calls may be under stream capture
 #endif
-  attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, qu, qv, fx.zero, fx.zero_n);
+  attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, qu, qv, fx.zero, fx.zero_n, nrows);
   // 4 key tiles per workgroup (one workgroup per CU) unless that grid spills into a second round of workgroups and the
   // 2-tile grid (two workgroups per CU) does not
   static int n_cu = 0;
@@ -2032,11 +2135,14 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
     if (fw == 2) EMO_FUSED_LAUNCH(true, 2); else EMO_FUSED_LAUNCH(true, 4);
     emo_timer_end(EMO_TIMER_ATTN_BWD_MAIN, s);
     if (a.dpos) {
-      const int nchunk = a.B < 8 ? a.B : 8;
-      dim3 g2(cdiv(2 * a.Tq - 1, 64), a.H, nchunk);
+      // batch chunks per table tile (stacked micro-batches: per segment, each with its own table: grid.z = segments x chunks)
+      int bmin = a.B;
+      for (int k = 0; k < a.nseg && a.nseg > 1; ++k) bmin = std::min(bmin, a.seg_b0[k + 1] - a.seg_b0[k]);
+      const int nchunk = bmin < 8 ? bmin : 8;
+      dim3 g2(cdiv(2 * a.Tq - 1, 64), a.H, nchunk * (a.nseg > 1 ? a.nseg : 1));
       emo_timer_begin(EMO_TIMER_ATTN_BWD_DPOS, s);
-      if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk));
-      else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk));
+      if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk);
+      else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk);
       emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, s);
     }
   } else {
@@ -2044,8 +2150,14 @@ int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_
     emo_timer_end(EMO_TIMER_ATTN_BWD_MAIN, s);
   }
 #undef EMO_FUSED_LAUNCH
-  attn_bwd_fin_kernel<T><<<cdiv((long)a.B * a.Tq, 16), 256, 0, s>>>((long)a.B * a.Tq, a.H * DK, ws.dq32, ws.dq_slab, 32 * fw, a.Tq,
-                                                                 a.Tk, a.klens, (T*)a.dq, a.ldq, fx.cast_src, (T*)fx.cast_dst, fx.cast_n);
+  FinSegs fsg{};
+  if (a.nseg > 1) {
+    fsg.n = a.nseg;
+    for (int k = 0; k < a.nseg; ++k) { fsg.b0[k] = a.seg_b0[k]; fsg.T[k] = a.seg_T[k]; fsg.row[k] = a.seg_row[k]; }
+    fsg.b0[a.nseg] = a.seg_b0[a.nseg]; fsg.row[a.nseg] = a.seg_row[a.nseg];
+  }
+  attn_bwd_fin_kernel<T><<<cdiv(nrows, 16), 256, 0, s>>>(nrows, a.H * DK, ws.dq32, ws.dq_slab, 32 * fw, a.Tq, a.Tk, a.klens,
+                                                       (T*)a.dq, a.ldq, fx.cast_src, (T*)fx.cast_dst, fx.cast_n, fsg);
 #ifdef EMO_ATTN_STAMP
   {  // debug builds: per-phase cycle counts of the main kernel's first workgroup (wave 0), averaged over the sweep
     static int printed = 0;
@@ -2090,6 +2202,7 @@ extern "C" int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream) 
 extern "C" int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream) {
   if (check_args(a, dtype)) return 1;
   EMO_CHECK(a->dout && a->out && a->delta && a->dq && a->dk && a->dv, "attn_bwd: missing buffers");
+  EMO_CHECK(a->nseg <= 1, "attn_bwd: stacked segments run emoasr_attn_bwd_fused");
   if (a->pdT) {
     EMO_CHECK(a->dsT && a->ldpd >= a->Tq && a->ldpd % 8 == 0, "attn_bwd: bad pdT/dsT scratch");
     EMO_CHECK(!a->pos || !a->dpos || (a->dbd && a->cs && a->ldbd >= 2 * a->Tq - 1 && a->ldbd % 8 == 0),
@@ -2104,13 +2217,18 @@ extern "C" int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream) 
   return 0;
 }
 
-extern "C" size_t emoasr_attn_bwd_fused_ws_bytes(int dtype, int B, int H, int Tq, int Tk, int rel) {
+// rows = B * Tq of a dense batch, or all rows of stacked micro-batches whose longest segment has Tk frames
+extern "C" size_t emoasr_attn_bwd_fused_ws_bytes_rows(int dtype, long rows, int H, int Tk, int rel) {
   const size_t esz = dtype == EMO_BF16 ? 2 : 4;
   auto up = [](size_t n) { return (n + 255) / 256 * 256; };
-  const size_t nqd = (size_t)B * Tq * H * DK;
+  const size_t nqd = (size_t)rows * H * DK;
   size_t n = up(nqd * 4 * ((Tk + 63) / 64));
-  if (rel) n += 2 * up(nqd * esz) + up((size_t)B * H * Tq * ((Tk + 31) / 32 * 32) * esz);
+  if (rel) n += 2 * up(nqd * esz) + up((size_t)rows * H * ((Tk + 31) / 32 * 32) * esz);
   return n;
+}
+
+extern "C" size_t emoasr_attn_bwd_fused_ws_bytes(int dtype, int B, int H, int Tq, int Tk, int rel) {
+  return emoasr_attn_bwd_fused_ws_bytes_rows(dtype, (long)B * Tq, H, Tk, rel);
 }
 
 extern "C" int emoasr_attn_bwd_fused(int dtype, const emoasr_attn_t* a, void* ws, size_t ws_bytes, void* stream) {

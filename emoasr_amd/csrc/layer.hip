@@ -24,6 +24,8 @@ int g_ffn_fused = 0;  // bf16, d = 256: the feed-forward block as ONE launch (cs
                       // only) -- measured slower than LayerNorm + two GEMMs at the L2 batch size (87 vs 40 us, see ffn.hip), so
                       // off unless emoasr_set_option("ffn_fused", 1)
 
+int g_stack_launch = 1;  // stacked micro-batches: 1 = the per-utterance kernels take all segments in ONE launch (segment table in
+                         // their arguments), 0 = one launch per segment (same arithmetic; A/B switch, option "stack_launch")
 int g_conv_fused = 1;  // bf16: the fused convolution-module kernels of csrc/convfused.hip (bit-identical to the separate launches)
 bool conv_fused_ok(int dtype, int d) { return g_conv_fused && dtype == EMO_BF16 && d % 8 == 0; }
 
@@ -72,10 +74,37 @@ bool seg_view(const emoasr_conformer_fwd_t* io, int d, SegView* v) {
   return true;
 }
 
+// attention arguments of segments [s0, s1) of a stacked pass (s1 - s0 == 1: a dense batch at the segment's offsets)
+void attn_args_for(emoasr_attn_t& a, const SegView& sv, int s0, int s1, int H, int d, size_t esz, const void* qkv, const void* pp,
+                   const int* klens, uint64_t seed) {
+  const size_t ro = (size_t)sv.row[s0];
+  const char* base = (const char*)qkv + ro * 3 * d * esz;
+  int nb = 0, tmax = 0;
+  for (int k = s0; k < s1; ++k) { nb += sv.B[k]; tmax = std::max(tmax, sv.T[k]); }
+  a.B = nb; a.H = H; a.DK = d / H; a.Tq = tmax; a.Tk = tmax;
+  a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d; a.ldp = d;
+  a.q = base; a.k = base + (size_t)d * esz; a.v = base + (size_t)2 * d * esz;
+  a.pos = (const char*)pp + (size_t)sv.prow[s0] * d * esz;
+  a.klens = klens ? klens + sv.b0[s0] : nullptr;
+  a.causal = 0; a.scale = 1.f / sqrtf((float)(d / H));
+  a.seed = seed + 0x9E3779B97F4A7C15ull * (uint64_t)s0;   // (the mask index restarts in every segment)
+  a.nseg = 0;
+  if (s1 - s0 > 1) {
+    a.nseg = s1 - s0;
+    for (int k = s0; k <= s1; ++k) {
+      a.seg_b0[k - s0] = k < s1 ? sv.b0[k] - sv.b0[s0] : nb;
+      a.seg_row[k - s0] = sv.row[k] - sv.row[s0];
+      a.seg_prow[k - s0] = sv.prow[k] - sv.prow[s0];
+      if (k < s1) a.seg_T[k - s0] = sv.T[k];
+    }
+  }
+}
+
 }  // namespace
 
 void emo_layer_set_ffn_fused(int v) { g_ffn_fused = v; }
 void emo_layer_set_conv_fused(int v) { g_conv_fused = v; }
+void emo_layer_set_stack_launch(int v) { g_stack_launch = v; }
 
 extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* L,
                                           const emoasr_conformer_fwd_t* io, void* stream) {
@@ -99,19 +128,13 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
     if (emoasr_gemm_nt(dtype, M, 3 * d, d, io->at_h, d, L->wqkv, d, io->qkv, 3 * d, &e, stream)) return 1;
     emoasr_epilogue_t ep = plain_ep();
     if (emoasr_gemm_nt(dtype, R, d, d, io->pos_t, d, L->wpos, d, io->pp, d, &ep, stream)) return 1;
-    for (int si = 0; si < sv.n; ++si) {   // attention is per utterance: one launch per stacked micro-batch
+    // attention is per utterance: all stacked micro-batches in one launch (segment table in the arguments), or one each
+    const int astep = g_stack_launch ? sv.n : 1;
+    for (int si = 0; si < sv.n; si += astep) {
       const size_t ro = (size_t)sv.row[si];
-      const char* qkv = (const char*)io->qkv + ro * 3 * d * esz;
       emoasr_attn_t a{};
-      a.B = sv.B[si]; a.H = H; a.DK = d / H; a.Tq = sv.T[si]; a.Tk = sv.T[si];
-      a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d; a.ldp = d;
-      a.q = qkv;
-      a.k = qkv + (size_t)d * esz;
-      a.v = qkv + (size_t)2 * d * esz;
-      a.pos = (const char*)io->pp + (size_t)sv.prow[si] * d * esz;
-      a.bias_u = L->bias_u; a.bias_v = L->bias_v; a.klens = io->klens ? io->klens + sv.b0[si] : nullptr;
-      a.causal = 0; a.scale = 1.f / sqrtf((float)(d / H)); a.drop_p = io->p_att;
-      a.seed = io->seed[2] + 0x9E3779B97F4A7C15ull * (uint64_t)si;   // (the mask index restarts in every segment)
+      attn_args_for(a, sv, si, si + astep, H, d, esz, io->qkv, io->pp, io->klens, io->seed[2]);
+      a.bias_u = L->bias_u; a.bias_v = L->bias_v; a.drop_p = io->p_att;
       a.out = (char*)io->o + ro * d * esz; a.lse = io->lse + ro * H;
       if (emoasr_attn_fwd(dtype, &a, stream)) return 1;
     }
@@ -199,11 +222,14 @@ BwdBufs bwd_layout(int dtype, const SegView& sv, int d, int H, int F, int K) {
   b.dpos = L.take(R * d * 4); b.delta = L.take(M * H * 4);
   // per-segment scratch is reused by the segments one after the other: sized for the largest
   size_t bn_scr = 0, dw_scr = 0, attn_ws = 0;
+  int tmax = 0;
   for (int i = 0; i < sv.n; ++i) {
     bn_scr = std::max(bn_scr, (size_t)emoasr_bn_swish_bwd_scratch_floats(sv.B[i] * sv.T[i], d) * 4);
     dw_scr = std::max(dw_scr, (size_t)emoasr_dwconv_bwd_w_scratch_floats(sv.B[i], sv.T[i], d, K) * 4);
     attn_ws = std::max(attn_ws, emoasr_attn_bwd_fused_ws_bytes(dtype, sv.B[i], H, sv.T[i], sv.T[i], 1));
+    tmax = std::max(tmax, sv.T[i]);
   }
+  attn_ws = std::max(attn_ws, emoasr_attn_bwd_fused_ws_bytes_rows(dtype, (long)M, H, tmax, 1));   // all segments in one launch
   b.bn_scr = L.take(bn_scr);
   b.dw_scr = L.take(dw_scr);
   b.attn_ws_bytes = attn_ws;
@@ -324,21 +350,15 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     wgrad(dy, d, d, st->o, d, d, M, G->wout, 1.f, G->bout);
     emoasr_epilogue_t e = plain_ep();
     if (emoasr_gemm_nn(dtype, M, d, d, dy, d, L->wout, d, ws + bb.dout, d, &e, stream)) return 1;
-    for (int si = 0; si < sv.n; ++si) {   // per micro-batch (the fused kernel's workspace is reused in order)
+    // all stacked micro-batches in one set of launches (segment table in the arguments), or one set each (workspace reused)
+    const int astep = g_stack_launch ? sv.n : 1;
+    for (int si = 0; si < sv.n; si += astep) {
       const size_t ro = (size_t)sv.row[si], po = (size_t)sv.prow[si];
-      const long Rs = 2L * sv.T[si] - 1;
-      const char* qkv = (const char*)st->qkv + ro * 3 * d * esz;
+      const long Rs = sv.prow[si + astep] - sv.prow[si];
       char* dqkv = ws + bb.dqkv + ro * 3 * d * esz;
       emoasr_attn_t a{};
-      a.B = sv.B[si]; a.H = H; a.DK = d / H; a.Tq = sv.T[si]; a.Tk = sv.T[si];
-      a.ldq = a.ldk = a.ldv = 3 * d; a.ldo = d; a.ldp = d;
-      a.q = qkv;
-      a.k = qkv + (size_t)d * esz;
-      a.v = qkv + (size_t)2 * d * esz;
-      a.pos = (const char*)st->pp + po * d * esz; a.bias_u = L->bias_u; a.bias_v = L->bias_v;
-      a.klens = st->klens ? st->klens + sv.b0[si] : nullptr;
-      a.causal = 0; a.scale = 1.f / sqrtf((float)(d / H)); a.drop_p = st->p_att;
-      a.seed = st->seed[2] + 0x9E3779B97F4A7C15ull * (uint64_t)si;   // (as the forward)
+      attn_args_for(a, sv, si, si + astep, H, d, esz, st->qkv, st->pp, st->klens, st->seed[2]);
+      a.bias_u = L->bias_u; a.bias_v = L->bias_v; a.drop_p = st->p_att;
       a.out = (char*)st->o + ro * d * esz; a.lse = st->lse + ro * H;
       a.dout = ws + bb.dout + ro * d * esz; a.delta = (float*)(ws + bb.delta) + ro * H;
       a.dq = dqkv; a.dk = dqkv + (size_t)d * esz; a.dv = dqkv + (size_t)2 * d * esz;

@@ -180,8 +180,8 @@ class ConformerLayerRuntime:
         if segs is not None:
             assert len(segs) <= lib.MAX_SEGMENTS, f"at most {lib.MAX_SEGMENTS} stacked micro-batches"
             io.seg.n = len(segs)
-            for k, (b, t) in enumerate(segs):
-                io.seg.B[k], io.seg.T[k] = b, t
+            for k, (sb, stt) in enumerate(segs):
+                io.seg.B[k], io.seg.T[k] = sb, stt
         io.x = tb_prev(x, esz)
         io.pos_t, io.klens = pos_t.data_ptr(), elens.data_ptr()
         io.training, io.p_enc, io.p_att = int(training), p_enc, p_att

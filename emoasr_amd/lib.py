@@ -35,7 +35,8 @@ class AttnArgs(Structure):
                 ("pdT", c_void_p), ("dsT", c_void_p), ("dbd", c_void_p),
                 ("ldpd", c_long), ("ldbd", c_long), ("cs", c_void_p),
                 ("st", c_void_p), ("ldst", c_long),
-                ("qu", c_void_p), ("qv", c_void_p), ("dbias_part", c_void_p)]
+                ("qu", c_void_p), ("qv", c_void_p), ("dbias_part", c_void_p),
+                ("nseg", c_int), ("seg_b0", c_int * 9), ("seg_T", c_int * 8), ("seg_row", c_long * 9), ("seg_prow", c_long * 9)]
 
 
 class TnProblem(Structure):

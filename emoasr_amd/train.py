@@ -189,6 +189,58 @@ def train_step(model, optimizer, data, params, device, no_grad=False, empty_cach
     return loss_dict
 
 
+def stacked_ok(model, optimizer, params):
+    """can the accum_grad micro-batches of one optimizer step go through the engine TOGETHER (train_group)?"""
+    from .optimizers import Adam as HipAdam
+    from . import lib
+    base = getattr(optimizer, "optimizer", optimizer)
+    if not isinstance(base, HipAdam) or not hasattr(model, "engine"):
+        return False
+    if not (1 < params.accum_grad <= lib.MAX_SEGMENTS) or getattr(model, "decoder_type", "") != "ctc":
+        return False
+    if not next(model.parameters()).is_cuda:
+        return False
+    dec = model.decoder
+    if dec.kd_weight > 0 or dec.mtl_phone_ctc_weight > 0 or dec.mtl_inter_ctc_weight > 0:
+        return False
+    return model.training and model.engine().stacked_ok()
+
+
+def train_group(model, optimizer, datas, params, device, group=None, sync=True, specaug=None, empty_cache=False):
+    """The `accum_grad` micro-batches of ONE optimizer step (asr/train_asr.py:106-128: forward, loss / accum_grad, backward for
+    each, then clip / NaN skip / step / zero_grad) as one stacked pass through the engine (engine.ctc_train_stacked: every
+    row-wise kernel runs once over all micro-batches' rows; attention, convolution padding and BatchNorm statistics stay per
+    micro-batch).  Same result as len(datas) calls of train_step up to summation order; needs stacked_ok(...).
+    -> list of the micro-batches' loss_dicts (values / accum_grad, as train_step returns them)."""
+    world = _world(group)
+    if world > 1:
+        rank_dropout_seed(model, group)
+    eng = model.engine()
+    batches = []
+    for data in datas:
+        xs = data["xs"].to(device)
+        xlens = [int(v) for v in data["xlens"]]
+        ylens = [int(v) for v in data["ylens"]]
+        if specaug is not None:
+            xs = specaug(xs.float(), data["xlens"])
+        xs = xs[:, : max(xlens)].to(torch.float32).contiguous()
+        batches.append((xs, xlens, data["ys"][:, : max(ylens)], ylens))
+    accum = params.accum_grad
+    losses = eng.ctc_train_stacked(batches, model.decoder.blank_id, scales=[1.0 / accum] * len(batches))
+    base = getattr(optimizer, "optimizer", optimizer)
+    if world > 1:
+        allreduce_sum_(eng.arena.grad, group)
+    base.clip_grad_norm, base.grad_mult = params.clip_grad_norm, 1.0 / world
+    optimizer.step()
+    optimizer.zero_grad()
+    if empty_cache:
+        torch.cuda.empty_cache()
+    if sync:
+        host = (losses / accum).tolist()
+        return [{"loss_ctc": v, "loss_total": v} for v in host]
+    return [{"loss_ctc": losses[k] / accum, "loss_total": losses[k] / accum} for k in range(len(batches))]
+
+
 def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False, group=None, log=None):
     """One epoch of asr/train_asr.py:100-143: every accum_grad-th micro-batch steps the optimizer; the
     running loss_dict sums are logged every params.log_step optimizer steps (the only host
@@ -204,13 +256,26 @@ def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False
         from .data import SpecAugment
         specaug = SpecAugment(params)
     n_total = len(dataloader) // params.accum_grad if hasattr(dataloader, "__len__") else -1
+    # the accum_grad micro-batches of an optimizer step go through the engine together when the model allows it (a trailing
+    # incomplete group is accumulated and never stepped, exactly as the one-by-one loop leaves it)
+    stacked = stacked_ok(model, optimizer, params)
+    pending = []
     for accum_step, data in enumerate(dataloader):
         stepping = (accum_step + 1) % params.accum_grad == 0
-        loss_dict = train_step(model, optimizer, data, params, device, no_grad=not stepping,
-                               empty_cache=empty_cache and stepping, group=group, sync=False, specaug=specaug)
+        if stacked:
+            pending.append(data)
+            if not stepping:
+                continue
+            dicts = train_group(model, optimizer, pending, params, device, group=group, sync=False, specaug=specaug,
+                                empty_cache=empty_cache)
+            pending = []
+        else:
+            dicts = [train_step(model, optimizer, data, params, device, no_grad=not stepping,
+                                empty_cache=empty_cache and stepping, group=group, sync=False, specaug=specaug)]
         step += int(stepping)
-        for k, v in loss_dict.items():
-            sums[k] = sums[k] + v if k in sums else v
+        for loss_dict in dicts:
+            for k, v in loss_dict.items():
+                sums[k] = sums[k] + v if k in sums else v
         if stepping and step % params.log_step == 0:
             from . import lib
             if lib.size_query("emoasr_lstm_coop_status") > 0:   # (this is the loop's host synchronisation point anyway; -1: no device)
@@ -221,4 +286,6 @@ def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False
             detail = " ".join(f"{k}: {float(v) / params.log_step:.3f}" for k, v in sums.items())
             log(f"epoch = {(epoch + 1):>2} step = {step:>6} / {n_total:>6} lr = {optimizer._lr:.5f} " + detail)
             sums = {}
+    for data in pending:   # an incomplete last group: gradients accumulate, no update (train_asr.py:106-128)
+        train_step(model, optimizer, data, params, device, no_grad=True, group=group, sync=False, specaug=specaug)
     return step

@@ -180,6 +180,7 @@ int emoasr_layernorm_bwd_finalize(int n, const emoasr_ln_finalize_item_t* items,
  * (NULL: none).  causal != 0 adds the lower-triangular mask (decoder self-attn).
  * scores = ((q+u).k + (q+v).pos[i-j]) * scale; softmax; dropout(drop_p); .v
  * lse f32 [B,H,Tq] is saved for backward. */
+#define EMOASR_MAX_SEGMENTS 8
 typedef struct {
   int B, H, DK, Tq, Tk;
   long ldq, ldk, ldv, ldo, ldp;
@@ -221,6 +222,15 @@ typedef struct {
    * [B * ceil(Tq/32), H, 2, DK], folded by one small reduction instead of contended atomics. */
   void *qu, *qv;
   float* dbias_part;
+  /* optional: several stacked micro-batches ("segments", see emoasr_segments_t below) in ONE launch -- emoasr_attn_fwd and
+   * emoasr_attn_bwd_fused only, self-attention (Tq == Tk).  nseg > 1: segment s holds utterances seg_b0[s] .. seg_b0[s+1]-1,
+   * each padded to seg_T[s] frames; its rows start at row seg_row[s] of q / k / v / out / dout / dq / dk / dv (seg_row[nseg] =
+   * all rows), its relative-position table at row seg_prow[s] of pos / dpos; lse and delta are [H * rows]: segment s at
+   * H * seg_row[s], laid out [utterances, H, seg_T[s]].  B = all utterances, Tq = Tk = the longest segment, klens [B] in
+   * order.  The dropout mask index restarts in every segment (seed + s * 0x9E3779B97F4A7C15).  nseg <= 1: one dense batch. */
+  int nseg;
+  int seg_b0[EMOASR_MAX_SEGMENTS + 1], seg_T[EMOASR_MAX_SEGMENTS];
+  long seg_row[EMOASR_MAX_SEGMENTS + 1], seg_prow[EMOASR_MAX_SEGMENTS + 1];
 } emoasr_attn_t;
 int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream);
 int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream);
@@ -231,6 +241,8 @@ int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream);
  * st / qu / qv / dbias_part fields are ignored.  `ws`: emoasr_attn_bwd_fused_ws_bytes(...) bytes of scratch, no
  * initialisation needed.  Reference: transformer.py:73-94, conformer.py:77-95 (their autograd backward). */
 size_t emoasr_attn_bwd_fused_ws_bytes(int dtype, int B, int H, int Tq, int Tk, int rel);
+/* the same for `rows` rows in all (stacked micro-batches: the segments' rows together, Tk = the longest segment) */
+size_t emoasr_attn_bwd_fused_ws_bytes_rows(int dtype, long rows, int H, int Tk, int rel);
 int emoasr_attn_bwd_fused(int dtype, const emoasr_attn_t* a, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Conformer convolution module (conformer.py:98-143) ---------------------- */
@@ -470,7 +482,6 @@ typedef struct emoasr_ffn_stash {
  * utterance, the depthwise convolution sees each segment's own zero padding and BatchNorm takes its batch statistics PER
  * SEGMENT and updates the running statistics once per segment, in order -- the arithmetic of the separate passes.
  * n = 0 (or 1 with B[0], T[0]): one dense batch. */
-#define EMOASR_MAX_SEGMENTS 8
 typedef struct emoasr_segments {
   int n;
   int B[EMOASR_MAX_SEGMENTS], T[EMOASR_MAX_SEGMENTS];

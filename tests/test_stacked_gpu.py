@@ -1,0 +1,189 @@
+"""Stacked micro-batches (engine.ctc_train_stacked / train.train_group): the `accum_grad` micro-batches of one optimizer step
+through the engine in ONE pass -- rows concatenated for the row-wise kernels, attention / convolution padding / BatchNorm
+statistics per micro-batch -- against the same micro-batches run one after the other through the module API, which is what
+the reference does (asr/train_asr.py:106-128) and what the goldens pin.
+
+bf16, dropout 0: losses equal to 1e-3, every parameter gradient to cosine 0.999 and 2 % of its norm (summation order differs:
+split-K slices and LayerNorm partial sums follow the row count), BatchNorm running statistics to 1e-4, num_batches_tracked
+exactly; then three optimizer steps of train.train vs the one-by-one loop."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(input_layer="conv2d", feat_dim=80, num_framestacks=1, encoder_type="conformer", decoder_type="ctc",
+           pos_encode_type="rel", enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=3,
+           enc_intermediate_size=512, dropout_enc_rate=0.0, dropout_attn_rate=0.0, vocab_size=96, blank_id=0,
+           eos_id=2, kd_weight=0, lr_schedule_type="noam", learning_rate=1.0, num_warmup_steps=10, accum_grad=3,
+           clip_grad_norm=5.0, weight_decay=1e-6, log_step=100)
+
+
+def _batch(seed, xlens):
+    g = torch.Generator().manual_seed(seed)
+    xlens = torch.tensor(xlens)
+    ylens = torch.clamp(xlens // 40, min=1)
+    B, T, L = len(xlens), int(xlens.max()), int(ylens.max())
+    xs = torch.randn(B, T, 80, generator=g)
+    ys = torch.randint(3, CFG["vocab_size"], (B, L), generator=g)
+    for b in range(B):
+        xs[b, xlens[b]:] = 0
+        ys[b, ylens[b]:] = 2
+    return dict(xs=xs, xlens=xlens, ys=ys, ylens=ylens, ys_in=None, ys_out=None)
+
+
+def _micro_batches():
+    # different batch sizes AND different padded lengths (T' = 49 / 99 / 74), ragged utterances inside each
+    return [_batch(1, [203, 187, 150, 96]), _batch(2, [403, 380]), _batch(3, [303, 290, 221])]
+
+
+def _model(dev, **over):
+    from emoasr_amd.modeling.asr import ASR
+    torch.manual_seed(0)
+    model = ASR(SimpleNamespace(**dict(CFG, **over)), compute_dtype=torch.bfloat16)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "batch_norm" in n or ".norm" in n:
+                p.add_(0.05 * torch.randn_like(p))
+    return model.to(dev).train()
+
+
+def _cos(a, b):
+    a, b = a.flatten().float(), b.flatten().float()
+    return (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
+
+
+def test_stacked_pass_equals_the_separate_passes(dev):
+    model = _model(dev)
+    eng = model.engine()
+    assert eng.stacked_ok()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    datas = _micro_batches()
+    n = len(datas)
+    # ---- one after the other (module API, autograd): loss / n each
+    eng.arena.grad.zero_()
+    want_losses = []
+    for data in datas:
+        loss, _ = model(data["xs"].to(dev), data["xlens"], data["ys"], data["ylens"], None, None)
+        (loss / n).backward()
+        want_losses.append(loss.item())
+    want_grad = eng.arena.grad.clone()
+    want_bufs = {k: v.detach().clone() for k, v in model.state_dict().items() if "running" in k or "tracked" in k}
+    # ---- stacked, from the same state
+    model.load_state_dict(sd0)
+    eng.arena.grad.zero_()
+    batches = [(d["xs"].to(dev), [int(v) for v in d["xlens"]], d["ys"], [int(v) for v in d["ylens"]]) for d in datas]
+    losses = eng.ctc_train_stacked(batches, 0)
+    torch.cuda.synchronize()
+    got = losses.tolist()
+    for a, b in zip(got, want_losses):
+        assert abs(a - b) < 1e-3 * abs(b), (got, want_losses)
+    A = eng.arena
+    worst = (1.0, "")
+    for name in A.names:
+        o, k = A.offsets[name], A.pviews[name].numel()
+        g, w = A.grad[o:o + k], want_grad[o:o + k]
+        if w.abs().max() == 0:
+            assert g.abs().max() == 0, name
+            continue
+        cos = _cos(g, w)
+        worst = min(worst, (cos, name))
+        assert cos > 0.999, (name, cos)
+        assert abs(g.norm().item() / w.norm().item() - 1) < 2e-2, (name, g.norm().item(), w.norm().item())
+    print("stacked vs separate: worst gradient cosine", worst)
+    for k, v in model.state_dict().items():
+        if "tracked" in k:
+            assert torch.equal(v, want_bufs[k]), k                 # one BatchNorm update per micro-batch
+        elif "running" in k:
+            err = (v - want_bufs[k]).abs().max().item() / (want_bufs[k].abs().max().item() + 1e-12)
+            assert err < 1e-4, (k, err)
+
+
+def test_stacked_pass_with_dropout_is_reproducible_and_finite(dev):
+    model = _model(dev, dropout_enc_rate=0.1, dropout_attn_rate=0.1)
+    eng = model.engine()
+    datas = _micro_batches()
+    same = [datas[0], datas[0]]   # the same micro-batch twice: independent dropout masks -> different losses
+    batches = [(d["xs"].to(dev), [int(v) for v in d["xlens"]], d["ys"], [int(v) for v in d["ylens"]]) for d in same]
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def run():
+        model.load_state_dict(sd0)
+        eng.step_count = 11
+        eng.arena.grad.zero_()
+        losses = eng.ctc_train_stacked(batches, 0)
+        return losses.tolist(), eng.arena.grad.clone()
+
+    l1, g1 = run()
+    l2, g2 = run()
+    assert l1 == l2 and l1[0] != l1[1], (l1, l2)
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    assert (g1 - g2).abs().max().item() < 2e-3 * g1.abs().max().item()   # (float atomics in the weight gradients)
+
+
+def test_train_loop_takes_the_stacked_path(dev, monkeypatch):
+    """train.train with accum_grad 3: two optimizer steps through train_group == six train_step calls"""
+    from emoasr_amd import train as tr
+    from emoasr_amd.optimizers import Adam, ScheduledOptimizer
+    datas = _micro_batches() + [_batch(4, [250, 240, 100]), _batch(5, [150, 140, 130, 120, 80]), _batch(6, [403])]
+    params = SimpleNamespace(**CFG)
+
+    def run(stacked):
+        monkeypatch.setenv("EMOASR_STACKED", "1" if stacked else "0")
+        model = _model(dev)
+        opt = ScheduledOptimizer(Adam(model.parameters(), lr=0, weight_decay=params.weight_decay), params)
+        calls = {"group": 0}
+        orig = tr.train_group
+
+        def counting(*a, **k):
+            calls["group"] += 1
+            return orig(*a, **k)
+
+        monkeypatch.setattr(tr, "train_group", counting)
+        steps = tr.train(model, opt, datas, params, dev, 0)
+        monkeypatch.setattr(tr, "train_group", orig)
+        assert steps == 2 and calls["group"] == (2 if stacked else 0), (steps, calls)
+        return model.engine().arena.flat.clone(), opt.state_dict()["_step"]
+
+    p_stacked, s1 = run(True)
+    p_single, s2 = run(False)
+    assert s1 == s2 == 2
+    # Adam's first updates are sign-like (m / sqrt(v) = +-1 whatever the gradient's size), so parameters whose gradient is at
+    # the noise level may move the opposite way: compare the update VECTORS, not element-wise maxima
+    p0 = _model(dev).engine().arena.flat
+    u1, u2 = p_stacked - p0, p_single - p0
+    cos = _cos(u1, u2)
+    rel = ((u1 - u2).norm() / u2.norm()).item()
+    print(f"parameter updates after 2 steps, stacked vs one-by-one: cosine {cos:.5f}, relative L2 distance {rel:.3e}")
+    assert u2.abs().max() > 0 and cos > 0.98 and rel < 0.2, (cos, rel)
+
+
+def test_one_launch_per_kernel_equals_one_launch_per_segment(dev):
+    """option "stack_launch": the per-utterance kernels (attention forward / backward, ...) take all stacked micro-batches in
+    ONE launch, their segment table in the arguments (1, default), or run once per segment (0).  Same arithmetic, same dropout
+    streams: losses identical, gradients equal up to the float atomics of the weight-gradient split-K."""
+    from emoasr_amd import lib
+    model = _model(dev, dropout_enc_rate=0.1, dropout_attn_rate=0.1)
+    eng = model.engine()
+    datas = _micro_batches()
+    batches = [(d["xs"].to(dev), [int(v) for v in d["xlens"]], d["ys"], [int(v) for v in d["ylens"]]) for d in datas]
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def run(flag):
+        lib.set_option("stack_launch", flag)
+        try:
+            model.load_state_dict(sd0)
+            eng.step_count = 5
+            eng.arena.grad.zero_()
+            losses = eng.ctc_train_stacked(batches, 0)
+            torch.cuda.synchronize()
+            return losses.tolist(), eng.arena.grad.clone()
+        finally:
+            lib.set_option("stack_launch", 1)
+
+    l1, g1 = run(1)
+    l0, g0 = run(0)
+    assert l1 == l0, (l1, l0)
+    scale = g0.abs().max().item()
+    assert scale > 0 and (g1 - g0).abs().max().item() < 2e-3 * scale, (g1 - g0).abs().max().item() / scale

@@ -12,8 +12,10 @@ M = int(os.environ.get("M", 7200))
 dt = torch.bfloat16
 shapes_nt = [("ffn1", M, 1024, 256), ("ffn2", M, 256, 1024), ("qkv", M, 768, 256), ("out", M, 256, 256),
              ("pw1", M, 512, 256), ("head", M, 10000, 256), ("lin", M, 256, 4864)]
+if os.environ.get("NO_DCOL"):
+    pass
 shapes_nn = [("d_ffn2", M, 1024, 256), ("d_ffn1", M, 256, 1024), ("d_qkv", M, 256, 768), ("d_out", M, 256, 256),
-             ("d_head", M, 256, 10000), ("d_lin", M, 4864, 256), ("dcol", M * 19, 2304, 256)]
+             ("d_pw1", M, 256, 512), ("d_head", M, 256, 10000), ("d_lin", M, 4864, 256)]
 shapes_tn = [("w_ffn1", 1024, 256, M), ("w_ffn2", 256, 1024, M), ("w_qkv", 768, 256, M), ("w_out", 256, 256, M),
              ("w_head", 10000, 256, M), ("w_lin", 256, 4864, M)]
 
@@ -32,15 +34,19 @@ for name, m, n, k in shapes_nt:
     a, b = rnd(m, k), rnd(n, k); out = torch.empty(m, n, device=dev, dtype=dt); bias = torch.randn(n, device=dev)
     us = timeit(lambda: ops.gemm_nt(a, b, out=out, bias=bias))
     tot += us
-    print(f"nt {name:8s} {m}x{n}x{k}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TF/s  {(m*k+n*k+m*n)*2/us/1e3:7.1f} GB/s")
+    ub = timeit(lambda: torch.mm(a, b.t(), out=out)) if os.environ.get("BLAS") else 0.0   # reference point only (hipBLASLt)
+    print(f"nt {name:8s} {m}x{n}x{k}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TF/s  {(m*k+n*k+m*n)*2/us/1e3:7.1f} GB/s   blas {ub:8.1f} us")
 for name, m, n, k in shapes_nn:
     a, b = rnd(m, k), rnd(k, n); out = torch.empty(m, n, device=dev, dtype=dt)
     us = timeit(lambda: ops.gemm_nn(a, b, out=out))
     tot += us
-    print(f"nn {name:8s} {m}x{n}x{k}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TF/s  {(m*k+n*k+m*n)*2/us/1e3:7.1f} GB/s")
+    ub = timeit(lambda: torch.mm(a, b, out=out)) if os.environ.get("BLAS") else 0.0
+    print(f"nn {name:8s} {m}x{n}x{k}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TF/s  {(m*k+n*k+m*n)*2/us/1e3:7.1f} GB/s   blas {ub:8.1f} us")
 for name, n1, n2, k in shapes_tn:
     a, b = rnd(k, n1), rnd(k, n2); out = torch.zeros(n1, n2, device=dev); cs = torch.zeros(n1, device=dev)
     us = timeit(lambda: ops.gemm_tn(a, b, out=out, accumulate=True, colsum=cs))
     tot += us
-    print(f"tn {name:8s} {n1}x{n2}x{k}: {us:8.1f} us  {2*n1*n2*k/us/1e6:7.1f} TF/s")
+    ob = torch.zeros(n1, n2, device=dev, dtype=dt)
+    ub = timeit(lambda: torch.mm(a.t(), b, out=ob)) if os.environ.get("BLAS") else 0.0
+    print(f"tn {name:8s} {n1}x{n2}x{k}: {us:8.1f} us  {2*n1*n2*k/us/1e6:7.1f} TF/s   blas {ub:8.1f} us")
 print(f"sum {tot:.1f} us")
