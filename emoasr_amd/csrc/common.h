@@ -376,3 +376,23 @@ enum { EMO_F32 = 0, EMO_BF16 = 1 };
     else if ((dtype) == EMO_BF16) { typedef bf16 T; __VA_ARGS__; }      \
     else { emo_set_error("bad dtype %d", (int)(dtype)); return 1; }     \
   } while (0)
+
+// Stacked micro-batches for the per-utterance kernels of the convolution module (include/emoasr_hip.h: emoasr_segments_t):
+// segment s = utterances b0[s] .. b0[s+1]-1, each padded to T[s] frames, rows row[s] .. row[s+1]-1 of the stacked [M, C] arrays;
+// part[s] / sums[s] = first float / first partial row of its area in the BatchNorm forward / backward partial-sum tables.
+// n <= 1: one dense batch (the kernels ignore the table).  Passed BY VALUE as a kernel argument (constant memory).
+struct RowSegs {
+  int n;
+  int b0[9], T[8];
+  long row[9], part[9], sums[9];
+};
+__device__ __forceinline__ int rowsegs_of_utt(const RowSegs& sg, int b) {
+  int s = 0;
+  for (int k = 1; k < 8; ++k) s += (k < sg.n && b >= sg.b0[k]) ? 1 : 0;
+  return s;
+}
+__device__ __forceinline__ int rowsegs_of_row(const RowSegs& sg, long row) {
+  int s = 0;
+  for (int k = 1; k < 8; ++k) s += (k < sg.n && row >= sg.row[k]) ? 1 : 0;
+  return s;
+}

@@ -17,6 +17,7 @@
 // one workgroup per CU (62 x 8 sigmoids per thread in the staging pass, quarter-rate exp / rcp), not by memory.  The
 // training step is unchanged within noise (9.69 vs 9.71 ms); the fused path is the default because it needs three [M, C]
 // buffers and five launches per layer less.
+#include <algorithm>
 #include "common.h"
 #include "../../include/emoasr_hip.h"
 
@@ -49,13 +50,25 @@ __device__ __forceinline__ unsigned lds_pair(const bf16* base, int row, int pair
 template <bool GLU>
 __global__ __launch_bounds__(CF_CB) void cf_dwconv_kernel(int Tn, int C, int K, const bf16* __restrict__ x,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
-                                                        bf16* __restrict__ y, int flip, float* __restrict__ part) {
+                                                        bf16* __restrict__ y, int flip, float* __restrict__ part,
+                                                        const RowSegs sg) {
   __shared__ __attribute__((aligned(16))) bf16 zs[CF_ROWS_P * CF_CB];
   __shared__ __attribute__((aligned(16))) bf16 os[CF_TT * CF_CB];    // the output tile (stored rows, BatchNorm partials)
   const int tid = threadIdx.x;
   const int cb = blockIdx.y * CF_CB;                 // first channel of this workgroup
-  const int b = blockIdx.z, t0 = blockIdx.x * CF_TT, pad = (K - 1) / 2;
   const int ldx = GLU ? 2 * C : C;
+  int b = blockIdx.z, nx = gridDim.x;
+  if (sg.n > 1) {   // stacked micro-batches: this utterance's segment (own padded length, own partial-statistics table)
+    const int si = rowsegs_of_utt(sg, b);
+    Tn = sg.T[si];
+    x += sg.row[si] * ldx;
+    y += sg.row[si] * C;
+    if (part) part += sg.part[si];
+    b -= sg.b0[si];
+    nx = (Tn + CF_TT - 1) / CF_TT;
+    if ((int)blockIdx.x >= nx) return;   // (the grid follows the longest segment)
+  }
+  const int t0 = blockIdx.x * CF_TT, pad = (K - 1) / 2;
   const int nch = min(CF_CB, C - cb);                // channels present (multiple of 8)
   // ---- this thread's taps: w[ch][K] is read once, coalesced, through LDS (per-thread reads of w[ch * K + j] are 64
   //      different cache lines per wave-instruction: 62 such gathers per thread cost more than the convolution) ----
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(CF_CB) void cf_dwconv_kernel(int Tn, int C, int K, 
       const float d = out[i] - mb;
       m2 += i < n ? d * d : 0.f;
     }
-    float* p = part + ((long)b * gridDim.x + blockIdx.x) * 2 * C + cb + tid;
+    float* p = part + ((long)b * nx + blockIdx.x) * 2 * C + cb + tid;
     p[0] = s;
     p[C] = m2;
   }
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(CF_CB) void cf_conv_bwd_kernel(int Tn, int C, int K
                                                           const float* __restrict__ beta, float eps,
                                                           const float* __restrict__ tot, const bf16* __restrict__ g,
                                                           const float* __restrict__ w, bf16* __restrict__ dg,
-                                                          float* __restrict__ wpart) {
+                                                          float* __restrict__ wpart, const RowSegs sg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* dcs = reinterpret_cast<bf16*>(smem);                       // [64][CB]  BatchNorm input gradient (tile + halo)
   bf16* zs = dcs + CF_ROWS_P * CF_CB;                                // [64][CB]  GLU output (tile + halo)
@@ -166,8 +179,24 @@ __global__ __launch_bounds__(CF_CB) void cf_conv_bwd_kernel(int Tn, int C, int K
   bf16* gbs = gas + CF_TT * CF_CB;                                   // [32][CB]  g[:, C:]
   const int tid = threadIdx.x;
   const int cb = blockIdx.y * CF_CB;
-  const int b = blockIdx.z, t0 = blockIdx.x * CF_TT, pad = (K - 1) / 2;
   const int nch = min(CF_CB, C - cb);
+  int b = blockIdx.z;
+  if (sg.n > 1) {   // stacked micro-batches: this utterance's segment (own padded length, batch statistics and means)
+    const int si = rowsegs_of_utt(sg, b);
+    Tn = sg.T[si];
+    ds += sg.row[si] * C; cv += sg.row[si] * C; g += sg.row[si] * 2 * C; dg += sg.row[si] * 2 * C;
+    mean += (long)si * C; var += (long)si * C; tot += (long)si * 2 * C;
+    b -= sg.b0[si];
+    if ((int)blockIdx.x * CF_TT >= Tn) {
+      // (the grid follows the longest segment: this block has no frames, but its slot of the weight-gradient partial table is
+      // summed by the reduce kernel like every other)
+      float* p = wpart + ((long)blockIdx.z * gridDim.x + blockIdx.x) * (K + 1) * C + cb + tid;
+      if (tid < nch)
+        for (int j = 0; j <= K; ++j) p[(long)j * C] = 0.f;
+      return;
+    }
+  }
+  const int t0 = blockIdx.x * CF_TT, pad = (K - 1) / 2;
   const int ch8 = (tid & (CF_CB / 8 - 1)) * 8;
   const bool chok = ch8 < nch;
   const int pr = tid & (CF_CB / 2 - 1), half = tid / (CF_CB / 2);
@@ -312,7 +341,7 @@ extern "C" int emoasr_glu_dwconv_fwd(int dtype, int B, int Tn, int C, int K, con
   EMO_CHECK((long)Tn * 2 * C * 2 < (1L << 32), "glu_dwconv_fwd: utterance larger than 4 GiB");
   if (B * Tn == 0) return 0;
   dim3 grid(cdiv(Tn, CF_TT), cdiv(C, CF_CB), B);
-  cf_dwconv_kernel<true><<<grid, CF_CB, 0, (hipStream_t)stream>>>(Tn, C, K, (const bf16*)g, w, bias, (bf16*)c, 0, part);
+  cf_dwconv_kernel<true><<<grid, CF_CB, 0, (hipStream_t)stream>>>(Tn, C, K, (const bf16*)g, w, bias, (bf16*)c, 0, part, RowSegs{});
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -322,7 +351,7 @@ extern "C" int emoasr_glu_dwconv_fwd(int dtype, int B, int Tn, int C, int K, con
 int emo_dwconv_lds(int B, int Tn, int C, int K, const void* x, const float* w, const float* bias, void* y, int flip,
                    float* part, hipStream_t s) {
   dim3 grid(cdiv(Tn, CF_TT), cdiv(C, CF_CB), B);
-  cf_dwconv_kernel<false><<<grid, CF_CB, 0, s>>>(Tn, C, K, (const bf16*)x, w, bias, (bf16*)y, flip, part);
+  cf_dwconv_kernel<false><<<grid, CF_CB, 0, s>>>(Tn, C, K, (const bf16*)x, w, bias, (bf16*)y, flip, part, RowSegs{});
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -350,7 +379,103 @@ extern "C" int emoasr_conv_bwd_fused(int dtype, int B, int Tn, int C, int K, con
   }
   dim3 grid(cdiv(Tn, CF_TT), cdiv(C, CF_CB), B);
   cf_conv_bwd_kernel<<<grid, CF_CB, bytes, s>>>(Tn, C, K, (const bf16*)ds, (const bf16*)cv, mean, var, gamma, beta, eps, tot,
-                                              (const bf16*)g, w, (bf16*)dg, scratch);
+                                              (const bf16*)g, w, (bf16*)dg, scratch, RowSegs{});
   EMO_LAUNCH_CHECK();
   return emo_dwconv_bwd_w_reduce(grid.x * B, C, K, scratch, dw, dbias, s);
+}
+
+// ---- the convolution module's per-utterance part for STACKED micro-batches (emoasr_segments_t): every kernel takes all segments
+// in one launch.  Same arithmetic as calling the entry points above once per segment, in order. -------------------------------
+int emo_bn_stats_finalize_seg(const RowSegs& sg, int C, const float* part, float* mean, float* var, float* running_mean,
+                              float* running_var, float momentum, long long* nbt, hipStream_t s);                    // convmodule.hip
+int emo_bn_swish_fwd_seg(const RowSegs& sg, int C, const void* y, const float* mean, const float* var, const float* gamma,
+                         const float* beta, float eps, void* z, hipStream_t s);                                       // convmodule.hip
+int emo_bn_swish_bwd_sums_seg(const RowSegs& sg, int C, const void* dz, const void* y, const float* mean, const float* var,
+                              const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta, float* scratch,
+                              float** tot_out, hipStream_t s);                                                        // convmodule.hip
+
+namespace {
+bool row_segs(const emoasr_segments_t* seg, int C, RowSegs* out, int* tmax) {
+  if (!seg || seg->n < 1 || seg->n > EMOASR_MAX_SEGMENTS) return false;
+  RowSegs sg{};
+  sg.n = seg->n;
+  *tmax = 0;
+  for (int i = 0; i < seg->n; ++i) {
+    if (seg->B[i] <= 0 || seg->T[i] <= 0) return false;
+    sg.b0[i + 1] = sg.b0[i] + seg->B[i];
+    sg.T[i] = seg->T[i];
+    sg.row[i + 1] = sg.row[i] + (long)seg->B[i] * seg->T[i];
+    sg.part[i + 1] = sg.part[i] + emoasr_dwconv_stats_floats(seg->B[i], seg->T[i], C);
+    sg.sums[i + 1] = sg.sums[i] + (emoasr_bn_swish_bwd_scratch_floats(seg->B[i] * seg->T[i], C) / (2 * C) - 1);
+    *tmax = std::max(*tmax, seg->T[i]);
+  }
+  *out = sg;
+  return true;
+}
+}  // namespace
+
+// c = depthwise_conv(GLU(g)) per segment, BatchNorm batch statistics per segment (training: bmean / bvar [n, C], the running
+// statistics updated once per segment in order; eval: the running statistics), z = Swish(BatchNorm(c)).  g [M, 2C], c / z [M, C],
+// part: sum over the segments of emoasr_dwconv_stats_floats(B[s], T[s], C) floats.  conformer.py:126-133.
+extern "C" int emoasr_conv_module_fwd_seg(int dtype, const emoasr_segments_t* seg, int C, int K, const void* g, const float* w,
+                                          const float* bias, void* c, float* part, float* bmean, float* bvar, float* running_mean,
+                                          float* running_var, float momentum, long long* num_batches_tracked, const float* gamma,
+                                          const float* beta, float eps, void* z, int training, void* stream) {
+  EMO_CHECK(dtype == EMO_BF16, "conv_module_fwd_seg: bf16 only");
+  EMO_CHECK(K <= CF_MAXK && (K & 1) && C % 8 == 0, "conv_module_fwd_seg: K=%d (odd, <= %d), C=%d (multiple of 8)", K, CF_MAXK, C);
+  RowSegs sg;
+  int tmax = 0;
+  EMO_CHECK(row_segs(seg, C, &sg, &tmax), "conv_module_fwd_seg: bad segment description");
+  EMO_CHECK((long)tmax * 2 * C * 2 < (1L << 32) && sg.row[sg.n] * 2 * C * 2 < (1L << 46), "conv_module_fwd_seg: batch too large");
+  EMO_CHECK(!training || (part && bmean && bvar), "conv_module_fwd_seg: training needs the BatchNorm buffers");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(tmax, CF_TT), cdiv(C, CF_CB), sg.b0[sg.n]);
+  cf_dwconv_kernel<true><<<grid, CF_CB, 0, s>>>(tmax, C, K, (const bf16*)g, w, bias, (bf16*)c, 0, training ? part : nullptr, sg);
+  EMO_LAUNCH_CHECK();
+  if (training) {
+    if (emo_bn_stats_finalize_seg(sg, C, part, bmean, bvar, running_mean, running_var, momentum, num_batches_tracked, s)) return 1;
+    return emo_bn_swish_fwd_seg(sg, C, c, bmean, bvar, gamma, beta, eps, z, s);
+  }
+  RowSegs one{};   // eval: the same (running) statistics for every row
+  one.n = 1; one.b0[1] = sg.b0[sg.n]; one.row[1] = sg.row[sg.n];
+  return emo_bn_swish_fwd_seg(one, C, c, running_mean, running_var, gamma, beta, eps, z, s);
+}
+
+// scratch of emoasr_conv_module_bwd_seg: which = 0 the BatchNorm partial sums + means (floats), 1 the depthwise weight-gradient
+// partials (floats)
+extern "C" long emoasr_conv_module_bwd_seg_scratch_floats(const emoasr_segments_t* seg, int C, int K, int which) {
+  RowSegs sg;
+  int tmax = 0;
+  if (!row_segs(seg, C, &sg, &tmax)) return 0;
+  if (which == 0) return (sg.sums[sg.n] + sg.n) * 2 * C;
+  return emoasr_dwconv_bwd_w_scratch_floats(sg.b0[sg.n], tmax, C, K);
+}
+
+// dz (gradient w.r.t. the Swish output) -> dg [M, 2C] through BatchNorm(training, per-segment statistics) / Swish, the depthwise
+// convolution and the GLU; dgamma / dbeta / dw / dbias accumulated.  Autograd of conformer.py:126-133.
+extern "C" int emoasr_conv_module_bwd_seg(int dtype, const emoasr_segments_t* seg, int C, int K, const void* dz, const void* c,
+                                          const float* bmean, const float* bvar, const float* gamma, const float* beta, float eps,
+                                          float* dgamma, float* dbeta, const void* g, const float* w, void* dg, float* dw,
+                                          float* dbias, float* bn_scratch, float* dw_scratch, void* stream) {
+  EMO_CHECK(dtype == EMO_BF16, "conv_module_bwd_seg: bf16 only");
+  EMO_CHECK(K <= CF_MAXK && (K & 1) && C % 8 == 0, "conv_module_bwd_seg: K=%d (odd, <= %d), C=%d (multiple of 8)", K, CF_MAXK, C);
+  EMO_CHECK(bn_scratch && dw_scratch, "conv_module_bwd_seg: scratch required");
+  RowSegs sg;
+  int tmax = 0;
+  EMO_CHECK(row_segs(seg, C, &sg, &tmax), "conv_module_bwd_seg: bad segment description");
+  hipStream_t s = (hipStream_t)stream;
+  float* tot = nullptr;
+  if (emo_bn_swish_bwd_sums_seg(sg, C, dz, c, bmean, bvar, gamma, beta, eps, dgamma, dbeta, bn_scratch, &tot, s)) return 1;
+  constexpr int bytes = (2 * CF_ROWS_P + 2 * CF_TT) * CF_CB * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)cf_conv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { emo_set_error("hipFuncSetAttribute(%d): %s", bytes, hipGetErrorString(e)); return 1; }
+    attr_done = true;
+  }
+  dim3 grid(cdiv(tmax, CF_TT), cdiv(C, CF_CB), sg.b0[sg.n]);
+  cf_conv_bwd_kernel<<<grid, CF_CB, bytes, s>>>(tmax, C, K, (const bf16*)dz, (const bf16*)c, bmean, bvar, gamma, beta, eps, tot,
+                                              (const bf16*)g, w, (bf16*)dg, dw_scratch, sg);
+  EMO_LAUNCH_CHECK();
+  return emo_dwconv_bwd_w_reduce(grid.x * sg.b0[sg.n], C, K, dw_scratch, dw, dbias, s);
 }

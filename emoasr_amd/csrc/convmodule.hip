@@ -3,6 +3,7 @@
 // over ALL B*T rows -- the reference never masks padded frames), Swish.
 // Channels-last activations [B, T, C]: threads run along C so every global access
 // is a coalesced row segment; the time window slides in registers.
+#include <algorithm>
 #include "common.h"
 #include "../../include/emoasr_hip.h"
 
@@ -71,53 +72,63 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const
 // running_var gets the unbiased M2 / (M - 1) like nn.BatchNorm1d.  One block = 16 channels x 64
 // groups of partial blocks (16 blocks for C = 256: the partial table is walked in 7 steps, not 28).
 constexpr int BNF_CH = 16, BNF_G = 64;  // channels x groups of partial blocks per finalize block
-__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B, int Tn, int C, const float* __restrict__ part,
-                                                                 float* __restrict__ mean, float* __restrict__ var,
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B_, int Tn_, int C, const float* __restrict__ part_,
+                                                                 float* __restrict__ mean_, float* __restrict__ var_,
                                                                  float* __restrict__ running_mean,
                                                                  float* __restrict__ running_var, float momentum,
-                                                                 long long* __restrict__ num_batches_tracked) {
+                                                                 long long* __restrict__ num_batches_tracked, const RowSegs sg) {
   __shared__ float red[BNF_G][BNF_CH];
   __shared__ float mean_s[BNF_CH];
   const int lane = threadIdx.x % BNF_CH, grp = threadIdx.x / BNF_CH;
   const int c = blockIdx.x * BNF_CH + lane;
-  const int nx = (Tn + DW_TT - 1) / DW_TT, nblk = B * nx;
-  const float M = (float)B * Tn;
-  float s = 0.f;
-  if (c < C) {
+  // stacked micro-batches: one set of statistics per segment, the running statistics move once per segment IN ORDER (the
+  // arithmetic of the separate passes); sg.n <= 1: the one dense batch (B_, Tn_)
+  const int ns = sg.n > 1 ? sg.n : 1;
+  for (int si = 0; si < ns; ++si) {
+    const int B = sg.n > 1 ? sg.b0[si + 1] - sg.b0[si] : B_, Tn = sg.n > 1 ? sg.T[si] : Tn_;
+    const float* part = sg.n > 1 ? part_ + sg.part[si] : part_;
+    float* mean = mean_ + (long)si * C;
+    float* var = var_ + (long)si * C;
+    const int nx = (Tn + DW_TT - 1) / DW_TT, nblk = B * nx;
+    const float M = (float)B * Tn;
+    float s = 0.f;
+    if (c < C) {
 #pragma unroll 8
-    for (int k = grp; k < nblk; k += BNF_G) s += part[(long)k * 2 * C + c];
-  }
-  red[grp][lane] = s;
-  __syncthreads();
-  if (grp == 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int g = 0; g < BNF_G; ++g) t += red[g][lane];
-    mean_s[lane] = t / M;
-  }
-  __syncthreads();
-  const float mu = mean_s[lane];
-  float m2 = 0.f;
-  if (c < C)
-#pragma unroll 8
-    for (int k = grp; k < nblk; k += BNF_G) {
-      const int n = min(DW_TT, Tn - (k % nx) * DW_TT);
-      const float d = part[(long)k * 2 * C + c] / n - mu;
-      m2 += part[(long)k * 2 * C + C + c] + n * d * d;
+      for (int k = grp; k < nblk; k += BNF_G) s += part[(long)k * 2 * C + c];
     }
-  __syncthreads();
-  red[grp][lane] = m2;
-  __syncthreads();
-  if (grp == 0 && c < C) {
-    float t = 0.f;
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0) {
+      float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < BNF_G; ++g) t += red[g][lane];
-    mean[c] = mu;
-    var[c] = t / M;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (M > 1.f ? t / (M - 1.f) : t / M);
+      for (int g = 0; g < BNF_G; ++g) t += red[g][lane];
+      mean_s[lane] = t / M;
+    }
+    __syncthreads();
+    const float mu = mean_s[lane];
+    float m2 = 0.f;
+    if (c < C)
+#pragma unroll 8
+      for (int k = grp; k < nblk; k += BNF_G) {
+        const int n = min(DW_TT, Tn - (k % nx) * DW_TT);
+        const float d = part[(long)k * 2 * C + c] / n - mu;
+        m2 += part[(long)k * 2 * C + C + c] + n * d * d;
+      }
+    __syncthreads();
+    red[grp][lane] = m2;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < BNF_G; ++g) t += red[g][lane];
+      mean[c] = mu;
+      var[c] = t / M;
+      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+      if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (M > 1.f ? t / (M - 1.f) : t / M);
+    }
+    __syncthreads();   // (red / mean_s are reused by the next segment)
   }
-  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += ns;
 }
 
 // dw[c,j] += sum_{b,t} dy[b,t,c] * x[b,t+j-pad,c];  dbias[c] += sum dy
@@ -233,10 +244,12 @@ __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(long n, int C, const 
                                                            const float* __restrict__ var,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps,
-                                                           T* __restrict__ z) {
+                                                           T* __restrict__ z, const RowSegs sg) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int c = i % C;
-    const float xh = (to_f32(y[i]) - mean[c]) * rsqrtf(var[c] + eps);
+    // stacked micro-batches: the statistics of the row's segment ([n, C] tables)
+    const long so = sg.n > 1 ? (long)rowsegs_of_row(sg, i / C) * C : 0;
+    const float xh = (to_f32(y[i]) - mean[so + c]) * rsqrtf(var[so + c] + eps);
     z[i] = from_f32<T>(swishf_(gamma[c] * xh + beta[c]));
   }
 }
@@ -257,11 +270,20 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(int M, int C, const T*
                                                           const float* __restrict__ var,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, const RowSegs sg) {
   __shared__ float red[8][2][256];
   const int hl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 256 + hl * 8;
   const bool cok = c < C;
+  long rbase = 0;
+  if (sg.n > 1) {   // stacked micro-batches: blockIdx.z = segment (its rows, its statistics, its area of the partial table)
+    const int si = blockIdx.z;
+    rbase = sg.row[si];
+    M = (int)(sg.row[si + 1] - rbase);
+    if ((int)blockIdx.y * BN_SUM_ROWS >= M) return;
+    mean += (long)si * C; var += (long)si * C;
+    part += sg.sums[si] * 2 * C;
+  }
   float mu[8], is[8], g[8], bt[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -276,8 +298,8 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(int M, int C, const T*
     const int r = r0 + rl + 8 * it;
     const bool ok = cok && r < M;
     float yv[8], dv[8];
-    buf_load8<T>(rsy, (long)r * C + c, ok, yv);
-    buf_load8<T>(rsd, (long)r * C + c, ok, dv);  // dz = 0 past the end: contributes nothing
+    buf_load8<T>(rsy, (rbase + r) * C + c, ok, yv);
+    buf_load8<T>(rsd, (rbase + r) * C + c, ok, dv);  // dz = 0 past the end: contributes nothing
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = (yv[j] - mu[j]) * is[j];
@@ -299,28 +321,38 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(int M, int C, const T*
 }
 // pass 2: tot[c] = mean(dbn), tot[C + c] = mean(dbn * xhat) from the partial rows (16 channels x 64 groups of
 // partial rows per block, like bn_stats_finalize_kernel); also dbeta += sum dbn, dgamma += sum dbn*xhat.
-__global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(int npart, int C, float inv_m, const float* __restrict__ part,
-                                                           float* __restrict__ tot, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
+__global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(int npart_, int C, float inv_m_, const float* __restrict__ part_,
+                                                           float* __restrict__ tot_, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, const RowSegs sg) {
   __shared__ float red[2][64][16];
   const int lane = threadIdx.x % 16, grp = threadIdx.x / 16;
   const int c = blockIdx.x * 16 + lane;
-  float a = 0.f, b = 0.f;
-  if (c < C) {
+  // stacked micro-batches: one pair of means per segment ([n, 2, C]); dgamma / dbeta take the segments' sums in order
+  const int ns = sg.n > 1 ? sg.n : 1;
+  for (int si = 0; si < ns; ++si) {
+    const int npart = sg.n > 1 ? (int)(sg.sums[si + 1] - sg.sums[si]) : npart_;
+    const float inv_m = sg.n > 1 ? 1.f / (float)(sg.row[si + 1] - sg.row[si]) : inv_m_;
+    const float* part = sg.n > 1 ? part_ + sg.sums[si] * 2 * C : part_;
+    float* tot = tot_ + (long)si * 2 * C;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
 #pragma unroll 8
-    for (int k = grp; k < npart; k += 64) { a += part[(long)k * 2 * C + c]; b += part[(long)k * 2 * C + C + c]; }
-  }
-  red[0][grp][lane] = a;
-  red[1][grp][lane] = b;
-  __syncthreads();
-  if (grp != 0 || c >= C) return;
-  a = 0.f; b = 0.f;
+      for (int k = grp; k < npart; k += 64) { a += part[(long)k * 2 * C + c]; b += part[(long)k * 2 * C + C + c]; }
+    }
+    red[0][grp][lane] = a;
+    red[1][grp][lane] = b;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+      a = 0.f; b = 0.f;
 #pragma unroll
-  for (int g = 0; g < 64; ++g) { a += red[0][g][lane]; b += red[1][g][lane]; }
-  if (dbeta) dbeta[c] += a;
-  if (dgamma) dgamma[c] += b;
-  tot[c] = a * inv_m;
-  tot[C + c] = b * inv_m;
+      for (int g = 0; g < 64; ++g) { a += red[0][g][lane]; b += red[1][g][lane]; }
+      if (dbeta) dbeta[c] += a;
+      if (dgamma) dgamma[c] += b;
+      tot[c] = a * inv_m;
+      tot[C + c] = b * inv_m;
+    }
+    __syncthreads();   // (red is reused by the next segment)
+  }
 }
 // pass 3: dy = gamma*invstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat))
 template <typename T>
@@ -412,7 +444,7 @@ extern "C" int emoasr_bn_stats_finalize(int B, int Tn, int C, const float* part,
                                         long long* num_batches_tracked, void* stream) {
   EMO_CHECK(B * Tn > 0, "bn_stats_finalize: empty batch");
   bn_stats_finalize_kernel<<<cdiv(C, BNF_CH), 1024, 0, (hipStream_t)stream>>>(B, Tn, C, part, mean, var, running_mean,
-                                                                          running_var, momentum, num_batches_tracked);
+                                                                          running_var, momentum, num_batches_tracked, RowSegs{});
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -469,7 +501,7 @@ extern "C" int emoasr_bn_swish_fwd(int dtype, int M, int C, const void* y, const
   const long n = (long)M * C;
   if (n == 0) return 0;
   EMO_DISPATCH(dtype, (bn_swish_fwd_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(
-                          n, C, (const T*)y, mean, var, gamma, beta, eps, (T*)z)));
+                          n, C, (const T*)y, mean, var, gamma, beta, eps, (T*)z, RowSegs{})));
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -488,9 +520,9 @@ extern "C" int emoasr_bn_swish_bwd_sums(int dtype, int M, int C, const void* dz,
   const int npart = cdiv(M, BN_SUM_ROWS);
   dim3 sgrid(cdiv(C, 256), npart);
   EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<sgrid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
-                                                                  var, gamma, beta, eps, scratch)));
+                                                                  var, gamma, beta, eps, scratch, RowSegs{})));
   float* tot = scratch + (long)npart * 2 * C;
-  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta);
+  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta, RowSegs{});
   if (tot_out) *tot_out = tot;
   EMO_LAUNCH_CHECK();
   return 0;
@@ -508,11 +540,46 @@ extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, cons
   dim3 grid(cdiv(C, 256), cdiv(M, BN_APPLY_ROWS));
   dim3 sgrid(cdiv(C, 256), npart);
   EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<sgrid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
-                                                                  var, gamma, beta, eps, scratch)));
+                                                                  var, gamma, beta, eps, scratch, RowSegs{})));
   float* tot = scratch + (long)npart * 2 * C;
-  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta);
+  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta, RowSegs{});
   EMO_DISPATCH(dtype, (bn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
                                                                   var, gamma, beta, eps, tot, (T*)dy)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- stacked micro-batches: the BatchNorm kernels over all segments in one launch each (called by csrc/convfused.hip) -----------
+int emo_bn_stats_finalize_seg(const RowSegs& sg, int C, const float* part, float* mean, float* var, float* running_mean,
+                              float* running_var, float momentum, long long* nbt, hipStream_t s) {
+  bn_stats_finalize_kernel<<<cdiv(C, BNF_CH), 1024, 0, s>>>(sg.b0[1], sg.T[0], C, part, mean, var, running_mean, running_var,
+                                                          momentum, nbt, sg);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+int emo_bn_swish_fwd_seg(const RowSegs& sg, int C, const void* y, const float* mean, const float* var, const float* gamma,
+                         const float* beta, float eps, void* z, hipStream_t s) {
+  const long n = sg.row[sg.n] * C;
+  if (n == 0) return 0;
+  bn_swish_fwd_kernel<bf16><<<ew_grid(n), 256, 0, s>>>(n, C, (const bf16*)y, mean, var, gamma, beta, eps, (bf16*)z, sg);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+// scratch: [sum over segments of cdiv(M_s, 16) partial rows][2][C], then the means tot [n][2][C] (returned in *tot_out)
+int emo_bn_swish_bwd_sums_seg(const RowSegs& sg, int C, const void* dz, const void* y, const float* mean, const float* var,
+                              const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta, float* scratch,
+                              float** tot_out, hipStream_t s) {
+  long mmax = 0;
+  for (int i = 0; i < sg.n; ++i) mmax = std::max(mmax, sg.row[i + 1] - sg.row[i]);
+  EMO_CHECK(sg.row[sg.n] * C * 2 < (1L << 32), "bn_swish_bwd_sums_seg: activation larger than 4 GiB");
+  dim3 sgrid(cdiv(C, 256), cdiv((int)mmax, BN_SUM_ROWS), sg.n);
+  bn_bwd_sums_kernel<bf16><<<sgrid, 256, 0, s>>>((int)mmax, C, (const bf16*)dz, (const bf16*)y, mean, var, gamma, beta, eps, scratch,
+                                                sg);
+  float* tot = scratch + sg.sums[sg.n] * 2 * C;
+  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>((int)sg.sums[1], C, 1.f / (float)sg.row[1], scratch, tot, dgamma, dbeta, sg);
+  if (tot_out) *tot_out = tot;
   EMO_LAUNCH_CHECK();
   return 0;
 }

@@ -65,6 +65,12 @@ __device__ __forceinline__ int ext_label(const int* lab, int s, int blank) {
   return (s & 1) ? lab[s >> 1] : blank;
 }
 
+// Stacked micro-batches (engine.ctc_train_stacked): the utterances of several micro-batches in ONE set of launches.  Their logits
+// rows are not b * Tn + t then: utterance b starts at row row0[b] and has tpad[b] rows (its micro-batch's padded length); the
+// gradient scale is per utterance (uscale[b] = weight of its micro-batch / its micro-batch's size).  The lattice tables stay
+// [B, Tn, S] with Tn = the longest padded length.  All three NULL: the dense [B, Tn, V] layout.
+struct UttRows { const long* row0; const int* tpad; const float* uscale; };
+
 // lp[b,t,s] = logits[b,t,l'_s] - lse[b,t]   (t < elens[b], s < 2*ylens[b]+1; else -inf)
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_gather_kernel(int Tn, int S, int Lmax, const T* __restrict__ logits,
@@ -72,15 +78,16 @@ __global__ __launch_bounds__(256) void ctc_gather_kernel(int Tn, int S, int Lmax
                                                          const int* __restrict__ labels,
                                                          const int* __restrict__ elens,
                                                          const int* __restrict__ ylens, int blank,
-                                                         float* __restrict__ lp) {
+                                                         float* __restrict__ lp, const UttRows ur) {
   const int b = blockIdx.y, t = blockIdx.x;
   const int Sb = 2 * ylens[b] + 1;
   const bool live = t < elens[b];
-  const long row = (long)b * Tn + t;
-  const float l = live ? lse[row] : 0.f;
+  const long row = (long)b * Tn + t;                         // row of the lattice tables [B, Tn, S]
+  const long lrow = ur.row0 ? ur.row0[b] + t : row;         // row of logits / lse (stacked micro-batches: per utterance)
+  const float l = live ? lse[lrow] : 0.f;
   for (int s = threadIdx.x; s < S; s += blockDim.x) {
     float v = -INFINITY;
-    if (live && s < Sb) v = to_f32(logits[row * ld + ext_label(labels + (long)b * Lmax, s, blank)]) - l;
+    if (live && s < Sb) v = to_f32(logits[lrow * ld + ext_label(labels + (long)b * Lmax, s, blank)]) - l;
     lp[row * S + s] = v;
   }
 }
@@ -163,11 +170,13 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(int Tn, int V, int S, int
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ nll, float gscale,
                                                        const float* __restrict__ gscale_dev,
-                                                       T* __restrict__ grad, long ldg) {
+                                                       T* __restrict__ grad, long ldg, const UttRows ur) {
   extern __shared__ float rowbuf[];  // [V]
   const int b = blockIdx.y, t = blockIdx.x;
-  const long row = (long)b * Tn + t;
-  T* g = grad + row * ldg;
+  if (ur.tpad && t >= ur.tpad[b]) return;                   // (the grid follows the longest micro-batch)
+  const long row = (long)b * Tn + t;                         // row of the lattice tables
+  const long lrow = ur.row0 ? ur.row0[b] + t : row;         // row of logits / lse / grad
+  T* g = grad + lrow * ldg;
   const float nl = nll[b];
   const bool vec = (V % 8 == 0) && (ld % 8 == 0) && (ldg % 8 == 0);  // 16-byte row accesses
   if (t >= elens[b] || !isfinite(nl)) {
@@ -179,8 +188,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(int Tn, int V, int S, int
     }
     return;
   }
-  const float l = lse[row];
-  const T* lg = logits + row * ld;
+  const float l = lse[lrow];
+  const T* lg = logits + lrow * ld;
   if (vec) {
     for (int v = threadIdx.x * 8; v < V; v += 2048) {
       float x[8];
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(int Tn, int V, int S, int
     if (occ > 0.f) atomicAdd(&rowbuf[ext_label(lab, s, blank)], -occ);
   }
   __syncthreads();
-  const float gs = gscale_dev ? gscale * gscale_dev[0] : gscale;
+  const float gs = (gscale_dev ? gscale * gscale_dev[0] : gscale) * (ur.uscale ? ur.uscale[b] : 1.f);
   if (vec) {
     for (int v = threadIdx.x * 8; v < V; v += 2048) {
       float x[8];
@@ -270,14 +279,23 @@ extern "C" int emoasr_ctc_forward(int dtype, int B, int Tn, int V, int Lmax, con
                                   const float* lse, const int* labels, const int* elens, const int* ylens,
                                   int blank, float* lp, float* alpha, float* beta, float* nll,
                                   void* stream) {
+  return emoasr_ctc_forward_rows(dtype, B, Tn, V, Lmax, logits, ld, lse, labels, elens, ylens, blank, nullptr, lp, alpha, beta, nll,
+                                 stream);
+}
+
+extern "C" int emoasr_ctc_forward_rows(int dtype, int B, int Tn, int V, int Lmax, const void* logits, long ld,
+                                       const float* lse, const int* labels, const int* elens, const int* ylens,
+                                       int blank, const long* row0, float* lp, float* alpha, float* beta, float* nll,
+                                       void* stream) {
   const int S = 2 * Lmax + 1;
+  const UttRows ur{row0, nullptr, nullptr};
   EMO_CHECK(S <= 1024, "ctc: 2*Lmax+1=%d exceeds 1024 lattice states", S);
   if (B == 0 || Tn == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   dim3 ggrid(Tn, B);
   const int gthreads = std::min(256, cdiv(S, 64) * 64);
   EMO_DISPATCH(dtype, (ctc_gather_kernel<T><<<ggrid, gthreads, 0, s>>>(Tn, S, Lmax, (const T*)logits, ld, lse,
-                                                                      labels, elens, ylens, blank, lp)));
+                                                                      labels, elens, ylens, blank, lp, ur)));
   const int threads = cdiv(S, 64) * 64;
   ctc_lattice_kernel<<<2 * B, threads, sizeof(float) * 2 * (S + 4), s>>>(B, Tn, S, Lmax, lp, labels, elens,
                                                                         ylens, blank, alpha, beta, nll);
@@ -290,7 +308,18 @@ extern "C" int emoasr_ctc_grad(int dtype, int B, int Tn, int V, int Lmax, const 
                                int blank, const float* lp, const float* alpha, const float* beta,
                                const float* nll, float gscale, const float* gscale_dev, void* grad, long ldg,
                                void* stream) {
+  return emoasr_ctc_grad_rows(dtype, B, Tn, V, Lmax, logits, ld, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale,
+                              gscale_dev, nullptr, nullptr, nullptr, grad, ldg, stream);
+}
+
+extern "C" int emoasr_ctc_grad_rows(int dtype, int B, int Tn, int V, int Lmax, const void* logits, long ld,
+                                    const float* lse, const int* labels, const int* elens, const int* ylens,
+                                    int blank, const float* lp, const float* alpha, const float* beta,
+                                    const float* nll, float gscale, const float* gscale_dev, const long* row0, const int* tpad,
+                                    const float* uscale, void* grad, long ldg, void* stream) {
   const int S = 2 * Lmax + 1;
+  EMO_CHECK((row0 != nullptr) == (tpad != nullptr), "ctc_grad_rows: row0 and tpad go together");
+  const UttRows ur{row0, tpad, uscale};
   EMO_CHECK((size_t)V * 4 <= 160 * 1024 - 256, "ctc_grad: V=%d too large for an LDS row", V);
   if (B == 0 || Tn == 0) return 0;
   dim3 grid(Tn, B);
@@ -300,7 +329,7 @@ extern "C" int emoasr_ctc_grad(int dtype, int B, int Tn, int V, int Lmax, const 
     ctc_grad_kernel<T><<<grid, 256, sizeof(float) * V, (hipStream_t)stream>>>(
         Tn, V, S, Lmax, (const T*)logits, ld, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale,
         gscale_dev,
-        (T*)grad, ldg);
+        (T*)grad, ldg, ur);
   });
   EMO_LAUNCH_CHECK();
   return 0;

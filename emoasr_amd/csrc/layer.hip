@@ -154,7 +154,12 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
     const bool fused = conv_fused_ok(dtype, d);
     if (!fused && emoasr_glu_fwd(dtype, M, d, io->g, io->gl, stream)) return 1;
     if (io->training) EMO_CHECK(io->bn_part && io->bmean && io->bvar, "conformer_layer_fwd: training needs the BatchNorm buffers");
-    for (int si = 0; si < sv.n; ++si) {   // each micro-batch: its own zero padding, its own batch statistics
+    const bool conv_one_launch = fused && sv.n > 1 && g_stack_launch;   // all stacked micro-batches in one launch per kernel
+    if (conv_one_launch &&
+        emoasr_conv_module_fwd_seg(dtype, &io->seg, d, L->K, io->g, L->dw_w, L->dw_b, io->c, io->bn_part, io->bmean, io->bvar,
+                                   L->bn_rm, L->bn_rv, 0.1f, L->bn_nbt, L->bn_g, L->bn_b, 1e-5f, io->z, io->training, stream))
+      return 1;
+    for (int si = 0; si < sv.n && !conv_one_launch; ++si) {   // each micro-batch: its own zero padding, its own batch statistics
       const size_t ro = (size_t)sv.row[si];
       const int B = sv.B[si], T = sv.T[si];
       const char* g = (const char*)io->g + ro * 2 * d * esz;
@@ -230,6 +235,13 @@ BwdBufs bwd_layout(int dtype, const SegView& sv, int d, int H, int F, int K) {
     tmax = std::max(tmax, sv.T[i]);
   }
   attn_ws = std::max(attn_ws, emoasr_attn_bwd_fused_ws_bytes_rows(dtype, (long)M, H, tmax, 1));   // all segments in one launch
+  if (sv.n > 1) {
+    emoasr_segments_t sg{};
+    sg.n = sv.n;
+    for (int i = 0; i < sv.n; ++i) { sg.B[i] = sv.B[i]; sg.T[i] = sv.T[i]; }
+    bn_scr = std::max(bn_scr, (size_t)emoasr_conv_module_bwd_seg_scratch_floats(&sg, d, K, 0) * 4);
+    dw_scr = std::max(dw_scr, (size_t)emoasr_conv_module_bwd_seg_scratch_floats(&sg, d, K, 1) * 4);
+  }
   b.bn_scr = L.take(bn_scr);
   b.dw_scr = L.take(dw_scr);
   b.attn_ws_bytes = attn_ws;
@@ -314,7 +326,13 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     if (conv_fused_ok(dtype, d)) {
       // BatchNorm sums + fold, then ONE launch for BatchNorm/Swish apply -> depthwise data gradient -> GLU backward and the
       // depthwise weight-gradient partials (the GLU output is recomputed from g)
-      for (int si = 0; si < sv.n; ++si) {   // per micro-batch: its own batch statistics and zero padding; scratch reused in order
+      const bool conv_one_launch = sv.n > 1 && g_stack_launch;   // all stacked micro-batches in one launch per kernel
+      if (conv_one_launch &&
+          emoasr_conv_module_bwd_seg(dtype, &st->seg, d, K, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f,
+                                     (float*)G->bn_g, (float*)G->bn_b, st->g, L->dw_w, ws + bb.dg, (float*)G->dw_w, (float*)G->dw_b,
+                                     (float*)(ws + bb.bn_scr), (float*)(ws + bb.dw_scr), stream))
+        return 1;
+      for (int si = 0; si < sv.n && !conv_one_launch; ++si) {   // per micro-batch: own statistics / padding; scratch reused in order
         const size_t ro = (size_t)sv.row[si];
         const float *bmean = st->bmean + (size_t)si * d, *bvar = st->bvar + (size_t)si * d;
         const char* c = (const char*)st->c + ro * d * esz;

@@ -588,24 +588,31 @@ class CTCEngine(_DecoderMixinPlaceholder):
         logits = ops.gemm_nt(eouts, w, bias=A.p(head + ".bias"))
         lse = ops.row_lse(logits)
         dlogits = torch.empty_like(logits)
-        losses = []
-        b0 = 0
+        # all micro-batches' utterances in one set of launches: per-utterance first row / padded length / gradient scale
+        ylens_all = [int(v) for _, _, _, yl in batches for v in yl]
+        Lmax = max(max(ylens_all), 1)
+        lab = torch.zeros(Btot, Lmax, dtype=torch.int32)
+        row0, tpad, uscale, b0 = [], [], [], 0
         for k, (_, _, ys, ylens) in enumerate(batches):
             B, T2 = segs[k]
-            ylens_h = [int(v) for v in ylens]
-            Lmax = max(max(ylens_h), 1)
-            labels = torch.as_tensor(ys)[:, :Lmax].to(torch.int32)
-            if labels.shape[1] < Lmax:
-                labels = torch.nn.functional.pad(labels, (0, Lmax - labels.shape[1]))
-            labels = h2d_i32(labels.contiguous(), dev)
-            yl = h2d_i32(ylens_h, dev)
-            el = elens[b0:b0 + B]
-            lg = logits[rows[k]:rows[k + 1]].view(B, T2, V)
-            lp, alpha, beta, nll = ops.ctc_forward(lg, lse[rows[k]:rows[k + 1]], labels, el, yl, blank)
-            losses.append(torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll)).sum() / B)
-            ops.ctc_grad(lg, lse[rows[k]:rows[k + 1]], labels, el, yl, blank, lp, alpha, beta, nll, scales[k] / B,
-                         out=dlogits[rows[k]:rows[k + 1]].view(B, T2, V))
+            yk = torch.as_tensor(ys)[:, :Lmax].to(torch.int32)
+            lab[b0:b0 + B, : yk.shape[1]] = yk
+            row0 += [rows[k] + b * T2 for b in range(B)]
+            tpad += [T2] * B
+            uscale += [scales[k] / B] * B
             b0 += B
+        labels = h2d_i32(lab, dev)
+        yl = h2d_i32(ylens_all, dev)
+        row0_d = torch.tensor(row0, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+        tpad_d = h2d_i32(tpad, dev)
+        uscale_d = torch.tensor(uscale, dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
+        lp, alpha, beta, nll = ops.ctc_forward_rows(logits, lse, labels, elens, yl, blank, row0_d, Tmax)
+        nll0 = torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll))
+        bounds = [0]
+        for b, _ in segs:
+            bounds.append(bounds[-1] + b)
+        losses = torch.stack([nll0[bounds[k]:bounds[k + 1]].sum() / segs[k][0] for k in range(n)])
+        ops.ctc_grad_rows(logits, lse, labels, elens, yl, blank, lp, alpha, beta, nll, 1.0, row0_d, tpad_d, uscale_d, dlogits)
         # ---- backward ------------------------------------------------------------------------------------------------
         deouts = self._lin_bwd(dlogits, eouts, head + ".weight", head + ".bias")
         if self.grad_hook is not None:   # the head's gradients are final
@@ -639,7 +646,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
             dy1 = ops.conv2_dgrad_kc(dy2_k, wt, y1s[k])
             ops.conv1_wgrad(xs, dy1, A.g(pre + "conv.0.weight").view(C, 9), A.g(pre + "conv.0.bias"), accumulate=True)
         ops.strided_copy(dw2.view(C, 3, 3, C).permute(0, 3, 1, 2), out=A.g(pre + "conv.2.weight"), accumulate=True)
-        return torch.stack(losses)
+        return losses
 
     # ------------------------------------------------------------------ backward
     def _lin_bwd(self, dy, x_in, wname, bname, alpha=1.0, **epi):

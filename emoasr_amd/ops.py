@@ -613,6 +613,34 @@ def ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gsc
     return grad
 
 
+def ctc_forward_rows(logits2, lse, labels, elens, ylens, blank, row0, Tmax):
+    """CTC lattices of utterances whose logits rows are row0[b] + t in the stacked [M, V] `logits2` (several micro-batches in
+    one set of launches); the lattice tables are [B, Tmax, S].  -> (lp, alpha, beta, nll)"""
+    M, V = logits2.shape
+    B, Lmax = labels.shape
+    S = 2 * Lmax + 1
+    dev = logits2.device
+    lp = torch.empty(B, Tmax, S, device=dev, dtype=torch.float32)
+    alpha = torch.empty(B, Tmax, S, device=dev, dtype=torch.float32)
+    beta = torch.empty(B, Tmax, S, device=dev, dtype=torch.float32)
+    nll = torch.empty(B, device=dev, dtype=torch.float32)
+    assert row0.dtype == torch.int64
+    lib.call("emoasr_ctc_forward_rows", dt(logits2), B, Tmax, V, Lmax, _p(logits2), logits2.stride(0), _p(lse), _p(labels),
+             _p(elens), _p(ylens), blank, _p(row0), _p(lp), _p(alpha), _p(beta), _p(nll), _stream())
+    return lp, alpha, beta, nll
+
+
+def ctc_grad_rows(logits2, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale, row0, tpad, uscale, out):
+    """gradient rows of ctc_forward_rows' utterances written into `out` [M, V] (every row of every utterance, zeros on padding)"""
+    M, V = logits2.shape
+    B, Tmax, _ = lp.shape
+    assert out.shape == logits2.shape and out.dtype == logits2.dtype and tpad.dtype == torch.int32 and uscale.dtype == torch.float32
+    lib.call("emoasr_ctc_grad_rows", dt(logits2), B, Tmax, V, labels.shape[1], _p(logits2), logits2.stride(0), _p(lse), _p(labels),
+             _p(elens), _p(ylens), blank, _p(lp), _p(alpha), _p(beta), _p(nll), gscale, None, _p(row0), _p(tpad), _p(uscale),
+             _p(out), out.stride(0), _stream())
+    return out
+
+
 def ctc_greedy(logits, elens, blank):
     B, T, V = logits.shape
     dev = logits.device

@@ -332,6 +332,17 @@ int emoasr_ctc_grad(int dtype, int B, int T, int V, int Lmax, const void* logits
                     const float* lse, const int* labels, const int* elens, const int* ylens, int blank,
                     const float* lp, const float* alpha, const float* beta, const float* nll,
                     float gscale, const float* gscale_dev, void* grad, long ldg, void* stream);
+/* The same for the utterances of several stacked micro-batches in one set of launches (engine.ctc_train_stacked): utterance b's
+ * logits / lse / gradient rows are row0[b] + t, t < tpad[b] (its micro-batch's padded length; rows t >= tpad[b] do not exist),
+ * instead of b * Tn + t; the lattice tables lp / alpha / beta stay [B, Tn, S] with Tn = the longest padded length; uscale[b]
+ * (optional) multiplies gscale per utterance (micro-batch weight / micro-batch size).  row0 == NULL: the dense layout. */
+int emoasr_ctc_forward_rows(int dtype, int B, int Tn, int V, int Lmax, const void* logits, long ld, const float* lse,
+                            const int* labels, const int* elens, const int* ylens, int blank, const long* row0, float* lp,
+                            float* alpha, float* beta, float* nll, void* stream);
+int emoasr_ctc_grad_rows(int dtype, int B, int Tn, int V, int Lmax, const void* logits, long ld, const float* lse,
+                         const int* labels, const int* elens, const int* ylens, int blank, const float* lp, const float* alpha,
+                         const float* beta, const float* nll, float gscale, const float* gscale_dev, const long* row0,
+                         const int* tpad, const float* uscale, void* grad, long ldg, void* stream);
 /* greedy: best[b,t] = argmax_v logits (first max wins); hyp[b,:hyplen[b]] = collapse
  * repeats then drop blank, over t < elens[b] */
 int emoasr_ctc_greedy(int dtype, int B, int T, int V, const void* logits, long ld, const int* elens,
@@ -534,6 +545,22 @@ typedef struct emoasr_conformer_bwd {
   float* ln_part; long ln_part_stride;
 } emoasr_conformer_bwd_t;
 size_t emoasr_conformer_layer_bwd_ws_bytes(int dtype, int B, int T, int d, int H, int F, int K);
+/* The convolution module's per-utterance part for stacked micro-batches, every kernel taking ALL segments in one launch (bf16;
+ * csrc/convfused.hip).  Same arithmetic as emoasr_glu_dwconv_fwd + emoasr_bn_stats_finalize + emoasr_bn_swish_fwd (forward) and
+ * emoasr_bn_swish_bwd_sums + emoasr_conv_bwd_fused (backward) called once per segment, in order: the depthwise convolution sees each
+ * segment's own zero padding, BatchNorm takes its batch statistics per segment (bmean / bvar [n, C]) and moves the running
+ * statistics once per segment.  g / dg [M, 2C], c / z / dz [M, C]; part: the segments' emoasr_dwconv_stats_floats areas back to back;
+ * scratch sizes from emoasr_conv_module_bwd_seg_scratch_floats (which = 0: BatchNorm sums, 1: depthwise weight-gradient partials).
+ * Reference: conformer.py:126-133 and its autograd. */
+int emoasr_conv_module_fwd_seg(int dtype, const emoasr_segments_t* seg, int C, int K, const void* g, const float* w,
+                               const float* bias, void* c, float* part, float* bmean, float* bvar, float* running_mean,
+                               float* running_var, float momentum, long long* num_batches_tracked, const float* gamma,
+                               const float* beta, float eps, void* z, int training, void* stream);
+long emoasr_conv_module_bwd_seg_scratch_floats(const emoasr_segments_t* seg, int C, int K, int which);
+int emoasr_conv_module_bwd_seg(int dtype, const emoasr_segments_t* seg, int C, int K, const void* dz, const void* c,
+                               const float* bmean, const float* bvar, const float* gamma, const float* beta, float eps,
+                               float* dgamma, float* dbeta, const void* g, const float* w, void* dg, float* dw, float* dbias,
+                               float* bn_scratch, float* dw_scratch, void* stream);
 size_t emoasr_conformer_layer_bwd_ws_bytes_seg(int dtype, const emoasr_segments_t* seg, int d, int H, int F, int K);
 int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_layer_t* layer, const emoasr_conformer_layer_t* grads,
                                const emoasr_conformer_fwd_t* st, const emoasr_conformer_bwd_t* io, void* stream);
