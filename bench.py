@@ -46,12 +46,16 @@ def fwd_flops_per_utt(T, F=1024, V=10000, d=256, layers=12):
     return conv1 + conv2 + lin + layers * layer + head
 
 
+PMC_FILE = os.path.join("profiles", "r03_pmc.json")
+
+
 def pmc_kernel(kernel, key):
-    """per-launch figure of one kernel from the committed PMC passes of this bench (separate rocprofv3 --pmc runs,
-    summarised by tools/pmc_summary.py into profiles/r02_pmc.json): key = "traffic_bytes" (FETCH_SIZE x 2 + WRITE_SIZE, the
-    gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md) or "mfma_util" (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CU
-    cycles the kernel was resident)).  None when the file or the kernel is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    """per-launch figure of one kernel from the committed PMC passes (separate rocprofv3 --pmc runs of THIS bench command,
+    summarised by tools/pmc_summary.py): key = "traffic_bytes" (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction of
+    /opt/skills/guides/MI355X_MICROARCH.md) or "mfma_util" (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CU cycles the kernel was
+    resident)).  Counters cannot be collected inside a timed run, so these two figures are NOT live: they are None unless the
+    profile file of this round exists, and the bench line names the file they came from (`pmc_source`)."""
+    path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -61,6 +65,65 @@ def pmc_kernel(kernel, key):
         return None
     n = sum(v["launches"] for v in hit)
     return sum(v[key] * v["launches"] for v in hit) / max(n, 1)
+
+
+def pmc_source():
+    path = os.path.join(ROOT, PMC_FILE)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        meta = json.load(f)
+    return {"file": PMC_FILE, "commit": meta.get("commit"), "command": meta.get("command")}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# kernel families timed inside the library (emoasr_timer_read_ex); value: the kernel-table symbol(s) of profiles/*_kernel_stats.csv
+FAMILIES = {"gemm_nt_nn": "gemm_nt_kernel / gemm_nn (big_nt_kernel for wide products): forward and data-gradient products",
+            "gemm_tn": "gemm_tn_grouped_kernel / gemm_tn_kernel: weight gradients",
+            "attn_bwd_fused_kernel": "attn_bwd_fused_kernel", "attn_bwd_dpos2_kernel": "attn_bwd_dpos2_kernel",
+            "attn_fwd_kernel": "attn_fwd_kernel", "layernorm": "ln_fwd_kernel + ln_bwd8_kernel",
+            "conv_module": "cf_dwconv / bn_* / cf_conv_bwd kernels (convolution module, per-utterance part)"}
+RIDGE_FLOP_PER_BYTE = 2500e12 / 8000e9  # bf16 dense MFMA peak / HBM peak
+
+
+def family_table(emo_lib, attn_work, elapsed_s=None):
+    """{family: calls, ms, algorithmic GFLOP / GB, achieved TFLOP/s and GB/s, fractions of both peaks} from the library's timers.
+    attn_work: (fwd flops, bwd-main flops, dpos flops) of the recorded steps -- the attention kernels' algorithmic work depends on
+    the utterance lengths, which only the caller knows."""
+    out = {}
+    for name in FAMILIES:
+        calls, ms, fl, by = emo_lib.timer_read_ex(name)
+        if not calls:
+            continue
+        if name == "attn_fwd_kernel":
+            fl = attn_work[0]
+        elif name == "attn_bwd_fused_kernel":
+            fl = attn_work[1]
+        elif name == "attn_bwd_dpos2_kernel":
+            fl = attn_work[2]
+        row = {"calls": calls, "ms": ms, "avg_us": 1e3 * ms / calls}
+        if fl:
+            row["gflop"] = fl / 1e9
+            row["tflops"] = fl / (ms * 1e-3) / 1e12
+            row["mfma_frac"] = row["tflops"] / MFMA_PEAK_TFLOPS["bf16"]
+        if by:
+            row["gbytes"] = by / 1e9
+            row["gbps"] = by / (ms * 1e-3) / 1e9
+            row["hbm_frac"] = row["gbps"] / HBM_PEAK_GBS
+        if elapsed_s:
+            row["share_of_step"] = ms * 1e-3 / elapsed_s
+        out[name] = row
+    return out
 
 
 class CallTimer:
@@ -168,7 +231,7 @@ def cpu_baseline(model, max_seconds=14.0):
 
     nthr = torch.get_num_threads()
     rate, steps, t_total = train_rate(xs, xlens, ys, ylens, max_seconds, 5)
-    out = dict(value=rate, unit="frames/s", cores=nthr, kind="port",
+    out = dict(value=rate, unit="frames/s", cores=nthr, kind="port", cpu_model=cpu_model(),
                sample=f"{steps} fwd+bwd steps of one L2 batch (4 utts, xlens 1200/1037/911/640, fp32, dropout 0, "
                       f"no optimizer step) in {t_total:.1f}s on {nthr} threads")
     torch.set_num_threads(1)
@@ -358,7 +421,7 @@ LM12 = dict(lm_type="transformer", vocab_size=10000, hidden_size=256, num_layers
             intermediate_size=1024, max_seq_len=256)
 
 
-def decode_rtf_l33(dev, dtype, tmpdir, n_utts=20, repeats=5, out_steps=36):  # noqa: C901
+def decode_rtf_l33(dev, dtype, tmpdir, n_utts=20, repeats=5, out_steps=36, eos_biased=False):  # noqa: C901
     """config 4 (`L3-3`): joint CTC+attention beam 10 with Transformer-LM shallow fusion, batch 1, the reference's RTF
     protocol (20 utterances x 5 repeats, feature files read inside the timed region; emoasr_amd.decode.measure_rtf).
     Random-init weights never emit <eos>, so every utterance is decoded for exactly `out_steps` output steps with a full
@@ -369,23 +432,45 @@ def decode_rtf_l33(dev, dtype, tmpdir, n_utts=20, repeats=5, out_steps=36):  # n
     from emoasr_amd.modeling.lm import LM
     logging.disable(logging.WARNING)  # ("cannot decode": no hypothesis ever ends with <eos> here, by construction)
     torch.manual_seed(1)
-    model = ASR(SimpleNamespace(**L3), compute_dtype=dtype).to(dev).eval()
-    lm = LM(SimpleNamespace(**LM12), compute_dtype=dtype).to(dev).eval()
-    loader, vocab, _ = rtf_fixture(os.path.join(tmpdir, "l33"), n_utts, 2)
+    model = ASR(SimpleNamespace(**L3), compute_dtype=dtype)
+    lm = LM(SimpleNamespace(**LM12), compute_dtype=dtype)
+    if eos_biased:
+        # the second leg: heads biased as tests/test_fullsize_l3_l4_gpu.py does, so that hypotheses END (<eos> likely in the
+        # attention head, blank-dominated CTC posteriors, a flattened LM head): finished hypotheses, the results list and the
+        # search's own early stop are inside the timed region; the number of output steps is whatever the search takes
+        with torch.no_grad():
+            model.decoder.output.weight.mul_(6.0)
+            model.decoder.output.bias[2] += 8.0
+            model.decoder.ctc.output.weight.mul_(3.0)
+            model.decoder.ctc.output.bias[0] += 14.0
+            for n, p in lm.named_parameters():
+                if n.endswith("predictions.transform.LayerNorm.weight"):
+                    p.mul_(0.1)
+    model, lm = model.to(dev).eval(), lm.to(dev).eval()
+    loader, vocab, _ = rtf_fixture(os.path.join(tmpdir, "l33e" if eos_biased else "l33"), n_utts, 2)
     model.decoder.max_decode_ylen = 8
     dec.test(model, loader, vocab, 10, 0.0, 0.3, False, lm, 0.3, dev, num_samples=2)  # warm-up
-    model.decoder.max_decode_ylen = out_steps
+    model.decoder.max_decode_ylen = 200 if eos_biased else out_steps
     model.engine()._beam_stats = None
     runtime, rtf = dec.measure_rtf(model, loader, vocab, 10, 0.0, 0.3, False, lm, 0.3, dev, num_samples=n_utts,
                                    num_repeats=repeats)
     logging.disable(logging.NOTSET)
-    out = dict(rtf=rtf, out_steps=out_steps, ms_per_step=1e3 * runtime / out_steps, utts=n_utts, repeats=repeats, beam=10,
-               lm_weight=0.3, decode_ctc_weight=0.3, forced_steps=True)
     st = getattr(model.engine(), "_beam_stats", None)
+    steps_per_utt = (st["steps"] / max(st["utts"], 1)) if st and st["steps"] else float(out_steps)
+    out = dict(rtf=rtf, out_steps=steps_per_utt, ms_per_step=1e3 * runtime / steps_per_utt, utts=n_utts, repeats=repeats, beam=10,
+               lm_weight=0.3, decode_ctc_weight=0.3, forced_steps=not eos_biased)
+    # what one output step has to read: every weight of the decoder and the LM once (bf16) -- the HBM floor of a step
+    wbytes = 2 * (sum(p.numel() for n, p in model.named_parameters() if n.startswith("decoder.")) +
+                  sum(p.numel() for p in lm.parameters()))
+    out["weight_bytes_per_step"] = wbytes
     if st and st["steps"]:
         # inside the device-resident search loop only (graph refresh per utterance included; encoder, feature loading and the
-        # per-utterance set-up excluded): ms_per_step above is the whole utterance / out_steps, the RTF protocol's view
-        out["search_loop_ms_per_step"] = 1e3 * st["loop_s"] / st["steps"]
+        # per-utterance set-up excluded): ms_per_step above is the whole utterance / steps, the RTF protocol's view
+        ms = 1e3 * st["loop_s"] / st["steps"]
+        out["search_loop_ms_per_step"] = ms
+        out["steps_per_s"] = 1e3 / ms
+        out["achieved_GBps"] = wbytes / (ms * 1e-3) / 1e9
+        out["hbm_frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
     return out
 
 
@@ -541,26 +626,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up; the last warm-up step is instrumented per entry point to find the dominant kernel family
+    # algorithmic work of the attention kernels for a group of micro-batches (they depend on the utterance lengths):
+    # per valid (query, key, head) pair -- forward 3 products of 2*DK flop (Q K^T, Q pos^T, P V); backward main kernel 7
+    # (Q K^T, Q pos^T, dO V^T, dV, dK, dQ from K, dQ from pos); dpos kernel 1 (dS^T (Q+v))
+    H_, DK_, NL_ = L2["enc_num_attention_heads"], L2["enc_hidden_size"] // L2["enc_num_attention_heads"], L2["enc_num_layers"]
+
+    def attn_work(pairs):
+        unit = 2.0 * DK_ * H_ * pairs * NL_
+        return 3 * unit, 7 * unit, 1 * unit
+
+    # warm-up; the LAST warm-up step is instrumented (every kernel family timed inside the library with HIP events on the launch
+    # stream): it gives the per-family table and picks the dominant family, which alone is then timed over the timed region
     breakdown = None
+    families = {}
     for i in range(args.warmup):
-        if i == args.warmup - 1 and args.breakdown:
-            with CallTimer(emo_lib) as ct:
-                ct.attn_pairs = attn_pairs(batches[i])
+        if i == args.warmup - 1:
+            sync()
+            emo_lib.set_option("timers", 1)
+            for fam in FAMILIES:
+                emo_lib.timer_read_ex(fam)
+            t_w = time.perf_counter()
+            if args.breakdown:
+                with CallTimer(emo_lib) as ct:
+                    ct.attn_pairs = attn_pairs(batches[i])
+                    step(batches[i])
+                breakdown = ct.summary()
+            else:
                 step(batches[i])
-            breakdown = ct.summary()
+            sync()
+            t_w = time.perf_counter() - t_w
+            emo_lib.set_option("timers", 0)
+            families = family_table(emo_lib, attn_work(attn_pairs(batches[i])), t_w)
         else:
             step(batches[i])
-    # the roofline object is about ONE kernel family: composite entry points (a whole layer's ~24 kernels behind
-    # one C-ABI call) are not candidates
-    # the roofline object is about ONE kernel: the single-pass attention backward (the largest single kernel of the step,
-    # profiles/r02_*_kernel_stats.csv).  It runs behind the composite layer call, so it is timed inside the library with HIP
-    # events on its launch stream (emoasr_timer_read) over exactly the timed region.
-    dominant = "attn_bwd_fused_kernel"
+    # the roofline object is about ONE kernel family, chosen at run time: the one with the most device time in the instrumented
+    # step.  It is timed inside the library over exactly the timed region (only its own events are recorded there).
+    dominant = max(families, key=lambda k: families[k]["ms"]) if families else "gemm_nt_nn"
     sync()
     frames = sum(sum(b.xlens) for grp in batches[args.warmup:] for b in grp)
-    emo_lib.set_option("timers", 1)
-    emo_lib.timer_read(dominant)
+    emo_lib.set_option("timers", emo_lib.timer_mask(dominant))
+    emo_lib.timer_read_ex(dominant)
     t0 = time.perf_counter()
     pairs = 0.0
     for bt in batches[args.warmup:]:
@@ -569,10 +674,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     emo_lib.set_option("timers", 0)
-    dcalls, dms = emo_lib.timer_read(dominant)
-    # algorithmic work of the kernel: seven 2*DK-flop products per valid (query, key, head) pair -- Q K^T, Q pos^T, dO V^T,
-    # dV, dK, dQ from K, dQ from pos (the dpos product lives in attn_bwd_dpos2_kernel)
-    dom = dict(calls=dcalls, ms=dms, flops=7 * 2.0 * 64 * L2["enc_num_attention_heads"] * pairs * L2["enc_num_layers"])
+    dom = family_table(emo_lib, attn_work(pairs)).get(dominant, {"calls": 0, "ms": 0.0})
     tt = torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64)
     if world > 1:
         tmax = tt.clone()
@@ -599,17 +701,29 @@ def main():
         mean_T = frames / world / args.steps / accum / max(1, np.mean([len(b.xlens) for grp in batches[args.warmup:] for b in grp]))
         train_flops = 3.0 * fwd_flops_per_utt(int(mean_T)) / max(mean_T, 1) * frames
         res["model_mfma_frac"] = train_flops / elapsed / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12 * world)
-        if dom["calls"] and dom["flops"]:
-            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            res["roofline"] = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[args.dtype],
-                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[args.dtype],
+        if dom["calls"]:
+            # which roof bounds the family: its algorithmic intensity against the ridge of the two peaks
+            ai = (dom.get("gflop", 0.0) / dom["gbytes"]) if dom.get("gbytes") else None
+            bound = "hbm" if (ai is not None and ai < RIDGE_FLOP_PER_BYTE) or "tflops" not in dom else "mfma"
+            if bound == "hbm" and "gbps" in dom:
+                ach, peak, unit = dom["gbps"], HBM_PEAK_GBS, "GB/s"
+            else:
+                bound, ach, peak, unit = "mfma", dom["tflops"], MFMA_PEAK_TFLOPS[args.dtype], "TFLOP/s"
+            res["roofline"] = {"kernel": dominant, "symbols": FAMILIES[dominant], "chosen": "largest device time of the "
+                               "instrumented warm-up step (in-library HIP-event timers)", "bound": bound, "achieved": ach,
+                               "peak": peak, "unit": unit, "frac": ach / peak,
+                               "mfma_frac": dom.get("mfma_frac"), "hbm_frac": dom.get("hbm_frac"),
+                               "flop_per_byte": ai, "ridge_flop_per_byte": RIDGE_FLOP_PER_BYTE,
                                "traffic": pmc_kernel(dominant, "traffic_bytes"), "mfma_util": pmc_kernel(dominant, "mfma_util"),
-                               "launches": dom["calls"], "avg_us": 1e3 * dom["ms"] / dom["calls"],
-                               "flop_per_launch": dom["flops"] / dom["calls"], "share_of_step": dom["ms"] * 1e-3 / elapsed}
+                               "pmc_source": pmc_source(),
+                               "launches": dom["calls"], "avg_us": dom["avg_us"],
+                               "flop_per_launch": 1e9 * dom.get("gflop", 0.0) / dom["calls"],
+                               "bytes_per_launch": 1e9 * dom.get("gbytes", 0.0) / dom["calls"],
+                               "share_of_step": dom["ms"] * 1e-3 / elapsed}
         else:
             res["roofline"] = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": None, "traffic": None, "launches": dom["calls"],
-                               "avg_us": 1e3 * dom["ms"] / max(dom["calls"], 1)}
+                               "frac": None, "traffic": None, "launches": 0}
+        res["families"] = {"step": "the last warm-up step, every family timed (HIP events inside the library)", **families}
         if args.breakdown and breakdown:
             tot = sum(v["ms"] for v in breakdown.values())
             for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]):
@@ -623,6 +737,7 @@ def main():
                 res["decode_rtf"] = decode_rtf(model, dev, tmpdir)
                 res["decode_rtf_batch32"] = decode_rtf_batched(model, dev)
                 res["decode_l33"] = decode_rtf_l33(dev, dtype, tmpdir)
+                res["decode_l33_eos"] = decode_rtf_l33(dev, dtype, tmpdir, n_utts=10, repeats=2, eos_biased=True)
             # log-mel in the loop: the same steps starting from raw 16 kHz audio (fbank kernel -> SpecAugment -> model)
             from emoasr_amd.features import LogMel
             fb = logmel_rate(dev, batches[-1][-1].xlens)

@@ -43,34 +43,41 @@ void emo_layer_set_ffn_fused(int v);
 #include <vector>
 namespace {
 const char* const kTimerNames[EMO_TIMER_COUNT] = {"attn_bwd_fused_kernel", "attn_bwd_dpos2_kernel", "attn_fwd_kernel",
-                                                  "gemm_tn_grouped_kernel"};
-struct TimerRec { hipEvent_t e0, e1; };
+                                                  "gemm_tn_grouped_kernel", "gemm_nt_nn", "gemm_tn", "layernorm", "conv_module"};
+struct TimerRec { hipEvent_t e0, e1; double flops, bytes; bool ended; };
 std::vector<TimerRec> g_rec[EMO_TIMER_COUNT];
 int g_timers_on = 0;
+bool timer_on(int id) { return g_timers_on == 1 || (g_timers_on > 1 && ((g_timers_on >> (id + 1)) & 1)); }
 }  // namespace
-void emo_timer_begin(int id, hipStream_t s) {
-  if (!g_timers_on) return;
-  TimerRec r;
+void emo_timer_begin(int id, hipStream_t s, double flops, double bytes) {
+  if (!timer_on(id)) return;
+  TimerRec r{};
   hipEventCreate(&r.e0);
   hipEventCreate(&r.e1);
   hipEventRecord(r.e0, s);
+  r.flops = flops; r.bytes = bytes; r.ended = false;
   g_rec[id].push_back(r);
 }
 void emo_timer_end(int id, hipStream_t s) {
-  if (!g_timers_on || g_rec[id].empty()) return;
+  if (!timer_on(id) || g_rec[id].empty() || g_rec[id].back().ended) return;
   hipEventRecord(g_rec[id].back().e1, s);
+  g_rec[id].back().ended = true;
 }
-extern "C" int emoasr_timer_read(const char* name, int* calls, double* ms, int reset) {
+extern "C" int emoasr_timer_read_ex(const char* name, int* calls, double* ms, double* flops, double* bytes, int reset) {
   for (int id = 0; id < EMO_TIMER_COUNT; ++id) {
     if (strcmp(name, kTimerNames[id]) != 0) continue;
-    double tot = 0.0;
+    double tot = 0.0, fl = 0.0, by = 0.0;
+    int n = 0;
     for (const TimerRec& r : g_rec[id]) {
+      if (!r.ended) continue;
       float t = 0.f;
       hipEventSynchronize(r.e1);
-      if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) tot += t;
+      if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { tot += t; fl += r.flops; by += r.bytes; ++n; }
     }
-    if (calls) *calls = (int)g_rec[id].size();
+    if (calls) *calls = n;
     if (ms) *ms = tot;
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
     if (reset) {
       for (const TimerRec& r : g_rec[id]) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
       g_rec[id].clear();
@@ -79,6 +86,9 @@ extern "C" int emoasr_timer_read(const char* name, int* calls, double* ms, int r
   }
   emo_set_error("unknown timer '%s'", name);
   return 1;
+}
+extern "C" int emoasr_timer_read(const char* name, int* calls, double* ms, int reset) {
+  return emoasr_timer_read_ex(name, calls, ms, nullptr, nullptr, reset);
 }
 
 extern "C" const char* emoasr_last_error(void) { return g_err; }

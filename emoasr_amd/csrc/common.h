@@ -365,9 +365,17 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // HIP-event timers around selected kernels (api.hip; read with emoasr_timer_read, enabled by option "timers")
 enum { EMO_TIMER_ATTN_BWD_MAIN = 0, EMO_TIMER_ATTN_BWD_DPOS = 1, EMO_TIMER_ATTN_FWD = 2, EMO_TIMER_TN_GROUPED = 3,
-       EMO_TIMER_COUNT = 4 };
-void emo_timer_begin(int id, hipStream_t s);
+       EMO_TIMER_GEMM_NT_NN = 4, EMO_TIMER_GEMM_TN = 5, EMO_TIMER_LAYERNORM = 6, EMO_TIMER_CONV_MODULE = 7,
+       EMO_TIMER_COUNT = 8 };
+// option "timers": 0 off, 1 every family, else a bit mask (1 << (id + 1)) of the families to record
+void emo_timer_begin(int id, hipStream_t s, double flops = 0.0, double bytes = 0.0);
 void emo_timer_end(int id, hipStream_t s);
+// records the launches enqueued on `s` during its lifetime (with their algorithmic work) under family `id`
+struct EmoTimerScope {
+  int id; hipStream_t s;
+  EmoTimerScope(int id_, hipStream_t s_, double flops = 0.0, double bytes = 0.0) : id(id_), s(s_) { emo_timer_begin(id, s, flops, bytes); }
+  ~EmoTimerScope() { emo_timer_end(id, s); }
+};
 
 enum { EMO_F32 = 0, EMO_BF16 = 1 };
 #define EMO_DISPATCH(dtype, ...)                                        \

@@ -429,6 +429,8 @@ extern "C" int emoasr_conv_module_fwd_seg(int dtype, const emoasr_segments_t* se
   EMO_CHECK((long)tmax * 2 * C * 2 < (1L << 32) && sg.row[sg.n] * 2 * C * 2 < (1L << 46), "conv_module_fwd_seg: batch too large");
   EMO_CHECK(!training || (part && bmean && bvar), "conv_module_fwd_seg: training needs the BatchNorm buffers");
   hipStream_t s = (hipStream_t)stream;
+  // algorithmic bytes per row and channel: g (2) in, c out; c in, z out
+  EmoTimerScope timer_(EMO_TIMER_CONV_MODULE, s, 0.0, 5.0 * (double)sg.row[sg.n] * C * 2.0);
   dim3 grid(cdiv(tmax, CF_TT), cdiv(C, CF_CB), sg.b0[sg.n]);
   cf_dwconv_kernel<true><<<grid, CF_CB, 0, s>>>(tmax, C, K, (const bf16*)g, w, bias, (bf16*)c, 0, training ? part : nullptr, sg);
   EMO_LAUNCH_CHECK();
@@ -464,6 +466,8 @@ extern "C" int emoasr_conv_module_bwd_seg(int dtype, const emoasr_segments_t* se
   int tmax = 0;
   EMO_CHECK(row_segs(seg, C, &sg, &tmax), "conv_module_bwd_seg: bad segment description");
   hipStream_t s = (hipStream_t)stream;
+  // algorithmic bytes per row and channel: dz, c in (sums); dz, c, g (2) in, dg (2) out
+  EmoTimerScope timer_(EMO_TIMER_CONV_MODULE, s, 0.0, 8.0 * (double)sg.row[sg.n] * C * 2.0);
   float* tot = nullptr;
   if (emo_bn_swish_bwd_sums_seg(sg, C, dz, c, bmean, bvar, gamma, beta, eps, dgamma, dbeta, bn_scratch, &tot, s)) return 1;
   constexpr int bytes = (2 * CF_ROWS_P + 2 * CF_TT) * CF_CB * 2;

@@ -691,6 +691,9 @@ extern "C" int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, lon
   NtArgs a{};
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   if (ep) a.ep = *ep; else { a.ep = emoasr_epilogue_t{}; a.ep.alpha = 1.f; }
+  const double esz_ = dtype == EMO_BF16 ? 2.0 : 4.0;   // algorithmic work of the launch, for the family timer (bench.py)
+  EmoTimerScope timer_(EMO_TIMER_GEMM_NT_NN, (hipStream_t)stream, 2.0 * M * N * K,
+                       ((double)M * K + (double)N * K + (double)M * N * (1 + (a.ep.residual ? 1 : 0) + (a.ep.pre_out ? 1 : 0))) * esz_);
   // wide bf16 products over many rows (q/k/v, feed-forward w1, pointwise conv 1): the large-tile kernel of gemm_big.hip
   if (dtype == EMO_BF16 && emo_gemm_nt_big_wants(M, N, K, lda, ldb, ldc, a.ep))
     return emo_gemm_nt_big_ep(M, N, K, A, lda, B, ldb, C, ldc, a.ep, (hipStream_t)stream);
@@ -706,6 +709,9 @@ extern "C" int emoasr_gemm_nn(int dtype, int M, int N, int K, const void* A, lon
   NtArgs a{};
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   if (ep) a.ep = *ep; else { a.ep = emoasr_epilogue_t{}; a.ep.alpha = 1.f; }
+  const double esz_ = dtype == EMO_BF16 ? 2.0 : 4.0;
+  EmoTimerScope timer_(EMO_TIMER_GEMM_NT_NN, (hipStream_t)stream, 2.0 * M * N * K,
+                       ((double)M * K + (double)N * K + (double)M * N * (1 + (a.ep.residual ? 1 : 0) + (a.ep.dact_pre ? 1 : 0))) * esz_);
   EMO_DISPATCH(dtype, return (launch_nn<T>(a, (hipStream_t)stream)));
   return 0;
 }
@@ -745,6 +751,8 @@ extern "C" int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, l
   TnArgs a{};
   a.N1 = N1; a.N2 = N2; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.alpha = alpha; a.colsum = colsum; a.colsum_scale = colsum_scale;
+  EmoTimerScope timer_(EMO_TIMER_GEMM_TN, (hipStream_t)stream, 2.0 * N1 * N2 * K,
+                       ((double)K * N1 + (double)K * N2) * (dtype == EMO_BF16 ? 2.0 : 4.0) + 4.0 * N1 * N2);
   EMO_DISPATCH(dtype, return (launch_tn<T, 0>(a, (hipStream_t)stream)));
 }
 
@@ -791,7 +799,13 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   }
   G.start[n] = start;
   hipStream_t s = (hipStream_t)stream;
-  emo_timer_begin(EMO_TIMER_TN_GROUPED, s);
+  double gfl = 0.0, gby = 0.0;
+  for (int i = 0; i < n; ++i) {
+    gfl += 2.0 * probs[i].N1 * probs[i].N2 * probs[i].K;
+    gby += ((double)probs[i].K * probs[i].N1 + (double)probs[i].K * probs[i].N2) * (dtype == EMO_BF16 ? 2.0 : 4.0) + 4.0 * probs[i].N1 * probs[i].N2;
+  }
+  EmoTimerScope timer_(EMO_TIMER_GEMM_TN, s, gfl, gby);
+  emo_timer_begin(EMO_TIMER_TN_GROUPED, s, gfl, gby);
   if (dtype == EMO_BF16) {
     if (bt == 128) {
       if (g_tr_read) gemm_tn_grouped_kernel<bf16, true, 2, 128><<<start, 256, 0, s>>>(G);

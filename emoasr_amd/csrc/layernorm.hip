@@ -352,6 +352,7 @@ extern "C" int emoasr_layernorm_fwd(int dtype, int M, int N, const void* x, cons
                                     void* stream) {
   EMO_CHECK(N % 4 == 0 && N <= LN_MAXC * 256, "layernorm: N=%d unsupported", N);
   if (M == 0) return 0;
+  EmoTimerScope timer_(EMO_TIMER_LAYERNORM, (hipStream_t)stream, 0.0, 2.0 * M * N * (dtype == EMO_BF16 ? 2.0 : 4.0));
   EMO_DISPATCH(dtype, (ln_fwd_kernel<T><<<cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(
                           M, N, (const T*)x, gamma, beta, eps, (T*)y, mean, rstd)));
   EMO_LAUNCH_CHECK();
@@ -369,6 +370,9 @@ extern "C" int emoasr_layernorm_bwd_ex(int dtype, int M, int N, const void* dy, 
             LN_BWD8_MAXBLK * 2 * N);
   const int nblk = ln_bwd_nblk(M, N);
   hipStream_t s = (hipStream_t)stream;
+  // algorithmic bytes: dy, x in; dx out; + the residual gradient in and the dropped-out copy out when present
+  EmoTimerScope timer_(EMO_TIMER_LAYERNORM, s, 0.0,
+                       (3.0 + (dres ? 1 : 0) + (opts && opts->dy2 ? 1 : 0)) * M * N * (dtype == EMO_BF16 ? 2.0 : 4.0));
   float* part = want ? scratch : nullptr;
   void* dy2 = opts ? opts->dy2 : nullptr;
   const float scale2 = opts ? opts->scale2 : 1.f, p2 = opts ? opts->drop_p2 : 0.f;

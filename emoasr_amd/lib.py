@@ -356,6 +356,30 @@ def timer_read(name, reset=True):
     return calls.value, ms.value
 
 
+TIMER_FAMILIES = ("attn_bwd_fused_kernel", "attn_bwd_dpos2_kernel", "attn_fwd_kernel", "gemm_tn_grouped_kernel", "gemm_nt_nn",
+                  "gemm_tn", "layernorm", "conv_module")
+
+
+def timer_mask(*names):
+    """value of option "timers" that records only the named families"""
+    m = 0
+    for n in names:
+        m |= 1 << (TIMER_FAMILIES.index(n) + 1)
+    return m
+
+
+def timer_read_ex(name, reset=True):
+    """(launches, summed ms, algorithmic flops, algorithmic bytes) of a kernel family timed inside the library"""
+    lib = load()
+    calls, ms, fl, by = c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    fn = lib.emoasr_timer_read_ex
+    fn.argtypes = [c_char_p, POINTER(c_int)] + [POINTER(ctypes.c_double)] * 3 + [c_int]
+    fn.restype = c_int
+    if fn(name.encode(), ctypes.byref(calls), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), int(reset)) != 0:
+        raise EmoasrHipError(lib.emoasr_last_error().decode())
+    return calls.value, ms.value, fl.value, by.value
+
+
 def set_option(name, value):
     lib = load()
     if lib.emoasr_set_option(name.encode(), int(value)) != 0:
