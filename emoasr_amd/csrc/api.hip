@@ -26,6 +26,11 @@ void emo_gemm_set_big_min_tiles(int v);
 void emo_conv_set_dwconv_lds(int v);
 void emo_layer_set_conv_fused(int v);
 void emo_layer_set_stack_launch(int v);
+#ifdef EMOASR_EXPERIMENTAL
+void emo_gemm_set_k256(int v);
+void emo_gemm_set_k256_min_rows(int v);
+void emo_gemm_set_k256_dbg(int v);
+#endif
 void emo_decode_set_fused(int v);
 #ifdef EMOASR_EXPERIMENTAL
 void emo_decode_set_wg(int v);
@@ -47,10 +52,15 @@ const char* const kTimerNames[EMO_TIMER_COUNT] = {"attn_bwd_fused_kernel", "attn
 struct TimerRec { hipEvent_t e0, e1; double flops, bytes; bool ended; };
 std::vector<TimerRec> g_rec[EMO_TIMER_COUNT];
 int g_timers_on = 0;
+int g_timer_stride = 1;              // record every n-th launch of a family only (option "timer_stride"): an event pair per launch
+long g_timer_seen[EMO_TIMER_COUNT];  // costs ~2 % of the step for the 208-launch GEMM family; 1 in 7 is a uniform sample of its shapes
+bool g_timer_open[EMO_TIMER_COUNT];
 bool timer_on(int id) { return g_timers_on == 1 || (g_timers_on > 1 && ((g_timers_on >> (id + 1)) & 1)); }
 }  // namespace
 void emo_timer_begin(int id, hipStream_t s, double flops, double bytes) {
   if (!timer_on(id)) return;
+  g_timer_open[id] = (g_timer_seen[id]++ % g_timer_stride) == 0;
+  if (!g_timer_open[id]) return;
   TimerRec r{};
   hipEventCreate(&r.e0);
   hipEventCreate(&r.e1);
@@ -59,7 +69,7 @@ void emo_timer_begin(int id, hipStream_t s, double flops, double bytes) {
   g_rec[id].push_back(r);
 }
 void emo_timer_end(int id, hipStream_t s) {
-  if (!timer_on(id) || g_rec[id].empty() || g_rec[id].back().ended) return;
+  if (!timer_on(id) || !g_timer_open[id] || g_rec[id].empty() || g_rec[id].back().ended) return;
   hipEventRecord(g_rec[id].back().e1, s);
   g_rec[id].back().ended = true;
 }
@@ -118,6 +128,17 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "conv_fused") == 0) { emo_layer_set_conv_fused(value); return 0; }
   if (strcmp(name, "stack_launch") == 0) { emo_layer_set_stack_launch(value); return 0; }
 #ifdef EMOASR_EXPERIMENTAL
+  if (strcmp(name, "gemm_k256") == 0) { emo_gemm_set_k256(value); return 0; }
+  if (strcmp(name, "gemm_k256_min_rows") == 0) { emo_gemm_set_k256_min_rows(value); return 0; }
+  if (strcmp(name, "gemm_k256_dbg") == 0) { emo_gemm_set_k256_dbg(value); return 0; }
+#else
+  if (strcmp(name, "gemm_k256") == 0 || strcmp(name, "gemm_k256_dbg") == 0) {
+    if (value == 0) return 0;
+    emo_set_error("option '%s' needs a library built with EMOASR_EXPERIMENTAL=1 (csrc/experimental/gemm_k256.hip)", name);
+    return 1;
+  }
+#endif
+#ifdef EMOASR_EXPERIMENTAL
   if (strcmp(name, "decode_fused") == 0) { emo_decode_set_fused(value); return 0; }
   if (strcmp(name, "decode_wg") == 0) { emo_decode_set_wg(value); return 0; }
   if (strcmp(name, "ffn_fused") == 0) { emo_layer_set_ffn_fused(value); return 0; }
@@ -133,6 +154,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "decode_coop_merge") == 0) { emo_decode_set_coop_merge(value); return 0; }
   if (strcmp(name, "attn_fw") == 0) { emo_attn_set_fw(value); return 0; }
   if (strcmp(name, "timers") == 0) { g_timers_on = value; return 0; }
+  if (strcmp(name, "timer_stride") == 0) { g_timer_stride = value > 0 ? value : 1; return 0; }
   emo_set_error("unknown option '%s'", name);
   return 1;
 }

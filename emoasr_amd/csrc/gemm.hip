@@ -359,11 +359,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
           load8<T>(dpre + off, d);
           dact_vec<8>(ep.dact, d, v);
         }
-        if (ep.drop_p > 0.f) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            v[e] *= dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col + e, ep.drop_p);
-        }
+        // (vec_ok: N % 8 == 0 and col % 8 == 0, so the 8 mask indices start at an even one)
+        dropout_apply8(ep.seed, (uint64_t)row * (uint64_t)g.N + col, ep.drop_p, v);
         if (res) {
           float d[8];
           load8<T>(res + (g.nh > 0 ? c_base : 0) + (long)row * ep.ldr + col, d);
@@ -671,6 +668,12 @@ int emo_gemm_nt_big_ep(int M, int N, int K, const void* A, long lda, const void*
                        const emoasr_epilogue_t& ep, hipStream_t s);
 int emo_conv2_fwd_big(int B, int T1, int F1, int C, const void* y1, const void* w, void* y2, const float* bias,
                       int relu, hipStream_t s);
+#ifdef EMOASR_EXPERIMENTAL
+// csrc/experimental/gemm_k256.hip (opt-in build, measured slower): persistent, weight-stationary kernel for K = 256 products
+bool emo_gemm_nt_k256_wants(int M, int N, int K, long lda, long ldb, long ldc, const emoasr_epilogue_t& ep);
+int emo_gemm_nt_k256(int M, int N, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                     const emoasr_epilogue_t& ep, hipStream_t s);
+#endif
 
 void emo_gemm_set_tr_read(int v) { g_tr_read = v; }
 void emo_gemm_set_tile(int v) { g_gemm_tile = v; }
@@ -694,6 +697,11 @@ extern "C" int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, lon
   const double esz_ = dtype == EMO_BF16 ? 2.0 : 4.0;   // algorithmic work of the launch, for the family timer (bench.py)
   EmoTimerScope timer_(EMO_TIMER_GEMM_NT_NN, (hipStream_t)stream, 2.0 * M * N * K,
                        ((double)M * K + (double)N * K + (double)M * N * (1 + (a.ep.residual ? 1 : 0) + (a.ep.pre_out ? 1 : 0))) * esz_);
+#ifdef EMOASR_EXPERIMENTAL
+  // K = 256 products over many rows: the persistent weight-stationary kernel of experimental/gemm_k256.hip (option "gemm_k256")
+  if (dtype == EMO_BF16 && emo_gemm_nt_k256_wants(M, N, K, lda, ldb, ldc, a.ep))
+    return emo_gemm_nt_k256(M, N, A, lda, B, ldb, C, ldc, a.ep, (hipStream_t)stream);
+#endif
   // wide bf16 products over many rows (q/k/v, feed-forward w1, pointwise conv 1): the large-tile kernel of gemm_big.hip
   if (dtype == EMO_BF16 && emo_gemm_nt_big_wants(M, N, K, lda, ldb, ldc, a.ep))
     return emo_gemm_nt_big_ep(M, N, K, A, lda, B, ldb, C, ldc, a.ep, (hipStream_t)stream);

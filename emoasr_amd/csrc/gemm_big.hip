@@ -323,10 +323,7 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
           const long off = (long)grow * g.ldc + col;
           if (pre_out) store8<bf16>(pre_out + off, v);
           act_vec<8>(ep.act, v);
-          if (ep.drop_p > 0.f) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= dropout_scale(ep.seed, (uint64_t)grow * (uint64_t)g.N + col + e, ep.drop_p);
-          }
+          dropout_apply8(ep.seed, (uint64_t)grow * (uint64_t)g.N + col, ep.drop_p, v);   // (N % 8 == 0, col % 8 == 0)
           store8<bf16>(Cp + off, v);
         }
       }

@@ -256,9 +256,8 @@ __global__ __launch_bounds__(256) void ln_bwd8_kernel(int M, int N, const T* __r
         if (dy2) {  // gradient entering the next residual branch x + scale2 * dropout(f(x)), from the ROUNDED dx
           float o2[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            o2[j] = to_f32(from_f32<T>(o[c][j])) * scale2 *
-                    dropout_scale(seed2, (uint64_t)((long)row * N + col + j), p2);
+          for (int j = 0; j < 8; ++j) o2[j] = to_f32(from_f32<T>(o[c][j])) * scale2;
+          dropout_apply8(seed2, (uint64_t)((long)row * N + col), p2, o2);   // (N % 8 == 0, col % 8 == 0: an even first index)
           ln_store8(dy2 + (long)row * N + col, o2);
         }
       }

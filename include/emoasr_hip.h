@@ -48,7 +48,8 @@ int emoasr_timer_read(const char* name, int* calls, double* ms, int reset);
  * data-gradient products), "gemm_tn" (emoasr_gemm_tn + _grouped, weight gradients), "layernorm" (forward + backward),
  * "conv_module" (emoasr_conv_module_fwd_seg / _bwd_seg), and the kernels named above.  "timers" = 1 records every family, a
  * bit mask 1 << (index + 1) only the chosen ones (index = position in this list: attn_bwd_fused_kernel 0, attn_bwd_dpos2_kernel
- * 1, attn_fwd_kernel 2, gemm_tn_grouped_kernel 3, gemm_nt_nn 4, gemm_tn 5, layernorm 6, conv_module 7). */
+ * 1, attn_fwd_kernel 2, gemm_tn_grouped_kernel 3, gemm_nt_nn 4, gemm_tn 5, layernorm 6, conv_module 7).  Option
+ * "timer_stride" = n records every n-th launch of a family only (an event pair per launch costs device time). */
 int emoasr_timer_read_ex(const char* name, int* calls, double* ms, double* flops, double* bytes, int reset);
 
 /* GEMM epilogue, applied in this order to v = alpha*acc + bias[col]:

@@ -6,8 +6,8 @@ from emoasr_amd import ops
 
 dev = torch.device("cuda:0")
 from emoasr_amd import lib as _lib
-for _o in ('gemm_tile', 'gemm_kb', 'gemm_xcd'):
-    if os.environ.get(_o.upper()) is not None: _lib.set_option(_o, int(os.environ[_o.upper()]))
+for _o in ('gemm_tile', 'gemm_kb', 'gemm_xcd', 'big_min_tiles', 'gemm_k256', 'gemm_k256_dbg'):
+    if os.environ.get(_o.upper()) is not None and (not _o.startswith('gemm_k256') or _lib.experimental()): _lib.set_option(_o, int(os.environ[_o.upper()]))
 M = int(os.environ.get("M", 7200))
 dt = torch.bfloat16
 shapes_nt = [("ffn1", M, 1024, 256), ("ffn2", M, 256, 1024), ("qkv", M, 768, 256), ("out", M, 256, 256),
@@ -33,6 +33,11 @@ tot = 0.0
 for name, m, n, k in shapes_nt:
     a, b = rnd(m, k), rnd(n, k); out = torch.empty(m, n, device=dev, dtype=dt); bias = torch.randn(n, device=dev)
     us = timeit(lambda: ops.gemm_nt(a, b, out=out, bias=bias))
+    if os.environ.get("EPI") and k == 256:   # the training epilogues: w1 (bias, Swish, dropout, saved pre-activation) / residual
+        pre = torch.empty_like(out); resid = rnd(m, n)
+        u1 = timeit(lambda: ops.gemm_nt(a, b, out=out, bias=bias, act=ops.ACT_SWISH, pre_out=pre, drop_p=0.1, seed=5))
+        u2 = timeit(lambda: ops.gemm_nt(a, b, out=out, bias=bias, residual=resid, res_scale=0.5, drop_p=0.1, seed=5))
+        print(f"   {name:8s} with swish+dropout+pre_out {u1:8.1f} us   with residual+dropout {u2:8.1f} us")
     tot += us
     ub = timeit(lambda: torch.mm(a, b.t(), out=out)) if os.environ.get("BLAS") else 0.0   # reference point only (hipBLASLt)
     print(f"nt {name:8s} {m}x{n}x{k}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TF/s  {(m*k+n*k+m*n)*2/us/1e3:7.1f} GB/s   blas {ub:8.1f} us")
