@@ -6,7 +6,9 @@ as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE ar
 read requests at 64 bytes, so reads are doubled; WRITE_SIZE is exact for 16-byte stores and f32 atomics.  MFMA utilisation of a
 kernel = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums
 the 8 XCDs).
-usage: python tools/pmc_summary.py <fetch.db> <write.db> <mfma.db> <steps> <out.json>"""
+Besides the per-kernel entries the output holds one aggregated entry per kernel FAMILY of bench.py's roofline object ("gemm_nt_nn",
+"gemm_tn", "layernorm", "conv_module": launch-weighted means over the family's kernels), plus the commit and command the passes ran.
+usage: python tools/pmc_summary.py <fetch.db> <write.db> <mfma.db> <steps> <out.json> [commit] [command]"""
 import json
 import re
 import sqlite3
@@ -58,9 +60,24 @@ for f in sorted(set(fetch) | set(write) | set(mfma)):
         r["mfma_busy_cycles"] = busy / max(nm, 1)
     res[f] = r
 tot = sum(v["traffic_bytes"] * v["launches"] for v in res.values())
+# families of bench.py's roofline object (emoasr_timer_read_ex): launch-weighted aggregates of their kernels
+FAMILY_OF = {"gemm_nt_nn": ("gemm_nt[", "gemm_nn[", "gemm_nt_big["), "gemm_tn": ("gemm_tn_grouped_kernel", "gemm_tn_kernel"),
+             "layernorm": ("ln_fwd_kernel", "ln_bwd8_kernel"),
+             "conv_module": ("cf_conv_bwd_kernel", "cf_dwconv_kernel", "bn_bwd_sums_kernel", "bn_swish_fwd_kernel",
+                             "bn_stats_finalize_kernel", "bn_bwd_fold_kernel", "dwconv_bwd_w_reduce_kernel")}
+for fam, keys in FAMILY_OF.items():
+    members = [v for k, v in res.items() if any(k.startswith(p) for p in keys)]
+    n = sum(m["launches"] for m in members)
+    if not n:
+        continue
+    agg = {"launches": n, "kernels": sorted(k for k in res if any(k.startswith(p) for p in keys))}
+    for key in ("read_bytes", "write_bytes", "traffic_bytes", "mfma_util"):
+        agg[key] = sum(m.get(key, 0.0) * m["launches"] for m in members) / n
+    res[fam] = agg
 json.dump({"note": "per launch, by kernel; reads = FETCH_SIZE x 2 (gfx950 correction), writes = WRITE_SIZE, mfma_util = "
                    "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); three separate --pmc passes of "
-                   "`bench.py --steps 5 --warmup 2 --no-decode --no-cpu-baseline`",
+                   "the bench command recorded under `command`",
+           "commit": sys.argv[6] if len(sys.argv) > 6 else None, "command": sys.argv[7] if len(sys.argv) > 7 else None,
            "total_bytes_per_step": tot / steps, "kernels": res}, open(sys.argv[5], "w"), indent=1)
 for f, v in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes"] * kv[1]["launches"])[:24]:
     print(f"{f:34s} n={v['launches']:5d} read {v['read_bytes'] / 1e6:9.2f} MB  write {v['write_bytes'] / 1e6:9.2f} MB  "
