@@ -1279,6 +1279,9 @@ class _RNNTMixin:
             A.refresh_shadow()
             dev = eouts.device
             hyps, aligns = [], []
+            V = A.w("decoder.output.weight").shape[0]
+            if ops.lib.size_query("emoasr_rnnt_greedy_supported", ops.dt(eouts), self.r_emb, self.r_H, J, V, self.r_nl):
+                return self._rnnt_greedy_device(eouts, elens_host, blank, eos, max_seq_len)
             for b in range(eouts.shape[0]):
                 T = int(elens_host[b])
                 e_all = ops.gemm_nt(eouts[b, :max(T, 1)], A.w("decoder.w_enc.weight"), bias=A.p("decoder.w_enc.bias"))
@@ -1304,6 +1307,42 @@ class _RNNTMixin:
                 hyps.append(hyp)
                 aligns.append(align)
             return hyps, aligns
+
+    def _rnnt_greedy_device(self, eouts, elens_host, blank, eos, max_seq_len):
+        """the whole search of an utterance as ONE cooperative launch (csrc/rnnt_greedy.hip): no host round trip per label; the
+        utterances of a batch are enqueued one after the other and read back with a single synchronisation"""
+        from . import lib
+        A, J, H, E = self.arena, self.r_J, self.r_H, self.r_emb
+        dev = eouts.device
+        w_out = A.w("decoder.output.weight")
+        V = w_out.shape[0]
+        nbytes = lib.size_query("emoasr_rnnt_greedy_ws_bytes", H, J)
+        b_l = [self._lstm_bias(f"decoder.rnns.{l}").contiguous() for l in range(2)]
+        outs = []
+        for b in range(eouts.shape[0]):
+            T = int(elens_host[b])
+            e_all = ops.gemm_nt(eouts[b, :max(T, 1)], A.w("decoder.w_enc.weight"), bias=A.p("decoder.w_enc.bias"))
+            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            hyp = torch.empty(max_seq_len + 1, device=dev, dtype=torch.int32)
+            align = torch.empty(T + max_seq_len + 1, device=dev, dtype=torch.int32)
+            lens = torch.zeros(2, device=dev, dtype=torch.int32)
+            lib.call("emoasr_rnnt_greedy", ops.dt(eouts), T, E, H, J, V, blank, eos, max_seq_len, ops._p(e_all),
+                     ops._p(A.w("decoder.embed.weight")), ops._p(A.w("decoder.rnns.0.weight_ih_l0")),
+                     ops._p(A.w("decoder.rnns.0.weight_hh_l0")), ops._p(b_l[0]), ops._p(A.w("decoder.rnns.1.weight_ih_l0")),
+                     ops._p(A.w("decoder.rnns.1.weight_hh_l0")), ops._p(b_l[1]), ops._p(A.w("decoder.w_dec.weight")),
+                     ops._p(A.p("decoder.w_dec.bias")), ops._p(w_out), ops._p(A.p("decoder.output.bias")), ops._p(ws), nbytes,
+                     ops._p(hyp), ops._p(align), ops._p(lens), ops._stream())
+            outs.append((e_all, ws, hyp, align, lens))
+        hyps, aligns = [], []
+        for e_all, ws, hyp, align, lens in outs:
+            nh, na = lens.tolist()    # (the first read synchronises)
+            err = int(ws[64:68].view(torch.int32).item())
+            if err:
+                raise RuntimeError("rnnt_greedy: a grid barrier gave up waiting (csrc/rnnt_greedy.hip); "
+                                   "emoasr_set_option('rnnt_greedy_coop', 0) selects the launch chain")
+            hyps.append(hyp[:nh].tolist())
+            aligns.append(align[:na].tolist())
+        return hyps, aligns
 
     def rnnt_beam_search(self, eouts, beam_width, blank, eos, num_expands=3):
         """alignment-length synchronous beam search for ONE utterance (rnn_transducer.py:242-325,348-359).

@@ -230,6 +230,7 @@ SIGNATURES = {
     "emoasr_row_lse": [I, I, I, P, L, P, P],
     "emoasr_ctc_forward": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, P],
     "emoasr_ctc_grad": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, F, P, P, L, P],
+    "emoasr_rnnt_greedy": [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P],
     "emoasr_ctc_forward_rows": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, P, P],
     "emoasr_ctc_grad_rows": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, F, P, P, P, P, P, L, P],
     "emoasr_ctc_greedy": [I, I, I, I, P, L, P, I, P, P, P, P],

@@ -460,6 +460,21 @@ int emoasr_argmax_rows(int dtype, int M, int V, const void* x, long ldx, int* ou
  * transducer search (rnn_transducer.py:194-240) finds the next non-blank frame with one 8-byte D2H copy */
 int emoasr_first_not_equal(int n, const int* x, int value, int* out, void* stream);
 
+/* ---- greedy transducer search on the device (csrc/rnnt_greedy.hip; RNNTDecoder._greedy, rnn_transducer.py:194-240) --------------
+ * ONE launch per utterance: 32 co-resident workgroups run the whole time-synchronous search (joint + output arg-max per step, the two
+ * LSTM layers + w_dec per emitted label) and meet at grid barriers; no host round trip per label.  e_all [T, J] = w_enc . eouts + bias
+ * in the compute dtype; b_lstm0 / b_lstm1 = bias_ih + bias_hh [4H] of the two layers; ws: emoasr_rnnt_greedy_ws_bytes(H, J) bytes.
+ * Outputs (device): hyp int32 [max_len + 1], align int32 [T + max_len + 1] (the arg-max of every joint evaluation, in order),
+ * lens int32 [2] = {len(hyp), len(align)}.  emoasr_rnnt_greedy_status: 0 unless a barrier of the last launch in `ws` gave up
+ * (synchronises the stream).  emoasr_rnnt_greedy_supported: two LSTM layers, widths multiples of 8, H a multiple of 32 up to 512. */
+long emoasr_rnnt_greedy_supported(int dtype, int E, int H, int J, int V, int nl);
+long emoasr_rnnt_greedy_ws_bytes(int H, int J);
+int emoasr_rnnt_greedy(int dtype, int T, int E, int H, int J, int V, int blank, int eos, int max_len, const void* e_all,
+                       const void* emb, const void* w_ih0, const void* w_hh0, const float* b_lstm0, const void* w_ih1,
+                       const void* w_hh1, const float* b_lstm1, const void* w_dec, const float* b_dec, const void* w_out,
+                       const float* b_out, void* ws, long ws_bytes, int* hyp, int* align, int* lens, void* stream);
+long emoasr_rnnt_greedy_status(const void* ws, void* stream);
+
 /* ---- one Conformer encoder layer, forward, sequenced on the host in C++ ---------
  * ConformerEncoderLayer.forward (asr/modeling/conformer.py:146-225) with relative-position attention:
  *   x += 0.5 * drop(FFN_macaron(LN(x)));  x += drop(RelMHA(LN(x)));  x += drop(ConvModule(LN(x)));

@@ -80,15 +80,53 @@ def test_greedy_decode_f32(dev):
     assert hyps2 == hyps and s2 is None and l2 is None and a2 is None  # decode() discards them (quirk 7)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_greedy_on_the_device_equals_the_launch_chain(dev, dtype):
+    """csrc/rnnt_greedy.hip (the whole search of an utterance as ONE cooperative launch: option "rnnt_greedy_coop" 1, the default)
+    against the launch chain it replaces (one host round trip per emitted label) and, in f32, the reference's golden hypotheses
+    and alignments (the arg-max of EVERY joint evaluation, in order)."""
+    from emoasr_amd import lib
+    model, g = _build(dtype, dev)
+    model.eval()
+    eng = model.engine()
+    from emoasr_amd import ops
+    assert lib.size_query("emoasr_rnnt_greedy_supported", ops._DT[dtype], eng.r_emb, eng.r_H, eng.r_J, model.decoder.output.weight.shape[0],
+                          eng.r_nl) == 1
+
+    def run(flag):
+        lib.set_option("rnnt_greedy_coop", flag)
+        try:
+            with torch.no_grad():
+                eouts, elens, _ = model.encoder(g["xs"].to(dev), g["xlens"])
+                return model.decoder._greedy(eouts, elens)
+        finally:
+            lib.set_option("rnnt_greedy_coop", 1)
+
+    hyps1, _, _, aligns1 = run(1)
+    hyps0, _, _, aligns0 = run(0)
+    if dtype == torch.float32:
+        assert hyps1 == split_ragged(g["eval/hyps"], g["eval/hyp_lens"])
+        assert aligns1 == split_ragged(g["eval/aligns"], g["eval/align_lens"])
+        assert hyps1 == hyps0 and aligns1 == aligns0
+    else:  # bf16: a near-tie may flip and the sequences diverge from there
+        agree = sum(int(a == b) for h1, h0 in zip(hyps1, hyps0) for a, b in zip(h1, h0)) / max(1, sum(len(h) for h in hyps0))
+        assert agree > 0.8, (agree, hyps1, hyps0)
+
+
 @pytest.mark.parametrize("window", [1, 3, 7, 64])
 def test_greedy_window_sizes(dev, window):
     """the windowed search (frames scored in batches against an unchanged decoder state) takes the same
     (frame, token) decisions for every window size -- window 1 is the reference's frame-by-frame loop"""
+    from emoasr_amd import lib
     model, g = _build(torch.float32, dev)
     model.eval()
-    with torch.no_grad():
-        eouts, elens, _ = model.encoder(g["xs"].to(dev), g["xlens"])
-        hyps, aligns = model.engine().rnnt_greedy(eouts, elens.tolist(), 0, 2, window=window)
+    lib.set_option("rnnt_greedy_coop", 0)   # (the windows belong to the launch chain; the device-resident search has none)
+    try:
+        with torch.no_grad():
+            eouts, elens, _ = model.encoder(g["xs"].to(dev), g["xlens"])
+            hyps, aligns = model.engine().rnnt_greedy(eouts, elens.tolist(), 0, 2, window=window)
+    finally:
+        lib.set_option("rnnt_greedy_coop", 1)
     assert hyps == split_ragged(g["eval/hyps"], g["eval/hyp_lens"])
     assert aligns == split_ragged(g["eval/aligns"], g["eval/align_lens"])
 
