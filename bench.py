@@ -345,12 +345,15 @@ L4 = dict(L2, decoder_type="rnn_transducer", vocab_size=1000, embedding_size=256
           joint_hidden_size=512, dropout_emb_rate=0.1, dropout_dec_rate=0.1, mtl_ctc_weight=0.3, lsm_prob=0.0)
 
 
-def l4_rnnt(dev, dtype, steps=5, warmup=2, n_dec=5):
-    """config 5 (`L4`): RNN-T (Conformer) 26 M -- training frames/s (fwd + transducer lattice + bwd + Adam on
-    LibriSpeech-shaped batches at the standard 30 000-frame budget: the joint logits [B,T',U+1,1000] are ~0.9 GB in bf16) and streaming greedy
-    decode RTF at batch 1 (decode steps capped by the model's own max-symbols rule)."""
+def l4_rnnt(dev, dtype, steps=4, warmup=2, n_dec=5, accum=5):
+    """config 5 (`L4`): RNN-T (Conformer) 26 M -- training frames/s (optimizer steps of `accum` micro-batches as the reference
+    runs them: the ENCODER of all micro-batches in one stacked pass, the prediction network / joint / transducer lattice per
+    micro-batch on its slice, loss / accum each, then Adam; LibriSpeech-shaped batches at the standard 30 000-frame budget: the
+    joint logits [B,T',U+1,1000] are ~0.9 GB in bf16 per micro-batch) and streaming greedy decode RTF at batch 1 (the whole search
+    of an utterance as one device-resident launch; decode steps capped by the model's own max-symbols rule)."""
     from emoasr_amd.data import libri_shaped_lengths, pack_batches
     from emoasr_amd.modeling.asr import ASR
+    from emoasr_amd.modeling.functions import encoder_apply_stacked
     from emoasr_amd.train import ArenaAdam, noam_lr
     torch.manual_seed(2)
     model = ASR(SimpleNamespace(**L4), compute_dtype=dtype).to(dev).train()
@@ -362,8 +365,11 @@ def l4_rnnt(dev, dtype, steps=5, warmup=2, n_dec=5):
     rs = random.Random(3)
     rs.shuffle(batches)
     g = torch.Generator().manual_seed(5)
+    stacked = accum > 1 and dtype == torch.bfloat16 and eng.encoder_stacked_ok()
+    if not stacked:
+        accum = 1
     data = []
-    for idx in batches[: steps + warmup]:
+    for idx in batches[: (steps + warmup) * accum]:
         xl, yl = [int(xlens[i]) for i in idx], [int(ylens[i]) for i in idx]
         xs = torch.randn(len(idx), max(xl), 80, generator=g)
         ys = torch.randint(3, L4["vocab_size"], (len(idx), max(yl)), generator=g)
@@ -372,25 +378,36 @@ def l4_rnnt(dev, dtype, steps=5, warmup=2, n_dec=5):
             xs[b, xl[b]:] = 0
             ys[b, yl[b]:] = L4["eos_id"]
         data.append((xs.to(dev), xl, ys, yl, torch.cat([eos, ys], 1), torch.cat([ys, eos], 1)))
+    groups = [data[i * accum:(i + 1) * accum] for i in range(steps + warmup)]
 
-    def step(bt):
-        loss, _ = model(*bt)
+    def step(grp):
         opt.zero_grad()
-        loss.backward()
+        if stacked:
+            outs = encoder_apply_stacked(model.encoder, [bt[0] for bt in grp], [bt[1] for bt in grp])
+            total = None
+            for (eouts, elens, _), bt in zip(outs, grp):
+                loss, _, _ = model.decoder(eouts, elens, None, bt[2], bt[3], bt[4], bt[5], None, None, None)
+                total = loss / accum if total is None else total + loss / accum
+            total.backward()
+        else:
+            for bt in grp:
+                loss, _ = model(*bt)
+                (loss / accum).backward()
         opt.step()
         return loss
 
-    for bt in data[:warmup]:
-        step(bt)
+    for grp in groups[:warmup]:
+        step(grp)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for bt in data[warmup:]:
-        loss = step(bt)
+    for grp in groups[warmup:]:
+        loss = step(grp)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    frames = sum(sum(bt[1]) for bt in data[warmup:])
-    out = dict(train_frames_per_s=frames / el, ms_per_step=1e3 * el / steps, frames_per_step=frames / steps,
-               params_M=sum(p.numel() for p in model.parameters()) / 1e6, final_loss=float(loss.detach()))
+    frames = sum(sum(bt[1]) for grp in groups[warmup:] for bt in grp)
+    out = dict(train_frames_per_s=frames / el, ms_per_step=1e3 * el / steps, frames_per_step=frames / steps, accum_grad=accum,
+               stacked_encoder=bool(stacked), params_M=sum(p.numel() for p in model.parameters()) / 1e6,
+               final_loss=float(loss.detach()))
     model.eval()
     rs2 = np.random.RandomState(4)
     pick = rs2.choice(len(xlens), n_dec, replace=False)

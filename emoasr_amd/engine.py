@@ -497,11 +497,8 @@ class CTCEngine(_DecoderMixinPlaceholder):
         """can ctc_train_stacked take this model?  (bf16 relative-position Conformer + plain CTC head, the layer runtime and
         the single-pass attention backward on, no intermediate / distillation branches)"""
         cfg = self.cfg
-        return (self.conformer and self.rel and self.dtype == torch.bfloat16 and self._cpp_layers and self.attn_fused
-                and not self.attn_store_scores and not self._side_wgrads and self.inter_layer == 0
-                and _cfg(cfg, "decoder_type", "ctc") == "ctc" and not (_cfg(cfg, "kd_weight", 0) or 0) > 0
-                and os.environ.get("EMOASR_CPP_BWD", "1") != "0" and self._implicit_dgrad and self._conv_big
-                and self.d % 256 == 0 and os.environ.get("EMOASR_STACKED", "1") != "0")
+        return (self.encoder_stacked_ok() and _cfg(cfg, "decoder_type", "ctc") == "ctc"
+                and not (_cfg(cfg, "kd_weight", 0) or 0) > 0)
 
     def ctc_train_stacked(self, batches, blank, scales=None, head="decoder.output"):
         """Forward + CTC loss + backward of several micro-batches in ONE stacked pass (asr/train_asr.py:106-128 runs them one
@@ -524,7 +521,16 @@ class CTCEngine(_DecoderMixinPlaceholder):
             self._wq = []
             self._ln_deferred = []
 
-    def _ctc_train_stacked(self, batches, blank, scales, head):
+    def encoder_stacked_ok(self):
+        """can the ENCODER take several micro-batches in one stacked pass (any decoder on top)?"""
+        return (self.conformer and self.rel and self.dtype == torch.bfloat16 and self._cpp_layers and self.attn_fused
+                and not self.attn_store_scores and not self._side_wgrads and self.inter_layer == 0
+                and os.environ.get("EMOASR_CPP_BWD", "1") != "0" and self._implicit_dgrad and self._conv_big
+                and self.d % 256 == 0 and os.environ.get("EMOASR_STACKED", "1") != "0")
+
+    def _encoder_fwd_stacked(self, xs_list, xlens_list):
+        """Conv2d front-end per micro-batch, everything after it over the stacked rows.
+        -> (eouts [M, d], stash): segment k = rows st.rows[k] .. st.rows[k + 1] as [B_k, T_k, d]"""
         from . import lib
         self.ensure_bound()
         A, d, dt = self.arena, self.d, self.dtype
@@ -532,10 +538,9 @@ class CTCEngine(_DecoderMixinPlaceholder):
         A.attach_grads()
         self.step_count += 1
         self._keep = True
-        n = len(batches)
+        n = len(xs_list)
         assert 1 <= n <= lib.MAX_SEGMENTS
-        scales = [1.0 / n] * n if scales is None else [float(v) for v in scales]
-        dev = batches[0][0].device
+        dev = xs_list[0].device
         p_enc, p_att = self.p_enc, self.p_att
         pre = "encoder.conv."
         C = d
@@ -543,7 +548,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
         w1 = A.p(pre + "conv.0.weight").view(C, 9)
         w2r = ops.strided_copy(A.p(pre + "conv.2.weight").permute(0, 2, 3, 1), out_dtype=dt).view(C, 9 * C)
         y1s, segs, xlens_all = [], [], []
-        for xs, xlens, _, _ in batches:
+        for xs, xlens in zip(xs_list, xlens_list):
             B, T, Fd = xs.shape
             T1, F1 = (T - 3) // 2 + 1, (Fd - 3) // 2 + 1
             T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
@@ -554,7 +559,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
             rows.append(rows[-1] + b * t)
         M = rows[-1]
         y2 = torch.empty(M, F2 * C, device=dev, dtype=dt)
-        for k, (xs, _, _, _) in enumerate(batches):
+        for k, xs in enumerate(xs_list):
             y1 = ops.conv1_fwd(xs, w1, A.p(pre + "conv.0.bias"), dt)
             ops.conv2_fwd(y1, w2r, out=y2[rows[k]:rows[k + 1]], bias=A.p(pre + "conv.2.bias"), act=ACT_RELU)
             y1s.append(y1)
@@ -581,6 +586,72 @@ class CTCEngine(_DecoderMixinPlaceholder):
             layers.append(cur)
         x_final = cur.tv("y")
         eouts, fin_mean, fin_rstd = ops.layernorm_fwd(x_final, A.p("encoder.norm.weight"), A.p("encoder.norm.bias"), 1e-12, True)
+        st = _Stash()
+        st.xs_list, st.y1s, st.y2, st.wlr, st.segs, st.rows, st.M, st.F2 = xs_list, y1s, y2, wlr, segs, rows, M, F2
+        st.elens, st.elens_host, st.s_pe, st.layers = elens, elens_host, s_pe, layers
+        st.pos_t = pos_t   # (the layers' C structs hold its raw address: it must live until the backward sweep is done)
+        st.x_final, st.fin_mean, st.fin_rstd, st.Btot, st.Tmax = x_final, fin_mean, fin_rstd, Btot, Tmax
+        return eouts, st
+
+    def _encoder_bwd_stacked(self, st, deouts):
+        """deouts [M, d] (compute dtype): gradient w.r.t. the stacked encoder output; accumulates every encoder gradient"""
+        A, d, dt = self.arena, self.d, self.dtype
+        dev = deouts.device
+        M, F2, C, rows = st.M, st.F2, self.d, st.rows
+        pre = "encoder.conv."
+        dx, _ = self._ln_bwd(deouts, st.x_final, "encoder.norm", st.fin_mean, st.fin_rstd, None, None)
+        lnf = ops.lib.size_query("emoasr_layernorm_bwd_scratch_floats", d)
+        ln_parts = torch.empty(self.nl, 5, lnf, device=dev, dtype=torch.float32)
+        dx_bufs = [torch.empty(M, d, device=dev, dtype=dt) for _ in range(2)]
+        for li in reversed(range(self.nl)):
+            out = dx_bufs[li & 1]
+            self._layer_rt.backward(li, st.layers[li], dx, out, ln_parts[li], self._ln_deferred)
+            dx = out
+            if self.grad_hook is not None:
+                self._flush_wgrads()
+                ops.layernorm_bwd_finalize(self._ln_deferred)
+                self.grad_hook(self._layer_offset(li))
+        self._flush_wgrads()
+        ops.layernorm_bwd_finalize(self._ln_deferred)
+        # positional scaling, Linear (all rows at once), then the two convolutions per micro-batch
+        dlin = ops.scale_dropout(dx, math.sqrt(d), self.p_enc, st.s_pe)
+        dwl = torch.zeros(d, F2 * C, device=dev, dtype=torch.float32)  # (f, c) order
+        ops.gemm_tn(dlin, st.y2, out=dwl, accumulate=True, colsum=A.g(pre + "output.bias"))
+        ops.strided_copy(dwl.view(d, F2, C).permute(0, 2, 1), out=A.g(pre + "output.weight").view(d, C, F2), accumulate=True)
+        dy2 = ops.gemm_nn(dlin, st.wlr, dact_pre=st.y2, dact=ACT_RELU)
+        dw2 = torch.zeros(C, 9 * C, device=dev, dtype=torch.float32)
+        wt = ops.strided_copy(A.p(pre + "conv.2.weight").permute(1, 2, 3, 0), out_dtype=dt).view(C, 9 * C)
+        for k, xs in enumerate(st.xs_list):
+            dy2_k = dy2[rows[k]:rows[k + 1]].view(-1, C)
+            ops.conv2_wgrad(dy2_k, st.y1s[k], dw2, dbias=A.g(pre + "conv.2.bias"), accumulate=True)
+            dy1 = ops.conv2_dgrad_kc(dy2_k, wt, st.y1s[k])
+            ops.conv1_wgrad(xs, dy1, A.g(pre + "conv.0.weight").view(C, 9), A.g(pre + "conv.0.bias"), accumulate=True)
+        ops.strided_copy(dw2.view(C, 3, 3, C).permute(0, 3, 1, 2), out=A.g(pre + "conv.2.weight"), accumulate=True)
+
+    def encoder_forward_stacked(self, xs_list, xlens_list):
+        """the encoder over several micro-batches in one stacked pass, for ANY decoder on top (modeling/functions.py:
+        encoder_apply_stacked wraps it into autograd).  -> (eouts [M, d], stash)"""
+        assert self.encoder_stacked_ok(), "encoder_forward_stacked: unsupported configuration (see encoder_stacked_ok)"
+        with ops.stream_scope():
+            return self._encoder_fwd_stacked(xs_list, xlens_list)
+
+    def encoder_backward_stacked(self, st, deouts):
+        self._defer_wgrads = self._group_wgrads
+        try:
+            with ops.stream_scope():
+                self._encoder_bwd_stacked(st, deouts)
+        finally:
+            self._defer_wgrads = False
+            self._wq = []
+            self._ln_deferred = []
+
+    def _ctc_train_stacked(self, batches, blank, scales, head):
+        A = self.arena
+        n = len(batches)
+        scales = [1.0 / n] * n if scales is None else [float(v) for v in scales]
+        eouts, st = self._encoder_fwd_stacked([b[0] for b in batches], [b[1] for b in batches])
+        dev = eouts.device
+        segs, rows, elens, Btot, Tmax = st.segs, st.rows, st.elens, st.Btot, st.Tmax
         # ---- vocabulary head over all rows; CTC lattices per micro-batch -----------------------------------------------
         w = A.w(head + ".weight")
         V = w.shape[0]
@@ -618,34 +689,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
         if self.grad_hook is not None:   # the head's gradients are final
             self._flush_wgrads()
             self.grad_hook(A.offsets[head + ".weight"])
-        dx, _ = self._ln_bwd(deouts, x_final, "encoder.norm", fin_mean, fin_rstd, None, None)
-        lnf = ops.lib.size_query("emoasr_layernorm_bwd_scratch_floats", d)
-        ln_parts = torch.empty(self.nl, 5, lnf, device=dev, dtype=torch.float32)
-        dx_bufs = [torch.empty(M, d, device=dev, dtype=dt) for _ in range(2)]
-        for li in reversed(range(self.nl)):
-            out = dx_bufs[li & 1]
-            self._layer_rt.backward(li, layers[li], dx, out, ln_parts[li], self._ln_deferred)
-            dx = out
-            if self.grad_hook is not None:
-                self._flush_wgrads()
-                ops.layernorm_bwd_finalize(self._ln_deferred)
-                self.grad_hook(self._layer_offset(li))
-        self._flush_wgrads()
-        ops.layernorm_bwd_finalize(self._ln_deferred)
-        # positional scaling, Linear (all rows at once), then the two convolutions per micro-batch
-        dlin = ops.scale_dropout(dx, math.sqrt(d), p_enc, s_pe)
-        dwl = torch.zeros(d, F2 * C, device=dev, dtype=torch.float32)  # (f, c) order
-        ops.gemm_tn(dlin, y2, out=dwl, accumulate=True, colsum=A.g(pre + "output.bias"))
-        ops.strided_copy(dwl.view(d, F2, C).permute(0, 2, 1), out=A.g(pre + "output.weight").view(d, C, F2), accumulate=True)
-        dy2 = ops.gemm_nn(dlin, wlr, dact_pre=y2, dact=ACT_RELU)
-        dw2 = torch.zeros(C, 9 * C, device=dev, dtype=torch.float32)
-        wt = ops.strided_copy(A.p(pre + "conv.2.weight").permute(1, 2, 3, 0), out_dtype=dt).view(C, 9 * C)
-        for k, (xs, _, _, _) in enumerate(batches):
-            dy2_k = dy2[rows[k]:rows[k + 1]].view(-1, C)
-            ops.conv2_wgrad(dy2_k, y1s[k], dw2, dbias=A.g(pre + "conv.2.bias"), accumulate=True)
-            dy1 = ops.conv2_dgrad_kc(dy2_k, wt, y1s[k])
-            ops.conv1_wgrad(xs, dy1, A.g(pre + "conv.0.weight").view(C, 9), A.g(pre + "conv.0.bias"), accumulate=True)
-        ops.strided_copy(dw2.view(C, 3, 3, C).permute(0, 3, 1, 2), out=A.g(pre + "conv.2.weight"), accumulate=True)
+        self._encoder_bwd_stacked(st, deouts)
         return losses
 
     # ------------------------------------------------------------------ backward

@@ -61,6 +61,53 @@ def encoder_apply(enc, xs, xlens):
     return eouts, elens, inter
 
 
+class _EncoderStackedFn(torch.autograd.Function):
+    """the encoder over several micro-batches in ONE stacked pass (engine.encoder_forward_stacked): outputs one eouts tensor per
+    micro-batch (views of the stacked rows); the backward waits for all of their gradients and runs one stacked sweep"""
+
+    @staticmethod
+    def forward(ctx, eng, n, *args):
+        xs_list, xlens_list = list(args[:n]), list(args[n:2 * n])
+        eouts, st = eng.encoder_forward_stacked(xs_list, xlens_list)
+        ctx.eng, ctx.st = eng, st
+        outs = tuple(eouts[st.rows[k]:st.rows[k + 1]].view(st.segs[k][0], st.segs[k][1], eouts.shape[1]) for k in range(n))
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        st = ctx.st
+        eng = ctx.eng
+        d = grads[0].shape[-1] if grads[0] is not None else eng.d
+        deouts = torch.empty(st.M, d, device=st.y2.device, dtype=eng.dtype)
+        for k, gk in enumerate(grads):
+            dst = deouts[st.rows[k]:st.rows[k + 1]]
+            if gk is None:
+                dst.zero_()
+            else:
+                dst.copy_(gk.reshape(-1, d))
+        eng.encoder_backward_stacked(st, deouts)
+        ctx.st = None
+        return (None, None) + (None,) * (len(grads) * 2 + len(eng.arena.params))
+
+
+def encoder_apply_stacked(enc, xs_list, xlens_list):
+    """TransformerEncoder.forward for several micro-batches at once (training, autograd on): -> [(eouts, elens, None), ...].
+    Each micro-batch keeps its own padding, BatchNorm batch statistics and relative-position table (include/emoasr_hip.h:
+    emoasr_segments_t); only the row-wise kernels see them together."""
+    eng = _engine_of(enc)
+    xs_list = [x.to(torch.float32).contiguous() for x in xs_list]
+    hosts = [_host_list(v) for v in xlens_list]
+    n = len(xs_list)
+    outs = _EncoderStackedFn.apply(eng, n, *xs_list, *hosts, *eng.arena.params)
+    res = []
+    for k in range(n):
+        elens = torch.tensor([((v - 1) // 2 - 1) // 2 for v in hosts[k]], dtype=torch.int64)
+        eo = outs[k]
+        eo._emo_elens_dev = None   # (decoders fall back to building the device tensor from `elens`)
+        res.append((eo, elens, None))
+    return res
+
+
 class _CTCLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, eouts, elens_dev, ys_host, ylens_host, blank, head, *params):

@@ -190,43 +190,80 @@ def train_step(model, optimizer, data, params, device, no_grad=False, empty_cach
 
 
 def stacked_ok(model, optimizer, params):
-    """can the accum_grad micro-batches of one optimizer step go through the engine TOGETHER (train_group)?"""
+    """can the accum_grad micro-batches of one optimizer step go through the engine TOGETHER (train_group)?
+    -> "ctc" (encoder + CTC head + lattices stacked: engine.ctc_train_stacked), "encoder" (the encoder stacked, any decoder per
+    micro-batch on its slice of the stacked output) or False"""
     from .optimizers import Adam as HipAdam
     from . import lib
     base = getattr(optimizer, "optimizer", optimizer)
     if not isinstance(base, HipAdam) or not hasattr(model, "engine"):
         return False
-    if not (1 < params.accum_grad <= lib.MAX_SEGMENTS) or getattr(model, "decoder_type", "") != "ctc":
+    if not (1 < params.accum_grad <= lib.MAX_SEGMENTS) or not model.training:
         return False
     if not next(model.parameters()).is_cuda:
         return False
-    dec = model.decoder
-    if dec.kd_weight > 0 or dec.mtl_phone_ctc_weight > 0 or dec.mtl_inter_ctc_weight > 0:
+    eng = model.engine()
+    if not eng.encoder_stacked_ok():
         return False
-    return model.training and model.engine().stacked_ok()
+    dec = model.decoder
+    plain_ctc = (getattr(model, "decoder_type", "") == "ctc" and not (dec.kd_weight > 0 or dec.mtl_phone_ctc_weight > 0 or
+                                                                      dec.mtl_inter_ctc_weight > 0))
+    if plain_ctc and eng.stacked_ok():
+        return "ctc"
+    if getattr(model, "decoder_type", "") == "ctc":
+        return False   # (auxiliary CTC branches read the encoder's intermediate output: one-by-one passes)
+    return "encoder"
 
 
 def train_group(model, optimizer, datas, params, device, group=None, sync=True, specaug=None, empty_cache=False):
     """The `accum_grad` micro-batches of ONE optimizer step (asr/train_asr.py:106-128: forward, loss / accum_grad, backward for
     each, then clip / NaN skip / step / zero_grad) as one stacked pass through the engine (engine.ctc_train_stacked: every
     row-wise kernel runs once over all micro-batches' rows; attention, convolution padding and BatchNorm statistics stay per
-    micro-batch).  Same result as len(datas) calls of train_step up to summation order; needs stacked_ok(...).
-    -> list of the micro-batches' loss_dicts (values / accum_grad, as train_step returns them)."""
+    micro-batch).  Models with another decoder stack the ENCODER only (modeling/functions.py: encoder_apply_stacked) and run the
+    decoder per micro-batch on its slice.  Same result as len(datas) calls of train_step up to summation order; needs
+    stacked_ok(...).  -> list of the micro-batches' loss_dicts (values / accum_grad, as train_step returns them)."""
     world = _world(group)
     if world > 1:
         rank_dropout_seed(model, group)
     eng = model.engine()
-    batches = []
+    accum = params.accum_grad
+    mode = "ctc" if (getattr(model, "decoder_type", "") == "ctc" and eng.stacked_ok()) else "encoder"
+    xs_list, xl_list = [], []
     for data in datas:
         xs = data["xs"].to(device)
         xlens = [int(v) for v in data["xlens"]]
-        ylens = [int(v) for v in data["ylens"]]
         if specaug is not None:
             xs = specaug(xs.float(), data["xlens"])
-        xs = xs[:, : max(xlens)].to(torch.float32).contiguous()
-        batches.append((xs, xlens, data["ys"][:, : max(ylens)], ylens))
-    accum = params.accum_grad
-    losses = eng.ctc_train_stacked(batches, model.decoder.blank_id, scales=[1.0 / accum] * len(batches))
+        xs_list.append(xs[:, : max(xlens)].to(torch.float32).contiguous())
+        xl_list.append(xlens)
+    if mode == "ctc":
+        batches = []
+        for xs, xlens, data in zip(xs_list, xl_list, datas):
+            ylens = [int(v) for v in data["ylens"]]
+            batches.append((xs, xlens, data["ys"][:, : max(ylens)], ylens))
+        losses = eng.ctc_train_stacked(batches, model.decoder.blank_id, scales=[1.0 / accum] * len(batches))
+        if sync:
+            host = (losses / accum).tolist()
+            dicts = [{"loss_ctc": v, "loss_total": v} for v in host]
+        else:
+            dicts = [{"loss_ctc": losses[k] / accum, "loss_total": losses[k] / accum} for k in range(len(batches))]
+    else:
+        from .modeling.functions import encoder_apply_stacked
+        outs = encoder_apply_stacked(model.encoder, xs_list, xl_list)
+        total, dicts = None, []
+        for (eouts, elens, _), data in zip(outs, datas):
+            ymax = int(max(data["ylens"]))   # the targets are trimmed to the batch as ASR.forward does (asr.py:57-62)
+            ys = data["ys"][:, :ymax]
+            ys_in = data["ys_in"][:, : ymax + 1] if data.get("ys_in") is not None else None
+            ys_out = data["ys_out"][:, : ymax + 1] if data.get("ys_out") is not None else None
+            soft = data["soft_labels"].to(device) if data.get("soft_labels") is not None else None
+            ps, plens = data.get("ps"), data.get("plens")
+            if ps is not None:
+                ps = ps[:, : int(max(plens))]
+            loss, loss_dict, _ = model.decoder(eouts, elens, None, ys, data["ylens"], ys_in, ys_out, soft, ps, plens)
+            total = loss / accum if total is None else total + loss / accum
+            dicts.append({k: (v.item() / accum if sync else v.detach() / accum) for k, v in loss_dict.items()})
+        total.backward()
     base = getattr(optimizer, "optimizer", optimizer)
     if world > 1:
         allreduce_sum_(eng.arena.grad, group)
@@ -235,10 +272,7 @@ def train_group(model, optimizer, datas, params, device, group=None, sync=True, 
     optimizer.zero_grad()
     if empty_cache:
         torch.cuda.empty_cache()
-    if sync:
-        host = (losses / accum).tolist()
-        return [{"loss_ctc": v, "loss_total": v} for v in host]
-    return [{"loss_ctc": losses[k] / accum, "loss_total": losses[k] / accum} for k in range(len(batches))]
+    return dicts
 
 
 def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False, group=None, log=None):

@@ -187,3 +187,55 @@ def test_one_launch_per_kernel_equals_one_launch_per_segment(dev):
     assert l1 == l0, (l1, l0)
     scale = g0.abs().max().item()
     assert scale > 0 and (g1 - g0).abs().max().item() < 2e-3 * scale, (g1 - g0).abs().max().item() / scale
+
+
+DEC_CFGS = {
+    "rnnt": dict(decoder_type="rnn_transducer", vocab_size=96, embedding_size=64, dec_hidden_size=128, dec_num_layers=2,
+                 joint_hidden_size=128, dropout_emb_rate=0.0, dropout_dec_rate=0.0, mtl_ctc_weight=0.3, lsm_prob=0.0),
+    "attention": dict(decoder_type="transformer", dec_hidden_size=256, dec_num_attention_heads=4, dec_num_layers=2,
+                      dec_intermediate_size=512, dropout_dec_rate=0.0, mtl_ctc_weight=0.3, lsm_prob=0.1,
+                      loss_normalize_length=False, loss_normalize_batch=True, max_decode_ylen=20),
+}
+
+
+@pytest.mark.parametrize("kind", ["rnnt", "attention"])
+def test_stacked_encoder_under_other_decoders(dev, kind):
+    """modeling/functions.py: encoder_apply_stacked -- the ENCODER over several micro-batches in one stacked pass, the decoder
+    (RNN-T with auxiliary CTC / Transformer decoder with auxiliary CTC) per micro-batch on its slice of the stacked output --
+    against the micro-batches one after the other: losses 1e-3, every parameter gradient cosine 0.999."""
+    from emoasr_amd.modeling.functions import encoder_apply_stacked
+    model = _model(dev, **DEC_CFGS[kind])
+    eng = model.engine()
+    assert eng.encoder_stacked_ok() and not eng.stacked_ok()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    datas = _micro_batches()
+    for d in datas:
+        eos = torch.full((d["ys"].shape[0], 1), 2)
+        d["ys_in"], d["ys_out"] = torch.cat([eos, d["ys"]], 1), torch.cat([d["ys"], eos], 1)
+    n = len(datas)
+    eng.arena.grad.zero_()
+    want = []
+    for d in datas:
+        loss, _ = model(d["xs"].to(dev), d["xlens"], d["ys"], d["ylens"], d["ys_in"], d["ys_out"])
+        (loss / n).backward()
+        want.append(loss.item())
+    want_grad = eng.arena.grad.clone()
+    model.load_state_dict(sd0)
+    eng.arena.grad.zero_()
+    outs = encoder_apply_stacked(model.encoder, [d["xs"].to(dev) for d in datas], [d["xlens"] for d in datas])
+    total, got = None, []
+    for (eouts, elens, _), d in zip(outs, datas):
+        loss, _, _ = model.decoder(eouts, elens, None, d["ys"], d["ylens"], d["ys_in"], d["ys_out"], None, None, None)
+        total = loss / n if total is None else total + loss / n
+        got.append(loss.item())
+    total.backward()
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert abs(a - b) < 1e-3 * abs(b), (got, want)
+    A = eng.arena
+    for name in A.names:
+        o, k = A.offsets[name], A.pviews[name].numel()
+        g, w = A.grad[o:o + k], want_grad[o:o + k]
+        if w.abs().max() == 0:
+            continue
+        assert _cos(g, w) > 0.999, (name, _cos(g, w))
