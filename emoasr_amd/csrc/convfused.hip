@@ -449,7 +449,7 @@ extern "C" long emoasr_conv_module_bwd_seg_scratch_floats(const emoasr_segments_
   RowSegs sg;
   int tmax = 0;
   if (!row_segs(seg, C, &sg, &tmax)) return 0;
-  if (which == 0) return (sg.sums[sg.n] + sg.n) * 2 * C;
+  if (which == 0) return (sg.sums[sg.n] + 2 * sg.n) * 2 * C;   // partial rows, the means, the raw sums
   return emoasr_dwconv_bwd_w_scratch_floats(sg.b0[sg.n], tmax, C, K);
 }
 

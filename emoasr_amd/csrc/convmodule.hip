@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const
 // running_var gets the unbiased M2 / (M - 1) like nn.BatchNorm1d.  One block = 16 channels x 64
 // groups of partial blocks (16 blocks for C = 256: the partial table is walked in 7 steps, not 28).
 constexpr int BNF_CH = 16, BNF_G = 64;  // channels x groups of partial blocks per finalize block
+__device__ unsigned g_bn_tickets[2][64];   // arrival tickets per channel group ([0] statistics, [1] backward fold): zero between launches
 __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B_, int Tn_, int C, const float* __restrict__ part_,
                                                                  float* __restrict__ mean_, float* __restrict__ var_,
                                                                  float* __restrict__ running_mean,
@@ -79,56 +80,80 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B_, int Tn_
                                                                  long long* __restrict__ num_batches_tracked, const RowSegs sg) {
   __shared__ float red[BNF_G][BNF_CH];
   __shared__ float mean_s[BNF_CH];
+  __shared__ int s_last;
   const int lane = threadIdx.x % BNF_CH, grp = threadIdx.x / BNF_CH;
   const int c = blockIdx.x * BNF_CH + lane;
-  // stacked micro-batches: one set of statistics per segment, the running statistics move once per segment IN ORDER (the
-  // arithmetic of the separate passes); sg.n <= 1: the one dense batch (B_, Tn_)
-  const int ns = sg.n > 1 ? sg.n : 1;
-  for (int si = 0; si < ns; ++si) {
-    const int B = sg.n > 1 ? sg.b0[si + 1] - sg.b0[si] : B_, Tn = sg.n > 1 ? sg.T[si] : Tn_;
-    const float* part = sg.n > 1 ? part_ + sg.part[si] : part_;
-    float* mean = mean_ + (long)si * C;
-    float* var = var_ + (long)si * C;
-    const int nx = (Tn + DW_TT - 1) / DW_TT, nblk = B * nx;
-    const float M = (float)B * Tn;
-    float s = 0.f;
-    if (c < C) {
+  // stacked micro-batches: blockIdx.y = segment (one set of statistics each, computed in parallel); the running statistics must
+  // move once per segment IN ORDER (the arithmetic of the separate passes): the block of a channel group that arrives last
+  // applies all segments' updates.  sg.n <= 1: the one dense batch (B_, Tn_).
+  const int ns = sg.n > 1 ? sg.n : 1, si = blockIdx.y;
+  const int B = sg.n > 1 ? sg.b0[si + 1] - sg.b0[si] : B_, Tn = sg.n > 1 ? sg.T[si] : Tn_;
+  const float* part = sg.n > 1 ? part_ + sg.part[si] : part_;
+  float* mean = mean_ + (long)si * C;
+  float* var = var_ + (long)si * C;
+  const int nx = (Tn + DW_TT - 1) / DW_TT, nblk = B * nx;
+  const float M = (float)B * Tn;
+  float s = 0.f;
+  if (c < C) {
 #pragma unroll 8
-      for (int k = grp; k < nblk; k += BNF_G) s += part[(long)k * 2 * C + c];
-    }
-    red[grp][lane] = s;
-    __syncthreads();
-    if (grp == 0) {
-      float t = 0.f;
-#pragma unroll
-      for (int g = 0; g < BNF_G; ++g) t += red[g][lane];
-      mean_s[lane] = t / M;
-    }
-    __syncthreads();
-    const float mu = mean_s[lane];
-    float m2 = 0.f;
-    if (c < C)
-#pragma unroll 8
-      for (int k = grp; k < nblk; k += BNF_G) {
-        const int n = min(DW_TT, Tn - (k % nx) * DW_TT);
-        const float d = part[(long)k * 2 * C + c] / n - mu;
-        m2 += part[(long)k * 2 * C + C + c] + n * d * d;
-      }
-    __syncthreads();
-    red[grp][lane] = m2;
-    __syncthreads();
-    if (grp == 0 && c < C) {
-      float t = 0.f;
-#pragma unroll
-      for (int g = 0; g < BNF_G; ++g) t += red[g][lane];
-      mean[c] = mu;
-      var[c] = t / M;
-      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-      if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (M > 1.f ? t / (M - 1.f) : t / M);
-    }
-    __syncthreads();   // (red / mean_s are reused by the next segment)
+    for (int k = grp; k < nblk; k += BNF_G) s += part[(long)k * 2 * C + c];
   }
-  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += ns;
+  red[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < BNF_G; ++g) t += red[g][lane];
+    mean_s[lane] = t / M;
+  }
+  __syncthreads();
+  const float mu = mean_s[lane];
+  float m2 = 0.f;
+  if (c < C)
+#pragma unroll 8
+    for (int k = grp; k < nblk; k += BNF_G) {
+      const int n = min(DW_TT, Tn - (k % nx) * DW_TT);
+      const float d = part[(long)k * 2 * C + c] / n - mu;
+      m2 += part[(long)k * 2 * C + C + c] + n * d * d;
+    }
+  __syncthreads();
+  red[grp][lane] = m2;
+  __syncthreads();
+  float m2sum = 0.f;   // this segment's centred sum of squares (lanes of group 0)
+  if (grp == 0 && c < C) {
+#pragma unroll
+    for (int g = 0; g < BNF_G; ++g) m2sum += red[g][lane];
+    mean[c] = mu;
+    var[c] = m2sum / M;
+  }
+  if (!running_mean && !running_var && !num_batches_tracked) return;
+  // ---- running statistics, in segment order, by the last block of this channel group ------------------------------------------------
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(&g_bn_tickets[0][blockIdx.x], 1u) == (unsigned)ns - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (grp == 0 && c < C) {
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+    for (int k = 0; k < ns; ++k) {
+      const float Mk = sg.n > 1 ? (float)(sg.row[k + 1] - sg.row[k]) : M;
+      const float mk = __hip_atomic_load(mean_ + (long)k * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float vk = __hip_atomic_load(var_ + (long)k * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // biased: M2 / M
+      // (the own segment's sum is at hand exactly -- a dense batch updates bit for bit as before; the others' come back from var)
+      const float m2k = k == si ? m2sum : vk * Mk;
+      rm = (1.f - momentum) * rm + momentum * (k == si ? mu : mk);
+      rv = (1.f - momentum) * rv + momentum * (Mk > 1.f ? m2k / (Mk - 1.f) : m2k / Mk);
+    }
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+  }
+  if (threadIdx.x == 0) {
+    g_bn_tickets[0][blockIdx.x] = 0u;
+    if (num_batches_tracked && blockIdx.x == 0) *num_batches_tracked += ns;
+  }
 }
 
 // dw[c,j] += sum_{b,t} dy[b,t,c] * x[b,t+j-pad,c];  dbias[c] += sum dy
@@ -325,34 +350,59 @@ __global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(int npart_, int C, fl
                                                            float* __restrict__ tot_, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, const RowSegs sg) {
   __shared__ float red[2][64][16];
+  __shared__ int s_last;
   const int lane = threadIdx.x % 16, grp = threadIdx.x / 16;
   const int c = blockIdx.x * 16 + lane;
-  // stacked micro-batches: one pair of means per segment ([n, 2, C]); dgamma / dbeta take the segments' sums in order
-  const int ns = sg.n > 1 ? sg.n : 1;
-  for (int si = 0; si < ns; ++si) {
-    const int npart = sg.n > 1 ? (int)(sg.sums[si + 1] - sg.sums[si]) : npart_;
-    const float inv_m = sg.n > 1 ? 1.f / (float)(sg.row[si + 1] - sg.row[si]) : inv_m_;
-    const float* part = sg.n > 1 ? part_ + sg.sums[si] * 2 * C : part_;
-    float* tot = tot_ + (long)si * 2 * C;
-    float a = 0.f, b = 0.f;
-    if (c < C) {
+  // stacked micro-batches: blockIdx.y = segment (one pair of means each: tot [n, 2, C], then the raw sums [n, 2, C]); dgamma / dbeta
+  // take the segments' sums IN ORDER, added by the block of a channel group that arrives last (no float atomics)
+  const int ns = sg.n > 1 ? sg.n : 1, si = blockIdx.y;
+  const int npart = sg.n > 1 ? (int)(sg.sums[si + 1] - sg.sums[si]) : npart_;
+  const float inv_m = sg.n > 1 ? 1.f / (float)(sg.row[si + 1] - sg.row[si]) : inv_m_;
+  const float* part = sg.n > 1 ? part_ + sg.sums[si] * 2 * C : part_;
+  float* tot = tot_ + (long)si * 2 * C;
+  float* raw = tot_ + (long)ns * 2 * C + (long)si * 2 * C;   // (stacked launches only)
+  float a = 0.f, b = 0.f;
+  if (c < C) {
 #pragma unroll 8
-      for (int k = grp; k < npart; k += 64) { a += part[(long)k * 2 * C + c]; b += part[(long)k * 2 * C + C + c]; }
-    }
-    red[0][grp][lane] = a;
-    red[1][grp][lane] = b;
-    __syncthreads();
-    if (grp == 0 && c < C) {
-      a = 0.f; b = 0.f;
+    for (int k = grp; k < npart; k += 64) { a += part[(long)k * 2 * C + c]; b += part[(long)k * 2 * C + C + c]; }
+  }
+  red[0][grp][lane] = a;
+  red[1][grp][lane] = b;
+  __syncthreads();
+  if (grp == 0 && c < C) {
+    a = 0.f; b = 0.f;
 #pragma unroll
-      for (int g = 0; g < 64; ++g) { a += red[0][g][lane]; b += red[1][g][lane]; }
+    for (int g = 0; g < 64; ++g) { a += red[0][g][lane]; b += red[1][g][lane]; }
+    tot[c] = a * inv_m;
+    tot[C + c] = b * inv_m;
+    if (ns == 1) {
       if (dbeta) dbeta[c] += a;
       if (dgamma) dgamma[c] += b;
-      tot[c] = a * inv_m;
-      tot[C + c] = b * inv_m;
+    } else {
+      raw[c] = a;
+      raw[C + c] = b;
     }
-    __syncthreads();   // (red is reused by the next segment)
   }
+  if (ns == 1 || (!dbeta && !dgamma)) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(&g_bn_tickets[1][blockIdx.x], 1u) == (unsigned)ns - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (grp == 0 && c < C) {
+    float da = 0.f, db = 0.f;
+    const float* r0 = tot_ + (long)ns * 2 * C;
+    for (int k = 0; k < ns; ++k) {
+      da += __hip_atomic_load(r0 + (long)k * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      db += __hip_atomic_load(r0 + (long)k * 2 * C + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (dbeta) dbeta[c] += da;
+    if (dgamma) dgamma[c] += db;
+  }
+  if (threadIdx.x == 0) g_bn_tickets[1][blockIdx.x] = 0u;
 }
 // pass 3: dy = gamma*invstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat))
 template <typename T>
@@ -443,6 +493,7 @@ extern "C" int emoasr_bn_stats_finalize(int B, int Tn, int C, const float* part,
                                         float* running_mean, float* running_var, float momentum,
                                         long long* num_batches_tracked, void* stream) {
   EMO_CHECK(B * Tn > 0, "bn_stats_finalize: empty batch");
+  EMO_CHECK(cdiv(C, BNF_CH) <= 64, "bn_stats_finalize: C=%d too wide for the ticket table", C);
   bn_stats_finalize_kernel<<<cdiv(C, BNF_CH), 1024, 0, (hipStream_t)stream>>>(B, Tn, C, part, mean, var, running_mean,
                                                                           running_var, momentum, num_batches_tracked, RowSegs{});
   EMO_LAUNCH_CHECK();
@@ -552,8 +603,9 @@ extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, cons
 // ---- stacked micro-batches: the BatchNorm kernels over all segments in one launch each (called by csrc/convfused.hip) -----------
 int emo_bn_stats_finalize_seg(const RowSegs& sg, int C, const float* part, float* mean, float* var, float* running_mean,
                               float* running_var, float momentum, long long* nbt, hipStream_t s) {
-  bn_stats_finalize_kernel<<<cdiv(C, BNF_CH), 1024, 0, s>>>(sg.b0[1], sg.T[0], C, part, mean, var, running_mean, running_var,
-                                                          momentum, nbt, sg);
+  EMO_CHECK(cdiv(C, BNF_CH) <= 64, "bn_stats_finalize: C=%d too wide for the ticket table", C);
+  bn_stats_finalize_kernel<<<dim3(cdiv(C, BNF_CH), sg.n > 1 ? sg.n : 1), 1024, 0, s>>>(sg.b0[1], sg.T[0], C, part, mean, var,
+                                                                                     running_mean, running_var, momentum, nbt, sg);
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -567,7 +619,8 @@ int emo_bn_swish_fwd_seg(const RowSegs& sg, int C, const void* y, const float* m
   return 0;
 }
 
-// scratch: [sum over segments of cdiv(M_s, 16) partial rows][2][C], then the means tot [n][2][C] (returned in *tot_out)
+// scratch: [sum over segments of cdiv(M_s, 16) partial rows][2][C], then the means tot [n][2][C] (returned in *tot_out), then
+// the segments' raw sums [n][2][C]
 int emo_bn_swish_bwd_sums_seg(const RowSegs& sg, int C, const void* dz, const void* y, const float* mean, const float* var,
                               const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta, float* scratch,
                               float** tot_out, hipStream_t s) {
@@ -578,7 +631,9 @@ int emo_bn_swish_bwd_sums_seg(const RowSegs& sg, int C, const void* dz, const vo
   bn_bwd_sums_kernel<bf16><<<sgrid, 256, 0, s>>>((int)mmax, C, (const bf16*)dz, (const bf16*)y, mean, var, gamma, beta, eps, scratch,
                                                 sg);
   float* tot = scratch + sg.sums[sg.n] * 2 * C;
-  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>((int)sg.sums[1], C, 1.f / (float)sg.row[1], scratch, tot, dgamma, dbeta, sg);
+  EMO_CHECK(cdiv(C, 16) <= 64, "bn_swish_bwd_sums_seg: C=%d too wide for the ticket table", C);
+  bn_bwd_fold_kernel<<<dim3(cdiv(C, 16), sg.n > 1 ? sg.n : 1), 1024, 0, s>>>((int)sg.sums[1], C, 1.f / (float)sg.row[1], scratch, tot,
+                                                                         dgamma, dbeta, sg);
   if (tot_out) *tot_out = tot;
   EMO_LAUNCH_CHECK();
   return 0;
