@@ -175,8 +175,9 @@ __global__ __launch_bounds__(CF_CB) void cf_conv_bwd_kernel(int Tn, int C, int K
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* dcs = reinterpret_cast<bf16*>(smem);                       // [64][CB]  BatchNorm input gradient (tile + halo)
   bf16* zs = dcs + CF_ROWS_P * CF_CB;                                // [64][CB]  GLU output (tile + halo)
-  bf16* gas = zs + CF_ROWS_P * CF_CB;                                // [32][CB]  g[:, :C] of the tile's frames
-  bf16* gbs = gas + CF_TT * CF_CB;                                   // [32][CB]  g[:, C:]
+  // (the raw GLU halves of the tile's own frames used to sit in two more [32][CB] images: 96 KB per workgroup, ONE workgroup per
+  // CU, every phase's memory round trip exposed.  They are re-read from global memory in the last phase instead -- L2-resident,
+  // this workgroup staged them microseconds ago -- which leaves 64 KB and two workgroups per CU.)
   const int tid = threadIdx.x;
   const int cb = blockIdx.y * CF_CB;
   const int nch = min(CF_CB, C - cb);
@@ -229,10 +230,7 @@ __global__ __launch_bounds__(CF_CB) void cf_conv_bwd_kernel(int Tn, int C, int K
       for (int it = 0; it < CF_ROWS_P / 8; ++it) {
         const int row = tid / (CF_CB / 8) + it * 8;
         const int core = row - pad;
-        if (core >= 0 && core < CF_TT) {
-          store16(&gas[core * CF_CB + ch8], ga[it]);
-          store16(&gbs[core * CF_CB + ch8], gb[it]);
-        }
+        (void)core;
         Vec16<bf16> z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z.v[e] = (bf16)((float)ga[it].v[e] * sigmoidf_((float)gb[it].v[e]));
@@ -290,7 +288,10 @@ __global__ __launch_bounds__(CF_CB) void cf_conv_bwd_kernel(int Tn, int C, int K
       for (int j = 0; j < CF_MAXK; ++j) acc += wr[j] * dcw[i + j];
       const f2 d = unpack2(pack2(acc));   // the data gradient is stored as bf16 by the unfused kernel
       const int fr = half * (CF_TT / 2) + i;
-      const f2 a = unpack2(lds_pair(gas, fr, pr)), gt = unpack2(lds_pair(gbs, fr, pr));
+      const bool fok = t0 + fr < Tn;
+      const bf16* gp = g + ((long)b * Tn + (fok ? t0 + fr : 0)) * 2 * C + c0;
+      const f2 a = fok ? unpack2(*reinterpret_cast<const unsigned*>(gp)) : f2{0.f, 0.f};
+      const f2 gt = fok ? unpack2(*reinterpret_cast<const unsigned*>(gp + C)) : f2{0.f, 0.f};
       const f2 sg = f2{sigmoidf_(gt[0]), sigmoidf_(gt[1])};
       if (t0 + fr < Tn) {
         *reinterpret_cast<unsigned*>(dgb + (long)(t0 + fr) * 2 * C) = pack2(d * sg);
@@ -370,7 +371,7 @@ extern "C" int emoasr_conv_bwd_fused(int dtype, int B, int Tn, int C, int K, con
   EMO_CHECK(scratch != nullptr && tot != nullptr, "conv_bwd_fused: scratch and tot are required");
   if (B * Tn == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  constexpr int bytes = (2 * CF_ROWS_P + 2 * CF_TT) * CF_CB * 2;
+  constexpr int bytes = 2 * CF_ROWS_P * CF_CB * 2;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)cf_conv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -470,7 +471,7 @@ extern "C" int emoasr_conv_module_bwd_seg(int dtype, const emoasr_segments_t* se
   EmoTimerScope timer_(EMO_TIMER_CONV_MODULE, s, 0.0, 8.0 * (double)sg.row[sg.n] * C * 2.0);
   float* tot = nullptr;
   if (emo_bn_swish_bwd_sums_seg(sg, C, dz, c, bmean, bvar, gamma, beta, eps, dgamma, dbeta, bn_scratch, &tot, s)) return 1;
-  constexpr int bytes = (2 * CF_ROWS_P + 2 * CF_TT) * CF_CB * 2;
+  constexpr int bytes = 2 * CF_ROWS_P * CF_CB * 2;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)cf_conv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
