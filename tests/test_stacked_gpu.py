@@ -239,3 +239,31 @@ def test_stacked_encoder_under_other_decoders(dev, kind):
         if w.abs().max() == 0:
             continue
         assert _cos(g, w) > 0.999, (name, _cos(g, w))
+
+
+def test_train_loop_stacks_the_encoder_for_an_rnnt_model(dev, monkeypatch):
+    """train.train with accum_grad 3 on an RNN-T model: stacked_ok(...) == "encoder", two optimizer steps through train_group
+    (encoder of three micro-batches in one pass, decoder per micro-batch) against the one-by-one loop"""
+    from emoasr_amd import train as tr
+    from emoasr_amd.optimizers import Adam, ScheduledOptimizer
+    datas = _micro_batches() + [_batch(4, [250, 240, 100]), _batch(5, [150, 140, 130, 120, 80]), _batch(6, [403])]
+    for d in datas:
+        eos = torch.full((d["ys"].shape[0], 1), 2)
+        d["ys_in"], d["ys_out"] = torch.cat([eos, d["ys"]], 1), torch.cat([d["ys"], eos], 1)
+    params = SimpleNamespace(**dict(CFG, **DEC_CFGS["rnnt"]))
+
+    def run(stacked):
+        monkeypatch.setenv("EMOASR_STACKED", "1" if stacked else "0")
+        model = _model(dev, **DEC_CFGS["rnnt"])
+        opt = ScheduledOptimizer(Adam(model.parameters(), lr=0, weight_decay=params.weight_decay), params)
+        assert tr.stacked_ok(model, opt, params) == ("encoder" if stacked else False)
+        steps = tr.train(model, opt, datas, params, dev, 0)
+        assert steps == 2
+        return model.engine().arena.flat.clone()
+
+    p_stacked, p_single = run(True), run(False)
+    p0 = _model(dev, **DEC_CFGS["rnnt"]).engine().arena.flat
+    u1, u2 = p_stacked - p0, p_single - p0
+    cos, rel = _cos(u1, u2), ((u1 - u2).norm() / u2.norm()).item()
+    print(f"RNN-T parameter updates after 2 steps, stacked encoder vs one-by-one: cosine {cos:.5f}, relative L2 distance {rel:.3e}")
+    assert u2.abs().max() > 0 and cos > 0.98 and rel < 0.2, (cos, rel)
