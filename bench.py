@@ -60,7 +60,7 @@ def pmc_kernel(kernel, key):
         return None
     with open(path) as f:
         fams = json.load(f).get("kernels", {})
-    hit = [v for k, v in fams.items() if kernel in k]
+    hit = [v for k, v in fams.items() if k == kernel] or [v for k, v in fams.items() if kernel in k]
     if not hit or key not in hit[0]:
         return None
     n = sum(v["launches"] for v in hit)
@@ -122,6 +122,14 @@ def family_table(emo_lib, attn_work, elapsed_s=None):
             row["hbm_frac"] = row["gbps"] / HBM_PEAK_GBS
         if elapsed_s:
             row["share_of_step"] = ms * 1e-3 / elapsed_s
+        # HBM bytes per launch from the committed counter passes (not live: see pmc_kernel): what the family ACTUALLY moved against
+        # its algorithmic bytes, and the bandwidth that traffic amounts to at this run's launch time
+        tr = pmc_kernel(name, "traffic_bytes")
+        if tr:
+            row["pmc_traffic_MB"] = tr / 1e6
+            row["pmc_traffic_gbps"] = tr / (1e-3 * ms / calls) / 1e9
+            if by:
+                row["traffic_over_algorithmic"] = tr / (by / calls)
         out[name] = row
     return out
 
