@@ -542,6 +542,13 @@ def parity_mode(dev, batches, steps=4, warmup=2):
             loss, _ = m(bt.xs, bt.xlens, bt.ys, bt.ylens, None, None)
             hyps = m.decode(bt.xs, bt.xlens)[0]
             res.append((float(loss), logits, hyps, [int(e) for e in elens]))
+        # the mixed mode of greedy decoding: bf16 encoder, f32 logits out of the head product (engine.f32_head, the default)
+        eng16 = a16.engine()
+        e16, el16, _ = a16.encoder(bt.xs, bt.xlens)
+        z16f = eng16.head_logits(e16, "decoder.output", out_f32=True).float()
+        eng16.f32_head = False
+        h16_bf16_head = a16.decode(bt.xs, bt.xlens)[0]
+        eng16.f32_head = True
     (l32, z32, h32, el32), (l16, z16, h16, _) = res
     mask = torch.zeros(z32.shape[:2], dtype=torch.bool, device=dev)
     for b, e in enumerate(el32):
@@ -552,6 +559,10 @@ def parity_mode(dev, batches, steps=4, warmup=2):
                           "logits_rel": float((z16 - z32)[mask].abs().max() / (z32[mask].max() - z32[mask].min())),
                           "greedy_frame_agreement": float((a1 == a2).float().mean()),
                           "greedy_hyp_exact": float(np.mean([x == y for x, y in zip(h32, h16)])),
+                          "f32_head": {"note": "bf16 encoder, head product with f32 output (what greedy decoding uses)",
+                                       "greedy_frame_agreement": float((a1 == z16f.argmax(-1)[mask]).float().mean()),
+                                       "logits_rel": float((z16f - z32)[mask].abs().max() / (z32[mask].max() - z32[mask].min()))},
+                          "bf16_head_greedy_frame_agreement": float((a1 == a2).float().mean()),
                           "batch": f"B={len(bt.xlens)}, {sum(bt.xlens)} frames, random-init weights, dropout 0"}
     return out
 

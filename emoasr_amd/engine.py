@@ -240,6 +240,8 @@ class CTCEngine(_DecoderMixinPlaceholder):
         # bf16 attention backward as ONE score recomputation (EMOASR_ATTN_FUSED=0: the materialised three-GEMM path)
         self.attn_fused = os.environ.get("EMOASR_ATTN_FUSED", "1") != "0"
         self._bufs = {}
+        # greedy decoding in bf16 takes the arg-max over f32 logits (EMOASR_F32_HEAD=0: over logits rounded to bf16)
+        self.f32_head = os.environ.get("EMOASR_F32_HEAD", "1") != "0"
         self.seed = 0x5EED
         if _cfg(cfg, "decoder_type", "ctc") == "transformer":
             self._dec_init()
@@ -455,7 +457,9 @@ class CTCEngine(_DecoderMixinPlaceholder):
         return x, (None, s_att, None, s_ff, None)
 
     # ------------------------------------------------------------------ CTC head
-    def head_logits(self, eouts, head="decoder.output"):
+    def head_logits(self, eouts, head="decoder.output", out_f32=False):
+        """out_f32 (decoding in bf16 only): the logits leave the product as f32 instead of being rounded to bf16 -- an arg-max
+        over 10 000 bf16 logits flips on every pair closer than one bf16 ulp (0.03-0.06 at |logit| ~ 8); see bench `bf16_vs_f32`"""
         B, T, d = eouts.shape
         A = self.arena
         w = A.w(head + ".weight")
@@ -463,7 +467,11 @@ class CTCEngine(_DecoderMixinPlaceholder):
         out = None
         if V % 8:  # ragged vocabulary (phone heads): rows padded to the GEMMs' 16-byte leading-dimension rule
             out = torch.empty(B * T, (V + 7) // 8 * 8, device=eouts.device, dtype=eouts.dtype)[:, :V]
-        logits = ops.gemm_nt(eouts.reshape(B * T, d), w, out=out, bias=A.p(head + ".bias"))
+            out_f32 = False
+        if out_f32 and eouts.dtype != torch.float32:
+            logits = ops.gemm_nt(eouts.reshape(B * T, d), w, bias=A.p(head + ".bias"), out_f32=True)
+        else:
+            logits = ops.gemm_nt(eouts.reshape(B * T, d), w, out=out, bias=A.p(head + ".bias"))
         return logits.view(B, T, V)
 
     def ctc_loss(self, logits, elens, ys_host, ylens_host, blank, want_grad, gscale_over_b=None):

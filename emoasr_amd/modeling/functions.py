@@ -219,7 +219,7 @@ def ctc_loss_apply(dec, eouts, elens, ys, ylens, head="decoder.output"):
 
 def ctc_greedy_apply(dec, eouts, elens):
     eng = _engine_of(dec)
-    logits = eng.head_logits(eouts, getattr(dec, "_prefix", "decoder") + ".output")
+    logits = eng.head_logits(eouts, getattr(dec, "_prefix", "decoder") + ".output", out_f32=eng.f32_head)
     best, hyp, hyplen = eng.greedy(logits, _elens_dev(eouts, elens), dec.blank_id)
     best_h, hyp_h, n_h = best.cpu(), hyp.cpu(), hyplen.cpu().tolist()  # one D2H per batch
     el = _host_list(elens)
