@@ -81,10 +81,42 @@ def main():
     dist.all_gather(everyone, flat)
     for r in range(1, world):
         assert torch.equal(everyone[0], everyone[r]), f"parameters of rank {r} differ from rank 0 after 3 steps"
+    # ---- the stacked path (accum_grad micro-batches through the engine in one pass) under the same two ranks: a d = 256 model
+    #      (the large-tile front-end kernels want 256 channels), identical initial weights, different micro-batches per rank
+    from emoasr_amd.train import stacked_ok, train_group
+    cfg2 = dict(input_layer="conv2d", feat_dim=80, num_framestacks=1, encoder_type="conformer", decoder_type="ctc",
+                pos_encode_type="rel", enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=2,
+                enc_intermediate_size=512, dropout_enc_rate=0.1, dropout_attn_rate=0.1, vocab_size=96, blank_id=0, eos_id=2,
+                kd_weight=0, lr_schedule_type="noam", learning_rate=1.0, num_warmup_steps=10, accum_grad=2, clip_grad_norm=5.0,
+                weight_decay=1e-6, log_step=100)
+    p2 = SimpleNamespace(**cfg2)
+    torch.manual_seed(0)
+    m2 = ASR(p2, compute_dtype=torch.bfloat16)
+    o2 = ScheduledOptimizer(Adam(m2.parameters(), lr=0, weight_decay=p2.weight_decay), p2)
+    m2 = m2.to(dev).train()
+    assert stacked_ok(m2, o2, p2) == "ctc"
+    gen = torch.Generator().manual_seed(100 + rank)
+
+    def micro(xlens):
+        xl = torch.tensor(xlens)
+        yl = torch.clamp(xl // 40, min=1)
+        xs = torch.randn(len(xlens), int(xl.max()), 80, generator=gen)
+        ys = torch.randint(3, 96, (len(xlens), int(yl.max())), generator=gen)
+        return dict(xs=xs, xlens=xl, ys=ys, ylens=yl, ys_in=None, ys_out=None)
+
+    o2.update_epoch()
+    for _ in range(2):
+        train_group(m2, o2, [micro([203, 150, 96]), micro([303, 280])], p2, dev)
+    flat2 = m2.engine().arena.flat.clone()
+    both = [torch.zeros_like(flat2) for _ in range(world)]
+    dist.all_gather(both, flat2)
+    for r in range(1, world):
+        assert torch.equal(both[0], both[r]), f"stacked path: parameters of rank {r} differ from rank 0 after 2 steps"
+    assert torch.isfinite(flat2).all()
     if rank == 0:
         with open(out, "w") as f:
             json.dump({"ok": True, "allreduce_err": err, "rank_grad_difference": differ, "async_ranges": n_async,
-                       "step": optimizer._step}, f)
+                       "step": optimizer._step, "stacked_step": o2._step}, f)
     dist.barrier()
     dist.destroy_process_group()
 

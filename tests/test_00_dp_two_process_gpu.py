@@ -4,7 +4,7 @@ by a gloo group -- RCCL needs one GPU per rank, everything above the collective 
 
 The children assert: the rank dropout seed is applied before the first forward; the bucketed asynchronous all-reduce leaves
 the SUM of the ranks' own gradients in every arena; after three train_step updates the parameters are bit-identical on
-both ranks.  This process makes no GPU call itself (it sorts first in the suite for that reason) and only waits."""
+both ranks; the same after two train_group updates (two stacked micro-batches per rank and step) of a d = 256 model.  This process makes no GPU call itself (it sorts first in the suite for that reason) and only waits."""
 import json
 import os
 import socket
@@ -45,5 +45,5 @@ def test_two_ranks_on_one_gpu(tmp_path):
     for r, (p, log) in enumerate(zip(procs, logs)):
         assert p.returncode == 0, f"rank {r} failed:\n{log[-3000:]}"
     res = json.load(open(out))
-    assert res["ok"] and res["step"] == 3 and res["async_ranges"] >= 1, res
+    assert res["ok"] and res["step"] == 3 and res["async_ranges"] >= 1 and res["stacked_step"] == 2, res
     print("two ranks on one GPU:", res)
