@@ -17,6 +17,8 @@ void emo_set_error(const char* fmt, ...) {
 void emo_gemm_set_tr_read(int v);
 void emo_gemm_set_tile(int v);
 void emo_gemm_set_tn_group_blocks(int v);
+void emo_gemm_set_tn_group_kb(int v);
+void emo_gemm_set_tn_place(int v);
 void emo_gemm_set_kb(int v);
 void emo_gemm_set_xcd(int v);
 void emo_gemm_set_conv_big(int v);
@@ -119,6 +121,8 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   }
   if (strcmp(name, "gemm_tile") == 0) { emo_gemm_set_tile(value); return 0; }
   if (strcmp(name, "tn_group_blocks") == 0) { emo_gemm_set_tn_group_blocks(value); return 0; }
+  if (strcmp(name, "tn_group_kb") == 0) { emo_gemm_set_tn_group_kb(value); return 0; }
+  if (strcmp(name, "tn_place") == 0) { emo_gemm_set_tn_place(value); return 0; }
   if (strcmp(name, "gemm_kb") == 0) { emo_gemm_set_kb(value); return 0; }
   if (strcmp(name, "gemm_xcd") == 0) { emo_gemm_set_xcd(value); return 0; }
   if (strcmp(name, "conv_big") == 0) { emo_gemm_set_conv_big(value); return 0; }

@@ -14,6 +14,7 @@
 // registers -> LDS (double buffered, one barrier per k-tile); the next k-tile's
 // global loads are issued before the current tile's MFMAs.
 #include <algorithm>
+#include <vector>
 #include "mma.h"
 #include "../../include/emoasr_hip.h"
 
@@ -61,7 +62,7 @@ __device__ __forceinline__ void dgrad_row(const DgradGeom& g, int m, int& b, int
 }
 
 int g_tr_read = 1;
-int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1;
+int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1, g_tn_group_kb = 0, g_tn_place = 0;
 int g_tn_group_blocks = 0;  // override of a grouped TN launch's block budget (emoasr_set_option "tn_group_blocks"; 0 = auto)
 
 // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Reading
@@ -411,7 +412,7 @@ struct TnArgs {
 
 // one (n1 tile, n2 tile, k slice) of a TN product; shared by the plain and the grouped kernels
 template <typename T, int BN1, int BN2, int BMODE, bool TR, int KB>
-__device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const int by, const int bz, const int nbx) {
   using Cfg = TileCfg<T, KB>;
   using M_ = Mma<T>;
   constexpr int VEC = Cfg::VEC, BK = Cfg::BK;
@@ -501,7 +502,10 @@ __device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const bool do_colsum = g.colsum != nullptr && bx == 0 && tid < BN1;
+  // bias gradient: the nbx blocks of one row of tiles hold the same A tile; they take its k-tiles in turn, so that the blocks that
+  // share operand tiles do the same amount of work and stay within an L2 lifetime of each other (with the column sums on the bx = 0
+  // blocks alone those fell behind their neighbours and the 1024x256 product re-read a third of its A operand from HBM)
+  const bool do_colsum = g.colsum != nullptr && tid < BN1;
   float csum = 0.f;
   // same 3-deep register ring as the NT kernel (see there)
   Stage s0, s1, s2;
@@ -512,7 +516,7 @@ __device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const in
   auto step = [&](int kt, Stage& nxt, Stage& fre) {
     const int buf = (kt - kt_begin) & 1;
     load_tile(fre, kt + 2);
-    if (do_colsum) {
+    if (do_colsum && kt % nbx == bx) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) csum += to_f32(As[buf][k * LDA + tid]);
     }
@@ -558,26 +562,52 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
   // all (n1, n2) tiles of one k slice read the same rows of A and B: keep a slice on one XCD
   const int gx = gridDim.x, gy = gridDim.y;
   const int lin = xcd_remap((blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x, gx * gy * gridDim.z);
-  tn_block<T, BN1, BN2, BMODE, TR, KB>(g, lin % gx, (lin / gx) % gy, lin / (gx * gy));
+  tn_block<T, BN1, BN2, BMODE, TR, KB>(g, lin % gx, (lin / gx) % gy, lin / (gx * gy), gx);
 }
 
 // Grouped form: up to EMOASR_TN_GROUP_MAX independent products in one launch (the ~10 weight
 // gradients of one encoder layer: each alone is 16..64 tiles, far too few for 256 CUs).  Blocks
 // are numbered problem by problem; start[p] is the first block of problem p.
+// Placement (option "tn_place", off by default): a k slice of one problem (all its (n1, n2) tiles read the same rows of A and B) is
+// the unit that has to share an L2.  The hardware hands block i to XCD i % 8; with placement the host deals WHOLE slices to the eight
+// XCDs (largest first, to the least loaded) and block i = (xcd, slot) looks its slice up in that XCD's list.  The default --
+// contiguous eighths of the problem-by-problem block list -- cuts slices at the XCD boundaries.  Measured at 35 k rows
+// (tools/tn_probe.py, tools/tn_ab.sh): alone in a loop the placed launch of a layer's nine products is ahead (182 vs 193 us, and
+// with BK = 64 it read 790 instead of 855 MB), but inside the training step it is behind (291 vs 206 us per layer, rocprofv3
+// kernel trace of bench.py under both settings), so the step keeps the contiguous mapping.
+constexpr int TN_PLACE_MAX = 24;
+struct TnPlace {
+  unsigned short start[8][TN_PLACE_MAX + 1];   // first slot of entry e on XCD x; start[x][cnt[x]] = blocks of XCD x
+  unsigned char prob[8][TN_PLACE_MAX], split[8][TN_PLACE_MAX];
+  unsigned char cnt[8];
+};
 struct TnGroup {
   int n;
+  int xcd;   // 1: slices placed per XCD (place), 2: contiguous eighths of the block list, 0: hardware block order
   int start[EMOASR_TN_GROUP_MAX + 1];
   TnArgs p[EMOASR_TN_GROUP_MAX];
+  TnPlace place;
 };
 template <typename T, bool TR, int KB, int BT>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup G) {
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);  // see gemm_tn_kernel
+  if (G.xcd == 1) {
+    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, cnt = G.place.cnt[x];
+    if (slot >= G.place.start[x][cnt]) return;
+    int e = 0;
+    while (e + 1 < cnt && slot >= G.place.start[x][e + 1]) ++e;
+    const TnArgs& g = G.p[G.place.prob[x][e]];
+    const int local = slot - G.place.start[x][e];
+    const int tx = (g.N2 + BT - 1) / BT;
+    tn_block<T, BT, BT, 0, TR, KB>(g, local % tx, local / tx, G.place.split[x][e], tx);
+    return;
+  }
+  const int bid = G.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;  // see gemm_tn_kernel
   int p = 0;
   while (p + 1 < G.n && bid >= G.start[p + 1]) ++p;
   const TnArgs& g = G.p[p];
   const int local = bid - G.start[p];
   const int tx = (g.N2 + BT - 1) / BT, ty = (g.N1 + BT - 1) / BT;
-  tn_block<T, BT, BT, 0, TR, KB>(g, local % tx, (local / tx) % ty, local / (tx * ty));
+  tn_block<T, BT, BT, 0, TR, KB>(g, local % tx, (local / tx) % ty, local / (tx * ty), tx);
 }
 
 template <typename T, int AMODE, bool BKM, bool TR>
@@ -616,17 +646,19 @@ int launch_nn(const NtArgs& a, hipStream_t s, int nz = 1) {
 
 template <typename T, int BMODE>
 int launch_tn(TnArgs a, hipStream_t s) {
-  const int kb = sizeof(T) == 2 ? (g_gemm_kb ? g_gemm_kb : (a.K >= 512 ? 2 : 1)) : 1;
+  const bool big = (long)cdiv(a.N1, 128) * cdiv(a.N2, 128) >= 32 && a.N1 >= 128 && a.N2 >= 128;
+  // BK = 32 with the 128x128 tile (three resident blocks per CU instead of two; see emoasr_gemm_tn_grouped), 64 for long reductions on 64x64
+  const int kb = sizeof(T) == 2 ? (g_gemm_kb ? g_gemm_kb : (a.K >= 512 && !big ? 2 : 1)) : 1;
   const int BK = TileCfg<T>::BK * kb;
   const int nk = cdiv(a.K, BK);
-  const bool big = (long)cdiv(a.N1, 128) * cdiv(a.N2, 128) >= 32 && a.N1 >= 128 && a.N2 >= 128;
   const int bn = big ? 128 : 64;
   const long tiles = (long)cdiv(a.N1, bn) * cdiv(a.N2, bn);
   // split-K: as many slices as fit ONE round of resident blocks (rounding up past it leaves a mostly empty
   // second round) with at least 4 k-tiles each, but keep
   // the f32 atomic traffic (output bytes x slices) around 8 MB: global float atomics run at
   // ~1.3 TB/s chip-wide, so more slices than that make the kernel atomic-bound.
-  int splits = (int)std::max(1L, (big ? 512 : 768) / tiles);  // one full round of resident blocks (2 / 3 per CU)
+  const long slots_ = g_tn_group_blocks > 0 ? g_tn_group_blocks : (big && kb == 2 ? 512 : 768);
+  int splits = (int)std::max(1L, slots_ / tiles);  // one full round of resident blocks (2 per CU for the 128x128 BK=64 tile, else 3)
   const long out_bytes = (long)a.N1 * a.N2 * 4;
   // ... unless the reduction is so long that the atomics stay below ~10 % of the product's own time
   // (estimated at 300 TFLOP/s): the Conv2d weight gradient (K = B*T'*F2 ~ 130 k) wants 15 slices, not 3
@@ -679,6 +711,8 @@ void emo_gemm_set_tr_read(int v) { g_tr_read = v; }
 void emo_gemm_set_tile(int v) { g_gemm_tile = v; }
 void emo_gemm_set_tn_group_blocks(int v) { g_tn_group_blocks = v > 0 ? v : 0; }
 void emo_gemm_set_kb(int v) { g_gemm_kb = v; }
+void emo_gemm_set_tn_place(int v) { g_tn_place = v != 0; }
+void emo_gemm_set_tn_group_kb(int v) { g_tn_group_kb = (v == 1 || v == 2) ? v : 0; }
 void emo_gemm_set_xcd(int v) { g_gemm_xcd = v; }
 
 static int check_vec(long ld, int dtype, const char* what) {
@@ -767,8 +801,6 @@ extern "C" int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, l
 // Grouped weight-gradient products (always accumulating): see TnGroup.
 extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_t* probs, void* stream) {
   EMO_CHECK(n > 0 && n <= EMOASR_TN_GROUP_MAX, "gemm_tn_grouped: n=%d outside 1..%d", n, EMOASR_TN_GROUP_MAX);
-  const int kb = dtype == EMO_BF16 ? 2 : 1;
-  const int BK = (dtype == EMO_BF16 ? 32 : 16) * kb;
   TnGroup G{};
   G.n = n;
   long tiles = 0;
@@ -777,6 +809,12 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   for (int i = 0; i < n; ++i)
     if (probs[i].N1 < 128 || probs[i].N2 < 128) bt = 64;
   if (g_gemm_tile == 3) bt = 64;
+  // k extent of a tile: 32 for the 128x128 bf16 tile (40 KB of LDS, three blocks per CU), 64 for the 64x64 one.  (BK = 64 with the
+  // 128 tile is 80 KB: the 480-block launch of a layer then ran in TWO rounds, blocks sharing operand tiles were no longer
+  // co-resident and the launch read 1.2-1.6x its operands from HBM; BK = 32 reads them once -- 216 -> 185 us at 35 k rows,
+  // tools/tn_probe.py.)  Option "gemm_kb" overrides.
+  const int kb = dtype == EMO_BF16 ? (g_tn_group_kb ? g_tn_group_kb : g_gemm_kb ? g_gemm_kb : (bt == 128 ? 1 : 2)) : 1;
+  const int BK = (dtype == EMO_BF16 ? 32 : 16) * kb;
   for (int i = 0; i < n; ++i) {
     const emoasr_tn_problem_t& q = probs[i];
     EMO_CHECK(q.N1 > 0 && q.N2 > 0 && q.K > 0, "gemm_tn_grouped: empty problem %d", i);
@@ -787,9 +825,9 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   }
   // at least 4 k-tiles per slice, and per problem no more f32 atomic traffic than ~8 MB (see launch_tn)
   // one split factor for the whole group, chosen so that the launch is ONE full round of resident blocks:
-  // a 128x128-tile block takes 80 KB of LDS (2 per CU), a 64x64 one 48 KB (3 per CU).  Rounding the block
-  // count up past that (768 blocks of the 128 tile = 1.5 rounds) measured 68 us against 52 us for 460.
-  const long slots = g_tn_group_blocks > 0 ? g_tn_group_blocks : (bt == 128 ? 512 : 768);
+  // three blocks per CU for the 128x128 BK=32 tile (40 KB of LDS) and the 64x64 one (48 KB), two for 128x128 BK=64.  Rounding
+  // the block count up past that measured slower every time (at 35 k rows: 768 blocks 185 us, 896 blocks 257 us).
+  const long slots = g_tn_group_blocks > 0 ? g_tn_group_blocks : (bt == 128 && kb == 2 ? 512 : 768);
   const int want = (int)std::max(1L, slots / tiles);
   int start = 0;
   for (int i = 0; i < n; ++i) {
@@ -807,6 +845,41 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   }
   G.start[n] = start;
   hipStream_t s = (hipStream_t)stream;
+  G.xcd = g_tn_place ? 1 : (g_gemm_xcd ? 2 : 0);
+  if (G.xcd == 1) {   // deal whole slices to the XCDs: largest first, each to the XCD with the fewest blocks so far
+    struct Slice { int tiles, prob, split; };
+    std::vector<Slice> sl;
+    for (int i = 0; i < n; ++i) {
+      const int tiles_i = cdiv(probs[i].N1, bt) * cdiv(probs[i].N2, bt);
+      const int splits_i = (G.start[i + 1] - G.start[i]) / tiles_i;
+      for (int z = 0; z < splits_i; ++z) sl.push_back({tiles_i, i, z});
+    }
+    std::stable_sort(sl.begin(), sl.end(), [](const Slice& a, const Slice& b) { return a.tiles > b.tiles; });
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool fits = true;
+    for (const Slice& q : sl) {
+      int x = 0;
+      for (int j = 1; j < 8; ++j)
+        if (load[j] < load[x]) x = j;
+      if (cnt[x] == TN_PLACE_MAX || load[x] + q.tiles > 65535 || q.split > 255) { fits = false; break; }
+      G.place.start[x][cnt[x]] = (unsigned short)load[x];
+      G.place.prob[x][cnt[x]] = (unsigned char)q.prob;
+      G.place.split[x][cnt[x]] = (unsigned char)q.split;
+      load[x] += q.tiles;
+      ++cnt[x];
+    }
+    if (fits) {
+      int most = 0;
+      for (int x = 0; x < 8; ++x) {
+        G.place.start[x][cnt[x]] = (unsigned short)load[x];
+        G.place.cnt[x] = (unsigned char)cnt[x];
+        most = std::max(most, load[x]);
+      }
+      start = 8 * most;   // blocks past an XCD's list return at once
+    } else {
+      G.xcd = 2;
+    }
+  }
   double gfl = 0.0, gby = 0.0;
   for (int i = 0; i < n; ++i) {
     gfl += 2.0 * probs[i].N1 * probs[i].N2 * probs[i].K;
@@ -815,7 +888,10 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   EmoTimerScope timer_(EMO_TIMER_GEMM_TN, s, gfl, gby);
   emo_timer_begin(EMO_TIMER_TN_GROUPED, s, gfl, gby);
   if (dtype == EMO_BF16) {
-    if (bt == 128) {
+    if (bt == 128 && kb == 1) {
+      if (g_tr_read) gemm_tn_grouped_kernel<bf16, true, 1, 128><<<start, 256, 0, s>>>(G);
+      else gemm_tn_grouped_kernel<bf16, false, 1, 128><<<start, 256, 0, s>>>(G);
+    } else if (bt == 128) {
       if (g_tr_read) gemm_tn_grouped_kernel<bf16, true, 2, 128><<<start, 256, 0, s>>>(G);
       else gemm_tn_grouped_kernel<bf16, false, 2, 128><<<start, 256, 0, s>>>(G);
     } else {

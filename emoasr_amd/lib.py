@@ -298,6 +298,11 @@ def load():
         fn.argtypes = args
         fn.restype = c_int
     _lib = lib
+    # tuning overrides for measurements: EMOASR_OPTIONS="name=value,name=value" (the names of emoasr_set_option)
+    for item in filter(None, os.environ.get("EMOASR_OPTIONS", "").split(",")):
+        name, _, value = item.partition("=")
+        if lib.emoasr_set_option(name.strip().encode(), int(value)) != 0:
+            raise EmoasrHipError(f"EMOASR_OPTIONS: {lib.emoasr_last_error().decode()}")
     return lib
 
 
