@@ -320,6 +320,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
       for (int r = 0; r < 16; ++r) sc[(r0 + c_row(r, lane)) * EP_LD + wn + j * 32 + c_col(lane)] = a[r];
     }
   };
+  // The epilogue's own operands (residual rows, the saved pre-activation of a backward pass) are fetched BEFORE the tile is staged:
+  // the output may alias the residual (x += ...), so behind the barrier the compiler has to keep load -> store -> load order across
+  // the passes -- one exposed global round trip per pass and block.  Each thread reads exactly the elements it later writes.
+  constexpr int NPASS = EPI_ROWS / RPP;
+  constexpr int RAWN = sizeof(T) == 2 ? 1 : 2;
+  Vec16<T> pf_res[NPASS][RAWN], pf_dpre[NPASS][RAWN];
+  if (vec_ok && (res || dpre)) {
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = m0 + hrow0 + pass * RPP + er;
+      if (row < g.M && col < g.N) {
+        if (res) {
+          const T* rp = res + (g.nh > 0 ? c_base : 0) + (long)row * ep.ldr + col;
+#pragma unroll
+          for (int q = 0; q < RAWN; ++q) pf_res[pass][q] = load16(rp + q * Vec16<T>::N);
+        }
+        if (dpre) {
+          long off = c_base + (long)row * g.ldc + col;
+          if constexpr (AMODE == 2) {
+            int bb, ii, jj;
+            dgrad_row(g.dg, row, bb, ii, jj);
+            off = (((long)bb * g.dg.T1 + 2 * ii + g.dg.pt) * g.dg.F1 + 2 * jj + g.dg.pf) * g.dg.C + col;
+          }
+#pragma unroll
+          for (int q = 0; q < RAWN; ++q) pf_dpre[pass][q] = load16(dpre + off + q * Vec16<T>::N);
+        }
+      }
+    }
+  }
+  auto raw8 = [&](const Vec16<T> (&r)[RAWN], float (&d)[8]) __attribute__((always_inline)) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = r[0].get(e);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[e] = r[0].get(e); d[4 + e] = r[RAWN - 1].get(e); }
+    }
+  };
   stage_tile(acc[0][0], 0, 0);
   if constexpr (TN > 1) stage_tile(acc[0][TN - 1], 0, TN - 1);
   if constexpr (TM > 1) {
@@ -357,14 +395,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
         act_vec<8>(ep.act, v);
         if (dpre) {
           float d[8];
-          load8<T>(dpre + off, d);
+          raw8(pf_dpre[pass], d);
           dact_vec<8>(ep.dact, d, v);
         }
         // (vec_ok: N % 8 == 0 and col % 8 == 0, so the 8 mask indices start at an even one)
         dropout_apply8(ep.seed, (uint64_t)row * (uint64_t)g.N + col, ep.drop_p, v);
         if (res) {
           float d[8];
-          load8<T>(res + (g.nh > 0 ? c_base : 0) + (long)row * ep.ldr + col, d);
+          raw8(pf_res[pass], d);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = d[e] + ep.res_scale * v[e];
         }

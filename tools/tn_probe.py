@@ -51,7 +51,8 @@ B_, T1, F1, C = 16, 4 * (K // 5 // 16) // 2, 39, 256
 y1 = rnd(B_, T1, F1, C); T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
 dy2 = rnd(B_, T2, F2, C); dw = torch.zeros(C, 3, 3, C, device=dev); db = torch.zeros(C, device=dev)
 print(f"conv2 wgrad: K = {B_ * T2 * F2}")
-for name, opts in [("default", {}), ("BK=64, 512", {"gemm_kb": 2, "tn_group_blocks": 512}), ("BK=32, 512", {"tn_group_blocks": 512})]:
+for name, opts in [("default", {}), ("BK=64, 512", {"gemm_kb": 2, "tn_group_blocks": 512}), ("288 blocks", {"tn_group_blocks": 288}),
+                   ("576 blocks", {"tn_group_blocks": 576}), ("864 blocks", {"tn_group_blocks": 864})]:
     for k, v in opts.items(): lib.set_option(k, v)
     u1 = timeit(lambda: ops.gemm_tn(a, b, out=out, accumulate=True, colsum=cs))
     u2 = timeit(lambda: ops.conv2_wgrad(dy2, y1, dw, db, accumulate=True))
