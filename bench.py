@@ -576,6 +576,8 @@ def main():
     ap.add_argument("--accum", type=int, default=5,
                     help="micro-batches per optimizer step (the reference trains with accum_grad: 5, asr/correct/exps/csj/asr.yaml:52, "
                          "asr/train_asr.py:106-128); a `step` of this benchmark is one optimizer step = this many micro-batches")
+    ap.add_argument("--timer-stride", type=int, default=17,
+                    help="in the timed region every n-th launch of the dominant kernel family is timed with a HIP event pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point GPU time table to stderr")
@@ -700,9 +702,10 @@ def main():
     dominant = max(families, key=lambda k: families[k]["ms"]) if families else "gemm_nt_nn"
     sync()
     frames = sum(sum(b.xlens) for grp in batches[args.warmup:] for b in grp)
-    # an event pair per launch is not free: families with hundreds of launches per step are SAMPLED, every 7th launch (7 is
-    # coprime with the per-step launch counts, so over the timed steps every shape is sampled equally often)
-    stride = 7 if families.get(dominant, {}).get("calls", 0) > 48 else 1
+    # an event pair per launch is not free (~10 us of lost overlap with the neighbouring kernels): families with hundreds of
+    # launches per step are SAMPLED, every 17th launch (17 is coprime with the per-step launch counts -- 208 = 16 x 13 for the
+    # GEMMs -- so over the timed steps every call site is sampled equally often)
+    stride = args.timer_stride if families.get(dominant, {}).get("calls", 0) > 48 else 1
     emo_lib.set_option("timer_stride", stride)
     emo_lib.set_option("timers", emo_lib.timer_mask(dominant))
     emo_lib.timer_read_ex(dominant)
