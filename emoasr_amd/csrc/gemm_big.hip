@@ -452,8 +452,11 @@ int emo_conv_big_enabled() { return g_conv_big; }
 
 // Measured in the L2 training step (M ~ 7 k rows): with the q/k/v, feed-forward w1 and pointwise-conv-1 products
 // (165 - 220 tiles of 128 x 256) on this kernel the step took 9.72 ms against 9.66 ms without -- those launches are
-// latency-bound either way -- so only products of at least two full rounds of tiles are taken.
-int g_big_min_tiles = 512;
+// latency-bound either way -- so only products of at least two full rounds of tiles are taken.  Round 3, stacked rows
+// (M ~ 35 k): the same three products (550 - 1100 tiles) run FASTER on the 64 x 64 kernel of gemm.hip (step 31.44 -> 30.96 ms
+// with the threshold at 2000 tiles, 31.17 with this kernel off for plain products): what stays here is the vocabulary
+// projection (N = 10 000: 2 280 tiles at 7 k rows, 11 000 at 35 k) and the Conv2d products.
+int g_big_min_tiles = 2000;
 
 // Does the large-tile kernel take this emoasr_gemm_nt call?  (bf16 product, full 256-column tiles, 64-deep k-tiles, an
 // epilogue without residual / saved-activation / f32 output, and enough 128-row tiles to occupy most CUs.)
