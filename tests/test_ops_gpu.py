@@ -830,6 +830,35 @@ def test_gemm_tn_grouped(dev, dtype, tr_mode):
             _close(cs, ref_cs, 1e-4, f"grouped colsum {i}")
 
 
+@pytest.mark.parametrize("place", [0, 1], ids=["contiguous", "placed"])
+def test_gemm_tn_grouped_layer_shapes(dev, place):
+    """the products of one encoder layer's backward (every N >= 128: the 128 x 128, BK = 32 tile; bias sums dealt round-robin to the
+    blocks of a tile row; k slices either in contiguous eighths of the block list or dealt whole to the XCDs, option tn_place)
+    against torch, with a short reduction among long ones and one product without bias sums, as csrc/layer.hip groups them"""
+    from emoasr_amd import lib, ops
+    K, R = 3001, 411
+    shapes = [(256, 1024, K, 1), (1024, 256, K, 1), (256, 256, K, 1), (512, 256, K, 1), (256, 256, K, 1), (256, 256, R, 0),
+              (768, 256, K, 1), (256, 1024, K, 1), (1024, 256, K, 1)]
+    probs, refs = [], []
+    for i, (n1, n2, k, cs_on) in enumerate(shapes):
+        a = _rnd(dev, k, n1, dtype=torch.bfloat16)
+        b = _rnd(dev, k, n2, dtype=torch.bfloat16, scale=k ** -0.5)
+        out = torch.randn(n1, n2, device=dev)
+        cs = torch.randn(n1, device=dev) if cs_on else None
+        alpha = 1.0 if i % 2 else 0.5
+        refs.append((out + alpha * (a.float().t() @ b.float()), None if cs is None else cs + alpha * a.float().sum(0)))
+        probs.append((a, b, out, alpha, cs, alpha))
+    lib.set_option("tn_place", place)
+    try:
+        ops.gemm_tn_grouped(probs)
+    finally:
+        lib.set_option("tn_place", 0)
+    for i, ((a, b, out, alpha, cs, _), (ref, ref_cs)) in enumerate(zip(probs, refs)):
+        _close(out, ref, _tol(torch.bfloat16), f"layer product {i}")
+        if cs is not None:
+            _close(cs, ref_cs, 2e-3, f"layer bias sum {i}")
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_dwconv_bn_stats_fused(dev, dtype):
     """conv + fused batch statistics == separate conv, then torch mean / var over all B*T rows
