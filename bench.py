@@ -776,6 +776,26 @@ def main():
                 print(f"  {k:28s} calls {v['calls']:5d}  {v['ms']:9.3f} ms  {100 * v['ms'] / tot:5.1f}%  {tf:7.1f} TF/s",
                       file=sys.stderr)
             print(f"  total instrumented GPU time {tot:.2f} ms (one step, {accum} micro-batches)", file=sys.stderr)
+        if world == 1:
+            # the same optimizer steps with the features handed over as HOST buffers (pinned, as a DataLoader with pin_memory
+            # yields them): the H2D copies are inside the timed region.  Never `value`; noted in DESIGN.md section 4.
+            host_steps = batches[args.warmup:args.warmup + 4]
+            pinned = [[bt.xs.cpu().pin_memory() for bt in grp] for grp in host_steps]
+
+            def host_step(grp, pins):
+                return step([SimpleNamespace(xs=px.to(dev, non_blocking=True), xlens=bt.xlens, ys=bt.ys, ylens=bt.ylens)
+                             for bt, px in zip(grp, pins)])
+
+            host_step(host_steps[0], pinned[0])
+            sync()
+            t0 = time.perf_counter()
+            for grp, pins in zip(host_steps[1:], pinned[1:]):
+                host_step(grp, pins)
+            sync()
+            res["host_inputs"] = {"frames_per_s": sum(sum(b.xlens) for grp in host_steps[1:] for b in grp) / (time.perf_counter() - t0),
+                                  "steps": len(host_steps) - 1,
+                                  "MB_per_step": sum(px.numel() * 4 for px in pinned[1]) / 1e6,
+                                  "note": "features start in pinned host memory, H2D inside the timed region (PCIe-inclusive rate)"}
         if world == 1 and not args.no_decode:
             import tempfile
             with tempfile.TemporaryDirectory() as tmpdir:
