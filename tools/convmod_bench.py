@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from emoasr_amd import lib, ops
-from tools.gemm_bench2 import graph_time
+from tools._timing import graph_time
 
 dev = torch.device("cuda:0")
 B, T, C, K = int(os.environ.get("B", 22)), int(os.environ.get("T", 320)), 256, 31

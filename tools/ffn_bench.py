@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from emoasr_amd import ops
-from tools.gemm_bench2 import graph_time
+from tools._timing import graph_time
 
 dev = torch.device("cuda:0")
 M, d, F = int(os.environ.get("M", 7029)), 256, 1024

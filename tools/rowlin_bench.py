@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from emoasr_amd import ops
-from tools.gemm_bench2 import graph_time
+from tools._timing import graph_time
 dev = torch.device("cuda:0")
 bf = torch.bfloat16
 for (M, N, K) in [(10, 768, 256), (10, 256, 256), (10, 1024, 256), (10, 256, 1024), (10, 10000, 256)]:
