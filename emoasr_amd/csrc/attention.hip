@@ -25,6 +25,7 @@
 //   attn_bwd_dq_kernel: per 32 queries, loops over key tiles   -> dq, dbias_u, dbias_v
 //   attn_bwd_dkv_kernel: per 32 keys, loops over query tiles   -> dk, dv
 //   attn_bwd_dpos_kernel: per 32 table rows, loops over query tiles -> dpos
+#include <algorithm>
 #include "mma.h"
 #include "../../include/emoasr_hip.h"
 
@@ -165,6 +166,21 @@ __device__ __forceinline__ SegRef seg_ref(const emoasr_attn_t& karg, int s) {
 __device__ __forceinline__ SegRef seg_of_utt(const emoasr_attn_t& karg, int b) {
   int s = 0;
   for (int k = 1; k < EMOASR_MAX_SEGMENTS; ++k) s += (k < karg.nseg && b >= karg.seg_b0[k]) ? 1 : 0;
+  return seg_ref(karg, s);
+}
+// workgroup slot z of a stacked launch -> (segment, utterance inside it): the slots run through the segments in seg_order
+// (longest first, filled by the launcher), so the hardware's in-order dispatch is a longest-processing-time-first schedule
+__device__ __forceinline__ SegRef seg_of_slot(const emoasr_attn_t& karg, int z, int& local) {
+  int v = z, s = karg.seg_order[0];
+  bool found = false;
+  for (int k = 0; k < EMOASR_MAX_SEGMENTS; ++k) {
+    if (k < karg.nseg && !found) {
+      const int sk = karg.seg_order[k], nbk = karg.seg_b0[sk + 1] - karg.seg_b0[sk];
+      if (v < nbk) { s = sk; found = true; }
+      else v -= nbk;
+    }
+  }
+  local = v;
   return seg_ref(karg, s);
 }
 __device__ __forceinline__ SegRef seg_of_row(const emoasr_attn_t& karg, long row) {
@@ -311,9 +327,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
   emoasr_attn_t a = a_in;
   int b = blockIdx.z;
   if (a_in.nseg > 1) {
-    const SegRef g = seg_of_utt(a_in, b);
+    const SegRef g = seg_of_slot(a_in, blockIdx.z, b);
     seg_apply<T>(a, g);
-    b -= g.b0;
   }
   const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y;
   if (i0 >= a.Tq) return;
@@ -1371,9 +1386,8 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
   FusedWs ws = ws_in;
   int b = blockIdx.z;
   if (a_in.nseg > 1) {   // stacked micro-batches: this workgroup's segment (the scratch images are stacked like the rows)
-    const SegRef g = seg_of_utt(a_in, b);
+    const SegRef g = seg_of_slot(a_in, blockIdx.z, b);
     seg_apply<T>(a, g);
-    b -= g.b0;
     ws.qu = (const T*)ws.qu + g.row * ws.ldqu;
     ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
     ws.dq32 += g.row * (long)(a.H * DK);
@@ -1899,6 +1913,13 @@ int set_smem(K kernel, int bytes) {
 int g_tr = 1;
 int g_fused_fw = 0;  // key tiles per workgroup of the single-pass backward (0 = by grid size; emoasr_set_option "attn_fw")
 
+int g_attn_lpt = 1;   // option "attn_lpt": 0 = segments in stacking order
+// dispatch order of a stacked launch's segments: longest first (stable), see seg_of_slot
+void fill_seg_order(emoasr_attn_t& a) {
+  for (int k = 0; k < EMOASR_MAX_SEGMENTS; ++k) a.seg_order[k] = k;
+  if (a.nseg > 1 && g_attn_lpt)
+    std::stable_sort(a.seg_order, a.seg_order + a.nseg, [&](int x, int y) { return a.seg_T[x] > a.seg_T[y]; });
+}
 int check_args(const emoasr_attn_t* a, int dtype) {
   EMO_CHECK(a->DK == DK, "attention: DK=%d unsupported (64 only)", a->DK);
   const int vec = dtype == EMO_BF16 ? 8 : 4;
@@ -1924,7 +1945,9 @@ int check_args(const emoasr_attn_t* a, int dtype) {
 }
 
 template <typename T>
-int launch_fwd(const emoasr_attn_t& a, hipStream_t s) {
+int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
+  emoasr_attn_t a = a_in;
+  fill_seg_order(a);
   constexpr int LD = AttnCfg<T>::LD;
   const int smem = 4 * (64 * 32 * 4 + 32 * LD * (int)sizeof(T));
   dim3 grid(cdiv(a.Tq, 128), a.H, a.B);   // (stacked micro-batches: Tq = the longest segment, B = all utterances)
@@ -2081,7 +2104,9 @@ struct FusedExtras { float* zero; long zero_n; const float* cast_src; void* cast
 FusedExtras g_fused_extras{};
 
 template <typename T>
-int launch_bwd_fused(const emoasr_attn_t& a, char* mem, size_t bytes, hipStream_t s) {
+int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStream_t s) {
+  emoasr_attn_t a = a_in;
+  fill_seg_order(a);
   const bool rel = a.pos != nullptr;
   const long nrows = a.nseg > 1 ? a.seg_row[a.nseg] : (long)a.B * a.Tq;   // stacked micro-batches: all segments' rows
   const long nqd = nrows * a.H * DK;
@@ -2190,6 +2215,7 @@ void emo_attn_bwd_fused_extras(float* zero, long zn, const float* cast_src, void
 }
 
 void emo_attn_set_tr_read(int v) { g_tr = v; }
+void emo_attn_set_lpt(int v) { g_attn_lpt = v; }
 void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }
 
 extern "C" int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream) {

@@ -36,7 +36,7 @@ class AttnArgs(Structure):
                 ("ldpd", c_long), ("ldbd", c_long), ("cs", c_void_p),
                 ("st", c_void_p), ("ldst", c_long),
                 ("qu", c_void_p), ("qv", c_void_p), ("dbias_part", c_void_p),
-                ("nseg", c_int), ("seg_b0", c_int * 9), ("seg_T", c_int * 8), ("seg_row", c_long * 9), ("seg_prow", c_long * 9)]
+                ("nseg", c_int), ("seg_b0", c_int * 9), ("seg_T", c_int * 8), ("seg_row", c_long * 9), ("seg_prow", c_long * 9), ("seg_order", c_int * 8)]
 
 
 class TnProblem(Structure):
