@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
     const SegRef g = seg_of_slot(a_in, blockIdx.z, b);
     seg_apply<T>(a, g);
   }
-  const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y;
+  const int i0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 32, h = blockIdx.y;   // 1, 2 or 4 independent waves per workgroup
   if (i0 >= a.Tq) return;
   constexpr int WAVE_BYTES = 64 * 32 * 4 + 32 * LD * (int)sizeof(T);
   float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
@@ -1913,6 +1913,7 @@ int set_smem(K kernel, int bytes) {
 int g_tr = 1;
 int g_fused_fw = 0;  // key tiles per workgroup of the single-pass backward (0 = by grid size; emoasr_set_option "attn_fw")
 
+int g_fwd_waves = 0;  // option "attn_fwd_waves": waves per workgroup of attn_fwd_kernel (0 = 1 for stacked launches, else 4)
 int g_attn_lpt = 1;   // option "attn_lpt": 0 = segments in stacking order
 // dispatch order of a stacked launch's segments: longest first (stable), see seg_of_slot
 void fill_seg_order(emoasr_attn_t& a) {
@@ -1949,31 +1950,34 @@ int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
   emoasr_attn_t a = a_in;
   fill_seg_order(a);
   constexpr int LD = AttnCfg<T>::LD;
-  const int smem = 4 * (64 * 32 * 4 + 32 * LD * (int)sizeof(T));
-  dim3 grid(cdiv(a.Tq, 128), a.H, a.B);   // (stacked micro-batches: Tq = the longest segment, B = all utterances)
+  // waves per workgroup: the waves of this kernel never meet (wave-private LDS), so a workgroup is only a unit of dispatch; stacked
+  // launches (thousands of query tiles of uneven length) are handed out wave by wave, which packs the CUs' wave slots tightest
+  const int nw = g_fwd_waves ? g_fwd_waves : (a.nseg > 1 ? 1 : 4);
+  const int smem = nw * (64 * 32 * 4 + 32 * LD * (int)sizeof(T));
+  dim3 grid(cdiv(a.Tq, 32 * nw), a.H, a.B);   // (stacked micro-batches: Tq = the longest segment, B = all utterances)
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
     hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
   }
-  const bool one_round = (long)grid.x * grid.y * grid.z <= n_cu;  // at most one block per CU: see attn_fwd_kernel
+  const bool one_round = (long)grid.x * grid.y * grid.z * nw <= 4L * n_cu;  // at most one wave per SIMD: see attn_fwd_kernel
   emo_timer_begin(EMO_TIMER_ATTN_FWD, s);
   if (g_tr) {
     if (one_round) {
       if (set_smem(attn_fwd_kernel<T, true, true>, smem)) return 1;
-      attn_fwd_kernel<T, true, true><<<grid, 256, smem, s>>>(a);
+      attn_fwd_kernel<T, true, true><<<grid, 64 * nw, smem, s>>>(a);
     } else {
       if (set_smem(attn_fwd_kernel<T, true, false>, smem)) return 1;
-      attn_fwd_kernel<T, true, false><<<grid, 256, smem, s>>>(a);
+      attn_fwd_kernel<T, true, false><<<grid, 64 * nw, smem, s>>>(a);
     }
   } else {
     if (one_round) {
       if (set_smem(attn_fwd_kernel<T, false, true>, smem)) return 1;
-      attn_fwd_kernel<T, false, true><<<grid, 256, smem, s>>>(a);
+      attn_fwd_kernel<T, false, true><<<grid, 64 * nw, smem, s>>>(a);
     } else {
       if (set_smem(attn_fwd_kernel<T, false, false>, smem)) return 1;
-      attn_fwd_kernel<T, false, false><<<grid, 256, smem, s>>>(a);
+      attn_fwd_kernel<T, false, false><<<grid, 64 * nw, smem, s>>>(a);
     }
   }
   emo_timer_end(EMO_TIMER_ATTN_FWD, s);
@@ -2216,6 +2220,7 @@ void emo_attn_bwd_fused_extras(float* zero, long zn, const float* cast_src, void
 
 void emo_attn_set_tr_read(int v) { g_tr = v; }
 void emo_attn_set_lpt(int v) { g_attn_lpt = v; }
+void emo_attn_set_fwd_waves(int v) { g_fwd_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
 void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }
 
 extern "C" int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream) {
