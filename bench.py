@@ -353,7 +353,7 @@ L4 = dict(L2, decoder_type="rnn_transducer", vocab_size=1000, embedding_size=256
           joint_hidden_size=512, dropout_emb_rate=0.1, dropout_dec_rate=0.1, mtl_ctc_weight=0.3, lsm_prob=0.0)
 
 
-def l4_rnnt(dev, dtype, steps=4, warmup=2, n_dec=5, accum=5):
+def l4_rnnt(dev, dtype, steps=8, warmup=2, n_dec=5, accum=5):
     """config 5 (`L4`): RNN-T (Conformer) 26 M -- training frames/s (optimizer steps of `accum` micro-batches as the reference
     runs them: the ENCODER of all micro-batches in one stacked pass, the prediction network / joint / transducer lattice per
     micro-batch on its slice, loss / accum each, then Adam; LibriSpeech-shaped batches at the standard 30 000-frame budget: the
