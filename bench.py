@@ -776,7 +776,7 @@ def main():
                 print(f"  {k:28s} calls {v['calls']:5d}  {v['ms']:9.3f} ms  {100 * v['ms'] / tot:5.1f}%  {tf:7.1f} TF/s",
                       file=sys.stderr)
             print(f"  total instrumented GPU time {tot:.2f} ms (one step, {accum} micro-batches)", file=sys.stderr)
-        if world == 1:
+        if world == 1 and not args.no_decode:
             # the same optimizer steps with the features handed over as HOST buffers (pinned, as a DataLoader with pin_memory
             # yields them): the H2D copies are inside the timed region.  Never `value`; noted in DESIGN.md section 4.
             host_steps = batches[args.warmup:args.warmup + 4]
