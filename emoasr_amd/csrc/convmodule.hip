@@ -278,6 +278,30 @@ __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(long n, int C, const 
     z[i] = from_f32<T>(swishf_(gamma[c] * xh + beta[c]));
   }
 }
+// C % 8 == 0: eight channels of one row per thread and pass, 16-byte accesses (the element-wise form above ran at 1.4 TB/s);
+// the same arithmetic per element, so the two agree bit for bit
+template <typename T>
+__global__ __launch_bounds__(256) void bn_swish_fwd8_kernel(long n8, int C, const T* __restrict__ y,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ var,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            T* __restrict__ z, const RowSegs sg) {
+  const int cg = C / 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const long row = i / cg;
+    const int c = (int)(i - row * cg) * 8;
+    const long so = sg.n > 1 ? (long)rowsegs_of_row(sg, row) * C : 0;
+    float v[8];
+    load8<T>(y + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (v[j] - mean[so + c + j]) * rsqrtf(var[so + c + j] + eps);
+      v[j] = swishf_(gamma[c + j] * xh + beta[c + j]);
+    }
+    store8<T>(z + i * 8, v);
+  }
+}
 
 // ---- BatchNorm + Swish backward (training statistics), C % 8 == 0 ------------------------------
 // Layout of both passes: a block is 8 row-lanes x 32 channel groups of 8 channels (16-byte loads);
@@ -551,8 +575,13 @@ extern "C" int emoasr_bn_swish_fwd(int dtype, int M, int C, const void* y, const
                                    void* z, void* stream) {
   const long n = (long)M * C;
   if (n == 0) return 0;
-  EMO_DISPATCH(dtype, (bn_swish_fwd_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(
-                          n, C, (const T*)y, mean, var, gamma, beta, eps, (T*)z, RowSegs{})));
+  if (C % 8 == 0 && (reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z)) % 16 == 0) {
+    EMO_DISPATCH(dtype, (bn_swish_fwd8_kernel<T><<<ew_grid(n / 8), 256, 0, (hipStream_t)stream>>>(
+                            n / 8, C, (const T*)y, mean, var, gamma, beta, eps, (T*)z, RowSegs{})));
+  } else {
+    EMO_DISPATCH(dtype, (bn_swish_fwd_kernel<T><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(
+                            n, C, (const T*)y, mean, var, gamma, beta, eps, (T*)z, RowSegs{})));
+  }
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -614,7 +643,8 @@ int emo_bn_swish_fwd_seg(const RowSegs& sg, int C, const void* y, const float* m
                          const float* beta, float eps, void* z, hipStream_t s) {
   const long n = sg.row[sg.n] * C;
   if (n == 0) return 0;
-  bn_swish_fwd_kernel<bf16><<<ew_grid(n), 256, 0, s>>>(n, C, (const bf16*)y, mean, var, gamma, beta, eps, (bf16*)z, sg);
+  if (C % 8 == 0) bn_swish_fwd8_kernel<bf16><<<ew_grid(n / 8), 256, 0, s>>>(n / 8, C, (const bf16*)y, mean, var, gamma, beta, eps, (bf16*)z, sg);
+  else bn_swish_fwd_kernel<bf16><<<ew_grid(n), 256, 0, s>>>(n, C, (const bf16*)y, mean, var, gamma, beta, eps, (bf16*)z, sg);
   EMO_LAUNCH_CHECK();
   return 0;
 }
