@@ -209,18 +209,27 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_reduce_kernel(int nblk, int 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;  // over (K+1)*C, laid out [j][c]
   const int n = (K + 1) * C;
+  // blockIdx.y = a quarter (gridDim.y-th) of the partial rows: 128 workgroups could not pull the ~80 MB of partials of a stacked
+  // launch faster than 2.4 TB/s; the parts meet in f32 atomics (the weight gradients of the GEMMs arrive the same way)
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
   float s = 0.f;
   if (i < n) {
 #pragma unroll 8
-    for (int b = wave; b < nblk; b += 4) s += part[(long)b * n + i];
+    for (int b = b0 + wave; b < b1; b += 4) s += part[(long)b * n + i];
   }
   red[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && i < n) {
     s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
     const int j = i / C, c = i % C;
-    if (j < K) dw[c * K + j] += s;
-    else if (dbias) dbias[c] += s;
+    if (gridDim.y == 1) {
+      if (j < K) dw[c * K + j] += s;
+      else if (dbias) dbias[c] += s;
+    } else {
+      if (j < K) atomicAdd(&dw[c * K + j], s);
+      else if (dbias) atomicAdd(&dbias[c], s);
+    }
   }
 }
 
@@ -479,7 +488,7 @@ static bool use_lds(int dtype, int Tn, int C) {
   return g_dwconv_lds && dtype == EMO_BF16 && C % 8 == 0 && (long)Tn * C * 2 < (1L << 32);
 }
 int emo_dwconv_bwd_w_reduce(int nblk, int C, int K, const float* part, float* dw, float* dbias, hipStream_t s) {
-  dwconv_bwd_w_reduce_kernel<<<cdiv((K + 1) * C, 64), 256, 0, s>>>(nblk, C, K, part, dw, dbias);
+  dwconv_bwd_w_reduce_kernel<<<dim3(cdiv((K + 1) * C, 64), nblk >= 1024 ? 4 : 1), 256, 0, s>>>(nblk, C, K, part, dw, dbias);
   EMO_LAUNCH_CHECK();
   return 0;
 }
