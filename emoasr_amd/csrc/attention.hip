@@ -183,6 +183,17 @@ __device__ __forceinline__ SegRef seg_of_slot(const emoasr_attn_t& karg, int z, 
   local = v;
   return seg_ref(karg, s);
 }
+// Workgroup coordinates of the forward / fused-backward launches.  nt == 0: the plain 3-D grid (tile, head, utterance slot).
+// nt > 0 (a 1-D launch of 8 * ceil(H B / 8) * nt workgroups): the nt tiles of one (head, utterance) GROUP -- which read the same
+// K / V (forward) or Q / dO / position rows (backward) -- get hardware ids of one residue class mod 8, i.e. one XCD and one L2,
+// next to each other in dispatch order; the groups go round-robin over the XCDs in slot order (longest segment first).
+struct Blk3 { int x, y, z; bool ok; };
+__device__ __forceinline__ Blk3 attn_block(int nt, int H, int B) {   // (H, B: the grid's y and z extents)
+  if (nt <= 0) return Blk3{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, true};
+  const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+  const int gl = slot / nt, tile = slot - gl * nt, g = gl * 8 + xcd;
+  return Blk3{tile, g % H, g / H, g < H * B};
+}
 __device__ __forceinline__ SegRef seg_of_row(const emoasr_attn_t& karg, long row) {
   int s = 0;
   for (int k = 1; k < EMOASR_MAX_SEGMENTS; ++k) s += (k < karg.nseg && row >= karg.seg_row[k]) ? 1 : 0;
@@ -319,18 +330,20 @@ __device__ __forceinline__ void store_dT(T* dst, long ld, int r0, int rlimit, co
 // blocks per CU (bf16).  Measured at B 20, T' 340 (240 blocks): 36 us with two sets, 45 us with one; at 264
 // blocks the two-set kernel's second round of blocks costs 80 us against 62.
 template <typename T, bool TR, bool PF2>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fwd_kernel(const emoasr_attn_t a_in) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fwd_kernel(const emoasr_attn_t a_in, const int nt) {
   using M_ = Mma<T>;
   constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = AttnCfg<T>::LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   emoasr_attn_t a = a_in;
-  int b = blockIdx.z;
+  const Blk3 blk = attn_block(nt, a_in.H, a_in.B);
+  if (!blk.ok) return;
+  int b = blk.z;
   if (a_in.nseg > 1) {
-    const SegRef g = seg_of_slot(a_in, blockIdx.z, b);
+    const SegRef g = seg_of_slot(a_in, blk.z, b);
     seg_apply<T>(a, g);
   }
-  const int i0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 32, h = blockIdx.y;   // 1, 2 or 4 independent waves per workgroup
+  const int i0 = (blk.x * (blockDim.x >> 6) + wave) * 32, h = blk.y;   // 1, 2 or 4 independent waves per workgroup
   if (i0 >= a.Tq) return;
   constexpr int WAVE_BYTES = 64 * 32 * 4 + 32 * LD * (int)sizeof(T);
   float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
@@ -1372,7 +1385,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <typename T, bool TR, bool REL, int FW>
-__global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr_attn_t a_in, const FusedWs ws_in) {
+__global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int nt) {
   using M_ = Mma<T>;
   using C_ = FusedCfg<T, FW>;
   constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = C_::LD, IMG = C_::IMG;
@@ -1384,16 +1397,18 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31;
   emoasr_attn_t a = a_in;
   FusedWs ws = ws_in;
-  int b = blockIdx.z;
+  const Blk3 blk = attn_block(nt, a_in.H, a_in.B);
+  if (!blk.ok) return;
+  int b = blk.z;
   if (a_in.nseg > 1) {   // stacked micro-batches: this workgroup's segment (the scratch images are stacked like the rows)
-    const SegRef g = seg_of_slot(a_in, blockIdx.z, b);
+    const SegRef g = seg_of_slot(a_in, blk.z, b);
     seg_apply<T>(a, g);
     ws.qu = (const T*)ws.qu + g.row * ws.ldqu;
     ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
     ws.dq32 += g.row * (long)(a.H * DK);
     if (ws.dsq) ws.dsq = (T*)ws.dsq + g.row * a.H * ws.ldds;
   }
-  const int jblk = blockIdx.x * (32 * FW), h = blockIdx.y;
+  const int jblk = blk.x * (32 * FW), h = blk.y;
   if (jblk >= a.Tk) return;   // (a shorter segment of a stacked launch: the grid follows the longest)
   const HeadPtrs hp = head_ptrs<T>(a, b, h);
   const int j0 = jblk + 32 * wave;
@@ -1495,7 +1510,7 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
   // stores: every (key block, query row) has exactly one writer, so dQ is bit-reproducible); wave w takes rows w, w + FW, ...
   // flush lane map: 4 query rows per pass (lane >> 4), 4 consecutive d per lane (lane & 15)
   const int f_row = lane >> 4, f_d = 4 * (lane & 15);
-  float* dq_part = ws.dq32 + (long)blockIdx.x * ws.dq_slab + (long)b * a.Tq * (a.H * DK) + ho + f_d;
+  float* dq_part = ws.dq32 + (long)blk.x * ws.dq_slab + (long)b * a.Tq * (a.H * DK) + ho + f_d;
   f32x4 dq_colsum4 = f32x4{0.f, 0.f, 0.f, 0.f};  // sum over this lane's query rows of dQ[:, f_d .. f_d + 3]
   auto flush = [&](const int ib) {
 #pragma unroll
@@ -1754,26 +1769,30 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
 // flight while this one is multiplied.  Waves are reduced through LDS before one set of atomics (rows of 64 d).
 template <typename T, bool TR>
 __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int bchunk_in,
-                                                             const int nchunk) {
+                                                             const int nchunk, const int nt) {
   using M_ = Mma<T>;
   constexpr int RT = 2;  // 32-row table tiles per block: the staged (Q+v) tile is multiplied into both
+  // (nt > 0: the table tiles of one (head, segment, batch chunk) on one XCD -- they read the same (Q+v) rows and neighbouring
+  // pieces of the same dS rows; see attn_block)
+  const Blk3 blk = attn_block(nt, a_in.H, nchunk * (a_in.nseg > 1 ? a_in.nseg : 1));
+  if (!blk.ok) return;
   constexpr int LD = AttnCfg<T>::LD, VEC = 16 / sizeof(T), PER_ROW = DK / VEC, QR = 32 * PER_ROW / 64;
   constexpr int QS_BYTES = 32 * LD * (int)sizeof(T), RED_BYTES = 4 * RT * 2 * 16 * 64 * 4;
   __shared__ __attribute__((aligned(16))) char smem[(4 * QS_BYTES > RED_BYTES) ? 4 * QS_BYTES : RED_BYTES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, hh = lane >> 5;
   emoasr_attn_t a = a_in;
   FusedWs ws = ws_in;
-  int bchunk = bchunk_in, zc = blockIdx.z;
-  if (a_in.nseg > 1) {   // stacked micro-batches: blockIdx.z = segment * nchunk + batch chunk; every segment has its own table
-    const int sgi = blockIdx.z / nchunk;
-    zc = blockIdx.z - sgi * nchunk;
+  int bchunk = bchunk_in, zc = blk.z;
+  if (a_in.nseg > 1) {   // stacked micro-batches: blk.z = segment * nchunk + batch chunk; every segment has its own table
+    const int sgi = blk.z / nchunk;
+    zc = blk.z - sgi * nchunk;
     const SegRef g = seg_ref(a_in, sgi);
     seg_apply<T>(a, g);
     ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
     ws.dsq = (T*)ws.dsq + g.row * a.H * ws.ldds;
     bchunk = (a.B + nchunk - 1) / nchunk;
   }
-  const int r0 = blockIdx.x * (32 * RT), h = blockIdx.y;
+  const int r0 = blk.x * (32 * RT), h = blk.y;
   if (r0 >= 2 * a.Tq - 1) return;
   const int b_lo = zc * bchunk, b_hi = min(a.B, b_lo + bchunk);
   const int nit = (a.Tq + 31) / 32;
@@ -1914,6 +1933,7 @@ int g_tr = 1;
 int g_fused_fw = 0;  // key tiles per workgroup of the single-pass backward (0 = by grid size; emoasr_set_option "attn_fw")
 
 int g_fwd_waves = 0;  // option "attn_fwd_waves": waves per workgroup of attn_fwd_kernel (0 = 1 for stacked launches, else 4)
+int g_attn_xcd = 1;   // option "attn_xcd": stacked forward / fused-backward launches keep a (head, utterance) group on one XCD
 int g_attn_lpt = 1;   // option "attn_lpt": 0 = segments in stacking order
 // dispatch order of a stacked launch's segments: longest first (stable), see seg_of_slot
 void fill_seg_order(emoasr_attn_t& a) {
@@ -1955,6 +1975,9 @@ int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
   const int nw = g_fwd_waves ? g_fwd_waves : (a.nseg > 1 ? 1 : 4);
   const int smem = nw * (64 * 32 * 4 + 32 * LD * (int)sizeof(T));
   dim3 grid(cdiv(a.Tq, 32 * nw), a.H, a.B);   // (stacked micro-batches: Tq = the longest segment, B = all utterances)
+  // stacked launches: 1-D, the query tiles of one (head, utterance) on one XCD (attn_block)
+  const int nt = (g_attn_xcd && a.nseg > 1) ? (int)grid.x : 0;
+  if (nt) grid = dim3(8 * cdiv(a.H * a.B, 8) * nt, 1, 1);
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -1966,18 +1989,18 @@ int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
   if (g_tr) {
     if (one_round) {
       if (set_smem(attn_fwd_kernel<T, true, true>, smem)) return 1;
-      attn_fwd_kernel<T, true, true><<<grid, 64 * nw, smem, s>>>(a);
+      attn_fwd_kernel<T, true, true><<<grid, 64 * nw, smem, s>>>(a, nt);
     } else {
       if (set_smem(attn_fwd_kernel<T, true, false>, smem)) return 1;
-      attn_fwd_kernel<T, true, false><<<grid, 64 * nw, smem, s>>>(a);
+      attn_fwd_kernel<T, true, false><<<grid, 64 * nw, smem, s>>>(a, nt);
     }
   } else {
     if (one_round) {
       if (set_smem(attn_fwd_kernel<T, false, true>, smem)) return 1;
-      attn_fwd_kernel<T, false, true><<<grid, 64 * nw, smem, s>>>(a);
+      attn_fwd_kernel<T, false, true><<<grid, 64 * nw, smem, s>>>(a, nt);
     } else {
       if (set_smem(attn_fwd_kernel<T, false, false>, smem)) return 1;
-      attn_fwd_kernel<T, false, false><<<grid, 64 * nw, smem, s>>>(a);
+      attn_fwd_kernel<T, false, false><<<grid, 64 * nw, smem, s>>>(a, nt);
     }
   }
   emo_timer_end(EMO_TIMER_ATTN_FWD, s);
@@ -2154,10 +2177,12 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
   do {                                                                                             \
     const int smem = FusedCfg<T, FW_>::smem_bytes(REL_);                                           \
     dim3 grid(cdiv(a.Tk, 32 * FW_), a.H, a.B);                                                     \
+    const int nt = (g_attn_xcd && a.nseg > 1) ? (int)grid.x : 0;   /* key blocks of one (head, utterance) on one XCD */ \
+    if (nt) grid = dim3(8 * cdiv(a.H * a.B, 8) * nt, 1, 1);                                        \
     if (g_tr) { if (set_smem(attn_bwd_fused_kernel<T, true, REL_, FW_>, smem)) return 1;           \
-                attn_bwd_fused_kernel<T, true, REL_, FW_><<<grid, 64 * FW_, smem, s>>>(a, ws); }   \
+                attn_bwd_fused_kernel<T, true, REL_, FW_><<<grid, 64 * FW_, smem, s>>>(a, ws, nt); }   \
     else      { if (set_smem(attn_bwd_fused_kernel<T, false, REL_, FW_>, smem)) return 1;          \
-                attn_bwd_fused_kernel<T, false, REL_, FW_><<<grid, 64 * FW_, smem, s>>>(a, ws); }  \
+                attn_bwd_fused_kernel<T, false, REL_, FW_><<<grid, 64 * FW_, smem, s>>>(a, ws, nt); }  \
   } while (0)
   emo_timer_begin(EMO_TIMER_ATTN_BWD_MAIN, s);
   if (rel) {
@@ -2169,9 +2194,11 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
       for (int k = 0; k < a.nseg && a.nseg > 1; ++k) bmin = std::min(bmin, a.seg_b0[k + 1] - a.seg_b0[k]);
       const int nchunk = bmin < 8 ? bmin : 8;
       dim3 g2(cdiv(2 * a.Tq - 1, 64), a.H, nchunk * (a.nseg > 1 ? a.nseg : 1));
+      const int nt2 = (g_attn_xcd && a.nseg > 1) ? (int)g2.x : 0;
+      if (nt2) g2 = dim3(8 * cdiv((int)(g2.y * g2.z), 8) * nt2, 1, 1);
       emo_timer_begin(EMO_TIMER_ATTN_BWD_DPOS, s);
-      if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk);
-      else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk);
+      if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
+      else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
       emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, s);
     }
   } else {
@@ -2220,6 +2247,7 @@ void emo_attn_bwd_fused_extras(float* zero, long zn, const float* cast_src, void
 
 void emo_attn_set_tr_read(int v) { g_tr = v; }
 void emo_attn_set_lpt(int v) { g_attn_lpt = v; }
+void emo_attn_set_xcd(int v) { g_attn_xcd = v; }
 void emo_attn_set_fwd_waves(int v) { g_fwd_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
 void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }
 
