@@ -91,6 +91,15 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
     while (cls + 1 < g.dg.ncls && t >= g.dg.tile0[cls + 1]) ++cls;
     tm = t - g.dg.tile0[cls];
     M = g.dg.M[cls];
+  } else if (AMODE == 0 && g.tiles_n > 1) {
+    // wide products (the vocabulary projection: 40 column tiles, W = 5 MB > one XCD's 4 MB of L2): groups of 8 row tiles,
+    // column-major inside a group -- the 32 tiles an XCD runs at once are 8 row bands x 4 weight tiles, and a weight tile
+    // serves 8 consecutive workgroups.  (Row-major order read the whole weight once per row band: 971 MB for 23 MB of operands.)
+    constexpr int GM = 8;
+    const int per = GM * g.tiles_n, grp = bid / per, first = grp * GM;
+    const int gsz = min(GM, g.tiles_m - first), local = bid - grp * per;
+    tn = local / gsz;
+    tm = first + local - tn * gsz;
   } else {
     tm = bid / g.tiles_n;
     tn = bid - tm * g.tiles_n;
