@@ -44,6 +44,7 @@ void emo_decode_set_coop_merge(int v);
 void emo_attn_set_tr_read(int v);
 void emo_attn_set_fw(int v);
 void emo_attn_set_lpt(int v);
+void emo_attn_set_fwd_split(int v);
 void emo_attn_set_xcd(int v);
 void emo_attn_set_fwd_waves(int v);
 void emo_layer_set_ffn_fused(int v);
@@ -163,6 +164,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "decode_coop_merge") == 0) { emo_decode_set_coop_merge(value); return 0; }
   if (strcmp(name, "attn_fw") == 0) { emo_attn_set_fw(value); return 0; }
   if (strcmp(name, "attn_lpt") == 0) { emo_attn_set_lpt(value); return 0; }
+  if (strcmp(name, "attn_fwd_split") == 0) { emo_attn_set_fwd_split(value); return 0; }
   if (strcmp(name, "attn_xcd") == 0) { emo_attn_set_xcd(value); return 0; }
   if (strcmp(name, "attn_fwd_waves") == 0) { emo_attn_set_fwd_waves(value); return 0; }
   if (strcmp(name, "timers") == 0) { g_timers_on = value; return 0; }

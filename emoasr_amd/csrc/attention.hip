@@ -330,7 +330,7 @@ __device__ __forceinline__ void store_dT(T* dst, long ld, int r0, int rlimit, co
 // blocks per CU (bf16).  Measured at B 20, T' 340 (240 blocks): 36 us with two sets, 45 us with one; at 264
 // blocks the two-set kernel's second round of blocks costs 80 us against 62.
 template <typename T, bool TR, bool PF2>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fwd_kernel(const emoasr_attn_t a_in, const int nt) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fwd_kernel(const emoasr_attn_t a_in, const int nt, const int ks) {
   using M_ = Mma<T>;
   constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = AttnCfg<T>::LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -343,7 +343,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
     const SegRef g = seg_of_slot(a_in, blk.z, b);
     seg_apply<T>(a, g);
   }
-  const int i0 = (blk.x * (blockDim.x >> 6) + wave) * 32, h = blk.y;   // 1, 2 or 4 independent waves per workgroup
+  // ks == 1: 1, 2 or 4 independent waves per workgroup, a query tile each.  ks == 4 (small launches: a batch-1 decode has 40
+  // query tiles for 256 CUs): the four waves share ONE query tile and take every fourth key tile; their soft-max states meet in LDS
+  const int i0 = (ks > 1 ? blk.x : blk.x * (blockDim.x >> 6) + wave) * 32, h = blk.y;
   if (i0 >= a.Tq) return;
   constexpr int WAVE_BYTES = 64 * 32 * 4 + 32 * LD * (int)sizeof(T);
   float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
   };
   auto tile = [&](Pre& cur, Pre& nxt, int j0) {
     EMO_FSTAMP(0);
-    if constexpr (PF2) fetch(nxt, j0 + 32);
+    if constexpr (PF2) fetch(nxt, j0 + 32 * ks);
     EMO_FSTAMP(1);
 #pragma unroll
     for (int i = 0; i < VR; ++i) {
@@ -498,17 +500,53 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
     __builtin_amdgcn_wave_barrier();
     EMO_FSTAMP(6);
   };
+  const int jstep = 32 * ks, jfirst = ks > 1 ? 32 * wave : 0;
   if constexpr (PF2) {
     Pre pa, pb;
-    fetch(pa, 0);
-    for (int j0 = 0; j0 < kend; j0 += 64) {
+    fetch(pa, jfirst);
+    for (int j0 = jfirst; j0 < kend; j0 += 2 * jstep) {
       tile(pa, pb, j0);
-      if (j0 + 32 < kend) tile(pb, pa, j0 + 32);
+      if (j0 + jstep < kend) tile(pb, pa, j0 + jstep);
     }
   } else {
     Pre pc;
-    fetch(pc, 0);
-    for (int j0 = 0; j0 < kend; j0 += 32) tile(pc, pc, j0);
+    fetch(pc, jfirst);
+    for (int j0 = jfirst; j0 < kend; j0 += jstep) tile(pc, pc, j0);
+  }
+  if (ks > 1) {
+    // merge the four waves' (m, l, O) of the same 32 queries: every register of a lane belongs to query lane & 31, so the
+    // states combine lane by lane.  Each wave parks its O in its own Gs image (2048 floats) and m / l at the head of its Vs.
+    float* sml = reinterpret_cast<float*>(Vs);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Gs[(dt * 16 + r) * 64 + lane] = o[dt][r];
+    if (lane < 32) { sml[lane] = m; sml[32 + lane] = l; }
+    __syncthreads();
+    if (wave != 0) return;
+    float mw[4], lw[4], sc[4], mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* q = reinterpret_cast<const float*>(smem + w * WAVE_BYTES + 64 * 32 * 4);
+      mw[w] = q[lane & 31]; lw[w] = q[32 + (lane & 31)];
+      mm = fmaxf(mm, mw[w]);
+    }
+    l = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      sc[w] = mw[w] == -INFINITY ? 0.f : __expf(mw[w] - mm);
+      l += lw[w] * sc[w];
+    }
+    m = mm;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc += reinterpret_cast<const float*>(smem + w * WAVE_BYTES)[(dt * 16 + r) * 64 + lane] * sc[w];
+        o[dt][r] = acc;
+      }
   }
   const float inv = l > 0.f ? 1.f / l : 0.f;
   store_dT<T>((T*)hp.out, a.ldo, i0, a.Tq, o, inv, lane);
@@ -1932,6 +1970,7 @@ int set_smem(K kernel, int bytes) {
 int g_tr = 1;
 int g_fused_fw = 0;  // key tiles per workgroup of the single-pass backward (0 = by grid size; emoasr_set_option "attn_fw")
 
+int g_fwd_split = 1;  // option "attn_fwd_split": key split for small launches
 int g_fwd_waves = 0;  // option "attn_fwd_waves": waves per workgroup of attn_fwd_kernel (0 = 1 for stacked launches, else 4)
 int g_attn_xcd = 1;   // option "attn_xcd": stacked forward / fused-backward launches keep a (head, utterance) group on one XCD
 int g_attn_lpt = 1;   // option "attn_lpt": 0 = segments in stacking order
@@ -1972,35 +2011,39 @@ int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
   constexpr int LD = AttnCfg<T>::LD;
   // waves per workgroup: the waves of this kernel never meet (wave-private LDS), so a workgroup is only a unit of dispatch; stacked
   // launches (thousands of query tiles of uneven length) are handed out wave by wave, which packs the CUs' wave slots tightest
-  const int nw = g_fwd_waves ? g_fwd_waves : (a.nseg > 1 ? 1 : 4);
-  const int smem = nw * (64 * 32 * 4 + 32 * LD * (int)sizeof(T));
-  dim3 grid(cdiv(a.Tq, 32 * nw), a.H, a.B);   // (stacked micro-batches: Tq = the longest segment, B = all utterances)
-  // stacked launches: 1-D, the query tiles of one (head, utterance) on one XCD (attn_block)
-  const int nt = (g_attn_xcd && a.nseg > 1) ? (int)grid.x : 0;
-  if (nt) grid = dim3(8 * cdiv(a.H * a.B, 8) * nt, 1, 1);
+  // key split (ks = 4): launches of at most two query tiles per CU -- decoding a few utterances -- where the tiles' own latency
+  // (one key tile after the other) is the whole time; not with stored scores (the materialised backward) 
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
     hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
   }
+  const bool split = g_fwd_split && a.nseg <= 1 && !a.st && (long)cdiv(a.Tq, 32) * a.H * a.B <= 2L * n_cu;
+  const int ks = split ? 4 : 1;
+  const int nw = split ? 4 : (g_fwd_waves ? g_fwd_waves : (a.nseg > 1 ? 1 : 4));
+  const int smem = nw * (64 * 32 * 4 + 32 * LD * (int)sizeof(T));
+  dim3 grid(cdiv(a.Tq, split ? 32 : 32 * nw), a.H, a.B);   // (stacked micro-batches: Tq = the longest segment, B = all utterances)
+  // stacked launches: 1-D, the query tiles of one (head, utterance) on one XCD (attn_block)
+  const int nt = (g_attn_xcd && a.nseg > 1) ? (int)grid.x : 0;
+  if (nt) grid = dim3(8 * cdiv(a.H * a.B, 8) * nt, 1, 1);
   const bool one_round = (long)grid.x * grid.y * grid.z * nw <= 4L * n_cu;  // at most one wave per SIMD: see attn_fwd_kernel
   emo_timer_begin(EMO_TIMER_ATTN_FWD, s);
   if (g_tr) {
     if (one_round) {
       if (set_smem(attn_fwd_kernel<T, true, true>, smem)) return 1;
-      attn_fwd_kernel<T, true, true><<<grid, 64 * nw, smem, s>>>(a, nt);
+      attn_fwd_kernel<T, true, true><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
     } else {
       if (set_smem(attn_fwd_kernel<T, true, false>, smem)) return 1;
-      attn_fwd_kernel<T, true, false><<<grid, 64 * nw, smem, s>>>(a, nt);
+      attn_fwd_kernel<T, true, false><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
     }
   } else {
     if (one_round) {
       if (set_smem(attn_fwd_kernel<T, false, true>, smem)) return 1;
-      attn_fwd_kernel<T, false, true><<<grid, 64 * nw, smem, s>>>(a, nt);
+      attn_fwd_kernel<T, false, true><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
     } else {
       if (set_smem(attn_fwd_kernel<T, false, false>, smem)) return 1;
-      attn_fwd_kernel<T, false, false><<<grid, 64 * nw, smem, s>>>(a, nt);
+      attn_fwd_kernel<T, false, false><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
     }
   }
   emo_timer_end(EMO_TIMER_ATTN_FWD, s);
@@ -2247,6 +2290,7 @@ void emo_attn_bwd_fused_extras(float* zero, long zn, const float* cast_src, void
 
 void emo_attn_set_tr_read(int v) { g_tr = v; }
 void emo_attn_set_lpt(int v) { g_attn_lpt = v; }
+void emo_attn_set_fwd_split(int v) { g_fwd_split = v; }
 void emo_attn_set_xcd(int v) { g_attn_xcd = v; }
 void emo_attn_set_fwd_waves(int v) { g_fwd_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
 void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }
