@@ -81,11 +81,17 @@ def test_stacked_pass_equals_the_separate_passes(dev):
         assert abs(a - b) < 1e-3 * abs(b), (got, want_losses)
     A = eng.arena
     worst = (1.0, "")
+    gmax = want_grad.abs().max().item()
     for name in A.names:
         o, k = A.offsets[name], A.pviews[name].numel()
         g, w = A.grad[o:o + k], want_grad[o:o + k]
         if w.abs().max() == 0:
             assert g.abs().max() == 0, name
+            continue
+        if w.abs().max() < 1e-3 * gmax:
+            # a gradient that is zero in exact arithmetic (linear_k.bias: the soft-max does not see a constant added to every key's
+            # score) is rounding noise in both passes: its direction means nothing, its size must stay noise
+            assert g.abs().max() < 2e-3 * gmax, (name, g.abs().max().item(), gmax)
             continue
         cos = _cos(g, w)
         worst = min(worst, (cos, name))
@@ -97,7 +103,9 @@ def test_stacked_pass_equals_the_separate_passes(dev):
             assert torch.equal(v, want_bufs[k]), k                 # one BatchNorm update per micro-batch
         elif "running" in k:
             err = (v - want_bufs[k]).abs().max().item() / (want_bufs[k].abs().max().item() + 1e-12)
-            assert err < 1e-4, (k, err)
+            # (bf16 activations; the separate passes' small attention launches split the keys over four waves, the stacked launch
+            # does not: the two differ by the order of the soft-max sums, 1.2e-4 measured)
+            assert err < 5e-4, (k, err)
 
 
 def test_stacked_pass_with_dropout_is_reproducible_and_finite(dev):
@@ -172,6 +180,9 @@ def test_one_launch_per_kernel_equals_one_launch_per_segment(dev):
 
     def run(flag):
         lib.set_option("stack_launch", flag)
+        # (a per-segment attention launch of this size would split its keys over four waves -- a different order of the soft-max
+        # sums than the stacked launch's; the claim here is about the launch structure, so both run unsplit)
+        lib.set_option("attn_fwd_split", 0)
         try:
             model.load_state_dict(sd0)
             eng.step_count = 5
@@ -181,6 +192,7 @@ def test_one_launch_per_kernel_equals_one_launch_per_segment(dev):
             return losses.tolist(), eng.arena.grad.clone()
         finally:
             lib.set_option("stack_launch", 1)
+            lib.set_option("attn_fwd_split", 1)
 
     l1, g1 = run(1)
     l0, g0 = run(0)
@@ -233,10 +245,12 @@ def test_stacked_encoder_under_other_decoders(dev, kind):
     for a, b in zip(got, want):
         assert abs(a - b) < 1e-3 * abs(b), (got, want)
     A = eng.arena
+    gmax = want_grad.abs().max().item()
     for name in A.names:
         o, k = A.offsets[name], A.pviews[name].numel()
         g, w = A.grad[o:o + k], want_grad[o:o + k]
-        if w.abs().max() == 0:
+        if w.abs().max() < 1e-3 * gmax:   # zero or rounding noise (see test_stacked_pass_equals_the_separate_passes)
+            assert g.abs().max() < 2e-3 * gmax, (name, g.abs().max().item(), gmax)
             continue
         assert _cos(g, w) > 0.999, (name, _cos(g, w))
 
