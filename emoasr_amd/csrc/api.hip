@@ -19,6 +19,7 @@ void emo_gemm_set_tile(int v);
 void emo_gemm_set_tn_group_blocks(int v);
 void emo_gemm_set_tn_group_kb(int v);
 void emo_gemm_set_tn_place(int v);
+void emo_gemm_set_wholek(int v);
 void emo_gemm_set_kb(int v);
 void emo_gemm_set_xcd(int v);
 void emo_gemm_set_conv_big(int v);
@@ -127,6 +128,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "tn_group_blocks") == 0) { emo_gemm_set_tn_group_blocks(value); return 0; }
   if (strcmp(name, "tn_group_kb") == 0) { emo_gemm_set_tn_group_kb(value); return 0; }
   if (strcmp(name, "tn_place") == 0) { emo_gemm_set_tn_place(value); return 0; }
+  if (strcmp(name, "gemm_wholek") == 0) { emo_gemm_set_wholek(value); return 0; }
   if (strcmp(name, "gemm_kb") == 0) { emo_gemm_set_kb(value); return 0; }
   if (strcmp(name, "gemm_xcd") == 0) { emo_gemm_set_xcd(value); return 0; }
   if (strcmp(name, "conv_big") == 0) { emo_gemm_set_conv_big(value); return 0; }

@@ -62,6 +62,7 @@ __device__ __forceinline__ void dgrad_row(const DgradGeom& g, int m, int& b, int
 }
 
 int g_tr_read = 1;
+int g_gemm_wholek = 1;   // option "gemm_wholek"
 int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1, g_tn_group_kb = 0, g_tn_place = 0;
 int g_tn_group_blocks = 0;  // override of a grouped TN launch's block budget (emoasr_set_option "tn_group_blocks"; 0 = auto)
 
@@ -125,14 +126,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 threads");
   constexpr int AS_ELEMS = BM * LD, BS_ELEMS = BKM ? BK * LDBK : BN * LD;
   constexpr int EP_LD = BN + 4;                           // f32 row stride of the staged block tile
-  constexpr int STAGE_BYTES = 2 * (AS_ELEMS + BS_ELEMS) * (int)sizeof(T);
+  constexpr int NBUF = KB >= 8 ? 1 : 2;   // KB = 8 (whole rows of K = 256 per tile, latency-bound launches): one LDS buffer
+  constexpr int STAGE_BYTES = NBUF * (AS_ELEMS + BS_ELEMS) * (int)sizeof(T);
   constexpr int EPI_ROWS = (BM * BN > 128 * 64) ? BM / 2 : BM;  // the 128x128 tile is staged in two 64-row halves
   constexpr int EPI_BYTES = EPI_ROWS * EP_LD * 4;
   constexpr int SMEM_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   T* As0 = reinterpret_cast<T*>(smem);
-  T* Bs0 = As0 + 2 * AS_ELEMS;
+  T* Bs0 = As0 + NBUF * AS_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
@@ -272,6 +274,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   };
 
   const int nk = (g.K + BK - 1) / BK;
+  if constexpr (KB >= 8) {
+    // Launches of a few workgroups (decoding a few utterances): the time of a 64 x 64 x 256 product is its dependent memory
+    // round trips -- the 3-deep ring over eight 32-wide k-tiles waits three to four times.  Here a tile is 256 k wide: all of a
+    // K = 256 product's operands are requested at once (eight 16-byte loads per thread and operand) and waited for once; longer
+    // reductions prefetch the next 256 into registers while the current one is multiplied.
+    Stage sa, sb;
+    load_tile(sa, 0);
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 1 < nk) load_tile(sb, (kt + 1) * BK);
+      if (kt > 0) __syncthreads();
+      store_tile(sa, 0);
+      __syncthreads();
+      compute_tile(0);
+      if (kt + 1 < nk) {
+        if (kt + 2 < nk) load_tile(sa, (kt + 2) * BK);
+        __syncthreads();
+        store_tile(sb, 0);
+        __syncthreads();
+        compute_tile(0);
+      }
+    }
+    __syncthreads();
+  } else {
   Stage s0, s1, s2;  // named stages: static register indexing (a runtime-indexed ring would spill)
   load_tile(s0, 0);
   load_tile(s1, BK);
@@ -291,6 +316,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
     step(kt, s1, s2);
     if (kt + 1 < nk) step(kt + 1, s2, s0);
     if (kt + 2 < nk) step(kt + 2, s0, s1);
+  }
   }
 
   // ---- epilogue -------------------------------------------------------------
@@ -670,6 +696,15 @@ int launch_nt_(const NtArgs& a_in, hipStream_t s, int nz = 1) {
       gemm_nt_kernel<T, BM_, BN_, AMODE, BKM, TR, 1><<<grid, 256, 0, s>>>(a);              \
     }                                                                                     \
   } while (0)
+  if constexpr (sizeof(T) == 2 && AMODE == 0 && !BKM) {
+    // a few workgroups only (decoding): 256-wide k tiles, one wait per 256 of K (see the kernel)
+    if (g_gemm_wholek && a.M <= 2048 && a.K % 256 == 0 && nz == 1) {
+      dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64), 1);
+      gemm_nt_kernel<T, 64, 64, AMODE, BKM, TR, 8><<<grid, 256, 0, s>>>(a);
+      EMO_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (tile == 1) EMO_NT_LAUNCH(128, 128);
   else if (tile == 2) EMO_NT_LAUNCH(128, 64);
   else EMO_NT_LAUNCH(64, 64);
@@ -751,6 +786,7 @@ void emo_gemm_set_tr_read(int v) { g_tr_read = v; }
 void emo_gemm_set_tile(int v) { g_gemm_tile = v; }
 void emo_gemm_set_tn_group_blocks(int v) { g_tn_group_blocks = v > 0 ? v : 0; }
 void emo_gemm_set_kb(int v) { g_gemm_kb = v; }
+void emo_gemm_set_wholek(int v) { g_gemm_wholek = v; }
 void emo_gemm_set_tn_place(int v) { g_tn_place = v != 0; }
 void emo_gemm_set_tn_group_kb(int v) { g_tn_group_kb = (v == 1 || v == 2) ? v : 0; }
 void emo_gemm_set_xcd(int v) { g_gemm_xcd = v; }

@@ -35,7 +35,7 @@ int emoasr_version(void);
  * the options "ffn_fused", "decode_wg", "decode_fused" exist), else 0 */
 int emoasr_experimental(void);
 /* options: "tr_read" (1 = ds_read_b64_tr_b16 operand reads, 0 = scalar fallback); tuning: "gemm_tile", "gemm_kb",
- * "gemm_xcd", "tn_group_blocks", "tn_group_kb", "tn_place", "attn_lpt", "attn_xcd", "attn_fwd_waves", "attn_fwd_split", "attn_fw" (key tiles per workgroup of the single-pass attention backward: 2, 4, 0 = auto);
+ * "gemm_xcd", "gemm_wholek", "tn_group_blocks", "tn_group_kb", "tn_place", "attn_lpt", "attn_xcd", "attn_fwd_waves", "attn_fwd_split", "attn_fw" (key tiles per workgroup of the single-pass attention backward: 2, 4, 0 = auto);
  * "timers" (see emoasr_timer_read) */
 int emoasr_set_option(const char* name, int value);
 /* Device time of selected kernels that sit behind composite entry points, measured with HIP events on the launch stream
