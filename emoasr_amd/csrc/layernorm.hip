@@ -33,7 +33,9 @@ __device__ __forceinline__ void store4(T* p, const float (&o)[4]) {
   }
 }
 
-template <typename T>
+// EARLY: gamma / beta requested together with the row (few rows -- decoding: one round trip less, 4.8 -> 4.0 us); otherwise they
+// are loaded where they are used (many rows: fewer registers in flight measured faster, 2.35 vs 2.39 ms per training step)
+template <typename T, bool EARLY>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int N, const T* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps,
@@ -44,14 +46,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int N, const T* __re
   if (row >= M) return;
   const T* xr = x + (long)row * N;
   float v[LN_MAXC][4];
+  float gm[LN_MAXC][4], bt[LN_MAXC][4];   // requested together with the row: a second round trip after the statistics otherwise
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < LN_MAXC; ++c) {
     const int col = c * 256 + lane * 4;
     if (col < N) {
       load4(xr + col, v[c]);
-      s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+      if constexpr (EARLY) { load4(gamma + col, gm[c]); load4(beta + col, bt[c]); }
     }
+  }
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int col = c * 256 + lane * 4;
+    if (col < N) s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
   }
   const float mu = wave_sum(s) / N;
   float q = 0.f;
@@ -71,8 +79,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int N, const T* __re
     const int col = c * 256 + lane * 4;
     if (col < N) {
       float o[4];
+      if constexpr (!EARLY) { load4(gamma + col, gm[c]); load4(beta + col, bt[c]); }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mu) * rs * gamma[col + j] + beta[col + j];
+      for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mu) * rs * gm[c][j] + bt[c][j];
       store4(yr + col, o);
     }
   }
@@ -352,8 +361,13 @@ extern "C" int emoasr_layernorm_fwd(int dtype, int M, int N, const void* x, cons
   EMO_CHECK(N % 4 == 0 && N <= LN_MAXC * 256, "layernorm: N=%d unsupported", N);
   if (M == 0) return 0;
   EmoTimerScope timer_(EMO_TIMER_LAYERNORM, (hipStream_t)stream, 0.0, 2.0 * M * N * (dtype == EMO_BF16 ? 2.0 : 4.0));
-  EMO_DISPATCH(dtype, (ln_fwd_kernel<T><<<cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(
-                          M, N, (const T*)x, gamma, beta, eps, (T*)y, mean, rstd)));
+  if (M <= 4096) {
+    EMO_DISPATCH(dtype, (ln_fwd_kernel<T, true><<<cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(
+                            M, N, (const T*)x, gamma, beta, eps, (T*)y, mean, rstd)));
+  } else {
+    EMO_DISPATCH(dtype, (ln_fwd_kernel<T, false><<<cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(
+                            M, N, (const T*)x, gamma, beta, eps, (T*)y, mean, rstd)));
+  }
   EMO_LAUNCH_CHECK();
   return 0;
 }
