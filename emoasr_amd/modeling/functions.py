@@ -221,7 +221,12 @@ def ctc_greedy_apply(dec, eouts, elens):
     eng = _engine_of(dec)
     logits = eng.head_logits(eouts, getattr(dec, "_prefix", "decoder") + ".output", out_f32=eng.f32_head)
     best, hyp, hyplen = eng.greedy(logits, _elens_dev(eouts, elens), dec.blank_id)
-    best_h, hyp_h, n_h = best.cpu(), hyp.cpu(), hyplen.cpu().tolist()  # one D2H per batch
+    B, T = best.shape
+    packed = best._base.cpu() if best._base is not None and best._base.numel() == 2 * B * T + B else None   # one D2H per batch
+    if packed is not None:
+        best_h, hyp_h, n_h = packed[:B * T].view(B, T), packed[B * T:2 * B * T].view(B, T), packed[2 * B * T:].tolist()
+    else:
+        best_h, hyp_h, n_h = best.cpu(), hyp.cpu(), hyplen.cpu().tolist()
     el = _host_list(elens)
     hyps = [hyp_h[b, : n_h[b]].tolist() for b in range(len(n_h))]
     aligns = [best_h[b, : el[b]].tolist() for b in range(len(n_h))]

@@ -644,9 +644,9 @@ def ctc_grad_rows(logits2, lse, labels, elens, ylens, blank, lp, alpha, beta, nl
 def ctc_greedy(logits, elens, blank):
     B, T, V = logits.shape
     dev = logits.device
-    best = torch.empty(B, T, device=dev, dtype=torch.int32)
-    hyp = torch.empty(B, T, device=dev, dtype=torch.int32)
-    hyplen = torch.empty(B, device=dev, dtype=torch.int32)
+    # one buffer, three views: the caller reads all of them back with ONE device-to-host copy (ctc_greedy_apply)
+    buf = torch.empty(2 * B * T + B, device=dev, dtype=torch.int32)
+    best, hyp, hyplen = buf[:B * T].view(B, T), buf[B * T:2 * B * T].view(B, T), buf[2 * B * T:]
     lib.call("emoasr_ctc_greedy", dt(logits), B, T, V, _p(logits), logits.stride(1), _p(elens), blank, _p(best),
              _p(hyp), _p(hyplen), _stream())
     return best, hyp, hyplen
