@@ -43,6 +43,25 @@ def test(model, dataloader, vocab, beam_width, len_weight, decode_ctc_weight, de
     respect_cpu_quota()   # (an oversized CPU pool under a cgroup quota freezes the decoding thread for 20-50 ms at a time)
     rows = []
     n = len(dataloader) if hasattr(dataloader, "__len__") else -1
+    # evaluation: the weights are constant for the whole loop (test_asr.py:63 runs under model.eval() / torch.no_grad())
+    arenas = []
+    for m in (model, lm):
+        eng = m.engine() if m is not None and hasattr(m, "engine") else None
+        if eng is not None and hasattr(eng, "arena"):
+            eng.ensure_bound()
+            arenas.append(eng.arena)
+    for a in arenas:
+        a.hold_shadow(True)
+    try:
+        return _test_rows(model, dataloader, vocab, beam_width, len_weight, decode_ctc_weight, decode_phone, lm, lm_weight, device,
+                          eos_id, num_samples, sample_utt_id, nbest, rows, n)
+    finally:
+        for a in arenas:
+            a.hold_shadow(False)
+
+
+def _test_rows(model, dataloader, vocab, beam_width, len_weight, decode_ctc_weight, decode_phone, lm, lm_weight, device, eos_id,
+               num_samples, sample_utt_id, nbest, rows, n):
     for i, data in enumerate(dataloader):
         if num_samples > 0 and (i + 1) > num_samples:
             return rows
