@@ -19,7 +19,7 @@ if os.environ.get("UNIFORM"):
     shapes = [(n1, n2, K, 1) for n1, n2, _, _ in shapes]
 probs = []
 for n1, n2, k, cs in shapes:
-    probs.append((rnd(k, n1), rnd(k, n2), torch.zeros(n1, n2, device=dev), 1.0, torch.zeros(n1, device=dev) if cs else None, 1.0))
+    probs.append((rnd(k, n1), rnd(k, n2), torch.zeros(n1, n2, device=dev), 1.0, torch.zeros(n1, device=dev) if cs and not os.environ.get("NO_COLSUM") else None, 1.0))
 alg = sum(k * (n1 + n2) * 2 for n1, n2, k, _ in shapes)
 print(f"rows {K}: algorithmic input bytes per grouped launch {alg/1e6:.1f} MB")
 
