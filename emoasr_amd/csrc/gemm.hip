@@ -993,9 +993,8 @@ extern "C" int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const v
   EMO_CHECK(T1 >= 3 && F1 >= 3, "conv2: input too small (T1=%d F1=%d)", T1, F1);
   const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
   EMO_CHECK(C % 32 == 0, "conv2: C must be a multiple of 32");
-  // bias (+ ReLU) only, bf16, C % 256 == 0: the large-tile kernel (gemm_big.hip) -- from 16 k output pixels: a single decoded
-  // utterance (5 700 pixels = 30 large tiles, each walking K = 2304 alone) takes 41 us there and 26 us on the 64 x 64 kernel below
-  if (dtype == EMO_BF16 && C % 256 == 0 && emo_conv_big_enabled() && (long)B * T2 * F2 >= 16384 && ep->alpha == 1.f && !ep->residual && !ep->dact_pre &&
+  // bias (+ ReLU) only, bf16, C % 256 == 0: the large-tile kernel (gemm_big.hip)
+  if (dtype == EMO_BF16 && C % 256 == 0 && emo_conv_big_enabled() && ep->alpha == 1.f && !ep->residual && !ep->dact_pre &&
       !ep->pre_out && ep->drop_p == 0.f && !ep->out_f32 && (ep->act == EMO_ACT_NONE || ep->act == EMO_ACT_RELU))
     return emo_conv2_fwd_big(B, T1, F1, C, y1, w, y2, ep->bias, ep->act == EMO_ACT_RELU, (hipStream_t)stream);
   NtArgs a{};
