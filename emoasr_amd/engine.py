@@ -199,6 +199,8 @@ class _DecoderMixinPlaceholder:
 def h2d_i32(values, device):
     """small host array -> int32 device tensor through pinned memory (asynchronous H2D)"""
     t = torch.as_tensor(values, dtype=torch.int32)
+    if torch.device(device).type == "cpu":
+        return t
     return t.pin_memory().to(device, non_blocking=True)
 
 

@@ -8,6 +8,8 @@ the parameter inputs.
 """
 import torch
 
+from ..engine import h2d_i32
+
 
 def _engine_of(mod):
     if mod._owner is None:
@@ -103,7 +105,10 @@ def encoder_apply_stacked(enc, xs_list, xlens_list):
     for k in range(n):
         elens = torch.tensor([((v - 1) // 2 - 1) // 2 for v in hosts[k]], dtype=torch.int64)
         eo = outs[k]
-        eo._emo_elens_dev = None   # (decoders fall back to building the device tensor from `elens`)
+        # the decoders' device copy of the lengths, uploaded from pinned memory without waiting for the stream (a pageable
+        # `.to(device)` here blocked the host behind the whole stacked encoder pass, once per micro-batch: the launch queue ran
+        # dry five times per optimizer step)
+        eo._emo_elens_dev = h2d_i32(elens.to(torch.int32), eo.device)
         res.append((eo, elens, None))
     return res
 
@@ -202,7 +207,9 @@ def ctc_forced_align_apply(log_probs, elens, ys, ylens, blank):
 def _elens_dev(eouts, elens):
     dev = getattr(eouts, "_emo_elens_dev", None)
     if dev is None:
-        dev = torch.as_tensor(elens).to(torch.int32).to(eouts.device)
+        t = torch.as_tensor(elens)
+        # (a host tensor goes up from pinned memory, asynchronously; a device tensor is converted in place on the stream)
+        dev = t.to(torch.int32) if t.is_cuda else h2d_i32(t.to(torch.int32), eouts.device)
     return dev
 
 
