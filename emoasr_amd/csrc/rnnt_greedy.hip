@@ -334,6 +334,28 @@ extern "C" long emoasr_rnnt_greedy_supported(int dtype, int E, int H, int J, int
          H % G == 0 && 4 * (H / G) <= 64 && E <= G_MAXE && H <= G_MAXH && J <= 4 * GT && V >= G && J >= G;
 }
 
+// LDS bytes of one workgroup of the search (the own units' LSTM rows of both layers included when everything fits: *wlds)
+static size_t greedy_smem(int dtype, int E, int H, int J, int V, bool* wlds) {
+  const int G = greedy_groups(H, V);
+  const size_t esz = dtype == EMO_BF16 ? 2 : 4;
+  const int nvmax = (V + G - 1) / G + 1, njmax = (J + G - 1) / G + 1, nu = H / G;
+  const size_t pad = 16 / esz;
+  const size_t nfl = (size_t)E + 2 * H + 3 * J + 128 + 8 * nu + nvmax + njmax + 2 * nu;
+  const size_t smem0 = (nfl * 4 + 15) / 16 * 16 + ((size_t)nvmax * (J + pad) + (size_t)njmax * (H + pad)) * esz;
+  const size_t lstm = ((size_t)4 * nu * (E + pad + H + pad) + (size_t)4 * nu * (H + pad + H + pad)) * esz;
+  *wlds = smem0 + lstm <= 160 * 1024;
+  return smem0 + (*wlds ? lstm : 0);
+}
+
+// Can ONE utterance of T encoder frames with at most max_len labels go through the one-launch search?  (_supported's model
+// conditions + the workgroup's LDS image within 160 KB + T + max_len within the 12-bit step tag of the hand-off words.)  Callers
+// fall back to the launch chain (emoasr_joint_tanh / emoasr_argmax_rows / emoasr_first_not_equal) for an utterance that does not fit.
+extern "C" long emoasr_rnnt_greedy_fits(int dtype, int E, int H, int J, int V, int nl, int T, int max_len) {
+  if (!emoasr_rnnt_greedy_supported(dtype, E, H, J, V, nl)) return 0;
+  bool wlds = false;
+  return greedy_smem(dtype, E, H, J, V, &wlds) <= 160 * 1024 && T + max_len + 2 < 4095 && V < (1 << 20);
+}
+
 // scratch of emoasr_rnnt_greedy (bytes; no initialisation needed)
 extern "C" long emoasr_rnnt_greedy_ws_bytes(int H, int J) { return (long)(2 * H + J + 2 * 64) * 8 + 256; }
 
@@ -367,14 +389,8 @@ extern "C" int emoasr_rnnt_greedy(int dtype, int T, int E, int H, int J, int V, 
   a.hyp = hyp; a.align = align; a.lens = lens;
   // tags start at 1 in every launch: the exchange words (and the error flag) are cleared on the launch stream first
   EMO_CHECK(hipMemsetAsync(p, 0, (size_t)emoasr_rnnt_greedy_ws_bytes(H, J), s) == hipSuccess, "rnnt_greedy: hipMemsetAsync failed");
-  const int nvmax = (V + G - 1) / G + 1, njmax = (J + G - 1) / G + 1, nu = H / G;
-  const size_t pad = 16 / esz;
-  const size_t nfl = (size_t)E + 2 * H + 3 * J + 128 + 8 * nu + nvmax + njmax + 2 * nu;
-  const size_t smem0 = (nfl * 4 + 15) / 16 * 16 + ((size_t)nvmax * (J + pad) + (size_t)njmax * (H + pad)) * esz;
-  // the own units' LSTM rows of both layers in LDS as well when everything fits (bf16 at the L4 sizes: ~140 KB)
-  const size_t lstm = ((size_t)4 * nu * (E + pad + H + pad) + (size_t)4 * nu * (H + pad + H + pad)) * esz;
-  const bool wlds = smem0 + lstm <= 160 * 1024;
-  const size_t smem = smem0 + (wlds ? lstm : 0);
+  bool wlds = false;
+  const size_t smem = greedy_smem(dtype, E, H, J, V, &wlds);
   EMO_CHECK(smem <= 160 * 1024, "rnnt_greedy: %zu bytes of LDS needed", smem);
   const void* kerns[4] = {(const void*)rnnt_greedy_kernel<bf16, false>, (const void*)rnnt_greedy_kernel<bf16, true>,
                           (const void*)rnnt_greedy_kernel<float, false>, (const void*)rnnt_greedy_kernel<float, true>};

@@ -102,14 +102,18 @@ class ParamArena:
         _ARENAS.add(self)
 
     def bound(self):
-        """do the module's parameters still live in this arena?  Moving the module (.to / .cpu().cuda() / .half) re-creates ALL of
-        them, so a few sentinels answer every call (0.16 ms for the 455 tensors of the L2 model was a tenth of a batch-1 decode);
-        every 16th call checks all, which also finds a single re-assigned parameter."""
-        self._bound_calls = getattr(self, "_bound_calls", 0) + 1
+        """do the module's parameters still live in this arena?  Every call checks EVERY parameter (0.16 ms for the 455 tensors of
+        the L2 model: nothing against a training step), so a single re-assigned parameter (p.data = ..., weight tying, a partial
+        load with assign=True) is seen before the next forward / update runs on stale arena storage.  Only inside a
+        hold_shadow(True) window -- an evaluation loop whose caller has promised not to touch the parameters, where that
+        0.16 ms was a tenth of a batch-1 decode -- a few sentinels answer (moving the module re-creates ALL parameters), with
+        the full check every 16th call."""
         n = len(self.params)
-        if self._bound_calls % 16 != 1 and n > 16:
-            idx = (0, n // 7, 2 * n // 7, 3 * n // 7, 4 * n // 7, 5 * n // 7, 6 * n // 7, n - 1)
-            return all(self.params[i].data_ptr() == self.pviews[self.names[i]].data_ptr() for i in idx)
+        if getattr(self, "_hold", False) and n > 16:
+            self._bound_calls = getattr(self, "_bound_calls", 0) + 1
+            if self._bound_calls % 16 != 1:
+                idx = (0, n // 7, 2 * n // 7, 3 * n // 7, 4 * n // 7, 5 * n // 7, 6 * n // 7, n - 1)
+                return all(self.params[i].data_ptr() == self.pviews[self.names[i]].data_ptr() for i in idx)
         return all(p.data_ptr() == self.pviews[n].data_ptr() for n, p in zip(self.names, self.params))
 
     def refresh_shadow(self):
@@ -1350,33 +1354,48 @@ class _RNNTMixin:
             dev = eouts.device
             hyps, aligns = [], []
             V = A.w("decoder.output.weight").shape[0]
-            if ops.lib.size_query("emoasr_rnnt_greedy_supported", ops.dt(eouts), self.r_emb, self.r_H, J, V, self.r_nl):
+            # the one-launch search per utterance that fits it (model shape, LDS image, step-tag range); the launch chain otherwise
+            fits = [bool(ops.lib.size_query("emoasr_rnnt_greedy_fits", ops.dt(eouts), self.r_emb, self.r_H, J, V, self.r_nl,
+                                            int(elens_host[b]), max_seq_len)) for b in range(eouts.shape[0])]
+            if all(fits):
                 return self._rnnt_greedy_device(eouts, elens_host, blank, eos, max_seq_len)
             for b in range(eouts.shape[0]):
-                T = int(elens_host[b])
-                e_all = ops.gemm_nt(eouts[b, :max(T, 1)], A.w("decoder.w_enc.weight"), bias=A.p("decoder.w_enc.bias"))
-                dout, state, _ = self.rnnt_recurrency(h2d_i32([[eos]], dev), None, False, False)
-                g = ops.gemm_nt(dout.view(1, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
-                hyp, align, t = [], [], 0
-                while t < T:
-                    n = min(window, T - t)
-                    h = ops.joint_tanh(e_all[t:t + n].view(1, n, J), g.view(1, 1, J))
-                    logits = ops.gemm_nt(h.view(n, J), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
-                    k, tok = ops.first_not_equal(ops.argmax_rows(logits), blank).tolist()
-                    if k < 0:  # every frame of the window is blank
-                        align += [blank] * n
-                        t += n
-                        continue
-                    align += [blank] * k + [tok]
-                    t += k  # the label is emitted AT frame t+k: the search stays on that frame
-                    hyp.append(tok)
-                    dout, state, _ = self.rnnt_recurrency(h2d_i32([[tok]], dev), state, False, False)
-                    g = ops.gemm_nt(dout.view(1, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
-                    if len(hyp) > max_seq_len:
-                        break
+                if fits[b]:
+                    h1, a1 = self._rnnt_greedy_device(eouts[b:b + 1], [int(elens_host[b])], blank, eos, max_seq_len)
+                    hyps += h1
+                    aligns += a1
+                    continue
+                hyp, align = self._rnnt_greedy_chain(eouts[b], int(elens_host[b]), blank, eos, max_seq_len, window)
                 hyps.append(hyp)
                 aligns.append(align)
             return hyps, aligns
+
+    def _rnnt_greedy_chain(self, eouts_b, T, blank, eos, max_seq_len, window):
+        """one utterance through the launch chain: windows of frames scored against the same decoder state, the first non-blank
+        frame found on the device, one host round trip per emitted label"""
+        A, J = self.arena, self.r_J
+        dev = eouts_b.device
+        e_all = ops.gemm_nt(eouts_b[:max(T, 1)], A.w("decoder.w_enc.weight"), bias=A.p("decoder.w_enc.bias"))
+        dout, state, _ = self.rnnt_recurrency(h2d_i32([[eos]], dev), None, False, False)
+        g = ops.gemm_nt(dout.view(1, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
+        hyp, align, t = [], [], 0
+        while t < T:
+            n = min(window, T - t)
+            h = ops.joint_tanh(e_all[t:t + n].view(1, n, J), g.view(1, 1, J))
+            logits = ops.gemm_nt(h.view(n, J), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
+            k, tok = ops.first_not_equal(ops.argmax_rows(logits), blank).tolist()
+            if k < 0:  # every frame of the window is blank
+                align += [blank] * n
+                t += n
+                continue
+            align += [blank] * k + [tok]
+            t += k  # the label is emitted AT frame t+k: the search stays on that frame
+            hyp.append(tok)
+            dout, state, _ = self.rnnt_recurrency(h2d_i32([[tok]], dev), state, False, False)
+            g = ops.gemm_nt(dout.view(1, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
+            if len(hyp) > max_seq_len:
+                break
+        return hyp, align
 
     def _rnnt_greedy_device(self, eouts, elens_host, blank, eos, max_seq_len):
         """the whole search of an utterance as ONE cooperative launch (csrc/rnnt_greedy.hip): no host round trip per label; the

@@ -275,10 +275,16 @@ def train_group(model, optimizer, datas, params, device, group=None, sync=True, 
     return dicts
 
 
-def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False, group=None, log=None):
+def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False, group=None, log=None, stacked="auto"):
     """One epoch of asr/train_asr.py:100-143: every accum_grad-th micro-batch steps the optimizer; the
     running loss_dict sums are logged every params.log_step optimizer steps (the only host
-    synchronisation of the loop)."""
+    synchronisation of the loop).
+
+    stacked: "auto" (default; also params.stacked when present) sends the accum_grad micro-batches of an optimizer step through the
+    engine together whenever stacked_ok(...) allows it (activation memory is accum_grad times one micro-batch's; dropout masks and
+    the rounding of the BatchNorm running variance differ from the one-by-one passes in the last bits); False keeps the
+    reference's one-by-one loop; True asserts that the stacked path is taken.  A group that runs out of device memory is re-run
+    one by one from zeroed gradients (the BatchNorm running statistics may then have moved once more for that group)."""
     import logging
     from .hostenv import respect_cpu_quota
     respect_cpu_quota()   # (an oversized CPU pool under a cgroup quota freezes the launching thread for 20-50 ms at a time)
@@ -292,7 +298,10 @@ def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False
     n_total = len(dataloader) // params.accum_grad if hasattr(dataloader, "__len__") else -1
     # the accum_grad micro-batches of an optimizer step go through the engine together when the model allows it (a trailing
     # incomplete group is accumulated and never stepped, exactly as the one-by-one loop leaves it)
-    stacked = stacked_ok(model, optimizer, params)
+    choice = getattr(params, "stacked", stacked)
+    assert choice in ("auto", True, False), "train: stacked must be 'auto', True or False"
+    stacked = stacked_ok(model, optimizer, params) if choice in ("auto", True) else False
+    assert stacked or choice is not True, "train(stacked=True): this model / optimizer cannot take the stacked path (stacked_ok)"
     pending = []
     for accum_step, data in enumerate(dataloader):
         stepping = (accum_step + 1) % params.accum_grad == 0
@@ -300,8 +309,18 @@ def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False
             pending.append(data)
             if not stepping:
                 continue
-            dicts = train_group(model, optimizer, pending, params, device, group=group, sync=False, specaug=specaug,
-                                empty_cache=empty_cache)
+            try:
+                dicts = train_group(model, optimizer, pending, params, device, group=group, sync=False, specaug=specaug,
+                                    empty_cache=empty_cache)
+            except torch.cuda.OutOfMemoryError:
+                # the stacked pass holds accum_grad micro-batches' activations at once: drop what it had allocated and whatever
+                # it had accumulated, then run this group (and the rest of the epoch) the reference's way
+                log("train: the stacked pass ran out of device memory; continuing with one-by-one micro-batches")
+                model.engine().arena.grad.zero_()
+                torch.cuda.empty_cache()
+                stacked = False
+                dicts = [train_step(model, optimizer, d, params, device, no_grad=k + 1 < len(pending), group=group,
+                                    sync=False, specaug=specaug) for k, d in enumerate(pending)]
             pending = []
         else:
             dicts = [train_step(model, optimizer, data, params, device, no_grad=not stepping,
@@ -321,5 +340,7 @@ def train(model, optimizer, dataloader, params, device, epoch, empty_cache=False
             log(f"epoch = {(epoch + 1):>2} step = {step:>6} / {n_total:>6} lr = {optimizer._lr:.5f} " + detail)
             sums = {}
     for data in pending:   # an incomplete last group: gradients accumulate, no update (train_asr.py:106-128)
-        train_step(model, optimizer, data, params, device, no_grad=True, group=group, sync=False, specaug=specaug)
+        loss_dict = train_step(model, optimizer, data, params, device, no_grad=True, group=group, sync=False, specaug=specaug)
+        for k, v in loss_dict.items():   # (the one-by-one loop adds these micro-batches' losses to the running sums too)
+            sums[k] = sums[k] + v if k in sums else v
     return step

@@ -464,12 +464,21 @@ int emoasr_argmax_rows(int dtype, int M, int V, const void* x, long ldx, int* ou
 int emoasr_first_not_equal(int n, const int* x, int value, int* out, void* stream);
 
 /* ---- greedy transducer search on the device (csrc/rnnt_greedy.hip; RNNTDecoder._greedy, rnn_transducer.py:194-240) --------------
- * ONE launch per utterance: 32 co-resident workgroups run the whole time-synchronous search (joint + output arg-max per step, the two
- * LSTM layers + w_dec per emitted label) and meet at grid barriers; no host round trip per label.  e_all [T, J] = w_enc . eouts + bias
- * in the compute dtype; b_lstm0 / b_lstm1 = bias_ih + bias_hh [4H] of the two layers; ws: emoasr_rnnt_greedy_ws_bytes(H, J) bytes.
+ * ONE launch per utterance: 32 or 64 co-resident workgroups (64 when H is a multiple of 64 and V >= 64) run the whole time-synchronous
+ * search.  Each owns a slice of every matrix (rows of the output and w_dec projections, the LSTM rows of its H / G hidden units), kept
+ * in LDS; per step a [V x J] GEMV + arg-max, per emitted label two LSTM layers + a [J x H] GEMV.  The hidden state, the joint input and
+ * the per-workgroup arg-max candidates travel between the workgroups as DATA-TAGGED 8-byte words (value + 12-bit step tag in one relaxed
+ * store, readers poll for the tag): no grid barrier, no host round trip per label; a wait that gives up sets the error flag.
+ * e_all [T, J] = w_enc . eouts + bias in the compute dtype; b_lstm0 / b_lstm1 = bias_ih + bias_hh [4H] of the two layers;
+ * ws: emoasr_rnnt_greedy_ws_bytes(H, J) bytes (cleared by the call).
  * Outputs (device): hyp int32 [max_len + 1], align int32 [T + max_len + 1] (the arg-max of every joint evaluation, in order),
- * lens int32 [2] = {len(hyp), len(align)}.  emoasr_rnnt_greedy_status: 0 unless a barrier of the last launch in `ws` gave up
- * (synchronises the stream).  emoasr_rnnt_greedy_supported: two LSTM layers, widths multiples of 8, H a multiple of 32 up to 512. */
+ * lens int32 [2] = {len(hyp), len(align)}.  emoasr_rnnt_greedy_status: 0 unless a wait of the last launch in `ws` gave up
+ * (synchronises the stream).
+ * emoasr_rnnt_greedy_supported (the MODEL): bf16 or f32, two LSTM layers, E / H / J multiples of 8, H a multiple of the G workgroups
+ * with at most 16 hidden units per workgroup, E <= 1024, H <= 1024, J <= 1024, V >= G, J >= G.
+ * emoasr_rnnt_greedy_fits (ONE utterance): _supported, and the workgroup's LDS image within 160 KB, T + max_len + 2 < 4095 (the step
+ * tag), V < 2^20.  An utterance that does not fit takes the launch chain (engine.rnnt_greedy falls back per utterance). */
+long emoasr_rnnt_greedy_fits(int dtype, int E, int H, int J, int V, int nl, int T, int max_len);
 long emoasr_rnnt_greedy_supported(int dtype, int E, int H, int J, int V, int nl);
 long emoasr_rnnt_greedy_ws_bytes(int H, int J);
 int emoasr_rnnt_greedy(int dtype, int T, int E, int H, int J, int V, int blank, int eos, int max_len, const void* e_all,

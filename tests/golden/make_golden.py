@@ -662,6 +662,63 @@ def run_train_trace():
           "lrs", [round(v, 6) for v in lrs[:5]], "gnorms", [round(v, 2) for v in gnorms[:4]])
 
 
+TRACE_D256 = dict(input_layer="conv2d", feat_dim=40, num_framestacks=1, encoder_type="conformer", decoder_type="ctc",
+                  pos_encode_type="rel", enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=2,
+                  enc_intermediate_size=256, dropout_enc_rate=0.0, dropout_attn_rate=0.0, dropout_dec_rate=0.0, vocab_size=40,
+                  blank_id=0, eos_id=2, kd_weight=0, lsm_prob=0.1, **TRAIN_TRACE)
+
+
+def run_train_trace_d256():
+    """as run_train_trace at enc_hidden_size 256 -- the width the stacked bf16 engine (engine.ctc_train_stacked, the benched
+    path) accepts -- so that tests/test_stacked_oracle_gpu.py can replay the REFERENCE's optimizer trace through it.  The model
+    has 4 M parameters: the fixture holds no weights, the initial state is tests/util.py: synthetic_state (a seeded rule both
+    sides apply), a few of its tensors are stored to prove the rule reproduced them -> train_trace_d256.npz"""
+    import math
+    sys.path.insert(1, os.path.dirname(os.path.dirname(OUT)))
+    from tests.util import synthetic_state
+    from asr.optimizers import ScheduledOptimizer
+    params = make_params(TRACE_D256)
+    model = ASR(params, phase="train")
+    sd0 = synthetic_state({k: v.shape for k, v in model.state_dict().items()})
+    model.load_state_dict(sd0)
+    model.train()
+    optimizer = ScheduledOptimizer(torch.optim.Adam(model.parameters(), lr=0, weight_decay=params.weight_decay), params)
+    batches = [make_batch(seed, 40, 40) for seed in (11, 12, 13)]
+    out = {}
+    for i, (xs, xlens, ys, ylens, ys_in, ys_out) in enumerate(batches):
+        out.update({f"batch{i}/xs": xs.numpy(), f"batch{i}/xlens": xlens.numpy(), f"batch{i}/ys": ys.numpy(),
+                    f"batch{i}/ylens": ylens.numpy(), f"batch{i}/ys_in": ys_in.numpy(), f"batch{i}/ys_out": ys_out.numpy()})
+    for k in ("encoder.norm.weight", "encoder.transformers.1.self_attn.pos_bias_u", "decoder.output.bias",
+              "encoder.transformers.0.conv.depthwise_conv.weight"):
+        out["init/" + k] = sd0[k].numpy()
+    losses, lrs, gnorms = [], [], []
+    optimizer.update_epoch()
+    for micro in range(24):
+        xs, xlens, ys, ylens, ys_in, ys_out = batches[micro % 3]
+        loss, loss_dict = model(xs, xlens, ys, ylens, ys_in, ys_out)
+        losses.append(loss_dict["loss_total"].item() / params.accum_grad)
+        (loss / params.accum_grad).backward()
+        if (micro + 1) % params.accum_grad == 0:
+            grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), params.clip_grad_norm)
+            gnorms.append(float(grad_norm))
+            if not math.isnan(grad_norm):
+                optimizer.step()
+            optimizer.zero_grad()
+            lrs.append(optimizer._lr)
+    out["losses"], out["lrs"], out["gnorms"] = np.array(losses), np.array(lrs), np.array(gnorms)
+    sd_end = model.state_dict()
+    for k in ("decoder.output.weight", "encoder.norm.weight", "encoder.transformers.0.conv.batch_norm.running_var",
+              "encoder.transformers.0.conv.batch_norm.running_mean", "encoder.transformers.1.self_attn.pos_bias_u",
+              "encoder.conv.conv.0.weight", "encoder.transformers.1.feed_forward.w2.weight",
+              "encoder.transformers.0.self_attn.linear_pos.weight", "encoder.transformers.1.conv.depthwise_conv.weight",
+              "encoder.transformers.0.conv.batch_norm.num_batches_tracked"):
+        out["end/" + k] = sd_end[k].numpy()
+    out["optim/_step"] = np.array(optimizer.state_dict()["_step"])
+    np.savez_compressed(os.path.join(OUT, "train_trace_d256.npz"), **out)
+    print("train trace d256: losses", [round(v, 3) for v in losses[:4]], "...", [round(v, 3) for v in losses[-2:]],
+          "lrs", [round(v, 6) for v in lrs[:5]], "gnorms", [round(v, 2) for v in gnorms[:4]])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ctc", "ctcabs", "l3", "l4"]
     if "ctc" in which:
@@ -679,6 +736,8 @@ if __name__ == "__main__":
         run_hostio()
     if "traintrace" in which:  # needs l2_tiny.npz
         run_train_trace()
+    if "traintrace256" in which:
+        run_train_trace_d256()
     if "kd" in which:  # needs l2_tiny.npz and l3_tiny.npz (reads their weights)
         run_kd()
     if "rnntbeam" in which:  # needs l4_tiny.npz (reads its weights)

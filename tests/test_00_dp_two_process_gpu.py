@@ -29,17 +29,22 @@ def test_two_ranks_on_one_gpu(tmp_path):
     out = str(tmp_path / "dp2.json")
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EMOASR_CPU_THREADS="2")
+    # each child's output goes to a file of its own: two pipes drained one after the other would deadlock as soon as rank 1
+    # filled its 64 KB pipe buffer (verbose hipcc lines on a cold build) while rank 0 sat in a collective waiting for it
+    files = [open(str(tmp_path / f"rank{r}.log"), "w") for r in range(2)]
     procs = [subprocess.Popen([sys.executable, "-m", "tests.dp_worker", str(r), "2", port, out], cwd=ROOT, env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    logs = []
-    for p in procs:
-        try:
-            log, _ = p.communicate(timeout=540)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        logs.append(log)
+                              stdout=files[r], stderr=subprocess.STDOUT) for r in range(2)]
+    try:
+        for p in procs:
+            p.wait(timeout=540)
+    except subprocess.TimeoutExpired:
+        for q in procs:
+            q.kill()
+        raise
+    finally:
+        for f in files:
+            f.close()
+    logs = [open(str(tmp_path / f"rank{r}.log")).read() for r in range(2)]
     if any("no GPU" in (log or "") and p.returncode != 0 for p, log in zip(procs, logs)):
         pytest.skip("no GPU")
     for r, (p, log) in enumerate(zip(procs, logs)):

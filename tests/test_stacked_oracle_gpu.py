@@ -1,0 +1,232 @@
+"""The path bench.py times -- engine.ctc_train_stacked / train.train_group: bf16, the `accum_grad` micro-batches of one optimizer
+step through the encoder in ONE stacked pass -- against the ORACLE (oracle/model.py, f32, CPU) run micro-batch by micro-batch,
+which is what the reference does (asr/train_asr.py:106-128: forward, loss / accum_grad, backward for each, then one update).
+tests/test_stacked_gpu.py compares the stacked pass with the un-stacked HIP passes; here nothing on the checking side is HIP.
+
+(a) full L2 size (23.5 M parameters, V = 10000), three micro-batches of 2-3 utterances with unequal padded lengths, one
+    utterance of 1203 frames: every micro-batch's loss within 2e-3, EVERY parameter gradient (455 tensors) cosine >= 0.995 and
+    norm within 2 % of sum_k grad(oracle loss_k) / n (gradients that are zero in exact arithmetic stay at the noise level),
+    BatchNorm running statistics against the oracle's SEQUENTIAL momentum updates, num_batches_tracked exactly;
+(b) the reference's own optimizer trace at d = 256 (tests/golden/train_trace_d256.npz, written by make_golden.py from the
+    reference's ASR + ScheduledOptimizer + torch.optim.Adam: 12 updates x accum_grad 2) replayed through train.train_group in
+    bf16: learning rates exact, losses 1e-2 relative, final parameters' UPDATE vectors cosine >= 0.97 against the reference's;
+(c) the stacked ENCODER under the RNN-T and the attention decoder (modeling/functions.py: encoder_apply_stacked, train_group's
+    "encoder" mode) against oracle/rnnt.py / oracle/decoder.py per micro-batch: loss dictionaries 2e-2, gradient cosines 0.97."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import synthetic_state
+
+pytestmark = pytest.mark.gpu
+
+L2 = dict(input_layer="conv2d", feat_dim=80, num_framestacks=1, encoder_type="conformer", decoder_type="ctc",
+          pos_encode_type="rel", enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=12,
+          enc_intermediate_size=1024, dropout_enc_rate=0.0, dropout_attn_rate=0.0, vocab_size=10000, blank_id=0,
+          eos_id=2, kd_weight=0)
+
+
+def _cos(a, b):
+    a, b = a.flatten().double(), b.flatten().double()
+    return (torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)).item()
+
+
+def _batch(seed, xlens, V, frames_per_label=30):
+    g = torch.Generator().manual_seed(seed)
+    xlens = torch.tensor(xlens)
+    ylens = torch.clamp(xlens // frames_per_label, min=1)
+    B, T, L = len(xlens), int(xlens.max()), int(ylens.max())
+    xs = torch.randn(B, T, 80, generator=g)
+    ys = torch.randint(3, V, (B, L), generator=g)
+    for b in range(B):
+        xs[b, xlens[b]:] = 0
+        ys[b, ylens[b]:] = 2
+    eos = torch.full((B, 1), 2)
+    return dict(xs=xs, xlens=xlens, ys=ys, ylens=ylens, ys_in=torch.cat([eos, ys], 1), ys_out=torch.cat([ys, eos], 1))
+
+
+def _build(cfg, dev, seed=0, head_gain=3.0):
+    from emoasr_amd.modeling.asr import ASR
+    torch.manual_seed(seed)
+    model = ASR(SimpleNamespace(**cfg), compute_dtype=torch.bfloat16)
+    with torch.no_grad():
+        if hasattr(model.decoder, "output") and head_gain != 1.0:
+            model.decoder.output.weight.mul_(head_gain)
+        for n, p in model.named_parameters():
+            if "batch_norm" in n or ".norm" in n:
+                p.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return model.to(dev).train(), sd
+
+
+def _oracle_params(sd):
+    params = {k: v for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    for v in params.values():
+        v.requires_grad_(True)
+    return params
+
+
+def _compare_grads(eng, params, cos_bar, norm_bar, label):
+    """every parameter tensor of the arena against the oracle's accumulated .grad"""
+    A = eng.arena
+    got = A.grad.detach().float().cpu()
+    gmax = max(p.grad.abs().max().item() for p in params.values() if p.grad is not None)
+    worst = (2.0, "")
+    checked = 0
+    for name in A.names:
+        o, k = A.offsets[name], A.pviews[name].numel()
+        g = got[o:o + k]
+        w = params[name].grad
+        w = torch.zeros(k) if w is None else w.flatten()
+        if w.abs().max() < 1e-3 * gmax:
+            # zero in exact arithmetic (linear_k.bias: a constant added to every key's score) or far below the other gradients:
+            # rounding noise on both sides -- its direction means nothing, its size must stay noise
+            assert g.abs().max() < 4e-3 * gmax, (label, name, g.abs().max().item(), gmax)
+            continue
+        cos = _cos(g, w)
+        worst = min(worst, (cos, name))
+        assert cos >= cos_bar, (label, name, cos)
+        ratio = g.norm().item() / w.norm().item()
+        assert abs(ratio - 1) < norm_bar, (label, name, ratio)
+        checked += 1
+    print(f"[measured {label}] {checked} parameter gradients vs oracle: worst cosine {worst[0]:.5f} ({worst[1]})")
+    return checked
+
+
+def test_stacked_ctc_full_size_against_oracle(dev):
+    from oracle import model as om
+    model, sd = _build(L2, dev)
+    eng = model.engine()
+    assert eng.stacked_ok()
+    cfg = SimpleNamespace(**L2)
+    datas = [_batch(21, [1203, 1100], 10000), _batch(22, [403, 367, 298], 10000), _batch(23, [650, 610, 500], 10000)]
+    n = len(datas)
+    # ---- the oracle, one micro-batch after the other (BatchNorm running statistics move in `sd` in order)
+    params = _oracle_params(sd)
+    want = []
+    for d in datas:
+        loss_ref, _, _ = om.asr_ctc_forward(sd, cfg, d["xs"], d["xlens"], d["ys"], d["ylens"], training=True)
+        (loss_ref / n).backward()
+        want.append(loss_ref.item())
+    # ---- the stacked HIP pass
+    eng.arena.grad.zero_()
+    batches = [(d["xs"].to(dev), [int(v) for v in d["xlens"]], d["ys"], [int(v) for v in d["ylens"]]) for d in datas]
+    losses = eng.ctc_train_stacked(batches, 0)
+    torch.cuda.synchronize()
+    got = losses.tolist()
+    rel = [abs(a - b) / abs(b) for a, b in zip(got, want)]
+    print(f"[measured stacked bf16 vs oracle] loss rel err {['%.2e' % r for r in rel]}")
+    assert max(rel) < 2e-3, (got, want)
+    checked = _compare_grads(eng, params, 0.995, 2e-2, "stacked bf16 L2")
+    assert checked > 400
+    for k, v in model.state_dict().items():
+        if "tracked" in k:
+            assert int(v) == int(sd[k]) == n, k
+        elif "running" in k:
+            err = (v.float().cpu() - sd[k]).abs().max().item() / (sd[k].abs().max().item() + 1e-12)
+            assert err < 2e-2, (k, err)   # bf16 activations under the statistics
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+TRACE_CFG = dict(input_layer="conv2d", feat_dim=40, num_framestacks=1, encoder_type="conformer", decoder_type="ctc",
+                 pos_encode_type="rel", enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=2,
+                 enc_intermediate_size=256, dropout_enc_rate=0.0, dropout_attn_rate=0.0, dropout_dec_rate=0.0, vocab_size=40,
+                 blank_id=0, eos_id=2, kd_weight=0, lsm_prob=0.1,
+                 lr_schedule_type="noam", learning_rate=0.02, num_warmup_steps=4, accum_grad=2, clip_grad_norm=5.0,
+                 weight_decay=1e-6, log_step=100)
+
+
+def test_reference_trace_d256_stacked_bf16(dev):
+    from emoasr_amd.modeling.asr import ASR
+    from emoasr_amd.optimizers import Adam, ScheduledOptimizer
+    from emoasr_amd.train import stacked_ok, train_group
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_trace_d256.npz"))
+    t = {k: torch.from_numpy(z[k]) for k in z.files}
+    params = SimpleNamespace(**TRACE_CFG)
+    model = ASR(params, compute_dtype=torch.bfloat16)
+    sd0 = synthetic_state({k: v.shape for k, v in model.state_dict().items()})
+    model.load_state_dict(sd0)
+    for k in [k for k in t if k.startswith("init/")]:   # the rule reproduced the generator's state
+        assert torch.equal(sd0[k[5:]], t[k]), k
+    optimizer = ScheduledOptimizer(Adam(model.parameters(), lr=0, weight_decay=params.weight_decay), params)
+    model.to(dev).train()
+    assert stacked_ok(model, optimizer, params) == "ctc"
+    optimizer.update_epoch()
+    data = lambda i: {k: t[f"batch{i}/{k}"] for k in ("xs", "xlens", "ys", "ylens", "ys_in", "ys_out")}
+    losses, lrs = [], []
+    for step in range(12):
+        dicts = train_group(model, optimizer, [data((2 * step) % 3), data((2 * step + 1) % 3)], params, dev)
+        losses += [d["loss_total"] for d in dicts]
+        lrs.append(optimizer._lr)
+    assert np.allclose(lrs, t["lrs"].numpy(), rtol=1e-12, atol=0)
+    rel = np.abs(np.array(losses) - t["losses"].numpy()) / t["losses"].numpy()
+    print(f"[measured] bf16 stacked replay of the reference trace: loss rel err max {rel.max():.2e}, last {rel[-1]:.2e}")
+    assert rel.max() < 1e-2, rel
+    sd = model.state_dict()
+    for k in [k for k in t if k.startswith("end/")]:
+        want, got, init = t[k], sd[k[4:]].cpu(), sd0[k[4:]]
+        if not want.dtype.is_floating_point:
+            assert torch.equal(got, want), k
+        elif "running" in k:
+            err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+            assert err < 2e-2, (k, err)
+        else:
+            # twelve Adam updates: compare the update VECTORS (the first updates are sign-like, so noise-level gradient
+            # elements may move either way: cosine, not element-wise maxima)
+            cos = _cos(got - init, want - init)
+            reln = ((got - want).norm() / (want - init).norm()).item()
+            print(f"[measured] {k}: update cosine {cos:.4f}, distance / update norm {reln:.3f}")
+            assert cos > 0.97 and reln < 0.3, (k, cos, reln)
+    assert optimizer.state_dict()["_step"] == int(t["optim/_step"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+SMALL = dict(input_layer="conv2d", feat_dim=80, num_framestacks=1, encoder_type="conformer", pos_encode_type="rel",
+             enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=3, enc_intermediate_size=512,
+             dropout_enc_rate=0.0, dropout_attn_rate=0.0, vocab_size=96, blank_id=0, eos_id=2, kd_weight=0)
+DEC_CFGS = {
+    "rnnt": dict(decoder_type="rnn_transducer", embedding_size=64, dec_hidden_size=128, dec_num_layers=2,
+                 joint_hidden_size=128, dropout_emb_rate=0.0, dropout_dec_rate=0.0, mtl_ctc_weight=0.3, lsm_prob=0.0),
+    "attention": dict(decoder_type="transformer", dec_hidden_size=256, dec_num_attention_heads=4, dec_num_layers=2,
+                      dec_intermediate_size=512, dropout_dec_rate=0.0, mtl_ctc_weight=0.3, lsm_prob=0.1,
+                      loss_normalize_length=False, loss_normalize_batch=True, max_decode_ylen=20),
+}
+
+
+@pytest.mark.parametrize("kind", ["rnnt", "attention"])
+def test_stacked_encoder_under_other_decoders_against_oracle(dev, kind):
+    from emoasr_amd.modeling.functions import encoder_apply_stacked
+    from oracle import decoder as od, model as om, rnnt as orn
+    cfgd = dict(SMALL, **DEC_CFGS[kind])
+    model, sd = _build(cfgd, dev, head_gain=1.0)
+    eng = model.engine()
+    assert eng.encoder_stacked_ok() and not eng.stacked_ok()
+    cfg = SimpleNamespace(**cfgd)
+    datas = [_batch(31, [203, 187, 150, 96], 96, 40), _batch(32, [403, 380], 96, 40), _batch(33, [303, 290, 221], 96, 40)]
+    n = len(datas)
+    params = _oracle_params(sd)
+    want = []
+    for d in datas:
+        eouts, elens = om.encoder_forward(sd, cfg, d["xs"], d["xlens"], training=True)
+        if kind == "rnnt":
+            loss_ref, ld_ref, _ = orn.rnnt_decoder_forward(sd, cfg, eouts, elens, d["ys"], d["ylens"], d["ys_in"])
+        else:
+            loss_ref, ld_ref, _ = od.decoder_forward(sd, cfg, eouts, elens, d["ys"], d["ylens"], d["ys_in"], d["ys_out"])
+        (loss_ref / n).backward()
+        want.append({k: float(v) for k, v in ld_ref.items()})
+    eng.arena.grad.zero_()
+    outs = encoder_apply_stacked(model.encoder, [d["xs"].to(dev) for d in datas], [d["xlens"] for d in datas])
+    total, got = None, []
+    for (eouts, elens, _), d in zip(outs, datas):
+        loss, ld, _ = model.decoder(eouts, elens, None, d["ys"], d["ylens"], d["ys_in"], d["ys_out"], None, None, None)
+        total = loss / n if total is None else total + loss / n
+        got.append({k: float(v) for k, v in ld.items()})
+    total.backward()
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        for k in b:
+            assert abs(a[k] - b[k]) < 2e-2 * abs(b[k]) + 1e-4, (k, a, b)
+    _compare_grads(eng, params, 0.97, 6e-2, f"stacked encoder + {kind}")

@@ -116,3 +116,26 @@ DISTILL_CASES = {"distill": dict(soft_label_weight=0.3, lsm_prob=0.1),
 def load_kd_golden():
     z = np.load(os.path.join(GOLDEN, "kd_tiny.npz"))
     return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def synthetic_state(shapes, seed=1234):
+    """the deterministic initial state make_golden.py gave the reference model (CPU generator, keys in sorted order): the
+    fixture holds no weights, both sides build them with this rule"""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros(shp, dtype=torch.int64)
+        elif k.endswith("running_mean"):
+            sd[k] = torch.zeros(shp)
+        elif k.endswith("running_var"):
+            sd[k] = torch.ones(shp)
+        elif ("norm" in k and k.endswith("weight")):
+            sd[k] = 1.0 + 0.05 * torch.randn(shp, generator=g)
+        elif len(shp) >= 2:
+            fan_in = int(np.prod(shp[1:]))
+            sd[k] = torch.randn(shp, generator=g) / fan_in ** 0.5
+        else:
+            sd[k] = 0.02 * torch.randn(shp, generator=g)
+    return sd
