@@ -1909,6 +1909,480 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t
   }
 }
 
+// ====================================================================================
+// backward, two passes (round 4; bf16) -- the default.  The single-pass kernel above has ONE stationary side (the keys), so the
+// other side's gradient (dQ) leaves it as per-key-block f32 partial slabs that a finalize launch sums, P and dS cross LDS as
+// transposed images, and its 98 KB of LDS / 232 registers allow one workgroup per CU: one wave per SIMD, nothing hides anything.
+// Here every score tile is recomputed TWICE (the matrix pipe sat at 6 %: the flops are free), each time in the orientation
+// whose accumulator is directly the next product's operand:
+//   attn_bwd_kv_kernel  key-stationary, S[query][key] with the KEY on the lane: P and dS chain straight into dV^T += dO^T P and
+//                       dK^T += (Q+u)^T dS (sums over the query index, which sits in the accumulator registers); per-key column
+//                       sums of dS are one add per element (dbias_u).  No image, no dQ.
+//   attn_bwd_q_kernel   query-stationary, S^T[key][query] with the QUERY on the lane: dS^T chains into dQ^T += K^T dS^T, the band
+//                       part through the un-skewed dG image (as before); dQ is complete in ONE workgroup and is stored once, in the
+//                       compute dtype: no partial slabs, no finalize pass, bit-reproducible.  Writes the dS image the position-table
+//                       gradient (attn_bwd_dpos2_kernel) walks.
+// Both: 4 waves per workgroup, the per-step operand tiles staged once per workgroup (registers one step ahead -> LDS), 65-70 KB
+// of LDS and <= 256 registers: TWO workgroups per CU, two waves per SIMD -- one wave's soft-max / dropout VALU work runs under
+// the other's MFMAs and LDS round trips.
+// Why the dS image stays (review item "no dS image"): dpos[r] = sum_{b,i} dS_b[i, i-(T-1)+r] (Q+v)_b[i] sums over the utterances
+// of a segment; a workgroup that holds a (b, h) tile can only add its [T+32 .. 2T][64] f32 partial with atomics -- 110-440 MB of
+// float atomics per layer launch at the chip's 1.3 TB/s atomic rate, against 110 MB written + read at stream rate for the bf16
+// image -- or a third recomputation sweep that is table-row-stationary (only half of each recomputed tile lies on its band).
+// ====================================================================================
+template <typename T, int FW> struct SplitCfg {
+  static constexpr int LD = AttnCfg<T>::LD;
+  static constexpr int BAND_ROWS = 32 * FW + 32;
+  static constexpr int LDG = 72;                     // dG image row stride ([32 queries][64 band columns] + padding)
+  static constexpr int GS_BYTES = 64 * 32 * 4;       // per wave: the f32 skew tile (the Q pass's dG image reuses it)
+  static constexpr int ROWC_BYTES = 64 * 4;          // KV pass: lse * log2(e) and delta of the step's 32 queries
+  static constexpr int kv_rows(bool rel) { return rel ? 96 : 64; }               // Q+u, Q+v, dO | Q, dO (the band comes from L2)
+  static constexpr int q_rows(bool rel) { return rel ? 64 + BAND_ROWS : 64; }    // K, V, band | K, V
+  static constexpr int kv_stage_bytes(bool rel) { return kv_rows(rel) * LD * (int)sizeof(T) + ROWC_BYTES; }
+  static constexpr int q_stage_bytes(bool rel) { return q_rows(rel) * LD * (int)sizeof(T); }
+  static constexpr int wave_bytes(bool rel) { return rel ? GS_BYTES : 256; }
+  static constexpr int kv_smem(bool rel) { return kv_stage_bytes(rel) + FW * wave_bytes(rel); }
+  static constexpr int q_smem(bool rel) { return q_stage_bytes(rel) + FW * wave_bytes(rel); }
+};
+
+template <typename T, bool TR, bool REL, int FW>
+__global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int nt) {
+  using M_ = Mma<T>;
+  using C_ = SplitCfg<T, FW>;
+  constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = C_::LD;
+  constexpr int VEC = 16 / sizeof(T), PER_ROW = DK / VEC;
+  constexpr int NTHR = 64 * FW;
+  constexpr int NROWS = C_::kv_rows(REL), NPIECE = NROWS * PER_ROW, PPT = NPIECE / NTHR;
+  static_assert(NPIECE % NTHR == 0, "staging pieces must divide evenly");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, hh = lane >> 5;
+  emoasr_attn_t a = a_in;
+  FusedWs ws = ws_in;
+  const Blk3 blk = attn_block(nt, a_in.H, a_in.B);
+  if (!blk.ok) return;
+  int b = blk.z;
+  if (a_in.nseg > 1) {
+    const SegRef g = seg_of_slot(a_in, blk.z, b);
+    seg_apply<T>(a, g);
+    ws.qu = (const T*)ws.qu + g.row * ws.ldqu;
+    ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
+  }
+  const int jblk = blk.x * (32 * FW), h = blk.y;
+  if (jblk >= a.Tk) return;
+  const HeadPtrs hp = head_ptrs<T>(a, b, h);
+  const int j0 = jblk + 32 * wave;
+  if (jblk >= hp.klen) {  // every key of this block is masked: its dK / dV rows are zero
+    f32x16 z[2];
+    zero16(z[0]); zero16(z[1]);
+    store_dT<T>((T*)hp.dk, a.ldk, j0, a.Tk, z, 1.f, lane);
+    store_dT<T>((T*)hp.dv, a.ldv, j0, a.Tk, z, 1.f, lane);
+    return;
+  }
+  const bool live = j0 < hp.klen;  // a dead wave still stages and joins the barriers
+
+  T* stage0 = reinterpret_cast<T*>(smem);
+  float* rowc = reinterpret_cast<float*>(smem + NROWS * LD * (int)sizeof(T));   // [0,32) lse * log2 e (+inf: no contribution), [32,64) delta
+  float* Gs = reinterpret_cast<float*>(smem + C_::kv_stage_bytes(REL) + wave * C_::wave_bytes(REL));  // [32 queries][64 band columns]
+
+  const long ho = (long)h * DK;
+  const T* qu_base = (const T*)ws.qu + (long)b * a.Tq * ws.ldqu + ho;
+  const T* qv_base = REL ? (const T*)ws.qv + (long)b * a.Tq * ws.ldqu + ho : qu_base;
+  const __amdgpu_buffer_rsrc_t rsQu = make_rsrc(qu_base), rsQv = make_rsrc(qv_base), rsDo = make_rsrc(hp.dout);
+  const int nstep = (a.Tq + 31) / 32;
+
+  // ---- one-step-ahead operand fetch (whole block), as in the single-pass kernel ------------------------------
+  constexpr int RPP = NTHR / PER_ROW;
+  static_assert(32 % RPP == 0, "a piece index must stay inside one 32-row operand tile");
+  Vec16<T> pre[PPT];
+  float pre_lse = 0.f, pre_del = 0.f;
+  bool pre_ok = false;
+  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(hp.lse), rsD = make_rsrc(hp.delta);
+  auto fetch = [&](const int step) {
+    const int i0 = step * 32;
+    const bool on = step < nstep;
+    const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
+    if (wave == 0) {
+      pre_ok = on && i0 + il < a.Tq;
+      const unsigned o = pre_ok ? (unsigned)((i0 + il) * 4) : EMO_OOB;
+      pre_lse = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsL, o, 0, 0));
+      pre_del = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, o, 0, 0));
+    }
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int srow = p * RPP;
+      const int mat = srow / 32, i = i0 + srow % 32 + trow;
+      const bool ok = on && i < a.Tq;
+      if (mat == 0) pre[p] = buf_load16<T>(rsQu, ok ? (unsigned)(((long)i * ws.ldqu + piece) * sizeof(T)) : EMO_OOB);
+      else if (REL && mat == 1) pre[p] = buf_load16<T>(rsQv, ok ? (unsigned)(((long)i * ws.ldqu + piece) * sizeof(T)) : EMO_OOB);
+      else pre[p] = buf_load16<T>(rsDo, ok ? (unsigned)(((long)i * a.ldo + piece) * sizeof(T)) : EMO_OOB);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int pid = tid + NTHR * p;
+      store16(stage0 + (pid / PER_ROW) * LD + (pid % PER_ROW) * VEC, pre[p]);
+    }
+    if (wave == 0 && hh == 0) {
+      // p = exp2(c_exp * s - lse * log2 e): padding queries and rows without a valid key (lse = -inf) get +inf -> p = 0
+      rowc[il] = (pre_ok && pre_lse != -INFINITY) ? pre_lse * 1.4426950408889634f : INFINITY;
+      rowc[32 + il] = pre_del;
+    }
+  };
+
+  // ---- stationary operands of this wave's key tile: K and V fragments (B operands: key on the lane) ----------
+  const int kj = j0 + il;
+  typename M_::Frag kfB[NK], vfB[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    kfB[kk] = frag_global<T>((const T*)hp.k, a.ldk, kj, live && kj < a.Tk, kk, lane, nullptr);
+    vfB[kk] = frag_global<T>((const T*)hp.v, a.ldv, kj, live && kj < a.Tk, kk, lane, nullptr);
+  }
+  f32x16 dk[2], dv[2];
+  zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+  float csum = 0.f;  // sum over this lane's queries of dS[:, key kj]
+  fetch(0);
+  stash();
+  fetch(1);
+  __syncthreads();
+  const bool kvalid = kj < hp.klen;
+  const float c_exp = a.scale * 1.4426950408889634f;
+  const float keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  const uint32_t thr = dropout_thr(a.drop_p);
+  const uint64_t drop_stride2 = (uint64_t)((a.Tk + 1) & ~1) >> 1;   // pairs per mask row
+
+  for (int step = 0; step < nstep; ++step) {
+    const int i0 = step * 32;
+    const T* Qus = stage0;
+    const T* Qvs = stage0 + 32 * LD;
+    const T* dOs = stage0 + (REL ? 64 : 32) * LD;
+    if (live) {
+      // this wave's 64 band rows of the projected position table (r = Tq - 32 - i0 + j0 + c): k-contiguous B operands straight
+      // from global memory (L2: the table of a segment is shared by all its workgroups), requested first and used last --
+      // staging them like the query-side tiles would cost 20 more prefetch registers per thread and 23 KB of LDS
+      typename M_::Frag fb[2][NK];
+      if constexpr (REL) {
+        const int rbase = a.Tq - 32 - i0 + j0;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const int prow = rbase + 32 * ct + il;
+#pragma unroll
+          for (int kk = 0; kk < NK; ++kk)
+            fb[ct][kk] = frag_global<T>((const T*)hp.pos, a.ldp, prow, prow >= 0 && prow < 2 * a.Tq - 1, kk, lane, nullptr);
+        }
+      }
+      f32x16 s, dp;
+      zero16(s); zero16(dp);
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        s = M_::mma(M_::load_kc(Qus, LD, 0, kk * M_::KSTEP, lane), kfB[kk], s);
+        dp = M_::mma(M_::load_kc(dOs, LD, 0, kk * M_::KSTEP, lane), vfB[kk], dp);
+      }
+      if constexpr (REL) {
+        // band product G[query][band column c] = (Q+v) band^T, two 32-column tiles; element (i_l, j_l) of the score tile is
+        // G[i_l][31 - i_l + j_l]: a lane rotation per accumulator row, through the wave's f32 tile
+        f32x16 g0, g1;
+        zero16(g0); zero16(g1);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          const typename M_::Frag fv = M_::load_kc(Qvs, LD, 0, kk * M_::KSTEP, lane);
+          g0 = M_::mma(fv, fb[0][kk], g0);
+          g1 = M_::mma(fv, fb[1][kk], g1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          Gs[c_row(r, lane) * 64 + il] = g0[r];
+          Gs[c_row(r, lane) * 64 + 32 + il] = g1[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += Gs[c_row(r, lane) * 64 + 31 - c_row(r, lane) + il];
+        __builtin_amdgcn_wave_barrier();
+      }
+      // soft-max, dropout, dS: accumulator rows 4 g .. 4 g + 3 are queries i0 + 8 g + 4 hh + 0 .. 3
+      typename M_::Frag pf[NS], df[NS];   // P and dS as the next products' B operands (accumulator rows 8 ks .. 8 ks + 7, chain_b's order)
+      const uint64_t pair0 = (drop_index(a, b, h, i0 + 4 * hh, 0) >> 1) + (uint64_t)(kj >> 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(rowc + 8 * g + 4 * hh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(rowc + 32 + 8 * g + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float p = __builtin_amdgcn_exp2f(s[r] * c_exp - l4[e]);
+          p = kvalid ? p : 0.f;
+          // the mask is hashed in pairs of keys (common.h: dropout_keep2); neighbouring keys are neighbouring LANES here.  Hashed
+          // unconditionally (drop_p = 0: threshold 0, every element kept, keep = 1): a branch per element would cut the step into
+          // basic blocks the scheduler cannot interleave with the MFMAs
+          const uint32_t x = dropout_hash(a.seed, pair0 + (uint64_t)(8 * g + e) * drop_stride2);
+          const uint32_t u = (kj & 1) ? dropout_second(x) : x;
+          const float m = (u & 0xFFFFFFu) >= thr ? keep : 0.f;
+          const float dsv = p * (dp[r] * m - d4[e]) * a.scale;
+          csum += dsv;
+          pf[g >> 1][4 * (g & 1) + e] = (bf16)(p * m);
+          df[g >> 1][4 * (g & 1) + e] = (bf16)dsv;
+        }
+      }
+      // dV^T += dO^T P,  dK^T += (Q+u)^T dS: the accumulators are the B operands (query index in the registers)
+      __builtin_amdgcn_sched_barrier(0);   // (the eight transposed operand reads hoisted above the soft-max cost 32 registers: spills)
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = M_::mma(chain_a<T, TR>(dOs, ks, 32 * dt, lane), pf[ks], dv[dt]);
+          dk[dt] = M_::mma(chain_a<T, TR>(Qus, ks, 32 * dt, lane), df[ks], dk[dt]);
+        }
+      }
+    }
+    lds_barrier();   // every wave has read the stage
+    stash();         // tiles of step + 1 (fetched during the previous step)
+    fetch(step + 2);
+    lds_barrier();   // stage ready
+  }
+  store_dT<T>((T*)hp.dk, a.ldk, j0, a.Tk, dk, 1.f, lane);  // (a dead wave stores zeros)
+  store_dT<T>((T*)hp.dv, a.ldv, j0, a.Tk, dv, 1.f, lane);
+  if (REL && a.dbias_u && live) {
+    // dbias_u[d] += sum_j colsum_j K[j][d];  dbias_v[d] -= that (attn_bwd_q_kernel adds colsum(dQ): dbias_v = colsum(dQ) - dbias_u)
+    csum += __shfl_xor(csum, 32, 64);
+    float* cs = Gs;
+    if (hh == 0) cs[il] = csum;
+    __builtin_amdgcn_wave_barrier();
+    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+      const int kr = j0 + j;
+      acc += cs[j] * buf_load_f32<T>(rsK, kr < a.Tk ? (unsigned)(((long)kr * a.ldk + lane) * sizeof(T)) : EMO_OOB);
+    }
+    atomicAdd(&a.dbias_u[h * DK + lane], acc);
+    atomicAdd(&a.dbias_v[h * DK + lane], -acc);
+  }
+}
+
+template <typename T, bool TR, bool REL, int FW>
+__global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int nt) {
+  using M_ = Mma<T>;
+  using C_ = SplitCfg<T, FW>;
+  constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = C_::LD, LDG = C_::LDG;
+  constexpr int VEC = 16 / sizeof(T), PER_ROW = DK / VEC;
+  constexpr int NTHR = 64 * FW;
+  constexpr int NROWS = C_::q_rows(REL), NPIECE = NROWS * PER_ROW, PPT = NPIECE / NTHR;
+  static_assert(NPIECE % NTHR == 0, "staging pieces must divide evenly");
+  static_assert(sizeof(T) == 2, "the two-pass backward is bf16 only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, hh = lane >> 5;
+  emoasr_attn_t a = a_in;
+  FusedWs ws = ws_in;
+  const Blk3 blk = attn_block(nt, a_in.H, a_in.B);
+  if (!blk.ok) return;
+  int b = blk.z;
+  if (a_in.nseg > 1) {
+    const SegRef g = seg_of_slot(a_in, blk.z, b);
+    seg_apply<T>(a, g);
+    ws.qu = (const T*)ws.qu + g.row * ws.ldqu;
+    ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
+    if (ws.dsq) ws.dsq = (T*)ws.dsq + g.row * a.H * ws.ldds;
+  }
+  const int iblk = blk.x * (32 * FW), h = blk.y;
+  if (iblk >= a.Tq) return;   // (a shorter segment of a stacked launch: the grid follows the longest)
+  const HeadPtrs hp = head_ptrs<T>(a, b, h);
+  const int i0 = iblk + 32 * wave;
+  const bool live = i0 < a.Tq;   // a dead wave still stages and joins the barriers
+  const int qi = i0 + il;
+  const bool qval = qi < a.Tq;
+
+  T* stage0 = reinterpret_cast<T*>(smem);
+  char* mine = smem + C_::q_stage_bytes(REL) + wave * C_::wave_bytes(REL);
+  float* Gs = reinterpret_cast<float*>(mine);   // [64 band rows][32 queries] f32 ...
+  T* img_g = reinterpret_cast<T*>(mine);        // ... then dG[query][band column] ([32][LDG]), read back k-contiguous
+
+  const long ho = (long)h * DK;
+  const T* qu_base = (const T*)ws.qu + (long)b * a.Tq * ws.ldqu + ho;
+  const T* qv_base = REL ? (const T*)ws.qv + (long)b * a.Tq * ws.ldqu + ho : qu_base;
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k), rsV = make_rsrc(hp.v), rsP = make_rsrc(REL ? hp.pos : hp.k);
+  const int nstep = (hp.klen + 31) / 32;   // key tiles with at least one valid key
+
+  constexpr int RPP = NTHR / PER_ROW;
+  static_assert(32 % RPP == 0, "a piece index must stay inside one 32-row operand tile");
+  Vec16<T> pre[PPT];
+  auto fetch = [&](const int step) {
+    const int j0 = step * 32;
+    const bool on = step < nstep;
+    const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int srow = p * RPP;
+      if (srow < 64) {
+        const int j = j0 + srow % 32 + trow;
+        const bool ok = on && j < a.Tk;
+        if (srow < 32) pre[p] = buf_load16<T>(rsK, ok ? (unsigned)(((long)j * a.ldk + piece) * sizeof(T)) : EMO_OOB);
+        else pre[p] = buf_load16<T>(rsV, ok ? (unsigned)(((long)j * a.ldv + piece) * sizeof(T)) : EMO_OOB);
+      } else {
+        // band rows of the block's 32 FW queries against this key tile: r = Tq - 32 FW - iblk + j0 + t, t in [0, 32 FW + 32)
+        const int r = a.Tq - 32 * FW - iblk + j0 + (srow - 64) + trow;
+        const bool ok = on && r >= 0 && r < 2 * a.Tq - 1;
+        pre[p] = buf_load16<T>(rsP, ok ? (unsigned)(((long)r * a.ldp + piece) * sizeof(T)) : EMO_OOB);
+      }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int pid = tid + NTHR * p;
+      store16(stage0 + (pid / PER_ROW) * LD + (pid % PER_ROW) * VEC, pre[p]);
+    }
+  };
+
+  // ---- stationary operands of this wave's query tile (B operands: query on the lane) ---------------------------
+  typename M_::Frag fqu[NK], fqv[NK], fdo[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    fqu[kk] = frag_global<T>(qu_base, ws.ldqu, qi, live && qval, kk, lane, nullptr);
+    if constexpr (REL) fqv[kk] = frag_global<T>(qv_base, ws.ldqu, qi, live && qval, kk, lane, nullptr);
+    fdo[kk] = frag_global<T>((const T*)hp.dout, a.ldo, qi, live && qval, kk, lane, nullptr);
+  }
+  float lse2 = INFINITY, del_q = 0.f;
+  if (live && qval) {
+    const float l = hp.lse[qi];
+    lse2 = l != -INFINITY ? l * 1.4426950408889634f : INFINITY;
+    del_q = hp.delta[qi];
+  }
+  f32x16 dq[2];
+  zero16(dq[0]); zero16(dq[1]);
+  fetch(0);
+  stash();
+  fetch(1);
+  __syncthreads();
+  const float c_exp = a.scale * 1.4426950408889634f;
+  const uint64_t drop_base = drop_index(a, b, h, qi, 0);
+  const float keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  const uint32_t thr = dropout_thr(a.drop_p);
+
+  for (int step = 0; step < nstep; ++step) {
+    const int j0 = step * 32;
+    const T* Ks = stage0;
+    const T* Vs = stage0 + 32 * LD;
+    const T* Bs = stage0 + (64 + 32 * (FW - 1 - wave)) * LD;  // this wave's 64 band rows (REL)
+    if (live) {
+      f32x16 s, dp;
+      zero16(s); zero16(dp);
+      if constexpr (REL) {
+        f32x16 g0, g1;
+        zero16(g0); zero16(g1);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          g0 = M_::mma(M_::load_kc(Bs, LD, 0, kk * M_::KSTEP, lane), fqv[kk], g0);   // g[c][i]
+          g1 = M_::mma(M_::load_kc(Bs + 32 * LD, LD, 0, kk * M_::KSTEP, lane), fqv[kk], g1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          Gs[c_row(r, lane) * 32 + il] = g0[r];
+          Gs[(32 + c_row(r, lane)) * 32 + il] = g1[r];
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        s = M_::mma(M_::load_kc(Ks, LD, 0, kk * M_::KSTEP, lane), fqu[kk], s);
+        dp = M_::mma(M_::load_kc(Vs, LD, 0, kk * M_::KSTEP, lane), fdo[kk], dp);
+      }
+      if constexpr (REL) {
+        __builtin_amdgcn_wave_barrier();
+        // element (key jl, query il) sits in band column c = 31 - il + jl
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += Gs[(31 - il + c_row(r, lane)) * 32 + il];
+        __builtin_amdgcn_wave_barrier();
+      }
+      // soft-max, dropout, dS -- packed straight into the B operand of the dQ product (accumulator rows 8 ks .. 8 ks + 7, chain_b's
+      // order); accumulator rows 4 g .. 4 g + 3 are keys j0 + 8 g + 4 hh + 0 .. 3: two hash pairs (drop_base, j0 even)
+      typename M_::Frag df[NS];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // (hashed unconditionally -- drop_p = 0: threshold 0, keep = 1 -- so that the step stays one basic block)
+        float m[4];
+        {
+          const uint64_t pr = (drop_base + (uint64_t)(j0 + 8 * g + 4 * hh)) >> 1;
+          bool k0, k1, k2, k3;
+          dropout_keep2(a.seed, pr, thr, k0, k1);
+          dropout_keep2(a.seed, pr + 1, thr, k2, k3);
+          m[0] = k0 ? keep : 0.f; m[1] = k1 ? keep : 0.f; m[2] = k2 ? keep : 0.f; m[3] = k3 ? keep : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float p = __builtin_amdgcn_exp2f(s[r] * c_exp - lse2);
+          p = (j0 + c_row(r, lane) >= hp.klen) ? 0.f : p;
+          const bf16 dsv = (bf16)(p * (dp[r] * m[e] - del_q) * a.scale);
+          df[g >> 1][4 * (g & 1) + e] = dsv;
+          if constexpr (REL) {
+            // dG[query il][band column c = key - il + 31]; the image shares its LDS with the f32 skew tile, so the column no key
+            // of this tile maps to ((c + 32) mod 64: the two sets partition the row) is cleared alongside
+            const int c = c_row(r, lane) + 31 - il;
+            img_g[il * LDG + c] = dsv;
+            img_g[il * LDG + ((c + 32) & 63)] = (bf16)0.f;
+          }
+        }
+      }
+      if constexpr (REL) {
+        // dS for the position-table gradient: query-major rows, 4 consecutive keys (8 bytes) per store
+        if (qval) {
+          T* drow = (T*)ws.dsq + (((long)b * a.H + h) * a.Tq + qi) * ws.ldds + j0 + 4 * hh;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            bf16x4 v4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = df[g4 >> 1][4 * (g4 & 1) + e];
+            *reinterpret_cast<bf16x4*>(drow + 8 * g4) = v4;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      // dQ^T += K^T dS^T (the accumulator is the B operand: key index in the registers) + band^T unskew(dS^T)
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = M_::mma(chain_a<T, TR>(Ks, ks, 32 * dt, lane), df[ks], dq[dt]);
+      }
+      if constexpr (REL) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int ks = 0; ks < NS; ++ks) {
+            const typename M_::Frag dg = M_::load_kc(img_g, LDG, 0, 32 * ct + ks * M_::KSTEP, lane);  // dG^T[c][i], c contiguous
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+              dq[dt] = M_::mma(M_::template load_km<TR>(Bs + 32 * ct * LD, LD, ks * M_::KSTEP, 32 * dt, lane), dg, dq[dt]);
+          }
+        __builtin_amdgcn_wave_barrier();   // the image has been read: the region takes the next step's skew tile
+      }
+    }
+    lds_barrier();   // every wave has read the stage
+    stash();
+    fetch(step + 2);
+    lds_barrier();   // stage ready
+  }
+  if (live) store_dT<T>((T*)hp.dq, a.ldq, i0, a.Tq, dq, 1.f, lane);
+  if (REL && a.dbias_v && live) {
+    // dbias_v[d] += colsum(dQ)[d] (attn_bwd_kv_kernel subtracts dbias_u): sum over the queries = the 32 lanes of a half wave
+    float* cs = Gs;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = dq[dt][r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (il == 0) cs[32 * dt + c_row(r, lane)] = v;
+      }
+    __builtin_amdgcn_wave_barrier();
+    atomicAdd(&a.dbias_v[h * DK + lane], cs[lane]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, const long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = from_f32<T>(src[i]);
+}
+
 // dq (T, strided) = sum over the utterance's live key blocks of their dQ partials, in block order (bit-reproducible).
 // Block = 16 rows x ncol columns; the slab loads of a row are issued together (out-of-range blocks: no traffic).
 struct FinSegs { int n; int b0[EMOASR_MAX_SEGMENTS + 1], T[EMOASR_MAX_SEGMENTS]; long row[EMOASR_MAX_SEGMENTS + 1]; };
@@ -1968,6 +2442,7 @@ int set_smem(K kernel, int bytes) {
 }
 
 int g_tr = 1;
+int g_bwd_split = 1;  // option "attn_bwd_split": the two-pass backward (attn_bwd_kv_kernel + attn_bwd_q_kernel); 0 = the single-pass kernel
 int g_fused_fw = 0;  // key tiles per workgroup of the single-pass backward (0 = by grid size; emoasr_set_option "attn_fw")
 
 int g_fwd_split = 1;  // option "attn_fwd_split": key split for small launches
@@ -2216,6 +2691,43 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
   }
   const long nb4 = (long)cdiv(a.Tk, 128) * a.H * a.B, nb2 = (long)cdiv(a.Tk, 64) * a.H * a.B;
   const int fw = g_fused_fw ? g_fused_fw : ((nb4 > n_cu && nb2 <= 2 * n_cu) ? 2 : 4);
+  if (g_bwd_split) {
+    // two passes, two workgroups per CU each (see attn_bwd_kv_kernel); no dQ partial slabs, no finalize launch
+    constexpr int FW = 4;
+    using SC = SplitCfg<T, FW>;
+    dim3 gk(cdiv(a.Tk, 32 * FW), a.H, a.B), gq(cdiv(a.Tq, 32 * FW), a.H, a.B);
+    const int ntk = (g_attn_xcd && a.nseg > 1) ? (int)gk.x : 0, ntq = (g_attn_xcd && a.nseg > 1) ? (int)gq.x : 0;
+    if (ntk) gk = dim3(8 * cdiv(a.H * a.B, 8) * ntk, 1, 1);
+    if (ntq) gq = dim3(8 * cdiv(a.H * a.B, 8) * ntq, 1, 1);
+    emo_timer_begin(EMO_TIMER_ATTN_BWD_MAIN, s);
+#define EMO_SPLIT_LAUNCH(TR_, REL_)                                                                                 \
+  do {                                                                                                              \
+    if (set_smem(attn_bwd_kv_kernel<T, TR_, REL_, FW>, SC::kv_smem(REL_))) return 1;                                \
+    if (set_smem(attn_bwd_q_kernel<T, TR_, REL_, FW>, SC::q_smem(REL_))) return 1;                                  \
+    attn_bwd_kv_kernel<T, TR_, REL_, FW><<<gk, 64 * FW, SC::kv_smem(REL_), s>>>(a, ws, ntk);                        \
+    attn_bwd_q_kernel<T, TR_, REL_, FW><<<gq, 64 * FW, SC::q_smem(REL_), s>>>(a, ws, ntq);                          \
+  } while (0)
+    if (rel) { if (g_tr) EMO_SPLIT_LAUNCH(true, true); else EMO_SPLIT_LAUNCH(false, true); }
+    else     { if (g_tr) EMO_SPLIT_LAUNCH(true, false); else EMO_SPLIT_LAUNCH(false, false); }
+#undef EMO_SPLIT_LAUNCH
+    emo_timer_end(EMO_TIMER_ATTN_BWD_MAIN, s);
+    if (rel && a.dpos) {
+      int bmin = a.B;
+      for (int k = 0; k < a.nseg && a.nseg > 1; ++k) bmin = std::min(bmin, a.seg_b0[k + 1] - a.seg_b0[k]);
+      const int nchunk = bmin < 8 ? bmin : 8;
+      dim3 g2(cdiv(2 * a.Tq - 1, 64), a.H, nchunk * (a.nseg > 1 ? a.nseg : 1));
+      const int nt2 = (g_attn_xcd && a.nseg > 1) ? (int)g2.x : 0;
+      if (nt2) g2 = dim3(8 * cdiv((int)(g2.y * g2.z), 8) * nt2, 1, 1);
+      emo_timer_begin(EMO_TIMER_ATTN_BWD_DPOS, s);
+      if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
+      else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
+      emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, s);
+    }
+    if (fx.cast_n > 0)   // the finished f32 position-table gradient in the compute dtype, for its weight-gradient product
+      attn_cast_kernel<T><<<(int)std::min<long>(cdiv(fx.cast_n, 256), 1024), 256, 0, s>>>(fx.cast_src, (T*)fx.cast_dst, fx.cast_n);
+    EMO_LAUNCH_CHECK();
+    return 0;
+  }
 #define EMO_FUSED_LAUNCH(REL_, FW_)                                                                \
   do {                                                                                             \
     const int smem = FusedCfg<T, FW_>::smem_bytes(REL_);                                           \
@@ -2293,6 +2805,7 @@ void emo_attn_set_lpt(int v) { g_attn_lpt = v; }
 void emo_attn_set_fwd_split(int v) { g_fwd_split = v; }
 void emo_attn_set_xcd(int v) { g_attn_xcd = v; }
 void emo_attn_set_fwd_waves(int v) { g_fwd_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
+void emo_attn_set_bwd_split(int v) { g_bwd_split = v ? 1 : 0; }
 void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }
 
 extern "C" int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream) {

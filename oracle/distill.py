@@ -272,6 +272,33 @@ def rnnt_decoder_forward_kd(sd, cfg, eouts, elens, ys, ylens, ys_in, soft_labels
     return loss, ld, logits
 
 
+def rnnt_alpha_beta(lp, lab, T, U, blank=0):
+    """transducer forward / backward variables of ONE utterance (rnnt_aligner.py:14-152): lp [T', U'+1, V] log-probabilities
+    (float64), lab the U labels -> alpha, beta [T, U+1]; alpha[0,0] = 0, beta[T-1,U] = the final blank.
+    tests/golden/rnnt_align_xcheck.npz holds what the reference's own recursion bodies gave (make_golden.py runs them in plain
+    Python); tests/test_oracle_rnnt.py compares."""
+    NEG = float("-inf")
+    alpha = torch.full((T, U + 1), NEG, dtype=torch.float64)
+    beta = torch.full((T, U + 1), NEG, dtype=torch.float64)
+    for t in range(T):
+        for u in range(U + 1):
+            if t == 0 and u == 0:
+                alpha[0, 0] = 0.0
+                continue
+            a = alpha[t - 1, u] + lp[t - 1, u, blank] if t > 0 else torch.tensor(NEG, dtype=torch.float64)
+            e = alpha[t, u - 1] + lp[t, u - 1, lab[u - 1]] if u > 0 else torch.tensor(NEG, dtype=torch.float64)
+            alpha[t, u] = torch.logaddexp(a, e)
+    for t in reversed(range(T)):
+        for u in reversed(range(U + 1)):
+            if t == T - 1 and u == U:
+                beta[t, u] = lp[t, u, blank]
+                continue
+            a = beta[t + 1, u] + lp[t, u, blank] if t < T - 1 else torch.tensor(NEG, dtype=torch.float64)
+            e = beta[t, u + 1] + lp[t, u, lab[u]] if u < U else torch.tensor(NEG, dtype=torch.float64)
+            beta[t, u] = torch.logaddexp(a, e)
+    return alpha, beta
+
+
 def rnnt_forced_align(log_probs, elens, ys, ylens, blank=0):
     """RNNTForcedAligner.__call__ (rnnt_aligner.py:158-198) -> int32 [B, maxU-1].
 
@@ -279,32 +306,15 @@ def rnnt_forced_align(log_probs, elens, ys, ylens, blank=0):
     = the final blank); the walk starts at (0,0) and, while t+1 < T and u < U, moves down in time when
     (alpha+beta)[t+1,u] > (alpha+beta)[t,u+1], else emits label u at frame t.  Labels not emitted before the
     last frame keep 0.  PARITY UNPINNED for the lattice part: the reference's Numba CUDA kernels cannot run
-    here (numba absent); the recursion is the standard one also used by oracle.rnnt.rnnt_nll."""
+    here (numba absent); the recursion is the standard one also used by oracle.rnnt.rnnt_nll.  Cross-check (not a pin: the
+    kernels' bodies executed as plain Python, one thread after the other): tests/golden/rnnt_align_xcheck.npz."""
     B, Tm, Um, _ = log_probs.shape
     out = torch.zeros(B, Um - 1, dtype=torch.int32)
     lp = log_probs.double()
     for b in range(B):
         T, U = int(elens[b]), int(ylens[b])
         lab = [int(v) for v in ys[b, :U]]
-        NEG = float("-inf")
-        alpha = torch.full((T, U + 1), NEG, dtype=torch.float64)
-        beta = torch.full((T, U + 1), NEG, dtype=torch.float64)
-        for t in range(T):
-            for u in range(U + 1):
-                if t == 0 and u == 0:
-                    alpha[0, 0] = 0.0
-                    continue
-                a = alpha[t - 1, u] + lp[b, t - 1, u, blank] if t > 0 else torch.tensor(NEG, dtype=torch.float64)
-                e = alpha[t, u - 1] + lp[b, t, u - 1, lab[u - 1]] if u > 0 else torch.tensor(NEG, dtype=torch.float64)
-                alpha[t, u] = torch.logaddexp(a, e)
-        for t in reversed(range(T)):
-            for u in reversed(range(U + 1)):
-                if t == T - 1 and u == U:
-                    beta[t, u] = lp[b, t, u, blank]
-                    continue
-                a = beta[t + 1, u] + lp[b, t, u, blank] if t < T - 1 else torch.tensor(NEG, dtype=torch.float64)
-                e = beta[t, u + 1] + lp[b, t, u, lab[u]] if u < U else torch.tensor(NEG, dtype=torch.float64)
-                beta[t, u] = torch.logaddexp(a, e)
+        alpha, beta = rnnt_alpha_beta(lp[b], lab, T, U, blank)
         post = alpha + beta
         t = u = 0
         while t + 1 < T and u < U:

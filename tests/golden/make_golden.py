@@ -719,6 +719,78 @@ def run_train_trace_d256():
           "lrs", [round(v, 6) for v in lrs[:5]], "gnorms", [round(v, 2) for v in gnorms[:4]])
 
 
+def run_rnnt_align_xcheck():
+    """CROSS-CHECK, not a pin: asr/modeling/decoders/rnnt_aligner.py:14-198 holds the only restatement of the transducer lattice
+    inside the reference (two Numba CUDA kernels + the alpha+beta walk); numba is absent and there is no GPU here.  The kernels'
+    Python bodies are executed as they stand, one (block, thread) after the other: `numba.cuda` is replaced by a shim whose
+    `jit` returns a launcher that sets blockIdx / threadIdx and calls the function -- threads u = 0..U in order for the forward
+    kernel, u = U..0 for the backward kernel, so that every spin-lock test (`cuda.atomic.add(lock, ., 0) < 0`) succeeds at its
+    first try (the shim raises if one would spin).  RNNTForcedAligner.__call__ then runs unchanged on CPU tensors.
+    -> rnnt_align_xcheck.npz: inputs, alpha, beta, log_p (both directions), best alignments."""
+    import importlib
+
+    class _Dim:
+        x = 0
+
+    class _Atomic:
+        spins = 0
+
+        @staticmethod
+        def add(arr, idx, val):
+            old = int(arr[idx])
+            if val == 0 and old >= 0:
+                _Atomic.spins += 1
+                if _Atomic.spins > 10000:
+                    raise RuntimeError("a thread would spin: the sequential order does not satisfy the lock protocol")
+            arr[idx] = old + val
+            return old
+
+    cuda = types.ModuleType("numba.cuda")
+    cuda.blockIdx, cuda.threadIdx, cuda.atomic = _Dim(), _Dim(), _Atomic
+
+    def jit(_sig):
+        def deco(fn):
+            class Launcher:
+                def __getitem__(self, cfg):
+                    nblk, nthr = cfg
+
+                    def launch(*args):
+                        order = range(nthr) if "forward" in fn.__name__ else reversed(range(nthr))
+                        order = list(order)
+                        for b in range(nblk):
+                            for u in order:
+                                cuda.blockIdx.x, cuda.threadIdx.x = b, u
+                                fn(*args)
+                    return launch
+            return Launcher()
+        return deco
+
+    cuda.jit = jit
+    numba = types.ModuleType("numba")
+    numba.cuda = cuda
+    sys.modules["numba"], sys.modules["numba.cuda"] = numba, cuda
+    ra = importlib.import_module("asr.modeling.decoders.rnnt_aligner")
+    g = torch.Generator().manual_seed(7)
+    B, T, L, V = 3, 7, 4, 6
+    lp = torch.log_softmax(2.0 * torch.randn(B, T, L + 1, V, generator=g), -1)
+    ys = torch.randint(1, V, (B, L), generator=g)
+    elens, ylens = torch.tensor([7, 5, 3]), torch.tensor([4, 2, 3])
+    # the aligner's own buffers, reproduced here so that alpha / beta / log_p can be stored as well (rnnt_aligner.py:158-181)
+    alpha = torch.zeros(B, T, L + 1)
+    beta = torch.zeros(B, T, L + 1)
+    lpa, lpb = torch.zeros(B), torch.zeros(B)
+    lock = torch.zeros(B, L + 1, dtype=torch.int32)
+    ra.cu_kernel_forward[B, L + 1](lp, ys.int(), alpha, lpa, elens.int(), ylens.int(), 0, lock)
+    lock = lock * 0
+    ra.cu_kernel_backward[B, L + 1](lp, ys.int(), beta, lpb, elens.int(), ylens.int(), 0, lock)
+    aligns = ra.RNNTForcedAligner(blank_id=0)(lp, elens, ys, ylens)
+    np.savez_compressed(os.path.join(OUT, "rnnt_align_xcheck.npz"), log_probs=lp.numpy(), ys=ys.numpy(), elens=elens.numpy(),
+                        ylens=ylens.numpy(), alpha=alpha.numpy(), beta=beta.numpy(), log_p_alpha=lpa.numpy(),
+                        log_p_beta=lpb.numpy(), aligns=aligns.numpy())
+    print("rnnt aligner cross-check: log_p alpha", lpa.tolist(), "beta", lpb.tolist(), "aligns", aligns.tolist(),
+          "lock tests that found the lock closed:", _Atomic.spins)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ctc", "ctcabs", "l3", "l4"]
     if "ctc" in which:
@@ -736,6 +808,8 @@ if __name__ == "__main__":
         run_hostio()
     if "traintrace" in which:  # needs l2_tiny.npz
         run_train_trace()
+    if "rnntalign" in which:
+        run_rnnt_align_xcheck()
     if "traintrace256" in which:
         run_train_trace_d256()
     if "kd" in which:  # needs l2_tiny.npz and l3_tiny.npz (reads their weights)

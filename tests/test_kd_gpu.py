@@ -209,6 +209,32 @@ def test_rnnt_forced_aligner(dev):
     assert got.dtype == torch.int32 and torch.equal(got.cpu(), want)
 
 
+def test_rnnt_lattice_against_the_reference_aligner_kernels(dev):
+    """the HIP transducer lattice (emoasr_rnnt_forward: alpha, beta, nll) and RNNTForcedAligner against what the reference's OWN
+    recursion bodies gave (rnnt_aligner.py:14-198 executed as plain Python by make_golden.py: rnnt_align_xcheck.npz) -- a
+    cross-check of the lattice the transducer loss runs on; the loss value's third-party source (warp_rnnt) stays unpinned"""
+    import os
+
+    import numpy as np
+
+    from emoasr_amd import ops
+    from emoasr_amd.modeling.decoders.rnnt_aligner import RNNTForcedAligner
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "rnnt_align_xcheck.npz"))
+    lp, ys = torch.from_numpy(z["log_probs"]), torch.from_numpy(z["ys"])
+    elens, ylens = torch.from_numpy(z["elens"]), torch.from_numpy(z["ylens"])
+    got = RNNTForcedAligner(blank_id=0)(lp.to(dev), elens, ys, ylens)
+    assert torch.equal(got.cpu(), torch.from_numpy(z["aligns"]))
+    with ops.stream_scope():
+        (_, _, _, alpha, beta), nll = ops.rnnt_forward(lp.to(dev).contiguous(), ys.to(torch.int32).to(dev),
+                                                       elens.to(torch.int32).to(dev), ylens.to(torch.int32).to(dev), 0)
+    alpha, beta, nll = alpha.cpu().numpy(), beta.cpu().numpy(), nll.cpu()
+    for b in range(lp.shape[0]):
+        T, U = int(elens[b]), int(ylens[b])
+        assert np.allclose(alpha[b, :T, :U + 1], z["alpha"][b, :T, :U + 1], atol=1e-4), b
+        assert np.allclose(beta[b, :T, :U + 1], z["beta"][b, :T, :U + 1], atol=1e-4), b
+    assert np.allclose((-nll / elens).numpy(), z["log_p_alpha"], atol=1e-4)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_rnnt_decoder_with_align_kd(dev, dtype):
     """kd_type 'align' (rnn_transducer.py:131-135) against the oracle composition on the l4_tiny weights"""

@@ -415,9 +415,13 @@ def _attn_ref(q, k, v, H, scale, pos, bu, bv, klens, causal):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", ["rel", "rel_long", "plain_mask", "causal", "cross"])
-@pytest.mark.parametrize("mat", ["stored", True, False, "fused"], ids=["stored", "gemmbwd", "recompute", "fused"])
+@pytest.mark.parametrize("mat", ["stored", True, False, "fused", "fused1"], ids=["stored", "gemmbwd", "recompute", "fused", "fused-single-pass"])
 def test_attention(dev, dtype, tr_mode, case, mat):
-    from emoasr_amd import ops
+    """"fused": the two-pass bf16 backward (attn_bwd_kv_kernel + attn_bwd_q_kernel, the default); "fused1": the single-pass kernel
+    of rounds 2-3 (option attn_bwd_split = 0), kept as the A/B reference"""
+    from emoasr_amd import lib, ops
+    single = mat == "fused1"
+    mat = "fused" if single else mat
     H, dk = 4, 64
     D = H * dk
     cfg = {"rel": (3, 75, 75, True, False, [75, 40, 9]), "rel_long": (2, 299, 299, True, False, [299, 170]),
@@ -460,8 +464,12 @@ def test_attention(dev, dtype, tr_mode, case, mat):
     dpos = torch.zeros(2 * Tq - 1, D, device=dev) if rel else None
     dbu = torch.zeros(D, device=dev) if rel else None
     dbv = torch.zeros(D, device=dev) if rel else None
-    ops.attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk_, dv, pos=pos, bias_u=bu, bias_v=bv, klens=klens,
-                 causal=causal, dpos=dpos, dbias_u=dbu, dbias_v=dbv, materialise=mat if mat == "fused" else bool(mat), st=st)
+    lib.set_option("attn_bwd_split", 0 if single else 1)
+    try:
+        ops.attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk_, dv, pos=pos, bias_u=bu, bias_v=bv, klens=klens,
+                     causal=causal, dpos=dpos, dbias_u=dbu, dbias_v=dbv, materialise=mat if mat == "fused" else bool(mat), st=st)
+    finally:
+        lib.set_option("attn_bwd_split", 1)
     btol = _tol(dtype, 1e-4, 4e-2)
     _close(dq, leaves[0].grad, btol, f"attn dq {case}")
     _close(dk_, leaves[1].grad, btol, f"attn dk {case}")
@@ -507,23 +515,28 @@ def test_attention_bwd_fused_vs_materialised(dev, case):
     out, lse = ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, drop_p=0.1, seed=77)
     dout = _rnd(dev, B, T, D, dtype=dt_)
     res = {}
-    for mode in (True, "fused"):
+    from emoasr_amd import lib
+    for mode in (True, "fused", "fused1"):
+        lib.set_option("attn_bwd_split", 0 if mode == "fused1" else 1)
         dqkv = torch.full_like(qkv, float("nan"))  # every entry must be written
         dq, dk_, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
         dpos = torch.zeros(2 * T - 1, D, device=dev) if rel else None
         dbu = torch.zeros(D, device=dev) if rel else None
         dbv = torch.zeros(D, device=dev) if rel else None
         ops.attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk_, dv, pos=pos, bias_u=bu, bias_v=bv, klens=klens,
-                     drop_p=0.1, seed=77, dpos=dpos, dbias_u=dbu, dbias_v=dbv, materialise=mode)
+                     drop_p=0.1, seed=77, dpos=dpos, dbias_u=dbu, dbias_v=dbv, materialise="fused" if mode == "fused1" else mode)
         res[mode] = (dqkv.float(), dpos, dbu, dbv)
-    a, f = res[True], res["fused"]
-    _close(f[0][..., :D], a[0][..., :D], 3e-2, "dq")
-    _close(f[0][..., D:2 * D], a[0][..., D:2 * D], 3e-2, "dk")
-    _close(f[0][..., 2 * D:], a[0][..., 2 * D:], 3e-2, "dv")
-    if rel:
-        _close(f[1], a[1], 3e-2, "dpos")
-        _close(f[2], a[2], 3e-2, "dbias_u")
-        _close(f[3], a[3], 3e-2, "dbias_v")
+    lib.set_option("attn_bwd_split", 1)
+    a = res[True]
+    for name in ("fused", "fused1"):   # the two-pass kernels (default) and the single-pass kernel
+        f = res[name]
+        _close(f[0][..., :D], a[0][..., :D], 3e-2, name + " dq")
+        _close(f[0][..., D:2 * D], a[0][..., D:2 * D], 3e-2, name + " dk")
+        _close(f[0][..., 2 * D:], a[0][..., 2 * D:], 3e-2, name + " dv")
+        if rel:
+            _close(f[1], a[1], 3e-2, name + " dpos")
+            _close(f[2], a[2], 3e-2, name + " dbias_u")
+            _close(f[3], a[3], 3e-2, name + " dbias_v")
 
 
 def test_attention_bwd_fused_run_to_run(dev):
@@ -544,7 +557,8 @@ def test_attention_bwd_fused_run_to_run(dev):
     out, lse = ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, drop_p=0.1, seed=5)
     dout = _rnd(dev, B, T, D, dtype=dt_)
     try:
-        for fw in (4, 2):
+        for fw in (0, 4, 2):   # 0: the two-pass backward (default); 4 / 2: the single-pass kernel at both workgroup sizes
+            lib.set_option("attn_bwd_split", 1 if fw == 0 else 0)
             lib.set_option("attn_fw", fw)
             first = None
             for it in range(8):
@@ -560,11 +574,14 @@ def test_attention_bwd_fused_run_to_run(dev):
                     first = cur
                     continue
                 assert torch.equal(cur[0][..., D:], first[0][..., D:]), f"dK/dV differ between runs (fw={fw}, run {it})"
+                if fw == 0:   # dQ has one writer per row in the two-pass backward: bit-identical as well
+                    assert torch.equal(cur[0][..., :D], first[0][..., :D]), f"dQ differs between runs (two-pass, run {it})"
                 _close(cur[0][..., :D], first[0][..., :D], 1e-2, "dq run to run")
                 _close(cur[1], first[1], 1e-3, "dpos run to run")
                 _close(cur[2], first[2], 1e-3, "dbias_u run to run")
     finally:
         lib.set_option("attn_fw", 0)
+        lib.set_option("attn_bwd_split", 1)
 
 
 # ---------------------------------------------------------------- conv module

@@ -98,3 +98,26 @@ def test_beam_search_pinned_to_reference():
             eouts, _ = om.encoder_forward(sd, cfg, g["xs"][b:b + 1, :n], g["xlens"][b:b + 1])
             for bw in RNNT_BEAM_WIDTHS:
                 assert orn.rnnt_beam_search(sd, cfg, eouts, bw) == want[bw][b], (b, bw)
+
+
+def test_lattice_against_the_reference_aligner_kernels():
+    """CROSS-CHECK (does not pin the loss value: warp_rnnt stays absent).  asr/modeling/decoders/rnnt_aligner.py:14-152 is the
+    reference's own statement of the transducer forward / backward recursions; tests/golden/make_golden.py
+    (run_rnnt_align_xcheck) executed those two kernel bodies as plain Python and stored alpha, beta, log_p and the alignments
+    of RNNTForcedAligner.__call__ (:158-198).  The oracle's lattice (oracle.distill.rnnt_alpha_beta), its loss
+    (oracle.rnnt.rnnt_nll: log_p = -nll / T) and its alignment walk must reproduce them."""
+    import os
+
+    from oracle import distill as od
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "rnnt_align_xcheck.npz"))
+    lp, ys = torch.from_numpy(z["log_probs"]), torch.from_numpy(z["ys"])
+    elens, ylens = torch.from_numpy(z["elens"]), torch.from_numpy(z["ylens"])
+    for b in range(lp.shape[0]):
+        T, U = int(elens[b]), int(ylens[b])
+        alpha, beta = od.rnnt_alpha_beta(lp[b].double(), [int(v) for v in ys[b, :U]], T, U, 0)
+        assert np.allclose(alpha.numpy(), z["alpha"][b, :T, :U + 1], atol=1e-5), b
+        assert np.allclose(beta.numpy(), z["beta"][b, :T, :U + 1], atol=1e-5), b
+    nll = orn.rnnt_nll(lp, ys, elens, ylens, 0)
+    assert np.allclose((-nll / elens).numpy(), z["log_p_alpha"], atol=1e-5)
+    assert np.allclose((-nll / elens).numpy(), z["log_p_beta"], atol=1e-5)
+    assert torch.equal(od.rnnt_forced_align(lp, elens, ys, ylens, 0), torch.from_numpy(z["aligns"]))

@@ -14,10 +14,10 @@ dev = torch.device("cuda:0")
 H, D = 4, 256
 dt = torch.bfloat16
 p = float(os.environ.get("P", 0.1))
-shapes = [(22, 320), (24, 299), (12, 590), (8, 875), (40, 170)]
+shapes = [(22, 320), (24, 299), (12, 590), (8, 875), (40, 170), (110, 320), (60, 590), (200, 170)]   # the last three: five stacked micro-batches' worth
 if os.environ.get("B"):
     shapes = [(int(os.environ["B"]), int(os.environ.get("T", 299)))]
-modes = os.environ.get("MODES", "fused,mat").split(",")
+modes = os.environ.get("MODES", "fused,fused1,mat").split(",")
 scale = 1 / math.sqrt(64)
 for B, T in shapes:
     torch.manual_seed(0)
@@ -37,8 +37,10 @@ for B, T in shapes:
     dbu, dbv = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     sc = ops.AttnScratch(B, H, T, T, dt, dev, True)
     row = f"B {B:3d} T' {T:4d}: fwd {fw:7.1f} us ({3 * 2 * 64 * pairs / fw / 1e6:5.0f} TF/s)"
-    for mode in modes:
-        mat = "fused" if mode == "fused" else (mode == "mat")
+    for mode in modes:   # fused: the two-pass backward (default); fused1: the single-pass kernel of rounds 2-3; mat: materialised
+        from emoasr_amd import lib
+        lib.set_option("attn_bwd_split", 0 if mode == "fused1" else 1)
+        mat = "fused" if mode in ("fused", "fused1") else (mode == "mat")
         f = lambda: ops.attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=pos, bias_u=bu, bias_v=bv, klens=klens,
                                  drop_p=p, seed=1, dpos=dpos, dbias_u=dbu, dbias_v=dbv, scratch=sc if mat is True else None,
                                  materialise=mat)
