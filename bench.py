@@ -726,6 +726,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         elapsed, frames = tmax[0].item(), tt[1].item()
     value = frames / elapsed
+    dp_info = None
+    if world > 1:
+        # the N > 1 line validates itself: what the collective backend reports, every rank's own frame count, and -- data-parallel
+        # replicas apply the SAME reduced gradient with the same fused Adam -- the parameters must be bit-identical on all ranks
+        # after the timed steps (a checksum over the raw bits of the flat f32 arena + its f64 sum, gathered from every rank)
+        flat = eng.arena.flat
+        bits = flat.view(torch.int32).to(torch.int64).sum()
+        mine = torch.stack([torch.tensor(float(sum(sum(b.xlens) for grp in batches[args.warmup:] for b in grp)), device=dev,
+                                         dtype=torch.float64), bits.to(torch.float64), flat.double().sum()])
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        dp_info = {"backend": dist.get_backend(), "nranks": dist.get_world_size(),
+                   "one_gpu_rehearsal": os.environ.get("EMOASR_BENCH_ONE_GPU") == "1",
+                   "frames_per_rank": [float(v) for v in allr[:, 0]],
+                   "param_bits_checksum": [int(v) for v in allr[:, 1]], "param_sum": [float(v) for v in allr[:, 2]],
+                   "params_identical_across_ranks": bool((allr[:, 1] == allr[0, 1]).all() and (allr[:, 2] == allr[0, 2]).all()),
+                   "overlapped_allreduce": buckets is not None,
+                   "note": "no scaling value has been measured on multi-GPU hardware by the builder: the driver's SCALE run is the "
+                           "only N > 1 execution over RCCL / xGMI"}
 
     if rank == 0:
         res = {
@@ -742,6 +762,8 @@ def main():
                        "params_M": sum(p.numel() for p in model.parameters()) / 1e6,
                        "parallelism": f"dp{world}", "final_loss": float(loss.detach())},
         }
+        if dp_info is not None:
+            res["dp"] = dp_info
         mean_T = frames / world / args.steps / accum / max(1, np.mean([len(b.xlens) for grp in batches[args.warmup:] for b in grp]))
         train_flops = 3.0 * fwd_flops_per_utt(int(mean_T)) / max(mean_T, 1) * frames
         res["model_mfma_frac"] = train_flops / elapsed / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12 * world)

@@ -1335,6 +1335,10 @@ struct FusedWs {       // workspace carved by emoasr_attn_bwd_fused
   const void *qu, *qv; // T [B, Tq, ldqu]: Q + pos_bias_u, Q + pos_bias_v  (without biases: q itself, ldq)
   long ldqu;
   unsigned long long* stamp;  // -DEMO_ATTN_STAMP builds only: s_memtime of wave 0 of workgroup (0,0,0) at 13 points per step
+  // two-pass backward: the attention-dropout keep mask as bits, one 32-bit word per (row, head, 32-key tile) -- [rows, H, mask_nw],
+  // bit k of word w = key 32 w + k kept (attn_dropmask_kernel; nullptr without dropout)
+  const unsigned* mask;
+  int mask_nw;
 };
 
 // prologue: delta[b,h,i] = dO.O, dense Q+u / Q+v.  8 lanes x 8 elements per (b,i,h) row.
@@ -1935,7 +1939,7 @@ template <typename T, int FW> struct SplitCfg {
   static constexpr int BAND_ROWS = 32 * FW + 32;
   static constexpr int LDG = 72;                     // dG image row stride ([32 queries][64 band columns] + padding)
   static constexpr int GS_BYTES = 64 * 32 * 4;       // per wave: the f32 skew tile (the Q pass's dG image reuses it)
-  static constexpr int ROWC_BYTES = 64 * 4;          // KV pass: lse * log2(e) and delta of the step's 32 queries
+  static constexpr int ROWC_BYTES = 64 * 4 + FW * 32 * 4;   // KV pass: lse * log2(e), delta and the waves' keep-mask words of the step's 32 queries
   static constexpr int kv_rows(bool rel) { return rel ? 96 : 64; }               // Q+u, Q+v, dO | Q, dO (the band comes from L2)
   static constexpr int q_rows(bool rel) { return rel ? 64 + BAND_ROWS : 64; }    // K, V, band | K, V
   static constexpr int kv_stage_bytes(bool rel) { return kv_rows(rel) * LD * (int)sizeof(T) + ROWC_BYTES; }
@@ -1944,6 +1948,46 @@ template <typename T, int FW> struct SplitCfg {
   static constexpr int kv_smem(bool rel) { return kv_stage_bytes(rel) + FW * wave_bytes(rel); }
   static constexpr int q_smem(bool rel) { return q_stage_bytes(rel) + FW * wave_bytes(rel); }
 };
+
+// The attention-dropout keep mask of one launch as BITS.  The forward regenerates the counter-based mask inline (one hash per pair
+// of keys, common.h: dropout_keep2); so did the single-pass backward -- and in the two recomputation passes of the two-pass backward
+// the hash was the largest VALU item of a step (PMC: 566 / 424 VALU instructions per 32 x 32 tile in the key- / query-stationary
+// pass, ~420 / ~220 of them the mask: 26 per element where the keys of a pair sit on neighbouring lanes, 13 where they sit in
+// neighbouring registers).  Here every pair is hashed ONCE per layer and step, by a kernel that does nothing else (one thread per
+// 32-key word, 16 pair hashes), and both passes test a bit: 2 instructions per element.  Same mask, bit for bit.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_dropmask_kernel(const emoasr_attn_t a_in, unsigned* __restrict__ mask, const int nw,
+                                                            const long nrows) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int w = (int)(idx % nw);
+  const long rh = idx / nw;
+  if (rh >= nrows * a_in.H) return;
+  const int h = (int)(rh % a_in.H);
+  const long row = rh / a_in.H;
+  emoasr_attn_t a = a_in;
+  int b, i;
+  if (a_in.nseg > 1) {
+    const SegRef g = seg_of_row(a_in, row);
+    seg_apply<T>(a, g);
+    const long loc = row - g.row;
+    b = (int)(loc / g.T); i = (int)(loc % g.T);
+  } else {
+    b = (int)(row / a.Tq); i = (int)(row % a.Tq);
+  }
+  const int klen = a.klens ? min(a.klens[b], a.Tk) : a.Tk;
+  if (32 * w >= klen) return;   // no valid key in this word: never read
+  const uint32_t thr = dropout_thr(a.drop_p);
+  const uint64_t pr0 = drop_index(a, b, h, i, 32 * w) >> 1;
+  unsigned bits = 0u;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    bool k0, k1;
+    dropout_keep2(a.seed, pr0 + (uint64_t)k, thr, k0, k1);
+    bits |= (k0 ? 1u : 0u) << (2 * k);
+    bits |= (k1 ? 1u : 0u) << (2 * k + 1);
+  }
+  mask[idx] = bits;
+}
 
 template <typename T, bool TR, bool REL, int FW>
 __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int nt) {
@@ -1966,6 +2010,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
     seg_apply<T>(a, g);
     ws.qu = (const T*)ws.qu + g.row * ws.ldqu;
     ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
+    if (ws.mask) ws.mask += g.row * a.H * ws.mask_nw;
   }
   const int jblk = blk.x * (32 * FW), h = blk.y;
   if (jblk >= a.Tk) return;
@@ -1982,6 +2027,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
 
   T* stage0 = reinterpret_cast<T*>(smem);
   float* rowc = reinterpret_cast<float*>(smem + NROWS * LD * (int)sizeof(T));   // [0,32) lse * log2 e (+inf: no contribution), [32,64) delta
+  unsigned* maskw = reinterpret_cast<unsigned*>(rowc + 64);   // [FW waves][32 queries]: the keep-mask words of the step's rows for each wave's key tile
   float* Gs = reinterpret_cast<float*>(smem + C_::kv_stage_bytes(REL) + wave * C_::wave_bytes(REL));  // [32 queries][64 band columns]
 
   const long ho = (long)h * DK;
@@ -1996,7 +2042,10 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   Vec16<T> pre[PPT];
   float pre_lse = 0.f, pre_del = 0.f;
   bool pre_ok = false;
-  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(hp.lse), rsD = make_rsrc(hp.delta);
+  unsigned pre_mask = 0xFFFFFFFFu;
+  const bool has_mask = ws.mask != nullptr;
+  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(hp.lse), rsD = make_rsrc(hp.delta), rsM = make_rsrc(ws.mask);
+  static_assert(NTHR >= 32 * FW, "one mask word per thread");
   auto fetch = [&](const int step) {
     const int i0 = step * 32;
     const bool on = step < nstep;
@@ -2006,6 +2055,11 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
       const unsigned o = pre_ok ? (unsigned)((i0 + il) * 4) : EMO_OOB;
       pre_lse = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsL, o, 0, 0));
       pre_del = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, o, 0, 0));
+    }
+    if (has_mask && tid < 32 * FW) {   // thread (wave slot tid >> 5, query tid & 31): word of key tile jblk / 32 + (tid >> 5)
+      const int i = i0 + (tid & 31), w = jblk / 32 + (tid >> 5);
+      const bool ok = on && i < a.Tq && w < ws.mask_nw;
+      pre_mask = __builtin_amdgcn_raw_buffer_load_b32(rsM, ok ? (unsigned)(((((long)b * a.Tq + i) * a.H + h) * ws.mask_nw + w) * 4) : EMO_OOB, 0, 0);
     }
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
@@ -2028,6 +2082,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
       rowc[il] = (pre_ok && pre_lse != -INFINITY) ? pre_lse * 1.4426950408889634f : INFINITY;
       rowc[32 + il] = pre_del;
     }
+    if (tid < 32 * FW) maskw[tid] = pre_mask;   // (without dropout: all ones)
   };
 
   // ---- stationary operands of this wave's key tile: K and V fragments (B operands: key on the lane) ----------
@@ -2047,19 +2102,18 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   __syncthreads();
   const bool kvalid = kj < hp.klen;
   const float c_exp = a.scale * 1.4426950408889634f;
-  const float keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-  const uint32_t thr = dropout_thr(a.drop_p);
-  const uint64_t drop_stride2 = (uint64_t)((a.Tk + 1) & ~1) >> 1;   // pairs per mask row
+  const unsigned keep_bits = __float_as_uint(a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f);
 
   for (int step = 0; step < nstep; ++step) {
     const int i0 = step * 32;
     const T* Qus = stage0;
     const T* Qvs = stage0 + 32 * LD;
     const T* dOs = stage0 + (REL ? 64 : 32) * LD;
+    EMO_STAMP(0);
     if (live) {
       // this wave's 64 band rows of the projected position table (r = Tq - 32 - i0 + j0 + c): k-contiguous B operands straight
-      // from global memory (L2: the table of a segment is shared by all its workgroups), requested first and used last --
-      // staging them like the query-side tiles would cost 20 more prefetch registers per thread and 23 KB of LDS
+      // from global memory (L2: the table of a segment is shared by all its workgroups).  Staged through LDS like the query-side
+      // tiles (20 more prefetch registers per thread) the kernel spills inside the sweep: 522 against 361 us at B 110, T' 320.
       typename M_::Frag fb[2][NK];
       if constexpr (REL) {
         const int rbase = a.Tq - 32 - i0 + j0;
@@ -2078,6 +2132,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
         s = M_::mma(M_::load_kc(Qus, LD, 0, kk * M_::KSTEP, lane), kfB[kk], s);
         dp = M_::mma(M_::load_kc(dOs, LD, 0, kk * M_::KSTEP, lane), vfB[kk], dp);
       }
+      EMO_STAMP(1);
       if constexpr (REL) {
         // band product G[query][band column c] = (Q+v) band^T, two 32-column tiles; element (i_l, j_l) of the score tile is
         // G[i_l][31 - i_l + j_l]: a lane rotation per accumulator row, through the wave's f32 tile
@@ -2095,34 +2150,33 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
           Gs[c_row(r, lane) * 64 + 32 + il] = g1[r];
         }
         __builtin_amdgcn_wave_barrier();
+        EMO_STAMP(2);
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] += Gs[c_row(r, lane) * 64 + 31 - c_row(r, lane) + il];
         __builtin_amdgcn_wave_barrier();
       }
+      EMO_STAMP(3);
       // soft-max, dropout, dS: accumulator rows 4 g .. 4 g + 3 are queries i0 + 8 g + 4 hh + 0 .. 3
       typename M_::Frag pf[NS], df[NS];   // P and dS as the next products' B operands (accumulator rows 8 ks .. 8 ks + 7, chain_b's order)
-      const uint64_t pair0 = (drop_index(a, b, h, i0 + 4 * hh, 0) >> 1) + (uint64_t)(kj >> 1);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(rowc + 8 * g + 4 * hh);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(rowc + 32 + 8 * g + 4 * hh);
+        const u32x4 m4 = *reinterpret_cast<const u32x4*>(maskw + 32 * wave + 8 * g + 4 * hh);   // keep bits of the rows' keys j0 .. j0 + 31
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           float p = __builtin_amdgcn_exp2f(s[r] * c_exp - l4[e]);
           p = kvalid ? p : 0.f;
-          // the mask is hashed in pairs of keys (common.h: dropout_keep2); neighbouring keys are neighbouring LANES here.  Hashed
-          // unconditionally (drop_p = 0: threshold 0, every element kept, keep = 1): a branch per element would cut the step into
-          // basic blocks the scheduler cannot interleave with the MFMAs
-          const uint32_t x = dropout_hash(a.seed, pair0 + (uint64_t)(8 * g + e) * drop_stride2);
-          const uint32_t u = (kj & 1) ? dropout_second(x) : x;
-          const float m = (u & 0xFFFFFFu) >= thr ? keep : 0.f;
+          // bit il of the row's word: 0 / -1 -> 0 / keep (attn_dropmask_kernel hashed the mask once for both passes)
+          const float m = __uint_as_float((unsigned)__builtin_amdgcn_sbfe(m4[e], il, 1) & keep_bits);
           const float dsv = p * (dp[r] * m - d4[e]) * a.scale;
           csum += dsv;
           pf[g >> 1][4 * (g & 1) + e] = (bf16)(p * m);
           df[g >> 1][4 * (g & 1) + e] = (bf16)dsv;
         }
       }
+      EMO_STAMP(4);
       // dV^T += dO^T P,  dK^T += (Q+u)^T dS: the accumulators are the B operands (query index in the registers)
       __builtin_amdgcn_sched_barrier(0);   // (the eight transposed operand reads hoisted above the soft-max cost 32 registers: spills)
 #pragma unroll
@@ -2134,10 +2188,15 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
         }
       }
     }
+    EMO_STAMP(5);
     lds_barrier();   // every wave has read the stage
+    EMO_STAMP(6);
     stash();         // tiles of step + 1 (fetched during the previous step)
+    EMO_STAMP(7);
     fetch(step + 2);
+    EMO_STAMP(8);
     lds_barrier();   // stage ready
+    EMO_STAMP(9);
   }
   store_dT<T>((T*)hp.dk, a.ldk, j0, a.Tk, dk, 1.f, lane);  // (a dead wave stores zeros)
   store_dT<T>((T*)hp.dv, a.ldv, j0, a.Tk, dv, 1.f, lane);
@@ -2182,6 +2241,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
     ws.qu = (const T*)ws.qu + g.row * ws.ldqu;
     ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
     if (ws.dsq) ws.dsq = (T*)ws.dsq + g.row * a.H * ws.ldds;
+    if (ws.mask) ws.mask += g.row * a.H * ws.mask_nw;
   }
   const int iblk = blk.x * (32 * FW), h = blk.y;
   if (iblk >= a.Tq) return;   // (a shorter segment of a stacked launch: the grid follows the longest)
@@ -2254,15 +2314,25 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
   fetch(1);
   __syncthreads();
   const float c_exp = a.scale * 1.4426950408889634f;
-  const uint64_t drop_base = drop_index(a, b, h, qi, 0);
-  const float keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-  const uint32_t thr = dropout_thr(a.drop_p);
+  const unsigned keep_bits = __float_as_uint(a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f);
+  // the keep-mask word of (query qi, key tile `step`), one step ahead (attn_dropmask_kernel; without dropout: all ones)
+  const bool has_mask = ws.mask != nullptr;
+  const __amdgpu_buffer_rsrc_t rsM = make_rsrc(ws.mask);
+  const unsigned mrow = (unsigned)((((long)b * a.Tq + qi) * a.H + h) * ws.mask_nw * 4);
+  auto mask_word = [&](const int step) -> unsigned {
+    if (!has_mask) return 0xFFFFFFFFu;
+    return __builtin_amdgcn_raw_buffer_load_b32(rsM, (live && qval && step < nstep) ? mrow + 4u * (unsigned)step : EMO_OOB, 0, 0);
+  };
+  unsigned mw_next = mask_word(0);
 
   for (int step = 0; step < nstep; ++step) {
     const int j0 = step * 32;
     const T* Ks = stage0;
     const T* Vs = stage0 + 32 * LD;
     const T* Bs = stage0 + (64 + 32 * (FW - 1 - wave)) * LD;  // this wave's 64 band rows (REL)
+    const unsigned mw = mw_next >> (4 * hh);   // this half wave's keys are 8 g + 4 hh + e
+    mw_next = mask_word(step + 1);
+    EMO_STAMP(0);
     if (live) {
       f32x16 s, dp;
       zero16(s); zero16(dp);
@@ -2285,6 +2355,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
         s = M_::mma(M_::load_kc(Ks, LD, 0, kk * M_::KSTEP, lane), fqu[kk], s);
         dp = M_::mma(M_::load_kc(Vs, LD, 0, kk * M_::KSTEP, lane), fdo[kk], dp);
       }
+      EMO_STAMP(1);
       if constexpr (REL) {
         __builtin_amdgcn_wave_barrier();
         // element (key jl, query il) sits in band column c = 31 - il + jl
@@ -2292,26 +2363,20 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
         for (int r = 0; r < 16; ++r) s[r] += Gs[(31 - il + c_row(r, lane)) * 32 + il];
         __builtin_amdgcn_wave_barrier();
       }
+      EMO_STAMP(2);
       // soft-max, dropout, dS -- packed straight into the B operand of the dQ product (accumulator rows 8 ks .. 8 ks + 7, chain_b's
       // order); accumulator rows 4 g .. 4 g + 3 are keys j0 + 8 g + 4 hh + 0 .. 3: two hash pairs (drop_base, j0 even)
       typename M_::Frag df[NS];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        // (hashed unconditionally -- drop_p = 0: threshold 0, keep = 1 -- so that the step stays one basic block)
-        float m[4];
-        {
-          const uint64_t pr = (drop_base + (uint64_t)(j0 + 8 * g + 4 * hh)) >> 1;
-          bool k0, k1, k2, k3;
-          dropout_keep2(a.seed, pr, thr, k0, k1);
-          dropout_keep2(a.seed, pr + 1, thr, k2, k3);
-          m[0] = k0 ? keep : 0.f; m[1] = k1 ? keep : 0.f; m[2] = k2 ? keep : 0.f; m[3] = k3 ? keep : 0.f;
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           float p = __builtin_amdgcn_exp2f(s[r] * c_exp - lse2);
           p = (j0 + c_row(r, lane) >= hp.klen) ? 0.f : p;
-          const bf16 dsv = (bf16)(p * (dp[r] * m[e] - del_q) * a.scale);
+          // bit 8 g + e of the half wave's word: 0 / -1 -> 0 / keep
+          const float m = __uint_as_float((unsigned)__builtin_amdgcn_sbfe(mw, 8 * g + e, 1) & keep_bits);
+          const bf16 dsv = (bf16)(p * (dp[r] * m - del_q) * a.scale);
           df[g >> 1][4 * (g & 1) + e] = dsv;
           if constexpr (REL) {
             // dG[query il][band column c = key - il + 31]; the image shares its LDS with the f32 skew tile, so the column no key
@@ -2322,6 +2387,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
           }
         }
       }
+      EMO_STAMP(3);
       if constexpr (REL) {
         // dS for the position-table gradient: query-major rows, 4 consecutive keys (8 bytes) per store
         if (qval) {
@@ -2336,6 +2402,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
         }
         __builtin_amdgcn_wave_barrier();
       }
+      EMO_STAMP(4);
       // dQ^T += K^T dS^T (the accumulator is the B operand: key index in the registers) + band^T unskew(dS^T)
 #pragma unroll
       for (int ks = 0; ks < NS; ++ks) {
@@ -2355,10 +2422,15 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
         __builtin_amdgcn_wave_barrier();   // the image has been read: the region takes the next step's skew tile
       }
     }
+    EMO_STAMP(5);
     lds_barrier();   // every wave has read the stage
+    EMO_STAMP(6);
     stash();
+    EMO_STAMP(7);
     fetch(step + 2);
+    EMO_STAMP(8);
     lds_barrier();   // stage ready
+    EMO_STAMP(9);
   }
   if (live) store_dT<T>((T*)hp.dq, a.ldq, i0, a.Tq, dq, 1.f, lane);
   if (REL && a.dbias_v && live) {
@@ -2670,6 +2742,12 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
   } else {
     ws.qu = a.q; ws.qv = a.q; ws.ldqu = a.ldq;
   }
+  unsigned* maskbuf = nullptr;
+  if (g_bwd_split && a.drop_p > 0.f) {
+    ws.mask_nw = cdiv(a.Tk, 32);
+    maskbuf = reinterpret_cast<unsigned*>(carve((size_t)nrows * a.H * ws.mask_nw * 4));
+    ws.mask = maskbuf;
+  }
   EMO_CHECK(off <= bytes, "attn_bwd_fused: workspace too small (%zu < %zu bytes)", bytes, off);
   const long rows = nrows * a.H;
   const FusedExtras fx = g_fused_extras;
@@ -2677,7 +2755,7 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
 #ifdef EMO_ATTN_STAMP
   static unsigned long long* d_stamp = nullptr;
   static int stamp_calls = 0;
-  if (!d_stamp) hipMalloc(&d_stamp, 64 * 13 * 8);
+  if (!d_stamp) hipMalloc(&d_stamp, 2 * 64 * 13 * 8);
   ws.stamp = stamp_calls++ == 0 ? d_stamp : nullptr;   // the first (eager) call only: later calls may be under stream capture
 #endif
   attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, qu, qv, fx.zero, fx.zero_n, nrows);
@@ -2700,11 +2778,16 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
     if (ntk) gk = dim3(8 * cdiv(a.H * a.B, 8) * ntk, 1, 1);
     if (ntq) gq = dim3(8 * cdiv(a.H * a.B, 8) * ntq, 1, 1);
     emo_timer_begin(EMO_TIMER_ATTN_BWD_MAIN, s);
+    if (maskbuf) {
+      const long nwords = nrows * a.H * ws.mask_nw;
+      attn_dropmask_kernel<T><<<cdiv(nwords, 256), 256, 0, s>>>(a, maskbuf, ws.mask_nw, nrows);
+    }
 #define EMO_SPLIT_LAUNCH(TR_, REL_)                                                                                 \
   do {                                                                                                              \
     if (set_smem(attn_bwd_kv_kernel<T, TR_, REL_, FW>, SC::kv_smem(REL_))) return 1;                                \
     if (set_smem(attn_bwd_q_kernel<T, TR_, REL_, FW>, SC::q_smem(REL_))) return 1;                                  \
     attn_bwd_kv_kernel<T, TR_, REL_, FW><<<gk, 64 * FW, SC::kv_smem(REL_), s>>>(a, ws, ntk);                        \
+    if (ws.stamp) ws.stamp += 64 * 13;                                                                              \
     attn_bwd_q_kernel<T, TR_, REL_, FW><<<gq, 64 * FW, SC::q_smem(REL_), s>>>(a, ws, ntq);                          \
   } while (0)
     if (rel) { if (g_tr) EMO_SPLIT_LAUNCH(true, true); else EMO_SPLIT_LAUNCH(false, true); }
@@ -2723,6 +2806,30 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
       else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
       emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, s);
     }
+#ifdef EMO_ATTN_STAMP
+    {  // debug builds: per-phase cycle counts of wave 0 of workgroup 0 of both passes, averaged over the sweep
+      static int printed = 0;
+      if (printed < 1 && ws.stamp) {
+        ++printed;
+        static unsigned long long h[2 * 64 * 13];
+        hipStreamSynchronize(s);
+        hipMemcpy(h, ws.stamp - 64 * 13, sizeof(h), hipMemcpyDeviceToHost);
+        const int ns = (a.Tq + 31) / 32 < 64 ? (a.Tq + 31) / 32 : 64;
+        const char* nm[2][10] = {{"", "loads+S+dP", "band+skew write", "skew read", "soft-max", "dV+dK", "barrier1", "stash", "fetch", "barrier2"},
+                                 {"", "band+skew write+S+dP", "skew read", "soft-max+image", "dS store", "dQ", "barrier1", "stash", "fetch", "barrier2"}};
+        for (int kq = 0; kq < 2; ++kq) {
+          double acc[10] = {0};
+          int cnt = 0;
+          for (int st = 1; st + 1 < ns; ++st, ++cnt)
+            for (int k = 1; k < 10; ++k) acc[k] += (double)(h[kq * 64 * 13 + st * 13 + k] - h[kq * 64 * 13 + st * 13 + k - 1]);
+          fprintf(stderr, "[attn stamp %s] B %d T %d: per step (cycles):", kq ? "q" : "kv", a.B, a.Tq);
+          double tot = 0;
+          for (int k = 1; k < 10; ++k) { fprintf(stderr, " %s %.0f", nm[kq][k], acc[k] / (cnt > 0 ? cnt : 1)); tot += acc[k] / (cnt > 0 ? cnt : 1); }
+          fprintf(stderr, " | total %.0f\n", tot);
+        }
+      }
+    }
+#endif
     if (fx.cast_n > 0)   // the finished f32 position-table gradient in the compute dtype, for its weight-gradient product
       attn_cast_kernel<T><<<(int)std::min<long>(cdiv(fx.cast_n, 256), 1024), 256, 0, s>>>(fx.cast_src, (T*)fx.cast_dst, fx.cast_n);
     EMO_LAUNCH_CHECK();
@@ -2840,6 +2947,7 @@ extern "C" size_t emoasr_attn_bwd_fused_ws_bytes_rows(int dtype, long rows, int 
   const size_t nqd = (size_t)rows * H * DK;
   size_t n = up(nqd * 4 * ((Tk + 63) / 64));
   if (rel) n += 2 * up(nqd * esz) + up((size_t)rows * H * ((Tk + 31) / 32 * 32) * esz);
+  n += up((size_t)rows * H * ((Tk + 31) / 32) * 4);   // keep-mask bits of the two-pass backward
   return n;
 }
 
