@@ -1940,12 +1940,12 @@ template <typename T, int FW> struct SplitCfg {
   static constexpr int LDG = 72;                     // dG image row stride ([32 queries][64 band columns] + padding)
   static constexpr int GS_BYTES = 64 * 32 * 4;       // per wave: the f32 skew tile (the Q pass's dG image reuses it)
   static constexpr int ROWC_BYTES = 64 * 4 + FW * 32 * 4;   // KV pass: lse * log2(e), delta and the waves' keep-mask words of the step's 32 queries
-  static constexpr int kv_rows(bool rel) { return rel ? 96 : 64; }               // Q+u, Q+v, dO | Q, dO (the band comes from L2)
+  static constexpr int kv_rows(bool rel) { return rel ? 96 + BAND_ROWS : 64; }   // Q+u, Q+v, dO, band | Q, dO
   static constexpr int q_rows(bool rel) { return rel ? 64 + BAND_ROWS : 64; }    // K, V, band | K, V
   static constexpr int kv_stage_bytes(bool rel) { return kv_rows(rel) * LD * (int)sizeof(T) + ROWC_BYTES; }
   static constexpr int q_stage_bytes(bool rel) { return q_rows(rel) * LD * (int)sizeof(T); }
   static constexpr int wave_bytes(bool rel) { return rel ? GS_BYTES : 256; }
-  static constexpr int kv_smem(bool rel) { return kv_stage_bytes(rel) + FW * wave_bytes(rel); }
+  static constexpr int kv_smem(bool rel) { return kv_stage_bytes(rel) + 2 * 32 * FW * LD * (int)sizeof(T); }   // + the workgroup's K / V tiles
   static constexpr int q_smem(bool rel) { return q_stage_bytes(rel) + FW * wave_bytes(rel); }
 };
 
@@ -1990,7 +1990,7 @@ __global__ __launch_bounds__(256) void attn_dropmask_kernel(const emoasr_attn_t 
 }
 
 template <typename T, bool TR, bool REL, int FW>
-__global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int nt) {
+__global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int nt, const int dbg) {
   using M_ = Mma<T>;
   using C_ = SplitCfg<T, FW>;
   constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = C_::LD;
@@ -2025,20 +2025,25 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   }
   const bool live = j0 < hp.klen;  // a dead wave still stages and joins the barriers
 
+  // LDS: the step's query-side tiles + band (one buffer, refilled between two barriers), the row constants and keep-mask words of
+  // the step, and the workgroup's own K / V tiles (staged once: as registers they pushed the kernel past 256 and into scratch)
   T* stage0 = reinterpret_cast<T*>(smem);
   float* rowc = reinterpret_cast<float*>(smem + NROWS * LD * (int)sizeof(T));   // [0,32) lse * log2 e (+inf: no contribution), [32,64) delta
   unsigned* maskw = reinterpret_cast<unsigned*>(rowc + 64);   // [FW waves][32 queries]: the keep-mask words of the step's rows for each wave's key tile
-  float* Gs = reinterpret_cast<float*>(smem + C_::kv_stage_bytes(REL) + wave * C_::wave_bytes(REL));  // [32 queries][64 band columns]
+  T* Kt = reinterpret_cast<T*>(smem + C_::kv_stage_bytes(REL)) + 32 * wave * LD;   // this wave's K tile [32][LD]
+  T* Vt = Kt + 32 * FW * LD;
 
   const long ho = (long)h * DK;
   const T* qu_base = (const T*)ws.qu + (long)b * a.Tq * ws.ldqu + ho;
   const T* qv_base = REL ? (const T*)ws.qv + (long)b * a.Tq * ws.ldqu + ho : qu_base;
-  const __amdgpu_buffer_rsrc_t rsQu = make_rsrc(qu_base), rsQv = make_rsrc(qv_base), rsDo = make_rsrc(hp.dout);
+  const __amdgpu_buffer_rsrc_t rsQu = make_rsrc(qu_base), rsQv = make_rsrc(qv_base), rsDo = make_rsrc(hp.dout),
+                               rsP = make_rsrc(REL ? hp.pos : hp.dout);
   const int nstep = (a.Tq + 31) / 32;
 
-  // ---- one-step-ahead operand fetch (whole block), as in the single-pass kernel ------------------------------
+  // ---- one-step-ahead operand fetch (whole block): registers now, LDS between the step's two barriers ------------------
   constexpr int RPP = NTHR / PER_ROW;
   static_assert(32 % RPP == 0, "a piece index must stay inside one 32-row operand tile");
+  constexpr int NMAT = REL ? 3 : 2;  // 32-row tiles ahead of the band: Q+u, (Q+v,) dO
   Vec16<T> pre[PPT];
   float pre_lse = 0.f, pre_del = 0.f;
   bool pre_ok = false;
@@ -2064,11 +2069,18 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
       const int srow = p * RPP;
-      const int mat = srow / 32, i = i0 + srow % 32 + trow;
-      const bool ok = on && i < a.Tq;
-      if (mat == 0) pre[p] = buf_load16<T>(rsQu, ok ? (unsigned)(((long)i * ws.ldqu + piece) * sizeof(T)) : EMO_OOB);
-      else if (REL && mat == 1) pre[p] = buf_load16<T>(rsQv, ok ? (unsigned)(((long)i * ws.ldqu + piece) * sizeof(T)) : EMO_OOB);
-      else pre[p] = buf_load16<T>(rsDo, ok ? (unsigned)(((long)i * a.ldo + piece) * sizeof(T)) : EMO_OOB);
+      if (srow < 32 * NMAT) {
+        const int mat = srow / 32, i = i0 + srow % 32 + trow;
+        const bool ok = on && i < a.Tq && !(dbg & 4);
+        if (mat == 0) pre[p] = buf_load16<T>(rsQu, ok ? (unsigned)(((long)i * ws.ldqu + piece) * sizeof(T)) : EMO_OOB);
+        else if (REL && mat == 1) pre[p] = buf_load16<T>(rsQv, ok ? (unsigned)(((long)i * ws.ldqu + piece) * sizeof(T)) : EMO_OOB);
+        else pre[p] = buf_load16<T>(rsDo, ok ? (unsigned)(((long)i * a.ldo + piece) * sizeof(T)) : EMO_OOB);
+      } else {
+        // the union of the waves' position bands: rows r = Tq - 32 - i0 + jblk + t, t in [0, 32 FW + 32)
+        const int r = a.Tq - 32 - i0 + jblk + (srow - 32 * NMAT) + trow;
+        const bool ok = on && r >= 0 && r < 2 * a.Tq - 1 && !(dbg & 1);
+        pre[p] = buf_load16<T>(rsP, ok ? (unsigned)(((long)r * a.ldp + piece) * sizeof(T)) : EMO_OOB);
+      }
     }
   };
   auto stash = [&]() {
@@ -2085,14 +2097,22 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
     if (tid < 32 * FW) maskw[tid] = pre_mask;   // (without dropout: all ones)
   };
 
-  // ---- stationary operands of this wave's key tile: K and V fragments (B operands: key on the lane) ----------
-  const int kj = j0 + il;
-  typename M_::Frag kfB[NK], vfB[NK];
+  // ---- the workgroup's K and V tiles (rows jblk .. jblk + 32 FW; beyond Tk: zeros) --------------------------------------
+  {
+    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k), rsV = make_rsrc(hp.v);
+    T* kt0 = reinterpret_cast<T*>(smem + C_::kv_stage_bytes(REL));
+    constexpr int KPT = 32 * FW * PER_ROW / NTHR;   // pieces per thread and operand (= 4)
 #pragma unroll
-  for (int kk = 0; kk < NK; ++kk) {
-    kfB[kk] = frag_global<T>((const T*)hp.k, a.ldk, kj, live && kj < a.Tk, kk, lane, nullptr);
-    vfB[kk] = frag_global<T>((const T*)hp.v, a.ldv, kj, live && kj < a.Tk, kk, lane, nullptr);
+    for (int p = 0; p < KPT; ++p) {
+      const int pid = tid + NTHR * p, row = pid / PER_ROW, piece = (pid % PER_ROW) * VEC;
+      const bool ok = jblk + row < a.Tk;
+      const Vec16<T> kx = buf_load16<T>(rsK, ok ? (unsigned)(((long)(jblk + row) * a.ldk + piece) * sizeof(T)) : EMO_OOB);
+      const Vec16<T> vx = buf_load16<T>(rsV, ok ? (unsigned)(((long)(jblk + row) * a.ldv + piece) * sizeof(T)) : EMO_OOB);
+      store16(kt0 + row * LD + piece, kx);
+      store16(kt0 + (32 * FW + row) * LD + piece, vx);
+    }
   }
+  const int kj = j0 + il;
   f32x16 dk[2], dv[2];
   zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
   float csum = 0.f;  // sum over this lane's queries of dS[:, key kj]
@@ -2103,57 +2123,48 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   const bool kvalid = kj < hp.klen;
   const float c_exp = a.scale * 1.4426950408889634f;
   const unsigned keep_bits = __float_as_uint(a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f);
+  // the band skew as a lane rotation (ds_bpermute: no LDS storage): accumulator row rr + 4 hh of the band tiles G[query][c] gives
+  // its element c = 31 - (rr + 4 hh) + il to lane il -- from tile 0 (c < 32, i.e. il <= row) or tile 1, the same source lane
+  const int skew_base = il + 31 - 4 * hh;
 
   for (int step = 0; step < nstep; ++step) {
     const int i0 = step * 32;
     const T* Qus = stage0;
     const T* Qvs = stage0 + 32 * LD;
     const T* dOs = stage0 + (REL ? 64 : 32) * LD;
+    const T* Bs = stage0 + (96 + 32 * wave) * LD;  // this wave's 64 band rows (REL)
     EMO_STAMP(0);
     if (live) {
-      // this wave's 64 band rows of the projected position table (r = Tq - 32 - i0 + j0 + c): k-contiguous B operands straight
-      // from global memory (L2: the table of a segment is shared by all its workgroups).  Staged through LDS like the query-side
-      // tiles (20 more prefetch registers per thread) the kernel spills inside the sweep: 522 against 361 us at B 110, T' 320.
-      typename M_::Frag fb[2][NK];
-      if constexpr (REL) {
-        const int rbase = a.Tq - 32 - i0 + j0;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const int prow = rbase + 32 * ct + il;
-#pragma unroll
-          for (int kk = 0; kk < NK; ++kk)
-            fb[ct][kk] = frag_global<T>((const T*)hp.pos, a.ldp, prow, prow >= 0 && prow < 2 * a.Tq - 1, kk, lane, nullptr);
-        }
-      }
+      // (Requesting every LDS operand of a phase ahead of its MFMAs -- 64 fragment registers in flight -- was measured: 373 against
+      // 363 us at B 110, T' 320; the compiler's own placement, each read next to its MFMA, with the second wave of the SIMD
+      // covering the round trip, stays.)
       f32x16 s, dp;
       zero16(s); zero16(dp);
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) {
-        s = M_::mma(M_::load_kc(Qus, LD, 0, kk * M_::KSTEP, lane), kfB[kk], s);
-        dp = M_::mma(M_::load_kc(dOs, LD, 0, kk * M_::KSTEP, lane), vfB[kk], dp);
+        s = M_::mma(M_::load_kc(Qus, LD, 0, kk * M_::KSTEP, lane), M_::load_kc(Kt, LD, 0, kk * M_::KSTEP, lane), s);
+        dp = M_::mma(M_::load_kc(dOs, LD, 0, kk * M_::KSTEP, lane), M_::load_kc(Vt, LD, 0, kk * M_::KSTEP, lane), dp);
       }
       EMO_STAMP(1);
       if constexpr (REL) {
-        // band product G[query][band column c] = (Q+v) band^T, two 32-column tiles; element (i_l, j_l) of the score tile is
-        // G[i_l][31 - i_l + j_l]: a lane rotation per accumulator row, through the wave's f32 tile
+        // band product G[query][band column c] = (Q+v) band^T, two 32-column tiles
         f32x16 g0, g1;
         zero16(g0); zero16(g1);
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
           const typename M_::Frag fv = M_::load_kc(Qvs, LD, 0, kk * M_::KSTEP, lane);
-          g0 = M_::mma(fv, fb[0][kk], g0);
-          g1 = M_::mma(fv, fb[1][kk], g1);
+          g0 = M_::mma(fv, M_::load_kc(Bs, LD, 0, kk * M_::KSTEP, lane), g0);
+          g1 = M_::mma(fv, M_::load_kc(Bs + 32 * LD, LD, 0, kk * M_::KSTEP, lane), g1);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          Gs[c_row(r, lane) * 64 + il] = g0[r];
-          Gs[c_row(r, lane) * 64 + 32 + il] = g1[r];
-        }
-        __builtin_amdgcn_wave_barrier();
         EMO_STAMP(2);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] += Gs[c_row(r, lane) * 64 + 31 - c_row(r, lane) + il];
-        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2);
+          const int addr = (((skew_base - rr) & 31) + 32 * hh) * 4;
+          const float x0 = (dbg & 2) ? g0[r] : __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(g0[r])));
+          const float x1 = (dbg & 2) ? g1[r] : __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(g1[r])));
+          s[r] += (il <= rr + 4 * hh) ? x0 : x1;
+        }
       }
       EMO_STAMP(3);
       // soft-max, dropout, dS: accumulator rows 4 g .. 4 g + 3 are queries i0 + 8 g + 4 hh + 0 .. 3
@@ -2178,7 +2189,6 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
       }
       EMO_STAMP(4);
       // dV^T += dO^T P,  dK^T += (Q+u)^T dS: the accumulators are the B operands (query index in the registers)
-      __builtin_amdgcn_sched_barrier(0);   // (the eight transposed operand reads hoisted above the soft-max cost 32 registers: spills)
 #pragma unroll
       for (int ks = 0; ks < NS; ++ks) {
 #pragma unroll
@@ -2203,16 +2213,9 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   if (REL && a.dbias_u && live) {
     // dbias_u[d] += sum_j colsum_j K[j][d];  dbias_v[d] -= that (attn_bwd_q_kernel adds colsum(dQ): dbias_v = colsum(dQ) - dbias_u)
     csum += __shfl_xor(csum, 32, 64);
-    float* cs = Gs;
-    if (hh == 0) cs[il] = csum;
-    __builtin_amdgcn_wave_barrier();
-    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k);
     float acc = 0.f;
 #pragma unroll 8
-    for (int j = 0; j < 32; ++j) {
-      const int kr = j0 + j;
-      acc += cs[j] * buf_load_f32<T>(rsK, kr < a.Tk ? (unsigned)(((long)kr * a.ldk + lane) * sizeof(T)) : EMO_OOB);
-    }
+    for (int j = 0; j < 32; ++j) acc += __shfl(csum, j, 64) * (float)Kt[j * LD + lane];
     atomicAdd(&a.dbias_u[h * DK + lane], acc);
     atomicAdd(&a.dbias_v[h * DK + lane], -acc);
   }
@@ -2514,6 +2517,7 @@ int set_smem(K kernel, int bytes) {
 }
 
 int g_tr = 1;
+int g_kv_dbg = 0;     // option "attn_kv_dbg": timing ablations of attn_bwd_kv_kernel (results are then wrong)
 int g_bwd_split = 1;  // option "attn_bwd_split": the two-pass backward (attn_bwd_kv_kernel + attn_bwd_q_kernel); 0 = the single-pass kernel
 int g_fused_fw = 0;  // key tiles per workgroup of the single-pass backward (0 = by grid size; emoasr_set_option "attn_fw")
 
@@ -2786,7 +2790,7 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
   do {                                                                                                              \
     if (set_smem(attn_bwd_kv_kernel<T, TR_, REL_, FW>, SC::kv_smem(REL_))) return 1;                                \
     if (set_smem(attn_bwd_q_kernel<T, TR_, REL_, FW>, SC::q_smem(REL_))) return 1;                                  \
-    attn_bwd_kv_kernel<T, TR_, REL_, FW><<<gk, 64 * FW, SC::kv_smem(REL_), s>>>(a, ws, ntk);                        \
+    attn_bwd_kv_kernel<T, TR_, REL_, FW><<<gk, 64 * FW, SC::kv_smem(REL_), s>>>(a, ws, ntk, g_kv_dbg);                      \
     if (ws.stamp) ws.stamp += 64 * 13;                                                                              \
     attn_bwd_q_kernel<T, TR_, REL_, FW><<<gq, 64 * FW, SC::q_smem(REL_), s>>>(a, ws, ntq);                          \
   } while (0)
@@ -2913,6 +2917,7 @@ void emo_attn_set_fwd_split(int v) { g_fwd_split = v; }
 void emo_attn_set_xcd(int v) { g_attn_xcd = v; }
 void emo_attn_set_fwd_waves(int v) { g_fwd_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
 void emo_attn_set_bwd_split(int v) { g_bwd_split = v ? 1 : 0; }
+void emo_attn_set_kv_dbg(int v) { g_kv_dbg = v; }
 void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }
 
 extern "C" int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream) {
