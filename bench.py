@@ -407,6 +407,7 @@ def l4_rnnt(dev, dtype, steps=8, warmup=2, n_dec=5, accum=5):
     for grp in groups[:warmup]:
         step(grp)
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
     for grp in groups[warmup:]:
         loss = step(grp)
@@ -415,7 +416,9 @@ def l4_rnnt(dev, dtype, steps=8, warmup=2, n_dec=5, accum=5):
     frames = sum(sum(bt[1]) for grp in groups[warmup:] for bt in grp)
     out = dict(train_frames_per_s=frames / el, ms_per_step=1e3 * el / steps, frames_per_step=frames / steps, accum_grad=accum,
                stacked_encoder=bool(stacked), params_M=sum(p.numel() for p in model.parameters()) / 1e6,
-               final_loss=float(loss.detach()))
+               final_loss=float(loss.detach()),
+               # the output layer + transducer loss without the [B,T,U,V] logits (emoasr_rnnt_head_fwd / _grad)
+               fused_output_layer=bool(model.engine().rnnt_fused), peak_mem_GiB=torch.cuda.max_memory_allocated() / 2 ** 30)
     model.eval()
     rs2 = np.random.RandomState(4)
     pick = rs2.choice(len(xlens), n_dec, replace=False)
@@ -605,7 +608,7 @@ def main():
 
     from emoasr_amd import lib as emo_lib, ops
     from emoasr_amd.data import specaug_spans
-    from emoasr_amd.engine import h2d_i32
+    from emoasr_amd.engine import h2d_i32, h2d_pack
     from emoasr_amd.modeling.asr import ASR
     from emoasr_amd.train import ArenaAdam, noam_lr
 
@@ -634,11 +637,12 @@ def main():
         """one optimizer step: `accum` micro-batches (SpecAugment on the device each), gradients of loss / accum summed -- through
         the engine together when it can stack them (engine.ctc_train_stacked), else one after the other --, all-reduce, Adam"""
         datas = []
-        for bt in group:
+        # the SpecAugment span tables and lengths of all micro-batches of the step in one pinned upload
+        tabs = h2d_pack([torch.as_tensor(t, dtype=torch.int32) for bt in group
+                         for t in (specaug_spans(bt.xlens, 80, np_rng=np_rng, py_rng=py_rng), bt.xlens)], dev)
+        for k, bt in enumerate(group):
             xs = bt.xs.clone()
-            spans = h2d_i32(specaug_spans(bt.xlens, 80, np_rng=np_rng, py_rng=py_rng), dev)
-            xl = h2d_i32(bt.xlens, dev)
-            ops.specaug_apply(xs, spans, 2, 2, xl)
+            ops.specaug_apply(xs, tabs[2 * k], 2, 2, tabs[2 * k + 1])
             datas.append((xs, bt.xlens, bt.ys, bt.ylens))
         opt.zero_grad()
         if stacked:

@@ -42,6 +42,19 @@ struct BigDgrad {  // data gradient, one entry per output-parity class (pt, pf)
   int pt[4], pf[4], nI[4], nJ[4], ntap[4], M[4];
   int dh[4][4], dw[4][4], wtap[4][4];
 };
+// Transducer joint head without the [B,T,U,V] logits (rnn_transducer.py:101-115,147-156): epilogue modes of the plain product
+// z = h . W^T + bias over rows n = lattice cells (b, t, u).
+//   mode 1 (forward): nothing is stored but, per row and 64-column chunk, (max, sum exp(z - max)) -> part[n, chunk, 2], and the two
+//                     logits the lattice needs: zb[n] = z[n, blank], zy[n] = z[n, label(b, u)];
+//   mode 2 (gradient, rows of one chunk): C[n, v] = exp(z - lse[n]) * occ[n] - [v == blank] gb[n] - [v == y[n]] gy[n], the four
+//                     row constants (already scaled) in coef[n, 4], the label column in ycol[n].
+struct BigRnnt {
+  int mode, Tn, U, Lmax, blank, nchunk;
+  long row0;               // cell index of row 0 of this launch
+  const int* labels; const int* ylens;
+  float* part; float* zb; float* zy;
+  const float* coef; const int* ycol;
+};
 struct BigArgs {
   int M, N, K;
   const void* A; long lda;
@@ -50,6 +63,7 @@ struct BigArgs {
   const float* bias;
   int relu;
   emoasr_epilogue_t ep;  // AMODE 0 only: the general epilogue of emoasr_gemm_nt (no residual / dact_pre / f32 output)
+  BigRnnt rn;            // AMODE 0 only: transducer-head epilogues (mode 0 = off)
   const void* dmask;  // data gradient only, optional: multiply by (dmask[same offset as C] > 0)  (ReLU backward)
   int tiles_m, tiles_n;
   int korder;  // gathered modes: 1 = channel chunk outermost, taps innermost; 0 = tap-major
@@ -305,6 +319,79 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
     const emoasr_epilogue_t& ep = g.ep;
     bf16* Cp = static_cast<bf16*>(g.C);
     bf16* pre_out = static_cast<bf16*>(ep.pre_out);
+    if (g.rn.mode != 0) {
+      const BigRnnt& rn = g.rn;
+      const int chunk = ncol0 >> 6;
+#pragma unroll
+      for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(fslab + frow * FLD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int id = lane + 64 * hh, row = id >> 3, cc = id & 7;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(fslab + row * FLD + cc * 8);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(fslab + row * FLD + cc * 8 + 4);
+          const int grow = m0 + wr * (BM / 2) + i * 16 + row;
+          const int col = ncol0 + cc * 8;
+          const bool rok = grow < M, cok = col < g.N;   // (N % 8 == 0: a lane's eight columns are all inside or all outside)
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+          if (ep.bias && cok) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.bias + col);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(ep.bias + col + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+          }
+          if (rn.mode == 1) {
+            float m = -INFINITY, sm = 0.f;
+            if (cok) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) m = fmaxf(m, v[e]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) sm += __expf(v[e] - m);
+            }
+            // the eight lanes of a row (lane bits 0..2) hold its 64 columns of this wave's chunk
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+              const float mo = __shfl_xor(m, o, 64), so = __shfl_xor(sm, o, 64);
+              const float mn = fmaxf(m, mo);
+              sm = sm * (m == mn ? 1.f : __expf(m - mn)) + so * (mo == mn ? 1.f : __expf(mo - mn));
+              m = mn;
+            }
+            if (rok) {
+              if (cc == 0) {
+                float* pp = rn.part + ((long)grow * rn.nchunk + chunk) * 2;
+                pp[0] = m; pp[1] = sm;
+              }
+              if (cok) {
+                const int cell = (int)(rn.row0 + grow);
+                const int u = cell % rn.U, b = cell / (rn.Tn * rn.U);
+                const int y = u < rn.ylens[b] ? rn.labels[b * rn.Lmax + u] : -1;
+                const int kb = rn.blank - col, ky = y - col;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  if (kb == e) rn.zb[grow] = v[e];
+                  if (ky == e) rn.zy[grow] = v[e];
+                }
+              }
+            }
+          } else if (rok && cok) {
+            const f32x4 cf = *reinterpret_cast<const f32x4*>(rn.coef + (long)grow * 4);   // lse, occ, gb, gy (scaled)
+            const int kb = rn.blank - col, ky = rn.ycol[grow] - col;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float gq = __expf(v[e] - cf[0]) * cf[1];
+              if (kb == e) gq -= cf[2];
+              if (ky == e) gq -= cf[3];
+              v[e] = gq;
+            }
+            store8<bf16>(Cp + (long)grow * g.ldc + col, v);
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
 #pragma unroll
@@ -496,6 +583,45 @@ extern "C" int emoasr_gemm_nt_big(int dtype, int M, int N, int K, const void* A,
   emoasr_epilogue_t ep{};
   ep.alpha = 1.f; ep.bias = bias; ep.act = relu ? EMO_ACT_RELU : EMO_ACT_NONE; ep.res_scale = 1.f;
   return emo_gemm_nt_big_ep(M, N, K, A, lda, B, ldb, C, ldc, ep, (hipStream_t)stream);
+}
+
+static int rnnt_head_launch(int nrows, int V, int J, const void* h, const void* w, const float* bias, void* C, long ldc,
+                            const BigRnnt& rn, hipStream_t s) {
+  EMO_CHECK(nrows > 0 && V % 8 == 0 && V >= 64 && J % 64 == 0, "rnnt_head: needs V %% 8 == 0, J %% 64 == 0 (rows=%d V=%d J=%d)", nrows, V, J);
+  EMO_CHECK((long)nrows * J * 2 < (1L << 32) && (long)V * J * 2 < (1L << 32), "rnnt_head: operands must be < 4 GiB (chunk the rows)");
+  BigArgs a{};
+  a.M = nrows; a.N = V; a.K = J; a.A = h; a.lda = J; a.B = w; a.ldb = J; a.C = C; a.ldc = ldc;
+  a.ep.alpha = 1.f; a.ep.bias = bias; a.ep.res_scale = 1.f;
+  a.rn = rn;
+  const int bm = g_big_bm ? g_big_bm : pick_bm(nrows, n_cu_cached());
+  a.tiles_m = cdiv(nrows, bm); a.tiles_n = cdiv(V, 256);
+  return launch_big_bm<0>(a, bm, a.tiles_m * a.tiles_n, s);
+}
+
+// Forward of the transducer's output layer over lattice cells row0 .. row0 + nrows (h: their [nrows, J] joint activations):
+// part [nrows, ceil(V / 64), 2], zb / zy [nrows] (see BigRnnt).  The logits are never stored.
+extern "C" int emoasr_rnnt_head_fwd(int dtype, long row0, int nrows, int Tn, int U, int V, int J, int Lmax, const void* h,
+                                    const void* w, const float* bias, const int* labels, const int* ylens, int blank,
+                                    float* part, float* zb, float* zy, void* stream) {
+  EMO_CHECK(dtype == EMO_BF16, "rnnt_head_fwd: bf16 only");
+  if (nrows == 0) return 0;
+  EMO_CHECK(blank >= 0 && blank < V && row0 + nrows < (1L << 31), "rnnt_head_fwd: bad blank / cell range");
+  BigRnnt rn{};
+  rn.mode = 1; rn.Tn = Tn; rn.U = U; rn.Lmax = Lmax; rn.blank = blank; rn.nchunk = cdiv(V, 64); rn.row0 = row0;
+  rn.labels = labels; rn.ylens = ylens; rn.part = part; rn.zb = zb; rn.zy = zy;
+  return rnnt_head_launch(nrows, V, J, h, w, bias, nullptr, V, rn, (hipStream_t)stream);
+}
+
+// Gradient rows of the same layer, recomputed: dz[n, :] (bf16, row stride lddz) for the nrows cells whose constants are in
+// coef [nrows, 4] (lse, occ, gamma_blank, gamma_label -- already scaled, emoasr_rnnt_coef) and label columns in ycol [nrows].
+extern "C" int emoasr_rnnt_head_grad(int dtype, int nrows, int V, int J, const void* h, const void* w, const float* bias,
+                                     const float* coef, const int* ycol, int blank, void* dz, long lddz, void* stream) {
+  EMO_CHECK(dtype == EMO_BF16, "rnnt_head_grad: bf16 only");
+  if (nrows == 0) return 0;
+  EMO_CHECK(lddz % 8 == 0 && lddz >= V, "rnnt_head_grad: bad row stride");
+  BigRnnt rn{};
+  rn.mode = 2; rn.blank = blank; rn.nchunk = cdiv(V, 64); rn.coef = coef; rn.ycol = ycol;
+  return rnnt_head_launch(nrows, V, J, h, w, bias, dz, lddz, rn, (hipStream_t)stream);
 }
 
 // Conv2d forward through the large-tile kernel; called by emoasr_conv2_fwd (gemm.hip) for bf16, C % 256 == 0.

@@ -490,6 +490,82 @@ extern "C" int emoasr_rnnt_forward(int dtype, int B, int T_, int U, int V, int L
   return 0;
 }
 
+// lse / lpb / lpy of every lattice cell from the output layer's per-chunk partials (emoasr_rnnt_head_fwd); zb / zy come in as the
+// raw blank / label logits and leave as log-probabilities
+__global__ __launch_bounds__(256) void rnnt_parts_kernel(long rows, int Tn, int U, int nchunk, const float* __restrict__ part,
+                                                         const int* __restrict__ ylens, float* __restrict__ lse,
+                                                         float* __restrict__ zb, float* __restrict__ zy) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const float* pp = part + row * nchunk * 2;
+  float m = -INFINITY;
+  for (int c = 0; c < nchunk; ++c) m = fmaxf(m, pp[2 * c]);
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += pp[2 * c + 1] * __expf(pp[2 * c] - m);
+  const float l = m + logf(s);
+  const int u = row % U;
+  const long b = row / ((long)Tn * U);
+  lse[row] = l;
+  zb[row] = zb[row] - l;
+  zy[row] = u < ylens[b] ? zy[row] - l : -INFINITY;
+}
+
+// emoasr_rnnt_forward without the logits: part / zb / zy from emoasr_rnnt_head_fwd (zb, zy become lpb, lpy in place)
+extern "C" int emoasr_rnnt_forward_parts(int B, int T_, int U, int V, const float* part, const int* elens, const int* ylens,
+                                         float* lse, float* zb_lpb, float* zy_lpy, float* alpha, float* beta, float* nll,
+                                         void* stream) {
+  const long rows = (long)B * T_ * U;
+  if (rows == 0) return 0;
+  EMO_CHECK(U <= 1024, "rnnt: U=%d exceeds 1024 label positions", U);
+  hipStream_t s = (hipStream_t)stream;
+  rnnt_parts_kernel<<<cdiv(rows, 256), 256, 0, s>>>(rows, T_, U, cdiv(V, 64), part, ylens, lse, zb_lpb, zy_lpy);
+  rnnt_lattice_kernel<<<2 * B, cdiv(U, 64) * 64, sizeof(float) * 2 * (U + 2), s>>>(B, T_, U, zb_lpb, zy_lpy, elens, ylens, alpha,
+                                                                                   beta, nll);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
+// row constants of the output layer's gradient (what rnnt_grad_kernel forms per row): coef[n] = (lse, occ, gamma_blank,
+// gamma_label) * (1, gs, gs, gs), ycol[n] = the label column or -1; all zero outside (elens, ylens) and for infeasible utterances
+__global__ __launch_bounds__(256) void rnnt_coef_kernel(long rows, int Tn, int U, int Lmax, const float* __restrict__ lse,
+                                                        const float* __restrict__ lpb, const float* __restrict__ lpy,
+                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                        const int* __restrict__ labels, const int* __restrict__ elens,
+                                                        const int* __restrict__ ylens, const float* __restrict__ nll,
+                                                        float gscale, const float* __restrict__ gscale_dev,
+                                                        float* __restrict__ coef, int* __restrict__ ycol) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const int u = row % U;
+  const int t = (row / U) % Tn;
+  const long b = row / ((long)Tn * U);
+  const int Tb = min(elens[b], Tn), Ub = ylens[b];
+  const float nl = nll[b];
+  float occ = 0.f, gb = 0.f, gy = 0.f;
+  int y = -1;
+  if (t < Tb && u <= Ub && isfinite(nl)) {
+    const float gs = gscale_dev ? gscale * gscale_dev[0] : gscale;
+    const float a = alpha[row];
+    if (t == Tb - 1) { if (u == Ub) gb = __expf(a + lpb[row] + nl); }
+    else gb = __expf(a + lpb[row] + beta[row + U] + nl);
+    if (u < Ub) { y = labels[b * Lmax + u]; gy = __expf(a + lpy[row] + beta[row + 1] + nl); }
+    occ = (gb + gy) * gs; gb *= gs; gy *= gs;
+  }
+  *reinterpret_cast<f32x4*>(coef + row * 4) = f32x4{lse[row], occ, gb, gy};
+  ycol[row] = y;
+}
+
+extern "C" int emoasr_rnnt_coef(int B, int T_, int U, int Lmax, const float* lse, const float* lpb, const float* lpy,
+                                const float* alpha, const float* beta, const int* labels, const int* elens, const int* ylens,
+                                const float* nll, float gscale, const float* gscale_dev, float* coef, int* ycol, void* stream) {
+  const long rows = (long)B * T_ * U;
+  if (rows == 0) return 0;
+  rnnt_coef_kernel<<<cdiv(rows, 256), 256, 0, (hipStream_t)stream>>>(rows, T_, U, Lmax, lse, lpb, lpy, alpha, beta, labels, elens,
+                                                                    ylens, nll, gscale, gscale_dev, coef, ycol);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int emoasr_rnnt_grad(int dtype, int B, int T_, int U, int V, int Lmax, const void* logits, const float* lse,
                                 const float* lpb, const float* lpy, const float* alpha, const float* beta,
                                 const int* labels, const int* elens, const int* ylens, const float* nll, int blank,

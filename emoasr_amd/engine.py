@@ -200,6 +200,21 @@ class _DecoderMixinPlaceholder:
     pass
 
 
+def h2d_pack(arrays, device):
+    """several small host arrays (int32 / int64 / float32) -> device tensors through ONE pinned staging buffer and ONE asynchronous
+    H2D copy (every piece 8-byte aligned); the per-step index tables of a stacked pass were six copies of a few hundred bytes"""
+    ts = [torch.as_tensor(a).contiguous() for a in arrays]
+    offs, total = [], 0
+    for t in ts:
+        offs.append(total)
+        total += (t.numel() * t.element_size() + 7) // 8 * 8
+    host = torch.empty(max(total, 8), dtype=torch.uint8).pin_memory()
+    for t, o in zip(ts, offs):
+        host[o:o + t.numel() * t.element_size()] = t.view(-1).view(torch.uint8)
+    dev = host.to(device, non_blocking=True)
+    return [dev[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for t, o in zip(ts, offs)]
+
+
 def h2d_i32(values, device):
     """small host array -> int32 device tensor through pinned memory (asynchronous H2D)"""
     t = torch.as_tensor(values, dtype=torch.int32)
@@ -558,7 +573,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
                 and os.environ.get("EMOASR_CPP_BWD", "1") != "0" and self._implicit_dgrad and self._conv_big
                 and self.d % 256 == 0 and os.environ.get("EMOASR_STACKED", "1") != "0")
 
-    def _encoder_fwd_stacked(self, xs_list, xlens_list):
+    def _encoder_fwd_stacked(self, xs_list, xlens_list, elens_dev=None):
         """Conv2d front-end per micro-batch, everything after it over the stacked rows.
         -> (eouts [M, d], stash): segment k = rows st.rows[k] .. st.rows[k + 1] as [B_k, T_k, d]"""
         from . import lib
@@ -597,7 +612,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
         wlr = ops.strided_copy(wl.view(d, C, F2).permute(0, 2, 1), out_dtype=dt).view(d, F2 * C)
         x = ops.gemm_nt(y2, wlr, bias=A.p(pre + "output.bias"))
         elens_host = [((v - 1) // 2 - 1) // 2 for v in xlens_all]
-        elens = h2d_i32(elens_host, dev)
+        elens = elens_dev if elens_dev is not None else h2d_i32(elens_host, dev)
         s_pe = self._seed(1)
         x = ops.posenc(x.view(1, M, d), None, math.sqrt(d), p_enc, s_pe).view(M, d)
         # every micro-batch has its own relative-position table (rows <-> rel = T-1 ... -(T-1)), dropped out independently
@@ -679,9 +694,35 @@ class CTCEngine(_DecoderMixinPlaceholder):
         A = self.arena
         n = len(batches)
         scales = [1.0 / n] * n if scales is None else [float(v) for v in scales]
-        eouts, st = self._encoder_fwd_stacked([b[0] for b in batches], [b[1] for b in batches])
-        dev = eouts.device
+        # every index table of the pass (encoder lengths, labels, per-utterance rows / padded lengths / gradient scales) goes up
+        # in ONE pinned copy before the first kernel
+        dev = batches[0][0].device
+        segs_h, rows_h = [], [0]
+        for xs, _, _, _ in batches:
+            Bk, Tk, Fd = xs.shape
+            T1 = (Tk - 3) // 2 + 1
+            segs_h.append((Bk, (T1 - 3) // 2 + 1))
+            rows_h.append(rows_h[-1] + Bk * segs_h[-1][1])
+        elens_h = [((int(v) - 1) // 2 - 1) // 2 for b in batches for v in b[1]]
+        ylens_all = [int(v) for _, _, _, yl in batches for v in yl]
+        Lmax = max(max(ylens_all), 1)
+        lab = torch.zeros(sum(b for b, _ in segs_h), Lmax, dtype=torch.int32)
+        row0, tpad, uscale, b0 = [], [], [], 0
+        for k, (_, _, ys, ylens) in enumerate(batches):
+            B, T2 = segs_h[k]
+            yk = torch.as_tensor(ys)[:, :Lmax].to(torch.int32)
+            lab[b0:b0 + B, : yk.shape[1]] = yk
+            row0 += [rows_h[k] + b * T2 for b in range(B)]
+            tpad += [T2] * B
+            uscale += [scales[k] / B] * B
+            b0 += B
+        elens_d, labels, yl, row0_d, tpad_d, uscale_d = h2d_pack(
+            [torch.tensor(elens_h, dtype=torch.int32), lab, torch.tensor(ylens_all, dtype=torch.int32),
+             torch.tensor(row0, dtype=torch.int64), torch.tensor(tpad, dtype=torch.int32),
+             torch.tensor(uscale, dtype=torch.float32)], dev)
+        eouts, st = self._encoder_fwd_stacked([b[0] for b in batches], [b[1] for b in batches], elens_dev=elens_d)
         segs, rows, elens, Btot, Tmax = st.segs, st.rows, st.elens, st.Btot, st.Tmax
+        assert list(segs) == segs_h and list(rows) == rows_h
         # ---- vocabulary head over all rows; CTC lattices per micro-batch -----------------------------------------------
         w = A.w(head + ".weight")
         V = w.shape[0]
@@ -689,24 +730,6 @@ class CTCEngine(_DecoderMixinPlaceholder):
         logits = ops.gemm_nt(eouts, w, bias=A.p(head + ".bias"))
         lse = ops.row_lse(logits)
         dlogits = torch.empty_like(logits)
-        # all micro-batches' utterances in one set of launches: per-utterance first row / padded length / gradient scale
-        ylens_all = [int(v) for _, _, _, yl in batches for v in yl]
-        Lmax = max(max(ylens_all), 1)
-        lab = torch.zeros(Btot, Lmax, dtype=torch.int32)
-        row0, tpad, uscale, b0 = [], [], [], 0
-        for k, (_, _, ys, ylens) in enumerate(batches):
-            B, T2 = segs[k]
-            yk = torch.as_tensor(ys)[:, :Lmax].to(torch.int32)
-            lab[b0:b0 + B, : yk.shape[1]] = yk
-            row0 += [rows[k] + b * T2 for b in range(B)]
-            tpad += [T2] * B
-            uscale += [scales[k] / B] * B
-            b0 += B
-        labels = h2d_i32(lab, dev)
-        yl = h2d_i32(ylens_all, dev)
-        row0_d = torch.tensor(row0, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
-        tpad_d = h2d_i32(tpad, dev)
-        uscale_d = torch.tensor(uscale, dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
         lp, alpha, beta, nll = ops.ctc_forward_rows(logits, lse, labels, elens, yl, blank, row0_d, Tmax)
         nll0 = torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll))
         bounds = [0]
@@ -1206,6 +1229,10 @@ class _RNNTMixin:
         self.p_emb = float(_cfg(cfg, "dropout_emb_rate", 0.0))
         self.p_dec = float(_cfg(cfg, "dropout_dec_rate", 0.0))
         self.mtl_ctc = float(_cfg(cfg, "mtl_ctc_weight", 0.0))
+        # the output layer + transducer loss without the [B,T,U,V] logits (csrc/gemm_big.hip epilogues); EMOASR_RNNT_FUSED=0: the
+        # materialised path.  rnnt_chunk: lattice cells per gradient chunk of the backward
+        self.rnnt_fused = os.environ.get("EMOASR_RNNT_FUSED", "1") != "0"
+        self.rnnt_chunk = int(os.environ.get("EMOASR_RNNT_CHUNK", 65536))
 
     def _lstm_bias(self, name):
         A = self.arena
@@ -1286,8 +1313,14 @@ class _RNNTMixin:
             dy = ops.gemm_nn(dgp2, w_ih).view(U, B, nin)
         ops.embed_bwd(st.ids, dy, 1.0, A.g("decoder.embed.weight"), st.p_emb, st.s_emb)
 
-    def rnnt_forward(self, eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training):
-        """-> (loss_rnnt 0-dim, logits [B,T,U,V], stash)"""
+    def rnnt_fused_ok(self, h, w_out):
+        """can the output layer run without materialising the logits?  (bf16, V % 8 == 0, J % 64 == 0; EMOASR_RNNT_FUSED=0 or
+        engine.rnnt_fused = False select the materialised path)"""
+        return (self.rnnt_fused and h.dtype == torch.bfloat16 and w_out.shape[0] % 8 == 0 and w_out.shape[0] >= 64
+                and w_out.shape[1] % 64 == 0)
+
+    def rnnt_forward(self, eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training, want_logits=True):
+        """-> (loss_rnnt 0-dim, logits [B,T,U,V] (None on the fused path: want_logits=False), stash)"""
         with ops.stream_scope():
             A, J = self.arena, self.r_J
             B, T, d = eouts.shape
@@ -1299,14 +1332,22 @@ class _RNNTMixin:
             g_tm = ops.gemm_nt(douts.view(U * B, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
             g = ops.strided_copy(g_tm.view(U, B, J).permute(1, 0, 2))  # [B,U,J]
             h = ops.joint_tanh(e, g)
-            logits = ops.gemm_nt(h.view(B * T * U, J), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
-            logits = logits.view(B, T, U, -1)
             labels = torch.as_tensor(ys_host)[:, : max(U - 1, 1)].to(torch.int32)
             if labels.shape[1] < max(U - 1, 1):
                 labels = torch.nn.functional.pad(labels, (0, max(U - 1, 1) - labels.shape[1]))
             labels = h2d_i32(labels.contiguous(), dev)
             ylens = h2d_i32([int(v) for v in ylens_host], dev)
-            ctx, nll = ops.rnnt_forward(logits, labels, elens_dev, ylens, blank)
+            w_out = A.w("decoder.output.weight")
+            if want_logits or not self.rnnt_fused_ok(h, w_out):
+                logits = ops.gemm_nt(h.view(B * T * U, J), w_out, bias=A.p("decoder.output.bias"))
+                logits = logits.view(B, T, U, -1)
+                ctx, nll = ops.rnnt_forward(logits, labels, elens_dev, ylens, blank)
+            else:
+                # the output layer reduced in the GEMM's epilogue (csrc/gemm_big.hip): soft-max partials + the blank / label logits of
+                # every lattice cell; the [B,T,U,V] logits (0.9 GB per micro-batch at the L4 sizes) are never formed
+                logits = None
+                ctx, nll = ops.rnnt_head_forward(h.view(B * T * U, J), w_out, A.p("decoder.output.bias"), B, T, U, labels,
+                                                 elens_dev, ylens, blank)
             st = _Stash()
             st.rst, st.douts, st.h, st.logits, st.ctx, st.nll = rst, douts, h, logits, ctx, nll
             st.labels, st.elens, st.ylens, st.blank, st.eouts = labels, elens_dev, ylens, blank, eouts
@@ -1321,6 +1362,8 @@ class _RNNTMixin:
             A, J, H = self.arena, self.r_J, self.r_H
             A.attach_grads()
             B, T, U = st.B, st.T, st.U
+            if st.logits is None:
+                return self._rnnt_backward_fused(st, gscale_dev)
             dz = ops.rnnt_grad(st.logits, st.ctx, st.nll, st.labels, st.elens, st.ylens, st.blank, 1.0 / B, gscale_dev,
                                out=st.logits)
             if isinstance(extra_dlogits, tuple):  # (row indices, a few gradient rows)
@@ -1340,6 +1383,34 @@ class _RNNTMixin:
             ddouts = self._lin_bwd(dg_tm, st.douts.view(U * B, H), "decoder.w_dec.weight", "decoder.w_dec.bias")
             self.rnnt_recurrency_bwd(st.rst, ddouts.view(U, B, H))
             return deouts
+
+    def _rnnt_backward_fused(self, st, gscale_dev):
+        """backward of the fused output layer: the cells are walked in row chunks; per chunk the logits are recomputed and turned
+        into their gradient inside the GEMM's epilogue (emoasr_rnnt_head_grad), then consumed by the weight-gradient and the
+        data-gradient products.  The chunk buffer (RNNT_CHUNK rows x V, 128 MB at the L4 sizes) is the only [cells, V] storage."""
+        A, J, H = self.arena, self.r_J, self.r_H
+        B, T, U = st.B, st.T, st.U
+        N = B * T * U
+        w_out, b_out = A.w("decoder.output.weight"), A.p("decoder.output.bias")
+        V = w_out.shape[0]
+        coef, ycol = ops.rnnt_coef(st.ctx, st.nll, st.labels, st.elens, st.ylens, 1.0 / B, gscale_dev)
+        h2 = st.h.view(N, J)
+        dpre = torch.empty(N, J, device=h2.device, dtype=h2.dtype)
+        CH = min(N, self.rnnt_chunk)
+        dzc = torch.empty(CH, V, device=h2.device, dtype=h2.dtype)
+        for r0 in range(0, N, CH):
+            n = min(CH, N - r0)
+            dz = ops.rnnt_head_grad(h2[r0:r0 + n], w_out, b_out, coef[r0:r0 + n], ycol[r0:r0 + n], st.blank, dzc[:n])
+            ops.gemm_tn(dz, h2[r0:r0 + n], out=A.g("decoder.output.weight"), accumulate=True, colsum=A.g("decoder.output.bias"))
+            ops.gemm_nn(dz, w_out, out=dpre[r0:r0 + n], dact_pre=h2[r0:r0 + n], dact=ops.DACT_TANH_OUT)
+        de, dg = ops.joint_reduce(dpre.view(B, T, U, J))
+        d = st.eouts.shape[2]
+        deouts = self._lin_bwd(de.view(B * T, J), st.eouts.reshape(B * T, d), "decoder.w_enc.weight",
+                               "decoder.w_enc.bias").view(B, T, d)
+        dg_tm = ops.strided_copy(dg.permute(1, 0, 2)).view(U * B, J)
+        ddouts = self._lin_bwd(dg_tm, st.douts.view(U * B, H), "decoder.w_dec.weight", "decoder.w_dec.bias")
+        self.rnnt_recurrency_bwd(st.rst, ddouts.view(U, B, H))
+        return deouts
 
     def rnnt_greedy(self, eouts, elens_host, blank, eos, max_seq_len=256, window=64):
         """time-synchronous greedy search (rnn_transducer.py:194-240).  While the arg-max is blank the

@@ -253,6 +253,10 @@ SIGNATURES = {
     "emoasr_joint_reduce": [I, I, I, I, I, P, P, P, P],
     "emoasr_rnnt_forward": [I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P],
     "emoasr_rnnt_grad": [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, F, P, P, P],
+    "emoasr_rnnt_head_fwd": [I, L, I, I, I, I, I, I, P, P, P, P, P, I, P, P, P, P],
+    "emoasr_rnnt_forward_parts": [I, I, I, I, P, P, P, P, P, P, P, P, P, P],
+    "emoasr_rnnt_coef": [I, I, I, I, P, P, P, P, P, P, P, P, P, F, P, P, P, P],
+    "emoasr_rnnt_head_grad": [I, I, I, I, P, P, P, P, P, I, P, L, P],
     "emoasr_argmax_rows": [I, I, I, P, L, P, P],
     "emoasr_first_not_equal": [I, P, I, P, P],
     "emoasr_sqnorm": [L, P, P, P],

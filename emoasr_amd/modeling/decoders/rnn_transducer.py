@@ -48,6 +48,10 @@ class RNNTDecoder(nn.Module):
                 self.forced_aligner = RNNTForcedAligner(blank_id=self.blank_id)
             else:
                 raise NotImplementedError(f"emoasr_amd: unknown kd_type {self.kd_type!r}")
+        # the reference returns the joint logits [B,T,U,V] as the third value of forward(); nothing in its drivers reads them in
+        # training, and forming them costs 0.9 GB per micro-batch at the L4 sizes: in train mode they are None unless this is set
+        # (or distillation needs them); eval-mode forward returns them as the reference does
+        self.return_logits = False
         self._owner = None
 
     def forward(self, eouts, elens, eouts_inter=None, ys=None, ylens=None, ys_in=None, ys_out=None,

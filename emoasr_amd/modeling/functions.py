@@ -314,12 +314,15 @@ def attn_decoder_logits(dec, eouts, elens, ys_in, ylens):
 # ---------------------------------------------------------------------------------------
 class _RNNTFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, training, eouts, elens_dev, ys_host, ylens_host, ys_in, blank, kd, *params):
+    def forward(ctx, eng, training, eouts, elens_dev, ys_host, ylens_host, ys_in, blank, kd, want_logits, *params):
         """kd = None | (soft f32 [B,L,V] on the device, kd_weight, reduce_main_loss_kd): word-level distillation
         (rnn_transducer.py:127-141, criteria.py:218-247) of every lattice cell towards its label's soft target"""
         from .. import ops
         from ..criteria import rnnt_word_rows
-        loss_rnnt, logits, st = eng.rnnt_forward(eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training)
+        # the 4-D logits are formed only when something reads them: distillation, or a caller that asked for them
+        # (RNNTDecoder.return_logits); training without either runs the fused output layer and returns logits = None
+        loss_rnnt, logits, st = eng.rnnt_forward(eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training,
+                                                 want_logits=want_logits or kd is not None)
         cctx, loss = None, loss_rnnt
         if eng.mtl_ctc > 0:
             ctc_logits = eng.head_logits(eouts, "decoder.ctc.output")
@@ -354,6 +357,8 @@ class _RNNTFn(torch.autograd.Function):
             loss = ((1 - kd_w) * loss if reduce else loss) + kd_w * loss_kd
             ctx.kd = (soft, kd_w, (1 - kd_w) if reduce else 1.0, src, w, z, lrow)
         ctx.eng, ctx.st, ctx.cctx, ctx.eouts = eng, st, cctx, eouts
+        if logits is None:
+            logits = eouts.new_empty(0)   # (autograd outputs must be tensors; rnnt_apply turns it back into None)
         ctx.mark_non_differentiable(logits)
         return loss, loss_rnnt, loss_ctc, logits, loss_kd
 
@@ -374,7 +379,7 @@ class _RNNTFn(torch.autograd.Function):
             dcl = eng.ctc_grad(ctx.cctx, 1.0, g_ctc_eff)
             deouts = ops.add(deouts, eng.head_backward(ctx.eouts, dcl, "decoder.ctc.output"))
         ctx.st = ctx.cctx = ctx.kd = None
-        return (None, None, deouts, None, None, None, None, None, None) + (None,) * len(eng.arena.params)
+        return (None, None, deouts, None, None, None, None, None, None, None) + (None,) * len(eng.arena.params)
 
 
 def rnnt_apply(dec, eouts, elens, ys, ylens, ys_in, kd=None):
@@ -386,8 +391,11 @@ def rnnt_apply(dec, eouts, elens, ys, ylens, ys_in, kd=None):
     if kd is not None:
         kd = (torch.as_tensor(kd[0]).to(device=eouts.device, dtype=torch.float32).contiguous(), float(kd[1]), bool(kd[2]),
               kd[3])
-    return _RNNTFn.apply(eng, dec.training, eouts, _elens_dev(eouts, elens), ys_host, ylens_host, ys_in, dec.blank_id, kd,
-                         *eng.arena.params)
+    want_logits = bool(getattr(dec, "return_logits", False)) or not dec.training
+    out = _RNNTFn.apply(eng, dec.training, eouts, _elens_dev(eouts, elens), ys_host, ylens_host, ys_in, dec.blank_id, kd,
+                        want_logits, *eng.arena.params)
+    loss, loss_rnnt, loss_ctc, logits, loss_kd = out
+    return loss, loss_rnnt, loss_ctc, (logits if logits.numel() else None), loss_kd
 
 
 def rnnt_forced_align_apply(log_probs, elens, ys, ylens, blank):

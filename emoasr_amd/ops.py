@@ -840,6 +840,48 @@ def rnnt_forward(logits, labels, elens, ylens, blank):
     return (lse, lpb, lpy, alpha, beta), nll
 
 
+def rnnt_head_forward(h, w, bias, B, T, U, labels, elens, ylens, blank):
+    """the transducer's output layer + loss lattice WITHOUT the [B,T,U,V] logits: h [B*T*U, J] (bf16), w [V, J]
+    -> ctx tuple (lse, lpb, lpy, alpha, beta) f32 [B,T,U], nll f32 [B]   (as rnnt_forward)"""
+    N, J = h.shape
+    V = w.shape[0]
+    dev = h.device
+    nchunk = (V + 63) // 64
+    part = torch.empty(N, nchunk, 2, device=dev, dtype=torch.float32)
+    f = lambda: torch.empty(B, T, U, device=dev, dtype=torch.float32)
+    lse, zb, zy, alpha, beta = f(), f(), f(), f(), f()
+    zy.fill_(0.0)   # (cells beyond ylens never get a label logit)
+    step = max(1, min(N, ((1 << 31) // (J * 2)) // 256 * 256))   # rows per launch: the operand stays below 4 GiB
+    for r0 in range(0, N, step):
+        n = min(step, N - r0)
+        lib.call("emoasr_rnnt_head_fwd", dt(h), r0, n, T, U, V, J, labels.shape[1], _p(h[r0:r0 + n]), _p(w), _p(bias), _p(labels),
+                 _p(ylens), blank, _p(part[r0:r0 + n]), _p(zb.view(-1)[r0:r0 + n]), _p(zy.view(-1)[r0:r0 + n]), _stream())
+    nll = torch.empty(B, device=dev, dtype=torch.float32)
+    lib.call("emoasr_rnnt_forward_parts", B, T, U, V, _p(part), _p(elens), _p(ylens), _p(lse), _p(zb), _p(zy), _p(alpha),
+             _p(beta), _p(nll), _stream())
+    return (lse, zb, zy, alpha, beta), nll
+
+
+def rnnt_coef(ctx, nll, labels, elens, ylens, gscale, gscale_dev=None):
+    """per-cell constants of the output layer's gradient -> coef f32 [cells, 4], ycol int32 [cells]"""
+    lse, lpb, lpy, alpha, beta = ctx
+    B, T, U = lse.shape
+    coef = torch.empty(B * T * U, 4, device=lse.device, dtype=torch.float32)
+    ycol = torch.empty(B * T * U, device=lse.device, dtype=torch.int32)
+    lib.call("emoasr_rnnt_coef", B, T, U, labels.shape[1], _p(lse), _p(lpb), _p(lpy), _p(alpha), _p(beta), _p(labels), _p(elens),
+             _p(ylens), _p(nll), gscale, _p(gscale_dev), _p(coef), _p(ycol), _stream())
+    return coef, ycol
+
+
+def rnnt_head_grad(h, w, bias, coef, ycol, blank, out):
+    """out [n, V] (bf16) = gradient rows of the output layer for the cells of h [n, J], logits recomputed"""
+    n, J = h.shape
+    V = w.shape[0]
+    lib.call("emoasr_rnnt_head_grad", dt(h), n, V, J, _p(h), _p(w), _p(bias), _p(coef), _p(ycol), blank, _p(out), out.stride(0),
+             _stream())
+    return out
+
+
 def rnnt_grad(logits, ctx, nll, labels, elens, ylens, blank, gscale, gscale_dev=None, out=None):
     B, T, U, V = logits.shape
     lse, lpb, lpy, alpha, beta = ctx

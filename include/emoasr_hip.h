@@ -457,6 +457,29 @@ int emoasr_rnnt_grad(int dtype, int B, int T, int U, int V, int Lmax, const void
                      const float* lpb, const float* lpy, const float* alpha, const float* beta, const int* labels,
                      const int* elens, const int* ylens, const float* nll, int blank, float gscale,
                      const float* gscale_dev, void* dlogits, void* stream);
+/* The transducer's output layer WITHOUT the [B,T,U,V] logits (csrc/gemm_big.hip epilogues + csrc/rnnt.hip; bf16, V % 8 == 0,
+ * J % 64 == 0).  Replaces `self.output(torch.tanh(...))` + `log_softmax` + warp_rnnt's gathers of rnn_transducer.py:101-115,
+ * 147-156 for training: z = h . W^T + bias is formed tile by tile on the MFMA pipeline and reduced in the epilogue.
+ *   emoasr_rnnt_head_fwd   cells row0 .. row0 + nrows (h: their joint activations [nrows, J]): per row and 64-column chunk the
+ *                          soft-max partials part[n, c] = (max, sum exp(z - max)) -- part [nrows, ceil(V / 64), 2] -- and the two
+ *                          logits the lattice reads, zb[n] = z[n, blank], zy[n] = z[n, labels[b, u]] (u < ylens[b]);
+ *   emoasr_rnnt_forward_parts   lse from the partials, zb / zy turned into lpb / lpy IN PLACE, then the alpha / beta lattices and
+ *                          nll exactly as emoasr_rnnt_forward;
+ *   emoasr_rnnt_coef       the per-cell constants of the gradient (coef [cells, 4] = lse, occ, gamma_blank, gamma_label, the last
+ *                          three times gscale [* gscale_dev]; ycol [cells] = label column or -1; zeros outside (elens, ylens));
+ *   emoasr_rnnt_head_grad  dz[n, :] = exp(z - lse) occ - [blank] gamma_b - [label] gamma_y for the nrows cells of one row chunk,
+ *                          z RECOMPUTED from h: the caller walks the cells in chunks (dz chunk -> emoasr_gemm_tn / _nn), so no
+ *                          [cells, V] buffer exists in either direction. */
+int emoasr_rnnt_head_fwd(int dtype, long row0, int nrows, int T, int U, int V, int J, int Lmax, const void* h, const void* w,
+                         const float* bias, const int* labels, const int* ylens, int blank, float* part, float* zb, float* zy,
+                         void* stream);
+int emoasr_rnnt_forward_parts(int B, int T, int U, int V, const float* part, const int* elens, const int* ylens, float* lse,
+                              float* zb_lpb, float* zy_lpy, float* alpha, float* beta, float* nll, void* stream);
+int emoasr_rnnt_coef(int B, int T, int U, int Lmax, const float* lse, const float* lpb, const float* lpy, const float* alpha,
+                     const float* beta, const int* labels, const int* elens, const int* ylens, const float* nll, float gscale,
+                     const float* gscale_dev, float* coef, int* ycol, void* stream);
+int emoasr_rnnt_head_grad(int dtype, int nrows, int V, int J, const void* h, const void* w, const float* bias, const float* coef,
+                          const int* ycol, int blank, void* dz, long lddz, void* stream);
 /* out[m] = argmax_v x[m,:V] (first maximum) */
 int emoasr_argmax_rows(int dtype, int M, int V, const void* x, long ldx, int* out, void* stream);
 /* out[0] = first i < n with x[i] != value (-1: none), out[1] = x[that i] (value: none) -- the windowed greedy

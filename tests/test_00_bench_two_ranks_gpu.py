@@ -54,7 +54,8 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     for r, (p, e) in enumerate(zip(procs, errs)):
         assert p.returncode == 0, f"rank {r} failed:\n{e[-3000:]}"
     lines = [ln for ln in open(str(tmp_path / "rank0.out")).read().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and not open(str(tmp_path / "rank1.out")).read().strip()   # rank 0 prints ONE line
+    # rank 0 prints ONE JSON line, rank 1 none (gloo itself may print a connection notice)
+    assert len(lines) == 1 and not [ln for ln in open(str(tmp_path / "rank1.out")).read().splitlines() if ln.startswith("{")]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and res["value"] > 0
     dp = res["dp"]

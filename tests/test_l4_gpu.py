@@ -175,3 +175,97 @@ def test_train_loss_and_grads(dev, dtype):
         assert worst < 1e-2, (worst, worst_name)
     else:
         assert cos_min > 0.97, (cos_min, cos_name, worst, worst_name)
+
+
+def test_fused_output_layer_against_oracle_and_materialised_path(dev):
+    """The transducer's output layer without the [B,T,U,V] logits (ops.rnnt_head_forward / rnnt_coef / rnnt_head_grad: soft-max
+    partials and the blank / label gathers in the GEMM's epilogue, the gradient rows recomputed chunk by chunk) at the L4 widths
+    (J = 512, V = 1000), ragged lengths, an utterance without labels and one frame-starved (infeasible) utterance:
+    (a) kernel level against the ORACLE (oracle/rnnt.py on f32 logits = h W^T + b): nll 2e-3, d(loss)/d(logits) rows 3e-3 of
+        the largest entry -- the fused path reduces f32 accumulators, it never rounds the logits to bf16;
+    (b) engine level against the materialised path on the same model: losses 2e-3, every decoder / encoder gradient cosine
+        0.999, the gradient walked in six chunks + a remainder; the training forward returns logits = None and its peak
+        memory stays below the materialised path's by most of the logits tensor's size (what replaces it: the 2048-row gradient
+        chunk, the soft-max partials and the row constants).
+    Reference: asr/modeling/decoders/rnn_transducer.py:101-115,147-156."""
+    from emoasr_amd import ops
+    from emoasr_amd.modeling.asr import ASR
+    from oracle import rnnt as orn
+    torch.manual_seed(0)
+    # ---- (a) kernels
+    B, T, L, V, J = 4, 37, 9, 1000, 512
+    U = L + 1
+    h = torch.tanh(torch.randn(B * T * U, J)).to(torch.bfloat16)
+    w = (torch.randn(V, J) / J ** 0.5 * 3).to(torch.bfloat16)
+    bias = torch.randn(V) * 0.5
+    bias[0] += 2.0
+    labels = torch.randint(1, V, (B, L))
+    elens, ylens = torch.tensor([37, 30, 11, 2]), torch.tensor([9, 5, 0, 7])   # the last one: 2 frames for 7 labels is FEASIBLE in a
+    # transducer (labels are emitted without consuming frames); an empty utterance (elens 0) is covered by test_rnnt_lattice_kernel
+    z = (h.float() @ w.float().t() + bias).view(B, T, U, V).requires_grad_(True)
+    nll_ref = orn.rnnt_nll(torch.log_softmax(z, -1), labels, elens, ylens, 0)
+    nll_ref.mean().backward()
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    hd, wd, bd = h.to(dev), w.to(dev), bias.to(dev)
+    with ops.stream_scope():
+        ctx, nll = ops.rnnt_head_forward(hd, wd, bd, B, T, U, i32(labels), i32(elens), i32(ylens), 0)
+        coef, ycol = ops.rnnt_coef(ctx, nll, i32(labels), i32(elens), i32(ylens), 1.0 / B)
+        dz = torch.full((B * T * U, V), float("nan"), device=dev, dtype=torch.bfloat16)
+        for r0 in range(0, B * T * U, 500):   # uneven chunks
+            n = min(500, B * T * U - r0)
+            ops.rnnt_head_grad(hd[r0:r0 + n], wd, bd, coef[r0:r0 + n], ycol[r0:r0 + n], 0, dz[r0:r0 + n])
+    assert torch.allclose(nll.cpu(), nll_ref.detach(), rtol=2e-3, atol=2e-3), (nll, nll_ref)
+    err = (dz.float().cpu().view(B, T, U, V) - z.grad).abs().max().item() / z.grad.abs().max().item()
+    print(f"[measured] fused transducer head: nll {nll.tolist()} vs {nll_ref.tolist()}, gradient rows max err {err:.2e} of max")
+    assert err < 3e-3, err
+    # ---- (b) engine: fused against materialised
+    cfg = dict(input_layer="conv2d", feat_dim=80, num_framestacks=1, encoder_type="conformer", pos_encode_type="rel",
+               enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=2, enc_intermediate_size=512,
+               dropout_enc_rate=0.0, dropout_attn_rate=0.0, vocab_size=1000, blank_id=0, eos_id=2, kd_weight=0,
+               decoder_type="rnn_transducer", embedding_size=256, dec_hidden_size=512, dec_num_layers=2, joint_hidden_size=512,
+               dropout_emb_rate=0.0, dropout_dec_rate=0.0, mtl_ctc_weight=0.3, lsm_prob=0.0)
+    model = ASR(SimpleNamespace(**cfg), compute_dtype=torch.bfloat16).to(dev).train()
+    eng = model.engine()
+    g = torch.Generator().manual_seed(5)
+    xlens, yl = torch.tensor([403, 363, 303, 250, 203, 99]), torch.tensor([20, 12, 10, 9, 1, 4])
+    xs = torch.randn(6, 403, 80, generator=g)
+    ys = torch.randint(3, 1000, (6, 20), generator=g)
+    for b in range(6):
+        xs[b, xlens[b]:] = 0
+        ys[b, yl[b]:] = 2
+    eos = torch.full((6, 1), 2)
+    ys_in, ys_out = torch.cat([eos, ys], 1), torch.cat([ys, eos], 1)
+    res = {}
+    for fused in (False, True):
+        eng.rnnt_fused, eng.rnnt_chunk = fused, 2048    # cells: 6 x 100 x 21 = 12 600 -> six chunks + a remainder
+        eng.arena.grad.zero_()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        loss, ld = model(xs.to(dev), xlens, ys, yl, ys_in, ys_out)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[fused] = ({k: float(v) for k, v in ld.items()}, eng.arena.grad.clone(), torch.cuda.max_memory_allocated() - base)
+    (l0, g0, m0), (l1, g1, m1) = res[False], res[True]
+    for k in l0:
+        assert abs(l0[k] - l1[k]) < 2e-3 * abs(l0[k]) + 1e-4, (k, l0, l1)
+    A = eng.arena
+    gmax = g0.abs().max().item()
+    for name in A.names:
+        o, k = A.offsets[name], A.pviews[name].numel()
+        a, b_ = g1[o:o + k], g0[o:o + k]
+        if b_.abs().max() < 1e-3 * gmax:
+            assert a.abs().max() < 4e-3 * gmax, name
+            continue
+        cos = (torch.dot(a, b_) / (a.norm() * b_.norm() + 1e-30)).item()
+        assert cos > 0.999, (name, cos)
+    logits_bytes = 6 * 100 * 21 * 1000 * 2
+    print(f"[measured] peak memory of one training step: materialised {m0 / 1e6:.1f} MB, fused {m1 / 1e6:.1f} MB "
+          f"(the logits tensor: {logits_bytes / 1e6:.1f} MB)")
+    assert m1 < m0 - 0.7 * logits_bytes, (m0, m1, logits_bytes)
+    eng.rnnt_fused = True
+    out = model.decoder(*model.encoder(xs.to(dev), xlens)[:2], None, ys, yl, ys_in, ys_out)
+    assert out[2] is None                      # training forward: no 4-D logits
+    model.decoder.return_logits = True
+    out = model.decoder(*model.encoder(xs.to(dev), xlens)[:2], None, ys, yl, ys_in, ys_out)
+    assert out[2] is not None and tuple(out[2].shape) == (6, 100, 21, 1000)
