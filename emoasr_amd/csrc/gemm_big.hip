@@ -47,7 +47,9 @@ struct BigDgrad {  // data gradient, one entry per output-parity class (pt, pf)
 //   mode 1 (forward): nothing is stored but, per row and 64-column chunk, (max, sum exp(z - max)) -> part[n, chunk, 2], and the two
 //                     logits the lattice needs: zb[n] = z[n, blank], zy[n] = z[n, label(b, u)];
 //   mode 2 (gradient, rows of one chunk): C[n, v] = exp(z - lse[n]) * occ[n] - [v == blank] gb[n] - [v == y[n]] gy[n], the four
-//                     row constants (already scaled) in coef[n, 4], the label column in ycol[n].
+//                     row constants (already scaled) in coef[n, 4], the label column in ycol[n];
+//   mode 3 (CTC head): the product is stored AND the partials of mode 1 are produced (of the values as rounded to bf16): the
+//                     vocabulary projection and the soft-max denominators in one pass over the logits.
 struct BigRnnt {
   int mode, Tn, U, Lmax, blank, nchunk;
   long row0;               // cell index of row 0 of this launch
@@ -343,7 +345,14 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
           }
-          if (rn.mode == 1) {
+          if (rn.mode == 3 && cok) {
+            // (the partials must describe the logits AS STORED: round to the output type first, so that exp(z - lse) of the stored
+            // row sums to one exactly as after a separate row pass)
+            if (rok) store8<bf16>(Cp + (long)grow * g.ldc + col, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)(bf16)v[e];
+          }
+          if (rn.mode == 1 || rn.mode == 3) {
             float m = -INFINITY, sm = 0.f;
             if (cok) {
 #pragma unroll
@@ -360,11 +369,11 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
               m = mn;
             }
             if (rok) {
-              if (cc == 0) {
+              if (cc == 0 && chunk < rn.nchunk) {   // (the last column tile may reach past ceil(N / 64) chunks)
                 float* pp = rn.part + ((long)grow * rn.nchunk + chunk) * 2;
                 pp[0] = m; pp[1] = sm;
               }
-              if (cok) {
+              if (cok && rn.mode == 1) {
                 const int cell = (int)(rn.row0 + grow);
                 const int u = cell % rn.U, b = cell / (rn.Tn * rn.U);
                 const int y = u < rn.ylens[b] ? rn.labels[b * rn.Lmax + u] : -1;
@@ -610,6 +619,38 @@ extern "C" int emoasr_rnnt_head_fwd(int dtype, long row0, int nrows, int Tn, int
   rn.mode = 1; rn.Tn = Tn; rn.U = U; rn.Lmax = Lmax; rn.blank = blank; rn.nchunk = cdiv(V, 64); rn.row0 = row0;
   rn.labels = labels; rn.ylens = ylens; rn.part = part; rn.zb = zb; rn.zy = zy;
   return rnnt_head_launch(nrows, V, J, h, w, bias, nullptr, V, rn, (hipStream_t)stream);
+}
+
+__global__ __launch_bounds__(256) void lse_parts_kernel(long rows, int nchunk, const float* __restrict__ part, float* __restrict__ lse) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const float* pp = part + row * nchunk * 2;
+  float m = -INFINITY;
+  for (int c = 0; c < nchunk; ++c) m = fmaxf(m, pp[2 * c]);
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += pp[2 * c + 1] * __expf(pp[2 * c] - m);
+  lse[row] = m + logf(s);
+}
+
+// C[M,N] = A . B^T + bias (bf16) AND lse[m] = log sum_n exp(C[m,n]) of the stored row, in one pass: the soft-max partials leave the
+// product's epilogue (part: scratch [M, ceil(N / 64), 2] f32).  The CTC head (decoders/ctc.py:103-113: Linear + log_softmax)
+// without the separate pass that read the 703 MB of logits back.
+extern "C" int emoasr_gemm_nt_lse(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                                  const float* bias, float* part, float* lse, void* stream) {
+  EMO_CHECK(dtype == EMO_BF16, "gemm_nt_lse: bf16 only");
+  if (M == 0) return 0;
+  EMO_CHECK(N % 8 == 0 && N >= 64 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "gemm_nt_lse: needs N %% 8 == 0, K %% 64 == 0");
+  EMO_CHECK((long)M * lda * 2 < (1L << 32) && (long)N * ldb * 2 < (1L << 32), "gemm_nt_lse: operands must be < 4 GiB");
+  BigArgs a{};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.ep.alpha = 1.f; a.ep.bias = bias; a.ep.res_scale = 1.f;
+  a.rn.mode = 3; a.rn.nchunk = cdiv(N, 64); a.rn.part = part;
+  const int bm = g_big_bm ? g_big_bm : pick_bm(M, n_cu_cached());
+  a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(N, 256);
+  if (launch_big_bm<0>(a, bm, a.tiles_m * a.tiles_n, (hipStream_t)stream)) return 1;
+  lse_parts_kernel<<<cdiv(M, 256), 256, 0, (hipStream_t)stream>>>(M, a.rn.nchunk, part, lse);
+  EMO_LAUNCH_CHECK();
+  return 0;
 }
 
 // Gradient rows of the same layer, recomputed: dz[n, :] (bf16, row stride lddz) for the nrows cells whose constants are in

@@ -727,8 +727,8 @@ class CTCEngine(_DecoderMixinPlaceholder):
         w = A.w(head + ".weight")
         V = w.shape[0]
         assert V % 8 == 0, "ctc_train_stacked: vocabulary must be a multiple of 8"
-        logits = ops.gemm_nt(eouts, w, bias=A.p(head + ".bias"))
-        lse = ops.row_lse(logits)
+        # the vocabulary projection with the soft-max denominators out of its epilogue: one pass over the 703 MB of logits
+        logits, lse = ops.gemm_nt_lse(eouts, w, A.p(head + ".bias"))
         dlogits = torch.empty_like(logits)
         lp, alpha, beta, nll = ops.ctc_forward_rows(logits, lse, labels, elens, yl, blank, row0_d, Tmax)
         nll0 = torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll))

@@ -228,6 +228,7 @@ SIGNATURES = {
     "emoasr_posenc": [I, I, I, I, P, P, F, F, U64, P, P],
     "emoasr_add": [I, L, P, P, P, P],
     "emoasr_row_lse": [I, I, I, P, L, P, P],
+    "emoasr_gemm_nt_lse": [I, I, I, I, P, L, P, L, P, L, P, P, P, P],
     "emoasr_ctc_forward": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, P],
     "emoasr_ctc_grad": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, F, P, P, L, P],
     "emoasr_rnnt_greedy": [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P],

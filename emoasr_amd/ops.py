@@ -576,6 +576,23 @@ def add(a, b):
 
 
 # ---- CTC -------------------------------------------------------------------------------
+def gemm_nt_lse(a, b, bias):
+    """logits = a @ b^T + bias and their row log-sum-exp in ONE pass over the logits (the CTC head: emoasr_gemm_nt_lse) when the
+    large-tile kernel takes the shape (bf16, N % 8 == 0, K % 64 == 0, operands below 4 GiB); else the product + a row pass"""
+    M, K, lda = _rows(_chk(a))
+    N, Kb, ldb = _rows(_chk(b, a.dtype))
+    assert K == Kb
+    if (a.dtype == torch.bfloat16 and N % 8 == 0 and N >= 256 and K % 64 == 0 and lda % 8 == 0 and ldb % 8 == 0
+            and M * lda * 2 < (1 << 32) and N * ldb * 2 < (1 << 32) and M >= 2048):
+        out = torch.empty(M, N, device=a.device, dtype=a.dtype)
+        part = torch.empty(M, (N + 63) // 64, 2, device=a.device, dtype=torch.float32)
+        lse = torch.empty(M, device=a.device, dtype=torch.float32)
+        lib.call("emoasr_gemm_nt_lse", dt(a), M, N, K, _p(a), lda, _p(b), ldb, _p(out), N, _p(bias), _p(part), _p(lse), _stream())
+        return out, lse
+    out = gemm_nt(a, b, bias=bias)
+    return out, row_lse(out)
+
+
 def row_lse(logits):
     M, V, ld = _rows(_chk(logits))
     lse = torch.empty(M, device=logits.device, dtype=torch.float32)

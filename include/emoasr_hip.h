@@ -330,6 +330,11 @@ int emoasr_add(int dtype, long n, const void* a, const void* b, void* y, void* s
 /* ---- CTC (decoders/ctc.py:36-38,103-115,176-201; torch.nn.CTCLoss semantics) -- */
 /* lse[m] = logsumexp_v logits[m,:V] */
 int emoasr_row_lse(int dtype, int M, int V, const void* logits, long ld, float* lse, void* stream);
+/* The CTC head in one pass (csrc/gemm_big.hip; bf16, N % 8 == 0, K % 64 == 0): C = A . B^T + bias stored AND lse[m] = log sum_n
+ * exp(C[m,n]) of the row as stored -- the soft-max partials leave the product's epilogue (part: scratch [M, ceil(N / 64), 2] f32)
+ * instead of a second pass over the logits (emoasr_gemm_nt + emoasr_row_lse).  decoders/ctc.py:103-113. */
+int emoasr_gemm_nt_lse(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                       const float* bias, float* part, float* lse, void* stream);
 /* Forward-backward lattices.  S = 2*Lmax+1 states.  lp (scratch), alpha, beta: f32 [B,T,S];
  * nll[b] = -log p(labels_b | x_b) (+inf if infeasible).  alpha and beta both include the
  * emission at t, so occupancy(t,s) = exp(alpha+beta-lp+nll). */

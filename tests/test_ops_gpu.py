@@ -584,6 +584,27 @@ def test_attention_bwd_fused_run_to_run(dev):
         lib.set_option("attn_bwd_split", 1)
 
 
+def test_gemm_nt_lse_is_the_product_plus_the_row_pass(dev):
+    """emoasr_gemm_nt_lse (the CTC head in one pass over the logits: soft-max partials out of the product's epilogue) against
+    emoasr_gemm_nt + a torch log-sum-exp of the STORED rows: logits bit-identical, lse to 2e-6 relative (the partials are taken
+    of the values as rounded to bf16, so exp(z - lse) of a stored row sums to one), ragged M and a vocabulary that is not a
+    multiple of the 256-column tile"""
+    from emoasr_amd import ops
+    torch.manual_seed(3)
+    for M, N, K in [(4099, 10000, 256), (2500, 1000, 512)]:
+        a = _rnd(dev, M, K, dtype=torch.bfloat16)
+        w = (_rnd(dev, N, K) * 0.2).to(torch.bfloat16)
+        bias = _rnd(dev, N)
+        with ops.stream_scope():
+            want = ops.gemm_nt(a, w, bias=bias)
+            got, lse = ops.gemm_nt_lse(a, w, bias)
+        assert torch.equal(got, want), (M, N, K)
+        ref = torch.logsumexp(got.float(), -1)
+        err = ((lse - ref).abs() / ref.abs().clamp(min=1)).max().item()
+        assert err < 2e-6, (M, N, K, err)
+        assert abs(torch.exp(got.float() - lse[:, None]).sum(-1) - 1).max().item() < 1e-4
+
+
 # ---------------------------------------------------------------- conv module
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_glu(dev, dtype):
