@@ -46,7 +46,7 @@ def fwd_flops_per_utt(T, F=1024, V=10000, d=256, layers=12):
     return conv1 + conv2 + lin + layers * layer + head
 
 
-PMC_FILE = os.path.join("profiles", "r03_pmc.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc.json")
 
 
 def pmc_kernel(kernel, key):
@@ -90,7 +90,7 @@ def cpu_model():
 # kernel families timed inside the library (emoasr_timer_read_ex); value: the kernel-table symbol(s) of profiles/*_kernel_stats.csv
 FAMILIES = {"gemm_nt_nn": "gemm_nt_kernel / gemm_nn (big_nt_kernel for wide products): forward and data-gradient products",
             "gemm_tn": "gemm_tn_grouped_kernel / gemm_tn_kernel: weight gradients",
-            "attn_bwd_fused_kernel": "attn_bwd_fused_kernel", "attn_bwd_dpos2_kernel": "attn_bwd_dpos2_kernel",
+            "attn_bwd_fused_kernel": "attn_dropmask_kernel + attn_bwd_kv_kernel + attn_bwd_q_kernel (the two-pass backward; the family keeps its round-2 timer name)", "attn_bwd_dpos2_kernel": "attn_bwd_dpos2_kernel",
             "attn_fwd_kernel": "attn_fwd_kernel", "layernorm": "ln_fwd_kernel + ln_bwd8_kernel",
             "conv_module": "cf_dwconv / bn_* / cf_conv_bwd kernels (convolution module, per-utterance part)"}
 RIDGE_FLOP_PER_BYTE = 2500e12 / 8000e9  # bf16 dense MFMA peak / HBM peak

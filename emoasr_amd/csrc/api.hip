@@ -29,6 +29,7 @@ void emo_gemm_set_big_min_tiles(int v);
 void emo_conv_set_dwconv_lds(int v);
 void emo_layer_set_conv_fused(int v);
 void emo_layer_set_stack_launch(int v);
+void emo_layer_set_ffn_save_dact(int v);
 void emo_rnnt_set_greedy_coop(int v);
 #ifdef EMOASR_EXPERIMENTAL
 void emo_gemm_set_k256(int v);
@@ -140,6 +141,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "dwconv_lds") == 0) { emo_conv_set_dwconv_lds(value); return 0; }
   if (strcmp(name, "conv_fused") == 0) { emo_layer_set_conv_fused(value); return 0; }
   if (strcmp(name, "stack_launch") == 0) { emo_layer_set_stack_launch(value); return 0; }
+  if (strcmp(name, "ffn_save_dact") == 0) { emo_layer_set_ffn_save_dact(value); return 0; }
   if (strcmp(name, "rnnt_greedy_coop") == 0) { emo_rnnt_set_greedy_coop(value); return 0; }
 #ifdef EMOASR_EXPERIMENTAL
   if (strcmp(name, "gemm_k256") == 0) { emo_gemm_set_k256(value); return 0; }

@@ -1956,23 +1956,22 @@ template <typename T, int FW> struct SplitCfg {
 // neighbouring registers).  Here every pair is hashed ONCE per layer and step, by a kernel that does nothing else (one thread per
 // 32-key word, 16 pair hashes), and both passes test a bit: 2 instructions per element.  Same mask, bit for bit.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_dropmask_kernel(const emoasr_attn_t a_in, unsigned* __restrict__ mask, const int nw,
+__global__ __launch_bounds__(1024) void attn_dropmask_kernel(const emoasr_attn_t a_in, unsigned* __restrict__ mask, const int nw,
                                                             const long nrows) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const int w = (int)(idx % nw);
-  const long rh = idx / nw;
-  if (rh >= nrows * a_in.H) return;
-  const int h = (int)(rh % a_in.H);
-  const long row = rh / a_in.H;
+  // block = RPB consecutive rows x H heads x nw words: (threadIdx.x, threadIdx.y, threadIdx.z) = (word, head, row in block), so
+  // that no thread divides (the first version decoded a linear index with five integer divisions per thread: 41 us per launch)
+  const long row = (long)blockIdx.x * blockDim.z + threadIdx.z;
+  const int w = threadIdx.x, h = threadIdx.y;
+  if (row >= nrows || w >= nw) return;
   emoasr_attn_t a = a_in;
   int b, i;
   if (a_in.nseg > 1) {
     const SegRef g = seg_of_row(a_in, row);
     seg_apply<T>(a, g);
     const long loc = row - g.row;
-    b = (int)(loc / g.T); i = (int)(loc % g.T);
+    b = (int)(loc / g.T); i = (int)(loc - (long)b * g.T);
   } else {
-    b = (int)(row / a.Tq); i = (int)(row % a.Tq);
+    b = (int)(row / a.Tq); i = (int)(row - (long)b * a.Tq);
   }
   const int klen = a.klens ? min(a.klens[b], a.Tk) : a.Tk;
   if (32 * w >= klen) return;   // no valid key in this word: never read
@@ -1986,7 +1985,7 @@ __global__ __launch_bounds__(256) void attn_dropmask_kernel(const emoasr_attn_t 
     bits |= (k0 ? 1u : 0u) << (2 * k);
     bits |= (k1 ? 1u : 0u) << (2 * k + 1);
   }
-  mask[idx] = bits;
+  mask[(row * a_in.H + h) * nw + w] = bits;
 }
 
 template <typename T, bool TR, bool REL, int FW>
@@ -2783,8 +2782,10 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
     if (ntq) gq = dim3(8 * cdiv(a.H * a.B, 8) * ntq, 1, 1);
     emo_timer_begin(EMO_TIMER_ATTN_BWD_MAIN, s);
     if (maskbuf) {
-      const long nwords = nrows * a.H * ws.mask_nw;
-      attn_dropmask_kernel<T><<<cdiv(nwords, 256), 256, 0, s>>>(a, maskbuf, ws.mask_nw, nrows);
+      const int bx = (ws.mask_nw + 7) / 8 * 8;                       // words, padded to a multiple of 8 lanes
+      EMO_CHECK(bx * a.H <= 1024, "attn_bwd_fused: H * ceil(Tk / 32) = %d exceeds one workgroup of the mask kernel", bx * a.H);
+      const int rpb = std::max(1, 256 / (bx * a.H));                 // rows per (about) 256-thread block
+      attn_dropmask_kernel<T><<<cdiv(nrows, rpb), dim3(bx, a.H, rpb), 0, s>>>(a, maskbuf, ws.mask_nw, nrows);
     }
 #define EMO_SPLIT_LAUNCH(TR_, REL_)                                                                                 \
   do {                                                                                                              \

@@ -193,7 +193,12 @@ __device__ __forceinline__ float dswishf_(float x) {
 }
 
 enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_SWISH = 2, EMO_ACT_GELU = 3, EMO_ACT_TANH = 4,
-       EMO_DACT_TANH_OUT = 5 };
+       EMO_DACT_TANH_OUT = 5,
+       EMO_DACT_MUL = 6 };        // epilogue.dact: the saved tensor IS the factor (see EMO_ACT_SAVE_DACT)
+// epilogue.act | EMO_ACT_SAVE_DACT: `pre_out` receives act'(pre) * dropout_scale -- the factor the data gradient multiplies by --
+// instead of the pre-activation.  The backward epilogue (dact = EMO_DACT_MUL, drop_p = 0) is then one multiply per element: no
+// sigmoid and no second hashing of the dropout mask (16 of its ~25 VALU operations per element).
+constexpr int EMO_ACT_SAVE_DACT = 0x100;
 
 __device__ __forceinline__ float geluf_(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgeluf_(float x) {
@@ -213,6 +218,7 @@ __device__ __forceinline__ float apply_dact(int act, float pre) {
   if (act == EMO_ACT_GELU) return dgeluf_(pre);
   if (act == EMO_ACT_TANH) { const float t = tanhf(pre); return 1.f - t * t; }
   if (act == EMO_DACT_TANH_OUT) return 1.f - pre * pre;  // `pre` holds tanh's OUTPUT here
+  if (act == EMO_DACT_MUL) return pre;
   return 1.f;
 }
 
@@ -253,6 +259,10 @@ __device__ __forceinline__ void dact_vec(int act, const float (&pre)[N], float (
     case EMO_ACT_SWISH:
 #pragma unroll
       for (int e = 0; e < N; ++e) v[e] *= dswishf_(pre[e]);
+      break;
+    case EMO_DACT_MUL:
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] *= pre[e];
       break;
     case EMO_ACT_GELU:
 #pragma unroll 1
@@ -338,6 +348,39 @@ __device__ __forceinline__ void dropout_apply8(uint64_t seed, uint64_t idx0, flo
     v[2 * k] *= (x & 0xFFFFFFu) >= thr ? inv : 0.f;
     v[2 * k + 1] *= (dropout_second(x) & 0xFFFFFFu) >= thr ? inv : 0.f;
   }
+}
+
+// m[e] = dropout_scale(seed, idx0 + e, p) for 8 consecutive elements from an even index (the multipliers of dropout_apply8)
+__device__ __forceinline__ void dropout_mult8(uint64_t seed, uint64_t idx0, float p, float (&m)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m[e] = 1.f;
+  if (p <= 0.f) return;
+  const uint32_t thr = dropout_thr(p);
+  const float inv = 1.f / (1.f - p);
+  const uint64_t pair0 = idx0 >> 1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t x = dropout_hash(seed, pair0 + (uint64_t)k);
+    m[2 * k] = (x & 0xFFFFFFu) >= thr ? inv : 0.f;
+    m[2 * k + 1] = (dropout_second(x) & 0xFFFFFFu) >= thr ? inv : 0.f;
+  }
+}
+// v <- act(v), d <- act'(v) in one go (Swish: one sigmoid for both)
+template <int N>
+__device__ __forceinline__ void act_dact_vec(int act, float (&v)[N], float (&d)[N]) {
+  if (act == EMO_ACT_SWISH) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const float s = sigmoidf_(v[e]), a = v[e] * s;
+      d[e] = s + a * (1.f - s);
+      v[e] = a;
+    }
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < N; ++e) d[e] = 1.f;
+  dact_vec<N>(act, v, d);
+  act_vec<N>(act, v);
 }
 
 // ---------------------------------------------------------------------------

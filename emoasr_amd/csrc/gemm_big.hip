@@ -426,9 +426,18 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
             for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
           }
           const long off = (long)grow * g.ldc + col;
-          if (pre_out) store8<bf16>(pre_out + off, v);
-          act_vec<8>(ep.act, v);
-          dropout_apply8(ep.seed, (uint64_t)grow * (uint64_t)g.N + col, ep.drop_p, v);   // (N % 8 == 0, col % 8 == 0)
+          if (ep.act & EMO_ACT_SAVE_DACT) {   // (common.h: the saved tensor is act'(pre) * dropout_scale)
+            float dd[8], mm[8];
+            act_dact_vec<8>(ep.act & 0xFF, v, dd);
+            dropout_mult8(ep.seed, (uint64_t)grow * (uint64_t)g.N + col, ep.drop_p, mm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] *= mm[e]; dd[e] *= mm[e]; }
+            if (pre_out) store8<bf16>(pre_out + off, dd);
+          } else {
+            if (pre_out) store8<bf16>(pre_out + off, v);
+            act_vec<8>(ep.act, v);
+            dropout_apply8(ep.seed, (uint64_t)grow * (uint64_t)g.N + col, ep.drop_p, v);   // (N % 8 == 0, col % 8 == 0)
+          }
           store8<bf16>(Cp + off, v);
         }
       }

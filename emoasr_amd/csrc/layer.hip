@@ -24,6 +24,8 @@ int g_ffn_fused = 0;  // bf16, d = 256: the feed-forward block as ONE launch (cs
                       // only) -- measured slower than LayerNorm + two GEMMs at the L2 batch size (87 vs 40 us, see ffn.hip), so
                       // off unless emoasr_set_option("ffn_fused", 1)
 
+int g_ffn_save_dact = 1;  // option "ffn_save_dact": the feed-forward blocks save Swish'(u) * dropout_scale instead of u (common.h:
+                          // EMO_ACT_SAVE_DACT); must not change between a forward and its backward
 int g_stack_launch = 1;  // stacked micro-batches: 1 = the per-utterance kernels take all segments in ONE launch (segment table in
                          // their arguments), 0 = one launch per segment (same arithmetic; A/B switch, option "stack_launch")
 int g_conv_fused = 1;  // bf16: the fused convolution-module kernels of csrc/convfused.hip (bit-identical to the separate launches)
@@ -38,7 +40,7 @@ int ffn_fwd(int dtype, int M, int d, int F, const emoasr_ffn_params_t& p, const 
 #endif
   if (emoasr_layernorm_fwd(dtype, M, d, x, p.ln_g, p.ln_b, 1e-5f, st.h, st.mean, st.rstd, stream)) return 1;
   emoasr_epilogue_t e1 = plain_ep();
-  e1.bias = p.b1; e1.act = EMOASR_ACT_SWISH; e1.pre_out = st.u; e1.drop_p = p_enc; e1.seed = s_in;
+  e1.bias = p.b1; e1.act = EMOASR_ACT_SWISH | (g_ffn_save_dact ? EMOASR_ACT_SAVE_DACT : 0); e1.pre_out = st.u; e1.drop_p = p_enc; e1.seed = s_in;
   if (emoasr_gemm_nt(dtype, M, F, d, st.h, d, p.w1, d, st.a, F, &e1, stream)) return 1;
   emoasr_epilogue_t e2 = plain_ep();
   e2.bias = p.b2; e2.residual = x; e2.ldr = d; e2.res_scale = res_scale; e2.drop_p = p_enc; e2.seed = s_out;
@@ -105,6 +107,7 @@ void attn_args_for(emoasr_attn_t& a, const SegView& sv, int s0, int s1, int H, i
 void emo_layer_set_ffn_fused(int v) { g_ffn_fused = v; }
 void emo_layer_set_conv_fused(int v) { g_conv_fused = v; }
 void emo_layer_set_stack_launch(int v) { g_stack_launch = v; }
+void emo_layer_set_ffn_save_dact(int v) { g_ffn_save_dact = v ? 1 : 0; }
 
 extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* L,
                                           const emoasr_conformer_fwd_t* io, void* stream) {
@@ -303,7 +306,9 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     const float alpha = p > 0.f ? 1.f : 0.5f;
     wgrad(dy, d, d, S.a, F, F, M, Gp.w2, alpha, Gp.b2);
     emoasr_epilogue_t e = plain_ep();
-    e.alpha = alpha; e.dact_pre = S.u; e.dact = EMOASR_ACT_SWISH; e.drop_p = p; e.seed = s_in;
+    e.alpha = alpha; e.dact_pre = S.u; e.seed = s_in;
+    if (g_ffn_save_dact) { e.dact = EMOASR_DACT_MUL; e.drop_p = 0.f; }   // S.u holds Swish'(u) * dropout_scale (ffn_fwd)
+    else { e.dact = EMOASR_ACT_SWISH; e.drop_p = p; }
     if (emoasr_gemm_nn(dtype, M, F, d, dy, d, P.w2, F, du, F, &e, stream)) return 1;
     wgrad(du, F, F, S.h, d, d, M, Gp.w1, 1.f, Gp.b1);
     emoasr_epilogue_t e1 = plain_ep();

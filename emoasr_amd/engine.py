@@ -243,6 +243,11 @@ class CTCEngine(_DecoderMixinPlaceholder):
             from . import lib as _lib
             _lib.set_option("conv_fused", 0)
             _lib.set_option("dwconv_lds", 0)
+        # feed-forward blocks save act'(u) * dropout_scale instead of u (csrc/common.h: EMO_ACT_SAVE_DACT; process-wide A/B switch)
+        self._ffn_save_dact = os.environ.get("EMOASR_FFN_SAVE_DACT", "1") != "0"
+        if not self._ffn_save_dact:
+            from . import lib as _lib
+            _lib.set_option("ffn_save_dact", 0)
         self._conv_big = os.environ.get("EMOASR_CONV_BIG", "1") != "0"  # A/B switch of csrc/gemm_big.hip (process-wide)
         if not self._conv_big:
             from . import lib as _lib
@@ -410,8 +415,9 @@ class CTCEngine(_DecoderMixinPlaceholder):
         h, mean, rstd = ops.layernorm_fwd(x, A.p(norm_name + ".weight"), A.p(norm_name + ".bias"), eps, self._keep)
         u = torch.empty(x.shape[0], A.p(name + ".w1.weight").shape[0], device=x.device, dtype=x.dtype) if self._keep else None
         s_in, s_out = self._seed(site), self._seed(site + 1)
-        a = ops.gemm_nt(h, A.w(name + ".w1.weight"), bias=A.p(name + ".w1.bias"), act=act, pre_out=u,
-                        drop_p=p_enc, seed=s_in)
+        a = ops.gemm_nt(h, A.w(name + ".w1.weight"), bias=A.p(name + ".w1.bias"),
+                        act=act | (ops.ACT_SAVE_DACT if (self._ffn_save_dact and u is not None) else 0), pre_out=u,
+                        drop_p=p_enc, seed=s_in)   # (save_dact: `u` holds act'(u) * dropout_scale, what _ffn_bwd multiplies by)
         y = ops.gemm_nt(a, A.w(name + ".w2.weight"), bias=A.p(name + ".w2.bias"), residual=x, res_scale=res_scale,
                         drop_p=p_enc, seed=s_out)
         return y, (x, mean, rstd, h, u, a, s_in, s_out)
@@ -826,7 +832,10 @@ class CTCEngine(_DecoderMixinPlaceholder):
         x, mean, rstd, h, u, a, s_in, s_out = st
         p = self.p_enc if p is None else p
         dy, alpha = self._branch_grad(dx, res_scale, p, s_out, pre)
-        du = self._lin_bwd(dy, a, name + ".w2.weight", name + ".w2.bias", alpha, dact_pre=u, dact=act, drop_p=p, seed=s_in)
+        if self._ffn_save_dact:
+            du = self._lin_bwd(dy, a, name + ".w2.weight", name + ".w2.bias", alpha, dact_pre=u, dact=ops.DACT_MUL)
+        else:
+            du = self._lin_bwd(dy, a, name + ".w2.weight", name + ".w2.bias", alpha, dact_pre=u, dact=act, drop_p=p, seed=s_in)
         dh = self._lin_bwd(du, h, name + ".w1.weight", name + ".w1.bias")
         r = self._ln_bwd(dh, x, norm_name, mean, rstd, dx, nxt)
         return r if nxt is not None else r[0]

@@ -787,6 +787,8 @@ def ctc_prefix_score(x, cands, last, out_len, blank, eos, prev_states=None, pare
 
 # ---- RNN-T -------------------------------------------------------------------------------------
 DACT_TANH_OUT = 5
+DACT_MUL = 6            # epilogue dact: multiply by the saved factor (ACT_SAVE_DACT forward)
+ACT_SAVE_DACT = 0x100   # epilogue act flag: pre_out <- act'(pre) * dropout_scale
 
 
 def lstm_cell_fwd(gates_pre, c_prev, h_out, c_out, gates_act):

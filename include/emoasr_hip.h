@@ -27,7 +27,14 @@ extern "C" {
 #endif
 
 enum { EMOASR_F32 = 0, EMOASR_BF16 = 1 };
-enum { EMOASR_ACT_NONE = 0, EMOASR_ACT_RELU = 1, EMOASR_ACT_SWISH = 2 };
+enum { EMOASR_ACT_NONE = 0, EMOASR_ACT_RELU = 1, EMOASR_ACT_SWISH = 2,
+       /* emoasr_epilogue_t.dact only: the tensor behind dact_pre IS the factor to multiply by (saved by a forward epilogue whose
+        * act carried EMOASR_ACT_SAVE_DACT); pass drop_p = 0 with it, the mask is part of the factor */
+       EMOASR_DACT_MUL = 6 };
+/* emoasr_epilogue_t.act | EMOASR_ACT_SAVE_DACT: pre_out receives act'(pre) * dropout_scale (the factor of the data gradient)
+ * instead of the pre-activation: the backward of x -> dropout(act(x W^T + b)) then needs neither the activation's derivative nor
+ * a second hashing of the dropout mask (transformer.py:117-118's feed-forward blocks in training). */
+#define EMOASR_ACT_SAVE_DACT 0x100
 
 const char* emoasr_last_error(void);
 int emoasr_version(void);
