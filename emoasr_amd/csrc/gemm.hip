@@ -384,12 +384,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
       for (int e = 0; e < 4; ++e) { d[e] = r[0].get(e); d[4 + e] = r[RAWN - 1].get(e); }
     }
   };
-  stage_tile(acc[0][0], 0, 0);
-  if constexpr (TN > 1) stage_tile(acc[0][TN - 1], 0, TN - 1);
-  if constexpr (TM > 1) {
-    stage_tile(acc[TM - 1][0], TM - 1, 0);
-    if constexpr (TN > 1) stage_tile(acc[TM - 1][TN - 1], TM - 1, TN - 1);
-  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) stage_tile(acc[i][j], i, j);
   __syncthreads();
 #pragma unroll
   for (int pass = 0; pass < EPI_ROWS / RPP; ++pass) {
@@ -465,7 +463,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
     }
   }
   }
-  static_assert(TM <= 2 && TN <= 2, "epilogue is written for at most 2x2 tiles per wave");
+  static_assert(TM * TN <= 4, "at most four 32x32 accumulator tiles per wave");
 }
 
 // ----------------------------------------------------------------------------
@@ -716,6 +714,9 @@ int launch_nt_(const NtArgs& a_in, hipStream_t s, int nz = 1) {
       return 0;
     }
   }
+  // (64 x 256 tiles -- wave tile 32 x 128, an A row block fetched once per 256 output columns -- were measured at 35 k rows in
+  // round 4: 10-30 % SLOWER on every shape, e.g. ffn2 51.7 against 44.4 us, d_ffn1 44.0 / 38.0, out 22.8 / 17.2: two workgroups
+  // per CU instead of seven; these products are bound by latency under low occupancy, not by L1 fill traffic.  Removed.)
   if (tile == 1) EMO_NT_LAUNCH(128, 128);
   else if (tile == 2) EMO_NT_LAUNCH(128, 64);
   else EMO_NT_LAUNCH(64, 64);

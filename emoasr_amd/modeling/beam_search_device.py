@@ -213,6 +213,12 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
         # Steps are issued one ahead of the flag they depend on: a step launched after the search has finished changes
         # nothing (emoasr_beam_update returns at once), and the GPU never waits for the host's round trip.
         ev_tail, ev_lm = torch.cuda.Event(), torch.cuda.Event()
+        # device time of the search loop for the running totals (bench.py: search_loop_ms_per_step): events on the search stream, so
+        # that the encoder pass / cross-attention K, V / CTC prefix setup still queued AHEAD of the first step are not charged to
+        # the loop (host wall time from here charged ~4 ms of them per utterance: 0.94 ms per step on ten-step searches, 0.53 on
+        # forced 36-step ones, for the same 0.55 ms steps)
+        ev_loop0, ev_loop1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev_loop0.record(main)
         two_streams = os.environ.get("EMOASR_BEAM_TWO_STREAMS", "1") != "0"
         mirror = Bf.state_host.numpy()               # [pos, n_alive, n_results, done], written by emoasr_beam_update
         mirror[:] = (0, 1, 0, 0)
@@ -267,6 +273,7 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
                         worst = (_t1 - _t0, i, "launch")
                     if _t2 - _t1 > worst[0]:
                         worst = (_t2 - _t1, i, "sync")
+            ev_loop1.record(main)
             main.synchronize()
             if lib.size_query("emoasr_decode_coop_status") > 0:
                 raise RuntimeError("decode_coop: a grid barrier gave up waiting (csrc/decode_coop.hip); emoasr_set_option('decode_coop', 0) "
@@ -280,7 +287,8 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
         stats = getattr(eng, "_beam_stats", None)    # running totals for bench.py: steps and wall time of the search loops
         if stats is None:
             stats = eng._beam_stats = {"steps": 0, "loop_s": 0.0, "utts": 0}
-        stats["steps"] += n_done; stats["loop_s"] += time.perf_counter() - t_loop0; stats["utts"] += 1
+        # (the loop issues one step beyond the last effective one: its device time is part of the figure)
+        stats["steps"] += n_done; stats["loop_s"] += 1e-3 * ev_loop0.elapsed_time(ev_loop1); stats["utts"] += 1
         if side is not None:
             main.wait_stream(side)
         if timing:
