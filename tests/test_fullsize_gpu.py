@@ -210,3 +210,70 @@ def test_equal_length_batch_decodes_like_single_utterances(dev):
         assert rel < 2e-2, rel  # different tile shapes -> different bf16 summation order
         agree = sum(int(x == y) for x, y in zip(a1[0], aligns[b])) / len(aligns[b])
         assert agree > 0.97, agree
+
+
+L1 = dict(input_layer="conv2d", feat_dim=80, num_framestacks=1, encoder_type="transformer", decoder_type="ctc",
+          enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=12, enc_intermediate_size=2048,
+          dropout_enc_rate=0.0, dropout_attn_rate=0.0, vocab_size=10000, blank_id=0, eos_id=2, kd_weight=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_l1_transformer_ctc_full_size_against_oracle(dev, dtype):
+    """BASELINE.json config 1 (`L1`: CTC(Transformer), 20.19 M parameters, the reference's CPU-runnable plumbing case: 4 utterances
+    of 1200 / 1037 / 911 / 640 frames) on the HIP path at its FULL size against the oracle: absolute
+    positions, pre-norm Transformer layers with LayerNorm eps 1e-12 and ReLU feed-forward blocks of 2048 (asr/modeling/
+    transformer.py:121-153, encoders/transformer.py:84-113).  f32: loss 1e-3, logits 1e-3, greedy ids identical, gradient cosines
+    0.9995; bf16: the bars of the L2 test above."""
+    from emoasr_amd.modeling.asr import ASR
+    from oracle import model as om
+    torch.manual_seed(0)
+    model = ASR(SimpleNamespace(**L1), compute_dtype=dtype)
+    assert abs(sum(p.numel() for p in model.parameters()) / 1e6 - 20.19) < 0.01
+    with torch.no_grad():
+        model.decoder.output.weight.mul_(3.0)
+        for n, p in model.named_parameters():
+            if ".norm" in n:
+                p.add_(0.05 * torch.randn_like(p))
+    model = model.to(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cfg = SimpleNamespace(**L1)
+    xs, xlens, ys, ylens = _batch(7, [1200, 1037, 911, 640])
+    params = {k: v for k, v in sd.items() if v.dtype.is_floating_point}
+    for v in params.values():
+        v.requires_grad_(True)
+    loss_ref, _, _ = om.asr_ctc_forward(sd, cfg, xs, xlens, ys, ylens, training=True)
+    loss_ref.backward()
+    model.train()
+    loss, _ = model(xs.to(dev), xlens, ys, ylens, None, None)
+    loss.backward()
+    rel = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+    print(f"[measured L1 {dtype}] loss rel err {rel:.2e}")
+    assert rel < (1e-3 if dtype == torch.float32 else 2e-3)
+    grads = {n: p.grad.float().cpu() for n, p in model.named_parameters()}
+    worst = 1.0
+    for name in ("decoder.output.weight", "encoder.norm.weight", "encoder.transformers.11.feed_forward.w2.weight",
+                 "encoder.transformers.6.self_attn.linear_q.weight", "encoder.transformers.0.feed_forward.w1.bias",
+                 "encoder.transformers.3.norm1.weight", "encoder.conv.conv.2.weight", "encoder.conv.output.weight"):
+        a, b = grads[name].flatten(), params[name].grad.flatten()
+        cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
+        worst = min(worst, cos)
+        assert cos > (0.9995 if dtype == torch.float32 else 0.995), (name, cos)
+    print(f"[measured L1 {dtype}] worst sampled gradient cosine {worst:.5f}")
+    with torch.no_grad():
+        sd_eval = {k: v.detach() for k, v in sd.items()}
+        eouts, elens = om.encoder_forward(sd_eval, cfg, xs, xlens)
+        logits_ref = om.ctc_decoder_forward(sd_eval, cfg, eouts, elens)
+        want, _ = om.ctc_greedy(logits_ref, elens, 0)
+    model.eval()
+    with torch.no_grad():
+        e2, el2, _ = model.encoder(xs.to(dev), xlens)
+        logits = model.decoder(e2, el2)
+    hyps, _, _, _ = model.decode(xs.to(dev), xlens)
+    lrel = ((logits.float().cpu() - logits_ref).abs().max() / logits_ref.abs().max()).item()
+    print(f"[measured L1 {dtype}] logits rel err {lrel:.2e}")
+    assert lrel < (1e-3 if dtype == torch.float32 else 3e-2), lrel
+    if dtype == torch.float32:
+        assert hyps == want
+    else:
+        agree = sum(int(a == b) for h, w in zip(hyps, want) for a, b in zip(h, w)) / max(1, sum(len(w) for w in want))
+        assert agree > 0.9, agree
