@@ -263,17 +263,21 @@ def test_l1_transformer_ctc_full_size_against_oracle(dev, dtype):
         sd_eval = {k: v.detach() for k, v in sd.items()}
         eouts, elens = om.encoder_forward(sd_eval, cfg, xs, xlens)
         logits_ref = om.ctc_decoder_forward(sd_eval, cfg, eouts, elens)
-        want, _ = om.ctc_greedy(logits_ref, elens, 0)
+        want, want_aligns = om.ctc_greedy(logits_ref, elens, 0)
     model.eval()
     with torch.no_grad():
         e2, el2, _ = model.encoder(xs.to(dev), xlens)
         logits = model.decoder(e2, el2)
-    hyps, _, _, _ = model.decode(xs.to(dev), xlens)
+    hyps, _, _, aligns = model.decode(xs.to(dev), xlens)
     lrel = ((logits.float().cpu() - logits_ref).abs().max() / logits_ref.abs().max()).item()
     print(f"[measured L1 {dtype}] logits rel err {lrel:.2e}")
     assert lrel < (1e-3 if dtype == torch.float32 else 3e-2), lrel
     if dtype == torch.float32:
         assert hyps == want
     else:
-        agree = sum(int(a == b) for h, w in zip(hyps, want) for a, b in zip(h, w)) / max(1, sum(len(w) for w in want))
+        # frame-level arg-max agreement (on random-init weights the ~200-token hypotheses differ by insertions, which shift every
+        # later position of a token-by-token comparison: 0.64 measured that way)
+        same = sum(int(a == b) for ga, wa in zip(aligns, want_aligns) for a, b in zip(ga, wa))
+        agree = same / max(1, sum(len(wa) for wa in want_aligns))
+        print(f"[measured L1 {dtype}] greedy frame agreement {agree:.4f}")
         assert agree > 0.9, agree
