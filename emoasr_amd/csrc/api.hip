@@ -47,6 +47,7 @@ void emo_attn_set_tr_read(int v);
 void emo_attn_set_fw(int v);
 void emo_attn_set_bwd_split(int v);
 void emo_attn_set_kv_dbg(int v);
+void emo_attn_set_side(int v);
 void emo_attn_set_lpt(int v);
 void emo_attn_set_fwd_split(int v);
 void emo_attn_set_xcd(int v);
@@ -171,6 +172,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "attn_fw") == 0) { emo_attn_set_fw(value); return 0; }
   if (strcmp(name, "attn_bwd_split") == 0) { emo_attn_set_bwd_split(value); return 0; }
   if (strcmp(name, "attn_kv_dbg") == 0) { emo_attn_set_kv_dbg(value); return 0; }
+  if (strcmp(name, "attn_side") == 0) { emo_attn_set_side(value); return 0; }
   if (strcmp(name, "attn_lpt") == 0) { emo_attn_set_lpt(value); return 0; }
   if (strcmp(name, "attn_fwd_split") == 0) { emo_attn_set_fwd_split(value); return 0; }
   if (strcmp(name, "attn_xcd") == 0) { emo_attn_set_xcd(value); return 0; }

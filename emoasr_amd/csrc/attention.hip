@@ -1354,15 +1354,17 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t 
   const bool ok = row < total;
   const int h = ok ? (int)(row % a.H) : 0;
   const long bt = ok ? row / a.H : 0;
-  float dv[8], ov[8];
-  load8<T>((const T*)a.dout + bt * a.ldo + h * DK + d0, dv);
-  load8<T>((const T*)a.out + bt * a.ldo + h * DK + d0, ov);
   float s = 0.f;
+  if (a.dout) {   // (nullptr: the side-stream prologue, which prepares what depends on forward data only)
+    float dv[8], ov[8];
+    load8<T>((const T*)a.dout + bt * a.ldo + h * DK + d0, dv);
+    load8<T>((const T*)a.out + bt * a.ldo + h * DK + d0, ov);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s += dv[j] * ov[j];
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    for (int j = 0; j < 8; ++j) s += dv[j] * ov[j];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  }
   if (!ok) return;
-  if (d0 == 0) {
+  if (d0 == 0 && a.dout) {
     if (a.nseg > 1) {   // delta of segment s: [utterances, H, T_s] at H * (its first row)
       const SegRef g = seg_of_row(a, bt);
       const long loc = bt - g.row;
@@ -2723,6 +2725,68 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
 struct FusedExtras { float* zero; long zero_n; const float* cast_src; void* cast_dst; long cast_n; };
 FusedExtras g_fused_extras{};
 
+// ---- side stream of the two-pass backward (option "attn_side", default on) ---------------------------------------------------------
+// Two launches of an attention backward neither depend on nor feed its critical chain right away: the keep-mask bits (a pure
+// function of seed and indices: they can be hashed while the layer's feed-forward / convolution backward runs) and the
+// position-table gradient + its cast (consumed only by the layer's grouped weight-gradient launch at the very end).  Both are
+// low-occupancy kernels (320 workgroups of the table gradient on 256 CUs), so on a second stream they run under the main chain.
+//   emo_attn_bwd_prelaunch       prepare what the NEXT emoasr_attn_bwd_fused call with these arguments needs of FORWARD data only
+//                                (keep mask, Q + bias copies, cleared table gradient) on the side stream
+//   emo_attn_bwd_defer_join(1)   that call leaves the table gradient running on the side stream; emo_attn_bwd_join(stream) makes
+//                                `stream` wait for it (csrc/layer.hip: right before the grouped weight-gradient launch)
+// Callers that know nothing of this (ops.attn_bwd) get the join inside the call: same stream semantics as before.
+int g_attn_side = 1;
+hipStream_t g_side = nullptr;
+hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_mask = nullptr;
+bool g_join_pending = false, g_defer_join = false;
+struct MaskTag { const void* buf = nullptr; uint64_t seed = 0; long nrows = -1; float p = 0.f; } g_mask_tag;
+
+bool side_ready() {
+  if (!g_attn_side) return false;
+  if (g_side) return true;
+  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; g_attn_side = 0; return false; }
+  hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming);
+  hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming);
+  hipEventCreateWithFlags(&g_ev_mask, hipEventDisableTiming);
+  return true;
+}
+void side_join(hipStream_t s) {
+  if (g_join_pending) { hipStreamWaitEvent(s, g_ev_join, 0); g_join_pending = false; }
+}
+
+struct FusedLayout { size_t dq32, qu, qv, dsq, mask, total; long ldds; int mask_nw; };
+template <typename T>
+FusedLayout fused_layout(const emoasr_attn_t& a, bool with_mask) {
+  const bool rel = a.pos != nullptr;
+  const long nrows = a.nseg > 1 ? a.seg_row[a.nseg] : (long)a.B * a.Tq;
+  const long nqd = nrows * a.H * DK;
+  FusedLayout L{};
+  size_t off = 0;
+  auto carve = [&](size_t n) { const size_t p = off; off += (n + 255) / 256 * 256; return p; };
+  L.dq32 = carve((size_t)nqd * 4 * cdiv(a.Tk, 64));  // room for 64-key blocks (the finer grid of the single-pass kernel)
+  if (rel) {
+    L.qu = carve(nqd * sizeof(T));
+    L.qv = carve(nqd * sizeof(T));
+    L.ldds = (a.Tk + 31) / 32 * 32;
+    L.dsq = carve((size_t)nrows * a.H * L.ldds * sizeof(T));
+  }
+  if (with_mask) {
+    L.mask_nw = cdiv(a.Tk, 32);
+    L.mask = carve((size_t)nrows * a.H * L.mask_nw * 4);
+  }
+  L.total = off;
+  return L;
+}
+
+template <typename T>
+int launch_dropmask(const emoasr_attn_t& a, unsigned* maskbuf, int nw, long nrows, hipStream_t s) {
+  const int bx = (nw + 7) / 8 * 8;                               // words, padded to a multiple of 8 lanes
+  EMO_CHECK(bx * a.H <= 1024, "attn_bwd_fused: H * ceil(Tk / 32) = %d exceeds one workgroup of the mask kernel", bx * a.H);
+  const int rpb = std::max(1, 256 / (bx * a.H));                 // rows per (about) 256-thread block
+  attn_dropmask_kernel<T><<<cdiv(nrows, rpb), dim3(bx, a.H, rpb), 0, s>>>(a, maskbuf, nw, nrows);
+  return 0;
+}
+
 template <typename T>
 int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStream_t s) {
   emoasr_attn_t a = a_in;
@@ -2730,28 +2794,29 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
   const bool rel = a.pos != nullptr;
   const long nrows = a.nseg > 1 ? a.seg_row[a.nseg] : (long)a.B * a.Tq;   // stacked micro-batches: all segments' rows
   const long nqd = nrows * a.H * DK;
+  side_join(s);   // (a table gradient left on the side stream by a caller that never joined: it used this workspace)
   FusedWs ws{};
-  size_t off = 0;
-  auto carve = [&](size_t n) { char* p = mem + off; off += (n + 255) / 256 * 256; return p; };
+  const bool want_mask = g_bwd_split && a.drop_p > 0.f;
+  const FusedLayout lay = fused_layout<T>(a, want_mask);
+  EMO_CHECK(lay.total <= bytes, "attn_bwd_fused: workspace too small (%zu < %zu bytes)", bytes, lay.total);
   ws.dq_slab = nqd;
-  ws.dq32 = reinterpret_cast<float*>(carve((size_t)nqd * 4 * cdiv(a.Tk, 64)));  // room for 64-key blocks (the finer grid)
+  ws.dq32 = reinterpret_cast<float*>(mem + lay.dq32);
   T *qu = nullptr, *qv = nullptr;
   if (rel) {
-    qu = reinterpret_cast<T*>(carve(nqd * sizeof(T)));
-    qv = reinterpret_cast<T*>(carve(nqd * sizeof(T)));
-    ws.ldds = (a.Tk + 31) / 32 * 32;
-    ws.dsq = carve((size_t)nrows * a.H * ws.ldds * sizeof(T));
+    qu = reinterpret_cast<T*>(mem + lay.qu);
+    qv = reinterpret_cast<T*>(mem + lay.qv);
+    ws.ldds = lay.ldds;
+    ws.dsq = mem + lay.dsq;
     ws.qu = qu; ws.qv = qv; ws.ldqu = (long)a.H * DK;
   } else {
     ws.qu = a.q; ws.qv = a.q; ws.ldqu = a.ldq;
   }
   unsigned* maskbuf = nullptr;
-  if (g_bwd_split && a.drop_p > 0.f) {
-    ws.mask_nw = cdiv(a.Tk, 32);
-    maskbuf = reinterpret_cast<unsigned*>(carve((size_t)nrows * a.H * ws.mask_nw * 4));
+  if (want_mask) {
+    ws.mask_nw = lay.mask_nw;
+    maskbuf = reinterpret_cast<unsigned*>(mem + lay.mask);
     ws.mask = maskbuf;
   }
-  EMO_CHECK(off <= bytes, "attn_bwd_fused: workspace too small (%zu < %zu bytes)", bytes, off);
   const long rows = nrows * a.H;
   const FusedExtras fx = g_fused_extras;
   g_fused_extras = FusedExtras{};
@@ -2761,7 +2826,16 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
   if (!d_stamp) hipMalloc(&d_stamp, 2 * 64 * 13 * 8);
   ws.stamp = stamp_calls++ == 0 ? d_stamp : nullptr;   // the first (eager) call only: later calls may be under stream capture
 #endif
-  attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, qu, qv, fx.zero, fx.zero_n, nrows);
+  // prepared ahead of time on the side stream (emo_attn_bwd_prelaunch)?  Then this prologue computes delta only.
+  const bool prepared = g_bwd_split && g_mask_tag.buf == mem && g_mask_tag.seed == a.seed && g_mask_tag.nrows == nrows &&
+                        g_mask_tag.p == a.drop_p;
+  if (prepared) {
+    hipStreamWaitEvent(s, g_ev_mask, 0);
+    attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, nullptr, nullptr, nullptr, 0, nrows);
+  } else {
+    attn_bwd_prep_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a, qu, qv, fx.zero, fx.zero_n, nrows);
+  }
+  g_mask_tag = MaskTag{};
   // 4 key tiles per workgroup (one workgroup per CU) unless that grid spills into a second round of workgroups and the
   // 2-tile grid (two workgroups per CU) does not
   static int n_cu = 0;
@@ -2781,12 +2855,7 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
     if (ntk) gk = dim3(8 * cdiv(a.H * a.B, 8) * ntk, 1, 1);
     if (ntq) gq = dim3(8 * cdiv(a.H * a.B, 8) * ntq, 1, 1);
     emo_timer_begin(EMO_TIMER_ATTN_BWD_MAIN, s);
-    if (maskbuf) {
-      const int bx = (ws.mask_nw + 7) / 8 * 8;                       // words, padded to a multiple of 8 lanes
-      EMO_CHECK(bx * a.H <= 1024, "attn_bwd_fused: H * ceil(Tk / 32) = %d exceeds one workgroup of the mask kernel", bx * a.H);
-      const int rpb = std::max(1, 256 / (bx * a.H));                 // rows per (about) 256-thread block
-      attn_dropmask_kernel<T><<<cdiv(nrows, rpb), dim3(bx, a.H, rpb), 0, s>>>(a, maskbuf, ws.mask_nw, nrows);
-    }
+    if (maskbuf && !prepared && launch_dropmask<T>(a, maskbuf, ws.mask_nw, nrows, s)) return 1;
 #define EMO_SPLIT_LAUNCH(TR_, REL_)                                                                                 \
   do {                                                                                                              \
     if (set_smem(attn_bwd_kv_kernel<T, TR_, REL_, FW>, SC::kv_smem(REL_))) return 1;                                \
@@ -2799,6 +2868,14 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
     else     { if (g_tr) EMO_SPLIT_LAUNCH(true, false); else EMO_SPLIT_LAUNCH(false, false); }
 #undef EMO_SPLIT_LAUNCH
     emo_timer_end(EMO_TIMER_ATTN_BWD_MAIN, s);
+    // the position-table gradient (+ its cast for the weight-gradient product): on the side stream when there is one
+    hipStream_t st2 = s;
+    const bool forked = rel && a.dpos && side_ready();
+    if (forked) {
+      hipEventRecord(g_ev_fork, s);
+      hipStreamWaitEvent(g_side, g_ev_fork, 0);
+      st2 = g_side;
+    }
     if (rel && a.dpos) {
       int bmin = a.B;
       for (int k = 0; k < a.nseg && a.nseg > 1; ++k) bmin = std::min(bmin, a.seg_b0[k + 1] - a.seg_b0[k]);
@@ -2806,10 +2883,10 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
       dim3 g2(cdiv(2 * a.Tq - 1, 64), a.H, nchunk * (a.nseg > 1 ? a.nseg : 1));
       const int nt2 = (g_attn_xcd && a.nseg > 1) ? (int)g2.x : 0;
       if (nt2) g2 = dim3(8 * cdiv((int)(g2.y * g2.z), 8) * nt2, 1, 1);
-      emo_timer_begin(EMO_TIMER_ATTN_BWD_DPOS, s);
-      if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
-      else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
-      emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, s);
+      emo_timer_begin(EMO_TIMER_ATTN_BWD_DPOS, st2);
+      if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, st2>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
+      else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, st2>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
+      emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, st2);
     }
 #ifdef EMO_ATTN_STAMP
     {  // debug builds: per-phase cycle counts of wave 0 of workgroup 0 of both passes, averaged over the sweep
@@ -2836,7 +2913,13 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
     }
 #endif
     if (fx.cast_n > 0)   // the finished f32 position-table gradient in the compute dtype, for its weight-gradient product
-      attn_cast_kernel<T><<<(int)std::min<long>(cdiv(fx.cast_n, 256), 1024), 256, 0, s>>>(fx.cast_src, (T*)fx.cast_dst, fx.cast_n);
+      attn_cast_kernel<T><<<(int)std::min<long>(cdiv(fx.cast_n, 256), 1024), 256, 0, st2>>>(fx.cast_src, (T*)fx.cast_dst, fx.cast_n);
+    if (forked) {
+      hipEventRecord(g_ev_join, g_side);
+      g_join_pending = true;
+      if (!g_defer_join) side_join(s);
+    }
+    g_defer_join = false;
     EMO_LAUNCH_CHECK();
     return 0;
   }
@@ -2912,6 +2995,37 @@ void emo_attn_bwd_fused_extras(float* zero, long zn, const float* cast_src, void
   g_fused_extras = FusedExtras{zero, zn, cast_src, cast_dst, cn};
 }
 
+void emo_attn_set_side(int v) { g_attn_side = v ? 1 : 0; }
+void emo_attn_bwd_defer_join(int v) { g_defer_join = v != 0; }
+void emo_attn_bwd_join(void* stream) { side_join((hipStream_t)stream); }
+// Everything of the next emoasr_attn_bwd_fused(a, ws) call that depends on FORWARD data only, now, on the side stream: the keep
+// mask (with dropout), the dense Q + pos_bias_u / Q + pos_bias_v copies, the clearing of the position-table gradient (zero, zn).
+// No-op without a side stream; the call itself does whatever was not prepared.
+int emo_attn_bwd_prelaunch(int dtype, const emoasr_attn_t* a_in, void* ws, size_t ws_bytes, float* zero, long zn, void* stream) {
+  if (dtype != EMO_BF16 || !g_bwd_split || !side_ready()) return 0;
+  emoasr_attn_t a = *a_in;
+  fill_seg_order(a);
+  const bool rel = a.pos != nullptr, want_mask = a.drop_p > 0.f;
+  if (!rel && !want_mask) return 0;
+  const FusedLayout lay = fused_layout<bf16>(a, want_mask);
+  if (lay.total > ws_bytes) return 0;
+  const long nrows = a.nseg > 1 ? a.seg_row[a.nseg] : (long)a.B * a.Tq;
+  char* mem = static_cast<char*>(ws);
+  // the regions' previous readers (the passes of the last call on this workspace) are ahead of this point on `stream`
+  hipEventRecord(g_ev_fork, (hipStream_t)stream);
+  hipStreamWaitEvent(g_side, g_ev_fork, 0);
+  if (want_mask && launch_dropmask<bf16>(a, reinterpret_cast<unsigned*>(mem + lay.mask), lay.mask_nw, nrows, g_side)) return 1;
+  if (rel) {
+    emoasr_attn_t aq = a;
+    aq.dout = nullptr;   // prologue kernel: the Q + bias copies and the clearing only (delta needs dO: the call's own prologue)
+    attn_bwd_prep_kernel<bf16><<<cdiv(nrows * a.H * 8, 256), 256, 0, g_side>>>(aq, reinterpret_cast<bf16*>(mem + lay.qu),
+                                                                              reinterpret_cast<bf16*>(mem + lay.qv), zero, zn, nrows);
+  }
+  hipEventRecord(g_ev_mask, g_side);
+  g_mask_tag.buf = mem; g_mask_tag.seed = a.seed; g_mask_tag.nrows = nrows; g_mask_tag.p = a.drop_p;
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
 void emo_attn_set_tr_read(int v) { g_tr = v; }
 void emo_attn_set_lpt(int v) { g_attn_lpt = v; }
 void emo_attn_set_fwd_split(int v) { g_fwd_split = v; }

@@ -9,6 +9,9 @@
 #include "../../include/emoasr_hip.h"
 
 void emo_attn_bwd_fused_extras(float* zero, long zn, const float* cast_src, void* cast_dst, long cn);  // csrc/attention.hip
+void emo_attn_bwd_defer_join(int v);
+void emo_attn_bwd_join(void* stream);
+int emo_attn_bwd_prelaunch(int dtype, const emoasr_attn_t* a, void* ws, size_t ws_bytes, float* zero, long zn, void* stream);
 
 namespace {
 
@@ -315,6 +318,15 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     return emoasr_gemm_nn(dtype, M, d, F, du, F, P.w1, d, ws + bb.dh, d, &e1, stream);
   };
 
+  // What the attention backward needs of FORWARD data only -- the dropout keep mask, the dense Q + pos_bias copies, the cleared
+  // position-table gradient -- is prepared now, on the attention's side stream, under the feed-forward / convolution backward
+  // that comes first (csrc/attention.hip: emo_attn_bwd_prelaunch)
+  if (g_stack_launch && dtype == EMO_BF16) {
+    emoasr_attn_t am{};
+    attn_args_for(am, sv, 0, sv.n, H, d, esz, st->qkv, st->pp, st->klens, st->seed[2]);
+    am.bias_u = L->bias_u; am.bias_v = L->bias_v; am.drop_p = st->p_att;
+    if (emo_attn_bwd_prelaunch(dtype, &am, ws + bb.attn_ws, bb.attn_ws_bytes, (float*)(ws + bb.dpos), (long)sv.R() * d, stream)) return 1;
+  }
   // ---- final LayerNorm ------------------------------------------------------------------------------------------
   if (ln_bwd(0, io->dy, st->ff.y, L->fin_ln_g, st->fin_mean, st->fin_rstd, nullptr, ws + bb.dx1, G->fin_ln_g, G->fin_ln_b,
              ws + bb.pre1, 0.5f, st->seed[6])) return 1;
@@ -390,6 +402,8 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
       // the position-table gradient is cleared by the attention backward's prologue launch and rounded to the compute dtype
       // by its finalize launch (two launches less per layer than a memset + a cast)
       emo_attn_bwd_fused_extras(dpos, Rs * d, dpos, ws + bb.dpos_t + po * d * esz, Rs * d);
+      // the position-table gradient may stay on the attention's side stream until the weight gradients need it (joined below)
+      emo_attn_bwd_defer_join(astep == sv.n);
       if (emoasr_attn_bwd_fused(dtype, &a, ws + bb.attn_ws, bb.attn_ws_bytes, stream)) return 1;
     }
     wgrad(ws + bb.dpos_t, d, d, st->pos_t, d, d, R, G->wpos, 1.f, nullptr);
@@ -403,5 +417,6 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
   if (ln_bwd(4, ws + bb.dh, st->x, L->ffm.ln_g, st->ffm.mean, st->ffm.rstd, ws + bb.dx4, io->dx, G->ffm.ln_g, G->ffm.ln_b,
              nullptr, 0.f, 0)) return 1;
   // ---- the layer's weight gradients, one launch -----------------------------------------------------------------------
+  emo_attn_bwd_join(stream);
   return emoasr_gemm_tn_grouped(dtype, npr, pr, stream);
 }
