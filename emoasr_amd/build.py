@@ -22,15 +22,18 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variant=None, defines=()):
+    """variant / defines: a second library build/libemoasr_hip_<variant>.so compiled with extra -D flags (compile-time A/B on one
+    box: EMOASR_HIP_LIB selects it); the default build is untouched by it."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build") if not variant else os.path.join(HERE, "build", "variant_" + variant)
+    LIB = globals()["LIB"] if not variant else os.path.join(HERE, "build", f"libemoasr_hip_{variant}.so")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in ("common.h", "mma.h")]
     headers.append(os.path.join(HERE, "..", "include", "emoasr_hip.h"))
     experimental = os.environ.get("EMOASR_EXPERIMENTAL", "0") == "1"
     sources = SOURCES + (EXPERIMENTAL if experimental else [])
-    flags = FLAGS + (["-DEMOASR_EXPERIMENTAL"] if experimental else [])
+    flags = FLAGS + (["-DEMOASR_EXPERIMENTAL"] if experimental else []) + ["-D" + d for d in defines]
     # a flavour change (default <-> experimental) rebuilds everything: the flag changes code in several units
     stamp = os.path.join(objdir, "flavour")
     flavour = "experimental" if experimental else "default"
@@ -65,4 +68,6 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    # python -m emoasr_amd.build [--force] [--variant NAME -DMACRO ...]
+    _v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    build(force="--force" in sys.argv, variant=_v, defines=[a[2:] for a in sys.argv if a.startswith("-D")])

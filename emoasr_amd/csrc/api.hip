@@ -30,6 +30,10 @@ void emo_conv_set_dwconv_lds(int v);
 void emo_layer_set_conv_fused(int v);
 void emo_layer_set_stack_launch(int v);
 void emo_layer_set_ffn_save_dact(int v);
+void emo_ln_set_fwd8(int v);
+void emo_gemm_set_wide128(int v);
+void emo_ln_set_bwd_pf(int v);
+void emo_ln_set_bwd_blocks(int v);
 void emo_rnnt_set_greedy_coop(int v);
 #ifdef EMOASR_EXPERIMENTAL
 void emo_gemm_set_k256(int v);
@@ -143,6 +147,10 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "conv_fused") == 0) { emo_layer_set_conv_fused(value); return 0; }
   if (strcmp(name, "stack_launch") == 0) { emo_layer_set_stack_launch(value); return 0; }
   if (strcmp(name, "ffn_save_dact") == 0) { emo_layer_set_ffn_save_dact(value); return 0; }
+  if (strcmp(name, "gemm_wide128") == 0) { emo_gemm_set_wide128(value); return 0; }
+  if (strcmp(name, "ln_fwd8") == 0) { emo_ln_set_fwd8(value); return 0; }
+  if (strcmp(name, "ln_bwd_pf") == 0) { emo_ln_set_bwd_pf(value); return 0; }
+  if (strcmp(name, "ln_bwd_blocks") == 0) { emo_ln_set_bwd_blocks(value); return 0; }
   if (strcmp(name, "rnnt_greedy_coop") == 0) { emo_rnnt_set_greedy_coop(value); return 0; }
 #ifdef EMOASR_EXPERIMENTAL
   if (strcmp(name, "gemm_k256") == 0) { emo_gemm_set_k256(value); return 0; }

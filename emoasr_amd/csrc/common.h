@@ -185,7 +185,14 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // ---------------------------------------------------------------------------
 // activations
 // ---------------------------------------------------------------------------
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (div_scale x2, rcp, 6 fma / mul, div_fmas, div_fixup: 11 VALU operations
+// per value -- the Swish epilogue of the first feed-forward product and the GLU / Swish staging of the convolution kernels take one
+// sigmoid per element)
+#ifdef EMO_SIGMOID_IEEE_DIV   // A/B builds only (python -m emoasr_amd.build --variant div -DEMO_SIGMOID_IEEE_DIV)
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+#else
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+#endif
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float dswishf_(float x) {
   const float s = sigmoidf_(x);

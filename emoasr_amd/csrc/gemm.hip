@@ -63,7 +63,7 @@ __device__ __forceinline__ void dgrad_row(const DgradGeom& g, int m, int& b, int
 
 int g_tr_read = 1;
 int g_gemm_wholek = 1;   // option "gemm_wholek"
-int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1, g_tn_group_kb = 0, g_tn_place = 0;
+int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1, g_tn_group_kb = 0, g_tn_place = 0, g_gemm_wide128 = 0;
 int g_tn_group_blocks = 0;  // override of a grouped TN launch's block budget (emoasr_set_option "tn_group_blocks"; 0 = auto)
 
 // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Reading
@@ -693,7 +693,11 @@ int launch_nt_(const NtArgs& a_in, hipStream_t s, int nz = 1) {
   const long t12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64) * nz;
   // ... and 64x64 again for the stacked row counts (M >= 16 k): with four to five rounds of blocks either way the smaller tile's
   // higher occupancy wins -- every instantiation of the training step 4-7 % faster in the kernel trace (6.92 -> 6.51 ms per step)
-  const int tile = g_gemm_tile ? g_gemm_tile : ((AMODE == 0 && a.M >= 16384) ? 3 : (t12864 >= 384 ? 2 : 3));
+  // (round 4, same shapes one by one: the 128-row tile is the faster one where the output is wide -- N >= 512: ffn1 45 / 50 us, qkv
+  // 36 / 43, d_ffn2 38 / 44 -- and the slower one for N = 256 -- ffn2 47 / 44, out 18.5 / 17.2.  INSIDE the training step the mixed
+  // rule is slower, three A/B pairs on one box: 29.89 against 29.65 ms per step -- option "gemm_wide128", off)
+  const bool stacked64 = AMODE == 0 && a.M >= 16384 && !(g_gemm_wide128 && a.N >= 512);
+  const int tile = g_gemm_tile ? g_gemm_tile : (stacked64 ? 3 : (t12864 >= 384 ? 2 : 3));
   const int kb = sizeof(T) == 2 ? (g_gemm_kb ? g_gemm_kb : (a.K >= 512 ? 2 : 1)) : 1;
 #define EMO_NT_LAUNCH(BM_, BN_)                                                           \
   do {                                                                                    \
@@ -796,6 +800,7 @@ int emo_gemm_nt_k256(int M, int N, const void* A, long lda, const void* B, long 
 
 void emo_gemm_set_tr_read(int v) { g_tr_read = v; }
 void emo_gemm_set_tile(int v) { g_gemm_tile = v; }
+void emo_gemm_set_wide128(int v) { g_gemm_wide128 = v ? 1 : 0; }
 void emo_gemm_set_tn_group_blocks(int v) { g_tn_group_blocks = v > 0 ? v : 0; }
 void emo_gemm_set_kb(int v) { g_gemm_kb = v; }
 void emo_gemm_set_wholek(int v) { g_gemm_wholek = v; }

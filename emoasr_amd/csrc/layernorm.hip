@@ -11,6 +11,9 @@
 namespace {
 
 constexpr int LN_MAXC = 4;  // chunks of 256 features -> N <= 1024
+int g_ln_fwd8 = 1;          // option "ln_fwd8": the half-wave-per-row forward kernel for M > 4096 rows
+int g_ln_bwd_pf = 1;        // option "ln_bwd_pf": the backward requests the next row before it reduces the current one
+int g_ln_bwd_blocks = 512;  // option "ln_bwd_blocks": persistent blocks of the N % 8 == 0 backward (<= LN_BWD8_MAXBLK)
 
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float (&o)[4]) {
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int N, const T* __re
 // per-feature dgamma / dbeta partial sums in registers; one LDS reduction and one
 // f32 atomic per feature per block at the end.
 constexpr int LN_BWD_MAXBLK = 256;   // general kernel: persistent blocks, 4 rows (one per wave) in flight each
-constexpr int LN_BWD8_MAXBLK = 512;  // N % 8 == 0 kernel: 8 rows (one per half-wave) in flight each; 1024 blocks: 9.3 us + a 26 us fold per step, 512: 8.5 + 15, 256: 9.9 + 8
+constexpr int LN_BWD8_MAXBLK = 2048;  // N % 8 == 0 kernel: 8 rows (one per half-wave) in flight each; 1024 blocks: 9.3 us + a 26 us fold per step, 512: 8.5 + 15, 256: 9.9 + 8
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int N, const T* __restrict__ dy,
@@ -204,7 +207,84 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return v;
 }
 
+// 8 consecutive features as they come from memory (16 bytes of bf16, 32 of f32): kept raw across a loop iteration so that the
+// NEXT row's loads are in flight while the current row is reduced (converting at the load would wait for it there)
+template <typename T> struct LnRaw8 {
+  Vec16<T> a[sizeof(T) == 2 ? 1 : 2];
+  __device__ __forceinline__ void load(const T* p) {
+    a[0] = load16(p);
+    if constexpr (sizeof(T) == 4) a[1] = load16(p + 4);
+  }
+  __device__ __forceinline__ void get(float (&o)[8]) const {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = a[0].get(j);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j] = a[0].get(j); o[4 + j] = a[1].get(j); }
+    }
+  }
+};
+
+// Forward fast path for many rows (training: M = 35 k stacked rows): one HALF-wave per row, 16 bytes per lane and 256-feature
+// chunk -- half as many waves in flight for the same bytes as the 4-features-per-lane kernel, whose 8-byte requests ran the pass at
+// ~2.7 TB/s (read + write).  Same two-pass statistics on the registers.
 template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_fwd8_kernel(int M, int N, const T* __restrict__ x,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps,
+                                                      T* __restrict__ y, float* __restrict__ mean,
+                                                      float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
+  const int row = (blockIdx.x * 4 + wave) * 2 + half;
+  if (row >= M) return;   // a whole half leaves: the xor offsets of half_wave_sum stay inside the other one
+  const T* xr = x + (long)row * N;
+  float v[NC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = c * 256 + hl * 8;
+    if (col < N) ln_load8(xr + col, v[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = c * 256 + hl * 8;
+    if (col < N) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[c][j];
+    }
+  }
+  const float mu = half_wave_sum(s) / N;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = c * 256 + hl * 8;
+    if (col < N) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mu; q += d * d; }
+    }
+  }
+  const float rs = rsqrtf(half_wave_sum(q) / N + eps);
+  if (hl == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+  T* yr = y + (long)row * N;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = c * 256 + hl * 8;
+    if (col < N) {
+      float o[8];
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + col), g1 = *reinterpret_cast<const f32x4*>(gamma + col + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + col), b1 = *reinterpret_cast<const f32x4*>(beta + col + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (v[c][j] - mu) * rs * g0[j] + b0[j];
+        o[4 + j] = (v[c][4 + j] - mu) * rs * g1[j] + b1[j];
+      }
+      ln_store8(yr + col, o);
+    }
+  }
+}
+
+template <typename T, int NC, bool PF>
 __global__ __launch_bounds__(256) void ln_bwd8_kernel(int M, int N, const T* __restrict__ dy,
                                                       const T* __restrict__ x,
                                                       const float* __restrict__ gamma,
@@ -225,22 +305,49 @@ __global__ __launch_bounds__(256) void ln_bwd8_kernel(int M, int N, const T* __r
       g[c][j] = col < N ? gamma[col + j] : 0.f;
     }
   }
+  // the next row's pieces are requested before the current row is reduced: a block walks M / (8 * gridDim.x) ~ 9 rows per
+  // half-wave at the stacked size, each a dependent round trip otherwise
+  LnRaw8<T> nx[NC], nd[NC], nr[NC];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](int row) __attribute__((always_inline)) {
+    if (row < M) {
+      nmu = mean[row]; nrs = rstd[row];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = c * 256 + hl * 8;
+        if (col < N) {
+          nx[c].load(x + (long)row * N + col);
+          nd[c].load(dy + (long)row * N + col);
+          if (dres) nr[c].load(dres + (long)row * N + col);
+        }
+      }
+    }
+  };
+  fetch((blockIdx.x * 4 + wave) * 2 + half);
   for (int row = (blockIdx.x * 4 + wave) * 2 + half; row < M; row += gridDim.x * 8) {
-    const float mu = mean[row], rs = rstd[row];
+    const float mu = nmu, rs = nrs;
     float xh[NC][8], gy[NC][8], o[NC][8];
+    float xv_[NC][8], dv_[NC][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int col = c * 256 + hl * 8;
       if (col < N) {
-        float xv[8], dv[8];
-        ln_load8(x + (long)row * N + col, xv);
-        ln_load8(dy + (long)row * N + col, dv);
-        if (dres) ln_load8(dres + (long)row * N + col, o[c]);
+        nx[c].get(xv_[c]); nd[c].get(dv_[c]);
+        if (dres) nr[c].get(o[c]);
         else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[c][j] = 0.f;
         }
+      }
+    }
+    if (PF) fetch(row + gridDim.x * 8);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = c * 256 + hl * 8;
+      if (col < N) {
+        const float (&xv)[8] = xv_[c];
+        const float (&dv)[8] = dv_[c];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           xh[c][j] = (xv[j] - mu) * rs;
@@ -271,6 +378,7 @@ __global__ __launch_bounds__(256) void ln_bwd8_kernel(int M, int N, const T* __r
         }
       }
     }
+    if (!PF) fetch(row + gridDim.x * 8);
   }
   if (!dgamma_part) return;
 #pragma unroll
@@ -350,10 +458,14 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_grouped_kernel(const LnFi
 }
 
 int ln_bwd_nblk(int M, int N) {
-  return N % 8 == 0 ? std::min(cdiv(M, 8), LN_BWD8_MAXBLK) : std::min(cdiv(M, 4), LN_BWD_MAXBLK);
+  return N % 8 == 0 ? std::min(cdiv(M, 8), g_ln_bwd_blocks) : std::min(cdiv(M, 4), LN_BWD_MAXBLK);
 }
 
 }  // namespace
+
+void emo_ln_set_fwd8(int v) { g_ln_fwd8 = v ? 1 : 0; }
+void emo_ln_set_bwd_pf(int v) { g_ln_bwd_pf = v ? 1 : 0; }
+void emo_ln_set_bwd_blocks(int v) { g_ln_bwd_blocks = std::max(64, std::min(v, LN_BWD8_MAXBLK)); }
 
 extern "C" int emoasr_layernorm_fwd(int dtype, int M, int N, const void* x, const float* gamma,
                                     const float* beta, float eps, void* y, float* mean, float* rstd,
@@ -364,6 +476,17 @@ extern "C" int emoasr_layernorm_fwd(int dtype, int M, int N, const void* x, cons
   if (M <= 4096) {
     EMO_DISPATCH(dtype, (ln_fwd_kernel<T, true><<<cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(
                             M, N, (const T*)x, gamma, beta, eps, (T*)y, mean, rstd)));
+  } else if (N % 8 == 0 && g_ln_fwd8) {
+#define EMO_LNF8(NC_)                                                                                      \
+  EMO_DISPATCH(dtype, (ln_fwd8_kernel<T, NC_><<<cdiv(M, 8), 256, 0, (hipStream_t)stream>>>(M, N, (const T*)x, gamma, beta, \
+                                                                                           eps, (T*)y, mean, rstd)))
+    switch (cdiv(N, 256)) {
+      case 1: EMO_LNF8(1); break;
+      case 2: EMO_LNF8(2); break;
+      case 3: EMO_LNF8(3); break;
+      default: EMO_LNF8(4); break;
+    }
+#undef EMO_LNF8
   } else {
     EMO_DISPATCH(dtype, (ln_fwd_kernel<T, false><<<cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(
                             M, N, (const T*)x, gamma, beta, eps, (T*)y, mean, rstd)));
@@ -392,10 +515,11 @@ extern "C" int emoasr_layernorm_bwd_ex(int dtype, int M, int N, const void* dy, 
   const uint64_t seed2 = opts ? opts->seed2 : 0;
   if (N % 8 == 0) {
     const int smem = 4 * 2 * N * (int)sizeof(float);
-#define EMO_LN8(NC_)                                                                              \
-  EMO_DISPATCH(dtype, (ln_bwd8_kernel<T, NC_><<<nblk, 256, smem, s>>>(M, N, (const T*)dy, (const T*)x, gamma, mean, \
-                                                                      rstd, (const T*)dres, (T*)dx, part,          \
-                                                                      (T*)dy2, scale2, p2, seed2)))
+#define EMO_LN8_(NC_, PF_)                                                                                     \
+  EMO_DISPATCH(dtype, (ln_bwd8_kernel<T, NC_, PF_><<<nblk, 256, smem, s>>>(M, N, (const T*)dy, (const T*)x, gamma, mean, \
+                                                                           rstd, (const T*)dres, (T*)dx, part,          \
+                                                                           (T*)dy2, scale2, p2, seed2)))
+#define EMO_LN8(NC_) do { if (g_ln_bwd_pf && nblk * 8 < M) EMO_LN8_(NC_, true); else EMO_LN8_(NC_, false); } while (0)
     switch (cdiv(N, 256)) {
       case 1: EMO_LN8(1); break;
       case 2: EMO_LN8(2); break;
@@ -403,6 +527,7 @@ extern "C" int emoasr_layernorm_bwd_ex(int dtype, int M, int N, const void* dy, 
       default: EMO_LN8(4); break;
     }
 #undef EMO_LN8
+#undef EMO_LN8_
   } else {
     EMO_DISPATCH(dtype, (ln_bwd_kernel<T><<<nblk, 256, 0, s>>>(M, N, (const T*)dy, (const T*)x, gamma, mean, rstd,
                                                                (const T*)dres, (T*)dx, part)));

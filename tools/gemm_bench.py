@@ -37,7 +37,8 @@ for name, m, n, k in shapes_nt:
         pre = torch.empty_like(out); resid = rnd(m, n)
         u1 = timeit(lambda: ops.gemm_nt(a, b, out=out, bias=bias, act=ops.ACT_SWISH, pre_out=pre, drop_p=0.1, seed=5))
         u2 = timeit(lambda: ops.gemm_nt(a, b, out=out, bias=bias, residual=resid, res_scale=0.5, drop_p=0.1, seed=5))
-        print(f"   {name:8s} with swish+dropout+pre_out {u1:8.1f} us   with residual+dropout {u2:8.1f} us")
+        u4 = timeit(lambda: ops.gemm_nt(a, b, out=out, bias=bias, act=ops.ACT_SWISH | ops.ACT_SAVE_DACT, pre_out=pre, drop_p=0.1, seed=5))
+        print(f"   {name:8s} with swish+dropout+pre_out {u1:8.1f} us   saved factor instead of pre {u4:8.1f} us   with residual+dropout {u2:8.1f} us")
     if os.environ.get("EPI") and n == 256:    # the block outputs: x += 0.5 * dropout(acc + bias), in place (C aliases the residual)
         x = rnd(m, n)
         u3 = timeit(lambda: ops.gemm_nt(a, b, out=x, bias=bias, residual=x, res_scale=0.5, drop_p=0.1, seed=5))
@@ -51,7 +52,8 @@ for name, m, n, k in shapes_nn:
     if os.environ.get("EPI") and k == 256 and n == 1024:   # dgrad through w2 with the Swish derivative of the saved pre-activation
         pre = rnd(m, n)
         u3 = timeit(lambda: ops.gemm_nn(a, b, out=out, dact_pre=pre, dact=ops.ACT_SWISH, drop_p=0.1, seed=5))
-        print(f"   {name:8s} with dact(pre) + dropout {u3:8.1f} us")
+        u5 = timeit(lambda: ops.gemm_nn(a, b, out=out, dact_pre=pre, dact=ops.DACT_MUL))
+        print(f"   {name:8s} with dact(pre) + dropout {u3:8.1f} us   with the saved factor {u5:8.1f} us")
     tot += us
     ub = timeit(lambda: torch.mm(a, b, out=out)) if os.environ.get("BLAS") else 0.0
     print(f"nn {name:8s} {m}x{n}x{k}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TF/s  {(m*k+n*k+m*n)*2/us/1e3:7.1f} GB/s   blas {ub:8.1f} us")
