@@ -53,6 +53,7 @@ struct BigDgrad {  // data gradient, one entry per output-parity class (pt, pf)
 struct BigRnnt {
   int mode, Tn, U, Lmax, blank, nchunk;
   long row0;               // cell index of row 0 of this launch
+  long part_rows, part_row0;   // partial table [chunk][part_rows][2]: this launch's row 0 is table row part_row0
   const int* labels; const int* ylens;
   float* part; float* zb; float* zy;
   const float* coef; const int* ycol;
@@ -370,8 +371,9 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
             }
             if (rok) {
               if (cc == 0 && chunk < rn.nchunk) {   // (the last column tile may reach past ceil(N / 64) chunks)
-                float* pp = rn.part + ((long)grow * rn.nchunk + chunk) * 2;
-                pp[0] = m; pp[1] = sm;
+                // chunk-major table: the eight rows of this pass land in 64 consecutive bytes, and the fold reads it coalesced
+                // (row-major, 8-byte pieces 8 * nchunk bytes apart: the fold of the CTC head's 35 k x 157 table took 103 us)
+                *reinterpret_cast<float2*>(rn.part + ((long)chunk * rn.part_rows + rn.part_row0 + grow) * 2) = float2{m, sm};
               }
               if (cok && rn.mode == 1) {
                 const int cell = (int)(rn.row0 + grow);
@@ -437,6 +439,11 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
             if (pre_out) store8<bf16>(pre_out + off, v);
             act_vec<8>(ep.act, v);
             dropout_apply8(ep.seed, (uint64_t)grow * (uint64_t)g.N + col, ep.drop_p, v);   // (N % 8 == 0, col % 8 == 0)
+          }
+          if (ep.residual) {   // x + res_scale * (...); C may alias the residual: every lane reads exactly what it then writes
+            const Vec16<bf16> rv = load16(static_cast<const bf16*>(ep.residual) + (long)grow * ep.ldr + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rv.get(e) + ep.res_scale * v[e];
           }
           store8<bf16>(Cp + off, v);
         }
@@ -574,12 +581,22 @@ int g_big_min_tiles = 2000;
 
 // Does the large-tile kernel take this emoasr_gemm_nt call?  (bf16 product, full 256-column tiles, 64-deep k-tiles, an
 // epilogue without residual / saved-activation / f32 output, and enough 128-row tiles to occupy most CUs.)
+// Round 4: ... and the long reductions onto ONE 256-column tile (N = 256, K >= 512, stacked row counts): the second feed-forward
+// product (K = 1024, residual epilogue), the front-end Linear (K = 4864).  A 192-row tile reads every A row once where the 64 x 64
+// grid reads it four times; tools/big_n256_probe.py at 35 145 rows: 38.0 -> 29.5 us (K = 1024), 30.9 -> 24.7 (768),
+// 184.7 -> 108.3 (4864), 370.7 -> 223.8 (10 048), bit-identical results (vendor BLAS: 23.6 / 20.6 / 87.1 / 191.2).
+// Option "big_n256".
+int g_big_n256 = 1;
 bool emo_gemm_nt_big_wants(int M, int N, int K, long lda, long ldb, long ldc, const emoasr_epilogue_t& ep) {
   if (!g_conv_big || N % 8 != 0 || N < 256 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) return false;
-  if (ep.residual || ep.dact_pre || ep.out_f32) return false;
+  if (ep.dact_pre || ep.out_f32) return false;
+  if (ep.residual && ep.ldr % 8 != 0) return false;
   if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldb * 2 >= (1L << 32)) return false;
+  if (g_big_n256 && N == 256 && K >= 512 && M >= 8192) return true;
+  if (ep.residual) return false;   // (only measured for the shapes above)
   return (long)cdiv(M, 128) * cdiv(N, 256) >= g_big_min_tiles;
 }
+void emo_gemm_set_big_n256(int v) { g_big_n256 = v ? 1 : 0; }
 int emo_gemm_nt_big_ep(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                        const emoasr_epilogue_t& ep, hipStream_t s) {
   BigArgs a{};
@@ -620,29 +637,45 @@ static int rnnt_head_launch(int nrows, int V, int J, const void* h, const void* 
 // part [nrows, ceil(V / 64), 2], zb / zy [nrows] (see BigRnnt).  The logits are never stored.
 extern "C" int emoasr_rnnt_head_fwd(int dtype, long row0, int nrows, int Tn, int U, int V, int J, int Lmax, const void* h,
                                     const void* w, const float* bias, const int* labels, const int* ylens, int blank,
-                                    float* part, float* zb, float* zy, void* stream) {
+                                    float* part, long part_rows, float* zb, float* zy, void* stream) {
   EMO_CHECK(dtype == EMO_BF16, "rnnt_head_fwd: bf16 only");
   if (nrows == 0) return 0;
   EMO_CHECK(blank >= 0 && blank < V && row0 + nrows < (1L << 31), "rnnt_head_fwd: bad blank / cell range");
+  EMO_CHECK(row0 >= 0 && row0 + nrows <= part_rows, "rnnt_head_fwd: cells %ld..%ld outside the partial table's %ld rows", row0, row0 + nrows, part_rows);
   BigRnnt rn{};
   rn.mode = 1; rn.Tn = Tn; rn.U = U; rn.Lmax = Lmax; rn.blank = blank; rn.nchunk = cdiv(V, 64); rn.row0 = row0;
-  rn.labels = labels; rn.ylens = ylens; rn.part = part; rn.zb = zb; rn.zy = zy;
+  rn.labels = labels; rn.ylens = ylens; rn.part = part; rn.part_rows = part_rows; rn.part_row0 = row0; rn.zb = zb; rn.zy = zy;
   return rnnt_head_launch(nrows, V, J, h, w, bias, nullptr, V, rn, (hipStream_t)stream);
 }
 
-__global__ __launch_bounds__(256) void lse_parts_kernel(long rows, int nchunk, const float* __restrict__ part, float* __restrict__ lse) {
-  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+// part [nchunk][rows][2] (chunk-major): one thread per row, 4 chunks per round trip
+__global__ __launch_bounds__(64) void lse_parts_kernel(long rows, int nchunk, const float* __restrict__ part, float* __restrict__ lse) {
+  const long row = (long)blockIdx.x * 64 + threadIdx.x;
   if (row >= rows) return;
-  const float* pp = part + row * nchunk * 2;
-  float m = -INFINITY;
-  for (int c = 0; c < nchunk; ++c) m = fmaxf(m, pp[2 * c]);
-  float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += pp[2 * c + 1] * __expf(pp[2 * c] - m);
+  const float2* pp = reinterpret_cast<const float2*>(part) + row;
+  float m = -INFINITY, s = 0.f;
+  int c = 0;
+  for (; c + 4 <= nchunk; c += 4) {
+    float2 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = pp[(long)(c + k) * rows];
+    const float mn = fmaxf(fmaxf(fmaxf(v[0].x, v[1].x), fmaxf(v[2].x, v[3].x)), m);
+    s = s * __expf(m - mn);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += v[k].y * __expf(v[k].x - mn);
+    m = mn;
+  }
+  for (; c < nchunk; ++c) {
+    const float2 v = pp[(long)c * rows];
+    const float mn = fmaxf(m, v.x);
+    s = s * __expf(m - mn) + v.y * __expf(v.x - mn);
+    m = mn;
+  }
   lse[row] = m + logf(s);
 }
 
 // C[M,N] = A . B^T + bias (bf16) AND lse[m] = log sum_n exp(C[m,n]) of the stored row, in one pass: the soft-max partials leave the
-// product's epilogue (part: scratch [M, ceil(N / 64), 2] f32).  The CTC head (decoders/ctc.py:103-113: Linear + log_softmax)
+// product's epilogue (part: scratch [ceil(N / 64), M, 2] f32).  The CTC head (decoders/ctc.py:103-113: Linear + log_softmax)
 // without the separate pass that read the 703 MB of logits back.
 extern "C" int emoasr_gemm_nt_lse(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                                   const float* bias, float* part, float* lse, void* stream) {
@@ -653,11 +686,11 @@ extern "C" int emoasr_gemm_nt_lse(int dtype, int M, int N, int K, const void* A,
   BigArgs a{};
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.ep.alpha = 1.f; a.ep.bias = bias; a.ep.res_scale = 1.f;
-  a.rn.mode = 3; a.rn.nchunk = cdiv(N, 64); a.rn.part = part;
+  a.rn.mode = 3; a.rn.nchunk = cdiv(N, 64); a.rn.part = part; a.rn.part_rows = M; a.rn.part_row0 = 0;
   const int bm = g_big_bm ? g_big_bm : pick_bm(M, n_cu_cached());
   a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(N, 256);
   if (launch_big_bm<0>(a, bm, a.tiles_m * a.tiles_n, (hipStream_t)stream)) return 1;
-  lse_parts_kernel<<<cdiv(M, 256), 256, 0, (hipStream_t)stream>>>(M, a.rn.nchunk, part, lse);
+  lse_parts_kernel<<<cdiv(M, 64), 64, 0, (hipStream_t)stream>>>(M, a.rn.nchunk, part, lse);
   EMO_LAUNCH_CHECK();
   return 0;
 }

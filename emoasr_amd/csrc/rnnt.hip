@@ -497,11 +497,14 @@ __global__ __launch_bounds__(256) void rnnt_parts_kernel(long rows, int Tn, int 
                                                          float* __restrict__ zb, float* __restrict__ zy) {
   const long row = (long)blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
-  const float* pp = part + row * nchunk * 2;
-  float m = -INFINITY;
-  for (int c = 0; c < nchunk; ++c) m = fmaxf(m, pp[2 * c]);
-  float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += pp[2 * c + 1] * __expf(pp[2 * c] - m);
+  const float2* pp = reinterpret_cast<const float2*>(part) + row;   // chunk-major table [nchunk][rows][2]
+  float m = -INFINITY, s = 0.f;
+  for (int c = 0; c < nchunk; ++c) {
+    const float2 v = pp[(long)c * rows];
+    const float mn = fmaxf(m, v.x);
+    s = s * __expf(m - mn) + v.y * __expf(v.x - mn);
+    m = mn;
+  }
   const float l = m + logf(s);
   const int u = row % U;
   const long b = row / ((long)Tn * U);

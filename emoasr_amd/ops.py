@@ -585,7 +585,7 @@ def gemm_nt_lse(a, b, bias):
     if (a.dtype == torch.bfloat16 and N % 8 == 0 and N >= 256 and K % 64 == 0 and lda % 8 == 0 and ldb % 8 == 0
             and M * lda * 2 < (1 << 32) and N * ldb * 2 < (1 << 32) and M >= 2048):
         out = torch.empty(M, N, device=a.device, dtype=a.dtype)
-        part = torch.empty(M, (N + 63) // 64, 2, device=a.device, dtype=torch.float32)
+        part = torch.empty((N + 63) // 64, M, 2, device=a.device, dtype=torch.float32)
         lse = torch.empty(M, device=a.device, dtype=torch.float32)
         lib.call("emoasr_gemm_nt_lse", dt(a), M, N, K, _p(a), lda, _p(b), ldb, _p(out), N, _p(bias), _p(part), _p(lse), _stream())
         return out, lse
@@ -866,7 +866,7 @@ def rnnt_head_forward(h, w, bias, B, T, U, labels, elens, ylens, blank):
     V = w.shape[0]
     dev = h.device
     nchunk = (V + 63) // 64
-    part = torch.empty(N, nchunk, 2, device=dev, dtype=torch.float32)
+    part = torch.empty(nchunk, N, 2, device=dev, dtype=torch.float32)   # chunk-major: every launch fills its rows
     f = lambda: torch.empty(B, T, U, device=dev, dtype=torch.float32)
     lse, zb, zy, alpha, beta = f(), f(), f(), f(), f()
     zy.fill_(0.0)   # (cells beyond ylens never get a label logit)
@@ -874,7 +874,7 @@ def rnnt_head_forward(h, w, bias, B, T, U, labels, elens, ylens, blank):
     for r0 in range(0, N, step):
         n = min(step, N - r0)
         lib.call("emoasr_rnnt_head_fwd", dt(h), r0, n, T, U, V, J, labels.shape[1], _p(h[r0:r0 + n]), _p(w), _p(bias), _p(labels),
-                 _p(ylens), blank, _p(part[r0:r0 + n]), _p(zb.view(-1)[r0:r0 + n]), _p(zy.view(-1)[r0:r0 + n]), _stream())
+                 _p(ylens), blank, _p(part), N, _p(zb.view(-1)[r0:r0 + n]), _p(zy.view(-1)[r0:r0 + n]), _stream())
     nll = torch.empty(B, device=dev, dtype=torch.float32)
     lib.call("emoasr_rnnt_forward_parts", B, T, U, V, _p(part), _p(elens), _p(ylens), _p(lse), _p(zb), _p(zy), _p(alpha),
              _p(beta), _p(nll), _stream())

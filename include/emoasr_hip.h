@@ -338,7 +338,7 @@ int emoasr_add(int dtype, long n, const void* a, const void* b, void* y, void* s
 /* lse[m] = logsumexp_v logits[m,:V] */
 int emoasr_row_lse(int dtype, int M, int V, const void* logits, long ld, float* lse, void* stream);
 /* The CTC head in one pass (csrc/gemm_big.hip; bf16, N % 8 == 0, K % 64 == 0): C = A . B^T + bias stored AND lse[m] = log sum_n
- * exp(C[m,n]) of the row as stored -- the soft-max partials leave the product's epilogue (part: scratch [M, ceil(N / 64), 2] f32)
+ * exp(C[m,n]) of the row as stored -- the soft-max partials leave the product's epilogue (part: scratch [ceil(N / 64), M, 2] f32)
  * instead of a second pass over the logits (emoasr_gemm_nt + emoasr_row_lse).  decoders/ctc.py:103-113. */
 int emoasr_gemm_nt_lse(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                        const float* bias, float* part, float* lse, void* stream);
@@ -473,7 +473,8 @@ int emoasr_rnnt_grad(int dtype, int B, int T, int U, int V, int Lmax, const void
  * J % 64 == 0).  Replaces `self.output(torch.tanh(...))` + `log_softmax` + warp_rnnt's gathers of rnn_transducer.py:101-115,
  * 147-156 for training: z = h . W^T + bias is formed tile by tile on the MFMA pipeline and reduced in the epilogue.
  *   emoasr_rnnt_head_fwd   cells row0 .. row0 + nrows (h: their joint activations [nrows, J]): per row and 64-column chunk the
- *                          soft-max partials part[n, c] = (max, sum exp(z - max)) -- part [nrows, ceil(V / 64), 2] -- and the two
+ *                          soft-max partials part[c, row0 + n] = (max, sum exp(z - max)) -- part is the WHOLE chunk-major table
+ *                          [ceil(V / 64), part_rows, 2] of all cells, every launch fills its rows -- and the two
  *                          logits the lattice reads, zb[n] = z[n, blank], zy[n] = z[n, labels[b, u]] (u < ylens[b]);
  *   emoasr_rnnt_forward_parts   lse from the partials, zb / zy turned into lpb / lpy IN PLACE, then the alpha / beta lattices and
  *                          nll exactly as emoasr_rnnt_forward;
@@ -483,8 +484,8 @@ int emoasr_rnnt_grad(int dtype, int B, int T, int U, int V, int Lmax, const void
  *                          z RECOMPUTED from h: the caller walks the cells in chunks (dz chunk -> emoasr_gemm_tn / _nn), so no
  *                          [cells, V] buffer exists in either direction. */
 int emoasr_rnnt_head_fwd(int dtype, long row0, int nrows, int T, int U, int V, int J, int Lmax, const void* h, const void* w,
-                         const float* bias, const int* labels, const int* ylens, int blank, float* part, float* zb, float* zy,
-                         void* stream);
+                         const float* bias, const int* labels, const int* ylens, int blank, float* part, long part_rows, float* zb,
+                         float* zy, void* stream);
 int emoasr_rnnt_forward_parts(int B, int T, int U, int V, const float* part, const int* elens, const int* ylens, float* lse,
                               float* zb_lpb, float* zy_lpy, float* alpha, float* beta, float* nll, void* stream);
 int emoasr_rnnt_coef(int B, int T, int U, int Lmax, const float* lse, const float* lpb, const float* lpy, const float* alpha,

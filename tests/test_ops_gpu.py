@@ -233,13 +233,43 @@ def test_gemm_nt_dispatch_to_large_tile_kernel(dev, M, N, K):
             outs.append((y, pre, ops.gemm_nt(a, b)))
     finally:
         lib.set_option("conv_big", 1)
-        lib.set_option("big_min_tiles", 512)
+        lib.set_option("big_min_tiles", 2000)   # (the library's default)
     (y1, p1, r1), (y0, p0, r0) = outs
     assert torch.equal(y1 == 0, y0 == 0), "dropout masks differ"
     _close(p1, 0.5 * (a.float() @ b.float().t()) + bias, 1e-2, "pre-activation")
     _close(p1, p0, 1e-2, "pre-activation vs 128x64")
     _close(y1, y0, 1e-2, "swish + dropout vs 128x64")
     _close(r1, r0, 1e-2, "plain")
+
+
+@pytest.mark.parametrize("M,N,K", [(8200, 256, 1024), (9001, 256, 768), (8192, 256, 4864)])
+def test_gemm_nt_long_reductions_on_one_column_tile(dev, M, N, K):
+    """N = 256, K >= 512, many rows (the second feed-forward product, the front-end Linear of the stacked step): emoasr_gemm_nt
+    takes the large-tile kernel, whose residual epilogue (x + res_scale * dropout(alpha * acc + bias), in place) must equal the
+    64 x 64 kernel's -- same dropout mask, same values -- and the f32 product of the same operands"""
+    from emoasr_amd import lib, ops
+    a = _rnd(dev, M, K, dtype=torch.bfloat16)
+    b = _rnd(dev, N, K, dtype=torch.bfloat16, scale=K ** -0.5)
+    bias = _rnd(dev, N, scale=0.5)
+    x0 = _rnd(dev, M, N, dtype=torch.bfloat16)
+    outs = []
+    try:
+        for big in (1, 0):
+            lib.set_option("big_n256", big)
+            x = x0.clone()
+            ops.gemm_nt(a, b, out=x, bias=bias, residual=x, res_scale=0.5, drop_p=0.1, seed=91)   # in place
+            outs.append((x, ops.gemm_nt(a, b, bias=bias, residual=x0, res_scale=0.5), ops.gemm_nt(a, b, bias=bias)))
+    finally:
+        lib.set_option("big_n256", 1)
+    (x1, r1, p1), (x0_, r0, p0) = outs
+    assert torch.equal(x1 == x0, x0_ == x0), "dropout masks differ"
+    ref = a.float() @ b.float().t() + bias
+    _close(p1, ref, 1e-2, "plain")
+    _close(r1, x0.float() + 0.5 * ref, 1e-2, "residual")
+    _close(x1, x0_, 1e-2, "residual + dropout vs 64x64")
+    _close(r1, r0, 1e-2, "residual vs 64x64")
+    kept = x1 != x0
+    _close(x1[kept], (x0.float() + 0.5 * ref / 0.9)[kept], 2e-2, "kept elements")
 
 
 @pytest.mark.parametrize("bm", [0, 256, 192, 128])
