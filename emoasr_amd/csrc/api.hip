@@ -57,7 +57,6 @@ void emo_attn_set_lpt(int v);
 void emo_attn_set_fwd_split(int v);
 void emo_attn_set_xcd(int v);
 void emo_attn_set_fwd_waves(int v);
-void emo_layer_set_ffn_fused(int v);
 
 // ---- kernel timers: HIP-event pairs around selected launches, on the stream they are launched on -----------------------
 // (bench.py's roofline object needs the live device time of ONE kernel that sits behind a composite entry point;
@@ -168,9 +167,8 @@ extern "C" int emoasr_set_option(const char* name, int value) {
 #ifdef EMOASR_EXPERIMENTAL
   if (strcmp(name, "decode_fused") == 0) { emo_decode_set_fused(value); return 0; }
   if (strcmp(name, "decode_wg") == 0) { emo_decode_set_wg(value); return 0; }
-  if (strcmp(name, "ffn_fused") == 0) { emo_layer_set_ffn_fused(value); return 0; }
 #else
-  if (strcmp(name, "decode_fused") == 0 || strcmp(name, "decode_wg") == 0 || strcmp(name, "ffn_fused") == 0) {
+  if (strcmp(name, "decode_fused") == 0 || strcmp(name, "decode_wg") == 0) {
     if (value == 0) return 0;
     emo_set_error("option '%s' needs a library built with EMOASR_EXPERIMENTAL=1 (measured-slower variants, csrc/experimental/)", name);
     return 1;

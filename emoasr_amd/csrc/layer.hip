@@ -22,11 +22,9 @@ emoasr_epilogue_t plain_ep() {
   return e;
 }
 
-// x + res_scale * drop(W2 act(W1 LN(x) + b1) + b2)
-int g_ffn_fused = 0;  // bf16, d = 256: the feed-forward block as ONE launch (csrc/experimental/ffn.hip, EMOASR_EXPERIMENTAL builds
-                      // only) -- measured slower than LayerNorm + two GEMMs at the L2 batch size (87 vs 40 us, see ffn.hip), so
-                      // off unless emoasr_set_option("ffn_fused", 1)
-
+// x + res_scale * drop(W2 act(W1 LN(x) + b1) + b2): LayerNorm + two products.  (The block as ONE launch -- 64 rows per workgroup, the
+// F-wide intermediate consumed on chip -- was built in round 2 and measured again at the stacked size in round 4: 263 us against
+// 120 us at M = 35 145, 90 against 36 at M = 7 029; every CU streams both weight matrices for its 64 rows.  Deleted.)
 int g_ffn_save_dact = 1;  // option "ffn_save_dact": the feed-forward blocks save Swish'(u) * dropout_scale instead of u (common.h:
                           // EMO_ACT_SAVE_DACT); must not change between a forward and its backward
 int g_stack_launch = 1;  // stacked micro-batches: 1 = the per-utterance kernels take all segments in ONE launch (segment table in
@@ -36,11 +34,6 @@ bool conv_fused_ok(int dtype, int d) { return g_conv_fused && dtype == EMO_BF16 
 
 int ffn_fwd(int dtype, int M, int d, int F, const emoasr_ffn_params_t& p, const void* x, float res_scale,
             float p_enc, uint64_t s_in, uint64_t s_out, const emoasr_ffn_stash_t& st, void* stream) {
-#ifdef EMOASR_EXPERIMENTAL
-  if (g_ffn_fused && dtype == EMO_BF16 && d == 256 && F % 256 == 0)
-    return emoasr_ffn_fwd(dtype, M, d, F, x, p.ln_g, p.ln_b, 1e-5f, p.w1, p.b1, p.w2, p.b2, EMOASR_ACT_SWISH, res_scale, p_enc,
-                          s_in, s_out, st.h, st.mean, st.rstd, st.u, st.a, st.y, stream);
-#endif
   if (emoasr_layernorm_fwd(dtype, M, d, x, p.ln_g, p.ln_b, 1e-5f, st.h, st.mean, st.rstd, stream)) return 1;
   emoasr_epilogue_t e1 = plain_ep();
   e1.bias = p.b1; e1.act = EMOASR_ACT_SWISH | (g_ffn_save_dact ? EMOASR_ACT_SAVE_DACT : 0); e1.pre_out = st.u; e1.drop_p = p_enc; e1.seed = s_in;
@@ -107,7 +100,6 @@ void attn_args_for(emoasr_attn_t& a, const SegView& sv, int s0, int s1, int H, i
 
 }  // namespace
 
-void emo_layer_set_ffn_fused(int v) { g_ffn_fused = v; }
 void emo_layer_set_conv_fused(int v) { g_conv_fused = v; }
 void emo_layer_set_stack_launch(int v) { g_stack_launch = v; }
 void emo_layer_set_ffn_save_dact(int v) { g_ffn_save_dact = v ? 1 : 0; }

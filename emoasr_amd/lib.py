@@ -190,7 +190,6 @@ SIGNATURES = {
     "emoasr_layernorm_bwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     "emoasr_layernorm_bwd_ex": [I, I, I, P, P, P, P, P, P, P, P, P, P, POINTER(LnBwdOpts), P],
     "emoasr_layernorm_bwd_finalize": [I, POINTER(LnFinalizeItem), P],
-    "emoasr_ffn_fwd": [I, I, I, I, P, P, P, F, P, P, P, P, I, F, F, U64, U64, P, P, P, P, P, P, P],
     "emoasr_conformer_layer_fwd": [I, POINTER(ConformerLayer), POINTER(ConformerFwd), P],
     "emoasr_conformer_layer_bwd": [I, POINTER(ConformerLayer), POINTER(ConformerLayer), POINTER(ConformerFwd),
                                    POINTER(ConformerBwd), P],
@@ -313,7 +312,7 @@ def load():
 
 _FN = {}
 # entry points that exist only in a library built with EMOASR_EXPERIMENTAL=1 (csrc/experimental/)
-EXPERIMENTAL_ONLY = {"emoasr_ffn_fwd"}
+EXPERIMENTAL_ONLY = set()
 
 
 def experimental():

@@ -283,23 +283,6 @@ def layernorm_bwd_finalize(deferred):
     del deferred[:]
 
 
-def ffn_fwd(x, ln_g, ln_b, eps, w1, b1, w2, b2, act, res_scale, drop_p=0.0, seed_in=0, seed_out=0, keep=True):
-    """fused feed-forward block (csrc/ffn.hip; bf16, d = 256, F % 256 == 0):
-    y = x + res_scale * drop(W2 drop(act(W1 LN(x) + b1)) + b2)  -> (y, h, mean, rstd, u | None, a)"""
-    M, d, ld = _rows(_chk(x))
-    F = w1.shape[0]
-    assert ld == d and w1.shape == (F, d) and w2.shape == (d, F)
-    dev = x.device
-    h, y = torch.empty_like(x), torch.empty_like(x)
-    a = torch.empty(M, F, device=dev, dtype=x.dtype)
-    u = torch.empty(M, F, device=dev, dtype=x.dtype) if keep else None
-    mean = torch.empty(M, device=dev, dtype=torch.float32) if keep else None
-    rstd = torch.empty(M, device=dev, dtype=torch.float32) if keep else None
-    lib.call("emoasr_ffn_fwd", dt(x), M, d, F, _p(x), _p(ln_g), _p(ln_b), eps, _p(_chk(w1, x.dtype)), _p(b1), _p(_chk(w2, x.dtype)),
-             _p(b2), act, res_scale, drop_p, seed_in, seed_out, _p(h), _p(mean), _p(rstd), _p(u), _p(a), _p(y), _stream())
-    return y, h, mean, rstd, u, a
-
-
 # ---- attention -------------------------------------------------------------------------
 def _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, seed):
     B, Tq, D = q.shape

@@ -39,7 +39,7 @@ enum { EMOASR_ACT_NONE = 0, EMOASR_ACT_RELU = 1, EMOASR_ACT_SWISH = 2,
 const char* emoasr_last_error(void);
 int emoasr_version(void);
 /* 1 when the library was built with EMOASR_EXPERIMENTAL=1 (the measured-slower variants of csrc/experimental/ are linked in and
- * the options "ffn_fused", "decode_wg", "decode_fused" exist), else 0 */
+ * the options "decode_wg", "decode_fused" exist), else 0 */
 int emoasr_experimental(void);
 /* options: "tr_read" (1 = ds_read_b64_tr_b16 operand reads, 0 = scalar fallback); tuning: "gemm_tile", "gemm_kb",
  * "gemm_xcd", "gemm_wholek", "tn_group_blocks", "tn_group_kb", "tn_place", "attn_lpt", "attn_xcd", "attn_fwd_waves", "attn_fwd_split", "attn_fw" (key tiles per workgroup of the single-pass attention backward: 2, 4, 0 = auto);
@@ -587,19 +587,6 @@ typedef struct emoasr_conformer_fwd {
 } emoasr_conformer_fwd_t;
 int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* layer,
                                const emoasr_conformer_fwd_t* io, void* stream);
-#ifdef EMOASR_EXPERIMENTAL
-/* (opt-in build, EMOASR_EXPERIMENTAL=1: csrc/experimental/ffn.hip -- bit-identical to the three launches it replaces,
- * measured 2.2x slower at the L2 batch size, NOT part of the default library) */
-/* Fused feed-forward block (bf16, d = 256, F a multiple of 256): y = x + res_scale * drop(W2 . drop(act(W1 . LN(x) + b1)) + b2)
- * in ONE launch (transformer.py:102-118 behind the LayerNorm and residual of conformer.py:196-207,222-225); the F-wide
- * intermediate is consumed on chip, its pre-activation u (optional) and activation a are still written for the backward.
- * Bit-identical to emoasr_layernorm_fwd + emoasr_gemm_nt (bias, act, pre_out, dropout seed_in) + emoasr_gemm_nt (bias,
- * dropout seed_out, residual, res_scale).  h [M,d], mean / rstd [M] (optional), u / a [M,F], y [M,d]. */
-int emoasr_ffn_fwd(int dtype, int M, int d, int F, const void* x, const float* ln_g, const float* ln_b, float eps,
-                   const void* w1, const float* b1, const void* w2, const float* b2, int act, float res_scale,
-                   float drop_p, uint64_t seed_in, uint64_t seed_out, void* h, float* mean, float* rstd, void* u,
-                   void* a, void* y, void* stream);
-#endif
 /* Backward of the same layer (bf16; training-mode forward with stash) as one call: gradient kernels in the order the
  * reference's autograd runs them (conformer.py:146-225 backwards), the layer's nine weight-gradient products as one grouped
  * launch.  `grads`: the layer struct again with every parameter pointer replaced by the address of its f32 gradient

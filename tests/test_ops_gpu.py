@@ -384,33 +384,6 @@ def test_layernorm(dev, dtype, N, eps):
     _close(db, br.grad, 1e-4, "ln dbeta")
 
 
-@pytest.mark.parametrize("act", ["swish", "relu"])
-@pytest.mark.parametrize("drop", [0.0, 0.1])
-@pytest.mark.parametrize("M,F", [(333, 1024), (64, 256), (7029, 1024)])
-def test_ffn_fwd_fused_is_bit_identical_to_layernorm_plus_two_gemms(dev, M, F, drop, act):
-    """csrc/experimental/ffn.hip keeps every accumulation order and every rounding point of the unfused path"""
-    from emoasr_amd import lib, ops
-    if not lib.experimental():
-        pytest.skip("measured-slower variant: only in a library built with EMOASR_EXPERIMENTAL=1")
-    d, dt_ = 256, torch.bfloat16
-    A = ops.ACT_SWISH if act == "swish" else ops.ACT_RELU
-    x = _rnd(dev, M, d, dtype=dt_)
-    ln_g, ln_b = 1 + 0.1 * _rnd(dev, d), 0.1 * _rnd(dev, d)
-    w1, b1 = _rnd(dev, F, d, dtype=dt_, scale=d ** -0.5), 0.1 * _rnd(dev, F)
-    w2, b2 = _rnd(dev, d, F, dtype=dt_, scale=F ** -0.5), 0.1 * _rnd(dev, d)
-    h, mean, rstd = ops.layernorm_fwd(x, ln_g, ln_b, 1e-5, True)
-    u = torch.empty(M, F, device=dev, dtype=dt_)
-    a = ops.gemm_nt(h, w1, bias=b1, act=A, pre_out=u, drop_p=drop, seed=11)
-    y = ops.gemm_nt(a, w2, bias=b2, residual=x, res_scale=0.5, drop_p=drop, seed=12)
-    y2, h2, mean2, rstd2, u2, a2 = ops.ffn_fwd(x, ln_g, ln_b, 1e-5, w1, b1, w2, b2, A, 0.5, drop, 11, 12)
-    assert torch.equal(h2, h) and torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
-    assert torch.equal(u2, u), (u2.float() - u.float()).abs().max()
-    assert torch.equal(a2, a), (a2.float() - a.float()).abs().max()
-    assert torch.equal(y2, y), (y2.float() - y.float()).abs().max()
-    y3, _, _, _, u3, a3 = ops.ffn_fwd(x, ln_g, ln_b, 1e-5, w1, b1, w2, b2, A, 0.5, drop, 11, 12, keep=False)
-    assert u3 is None and torch.equal(y3, y) and torch.equal(a3, a)
-
-
 # ---------------------------------------------------------------- attention
 def _attn_ref(q, k, v, H, scale, pos, bu, bv, klens, causal):
     B, Tq, D = q.shape
