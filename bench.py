@@ -392,9 +392,12 @@ def l4_rnnt(dev, dtype, steps=8, warmup=2, n_dec=5, accum=5):
         opt.zero_grad()
         if stacked:
             outs = encoder_apply_stacked(model.encoder, [bt[0] for bt in grp], [bt[1] for bt in grp])
+            # (as emoasr_amd/train.py: train_group) the prediction network of all micro-batches in one pass
+            preds = model.decoder.prediction_stacked([bt[4] for bt in grp], [bt[3] for bt in grp])
             total = None
-            for (eouts, elens, _), bt in zip(outs, grp):
-                loss, _, _ = model.decoder(eouts, elens, None, bt[2], bt[3], bt[4], bt[5], None, None, None)
+            for k, ((eouts, elens, _), bt) in enumerate(zip(outs, grp)):
+                extra = {} if preds is None else {"pred": preds[k]}
+                loss, _, _ = model.decoder(eouts, elens, None, bt[2], bt[3], bt[4], bt[5], None, None, None, **extra)
                 total = loss / accum if total is None else total + loss / accum
             total.backward()
         else:

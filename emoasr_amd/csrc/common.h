@@ -182,6 +182,19 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
+// One fused multiply-add per tap in the depthwise stencils (the build has -ffp-contract=off: a * b + c stays two instructions
+// and two roundings elsewhere, which the bit-identity tests between fused and unfused kernels rely on).  The convolution kernels
+// are VALU-bound (31 taps per output, forward, data gradient and weight gradient): v_fma_f32 / v_pk_fma_f32 halve their inner
+// loops.  Every stencil -- convmodule.hip and convfused.hip -- goes through these two, so they stay bit-identical to each other.
+typedef __attribute__((ext_vector_type(2))) float emo_f2;
+#ifdef EMO_CONV_NO_FMA   // A/B builds only
+__device__ __forceinline__ float emo_mac(float a, float b, float c) { return c + a * b; }
+__device__ __forceinline__ emo_f2 emo_mac2(emo_f2 a, emo_f2 b, emo_f2 c) { return c + a * b; }
+#else
+__device__ __forceinline__ float emo_mac(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ emo_f2 emo_mac2(emo_f2 a, emo_f2 b, emo_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+
 // ---------------------------------------------------------------------------
 // activations
 // ---------------------------------------------------------------------------

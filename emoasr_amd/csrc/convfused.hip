@@ -33,8 +33,8 @@ constexpr int CF_ROWS_P = 64;                 // LDS rows (the staging passes ar
 // Work split of the compute phases (both kernels): a thread owns TWO adjacent channels (packed f32x2 multiplies and adds:
 // half the VALU instructions of one channel per thread) and one HALF of the tile -- 16 of the 32 output frames of a
 // convolution, or 16 of the (up to) 31 taps of the weight gradient, whose sums over the 32 frames then keep the frame order
-// of the unfused kernel.  mul and add stay separate instructions (the build has -ffp-contract=off), as in the kernels
-// these replace.
+// of the unfused kernel.  Every tap is ONE fused multiply-add (emo_mac2 of common.h, v_pk_fma_f32), as in the kernels these
+// replace (emo_mac): round 4 -- the two kernels are VALU-bound, the stencils were half of their instructions.
 typedef __attribute__((ext_vector_type(2))) float f2;
 __device__ __forceinline__ f2 unpack2(unsigned u) { return f2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
 __device__ __forceinline__ unsigned pack2(f2 v) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(CF_CB) void cf_dwconv_kernel(int Tn, int C, int K, 
       for (int i = 0; i < CF_TT / 2; ++i) {
         f2 acc = bv;
 #pragma unroll
-        for (int j = 0; j < CF_MAXK; ++j) acc += wr[j] * win[i + j];
+        for (int j = 0; j < CF_MAXK; ++j) acc = emo_mac2(wr[j], win[i + j], acc);
         *reinterpret_cast<unsigned*>(os + (half * (CF_TT / 2) + i) * CF_CB + 2 * pr) = pack2(acc);
       }
     }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(CF_CB) void cf_conv_bwd_kernel(int Tn, int C, int K
     for (int i = 0; i < CF_TT / 2; ++i) {
       f2 acc = f2{0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < CF_MAXK; ++j) acc += wr[j] * dcw[i + j];
+      for (int j = 0; j < CF_MAXK; ++j) acc = emo_mac2(wr[j], dcw[i + j], acc);
       const f2 d = unpack2(pack2(acc));   // the data gradient is stored as bf16 by the unfused kernel
       const int fr = half * (CF_TT / 2) + i;
       const bool fok = t0 + fr < Tn;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(CF_CB) void cf_conv_bwd_kernel(int Tn, int C, int K
       const f2 d = dcc[i];
       sb += d;
 #pragma unroll
-      for (int j = 0; j < TAPS; ++j) acc[j] += d * zw[i + j];
+      for (int j = 0; j < TAPS; ++j) acc[j] = emo_mac2(d, zw[i + j], acc[j]);
     }
     const long blk = ((long)blockIdx.z * gridDim.x + blockIdx.x);
     float* p = wpart + blk * (K + 1) * C + c0;

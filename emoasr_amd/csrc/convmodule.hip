@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const
   for (int i = 0; i < DW_TT; ++i) {
     float acc = bv;
 #pragma unroll
-    for (int j = 0; j < DW_MAXK; ++j) acc += wr[j] * win[i + j];
+    for (int j = 0; j < DW_MAXK; ++j) acc = emo_mac(wr[j], win[i + j], acc);
     const T r = from_f32<T>(acc);
     out[i] = t0 + i < Tn ? to_f32(r) : 0.f;
     s += out[i];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(int Tn, int C, int K,
       const float d = dv[i];
       sb += d;
 #pragma unroll
-      for (int j = 0; j < DW_MAXK; ++j) acc[j] += d * win[i + j];
+      for (int j = 0; j < DW_MAXK; ++j) acc[j] = emo_mac(d, win[i + j], acc[j]);
     }
   }
   // per-block partials [blk][K+1][C] (coalesced along c); folded by dwconv_bwd_w_reduce_kernel

@@ -34,8 +34,12 @@ namespace {
 
 constexpr int LT = 512;          // threads per workgroup (8 waves)
 constexpr int LW = LT / 64;
-constexpr int L_MAXB = 64;       // rows (sequences) per batch: four 16-row MFMA tiles
+constexpr int L_MAXB = 64;       // rows (sequences) per batch GROUP: four 16-row MFMA tiles
 constexpr int L_MAXH = 512;
+// More than 64 sequences (the prediction network of several stacked micro-batches in one pass): ceil(B / 64) independent groups of
+// H / 16 workgroups in ONE launch, each group with its own barrier counter -- the recurrence is bound by the per-position barrier
+// and the dependent round trip, so 8 groups take the time of one.
+constexpr int L_MAXGRP = 8;
 
 #define EMO_FRESH(x) asm volatile("" : "+v"(x))
 
@@ -77,19 +81,21 @@ struct LstmFwdArgs {
   bf16* hseq;          // [U][B][H]
   float* cseq;         // [U][B][H]
   bf16* gact;          // [U][B][4H] activated gates
-  unsigned* counter; int* err; unsigned base;
+  unsigned* counter; int* err; unsigned base[L_MAXGRP];
+  int G;               // workgroups per batch group (H / 16); gridDim.x = G * ceil(B / 64)
 };
 
 // LDS: Ws [64][H + 8] | hs [64][H + 8] | gat [4][64][17] f32
 __global__ __launch_bounds__(LT) void lstm_seq_fwd_kernel(const LstmFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int H = a.H, B = a.B, ld = H + 8, g = blockIdx.x, G = gridDim.x;
+  const int H = a.H, ld = H + 8, G = a.G, gi = blockIdx.x / G, g = blockIdx.x - gi * G;
+  const int m0 = gi * L_MAXB, Bs = a.B, B = min(L_MAXB, Bs - m0);   // this group's rows m0 .. m0 + B of the Bs sequences
   bf16* Ws = reinterpret_cast<bf16*>(smem);
   bf16* hs = Ws + 64 * ld;
   float* gat = reinterpret_cast<float*>(hs + 64 * ld);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   LBar bar;
-  lbar_init(bar, a.counter, a.err, (unsigned)G, a.base);
+  lbar_init(bar, a.counter + 16 * gi, a.err, (unsigned)G, a.base[gi]);
   // the four gates' rows of the own 16 units: Ws[gate * 16 + j] = w_hh[gate * H + 16 g + j]
   for (int i = tid; i < 64 * (H / 8); i += LT) {
     const int r = i / (H / 8), c = (i - r * (H / 8)) * 8;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(LT) void lstm_seq_fwd_kernel(const LstmFwdArgs a) {
 #pragma unroll
   for (int o = 0; o < 2; ++o) {
     const int p = tid + LT * o, m = p >> 4, n = p & 15;
-    c_reg[o] = (a.c0 && m < B) ? a.c0[(long)m * H + 16 * g + n] : 0.f;
+    c_reg[o] = (a.c0 && m < B) ? a.c0[(long)(m0 + m) * H + 16 * g + n] : 0.f;
   }
   const int gate = wave & 3, mt0 = 2 * (wave >> 2);
   for (int u = 0; u < a.U; ++u) {
@@ -114,9 +120,9 @@ __global__ __launch_bounds__(LT) void lstm_seq_fwd_kernel(const LstmFwdArgs a) {
     for (int o = 0; o < 2; ++o) {
       const int p = t + LT * o, m = p >> 4, n = p & 15;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pv[o][q] = m < B ? (float)a.pre[((long)u * B + m) * 4 * H + q * H + 16 * g + n] : 0.f;
+      for (int q = 0; q < 4; ++q) pv[o][q] = m < B ? (float)a.pre[((long)u * Bs + m0 + m) * 4 * H + q * H + 16 * g + n] : 0.f;
     }
-    const bf16* hprev = u > 0 ? a.hseq + (long)(u - 1) * B * H : a.h0;
+    const bf16* hprev = u > 0 ? a.hseq + ((long)(u - 1) * Bs + m0) * H : (a.h0 ? a.h0 + (long)m0 * H : nullptr);
     if (u > 0) lgrid_sync(bar);   // h_{u-1} complete on every workgroup
     if (hprev) {
       for (int i = t; i < B * (H / 8); i += LT) {
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(LT) void lstm_seq_fwd_kernel(const LstmFwdArgs a) {
         const float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), gg = tanhf(z[2]), og = sigmoidf_(z[3]);
         const float cn = fg * c_reg[o] + ig * gg;
         c_reg[o] = cn;
-        const long row = (long)u * B + m;
+        const long row = (long)u * Bs + m0 + m;
         a.cseq[row * H + 16 * g + n] = cn;
         a.hseq[row * H + 16 * g + n] = (bf16)(og * tanhf(cn));
         bf16* ga = a.gact + row * 4 * H + 16 * g + n;
@@ -162,7 +168,10 @@ __global__ __launch_bounds__(LT) void lstm_seq_fwd_kernel(const LstmFwdArgs a) {
   // NaN and the optimizer's NaN skip drops the step (the host reports the flag at its next synchronisation point)
   if (lbar_failed(bar)) {
     const float qnan = __builtin_nanf("");
-    for (long i = threadIdx.x; i < (long)a.U * B * 16; i += LT) a.hseq[(i >> 4) * H + 16 * g + (i & 15)] = (bf16)qnan;
+    for (long i = threadIdx.x; i < (long)a.U * B * 16; i += LT) {
+      const long r = i >> 4, u = r / B, m = r - u * B;
+      a.hseq[(u * Bs + m0 + m) * H + 16 * g + (i & 15)] = (bf16)qnan;
+    }
   }
 }
 
@@ -174,20 +183,22 @@ struct LstmBwdArgs {
   const float* c0;      // [B][H] or null
   const bf16* w_hh;     // [4H][H]
   bf16* dgp;            // [U][B][4H] out: gradient w.r.t. the gate pre-activations
-  float* part;          // [2][G][64][H] f32 scratch: every workgroup's contribution to dh_{u-1}
-  unsigned* counter; int* err; unsigned base;
+  float* part;          // [groups][2][G][64][H] f32 scratch: every workgroup's contribution to dh_{u-1}
+  unsigned* counter; int* err; unsigned base[L_MAXGRP];
+  int G;
 };
 
 // LDS: WT [H][72] (the own 64 gate rows of W_hh, transposed: WT[n][k] = w_hh[row(k)][n]) | dg [64][72] (the own dgates of the position)
 __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int H = a.H, B = a.B, g = blockIdx.x, G = gridDim.x;
+  const int H = a.H, G = a.G, gi = blockIdx.x / G, g = blockIdx.x - gi * G;
+  const int m0 = gi * L_MAXB, Bs = a.B, B = min(L_MAXB, Bs - m0);
   constexpr int LDK = 72;
   bf16* WT = reinterpret_cast<bf16*>(smem);
   bf16* dg = WT + H * LDK;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   LBar bar;
-  lbar_init(bar, a.counter, a.err, (unsigned)G, a.base);
+  lbar_init(bar, a.counter + 16 * gi, a.err, (unsigned)G, a.base[gi]);
   for (int i = tid; i < 64 * H; i += LT) {   // k = gate * 16 + j <-> row gate * H + 16 g + j
     const int k = i / H, n = i - k * H;
     WT[n * LDK + k] = a.w_hh[((long)(k >> 4) * H + 16 * g + (k & 15)) * H + n];
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
   __syncthreads();
   float dc_reg[2] = {0.f, 0.f};
   const long slab = (long)64 * H;   // one workgroup's partial
+  float* const part = a.part + (long)gi * 2 * G * slab;
   for (int u = a.U - 1; u >= 0; --u) {
     int t = tid;
     EMO_FRESH(t);
@@ -204,13 +216,13 @@ __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
       const int p = t + LT * o, m = p >> 4, n = p & 15;
-      const long row = (long)u * B + m, col = 16 * g + n;
+      const long row = (long)u * Bs + m0 + m, col = 16 * g + n;
       const bool ok = m < B;
       dho[o] = ok ? (float)a.dh_seq[row * H + col] : 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) gv[o][q] = ok ? (float)a.gact[row * 4 * H + q * H + col] : 0.f;
       cu[o] = ok ? a.cseq[row * H + col] : 0.f;
-      cp[o] = !ok ? 0.f : (u > 0 ? a.cseq[(row - B) * H + col] : (a.c0 ? a.c0[(long)m * H + col] : 0.f));
+      cp[o] = !ok ? 0.f : (u > 0 ? a.cseq[(row - Bs) * H + col] : (a.c0 ? a.c0[(long)(m0 + m) * H + col] : 0.f));
     }
     const bool rec = u < a.U - 1;   // position u + 1 contributed to dh_u
     if (rec) lgrid_sync(bar);
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
       if (m < B) {
         float dh = dho[o];
         if (rec) {   // the workgroups' partials of the own column, in workgroup order
-          const float* src = a.part + ((long)((u + 1) & 1) * G) * slab + (long)m * H + 16 * g + n;
+          const float* src = part + ((long)((u + 1) & 1) * G) * slab + (long)m * H + 16 * g + n;
           float acc = 0.f;
           for (int w0 = 0; w0 < G; w0 += 8) {
             float pv[8];
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
         const bf16 d0 = (bf16)(dct * gg * ig * (1.f - ig)), d1 = (bf16)(dct * cp[o] * fg * (1.f - fg));
         const bf16 d2 = (bf16)(dct * ig * (1.f - gg * gg)), d3 = (bf16)(dh * tc * og * (1.f - og));
         dc_reg[o] = dct * fg;
-        bf16* dst = a.dgp + ((long)u * B + m) * 4 * H + 16 * g + n;
+        bf16* dst = a.dgp + ((long)u * Bs + m0 + m) * 4 * H + 16 * g + n;
         dst[0] = d0; dst[H] = d1; dst[2 * H] = d2; dst[3 * H] = d3;
         dg[m * LDK + n] = d0; dg[m * LDK + 16 + n] = d1; dg[m * LDK + 32 + n] = d2; dg[m * LDK + 48 + n] = d3;
       }
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
     if (u > 0) {
       __syncthreads();
       // partial dh_{u-1}[m][:] = dg [B x 64] . W_own [64 x H]: column strips of 16 dealt to the waves
-      float* dstp = a.part + ((long)(u & 1) * G + g) * slab;
+      float* dstp = part + ((long)(u & 1) * G + g) * slab;
       const int MT = (B + 15) / 16;
       for (int st = wave; st < H / 16; st += LW) {
         bf16x8 wf[2];
@@ -270,48 +282,60 @@ __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
   if (lbar_failed(bar)) {   // (see the forward kernel)
     const float qnan = __builtin_nanf("");
     for (long i = threadIdx.x; i < (long)a.U * B * 64; i += LT) {
-      const long row = i >> 6; const int k = (int)(i & 63);
-      a.dgp[row * 4 * H + (long)(k >> 4) * H + 16 * g + (k & 15)] = (bf16)qnan;
+      const long r = i >> 6, u = r / B, m = r - u * B; const int k = (int)(i & 63);
+      a.dgp[(u * Bs + m0 + m) * 4 * H + (long)(k >> 4) * H + 16 * g + (k & 15)] = (bf16)qnan;
     }
   }
 }
 
+constexpr int L_CNT_BYTES = 4096;   // [2 directions][L_MAXGRP groups] counters, 64 bytes apart; the error flag behind them
 unsigned* lstm_counter(int which, int** err) {
   static unsigned* buf = nullptr;
   if (!buf) {
-    if (hipMalloc(&buf, 1024) != hipSuccess || hipMemset(buf, 0, 1024) != hipSuccess) return nullptr;
+    if (hipMalloc(&buf, L_CNT_BYTES) != hipSuccess || hipMemset(buf, 0, L_CNT_BYTES) != hipSuccess) return nullptr;
   }
-  *err = reinterpret_cast<int*>(buf) + 128;
-  return buf + 16 * which;
+  *err = reinterpret_cast<int*>(buf) + 2 * L_MAXGRP * 16;
+  return buf + 16 * L_MAXGRP * which;
 }
 
 int g_lstm_coop = 1;
 
 // counter value at the start of the next launch, per counter (0 forward, 1 backward); launches are stream-ordered
-unsigned g_lstm_base[2] = {0u, 0u};
-unsigned lstm_base(int which, int G, int U) {
-  const unsigned b = g_lstm_base[which];
-  g_lstm_base[which] += (unsigned)G * (unsigned)(U - 1);
-  return b;
+unsigned g_lstm_base[2][L_MAXGRP] = {};
+void lstm_base(int which, int G, int U, int ngrp, unsigned (&base)[L_MAXGRP]) {
+  for (int i = 0; i < L_MAXGRP; ++i) {
+    base[i] = g_lstm_base[which][i];
+    if (i < ngrp) g_lstm_base[which][i] += (unsigned)G * (unsigned)(U - 1);
+  }
 }
+int lstm_groups(int B) { return (B + L_MAXB - 1) / L_MAXB; }
 
 // The kernels are launched with <<<>>>, so the co-residency of their G workgroups is verified here instead (once per kernel and
 // LDS size): the grid barrier would otherwise spin until its bail-out.
-bool lstm_fits(const void* kernel, size_t smem, int G) {
-  int per_cu = 0, dev = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, LT, smem) != hipSuccess) return false;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-    return false;
-  return (long)per_cu * cus >= G;
+int lstm_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+  }
+  return cus;
+}
+// workgroups of this kernel the device holds at once (0 = the query failed)
+long lstm_capacity(const void* kernel, size_t smem) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, LT, smem) != hipSuccess) return 0;
+  return (long)per_cu * lstm_cus();
 }
 
 }  // namespace
 
 void emo_lstm_set_coop(int v) { g_lstm_coop = v; }
 
-// Can the cooperative recurrence take this layer?  (bf16, B <= 64, H a multiple of 32 up to 512)
+// Can the cooperative recurrence take this layer?  (bf16, B <= 8 groups of 64, H a multiple of 32 up to 512)
 extern "C" int emoasr_lstm_seq_supported(int dtype, int B, int H) {
-  return g_lstm_coop && dtype == EMO_BF16 && B >= 1 && B <= L_MAXB && H % 32 == 0 && H >= 32 && H <= L_MAXH;
+  if (!(g_lstm_coop && dtype == EMO_BF16 && B >= 1 && B <= L_MAXB * L_MAXGRP && H % 32 == 0 && H >= 32 && H <= L_MAXH)) return 0;
+  // one workgroup per CU (the forward's 150 KB of LDS): all groups' workgroups must be resident together
+  return B <= L_MAXB || (long)lstm_groups(B) * (H / 16) <= lstm_cus();
 }
 
 // hseq[u], cseq[u], gact[u] for u = 0 .. U - 1 from pre[u] = x_u . W_ih^T + b (bf16 [U][B][4H]) and the recurrent weights
@@ -330,18 +354,22 @@ extern "C" int emoasr_lstm_seq_fwd(int dtype, int U, int B, int H, const void* p
   if (smem > set_bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     EMO_CHECK(e == hipSuccess, "lstm_seq_fwd: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
-    EMO_CHECK(lstm_fits((const void*)lstm_seq_fwd_kernel, smem, L_MAXH / 16), "lstm_seq_fwd: the device cannot hold %d workgroups at once",
-              L_MAXH / 16);
     set_bytes = smem;
   }
-  a.base = lstm_base(0, H / 16, U);
-  lstm_seq_fwd_kernel<<<H / 16, LT, smem, (hipStream_t)stream>>>(a);
+  static long cap = 0;
+  static size_t cap_bytes = 0;
+  if (smem != cap_bytes) { cap = lstm_capacity((const void*)lstm_seq_fwd_kernel, smem); cap_bytes = smem; }
+  const int ngrp = lstm_groups(B);
+  a.G = H / 16;
+  EMO_CHECK(cap >= (long)a.G * ngrp, "lstm_seq_fwd: the device holds %ld of the %d workgroups at once", cap, a.G * ngrp);
+  lstm_base(0, a.G, U, ngrp, a.base);
+  lstm_seq_fwd_kernel<<<a.G * ngrp, LT, smem, (hipStream_t)stream>>>(a);
   EMO_LAUNCH_CHECK();
   return 0;
 }
 
-// scratch of emoasr_lstm_seq_bwd: [2][H / 16][64][H] f32
-extern "C" long emoasr_lstm_seq_bwd_ws_bytes(int B, int H) { return (long)2 * (H / 16) * 64 * H * 4; }
+// scratch of emoasr_lstm_seq_bwd: [ceil(B / 64)][2][H / 16][64][H] f32
+extern "C" long emoasr_lstm_seq_bwd_ws_bytes(int B, int H) { return (long)lstm_groups(B) * 2 * (H / 16) * 64 * H * 4; }
 
 // dgp[u] (gradient w.r.t. the gate pre-activations, [U][B][4H]) for u = U - 1 .. 0 from dh_seq (gradient w.r.t. the layer's
 // outputs), the stored activated gates and cell states; the weight / input gradients follow from dgp as before
@@ -361,12 +389,16 @@ extern "C" int emoasr_lstm_seq_bwd(int dtype, int U, int B, int H, const void* d
   if (smem > set_bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     EMO_CHECK(e == hipSuccess, "lstm_seq_bwd: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
-    EMO_CHECK(lstm_fits((const void*)lstm_seq_bwd_kernel, smem, L_MAXH / 16), "lstm_seq_bwd: the device cannot hold %d workgroups at once",
-              L_MAXH / 16);
     set_bytes = smem;
   }
-  a.base = lstm_base(1, H / 16, U);
-  lstm_seq_bwd_kernel<<<H / 16, LT, smem, (hipStream_t)stream>>>(a);
+  static long cap = 0;
+  static size_t cap_bytes = 0;
+  if (smem != cap_bytes) { cap = lstm_capacity((const void*)lstm_seq_bwd_kernel, smem); cap_bytes = smem; }
+  const int ngrp = lstm_groups(B);
+  a.G = H / 16;
+  EMO_CHECK(cap >= (long)a.G * ngrp, "lstm_seq_bwd: the device holds %ld of the %d workgroups at once", cap, a.G * ngrp);
+  lstm_base(1, a.G, U, ngrp, a.base);
+  lstm_seq_bwd_kernel<<<a.G * ngrp, LT, smem, (hipStream_t)stream>>>(a);
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -380,8 +412,9 @@ extern "C" long emoasr_lstm_coop_status(void) {
   int e = 0;
   if (hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   if (e) {
-    if (hipDeviceSynchronize() != hipSuccess || hipMemset(c, 0, 1024) != hipSuccess) return -1;
-    g_lstm_base[0] = g_lstm_base[1] = 0u;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemset(c, 0, L_CNT_BYTES) != hipSuccess) return -1;
+    for (int w = 0; w < 2; ++w)
+      for (int i = 0; i < L_MAXGRP; ++i) g_lstm_base[w][i] = 0u;
   }
   return e;
 }

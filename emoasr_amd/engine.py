@@ -1322,21 +1322,55 @@ class _RNNTMixin:
             dy = ops.gemm_nn(dgp2, w_ih).view(U, B, nin)
         ops.embed_bwd(st.ids, dy, 1.0, A.g("decoder.embed.weight"), st.p_emb, st.s_emb)
 
+    def rnnt_prediction_stacked(self, ys_in_list, training):
+        """the prediction network of SEVERAL micro-batches in one pass (it reads the labels only): their <sos>-prefixed label
+        matrices [B_k, U_k] are padded to the longest and stacked along the batch; the cooperative recurrence takes up to eight
+        groups of 64 sequences in one launch (csrc/lstm_coop.hip), so the 2 x layers launches of ~0.3 / 0.5 ms that every
+        micro-batch paid are paid once.  Padded positions sit behind every real one of their sequence: they change neither the
+        real outputs nor (with a zero output gradient) any parameter gradient.
+        -> (douts [U_max, B_tot, H] time-major, stash for rnnt_recurrency_bwd, [(b0, b1, U_k)] per micro-batch)"""
+        with ops.stream_scope():
+            mats = [torch.as_tensor(y).to(torch.int32) for y in ys_in_list]
+            Umax, Btot = max(m.shape[1] for m in mats), sum(m.shape[0] for m in mats)
+            ids = torch.zeros(Btot, Umax, dtype=torch.int32)
+            spans, b0 = [], 0
+            for m in mats:
+                ids[b0:b0 + m.shape[0], : m.shape[1]] = m
+                spans.append((b0, b0 + m.shape[0], m.shape[1]))
+                b0 += m.shape[0]
+            dev = self.arena.flat.device
+            ids_tm = h2d_i32(ids.t().contiguous(), dev)
+            douts, _, rst = self.rnnt_recurrency(ids_tm, None, training, True)
+            return douts, rst, spans
+
+    def rnnt_prediction_stacked_ok(self, n_seqs):
+        """does the stacked prediction network pay?  (only with the cooperative recurrence: bf16, <= 512 sequences)"""
+        if os.environ.get("EMOASR_RNNT_PRED_STACKED", "1") == "0":   # (A/B switch)
+            return False
+        probe = torch.empty(0, device=self.arena.flat.device, dtype=self.dtype)
+        return self.dtype == torch.bfloat16 and ops.lstm_seq_supported(probe, n_seqs, self.r_H)
+
     def rnnt_fused_ok(self, h, w_out):
         """can the output layer run without materialising the logits?  (bf16, V % 8 == 0, J % 64 == 0; EMOASR_RNNT_FUSED=0 or
         engine.rnnt_fused = False select the materialised path)"""
         return (self.rnnt_fused and h.dtype == torch.bfloat16 and w_out.shape[0] % 8 == 0 and w_out.shape[0] >= 64
                 and w_out.shape[1] % 64 == 0)
 
-    def rnnt_forward(self, eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training, want_logits=True):
-        """-> (loss_rnnt 0-dim, logits [B,T,U,V] (None on the fused path: want_logits=False), stash)"""
+    def rnnt_forward(self, eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training, want_logits=True, pred=None):
+        """-> (loss_rnnt 0-dim, logits [B,T,U,V] (None on the fused path: want_logits=False), stash)
+        pred: the prediction network's output for this micro-batch, [U, B, H] time-major, when it was computed for several
+        micro-batches at once (rnnt_prediction_stacked); rnnt_backward then leaves its gradient in st.ddouts"""
         with ops.stream_scope():
             A, J = self.arena, self.r_J
             B, T, d = eouts.shape
             dev = eouts.device
             U = ys_in.shape[1]
-            ids_tm = h2d_i32(torch.as_tensor(ys_in).t().contiguous(), dev)  # [U,B]
-            douts, _, rst = self.rnnt_recurrency(ids_tm, None, training, True)
+            if pred is not None:
+                assert tuple(pred.shape) == (U, B, self.r_H) and pred.is_contiguous(), (pred.shape, (U, B, self.r_H))
+                douts, rst = pred, None
+            else:
+                ids_tm = h2d_i32(torch.as_tensor(ys_in).t().contiguous(), dev)  # [U,B]
+                douts, _, rst = self.rnnt_recurrency(ids_tm, None, training, True)
             e = ops.gemm_nt(eouts.reshape(B * T, d), A.w("decoder.w_enc.weight"), bias=A.p("decoder.w_enc.bias")).view(B, T, J)
             g_tm = ops.gemm_nt(douts.view(U * B, self.r_H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
             g = ops.strided_copy(g_tm.view(U, B, J).permute(1, 0, 2))  # [B,U,J]
@@ -1390,8 +1424,16 @@ class _RNNTMixin:
                                    "decoder.w_enc.bias").view(B, T, d)
             dg_tm = ops.strided_copy(dg.permute(1, 0, 2)).view(U * B, J)
             ddouts = self._lin_bwd(dg_tm, st.douts.view(U * B, H), "decoder.w_dec.weight", "decoder.w_dec.bias")
-            self.rnnt_recurrency_bwd(st.rst, ddouts.view(U, B, H))
+            self._rnnt_pred_bwd(st, ddouts.view(U, B, H))
             return deouts
+
+    def _rnnt_pred_bwd(self, st, ddouts):
+        """the prediction network's backward -- or, when its forward ran stacked over several micro-batches, the gradient handed
+        back to that pass (st.ddouts)"""
+        if st.rst is None:
+            st.ddouts = ddouts
+        else:
+            self.rnnt_recurrency_bwd(st.rst, ddouts)
 
     def _rnnt_backward_fused(self, st, gscale_dev):
         """backward of the fused output layer: the cells are walked in row chunks; per chunk the logits are recomputed and turned
@@ -1406,7 +1448,10 @@ class _RNNTMixin:
         h2 = st.h.view(N, J)
         dpre = torch.empty(N, J, device=h2.device, dtype=h2.dtype)
         CH = min(N, self.rnnt_chunk)
-        dzc = torch.empty(CH, V, device=h2.device, dtype=h2.dtype)
+        # (rows padded to a multiple of 64 columns: with V = 1000 a row is 2000 bytes and every 128-byte store of the gradient tile
+        # straddles two lines written by different workgroups)
+        Vp = (V + 63) // 64 * 64 if os.environ.get("EMOASR_RNNT_PAD", "1") != "0" else V
+        dzc = torch.empty(CH, Vp, device=h2.device, dtype=h2.dtype)[:, :V]
         for r0 in range(0, N, CH):
             n = min(CH, N - r0)
             dz = ops.rnnt_head_grad(h2[r0:r0 + n], w_out, b_out, coef[r0:r0 + n], ycol[r0:r0 + n], st.blank, dzc[:n])
@@ -1418,7 +1463,7 @@ class _RNNTMixin:
                                "decoder.w_enc.bias").view(B, T, d)
         dg_tm = ops.strided_copy(dg.permute(1, 0, 2)).view(U * B, J)
         ddouts = self._lin_bwd(dg_tm, st.douts.view(U * B, H), "decoder.w_dec.weight", "decoder.w_dec.bias")
-        self.rnnt_recurrency_bwd(st.rst, ddouts.view(U, B, H))
+        self._rnnt_pred_bwd(st, ddouts.view(U, B, H))
         return deouts
 
     def rnnt_greedy(self, eouts, elens_host, blank, eos, max_seq_len=256, window=64):

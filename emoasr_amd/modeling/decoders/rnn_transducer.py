@@ -11,7 +11,7 @@ scores/logits/aligns (:339-346).
 """
 import torch.nn as nn
 
-from ..functions import rnnt_apply, rnnt_beam_apply, rnnt_greedy_apply
+from ..functions import rnnt_apply, rnnt_beam_apply, rnnt_greedy_apply, rnnt_prediction_stacked
 from ...criteria import RNNTAlignDistillLoss, RNNTWordDistillLoss
 from .ctc import CTCDecoder
 from .rnnt_aligner import RNNTForcedAligner
@@ -54,12 +54,18 @@ class RNNTDecoder(nn.Module):
         self.return_logits = False
         self._owner = None
 
+    def prediction_stacked(self, ys_in_list, ylens_list):
+        """the prediction network (embedding + LSTM stack: it reads the labels only) of several micro-batches in ONE pass ->
+        a list of per-micro-batch outputs to hand to forward(..., pred=...), or None when the stacked pass does not apply
+        (not in the reference: its train loop runs the micro-batches one by one, train_asr.py:106-128)"""
+        return rnnt_prediction_stacked(self, ys_in_list, ylens_list)
+
     def forward(self, eouts, elens, eouts_inter=None, ys=None, ylens=None, ys_in=None, ys_out=None,
-                soft_labels=None, ps=None, plens=None):
+                soft_labels=None, ps=None, plens=None, pred=None):
         kd = None
         if self.kd_weight > 0 and soft_labels is not None:
             kd = (soft_labels, self.kd_weight, self.reduce_main_loss_kd, self.kd_type)
-        loss, loss_rnnt, loss_ctc, logits, loss_kd = rnnt_apply(self, eouts, elens, ys, ylens, ys_in, kd)
+        loss, loss_rnnt, loss_ctc, logits, loss_kd = rnnt_apply(self, eouts, elens, ys, ylens, ys_in, kd, pred)
         loss_dict = {"loss_rnnt": loss_rnnt}
         if self.mtl_ctc_weight > 0:
             loss_dict["loss_ctc"] = loss_ctc

@@ -312,9 +312,48 @@ def attn_decoder_logits(dec, eouts, elens, ys_in, ylens):
 # ---------------------------------------------------------------------------------------
 # RNN-T: transducer loss (+ auxiliary CTC) as one autograd node over the encoder output
 # ---------------------------------------------------------------------------------------
+class _PredNetFn(torch.autograd.Function):
+    """the RNN-T prediction network of several micro-batches in one pass (engine.rnnt_prediction_stacked)"""
+
+    @staticmethod
+    def forward(ctx, eng, training, ys_in_list, *params):
+        douts, rst, spans = eng.rnnt_prediction_stacked(ys_in_list, training)
+        ctx.eng, ctx.rst = eng, rst
+        ctx.spans = spans
+        return douts
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        eng = ctx.eng
+        with ops.stream_scope():
+            eng.arena.attach_grads()
+            eng.rnnt_recurrency_bwd(ctx.rst, g.contiguous())
+        ctx.rst = None
+        return (None, None, None) + (None,) * len(eng.arena.params)
+
+
+def rnnt_prediction_stacked(dec, ys_in_list, ylens_list):
+    """-> one [U_k, B_k, H] prediction-network output per micro-batch (inputs of rnnt_apply(..., pred=...)), all computed in ONE
+    pass, or None when the stacked pass does not apply (then every micro-batch runs its own, as before)"""
+    eng = _engine_of(dec)
+    mats = []
+    for ys_in, ylens in zip(ys_in_list, ylens_list):
+        L = max(_host_list(ylens))
+        mats.append((ys_in.cpu() if torch.is_tensor(ys_in) else torch.as_tensor(ys_in))[:, : L + 1])
+    if len(mats) < 2 or not eng.rnnt_prediction_stacked_ok(sum(m.shape[0] for m in mats)):
+        return None
+    douts = _PredNetFn.apply(eng, dec.training, mats, *eng.arena.params)
+    out, b0 = [], 0
+    for m in mats:
+        out.append(douts[: m.shape[1], b0:b0 + m.shape[0]].contiguous())
+        b0 += m.shape[0]
+    return out
+
+
 class _RNNTFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, training, eouts, elens_dev, ys_host, ylens_host, ys_in, blank, kd, want_logits, *params):
+    def forward(ctx, eng, training, eouts, elens_dev, ys_host, ylens_host, ys_in, blank, kd, want_logits, pred, *params):
         """kd = None | (soft f32 [B,L,V] on the device, kd_weight, reduce_main_loss_kd): word-level distillation
         (rnn_transducer.py:127-141, criteria.py:218-247) of every lattice cell towards its label's soft target"""
         from .. import ops
@@ -322,7 +361,8 @@ class _RNNTFn(torch.autograd.Function):
         # the 4-D logits are formed only when something reads them: distillation, or a caller that asked for them
         # (RNNTDecoder.return_logits); training without either runs the fused output layer and returns logits = None
         loss_rnnt, logits, st = eng.rnnt_forward(eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training,
-                                                 want_logits=want_logits or kd is not None)
+                                                 want_logits=want_logits or kd is not None,
+                                                 pred=None if pred is None else pred.detach())
         cctx, loss = None, loss_rnnt
         if eng.mtl_ctc > 0:
             ctc_logits = eng.head_logits(eouts, "decoder.ctc.output")
@@ -378,11 +418,12 @@ class _RNNTFn(torch.autograd.Function):
             g_ctc_eff = (g_total * (main * eng.mtl_ctc) + g_ctc).to(torch.float32).reshape(1)
             dcl = eng.ctc_grad(ctx.cctx, 1.0, g_ctc_eff)
             deouts = ops.add(deouts, eng.head_backward(ctx.eouts, dcl, "decoder.ctc.output"))
+        dpred = getattr(ctx.st, "ddouts", None)   # (the prediction network ran stacked: its gradient goes back to that pass)
         ctx.st = ctx.cctx = ctx.kd = None
-        return (None, None, deouts, None, None, None, None, None, None, None) + (None,) * len(eng.arena.params)
+        return (None, None, deouts, None, None, None, None, None, None, None, dpred) + (None,) * len(eng.arena.params)
 
 
-def rnnt_apply(dec, eouts, elens, ys, ylens, ys_in, kd=None):
+def rnnt_apply(dec, eouts, elens, ys, ylens, ys_in, kd=None, pred=None):
     eng = _engine_of(dec)
     ylens_host = _host_list(ylens)
     L = max(ylens_host)
@@ -393,7 +434,7 @@ def rnnt_apply(dec, eouts, elens, ys, ylens, ys_in, kd=None):
               kd[3])
     want_logits = bool(getattr(dec, "return_logits", False)) or not dec.training
     out = _RNNTFn.apply(eng, dec.training, eouts, _elens_dev(eouts, elens), ys_host, ylens_host, ys_in, dec.blank_id, kd,
-                        want_logits, *eng.arena.params)
+                        want_logits, pred, *eng.arena.params)
     loss, loss_rnnt, loss_ctc, logits, loss_kd = out
     return loss, loss_rnnt, loss_ctc, (logits if logits.numel() else None), loss_kd
 

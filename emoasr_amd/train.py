@@ -251,7 +251,11 @@ def train_group(model, optimizer, datas, params, device, group=None, sync=True, 
         from .modeling.functions import encoder_apply_stacked
         outs = encoder_apply_stacked(model.encoder, xs_list, xl_list)
         total, dicts = None, []
-        for (eouts, elens, _), data in zip(outs, datas):
+        # a transducer's prediction network reads the labels only: all micro-batches in one pass (None: not applicable)
+        preds = None
+        if hasattr(model.decoder, "prediction_stacked") and all(d.get("ys_in") is not None for d in datas):
+            preds = model.decoder.prediction_stacked([d["ys_in"] for d in datas], [d["ylens"] for d in datas])
+        for k, ((eouts, elens, _), data) in enumerate(zip(outs, datas)):
             ymax = int(max(data["ylens"]))   # the targets are trimmed to the batch as ASR.forward does (asr.py:57-62)
             ys = data["ys"][:, :ymax]
             ys_in = data["ys_in"][:, : ymax + 1] if data.get("ys_in") is not None else None
@@ -260,7 +264,8 @@ def train_group(model, optimizer, datas, params, device, group=None, sync=True, 
             ps, plens = data.get("ps"), data.get("plens")
             if ps is not None:
                 ps = ps[:, : int(max(plens))]
-            loss, loss_dict, _ = model.decoder(eouts, elens, None, ys, data["ylens"], ys_in, ys_out, soft, ps, plens)
+            extra = {} if preds is None else {"pred": preds[k]}
+            loss, loss_dict, _ = model.decoder(eouts, elens, None, ys, data["ylens"], ys_in, ys_out, soft, ps, plens, **extra)
             total = loss / accum if total is None else total + loss / accum
             dicts.append({k: (v.item() / accum if sync else v.detach() / accum) for k, v in loss_dict.items()})
         total.backward()

@@ -269,3 +269,65 @@ def test_fused_output_layer_against_oracle_and_materialised_path(dev):
     model.decoder.return_logits = True
     out = model.decoder(*model.encoder(xs.to(dev), xlens)[:2], None, ys, yl, ys_in, ys_out)
     assert out[2] is not None and tuple(out[2].shape) == (6, 100, 21, 1000)
+
+
+def test_prediction_network_of_all_micro_batches_in_one_pass(dev):
+    """train.train_group on a transducer stacks the ENCODER and (round 4) the PREDICTION NETWORK of the micro-batches: the LSTM
+    recurrences of all of them in one grouped cooperative launch per layer (csrc/lstm_coop.hip: groups of 64 sequences), labels
+    padded to the longest.  Against the same group with the prediction network run per micro-batch (decoder.prediction_stacked
+    switched off): losses 1e-3, every gradient cosine 0.999 / norm 1 % -- the recurrences are bit-identical per sequence, the
+    weight-gradient products sum over differently grouped rows.  70 + 66 + 3 sequences: three groups, ragged last one."""
+    from emoasr_amd.modeling.asr import ASR
+    from emoasr_amd.train import ArenaAdam, train_group
+    cfg = dict(input_layer="conv2d", feat_dim=80, num_framestacks=1, encoder_type="conformer", pos_encode_type="rel",
+               enc_hidden_size=256, enc_num_attention_heads=4, enc_num_layers=2, enc_intermediate_size=512,
+               dropout_enc_rate=0.0, dropout_attn_rate=0.0, vocab_size=1000, blank_id=0, eos_id=2, kd_weight=0,
+               decoder_type="rnn_transducer", embedding_size=256, dec_hidden_size=512, dec_num_layers=2, joint_hidden_size=512,
+               dropout_emb_rate=0.0, dropout_dec_rate=0.0, mtl_ctc_weight=0.3, lsm_prob=0.0, accum_grad=3, clip_grad_norm=5.0)
+    params = SimpleNamespace(**cfg)
+    g = torch.Generator().manual_seed(11)
+    datas = []
+    for B, T, L in ((70, 83, 7), (66, 99, 12), (3, 140, 5)):
+        xlens = torch.randint(T // 2, T + 1, (B,), generator=g)
+        xlens[0] = T
+        ylens = torch.randint(1, L + 1, (B,), generator=g)
+        ylens[1 % B] = L
+        xs = torch.randn(B, T, 80, generator=g)
+        ys = torch.randint(3, 1000, (B, L), generator=g)
+        for b in range(B):
+            xs[b, xlens[b]:] = 0
+            ys[b, ylens[b]:] = 2
+        eos = torch.full((B, 1), 2)
+        datas.append(dict(xs=xs, xlens=xlens, ys=ys, ylens=ylens, ys_in=torch.cat([eos, ys], 1), ys_out=torch.cat([ys, eos], 1)))
+    res = {}
+    for stacked_pred in (True, False):
+        torch.manual_seed(3)
+        model = ASR(params, compute_dtype=torch.bfloat16).to(dev).train()
+        eng = model.engine()
+        if not stacked_pred:
+            model.decoder.prediction_stacked = lambda *a, **k: None
+        else:
+            calls = []
+            orig = eng.rnnt_recurrency
+            eng.rnnt_recurrency = lambda ids, *a, **k: (calls.append(tuple(ids.shape)), orig(ids, *a, **k))[1]
+        opt = ArenaAdam(eng.arena, lambda s: 0.0, clip_grad_norm=5.0)   # lr 0: the step leaves the weights, the gradients are kept below
+        grads = {}
+        step = opt.step
+        opt.step = lambda: (grads.update(g=eng.arena.grad.clone()), step())[1]
+        dicts = train_group(model, opt, datas, params, dev)
+        res[stacked_pred] = ([d["loss_total"] for d in dicts], grads["g"], eng.arena)
+        if stacked_pred:
+            assert calls == [(13, 139)], calls   # ONE prediction-network pass: longest label row + <sos>, all sequences
+    (l1, g1, A), (l0, g0, _) = res[True], res[False]
+    for a, b in zip(l1, l0):
+        assert abs(a - b) < 1e-3 * abs(b), (l1, l0)
+    gmax = g0.abs().max().item()
+    for name in A.names:
+        o, k = A.offsets[name], A.pviews[name].numel()
+        a, b = g1[o:o + k], g0[o:o + k]
+        if b.abs().max() < 1e-3 * gmax:
+            assert a.abs().max() < 2e-3 * gmax, name
+            continue
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+        assert cos > 0.999, (name, cos)
+        assert abs(a.norm().item() / b.norm().item() - 1) < 1e-2, (name, a.norm().item(), b.norm().item())

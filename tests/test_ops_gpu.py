@@ -1090,6 +1090,34 @@ def test_lstm_seq_cooperative_survives_changing_grid_sizes(dev):
         assert lib.size_query("emoasr_lstm_coop_status") == 0, (U, B, H)
 
 
+@pytest.mark.parametrize("U,B,H", [(7, 150, 512), (5, 65, 256), (4, 128, 512), (6, 500, 128)])
+def test_lstm_seq_groups_of_64_sequences_in_one_launch(dev, U, B, H):
+    """more than 64 sequences (the prediction network of several stacked micro-batches): ceil(B / 64) groups of H / 16 workgroups
+    in ONE launch, each with its own barrier counter -- bit-identical, forward and backward, to one launch per 64-row slab"""
+    from emoasr_amd import lib, ops
+    dt_ = torch.bfloat16
+    pre = _rnd(dev, U, B, 4 * H, dtype=dt_, scale=1.0)
+    w_hh = _rnd(dev, 4 * H, H, dtype=dt_, scale=H ** -0.5)
+    h0, c0 = _rnd(dev, B, H, dtype=dt_, scale=0.5), _rnd(dev, B, H, scale=0.5)
+    dh_seq = _rnd(dev, U, B, H, dtype=dt_, scale=0.5)
+    assert ops.lstm_seq_supported(pre, B, H)
+    hseq, cseq = torch.empty(U, B, H, device=dev, dtype=dt_), torch.empty(U, B, H, device=dev)
+    gact, dgp = torch.empty(U, B, 4 * H, device=dev, dtype=dt_), torch.empty(U, B, 4 * H, device=dev, dtype=dt_)
+    ops.lstm_seq_fwd(pre, w_hh, h0, c0, hseq, cseq, gact)
+    ops.lstm_seq_bwd(dh_seq, gact, cseq, c0, w_hh, dgp)
+    assert lib.size_query("emoasr_lstm_coop_status") == 0
+    for b0 in range(0, B, 64):
+        b1 = min(B, b0 + 64)
+        n = b1 - b0
+        hs, cs = torch.empty(U, n, H, device=dev, dtype=dt_), torch.empty(U, n, H, device=dev)
+        ga, dg = torch.empty(U, n, 4 * H, device=dev, dtype=dt_), torch.empty(U, n, 4 * H, device=dev, dtype=dt_)
+        ops.lstm_seq_fwd(pre[:, b0:b1].contiguous(), w_hh, h0[b0:b1].contiguous(), c0[b0:b1].contiguous(), hs, cs, ga)
+        ops.lstm_seq_bwd(dh_seq[:, b0:b1].contiguous(), ga, cs, c0[b0:b1].contiguous(), w_hh, dg)
+        assert torch.equal(hs, hseq[:, b0:b1]) and torch.equal(cs, cseq[:, b0:b1]) and torch.equal(ga, gact[:, b0:b1]), (b0, "forward")
+        assert torch.equal(dg, dgp[:, b0:b1]), (b0, "backward")
+    assert lib.size_query("emoasr_lstm_coop_status") == 0
+
+
 @pytest.mark.parametrize("U,B,H,with_c0", [(9, 36, 512, False), (5, 50, 512, True), (7, 4, 128, False), (3, 17, 256, True)])
 def test_lstm_seq_backward_cooperative_matches_the_step_chain(dev, U, B, H, with_c0):
     """the backward recurrence of csrc/lstm_coop.hip against the per-position chain lstm_cell_bwd + gemm_nn"""
