@@ -84,17 +84,32 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsig
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_ptr)lds, 16, voff, soff, 0, 0);
 }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  static_assert(N == 8 || N == 6 || N == 4 || N == 3 || N == 2, "wait_vmcnt: unexpected piece count");
+}
+
 // AMODE 0: plain row-major A.  1: Conv2d forward gather.  2: Conv2d data gradient (parity classes).
-template <int TMW, int AMODE>
-__global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
+// NW = waves per workgroup: 8 (2 x 4 waves of (BM/2) x 64) or, round 4, 4 (2 x 2 waves of (BM/2) x 128 -- one wave per SIMD with
+// 256 accumulator registers at BM = 256: per k-tile and wave (BM/2 + 128) * 128 B of LDS reads for TWICE the flops of the 8-wave
+// layout, whose fragment reads alone need 85 % of the LDS bandwidth at the MFMA peak).
+template <int TMW, int AMODE, int NW>
+__global__ __launch_bounds__(NW * 64) void big_nt_kernel(const BigArgs g) {
   constexpr int BM = TMW * 32, BN = 256;
+  constexpr int NJ = BN / (NW / 2) / 16;           // 16-column groups per wave: 4 (64 columns) or 8 (128)
+  constexpr int WCOLS = NJ * 16;
+  constexpr int LPR = WCOLS / 8, HH = 16 / (64 / LPR);   // epilogue: lanes per slab row, passes of 64 lanes over a 16-row slab
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  constexpr int A_PCS = BM / 64, B_PCS = BN / 64;  // 1-KiB pieces (8 rows x 128 B) per wave and tile
-  constexpr int EP_LD = 144;                       // bytes per row of the wave-private transpose slab (128 + 16)
+  constexpr int A_PCS = BM / (NW * 8), B_PCS = BN / (NW * 8);  // 1-KiB pieces (8 rows x 128 B) per wave and tile
+  constexpr int EP_LD = WCOLS * 2 + 16;            // bytes per row of the wave-private transpose slab (bf16 row + 16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / (NW / 2), wc = wave % (NW / 2);
   // XCD-contiguous tile ranges (neighbouring row tiles share the convolution's halo rows in one L2); not for the data
   // gradient, whose tiles are ordered heaviest class first for the dispatcher
   const int bid = AMODE == 2 ? (int)blockIdx.x : xcd_remap_big(blockIdx.x, gridDim.x);
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
   const char* a_base = static_cast<const char*>(g.A);
 #pragma unroll
   for (int i = 0; i < A_PCS; ++i) {
-    const int row = (wave + 8 * i) * 8 + sub;
+    const int row = (wave + NW * i) * 8 + sub;
     const unsigned ch = (unsigned)(pc ^ ((row >> 1) & 7)) * 16u;
     const int grow = m0 + row;
     const bool ok = grow < M;
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
   if constexpr (AMODE == 2) a_base -= (long)(g.dg.F2 + 1) * g.dg.C * 2;
 #pragma unroll
   for (int i = 0; i < B_PCS; ++i) {
-    const int row = (wave + 8 * i) * 8 + sub;
+    const int row = (wave + NW * i) * 8 + sub;
     const unsigned ch = (unsigned)(pc ^ ((row >> 1) & 7)) * 16u;
     const int n = n0 + row;
     b_off[i] = n < g.N ? (unsigned)((long)n * g.ldb * 2) + ch : EMO_OOB;
@@ -219,9 +234,9 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
   auto issue_a = [&](const int p) __attribute__((always_inline)) {
     unsigned v = a_off[p];
     if constexpr (AMODE == 2) v = ((a_tapmask >> (4 * p + ia_tapbit)) & 1u) ? v : EMO_OOB;
-    dma16(rsA, ia_dst + p * 8192, v, ia_s);
+    dma16(rsA, ia_dst + p * (NW * 1024), v, ia_s);
   };
-  auto issue_b = [&](const int p) __attribute__((always_inline)) { dma16(rsB, ib_dst + p * 8192, b_off[p], ib_s); };
+  auto issue_b = [&](const int p) __attribute__((always_inline)) { dma16(rsB, ib_dst + p * (NW * 1024), b_off[p], ib_s); };
   constexpr int N_PCS = A_PCS + B_PCS;
 
   // ---- fragment read offsets -----------------------------------------------------------------------
@@ -233,13 +248,13 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
   fch[0] = (((unsigned)(lane >> 4)) ^ fsw) * 16u;
   fch[1] = (((unsigned)(4 + (lane >> 4))) ^ fsw) * 16u;
   const unsigned a_frag0 = (unsigned)((wr * (BM / 2) + frow) * 128);
-  const unsigned b_frag0 = (unsigned)(A_RING + (wc * 64 + frow) * 128);
+  const unsigned b_frag0 = (unsigned)(A_RING + (wc * WCOLS + frow) * 128);
 
-  f32x4 acc[TMW][4];
+  f32x4 acc[TMW][NJ];
 #pragma unroll
   for (int i = 0; i < TMW; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // prologue: A(0), B(0), then A(1) -- the one group that may stay in flight across the first wait
   setup_a(0);
@@ -257,9 +272,7 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
   constexpr int GROUPS = 2 * TMW;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) {
-      if constexpr (A_PCS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if constexpr (A_PCS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      wait_vmcnt<A_PCS>();
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -273,11 +286,11 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
     // four B groups of one 32-deep k slice (8 MFMAs); while it runs, the next pair (and, towards the end of slice 0,
     // slice 1's B groups) is read into the other register set, so no MFMA waits on a read issued just before it.
     constexpr int PAIRS = TMW / 2, STEPS = 2 * PAIRS;
-    bf16x8 bq[2][4], aq[2][2];
+    bf16x8 bq[2][NJ], aq[2][2];
     auto ld_b = [&](int ks, int j) { return *reinterpret_cast<const bf16x8*>(stb + b_frag0 + j * 2048 + fch[ks]); };
     auto ld_a = [&](int ks, int i) { return *reinterpret_cast<const bf16x8*>(sta + a_frag0 + i * 2048 + fch[ks]); };
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bq[0][j] = ld_b(0, j);
+    for (int j = 0; j < NJ; ++j) bq[0][j] = ld_b(0, j);
     aq[0][0] = ld_a(0, 0);
     aq[0][1] = ld_a(0, 1);
 #pragma unroll
@@ -288,13 +301,19 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
         aq[(sidx + 1) & 1][0] = ld_a(ks1, 2 * pr1);
         aq[(sidx + 1) & 1][1] = ld_a(ks1, 2 * pr1 + 1);
       }
-      if (PAIRS >= 2 && sidx == PAIRS - 2) { bq[1][0] = ld_b(1, 0); bq[1][1] = ld_b(1, 1); }
-      if (PAIRS >= 2 && sidx == PAIRS - 1) { bq[1][2] = ld_b(1, 2); bq[1][3] = ld_b(1, 3); }
+      if (PAIRS >= 2 && sidx == PAIRS - 2) {
+#pragma unroll
+        for (int j = 0; j < NJ / 2; ++j) bq[1][j] = ld_b(1, j);
+      }
+      if (PAIRS >= 2 && sidx == PAIRS - 1) {
+#pragma unroll
+        for (int j = NJ / 2; j < NJ; ++j) bq[1][j] = ld_b(1, j);
+      }
       __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these reads to just before their first use
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[2 * pr + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][j], aq[sidx & 1][i], acc[2 * pr + i][j], 0, 0, 0);
         const int grp = ks * TMW + 2 * pr + i;
 #pragma unroll
@@ -312,26 +331,40 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
   // acc[i][j][r] = C[m = group i, row lane & 15][n = group j, col 4 * (lane >> 4) + r]
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // every wave is done with the staging buffers
-  const int ncol0 = n0 + wc * 64;
+  const int ncol0 = n0 + wc * WCOLS;
   if constexpr (AMODE == 0) {
     // general epilogue, in the order and precision of gemm_nt_kernel's: alpha, bias, pre_out, activation, dropout (mask
     // indexed by row * N + col).  16-row slabs go through wave-private LDS as f32 (row stride 68 floats), then every lane
     // owns 8 consecutive columns of a row.
-    constexpr int FLD = 68;
+    constexpr int FLD = WCOLS + 4;
     float* fslab = reinterpret_cast<float*>(smem) + wave * (16 * FLD);
     const emoasr_epilogue_t& ep = g.ep;
     bf16* Cp = static_cast<bf16*>(g.C);
     bf16* pre_out = static_cast<bf16*>(ep.pre_out);
     if (g.rn.mode != 0) {
       const BigRnnt& rn = g.rn;
-      const int chunk = ncol0 >> 6;
+      const int chunk0 = ncol0 >> 6;
+      // mode 2: the row constants of the tile's BM rows go through LDS once (behind the wave-private slabs) -- read per row from
+      // global memory inside the slab loop they were 2 * TMW dependent round trips per wave
+      float* cfs = reinterpret_cast<float*>(smem + 40960);          // [BM][4]
+      int* ycs = reinterpret_cast<int*>(smem + 40960 + BM * 16);    // [BM]
+      if (rn.mode == 2) {
+        if (tid < BM) {
+          const int grow = m0 + tid;
+          const bool ok = grow < M;
+          *reinterpret_cast<f32x4*>(cfs + tid * 4) = ok ? *reinterpret_cast<const f32x4*>(rn.coef + (long)grow * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          ycs[tid] = ok ? rn.ycol[grow] : -1;
+        }
+        __syncthreads();
+      }
 #pragma unroll
       for (int i = 0; i < TMW; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(fslab + frow * FLD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+        for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(fslab + frow * FLD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int id = lane + 64 * hh, row = id >> 3, cc = id & 7;
+        for (int hh = 0; hh < HH; ++hh) {
+          const int id = lane + 64 * hh, row = id / LPR, cc = id % LPR;
+          const int chunk = chunk0 + (cc >> 3);   // (eight lanes = one 64-column chunk of the row)
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(fslab + row * FLD + cc * 8);
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(fslab + row * FLD + cc * 8 + 4);
           const int grow = m0 + wr * (BM / 2) + i * 16 + row;
@@ -370,7 +403,7 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
               m = mn;
             }
             if (rok) {
-              if (cc == 0 && chunk < rn.nchunk) {   // (the last column tile may reach past ceil(N / 64) chunks)
+              if ((cc & 7) == 0 && chunk < rn.nchunk) {   // (the last column tile may reach past ceil(N / 64) chunks)
                 // chunk-major table: the eight rows of this pass land in 64 consecutive bytes, and the fold reads it coalesced
                 // (row-major, 8-byte pieces 8 * nchunk bytes apart: the fold of the CTC head's 35 k x 157 table took 103 us)
                 *reinterpret_cast<float2*>(rn.part + ((long)chunk * rn.part_rows + rn.part_row0 + grow) * 2) = float2{m, sm};
@@ -388,8 +421,9 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
               }
             }
           } else if (rok && cok) {
-            const f32x4 cf = *reinterpret_cast<const f32x4*>(rn.coef + (long)grow * 4);   // lse, occ, gb, gy (scaled)
-            const int kb = rn.blank - col, ky = rn.ycol[grow] - col;
+            const int lrow = grow - m0;
+            const f32x4 cf = *reinterpret_cast<const f32x4*>(cfs + lrow * 4);   // lse, occ, gb, gy (scaled)
+            const int kb = rn.blank - col, ky = ycs[lrow] - col;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               float gq = __expf(v[e] - cf[0]) * cf[1];
@@ -406,10 +440,10 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(fslab + frow * FLD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+      for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(fslab + frow * FLD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int id = lane + 64 * hh, row = id >> 3, cc = id & 7;
+      for (int hh = 0; hh < HH; ++hh) {
+        const int id = lane + 64 * hh, row = id / LPR, cc = id % LPR;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(fslab + row * FLD + cc * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(fslab + row * FLD + cc * 8 + 4);
         const int grow = m0 + wr * (BM / 2) + i * 16 + row;
@@ -438,6 +472,13 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
           } else {
             if (pre_out) store8<bf16>(pre_out + off, v);
             act_vec<8>(ep.act, v);
+            if (ep.dact_pre) {   // data gradient through an activation: times act'(saved tensor), same offsets as C
+              const Vec16<bf16> pv = load16(static_cast<const bf16*>(ep.dact_pre) + off);
+              float d[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) d[e] = pv.get(e);
+              dact_vec<8>(ep.dact, d, v);
+            }
             dropout_apply8(ep.seed, (uint64_t)grow * (uint64_t)g.N + col, ep.drop_p, v);   // (N % 8 == 0, col % 8 == 0)
           }
           if (ep.residual) {   // x + res_scale * (...); C may alias the residual: every lane reads exactly what it then writes
@@ -452,9 +493,9 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
     return;
   }
   char* slab = smem + wave * (16 * EP_LD);
-  f32x4 bias4[4];
+  f32x4 bias4[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (g.bias) bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + ncol0 + j * 16 + 4 * (lane >> 4));
   }
@@ -462,13 +503,13 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
   const bf16* Dm = static_cast<const bf16*>(g.dmask);
   // output offsets of this lane's 2 * TMW row segments; the ReLU-mask loads of all of them go out together, before the
   // transposes (one dependent load per store would cost 2 * TMW memory round trips per tile)
-  long offs[TMW][2];
-  bf16x8 dm[TMW][2];
+  long offs[TMW][HH];
+  bf16x8 dm[TMW][HH];
 #pragma unroll
   for (int i = 0; i < TMW; ++i)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int id = lane + 64 * hh, row = id >> 3, cc = id & 7;
+    for (int hh = 0; hh < HH; ++hh) {
+      const int id = lane + 64 * hh, row = id / LPR, cc = id % LPR;
       const int grow = m0 + wr * (BM / 2) + i * 16 + row;
       long off = -1;
       if (grow < M) {
@@ -487,7 +528,7 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
 #pragma unroll
   for (int i = 0; i < TMW; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       bf16x4 h;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -498,8 +539,8 @@ __global__ __launch_bounds__(512) void big_nt_kernel(const BigArgs g) {
       *reinterpret_cast<bf16x4*>(slab + frow * EP_LD + (j * 16 + 4 * (lane >> 4)) * 2) = h;
     }
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int id = lane + 64 * hh, row = id >> 3, cc = id & 7;
+    for (int hh = 0; hh < HH; ++hh) {
+      const int id = lane + 64 * hh, row = id / LPR, cc = id % LPR;
       bf16x8 v = *reinterpret_cast<const bf16x8*>(slab + row * EP_LD + cc * 16);
       if (offs[i][hh] >= 0) {
         if (AMODE == 2 && Dm) {
@@ -528,6 +569,17 @@ inline int pick_bm(long M, int n_cu) {
   return best;
 }
 
+int n_cu_cached();
+// Plain products (AMODE 0).  pick_bm was fitted on the Conv2d products (K = 2304: 36 k-tiles per tile); round 4,
+// tools/big_waves_bench.py: SHORT reductions want the 128-row tile whatever the round count -- the CTC head with its soft-max
+// partials (35 145 x 10 000 x 256) 525 us against 807 (192 / 256 rows), the transducer head's forward 898 / 1209 and gradient
+// chunk (65 536 x 1000 x 512) 114 / 193 -- and so do the two column tiles of the joint's data gradient (65 536 x 512 x 1024:
+// 101 / 175 / 155); the long reductions onto one column tile (K >= 1024, N = 256) keep pick_bm's choice (192 at 35 k rows).
+inline int pick_bm_plain(long M, int N, int K) {
+  if (K <= 512 || (N == 512 && K >= 512)) return 128;
+  return pick_bm(M, n_cu_cached());
+}
+
 int n_cu_cached() {
   static int n = 0;
   if (!n) {
@@ -540,25 +592,32 @@ int n_cu_cached() {
   return n;
 }
 
-template <int TMW, int AMODE>
+int g_big_waves = 8;   // option "big_waves": 8 (2 x 4 waves, 64 columns each) or 4 (2 x 2 waves, 128 columns each)
+
+template <int TMW, int AMODE, int NW>
 int launch_big_t(const BigArgs& a, int tiles, hipStream_t s) {
   constexpr int bytes = (3 * TMW * 32 + 2 * 256) * 128;  // A ring of three stages + B ring of two
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)big_nt_kernel<TMW, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)big_nt_kernel<TMW, AMODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) { emo_set_error("hipFuncSetAttribute(%d): %s", bytes, hipGetErrorString(e)); return 1; }
     attr_done = true;
   }
-  big_nt_kernel<TMW, AMODE><<<tiles, 512, bytes, s>>>(a);
+  big_nt_kernel<TMW, AMODE, NW><<<tiles, NW * 64, bytes, s>>>(a);
   EMO_LAUNCH_CHECK();
   return 0;
 }
 
 template <int AMODE>
 int launch_big_bm(const BigArgs& a, int bm, int tiles, hipStream_t s) {
-  if (bm == 256) return launch_big_t<8, AMODE>(a, tiles, s);
-  if (bm == 192) return launch_big_t<6, AMODE>(a, tiles, s);
-  return launch_big_t<4, AMODE>(a, tiles, s);
+  if (g_big_waves == 4) {
+    if (bm == 256) return launch_big_t<8, AMODE, 4>(a, tiles, s);
+    if (bm == 192) return launch_big_t<6, AMODE, 4>(a, tiles, s);
+    return launch_big_t<4, AMODE, 4>(a, tiles, s);
+  }
+  if (bm == 256) return launch_big_t<8, AMODE, 8>(a, tiles, s);
+  if (bm == 192) return launch_big_t<6, AMODE, 8>(a, tiles, s);
+  return launch_big_t<4, AMODE, 8>(a, tiles, s);
 }
 
 int g_big_bm = 0;  // tuning override
@@ -568,6 +627,7 @@ int g_big_korder = 1;
 
 void emo_gemm_set_conv_big(int v) { g_conv_big = v; }
 void emo_gemm_set_big_bm(int v) { g_big_bm = v; }
+void emo_gemm_set_big_waves(int v) { g_big_waves = v == 4 ? 4 : 8; }
 void emo_gemm_set_big_korder(int v) { g_big_korder = v; }
 int emo_conv_big_enabled() { return g_conv_big; }
 
@@ -580,7 +640,7 @@ int emo_conv_big_enabled() { return g_conv_big; }
 int g_big_min_tiles = 2000;
 
 // Does the large-tile kernel take this emoasr_gemm_nt call?  (bf16 product, full 256-column tiles, 64-deep k-tiles, an
-// epilogue without residual / saved-activation / f32 output, and enough 128-row tiles to occupy most CUs.)
+// epilogue without f32 output, and enough 128-row tiles to occupy most CUs.)
 // Round 4: ... and the long reductions onto ONE 256-column tile (N = 256, K >= 512, stacked row counts): the second feed-forward
 // product (K = 1024, residual epilogue), the front-end Linear (K = 4864).  A 192-row tile reads every A row once where the 64 x 64
 // grid reads it four times; tools/big_n256_probe.py at 35 145 rows: 38.0 -> 29.5 us (K = 1024), 30.9 -> 24.7 (768),
@@ -589,11 +649,12 @@ int g_big_min_tiles = 2000;
 int g_big_n256 = 1;
 bool emo_gemm_nt_big_wants(int M, int N, int K, long lda, long ldb, long ldc, const emoasr_epilogue_t& ep) {
   if (!g_conv_big || N % 8 != 0 || N < 256 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) return false;
-  if (ep.dact_pre || ep.out_f32) return false;
+  if (ep.out_f32 || (ep.dact_pre && (ep.act & EMO_ACT_SAVE_DACT))) return false;
   if (ep.residual && ep.ldr % 8 != 0) return false;
   if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldb * 2 >= (1L << 32)) return false;
-  if (g_big_n256 && N == 256 && K >= 512 && M >= 8192) return true;
-  if (ep.residual) return false;   // (only measured for the shapes above)
+  // (N = 512: the transducer joint's data gradient, dz [65 536 x 1024] . W_out^T -- 143 us on the 64 x 64 kernel)
+  if (g_big_n256 && (N == 256 || N == 512) && K >= 512 && M >= 8192) return true;
+  if (ep.residual || ep.dact_pre) return false;   // (only measured for the shapes above)
   return (long)cdiv(M, 128) * cdiv(N, 256) >= g_big_min_tiles;
 }
 void emo_gemm_set_big_n256(int v) { g_big_n256 = v ? 1 : 0; }
@@ -602,7 +663,7 @@ int emo_gemm_nt_big_ep(int M, int N, int K, const void* A, long lda, const void*
   BigArgs a{};
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.ep = ep;
-  const int bm = g_big_bm ? g_big_bm : pick_bm(M, n_cu_cached());
+  const int bm = g_big_bm ? g_big_bm : pick_bm_plain(M, N, K);
   a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(N, 256);
   return launch_big_bm<0>(a, bm, a.tiles_m * a.tiles_n, s);
 }
@@ -628,7 +689,7 @@ static int rnnt_head_launch(int nrows, int V, int J, const void* h, const void* 
   a.M = nrows; a.N = V; a.K = J; a.A = h; a.lda = J; a.B = w; a.ldb = J; a.C = C; a.ldc = ldc;
   a.ep.alpha = 1.f; a.ep.bias = bias; a.ep.res_scale = 1.f;
   a.rn = rn;
-  const int bm = g_big_bm ? g_big_bm : pick_bm(nrows, n_cu_cached());
+  const int bm = g_big_bm ? g_big_bm : pick_bm_plain(nrows, V, J);
   a.tiles_m = cdiv(nrows, bm); a.tiles_n = cdiv(V, 256);
   return launch_big_bm<0>(a, bm, a.tiles_m * a.tiles_n, s);
 }
@@ -687,7 +748,7 @@ extern "C" int emoasr_gemm_nt_lse(int dtype, int M, int N, int K, const void* A,
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.ep.alpha = 1.f; a.ep.bias = bias; a.ep.res_scale = 1.f;
   a.rn.mode = 3; a.rn.nchunk = cdiv(N, 64); a.rn.part = part; a.rn.part_rows = M; a.rn.part_row0 = 0;
-  const int bm = g_big_bm ? g_big_bm : pick_bm(M, n_cu_cached());
+  const int bm = g_big_bm ? g_big_bm : pick_bm_plain(M, N, K);
   a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(N, 256);
   if (launch_big_bm<0>(a, bm, a.tiles_m * a.tiles_n, (hipStream_t)stream)) return 1;
   lse_parts_kernel<<<cdiv(M, 64), 64, 0, (hipStream_t)stream>>>(M, a.rn.nchunk, part, lse);

@@ -1450,13 +1450,24 @@ class _RNNTMixin:
         CH = min(N, self.rnnt_chunk)
         # (rows padded to a multiple of 64 columns: with V = 1000 a row is 2000 bytes and every 128-byte store of the gradient tile
         # straddles two lines written by different workgroups)
-        Vp = (V + 63) // 64 * 64 if os.environ.get("EMOASR_RNNT_PAD", "1") != "0" else V
-        dzc = torch.empty(CH, Vp, device=h2.device, dtype=h2.dtype)[:, :V]
+        Vp = (V + 63) // 64 * 64
+        dzp = torch.zeros(CH, Vp, device=h2.device, dtype=h2.dtype)   # (the pad columns stay zero: the kernels write V of them)
+        dzc = dzp[:, :V]
+        # the data gradient dz . W_out as an NT product over the PADDED columns against W_out^T [J, Vp] (zero pad): a long reduction
+        # onto two 256-column tiles, which the large-tile kernel takes (csrc/gemm_big.hip: emo_gemm_nt_big_wants) -- 143 -> ~80 us
+        # per 65 536-cell chunk on the 64 x 64 NN kernel
+        nt_form = os.environ.get("EMOASR_RNNT_DJOINT_NT", "1") != "0" and J % 256 == 0
+        if nt_form:
+            w_t = torch.zeros(J, Vp, device=h2.device, dtype=h2.dtype)
+            w_t[:, :V].copy_(w_out.t())
         for r0 in range(0, N, CH):
             n = min(CH, N - r0)
             dz = ops.rnnt_head_grad(h2[r0:r0 + n], w_out, b_out, coef[r0:r0 + n], ycol[r0:r0 + n], st.blank, dzc[:n])
             ops.gemm_tn(dz, h2[r0:r0 + n], out=A.g("decoder.output.weight"), accumulate=True, colsum=A.g("decoder.output.bias"))
-            ops.gemm_nn(dz, w_out, out=dpre[r0:r0 + n], dact_pre=h2[r0:r0 + n], dact=ops.DACT_TANH_OUT)
+            if nt_form:
+                ops.gemm_nt(dzp[:n], w_t, out=dpre[r0:r0 + n], dact_pre=h2[r0:r0 + n], dact=ops.DACT_TANH_OUT)
+            else:
+                ops.gemm_nn(dz, w_out, out=dpre[r0:r0 + n], dact_pre=h2[r0:r0 + n], dact=ops.DACT_TANH_OUT)
         de, dg = ops.joint_reduce(dpre.view(B, T, U, J))
         d = st.eouts.shape[2]
         deouts = self._lin_bwd(de.view(B * T, J), st.eouts.reshape(B * T, d), "decoder.w_enc.weight",

@@ -80,22 +80,26 @@ def test_full_model_against_oracle(dev, dtype):
         sd_eval = {k: v.detach() for k, v in sd.items()}
         eouts, elens = om.encoder_forward(sd_eval, cfg, xs, xlens)
         logits_ref = om.ctc_decoder_forward(sd_eval, cfg, eouts, elens)
-        want, _ = om.ctc_greedy(logits_ref, elens, 0)
+        want, want_aligns = om.ctc_greedy(logits_ref, elens, 0)
     model.load_state_dict({k: v.detach() for k, v in sd.items()})  # undo the BatchNorm running-stat update
     model.eval()
     with torch.no_grad():
         e2, el2, _ = model.encoder(xs.to(dev), xlens)
         logits = model.decoder(e2, el2)
-    hyps, _, _, _ = model.decode(xs.to(dev), xlens)
+    hyps, _, _, aligns = model.decode(xs.to(dev), xlens)
     rel = ((logits.float().cpu() - logits_ref).abs().max() / logits_ref.abs().max()).item()
     print(f"[measured {dtype}] logits rel err {rel:.2e}")
     assert rel < (1e-3 if dtype == torch.float32 else 3e-2), rel  # bf16 measured 1.25e-2 of the logits' range
     if dtype == torch.float32:
         assert hyps == want
     else:
-        agree = sum(int(a == b) for h, w in zip(hyps, want) for a, b in zip(h, w)) / max(1, sum(len(w) for w in want))
-        print(f"[measured {dtype}] greedy agreement {agree:.4f}")
-        assert agree > 0.9, agree  # bf16 measured 0.957 (random-init weights: many near-ties)
+        # frame-level arg-max agreement (random-init weights: near-ties over V = 10 000; a token-by-token comparison of the
+        # collapsed hypotheses shifts at every flipped frame -- 0.957 / 0.827 measured that way over two library builds with the
+        # same 1.26e-2 logits error)
+        same = sum(int(a == b) for ga, wa in zip(aligns, want_aligns) for a, b in zip(ga, wa))
+        agree = same / max(1, sum(len(wa) for wa in want_aligns))
+        print(f"[measured {dtype}] greedy frame agreement {agree:.4f}")
+        assert agree > 0.9, agree
 
 
 def test_bf16_greedy_hypotheses_exact_on_fitted_weights(dev):
