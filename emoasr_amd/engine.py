@@ -735,7 +735,14 @@ class CTCEngine(_DecoderMixinPlaceholder):
         assert V % 8 == 0, "ctc_train_stacked: vocabulary must be a multiple of 8"
         # the vocabulary projection with the soft-max denominators out of its epilogue: one pass over the 703 MB of logits
         logits, lse = ops.gemm_nt_lse(eouts, w, A.p(head + ".bias"))
-        dlogits = torch.empty_like(logits)
+        # the gradient rows are padded to a multiple of 64 columns (zero pad): full-line stores, and its product with the weight
+        # becomes an NT product over the padded columns that the large-tile kernel takes (35 145 x 256 x 10 048: 224 us against
+        # 371 us on the 64 x 64 NN kernel, tools/big_n256_probe.py)
+        Vp = (V + 63) // 64 * 64
+        dlp = torch.empty(logits.shape[0], Vp, device=dev, dtype=logits.dtype)
+        if Vp > V:
+            dlp[:, V:].zero_()
+        dlogits = dlp[:, :V]
         lp, alpha, beta, nll = ops.ctc_forward_rows(logits, lse, labels, elens, yl, blank, row0_d, Tmax)
         nll0 = torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll))
         bounds = [0]
@@ -744,7 +751,13 @@ class CTCEngine(_DecoderMixinPlaceholder):
         losses = torch.stack([nll0[bounds[k]:bounds[k + 1]].sum() / segs[k][0] for k in range(n)])
         ops.ctc_grad_rows(logits, lse, labels, elens, yl, blank, lp, alpha, beta, nll, 1.0, row0_d, tpad_d, uscale_d, dlogits)
         # ---- backward ------------------------------------------------------------------------------------------------
-        deouts = self._lin_bwd(dlogits, eouts, head + ".weight", head + ".bias")
+        if self.dtype == torch.bfloat16 and os.environ.get("EMOASR_HEAD_NT", "1") != "0":
+            self._wgrad(dlogits, eouts, A.g(head + ".weight", tuple(w.shape)), 1.0, A.g(head + ".bias"), 1.0)
+            w_t = torch.zeros(w.shape[1], Vp, device=dev, dtype=w.dtype)
+            w_t[:, :V].copy_(w.t())
+            deouts = ops.gemm_nt(dlp, w_t)
+        else:
+            deouts = self._lin_bwd(dlogits, eouts, head + ".weight", head + ".bias")
         if self.grad_hook is not None:   # the head's gradients are final
             self._flush_wgrads()
             self.grad_hook(A.offsets[head + ".weight"])

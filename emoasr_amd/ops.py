@@ -567,10 +567,12 @@ def gemm_nt_lse(a, b, bias):
     assert K == Kb
     if (a.dtype == torch.bfloat16 and N % 8 == 0 and N >= 256 and K % 64 == 0 and lda % 8 == 0 and ldb % 8 == 0
             and M * lda * 2 < (1 << 32) and N * ldb * 2 < (1 << 32) and M >= 2048):
-        out = torch.empty(M, N, device=a.device, dtype=a.dtype)
+        # rows padded to a multiple of 64 columns (V = 10 000: 20 000-byte rows put every 128-byte store of a tile astride two lines)
+        Np = (N + 63) // 64 * 64
+        out = torch.empty(M, Np, device=a.device, dtype=a.dtype)[:, :N]
         part = torch.empty((N + 63) // 64, M, 2, device=a.device, dtype=torch.float32)
         lse = torch.empty(M, device=a.device, dtype=torch.float32)
-        lib.call("emoasr_gemm_nt_lse", dt(a), M, N, K, _p(a), lda, _p(b), ldb, _p(out), N, _p(bias), _p(part), _p(lse), _stream())
+        lib.call("emoasr_gemm_nt_lse", dt(a), M, N, K, _p(a), lda, _p(b), ldb, _p(out), Np, _p(bias), _p(part), _p(lse), _stream())
         return out, lse
     out = gemm_nt(a, b, bias=bias)
     return out, row_lse(out)
