@@ -403,6 +403,14 @@ __device__ __forceinline__ void act_dact_vec(int act, float (&v)[N], float (&d)[
   act_vec<N>(act, v);
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for every outstanding global
+// store (the lattice kernels write one value per frame / diagonal) and load (their operands are prefetched chunks ahead) --
+// neither is part of the exchange the barrier protects.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // ---------------------------------------------------------------------------
 // log-space helpers for the CTC / RNN-T lattices
 // ---------------------------------------------------------------------------

@@ -136,19 +136,40 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(int B, int Tn, int S,
   }
   __syncthreads();
   float* prev = buf0; float* cur = buf1;
-  for (int i = 1; i < len; ++i) {
-    const int t = fwd ? i : len - 1 - i;
-    float v = -INFINITY;
-    if (s < Sb) {
-      const float e = lpb[(long)t * S + s];
-      const float a0 = prev[s];
-      const float a1 = fwd ? prev[s - 1] : prev[s + 1];
-      const float a2 = skip ? (fwd ? prev[s - 2] : prev[s + 2]) : -INFINITY;
-      v = lat_add3(a0, a1, a2) + e;
+  // The emission log-probabilities do not depend on the recursion: they are fetched CH frames ahead (two register sets, as in the
+  // transducer lattice, csrc/rnnt.hip), so a frame costs an LDS exchange + barrier instead of a dependent global load on top
+  // (0.7 us per frame before: 224 us for the stacked step's lattices).
+  constexpr int CH = 8;
+  float eA[CH], eB[CH];
+  auto fetch = [&](int i0, float (&e)[CH]) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int i = i0 + k;
+      const int t = fwd ? i : len - 1 - i;
+      e[k] = (i < len && s < Sb) ? lpb[(long)t * S + s] : -INFINITY;
     }
-    if (s < S) { out[(long)t * S + s] = v; cur[s] = v; }
-    __syncthreads();
-    float* tmp = prev; prev = cur; cur = tmp;
+  };
+  fetch(1, eA);
+  for (int i0 = 1; i0 < len; i0 += CH) {
+    fetch(i0 + CH, eB);
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int i = i0 + k;
+      if (i >= len) break;   // (block-uniform)
+      const int t = fwd ? i : len - 1 - i;
+      float v = -INFINITY;
+      if (s < Sb) {
+        const float a0 = prev[s];
+        const float a1 = fwd ? prev[s - 1] : prev[s + 1];
+        const float a2 = skip ? (fwd ? prev[s - 2] : prev[s + 2]) : -INFINITY;
+        v = lat_add3(a0, a1, a2) + eA[k];
+      }
+      if (s < S) { out[(long)t * S + s] = v; cur[s] = v; }
+      lds_barrier();   // (the alpha / beta rows written to global memory are not read here)
+      float* tmp = prev; prev = cur; cur = tmp;
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) eA[k] = eB[k];
   }
   if (fwd && s == 0) {
     const float a = prev[Sb - 1];

@@ -303,12 +303,13 @@ __global__ __launch_bounds__(1024) void rnnt_lattice_kernel(int Bn, int Tn, int 
       }
       if (u < U) cur[u] = act ? v : -INFINITY;
       if (act) own = v;
-      __syncthreads();
+      lds_barrier();   // (the lattice values written to global memory are read back only after the loop)
       float* tmp = cur; cur = prv; prv = tmp;
     }
 #pragma unroll
     for (int k = 0; k < CH; ++k) { sA[k] = sB[k]; eA[k] = eB[k]; }
   }
+  __syncthreads();   // thread 0 reads the last cell another thread stored
   if (fwd && u == 0) nll[b] = -(out[(long)(T - 1) * U + Ub] + pb[(long)(T - 1) * U + Ub]);
 }
 
