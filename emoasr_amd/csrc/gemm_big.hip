@@ -653,11 +653,14 @@ bool emo_gemm_nt_big_wants(int M, int N, int K, long lda, long ldb, long ldc, co
   if (ep.residual && ep.ldr % 8 != 0) return false;
   if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldb * 2 >= (1L << 32)) return false;
   // (N = 512: the transducer joint's data gradient, dz [65 536 x 1024] . W_out^T -- 143 us on the 64 x 64 kernel)
-  if (g_big_n256 && (N == 256 || N == 512) && K >= 512 && M >= 8192) return true;
+  // (option big_n256: 1 = N = 512 from K = 512 on, N = 256 from K = 2048 on; 2 = N = 256 from K = 512 on as well -- the second
+  // feed-forward product, K = 1024: 29.5 against 38 us alone, but 72 against 44 us INSIDE the step, where its operand was written by
+  // the launch before: three same-box pairs 29.4 against 28.9 ms per step)
+  if (g_big_n256 && M >= 8192 && ((N == 512 && K >= 512) || (N == 256 && K >= (g_big_n256 >= 2 ? 512 : 2048)))) return true;
   if (ep.residual || ep.dact_pre) return false;   // (only measured for the shapes above)
   return (long)cdiv(M, 128) * cdiv(N, 256) >= g_big_min_tiles;
 }
-void emo_gemm_set_big_n256(int v) { g_big_n256 = v ? 1 : 0; }
+void emo_gemm_set_big_n256(int v) { g_big_n256 = v < 0 ? 0 : v; }
 int emo_gemm_nt_big_ep(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                        const emoasr_epilogue_t& ep, hipStream_t s) {
   BigArgs a{};

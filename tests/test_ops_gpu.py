@@ -254,7 +254,7 @@ def test_gemm_nt_long_reductions_on_one_column_tile(dev, M, N, K):
     x0 = _rnd(dev, M, N, dtype=torch.bfloat16)
     outs = []
     try:
-        for big in (1, 0):
+        for big in (2, 0):   # (2: N = 256 from K = 512 on; the default, 1, takes K >= 2048 only)
             lib.set_option("big_n256", big)
             x = x0.clone()
             ops.gemm_nt(a, b, out=x, bias=bias, residual=x, res_scale=0.5, drop_p=0.1, seed=91)   # in place
