@@ -39,6 +39,46 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(int Tn, int F, int T1, i
   }
 }
 
+// The training shape (bf16, C = 256): one block per PAIR of output rows (five input rows in LDS), a thread owns TWO adjacent
+// channels of one of the two rows -- the nine broadcast LDS reads of a window feed 18 multiply-adds instead of 9, and a wave's
+// store is 256 contiguous bytes instead of 128 (round 4: 90 us per micro-batch, 3.1 TB/s of writes, with one channel per thread).
+// Same arithmetic per output (bias, then the nine taps in kh, kw order: bit-identical to the kernel above).
+__global__ __launch_bounds__(256) void conv1_fwd2_kernel(int Tn, int F, int T1, int F1, const float* __restrict__ x,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         bf16* __restrict__ y1) {
+  constexpr int C = 256;
+  extern __shared__ __attribute__((aligned(16))) float rows[];  // [5][F]
+  const int np = (T1 + 1) / 2;
+  const int b = blockIdx.x / np, t1a = (blockIdx.x % np) * 2;
+  const int nrow = min(5, Tn - 2 * t1a);   // (the second output row may not exist)
+  const float* xb = x + ((long)b * Tn + 2 * t1a) * F;
+  for (int i = threadIdx.x; i < nrow * F; i += 256) rows[i] = xb[i];
+  __syncthreads();
+  const int half = threadIdx.x >> 7, c = (threadIdx.x & 127) * 2;
+  const int t1 = t1a + half;
+  if (t1 >= T1) return;
+  float w0[9], w1[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { w0[j] = w[c * 9 + j]; w1[j] = w[(c + 1) * 9 + j]; }
+  const float b0 = bias[c], b1 = bias[c + 1];
+  const float* rw = rows + 2 * half * F;
+  bf16* yo = y1 + ((long)b * T1 + t1) * F1 * C + c;
+  for (int f1 = 0; f1 < F1; ++f1) {
+    float a0 = b0, a1 = b1;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float xv = rw[kh * F + 2 * f1 + kw];
+        a0 += w0[kh * 3 + kw] * xv;
+        a1 += w1[kh * 3 + kw] * xv;
+      }
+    bf16x2 o;
+    o[0] = (bf16)fmaxf(a0, 0.f); o[1] = (bf16)fmaxf(a1, 0.f);
+    *reinterpret_cast<bf16x2*>(yo + (long)f1 * C) = o;
+  }
+}
+
 // dw1[c, kh*3+kw] += sum dy1[b,t1,f1,c] * x[b,2t1+kh,2f1+kw];  db1[c] += sum dy1
 // Block = (b, chunk of C1_TROWS t1 rows, 256 channels); thread = 8 channels x one of 8 f1 lanes
 // (the f1 lanes of a channel group are adjacent lanes: 16-byte dy1 loads, 128-byte row segments, and a
@@ -202,15 +242,24 @@ __global__ __launch_bounds__(256) void col2im_kernel(int T1, int F1, int T2, int
   }
 }
 
+int g_conv1_pair = 1;   // option "conv1_pair"
+
 inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
 
 }  // namespace
+
+void emo_conv1_set_pair(int v) { g_conv1_pair = v ? 1 : 0; }
 
 extern "C" int emoasr_conv1_fwd(int dtype, int B, int Tn, int F, int C, const float* x, const float* w1,
                                 const float* b1, void* y1, void* stream) {
   EMO_CHECK(Tn >= 3 && F >= 3, "conv1: input too small (T=%d F=%d)", Tn, F);
   const int T1 = (Tn - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
   if (B == 0) return 0;
+  if (dtype == EMO_BF16 && C == 256 && g_conv1_pair) {
+    conv1_fwd2_kernel<<<B * ((T1 + 1) / 2), 256, 5 * F * sizeof(float), (hipStream_t)stream>>>(Tn, F, T1, F1, x, w1, b1, (bf16*)y1);
+    EMO_LAUNCH_CHECK();
+    return 0;
+  }
   EMO_DISPATCH(dtype, (conv1_fwd_kernel<T><<<B * T1, 256, 3 * F * sizeof(float), (hipStream_t)stream>>>(
                           Tn, F, T1, F1, C, x, w1, b1, (T*)y1)));
   EMO_LAUNCH_CHECK();

@@ -149,6 +149,26 @@ def _conv2_weight_repack(w):  # (C, C, 3, 3) -> (C, (kh,kw,c))
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
+@pytest.mark.parametrize("B,T,Fd", [(3, 67, 80), (2, 70, 83), (1, 3, 3), (2, 1200, 80)])
+def test_conv1_two_rows_per_block_equals_one_row_per_block(dev, B, T, Fd):
+    """the training-shape conv1 kernel (bf16, C = 256: two output rows per block, two channels per thread) is bit-identical to the
+    one-row kernel and matches torch's conv2d + ReLU; odd and even numbers of output rows, the smallest input"""
+    from emoasr_amd import lib, ops
+    C = 256
+    x = _rnd(dev, B, T, Fd)
+    w1, b1 = _rnd(dev, C, 1, 3, 3, scale=0.3), _rnd(dev, C, scale=0.1)
+    ref = F.relu(F.conv2d(x.unsqueeze(1), w1, b1, stride=2)).permute(0, 2, 3, 1)
+    outs = []
+    try:
+        for pair in (1, 0):
+            lib.set_option("conv1_pair", pair)
+            outs.append(ops.conv1_fwd(x, w1.reshape(C, 9).contiguous(), b1, torch.bfloat16))
+    finally:
+        lib.set_option("conv1_pair", 1)
+    assert torch.equal(outs[0], outs[1])
+    _close(outs[0], ref, 1e-2, "conv1")
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("T,Fd", [(67, 80), (70, 83), (9, 7)], ids=["odd-T1", "even-T1-F1", "tiny"])
 def test_frontend(dev, dtype, tr_mode, T, Fd):
