@@ -97,8 +97,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // NW = waves per workgroup: 8 (2 x 4 waves of (BM/2) x 64) or, round 4, 4 (2 x 2 waves of (BM/2) x 128 -- one wave per SIMD with
 // 256 accumulator registers at BM = 256: per k-tile and wave (BM/2 + 128) * 128 B of LDS reads for TWICE the flops of the 8-wave
 // layout, whose fragment reads alone need 85 % of the LDS bandwidth at the MFMA peak).
-template <int TMW, int AMODE, int NW>
+// MODE (AMODE 0 only): the epilogue variant -- 0 general, 1 / 2 / 3 the transducer / CTC head modes of BigRnnt -- as a TEMPLATE
+// parameter: with the mode a run-time field every instantiation carried all four fully unrolled epilogues (20 k instructions
+// for TMW = 4; a wave runs the epilogue once per tile, straight through: SQ_WAIT_INST_ANY was 43 % of the wave cycles of the
+// head-gradient launch, i.e. instruction fetch).
+template <int TMW, int AMODE, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) void big_nt_kernel(const BigArgs g) {
+  static_assert(AMODE == 0 || MODE == 0, "epilogue modes belong to the plain product");
   constexpr int BM = TMW * 32, BN = 256;
   constexpr int NJ = BN / (NW / 2) / 16;           // 16-column groups per wave: 4 (64 columns) or 8 (128)
   constexpr int WCOLS = NJ * 16;
@@ -341,14 +346,14 @@ __global__ __launch_bounds__(NW * 64) void big_nt_kernel(const BigArgs g) {
     const emoasr_epilogue_t& ep = g.ep;
     bf16* Cp = static_cast<bf16*>(g.C);
     bf16* pre_out = static_cast<bf16*>(ep.pre_out);
-    if (g.rn.mode != 0) {
+    if constexpr (MODE >= 1 && MODE <= 3) {
       const BigRnnt& rn = g.rn;
       const int chunk0 = ncol0 >> 6;
       // mode 2: the row constants of the tile's BM rows go through LDS once (behind the wave-private slabs) -- read per row from
       // global memory inside the slab loop they were 2 * TMW dependent round trips per wave
       float* cfs = reinterpret_cast<float*>(smem + 40960);          // [BM][4]
       int* ycs = reinterpret_cast<int*>(smem + 40960 + BM * 16);    // [BM]
-      if (rn.mode == 2) {
+      if constexpr (MODE == 2) {
         if (tid < BM) {
           const int grow = m0 + tid;
           const bool ok = grow < M;
@@ -379,14 +384,14 @@ __global__ __launch_bounds__(NW * 64) void big_nt_kernel(const BigArgs g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
           }
-          if (rn.mode == 3 && cok) {
+          if (MODE == 3 && cok) {
             // (the partials must describe the logits AS STORED: round to the output type first, so that exp(z - lse) of the stored
             // row sums to one exactly as after a separate row pass)
             if (rok) store8<bf16>(Cp + (long)grow * g.ldc + col, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (float)(bf16)v[e];
           }
-          if (rn.mode == 1 || rn.mode == 3) {
+          if constexpr (MODE == 1 || MODE == 3) {
             float m = -INFINITY, sm = 0.f;
             if (cok) {
 #pragma unroll
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(NW * 64) void big_nt_kernel(const BigArgs g) {
                 // (row-major, 8-byte pieces 8 * nchunk bytes apart: the fold of the CTC head's 35 k x 157 table took 103 us)
                 *reinterpret_cast<float2*>(rn.part + ((long)chunk * rn.part_rows + rn.part_row0 + grow) * 2) = float2{m, sm};
               }
-              if (cok && rn.mode == 1) {
+              if (cok && MODE == 1) {
                 const int cell = (int)(rn.row0 + grow);
                 const int u = cell % rn.U, b = cell / (rn.Tn * rn.U);
                 const int y = u < rn.ylens[b] ? rn.labels[b * rn.Lmax + u] : -1;
@@ -462,7 +467,23 @@ __global__ __launch_bounds__(NW * 64) void big_nt_kernel(const BigArgs g) {
             for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
           }
           const long off = (long)grow * g.ldc + col;
-          if (ep.act & EMO_ACT_SAVE_DACT) {   // (common.h: the saved tensor is act'(pre) * dropout_scale)
+          if constexpr (MODE == 4) {
+            // LEAN general epilogue (no activation, no saved tensor; act' in {the saved factor, 1 - tanh^2 of the saved output}):
+            // what the long reductions routed here need (front-end Linear, vocabulary head's data gradient, the joint's data
+            // gradient, residual outputs).  The full epilogue below inlines the Swish / GELU / tanh / erf ladders of act_vec and
+            // dact_vec at each of its 2 * TMW sites: 17 k instructions for TMW = 4.
+            if (ep.dact_pre) {
+              const Vec16<bf16> pv = load16(static_cast<const bf16*>(ep.dact_pre) + off);
+              if (ep.dact == EMO_DACT_MUL) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= pv.get(e);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float t = pv.get(e); v[e] *= 1.f - t * t; }
+              }
+            }
+            dropout_apply8(ep.seed, (uint64_t)grow * (uint64_t)g.N + col, ep.drop_p, v);
+          } else if (ep.act & EMO_ACT_SAVE_DACT) {   // (common.h: the saved tensor is act'(pre) * dropout_scale)
             float dd[8], mm[8];
             act_dact_vec<8>(ep.act & 0xFF, v, dd);
             dropout_mult8(ep.seed, (uint64_t)grow * (uint64_t)g.N + col, ep.drop_p, mm);
@@ -570,13 +591,12 @@ inline int pick_bm(long M, int n_cu) {
 }
 
 int n_cu_cached();
-// Plain products (AMODE 0).  pick_bm was fitted on the Conv2d products (K = 2304: 36 k-tiles per tile); round 4,
-// tools/big_waves_bench.py: SHORT reductions want the 128-row tile whatever the round count -- the CTC head with its soft-max
-// partials (35 145 x 10 000 x 256) 525 us against 807 (192 / 256 rows), the transducer head's forward 898 / 1209 and gradient
-// chunk (65 536 x 1000 x 512) 114 / 193 -- and so do the two column tiles of the joint's data gradient (65 536 x 512 x 1024:
-// 101 / 175 / 155); the long reductions onto one column tile (K >= 1024, N = 256) keep pick_bm's choice (192 at 35 k rows).
+// Plain products (AMODE 0): pick_bm's round-efficiency rule as well.  (For one evidence pass of round 4 short reductions took
+// 128-row tiles -- measured 1.5x faster for the head kernels -- but that was the instruction-fetch cost of the epilogue growing
+// with TMW while all epilogue variants sat in one kernel; with one lean epilogue per instantiation the taller tiles win again:
+// CTC head 509 / 453 / 467 us at 128 / 192 / 256 rows, head-gradient chunk 107 / 111 / 95, joint gradient 92 / 89 / 80.)
 inline int pick_bm_plain(long M, int N, int K) {
-  if (K <= 512 || (N == 512 && K >= 512)) return 128;
+  (void)N; (void)K;
   return pick_bm(M, n_cu_cached());
 }
 
@@ -594,30 +614,44 @@ int n_cu_cached() {
 
 int g_big_waves = 8;   // option "big_waves": 8 (2 x 4 waves, 64 columns each) or 4 (2 x 2 waves, 128 columns each)
 
-template <int TMW, int AMODE, int NW>
+template <int TMW, int AMODE, int NW, int MODE>
 int launch_big_t(const BigArgs& a, int tiles, hipStream_t s) {
   constexpr int bytes = (3 * TMW * 32 + 2 * 256) * 128;  // A ring of three stages + B ring of two
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)big_nt_kernel<TMW, AMODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)big_nt_kernel<TMW, AMODE, NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) { emo_set_error("hipFuncSetAttribute(%d): %s", bytes, hipGetErrorString(e)); return 1; }
     attr_done = true;
   }
-  big_nt_kernel<TMW, AMODE, NW><<<tiles, NW * 64, bytes, s>>>(a);
+  big_nt_kernel<TMW, AMODE, NW, MODE><<<tiles, NW * 64, bytes, s>>>(a);
   EMO_LAUNCH_CHECK();
   return 0;
 }
 
+template <int AMODE, int NW, int MODE>
+int launch_big_bm_(const BigArgs& a, int bm, int tiles, hipStream_t s) {
+  if (bm == 256) return launch_big_t<8, AMODE, NW, MODE>(a, tiles, s);
+  if (bm == 192) return launch_big_t<6, AMODE, NW, MODE>(a, tiles, s);
+  return launch_big_t<4, AMODE, NW, MODE>(a, tiles, s);
+}
+
 template <int AMODE>
 int launch_big_bm(const BigArgs& a, int bm, int tiles, hipStream_t s) {
-  if (g_big_waves == 4) {
-    if (bm == 256) return launch_big_t<8, AMODE, 4>(a, tiles, s);
-    if (bm == 192) return launch_big_t<6, AMODE, 4>(a, tiles, s);
-    return launch_big_t<4, AMODE, 4>(a, tiles, s);
+  if constexpr (AMODE == 0) {
+    switch (a.rn.mode) {
+      case 1: return launch_big_bm_<0, 8, 1>(a, bm, tiles, s);
+      case 2: return launch_big_bm_<0, 8, 2>(a, bm, tiles, s);
+      case 3: return launch_big_bm_<0, 8, 3>(a, bm, tiles, s);
+      default: break;
+    }
+    const emoasr_epilogue_t& ep = a.ep;
+    const bool lean = (ep.act & 0xFF) == EMO_ACT_NONE && !(ep.act & EMO_ACT_SAVE_DACT) && !ep.pre_out &&
+                      (!ep.dact_pre || ep.dact == EMO_DACT_MUL || ep.dact == EMO_DACT_TANH_OUT);
+    if (lean && g_big_waves != 4) return launch_big_bm_<0, 8, 4>(a, bm, tiles, s);
   }
-  if (bm == 256) return launch_big_t<8, AMODE, 8>(a, tiles, s);
-  if (bm == 192) return launch_big_t<6, AMODE, 8>(a, tiles, s);
-  return launch_big_t<4, AMODE, 8>(a, tiles, s);
+  // (the 4-wave layout -- measured slower on every product, DESIGN.md section 7 -- is kept for the general epilogue only)
+  if (g_big_waves == 4) return launch_big_bm_<AMODE, 4, 0>(a, bm, tiles, s);
+  return launch_big_bm_<AMODE, 8, 0>(a, bm, tiles, s);
 }
 
 int g_big_bm = 0;  // tuning override
@@ -646,7 +680,7 @@ int g_big_min_tiles = 2000;
 // grid reads it four times; tools/big_n256_probe.py at 35 145 rows: 38.0 -> 29.5 us (K = 1024), 30.9 -> 24.7 (768),
 // 184.7 -> 108.3 (4864), 370.7 -> 223.8 (10 048), bit-identical results (vendor BLAS: 23.6 / 20.6 / 87.1 / 191.2).
 // Option "big_n256".
-int g_big_n256 = 1;
+int g_big_n256 = 2;
 bool emo_gemm_nt_big_wants(int M, int N, int K, long lda, long ldb, long ldc, const emoasr_epilogue_t& ep) {
   if (!g_conv_big || N % 8 != 0 || N < 256 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) return false;
   if (ep.out_f32 || (ep.dact_pre && (ep.act & EMO_ACT_SAVE_DACT))) return false;
