@@ -129,6 +129,58 @@ extern "C" int emoasr_strided_copy(int dtype_in, int dtype_out, const void* in, 
   return 0;
 }
 
+namespace {
+struct TcGroup {
+  int n;
+  int tile0[EMOASR_TC_MAX + 1];   // first 32 x 32 tile of every item
+  emoasr_tc_item_t it[EMOASR_TC_MAX];
+};
+// one 32 x 32 tile per block through LDS: coalesced f32 reads along the source rows, coalesced stores along the destination rows
+template <typename TO>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const TcGroup G) {
+  __shared__ float t[32][33];
+  int i = 0;
+  while (i + 1 < G.n && (int)blockIdx.x >= G.tile0[i + 1]) ++i;
+  const emoasr_tc_item_t& q = G.it[i];
+  const int tl = blockIdx.x - G.tile0[i], tc = (q.cols + 31) / 32;
+  const int r0 = (tl / tc) * 32, c0 = (tl % tc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    t[ty + 8 * k][tx] = (r < q.rows && c < q.cols) ? q.src[(long)r * q.cols + c] : 0.f;
+  }
+  __syncthreads();
+  TO* dst = static_cast<TO*>(q.dst);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < q.cols && r < q.rows) dst[(long)c * q.ld_dst + r] = from_f32<TO>(t[tx][ty + 8 * k]);
+  }
+}
+}  // namespace
+
+extern "C" int emoasr_transpose_cast_batched(int dtype_out, int n, const emoasr_tc_item_t* items, void* stream) {
+  EMO_CHECK(n >= 0 && n <= EMOASR_TC_MAX, "transpose_cast_batched: n=%d outside 0..%d", n, EMOASR_TC_MAX);
+  if (n == 0) return 0;
+  TcGroup G{};
+  G.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    EMO_CHECK(items[i].src && items[i].dst && items[i].rows > 0 && items[i].cols > 0 && items[i].ld_dst >= items[i].rows,
+              "transpose_cast_batched: bad item %d", i);
+    G.it[i] = items[i];
+    G.tile0[i] = tiles;
+    tiles += ((items[i].rows + 31) / 32) * ((items[i].cols + 31) / 32);
+  }
+  G.tile0[n] = tiles;
+  if (dtype_out == EMO_BF16) transpose_cast_kernel<bf16><<<tiles, 256, 0, (hipStream_t)stream>>>(G);
+  else if (dtype_out == EMO_F32) transpose_cast_kernel<float><<<tiles, 256, 0, (hipStream_t)stream>>>(G);
+  else { emo_set_error("transpose_cast_batched: bad dtype"); return 1; }
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int emoasr_scale_dropout(int dtype, long n, const void* x, void* y, float scale, float drop_p,
                                     uint64_t seed, void* stream) {
   if (n == 0) return 0;

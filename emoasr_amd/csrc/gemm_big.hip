@@ -467,7 +467,20 @@ __global__ __launch_bounds__(NW * 64) void big_nt_kernel(const BigArgs g) {
             for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
           }
           const long off = (long)grow * g.ldc + col;
-          if constexpr (MODE == 4) {
+          if constexpr (MODE == 5) {
+            // the first feed-forward product's epilogue alone: Swish + the saved gradient factor + dropout (EMO_ACT_SAVE_DACT)
+            float dd[8], mm[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float sg = sigmoidf_(v[e]), a = v[e] * sg;
+              dd[e] = sg + a * (1.f - sg);
+              v[e] = a;
+            }
+            dropout_mult8(ep.seed, (uint64_t)grow * (uint64_t)g.N + col, ep.drop_p, mm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] *= mm[e]; dd[e] *= mm[e]; }
+            if (pre_out) store8<bf16>(pre_out + off, dd);
+          } else if constexpr (MODE == 4) {
             // LEAN general epilogue (no activation, no saved tensor; act' in {the saved factor, 1 - tanh^2 of the saved output}):
             // what the long reductions routed here need (front-end Linear, vocabulary head's data gradient, the joint's data
             // gradient, residual outputs).  The full epilogue below inlines the Swish / GELU / tanh / erf ladders of act_vec and
@@ -648,6 +661,8 @@ int launch_big_bm(const BigArgs& a, int bm, int tiles, hipStream_t s) {
     const bool lean = (ep.act & 0xFF) == EMO_ACT_NONE && !(ep.act & EMO_ACT_SAVE_DACT) && !ep.pre_out &&
                       (!ep.dact_pre || ep.dact == EMO_DACT_MUL || ep.dact == EMO_DACT_TANH_OUT);
     if (lean && g_big_waves != 4) return launch_big_bm_<0, 8, 4>(a, bm, tiles, s);
+    if (ep.act == (EMO_ACT_SWISH | EMO_ACT_SAVE_DACT) && !ep.dact_pre && !ep.residual && g_big_waves != 4)
+      return launch_big_bm_<0, 8, 5>(a, bm, tiles, s);
   }
   // (the 4-wave layout -- measured slower on every product, DESIGN.md section 7 -- is kept for the general epilogue only)
   if (g_big_waves == 4) return launch_big_bm_<AMODE, 4, 0>(a, bm, tiles, s);

@@ -295,8 +295,15 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
   };
   // x + res_scale * drop(W2 act(W1 LN(x))): gradient chain of one feed-forward block.  dx_in: gradient at the block's
   // output; pre_in: dropout(dx_in * res_scale) from the LayerNorm backward that produced dx_in (p > 0)
+  // dX = dY . W for W [n_out, d]: as the NT product against the transposed copy Wt [d, n_out] when the layer carries one (a long
+  // reduction onto one 256-column tile: the large-tile kernel), else the NN product on the 64 x 64 kernel
+  auto dgrad = [&](int n_out, const void* dy_, const void* W, const void* Wt, void* dx_) {
+    emoasr_epilogue_t e_ = plain_ep();
+    if (Wt) return emoasr_gemm_nt(dtype, M, d, n_out, dy_, n_out, Wt, n_out, dx_, d, &e_, stream);
+    return emoasr_gemm_nn(dtype, M, d, n_out, dy_, n_out, W, d, dx_, d, &e_, stream);
+  };
   auto ffn_bwd = [&](const emoasr_ffn_params_t& P, const emoasr_ffn_params_t& Gp, const emoasr_ffn_stash_t& S, const void* x_in,
-                     const void* dx_in, const void* pre_in, void* du, uint64_t s_in) {
+                     const void* dx_in, const void* pre_in, void* du, uint64_t s_in, const void* w1t) {
     const void* dy = p > 0.f ? pre_in : dx_in;
     const float alpha = p > 0.f ? 1.f : 0.5f;
     wgrad(dy, d, d, S.a, F, F, M, Gp.w2, alpha, Gp.b2);
@@ -306,8 +313,7 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     else { e.dact = EMOASR_ACT_SWISH; e.drop_p = p; }
     if (emoasr_gemm_nn(dtype, M, F, d, dy, d, P.w2, F, du, F, &e, stream)) return 1;
     wgrad(du, F, F, S.h, d, d, M, Gp.w1, 1.f, Gp.b1);
-    emoasr_epilogue_t e1 = plain_ep();
-    return emoasr_gemm_nn(dtype, M, d, F, du, F, P.w1, d, ws + bb.dh, d, &e1, stream);
+    return dgrad(F, du, P.w1, w1t, ws + bb.dh);
   };
 
   // What the attention backward needs of FORWARD data only -- the dropout keep mask, the dense Q + pos_bias copies, the cleared
@@ -323,7 +329,7 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
   if (ln_bwd(0, io->dy, st->ff.y, L->fin_ln_g, st->fin_mean, st->fin_rstd, nullptr, ws + bb.dx1, G->fin_ln_g, G->fin_ln_b,
              ws + bb.pre1, 0.5f, st->seed[6])) return 1;
   // ---- feed-forward -----------------------------------------------------------------------------------------------
-  if (ffn_bwd(L->ff, G->ff, st->ff, st->cv_y, ws + bb.dx1, ws + bb.pre1, ws + bb.du_ff, st->seed[5])) return 1;
+  if (ffn_bwd(L->ff, G->ff, st->ff, st->cv_y, ws + bb.dx1, ws + bb.pre1, ws + bb.du_ff, st->seed[5], L->ff_w1t)) return 1;
   if (ln_bwd(1, ws + bb.dh, st->cv_y, L->ff.ln_g, st->ff.mean, st->ff.rstd, ws + bb.dx1, ws + bb.dx2, G->ff.ln_g, G->ff.ln_b,
              ws + bb.pre2, 1.f, st->seed[4])) return 1;
   // ---- convolution module -----------------------------------------------------------------------------------------
@@ -367,7 +373,7 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
       if (emoasr_glu_bwd(dtype, M, d, st->g, ws + bb.dgl, ws + bb.dg, stream)) return 1;
     }
     wgrad(ws + bb.dg, 2 * d, 2 * d, st->cv_h, d, d, M, G->pw1, 1.f, G->pw1_b);
-    if (emoasr_gemm_nn(dtype, M, d, 2 * d, ws + bb.dg, 2 * d, L->pw1, d, ws + bb.dh, d, &e, stream)) return 1;
+    if (dgrad(2 * d, ws + bb.dg, L->pw1, L->pw1_t, ws + bb.dh)) return 1;
     if (ln_bwd(2, ws + bb.dh, st->at_y, L->cv_ln_g, st->cv_mean, st->cv_rstd, ws + bb.dx2, ws + bb.dx3, G->cv_ln_g, G->cv_ln_b,
                ws + bb.pre3, 1.f, st->seed[3])) return 1;
   }
@@ -400,12 +406,12 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     }
     wgrad(ws + bb.dpos_t, d, d, st->pos_t, d, d, R, G->wpos, 1.f, nullptr);
     wgrad(ws + bb.dqkv, 3 * d, 3 * d, st->at_h, d, d, M, G->wqkv, 1.f, G->bqkv);
-    if (emoasr_gemm_nn(dtype, M, d, 3 * d, ws + bb.dqkv, 3 * d, L->wqkv, d, ws + bb.dh, d, &e, stream)) return 1;
+    if (dgrad(3 * d, ws + bb.dqkv, L->wqkv, L->wqkv_t, ws + bb.dh)) return 1;
     if (ln_bwd(3, ws + bb.dh, st->ffm.y, L->att_ln_g, st->at_mean, st->at_rstd, ws + bb.dx3, ws + bb.dx4, G->att_ln_g,
                G->att_ln_b, ws + bb.pre4, 0.5f, st->seed[1])) return 1;
   }
   // ---- macaron feed-forward ---------------------------------------------------------------------------------------
-  if (ffn_bwd(L->ffm, G->ffm, st->ffm, st->x, ws + bb.dx4, ws + bb.pre4, ws + bb.du_ffm, st->seed[0])) return 1;
+  if (ffn_bwd(L->ffm, G->ffm, st->ffm, st->x, ws + bb.dx4, ws + bb.pre4, ws + bb.du_ffm, st->seed[0], L->ffm_w1t)) return 1;
   if (ln_bwd(4, ws + bb.dh, st->x, L->ffm.ln_g, st->ffm.mean, st->ffm.rstd, ws + bb.dx4, io->dx, G->ffm.ln_g, G->ffm.ln_b,
              nullptr, 0.f, 0)) return 1;
   // ---- the layer's weight gradients, one launch -----------------------------------------------------------------------

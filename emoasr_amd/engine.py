@@ -119,6 +119,23 @@ class ParamArena:
     def refresh_shadow(self):
         if self.shadow is not self.flat and not getattr(self, "_hold", False):
             ops.strided_copy(self.flat, out=self.shadow)
+            if getattr(self, "_tpairs", None):
+                ops.transpose_cast_batched(self._tpairs)
+
+    def transposed(self, first, last=None, shape=None):
+        """a compute-dtype copy of parameter `first` (or of the span first..last viewed as `shape` = [rows, cols]) stored
+        TRANSPOSED, kept current by refresh_shadow (one batched launch for all of them).  -> [cols, rows]"""
+        key = (first, last)
+        reg = self.__dict__.setdefault("_tcache", {})
+        if key not in reg:
+            src = self.pviews[first] if last is None else self._span(self.flat, first, last, shape)
+            src = src.view(shape) if (shape is not None and last is None) else src
+            src = src.view(src.shape[0], -1)
+            dst = torch.empty(src.shape[1], src.shape[0], device=src.device, dtype=self.shadow.dtype)
+            self.__dict__.setdefault("_tpairs", []).append((src, dst))
+            ops.transpose_cast_batched([(src, dst)])
+            reg[key] = dst
+        return reg[key]
 
     def hold_shadow(self, on):
         """The caller promises not to change the parameters while `on` (an evaluation loop, decode.test): the compute-dtype copy

@@ -6,6 +6,7 @@ workspaces (compute dtype / f32) that receive every intermediate.  The backward 
 intermediates as tensors; the views are created lazily, when the backward sweep reaches the layer.
 """
 import ctypes
+import os
 
 import torch
 
@@ -151,6 +152,12 @@ class ConformerLayerRuntime:
         L.bn_nbt = eng._buffers(bn + ".num_batches_tracked").data_ptr()
         L.pw2, L.pw2_b = A.w(cv + ".pointwise_conv2.weight", (d, d)).data_ptr(), A.p(cv + ".pointwise_conv2.bias").data_ptr()
         L.fin_ln_g, L.fin_ln_b = A.p(name + ".norm_final.weight").data_ptr(), A.p(name + ".norm_final.bias").data_ptr()
+        if A.shadow.dtype == torch.bfloat16 and os.environ.get("EMOASR_DGRAD_NT", "1") != "0":
+            # transposed copies of the weights whose data gradients are long reductions (csrc/layer.hip uses them when present)
+            L.ffm_w1t = A.transposed(name + ".feed_forward_macaron.w1.weight").data_ptr()
+            L.ff_w1t = A.transposed(name + ".feed_forward.w1.weight").data_ptr()
+            L.wqkv_t = A.transposed(sa + ".linear_q.weight", sa + ".linear_v.weight", (3 * d, d)).data_ptr()
+            L.pw1_t = A.transposed(cv + ".pointwise_conv1.weight", None, (2 * d, d)).data_ptr()
         self.params[li] = (L, guard)
         return L
 

@@ -137,7 +137,15 @@ class ConformerLayer(Structure):
                 ("cv_ln_g", c_void_p), ("cv_ln_b", c_void_p), ("pw1", c_void_p), ("pw1_b", c_void_p),
                 ("dw_w", c_void_p), ("dw_b", c_void_p), ("bn_g", c_void_p), ("bn_b", c_void_p),
                 ("bn_rm", c_void_p), ("bn_rv", c_void_p), ("bn_nbt", c_void_p), ("pw2", c_void_p), ("pw2_b", c_void_p),
-                ("fin_ln_g", c_void_p), ("fin_ln_b", c_void_p)]
+                ("fin_ln_g", c_void_p), ("fin_ln_b", c_void_p),
+                ("ffm_w1t", c_void_p), ("ff_w1t", c_void_p), ("wqkv_t", c_void_p), ("pw1_t", c_void_p)]
+
+
+class TcItem(Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_int), ("cols", c_int), ("ld_dst", c_long)]
+
+
+TC_MAX = 64
 
 
 class FfnStash(Structure):
@@ -223,6 +231,7 @@ SIGNATURES = {
     "emoasr_bn_swish_bwd_sums": [I, I, I, P, P, P, P, P, P, F, P, P, P, P, P],
     "emoasr_conv_bwd_fused": [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P],
     "emoasr_strided_copy": [I, I, P, P, I, I, I, I, L, L, L, L, I, P],
+    "emoasr_transpose_cast_batched": [I, I, P, P],
     "emoasr_scale_dropout": [I, L, P, P, F, F, U64, P],
     "emoasr_posenc": [I, I, I, I, P, P, F, F, U64, P, P],
     "emoasr_add": [I, L, P, P, P, P],

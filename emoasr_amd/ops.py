@@ -539,6 +539,20 @@ def strided_copy(src, out=None, out_dtype=None, accumulate=False):
     return out
 
 
+def transpose_cast_batched(pairs):
+    """pairs: [(src f32 [rows, cols] contiguous, dst [cols, rows] compute dtype, last dim contiguous)] -> every dst = src^T, one
+    launch per lib.TC_MAX pairs (the transposed weight copies of the layer runtime, refreshed with the parameter shadow)"""
+    for i0 in range(0, len(pairs), lib.TC_MAX):
+        chunk = pairs[i0:i0 + lib.TC_MAX]
+        arr = (lib.TcItem * len(chunk))()
+        for q, (src, dst) in zip(arr, chunk):
+            rows, cols = src.shape
+            assert src.is_contiguous() and src.dtype == torch.float32 and tuple(dst.shape) == (cols, rows) and dst.stride(1) == 1
+            assert dst.dtype == chunk[0][1].dtype
+            q.src, q.dst, q.rows, q.cols, q.ld_dst = src.data_ptr(), dst.data_ptr(), rows, cols, dst.stride(0)
+        lib.call("emoasr_transpose_cast_batched", dt(chunk[0][1]), len(chunk), arr, _stream())
+
+
 def scale_dropout(x, scale=1.0, drop_p=0.0, seed=0):
     y = torch.empty_like(x)
     lib.call("emoasr_scale_dropout", dt(x), x.numel(), _p(_chk(x)), _p(y), scale, drop_p, seed, _stream())

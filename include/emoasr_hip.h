@@ -334,6 +334,15 @@ int emoasr_posenc(int dtype, int B, int T, int N, const void* x, const float* pe
 /* y[i] = a[i] + b[i] */
 int emoasr_add(int dtype, long n, const void* a, const void* b, void* y, void* stream);
 
+/* dst_i [cols_i, rows_i] (compute dtype `dtype_out`, row stride ld_dst_i) = transpose of src_i [rows_i, cols_i] (f32, dense), all
+ * n items in ONE launch: the transposed weight copies of emoasr_conformer_layer_t, refreshed after every optimizer step. */
+typedef struct emoasr_tc_item {
+  const float* src; void* dst;
+  int rows, cols; long ld_dst;
+} emoasr_tc_item_t;
+#define EMOASR_TC_MAX 64
+int emoasr_transpose_cast_batched(int dtype_out, int n, const emoasr_tc_item_t* items, void* stream);
+
 /* ---- CTC (decoders/ctc.py:36-38,103-115,176-201; torch.nn.CTCLoss semantics) -- */
 /* lse[m] = logsumexp_v logits[m,:V] */
 int emoasr_row_lse(int dtype, int M, int V, const void* logits, long ld, float* lse, void* stream);
@@ -552,6 +561,10 @@ typedef struct emoasr_conformer_layer {
   float *bn_rm, *bn_rv; long long* bn_nbt;
   const void* pw2; const float* pw2_b;
   const float *fin_ln_g, *fin_ln_b;
+  /* optional (bf16 backward, NULL = absent): TRANSPOSED copies of the weights whose data-gradient products are long reductions
+   * onto one 256-column tile -- ffm / ff w1 as [d,F], wqkv as [d,3d], pw1 as [d,2d] (emoasr_transpose_cast_batched keeps them
+   * current).  dX = dY . W is then the NT product dY . (W^T)^T, which the large-tile kernel takes (csrc/gemm_big.hip). */
+  const void *ffm_w1t, *ff_w1t, *wqkv_t, *pw1_t;
 } emoasr_conformer_layer_t;
 typedef struct emoasr_ffn_stash {
   void *h, *u, *a, *y;               /* LN out [M,d], pre-activation [M,F] (optional), activation [M,F], block output [M,d] */

@@ -149,6 +149,19 @@ def _conv2_weight_repack(w):  # (C, C, 3, 3) -> (C, (kh,kw,c))
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
+def test_transpose_cast_batched(dev):
+    """several f32 matrices -> their transposes in the compute dtype, one launch (the layer runtime's transposed weight copies);
+    ragged shapes, a padded destination row stride"""
+    from emoasr_amd import ops
+    shapes = [(1024, 256), (768, 256), (33, 65), (1, 7), (512, 256)]
+    for dt_ in (torch.bfloat16, torch.float32):
+        srcs = [_rnd(dev, r, c) for r, c in shapes]
+        dsts = [torch.full((c, r + (8 if i == 2 else 0)), float("nan"), device=dev, dtype=dt_)[:, :r] for i, (r, c) in enumerate(shapes)]
+        ops.transpose_cast_batched(list(zip(srcs, dsts)))
+        for s_, d_ in zip(srcs, dsts):
+            assert torch.equal(d_, s_.t().to(dt_))
+
+
 @pytest.mark.parametrize("B,T,Fd", [(3, 67, 80), (2, 70, 83), (1, 3, 3), (2, 1200, 80)])
 def test_conv1_two_rows_per_block_equals_one_row_per_block(dev, B, T, Fd):
     """the training-shape conv1 kernel (bf16, C = 256: two output rows per block, two channels per thread) is bit-identical to the
