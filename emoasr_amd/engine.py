@@ -1600,6 +1600,131 @@ class _RNNTMixin:
         return hyps, aligns
 
     def rnnt_beam_search(self, eouts, beam_width, blank, eos, num_expands=3):
+        """alignment-length synchronous beam search for ONE utterance (rnn_transducer.py:242-325,348-359): the expansion round as a
+        replayed HIP graph (_rnnt_beam_search_graph) unless EMOASR_RNNT_BEAM_GRAPH=0 or the utterance does not fit its static
+        buffers; then the launch chain below."""
+        T = eouts.shape[1]
+        if (os.environ.get("EMOASR_RNNT_BEAM_GRAPH", "1") != "0" and beam_width <= 16
+                and (T * num_expands + 2) * beam_width + 1 <= self._BEAM_POOL and T <= self._BEAM_TMAX):
+            return self._rnnt_beam_search_graph(eouts, beam_width, blank, eos, num_expands)
+        return self._rnnt_beam_search_chain(eouts, beam_width, blank, eos, num_expands)
+
+    _BEAM_POOL, _BEAM_TMAX = 32768, 4096
+
+    def _rnnt_beam_round_graph(self, beam_width, nb, blank):
+        """the device work of ONE expansion round over nb live hypotheses, captured once as a HIP graph over static buffers:
+        control words (last labels, source / destination slots of the LSTM states in the pool, frame index) come in through
+        `ctl`, (blank log-prob, top-k log-probs, top-k ids) per hypothesis go out through `out`.  The host loop pays one small
+        upload, one replay and one small download per round instead of ~12 C-ABI calls, ~16 allocations and the torch glue
+        (246 us per round, host-bound: tools/l4_beam_prof.py)."""
+        st = self.__dict__.setdefault("_beam_static", None)
+        A, J, H, nl = self.arena, self.r_J, self.r_H, self.r_nl
+        dev = A.flat.device
+        if st is None:
+            st = self._beam_static = _Stash()
+            st.ph = [torch.zeros(self._BEAM_POOL, H, device=dev, dtype=self.dtype) for _ in range(nl)]
+            st.pc = [torch.zeros(self._BEAM_POOL, H, device=dev, dtype=torch.float32) for _ in range(nl)]
+            st.e = torch.zeros(self._BEAM_TMAX, J, device=dev, dtype=self.dtype)
+            st.ctl = torch.zeros(3 * 16 + 1, device=dev, dtype=torch.int64)
+            st.ctl_host = torch.zeros(3 * 16 + 1, dtype=torch.int64).pin_memory()
+            st.out = torch.zeros(16, 1 + 2 * 16, device=dev, dtype=torch.float32)
+            st.out_host = torch.zeros(16, 1 + 2 * 16, dtype=torch.float32).pin_memory()
+            st.graphs = {}
+        key = (beam_width, nb, blank)
+        if key in st.graphs:
+            return st, st.graphs[key]
+
+        def body():
+            with ops.stream_scope():
+                ids = st.ctl[:nb].to(torch.int32).view(1, nb)
+                src, dst, t = st.ctl[16:16 + nb], st.ctl[32:32 + nb], st.ctl[48:49]
+                prev = ([p.index_select(0, src) for p in st.ph], [p.index_select(0, src) for p in st.pc])
+                dout, (nh, nc), _ = self.rnnt_recurrency(ids, prev, False, False)
+                for l in range(nl):
+                    st.ph[l].index_copy_(0, dst, nh[l])
+                    st.pc[l].index_copy_(0, dst, nc[l])
+                g = ops.gemm_nt(dout.view(nb, H), A.w("decoder.w_dec.weight"), bias=A.p("decoder.w_dec.bias"))
+                h = ops.joint_tanh(st.e.index_select(0, t).view(1, 1, J), g.view(1, nb, J))
+                logits = ops.gemm_nt(h.view(nb, J), A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
+                lp = ops.log_softmax(logits)
+                vals, idx, _ = ops.topk(lp[:, 1:], beam_width)
+                st.out[:nb, 0:1].copy_(lp[:, blank:blank + 1])
+                st.out[:nb, 1:1 + beam_width].copy_(vals)
+                st.out[:nb, 1 + beam_width:1 + 2 * beam_width].copy_(idx)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            body()   # warm-up outside the capture (allocator, lazy initialisation)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            body()
+        st.graphs[key] = g_
+        return st, g_
+
+    def _rnnt_beam_search_graph(self, eouts, beam_width, blank, eos, num_expands=3):
+        """the search of rnnt_beam_search with every expansion round's device work replayed from a HIP graph; the bookkeeping
+        (stable sort by float64 score, merge of equal label sequences by log-add, cut to the beam) stays on the host, as in the
+        reference and in _rnnt_beam_search_chain, whose arithmetic and launch order the captured body repeats."""
+        import numpy as np
+        with ops.stream_scope(), torch.no_grad():
+            A, J = self.arena, self.r_J
+            A.refresh_shadow()
+            T = eouts.shape[1]
+            e_all = ops.gemm_nt(eouts[0], A.w("decoder.w_enc.weight"), bias=A.p("decoder.w_enc.bias"))  # [T,J]
+            st, _ = self._rnnt_beam_round_graph(beam_width, 1, blank)
+            st.e[:T].copy_(e_all)
+            for l in range(self.r_nl):   # slot 0: the zero state every search starts from
+                st.ph[l][0].zero_()
+                st.pc[l][0].zero_()
+            ctl, out = st.ctl_host.numpy(), st.out_host.numpy()
+            stream = torch.cuda.current_stream()
+            nslot = 1
+            beams = [([eos], 0.0, 0)]   # (hyp, score, slot of the LSTM state from BEFORE its last label)
+
+            def merge(cands):
+                seen = {}
+                for hyp, score, slot in cands:
+                    key = tuple(hyp)
+                    if key in seen:
+                        seen[key][1] = float(np.logaddexp(seen[key][1], score))
+                    else:
+                        seen[key] = [hyp, score, slot]
+                return [tuple(c) for c in seen.values()]
+
+            for t in range(T):
+                frame_out, live = [], beams
+                for v in range(num_expands):
+                    nb = len(live)
+                    if nb == 0:
+                        break
+                    _, graph = self._rnnt_beam_round_graph(beam_width, nb, blank)
+                    for i, (hyp, _, slot) in enumerate(live):
+                        ctl[i], ctl[16 + i], ctl[32 + i] = hyp[-1], slot, nslot + i
+                    ctl[48] = t
+                    st.ctl.copy_(st.ctl_host, non_blocking=True)
+                    graph.replay()
+                    st.out_host.copy_(st.out, non_blocking=True)
+                    stream.synchronize()
+                    host = out[:nb].astype(np.float64)
+                    last = v == num_expands - 1
+                    for i, (hyp, score, slot) in enumerate(live):
+                        frame_out.append((hyp, score + float(host[i, 0]), slot))
+                    grown = []
+                    if not last:
+                        for i, (hyp, score, slot) in enumerate(live):
+                            for k in range(beam_width):
+                                grown.append((hyp + [int(host[i, 1 + beam_width + k]) + 1], score + float(host[i, 1 + k]), nslot + i))
+                    nslot += nb
+                    grown.sort(key=lambda c: -c[1])
+                    live = merge(grown)[:beam_width]
+                frame_out.sort(key=lambda c: -c[1])
+                beams = merge(frame_out)[:beam_width]
+            return [hyp for hyp, _, _ in beams]
+
+    def _rnnt_beam_search_chain(self, eouts, beam_width, blank, eos, num_expands=3):
         """alignment-length synchronous beam search for ONE utterance (rnn_transducer.py:242-325,348-359).
 
         eouts [1,T,d].  Per frame up to `num_expands` rounds; each round is one batched prediction-network

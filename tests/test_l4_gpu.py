@@ -131,10 +131,13 @@ def test_greedy_window_sizes(dev, window):
     assert aligns == split_ragged(g["eval/aligns"], g["eval/align_lens"])
 
 
-def test_beam_search_f32(dev):
+@pytest.mark.parametrize("graph", ["1", "0"], ids=["graph", "chain"])
+def test_beam_search_f32(dev, graph, monkeypatch):
     """ALSD beam search (rnn_transducer.py:242-325): the same hypotheses, in the same order, as the
-    reference produced for the fitted l4_tiny weights (tests/golden/rnntbeam_tiny.npz)"""
+    reference produced for the fitted l4_tiny weights (tests/golden/rnntbeam_tiny.npz) -- with the expansion round replayed
+    from a HIP graph (the default) and as the launch chain"""
     from tests.util import RNNT_BEAM_WIDTHS, load_rnnt_beam_golden
+    monkeypatch.setenv("EMOASR_RNNT_BEAM_GRAPH", graph)
     model, g = _build(torch.float32, dev)
     model.eval()
     want = load_rnnt_beam_golden()
