@@ -84,6 +84,19 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsig
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_ptr)lds, 16, voff, soff, 0, 0);
 }
 
+// exchange inside groups of 8 lanes on the VALU (DPP), for reductions: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+// (lane i <-> 7 - i of its half-row: after the two quad steps every lane of a quad holds the quad's result, so the mirror pairs the
+// two quads' results).  __shfl_xor compiles to ds_bpermute_b32 -- an LDS-pipe round trip per step.
+template <int CTRL> __device__ __forceinline__ float dpp8(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float max8(float x) {
+  x = fmaxf(x, dpp8<0xB1>(x)); x = fmaxf(x, dpp8<0x4E>(x)); return fmaxf(x, dpp8<0x141>(x));
+}
+__device__ __forceinline__ float sum8(float x) {
+  x += dpp8<0xB1>(x); x += dpp8<0x4E>(x); return x + dpp8<0x141>(x);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -392,21 +405,20 @@ __global__ __launch_bounds__(NW * 64) void big_nt_kernel(const BigArgs g) {
             for (int e = 0; e < 8; ++e) v[e] = (float)(bf16)v[e];
           }
           if constexpr (MODE == 1 || MODE == 3) {
+            // the eight lanes of a row (lane bits 0..2) hold its 64 columns of this wave's chunk: the chunk's maximum first (three
+            // DPP steps), then the sum of exp(z - max) (three more) -- a butterfly over (max, sum) pairs cost two ds_bpermute and two
+            // more exponentials per step
             float m = -INFINITY, sm = 0.f;
             if (cok) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) m = fmaxf(m, v[e]);
+            }
+            m = max8(m);
+            if (cok) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) sm += __expf(v[e] - m);
             }
-            // the eight lanes of a row (lane bits 0..2) hold its 64 columns of this wave's chunk
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-              const float mo = __shfl_xor(m, o, 64), so = __shfl_xor(sm, o, 64);
-              const float mn = fmaxf(m, mo);
-              sm = sm * (m == mn ? 1.f : __expf(m - mn)) + so * (mo == mn ? 1.f : __expf(mo - mn));
-              m = mn;
-            }
+            sm = sum8(sm);
             if (rok) {
               if ((cc & 7) == 0 && chunk < rn.nchunk) {   // (the last column tile may reach past ceil(N / 64) chunks)
                 // chunk-major table: the eight rows of this pass land in 64 consecutive bytes, and the fold reads it coalesced
