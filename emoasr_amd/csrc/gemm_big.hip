@@ -375,6 +375,12 @@ __global__ __launch_bounds__(NW * 64) void big_nt_kernel(const BigArgs g) {
         }
         __syncthreads();
       }
+      if constexpr (MODE == 1) {
+        // the label column of the tile's rows (emoasr_rnnt_ycol: -1 = none) through LDS: formed per row inside the slab loop it
+        // was two integer divisions and two DEPENDENT global loads (ylens[b], labels[b, u]) per pass
+        if (tid < BM) ycs[tid] = (m0 + tid < M) ? rn.ycol[m0 + tid] : -1;
+        __syncthreads();
+      }
 #pragma unroll
       for (int i = 0; i < TMW; ++i) {
 #pragma unroll
@@ -426,10 +432,7 @@ __global__ __launch_bounds__(NW * 64) void big_nt_kernel(const BigArgs g) {
                 *reinterpret_cast<float2*>(rn.part + ((long)chunk * rn.part_rows + rn.part_row0 + grow) * 2) = float2{m, sm};
               }
               if (cok && MODE == 1) {
-                const int cell = (int)(rn.row0 + grow);
-                const int u = cell % rn.U, b = cell / (rn.Tn * rn.U);
-                const int y = u < rn.ylens[b] ? rn.labels[b * rn.Lmax + u] : -1;
-                const int kb = rn.blank - col, ky = y - col;
+                const int kb = rn.blank - col, ky = ycs[grow - m0] - col;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                   if (kb == e) rn.zb[grow] = v[e];
@@ -762,14 +765,16 @@ static int rnnt_head_launch(int nrows, int V, int J, const void* h, const void* 
 // part [nrows, ceil(V / 64), 2], zb / zy [nrows] (see BigRnnt).  The logits are never stored.
 extern "C" int emoasr_rnnt_head_fwd(int dtype, long row0, int nrows, int Tn, int U, int V, int J, int Lmax, const void* h,
                                     const void* w, const float* bias, const int* labels, const int* ylens, int blank,
-                                    float* part, long part_rows, float* zb, float* zy, void* stream) {
+                                    float* part, long part_rows, float* zb, float* zy, const int* ycol, void* stream) {
   EMO_CHECK(dtype == EMO_BF16, "rnnt_head_fwd: bf16 only");
   if (nrows == 0) return 0;
   EMO_CHECK(blank >= 0 && blank < V && row0 + nrows < (1L << 31), "rnnt_head_fwd: bad blank / cell range");
   EMO_CHECK(row0 >= 0 && row0 + nrows <= part_rows, "rnnt_head_fwd: cells %ld..%ld outside the partial table's %ld rows", row0, row0 + nrows, part_rows);
   BigRnnt rn{};
   rn.mode = 1; rn.Tn = Tn; rn.U = U; rn.Lmax = Lmax; rn.blank = blank; rn.nchunk = cdiv(V, 64); rn.row0 = row0;
+  EMO_CHECK(ycol, "rnnt_head_fwd: ycol (emoasr_rnnt_ycol) required");
   rn.labels = labels; rn.ylens = ylens; rn.part = part; rn.part_rows = part_rows; rn.part_row0 = row0; rn.zb = zb; rn.zy = zy;
+  rn.ycol = ycol;
   return rnnt_head_launch(nrows, V, J, h, w, bias, nullptr, V, rn, (hipStream_t)stream);
 }
 

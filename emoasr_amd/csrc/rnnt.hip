@@ -514,6 +514,24 @@ __global__ __launch_bounds__(256) void rnnt_parts_kernel(long rows, int Tn, int 
   zy[row] = u < ylens[b] ? zy[row] - l : -INFINITY;
 }
 
+// label column of every lattice cell (b, t, u): labels[b, u] for u < ylens[b], else -1 (what emoasr_rnnt_head_fwd gathers)
+__global__ __launch_bounds__(256) void rnnt_ycol_kernel(long rows, int Tn, int U, int Lmax, const int* __restrict__ labels,
+                                                        const int* __restrict__ ylens, int* __restrict__ ycol) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const int u = row % U;
+  const long b = row / ((long)Tn * U);
+  ycol[row] = u < ylens[b] ? labels[b * Lmax + u] : -1;
+}
+
+extern "C" int emoasr_rnnt_ycol(int B, int T_, int U, int Lmax, const int* labels, const int* ylens, int* ycol, void* stream) {
+  const long rows = (long)B * T_ * U;
+  if (rows == 0) return 0;
+  rnnt_ycol_kernel<<<cdiv(rows, 256), 256, 0, (hipStream_t)stream>>>(rows, T_, U, Lmax, labels, ylens, ycol);
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+
 // emoasr_rnnt_forward without the logits: part / zb / zy from emoasr_rnnt_head_fwd (zb, zy become lpb, lpy in place)
 extern "C" int emoasr_rnnt_forward_parts(int B, int T_, int U, int V, const float* part, const int* elens, const int* ylens,
                                          float* lse, float* zb_lpb, float* zy_lpy, float* alpha, float* beta, float* nll,

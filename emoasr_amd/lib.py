@@ -262,7 +262,8 @@ SIGNATURES = {
     "emoasr_joint_reduce": [I, I, I, I, I, P, P, P, P],
     "emoasr_rnnt_forward": [I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P],
     "emoasr_rnnt_grad": [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, F, P, P, P],
-    "emoasr_rnnt_head_fwd": [I, L, I, I, I, I, I, I, P, P, P, P, P, I, P, L, P, P, P],
+    "emoasr_rnnt_head_fwd": [I, L, I, I, I, I, I, I, P, P, P, P, P, I, P, L, P, P, P, P],
+    "emoasr_rnnt_ycol": [I, I, I, I, P, P, P, P],
     "emoasr_rnnt_forward_parts": [I, I, I, I, P, P, P, P, P, P, P, P, P, P],
     "emoasr_rnnt_coef": [I, I, I, I, P, P, P, P, P, P, P, P, P, F, P, P, P, P],
     "emoasr_rnnt_head_grad": [I, I, I, I, P, P, P, P, P, I, P, L, P],

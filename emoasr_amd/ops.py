@@ -869,11 +869,13 @@ def rnnt_head_forward(h, w, bias, B, T, U, labels, elens, ylens, blank):
     f = lambda: torch.empty(B, T, U, device=dev, dtype=torch.float32)
     lse, zb, zy, alpha, beta = f(), f(), f(), f(), f()
     zy.fill_(0.0)   # (cells beyond ylens never get a label logit)
+    ycol = torch.empty(N, device=dev, dtype=torch.int32)
+    lib.call("emoasr_rnnt_ycol", B, T, U, labels.shape[1], _p(labels), _p(ylens), _p(ycol), _stream())
     step = max(1, min(N, ((1 << 31) // (J * 2)) // 256 * 256))   # rows per launch: the operand stays below 4 GiB
     for r0 in range(0, N, step):
         n = min(step, N - r0)
         lib.call("emoasr_rnnt_head_fwd", dt(h), r0, n, T, U, V, J, labels.shape[1], _p(h[r0:r0 + n]), _p(w), _p(bias), _p(labels),
-                 _p(ylens), blank, _p(part), N, _p(zb.view(-1)[r0:r0 + n]), _p(zy.view(-1)[r0:r0 + n]), _stream())
+                 _p(ylens), blank, _p(part), N, _p(zb.view(-1)[r0:r0 + n]), _p(zy.view(-1)[r0:r0 + n]), _p(ycol[r0:r0 + n]), _stream())
     nll = torch.empty(B, device=dev, dtype=torch.float32)
     lib.call("emoasr_rnnt_forward_parts", B, T, U, V, _p(part), _p(elens), _p(ylens), _p(lse), _p(zb), _p(zy), _p(alpha),
              _p(beta), _p(nll), _stream())

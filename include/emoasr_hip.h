@@ -494,7 +494,9 @@ int emoasr_rnnt_grad(int dtype, int B, int T, int U, int V, int Lmax, const void
  *                          [cells, V] buffer exists in either direction. */
 int emoasr_rnnt_head_fwd(int dtype, long row0, int nrows, int T, int U, int V, int J, int Lmax, const void* h, const void* w,
                          const float* bias, const int* labels, const int* ylens, int blank, float* part, long part_rows, float* zb,
-                         float* zy, void* stream);
+                         float* zy, const int* ycol, void* stream);
+/* ycol [B*T*U] for emoasr_rnnt_head_fwd: the label column of every lattice cell, labels[b, u] for u < ylens[b], else -1 */
+int emoasr_rnnt_ycol(int B, int T, int U, int Lmax, const int* labels, const int* ylens, int* ycol, void* stream);
 int emoasr_rnnt_forward_parts(int B, int T, int U, int V, const float* part, const int* elens, const int* ylens, float* lse,
                               float* zb_lpb, float* zy_lpy, float* alpha, float* beta, float* nll, void* stream);
 int emoasr_rnnt_coef(int B, int T, int U, int Lmax, const float* lse, const float* lpb, const float* lpy, const float* alpha,
