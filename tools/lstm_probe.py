@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo')
 from emoasr_amd import ops
 dev = torch.device('cuda:0'); dt = torch.bfloat16
 H, U = 512, 100
-for B in (8, 16, 24, 32, 48, 64):
+for B in (36, 64, 65, 128, 139, 192, 256, 512):
     pre = (torch.randn(U, B, 4 * H, device=dev) * 0.1).to(dt)
     w_hh = (torch.randn(4 * H, H, device=dev) * 0.04).to(dt)
     hseq = torch.empty(U, B, H, device=dev, dtype=dt); cseq = torch.empty(U, B, H, device=dev, dtype=torch.float32)
