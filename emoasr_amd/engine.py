@@ -1386,15 +1386,19 @@ class _RNNTMixin:
         return (self.rnnt_fused and h.dtype == torch.bfloat16 and w_out.shape[0] % 8 == 0 and w_out.shape[0] >= 64
                 and w_out.shape[1] % 64 == 0)
 
-    def rnnt_forward(self, eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training, want_logits=True, pred=None):
+    def rnnt_forward(self, eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training, want_logits=True, pred=None,
+                     defer_lattice=False):
         """-> (loss_rnnt 0-dim, logits [B,T,U,V] (None on the fused path: want_logits=False), stash)
         pred: the prediction network's output for this micro-batch, [U, B, H] time-major, when it was computed for several
-        micro-batches at once (rnnt_prediction_stacked); rnnt_backward then leaves its gradient in st.ddouts"""
+        micro-batches at once (rnnt_prediction_stacked); rnnt_backward then leaves its gradient in st.ddouts
+        defer_lattice (fused output layer only): the lattice runs on a side stream and the first value returned is None; the
+        caller does other work of the micro-batch (the auxiliary CTC branch), then calls rnnt_lattice_join(st) -> loss"""
         with ops.stream_scope():
             A, J = self.arena, self.r_J
             B, T, d = eouts.shape
             dev = eouts.device
             U = ys_in.shape[1]
+            lat_pending = None
             if pred is not None:
                 assert tuple(pred.shape) == (U, B, self.r_H) and pred.is_contiguous(), (pred.shape, (U, B, self.r_H))
                 douts, rst = pred, None
@@ -1419,13 +1423,31 @@ class _RNNTMixin:
                 # the output layer reduced in the GEMM's epilogue (csrc/gemm_big.hip): soft-max partials + the blank / label logits of
                 # every lattice cell; the [B,T,U,V] logits (0.9 GB per micro-batch at the L4 sizes) are never formed
                 logits = None
-                ctx, nll = ops.rnnt_head_forward(h.view(B * T * U, J), w_out, A.p("decoder.output.bias"), B, T, U, labels,
-                                                 elens_dev, ylens, blank)
+                if defer_lattice and os.environ.get("EMOASR_RNNT_LATTICE_SIDE", "1") != "0":
+                    if getattr(self, "_lat_stream", None) is None:
+                        self._lat_stream = torch.cuda.Stream(device=dev)
+                    ctx, nll, ev, keep = ops.rnnt_head_forward(h.view(B * T * U, J), w_out, A.p("decoder.output.bias"), B, T, U,
+                                                               labels, elens_dev, ylens, blank, lattice_stream=self._lat_stream)
+                    lat_pending = (ev, keep)
+                else:
+                    ctx, nll = ops.rnnt_head_forward(h.view(B * T * U, J), w_out, A.p("decoder.output.bias"), B, T, U, labels,
+                                                     elens_dev, ylens, blank)
             st = _Stash()
             st.rst, st.douts, st.h, st.logits, st.ctx, st.nll = rst, douts, h, logits, ctx, nll
             st.labels, st.elens, st.ylens, st.blank, st.eouts = labels, elens_dev, ylens, blank, eouts
             st.B, st.T, st.U = B, T, U
+            if lat_pending is not None:
+                st.lat_pending = lat_pending
+                return None, logits, st
             return nll.mean(), logits, st
+
+    def rnnt_lattice_join(self, st):
+        """the loss of a rnnt_forward(..., defer_lattice=True) call: the calling stream waits for the side stream's lattice"""
+        pend = getattr(st, "lat_pending", None)
+        if pend is not None:
+            torch.cuda.current_stream().wait_event(pend[0])
+            st.lat_pending = None
+        return st.nll.mean()
 
     def rnnt_backward(self, st, gscale_dev, extra_dlogits=None):
         """-> d_eouts [B,T,d]; accumulates decoder gradients (the logits buffer is overwritten by its gradient).

@@ -360,13 +360,17 @@ class _RNNTFn(torch.autograd.Function):
         from ..criteria import rnnt_word_rows
         # the 4-D logits are formed only when something reads them: distillation, or a caller that asked for them
         # (RNNTDecoder.return_logits); training without either runs the fused output layer and returns logits = None
+        # with an auxiliary CTC branch the transducer lattice (2 B blocks, ~190 us of a mostly idle chip) runs on a side stream under it
         loss_rnnt, logits, st = eng.rnnt_forward(eouts, elens_dev, ys_in, ys_host, ylens_host, blank, training,
                                                  want_logits=want_logits or kd is not None,
-                                                 pred=None if pred is None else pred.detach())
+                                                 pred=None if pred is None else pred.detach(),
+                                                 defer_lattice=eng.mtl_ctc > 0)
         cctx, loss = None, loss_rnnt
         if eng.mtl_ctc > 0:
             ctc_logits = eng.head_logits(eouts, "decoder.ctc.output")
             loss_ctc, cctx = eng.ctc_loss(ctc_logits, elens_dev, ys_host, ylens_host, blank, True)
+            if loss_rnnt is None:
+                loss_rnnt = eng.rnnt_lattice_join(st)
             loss = loss_rnnt + eng.mtl_ctc * loss_ctc
         else:
             loss_ctc = torch.zeros_like(loss_rnnt)

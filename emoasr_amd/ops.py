@@ -858,9 +858,12 @@ def rnnt_forward(logits, labels, elens, ylens, blank):
     return (lse, lpb, lpy, alpha, beta), nll
 
 
-def rnnt_head_forward(h, w, bias, B, T, U, labels, elens, ylens, blank):
+def rnnt_head_forward(h, w, bias, B, T, U, labels, elens, ylens, blank, lattice_stream=None):
     """the transducer's output layer + loss lattice WITHOUT the [B,T,U,V] logits: h [B*T*U, J] (bf16), w [V, J]
-    -> ctx tuple (lse, lpb, lpy, alpha, beta) f32 [B,T,U], nll f32 [B]   (as rnnt_forward)"""
+    -> ctx tuple (lse, lpb, lpy, alpha, beta) f32 [B,T,U], nll f32 [B]   (as rnnt_forward)
+    lattice_stream: a torch side stream for the fold + lattice launches (2 B blocks of one wave row each: ~190 us of a mostly
+    idle chip); -> (ctx, nll, event, keep) then -- the caller waits for `event` on its own stream before it reads ctx / nll and
+    holds `keep` (scratch the side stream still reads) until then"""
     N, J = h.shape
     V = w.shape[0]
     dev = h.device
@@ -877,6 +880,16 @@ def rnnt_head_forward(h, w, bias, B, T, U, labels, elens, ylens, blank):
         lib.call("emoasr_rnnt_head_fwd", dt(h), r0, n, T, U, V, J, labels.shape[1], _p(h[r0:r0 + n]), _p(w), _p(bias), _p(labels),
                  _p(ylens), blank, _p(part), N, _p(zb.view(-1)[r0:r0 + n]), _p(zy.view(-1)[r0:r0 + n]), _p(ycol[r0:r0 + n]), _stream())
     nll = torch.empty(B, device=dev, dtype=torch.float32)
+    if lattice_stream is not None:
+        main = torch.cuda.current_stream()
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        lattice_stream.wait_event(ev0)
+        lib.call("emoasr_rnnt_forward_parts", B, T, U, V, _p(part), _p(elens), _p(ylens), _p(lse), _p(zb), _p(zy), _p(alpha),
+                 _p(beta), _p(nll), c_void_p(lattice_stream.cuda_stream))
+        ev1 = torch.cuda.Event()
+        ev1.record(lattice_stream)
+        return (lse, zb, zy, alpha, beta), nll, ev1, (part, ycol)
     lib.call("emoasr_rnnt_forward_parts", B, T, U, V, _p(part), _p(elens), _p(ylens), _p(lse), _p(zb), _p(zy), _p(alpha),
              _p(beta), _p(nll), _stream())
     return (lse, zb, zy, alpha, beta), nll
