@@ -859,7 +859,12 @@ def main():
             res["logmel"] = {"frames_per_s": fb, "train_frames_per_s_with_logmel":
                              sum(sum(b.xlens) for grp in sub[1:] for b in grp) / (time.perf_counter() - t0),
                              "steps": len(sub) - 1}
+            # (the secondary legs start from an empty caching allocator: the blocks the L2 legs left behind fragment the
+            # pool the transducer step's 0.3-1 GB tensors are carved from)
+            del wavs, sub
+            torch.cuda.empty_cache()
             res["l4_rnnt"] = l4_rnnt(dev, dtype)
+            torch.cuda.empty_cache()
             if args.dtype == "bf16":
                 res.update(parity_mode(dev, [b for grp in batches for b in grp]))
         if world == 1 and not args.no_cpu_baseline:
