@@ -43,6 +43,10 @@ int emoasr_version(void);
 int emoasr_experimental(void);
 /* options: "tr_read" (1 = ds_read_b64_tr_b16 operand reads, 0 = scalar fallback); tuning: "gemm_tile", "gemm_kb",
  * "gemm_xcd", "gemm_wholek", "tn_group_blocks", "tn_group_kb", "tn_place", "attn_lpt", "attn_xcd", "attn_fwd_waves", "attn_fwd_split", "attn_fw" (key tiles per workgroup of the single-pass attention backward: 2, 4, 0 = auto);
+ * round 4: "attn_bwd_split", "attn_side", "ffn_save_dact", "big_n256" (long reductions onto one / two 256-column tiles on the
+ * large-tile kernel: 0 off, 1 = N 512 from K 512 and N 256 from K 2048, 2 = N 256 from K 512 as well), "big_waves" (8 / 4),
+ * "big_bm", "big_min_tiles", "gemm_wide128", "ln_fwd8", "ln_bwd_pf", "ln_bwd_blocks", "conv1_pair", "lstm_coop", "decode_coop",
+ * "rnnt_greedy_coop" -- every default is what the training step (or the decode leg) measured fastest;
  * "timers" (see emoasr_timer_read) */
 int emoasr_set_option(const char* name, int value);
 /* Device time of selected kernels that sit behind composite entry points, measured with HIP events on the launch stream
