@@ -207,6 +207,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 #endif
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+// tanh on the hardware exp / rcp units: 1 - 2 / (exp(2x) + 1) (inf for large x -> 1, 0 for very negative x -> -1; relative error
+// ~1e-6).  tanhf's library expansion is ~30 instructions with a division: the LSTM cells take two per (sequence, unit) and position
+// on the recurrence's critical path.
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 __device__ __forceinline__ float dswishf_(float x) {
   const float s = sigmoidf_(x);
   return s * (1.f + x * (1.f - s));

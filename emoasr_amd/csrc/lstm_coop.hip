@@ -153,12 +153,12 @@ __global__ __launch_bounds__(LT) void lstm_seq_fwd_kernel(const LstmFwdArgs a) {
         float z[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) z[q] = rbf(pv[o][q] + (hprev ? gat[(q * 64 + m) * 17 + n] : 0.f));   // the chain's GEMM output was bf16
-        const float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), gg = tanhf(z[2]), og = sigmoidf_(z[3]);
+        const float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), gg = tanh_fast(z[2]), og = sigmoidf_(z[3]);
         const float cn = fg * c_reg[o] + ig * gg;
         c_reg[o] = cn;
         const long row = (long)u * Bs + m0 + m;
         a.cseq[row * H + 16 * g + n] = cn;
-        a.hseq[row * H + 16 * g + n] = (bf16)(og * tanhf(cn));
+        a.hseq[row * H + 16 * g + n] = (bf16)(og * tanh_fast(cn));
         bf16* ga = a.gact + row * 4 * H + 16 * g + n;
         ga[0] = (bf16)ig; ga[H] = (bf16)fg; ga[2 * H] = (bf16)gg; ga[3 * H] = (bf16)og;
       }
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
           dh += acc;
         }
         const float ig = gv[o][0], fg = gv[o][1], gg = gv[o][2], og = gv[o][3];
-        const float tc = tanhf(cu[o]);
+        const float tc = tanh_fast(cu[o]);
         const float dct = dc_reg[o] + dh * og * (1.f - tc * tc);
         const bf16 d0 = (bf16)(dct * gg * ig * (1.f - ig)), d1 = (bf16)(dct * cp[o] * fg * (1.f - fg));
         const bf16 d2 = (bf16)(dct * ig * (1.f - gg * gg)), d3 = (bf16)(dh * tc * og * (1.f - og));
