@@ -739,17 +739,31 @@ def main():
         # replicas apply the SAME reduced gradient with the same fused Adam -- the parameters must be bit-identical on all ranks
         # after the timed steps (a checksum over the raw bits of the flat f32 arena + its f64 sum, gathered from every rank)
         flat = eng.arena.flat
-        bits = flat.view(torch.int32).to(torch.int64).sum()
+        # bit identity is decided element by element: rank 0's arena is broadcast and every rank counts the words that differ
+        ref0 = flat.clone()
+        dist.broadcast(ref0, 0)
+        ndiff = (flat.view(torch.int32) != ref0.view(torch.int32)).sum().to(torch.int64)
+        dist.all_reduce(ndiff, op=dist.ReduceOp.SUM)
+        del ref0
+        # reported checksum: position-weighted wrap-around sum of the raw words, gathered as int64 (no float round trip)
+        words = flat.view(torch.int32).to(torch.int64)
+        weight = torch.arange(words.numel(), device=dev, dtype=torch.int64) % 65521 + 1
+        bits = (words * weight).sum()
+        mine_i = torch.stack([bits])
+        alli = [torch.zeros_like(mine_i) for _ in range(world)]
+        dist.all_gather(alli, mine_i)
+        alli = torch.stack(alli).cpu()
         mine = torch.stack([torch.tensor(float(sum(sum(b.xlens) for grp in batches[args.warmup:] for b in grp)), device=dev,
-                                         dtype=torch.float64), bits.to(torch.float64), flat.double().sum()])
+                                         dtype=torch.float64), flat.double().sum()])
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         allr = torch.stack(allr).cpu()
         dp_info = {"backend": dist.get_backend(), "nranks": dist.get_world_size(),
                    "one_gpu_rehearsal": os.environ.get("EMOASR_BENCH_ONE_GPU") == "1",
                    "frames_per_rank": [float(v) for v in allr[:, 0]],
-                   "param_bits_checksum": [int(v) for v in allr[:, 1]], "param_sum": [float(v) for v in allr[:, 2]],
-                   "params_identical_across_ranks": bool((allr[:, 1] == allr[0, 1]).all() and (allr[:, 2] == allr[0, 2]).all()),
+                   "param_bits_checksum": [int(v) for v in alli[:, 0]], "param_sum": [float(v) for v in allr[:, 1]],
+                   "param_words_differing_from_rank0": int(ndiff.item()),
+                   "params_identical_across_ranks": bool(int(ndiff.item()) == 0 and (alli[:, 0] == alli[0, 0]).all()),
                    "overlapped_allreduce": buckets is not None,
                    "note": "no scaling value has been measured on multi-GPU hardware by the builder: the driver's SCALE run is the "
                            "only N > 1 execution over RCCL / xGMI"}

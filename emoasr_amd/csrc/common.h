@@ -200,19 +200,34 @@ __device__ __forceinline__ emo_f2 emo_mac2(emo_f2 a, emo_f2 b, emo_f2 c) { retur
 // ---------------------------------------------------------------------------
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (div_scale x2, rcp, 6 fma / mul, div_fmas, div_fixup: 11 VALU operations
 // per value -- the Swish epilogue of the first feed-forward product and the GLU / Swish staging of the convolution kernels take one
-// sigmoid per element)
+// sigmoid per element).  The hardware forms serve the bf16 instantiations ONLY: the f32 engine is the parity mode and keeps the
+// IEEE division and the library tanhf (sigmoid_t / tanh_t / swish_t / dswish_t below pick by the kernel's element type).
 #ifdef EMO_SIGMOID_IEEE_DIV   // A/B builds only (python -m emoasr_amd.build --variant div -DEMO_SIGMOID_IEEE_DIV)
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 #else
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 #endif
+__device__ __forceinline__ float sigmoid_exact(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
-// tanh on the hardware exp / rcp units: 1 - 2 / (exp(2x) + 1) (inf for large x -> 1, 0 for very negative x -> -1; relative error
-// ~1e-6).  tanhf's library expansion is ~30 instructions with a division: the LSTM cells take two per (sequence, unit) and position
-// on the recurrence's critical path.
+// tanh on the hardware exp / rcp units: 1 - 2 / (exp(2x) + 1) (inf for large x -> 1, 0 for very negative x -> -1).  ABSOLUTE error
+// ~1e-7 (the subtraction cancels near 0: the relative error there is ~1e-7 / |x|), which is below bf16's rounding and not good
+// enough for a parity claim: bf16 kernels only.  tanhf's library expansion is ~30 instructions with a division: the LSTM cells
+// take two per (sequence, unit) and position on the recurrence's critical path.
 __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 __device__ __forceinline__ float dswishf_(float x) {
   const float s = sigmoidf_(x);
+  return s * (1.f + x * (1.f - s));
+}
+// element-type dispatch: float -> exact forms, bf16 -> hardware forms
+template <typename T> __device__ __forceinline__ float sigmoid_t(float x) {
+  if constexpr (sizeof(T) == 4) return sigmoid_exact(x); else return sigmoidf_(x);
+}
+template <typename T> __device__ __forceinline__ float tanh_t(float x) {
+  if constexpr (sizeof(T) == 4) return tanhf(x); else return tanh_fast(x);
+}
+template <typename T> __device__ __forceinline__ float swish_t(float x) { return x * sigmoid_t<T>(x); }
+template <typename T> __device__ __forceinline__ float dswish_t(float x) {
+  const float s = sigmoid_t<T>(x);
   return s * (1.f + x * (1.f - s));
 }
 
@@ -229,16 +244,18 @@ __device__ __forceinline__ float dgeluf_(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
+template <typename T = bf16>
 __device__ __forceinline__ float apply_act(int act, float x) {
   if (act == EMO_ACT_RELU) return fmaxf(x, 0.f);
-  if (act == EMO_ACT_SWISH) return swishf_(x);
+  if (act == EMO_ACT_SWISH) return swish_t<T>(x);
   if (act == EMO_ACT_GELU) return geluf_(x);
   if (act == EMO_ACT_TANH) return tanhf(x);
   return x;
 }
+template <typename T = bf16>
 __device__ __forceinline__ float apply_dact(int act, float pre) {
   if (act == EMO_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
-  if (act == EMO_ACT_SWISH) return dswishf_(pre);
+  if (act == EMO_ACT_SWISH) return dswish_t<T>(pre);
   if (act == EMO_ACT_GELU) return dgeluf_(pre);
   if (act == EMO_ACT_TANH) { const float t = tanhf(pre); return 1.f - t * t; }
   if (act == EMO_DACT_TANH_OUT) return 1.f - pre * pre;  // `pre` holds tanh's OUTPUT here
@@ -250,7 +267,7 @@ __device__ __forceinline__ float apply_dact(int act, float pre) {
 // apply_act / apply_dact per element inside an unrolled loop makes the compiler emit the whole
 // compare-and-branch ladder (with the erf / tanh / exp expansions behind it) once per element: the GEMM
 // epilogue was ~12 000 instructions and ~900 scalar branches long, most of a K = 256 tile's time.
-template <int N>
+template <int N, typename T = bf16>
 __device__ __forceinline__ void act_vec(int act, float (&v)[N]) {
   switch (act) {
     case EMO_ACT_RELU:
@@ -259,7 +276,7 @@ __device__ __forceinline__ void act_vec(int act, float (&v)[N]) {
       break;
     case EMO_ACT_SWISH:
 #pragma unroll
-      for (int e = 0; e < N; ++e) v[e] = swishf_(v[e]);
+      for (int e = 0; e < N; ++e) v[e] = swish_t<T>(v[e]);
       break;
     case EMO_ACT_GELU:
 #pragma unroll 1
@@ -273,7 +290,7 @@ __device__ __forceinline__ void act_vec(int act, float (&v)[N]) {
   }
 }
 // v[e] *= act'(pre[e])   (EMO_DACT_TANH_OUT: pre holds tanh's output)
-template <int N>
+template <int N, typename T = bf16>
 __device__ __forceinline__ void dact_vec(int act, const float (&pre)[N], float (&v)[N]) {
   switch (act) {
     case EMO_ACT_RELU:
@@ -282,7 +299,7 @@ __device__ __forceinline__ void dact_vec(int act, const float (&pre)[N], float (
       break;
     case EMO_ACT_SWISH:
 #pragma unroll
-      for (int e = 0; e < N; ++e) v[e] *= dswishf_(pre[e]);
+      for (int e = 0; e < N; ++e) v[e] *= dswish_t<T>(pre[e]);
       break;
     case EMO_DACT_MUL:
 #pragma unroll
@@ -390,12 +407,12 @@ __device__ __forceinline__ void dropout_mult8(uint64_t seed, uint64_t idx0, floa
   }
 }
 // v <- act(v), d <- act'(v) in one go (Swish: one sigmoid for both)
-template <int N>
+template <int N, typename T = bf16>
 __device__ __forceinline__ void act_dact_vec(int act, float (&v)[N], float (&d)[N]) {
   if (act == EMO_ACT_SWISH) {
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-      const float s = sigmoidf_(v[e]), a = v[e] * s;
+      const float s = sigmoid_t<T>(v[e]), a = v[e] * s;
       d[e] = s + a * (1.f - s);
       v[e] = a;
     }
@@ -403,8 +420,8 @@ __device__ __forceinline__ void act_dact_vec(int act, float (&v)[N], float (&d)[
   }
 #pragma unroll
   for (int e = 0; e < N; ++e) d[e] = 1.f;
-  dact_vec<N>(act, v, d);
-  act_vec<N>(act, v);
+  dact_vec<N, T>(act, v, d);
+  act_vec<N, T>(act, v);
 }
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for every outstanding global

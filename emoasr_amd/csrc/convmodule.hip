@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(long n, int C, const 
     // stacked micro-batches: the statistics of the row's segment ([n, C] tables)
     const long so = sg.n > 1 ? (long)rowsegs_of_row(sg, i / C) * C : 0;
     const float xh = (to_f32(y[i]) - mean[so + c]) * rsqrtf(var[so + c] + eps);
-    z[i] = from_f32<T>(swishf_(gamma[c] * xh + beta[c]));
+    z[i] = from_f32<T>(swish_t<T>(gamma[c] * xh + beta[c]));
   }
 }
 // C % 8 == 0: eight channels of one row per thread and pass, 16-byte accesses (the element-wise form above ran at 1.4 TB/s);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void bn_swish_fwd8_kernel(long n8, int C, cons
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = (v[j] - mean[so + c + j]) * rsqrtf(var[so + c + j] + eps);
-      v[j] = swishf_(gamma[c + j] * xh + beta[c + j]);
+      v[j] = swish_t<T>(gamma[c + j] * xh + beta[c + j]);
     }
     store8<T>(z + i * 8, v);
   }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(int M, int C, const T*
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = (yv[j] - mu[j]) * is[j];
-      const float dbn = dv[j] * dswishf_(g[j] * xh + bt[j]);
+      const float dbn = dv[j] * dswish_t<T>(g[j] * xh + bt[j]);
       s1[j] += dbn; s2[j] += dbn * xh;
     }
   }
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int C, const T
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = (yv[j] - mu[j]) * is[j];
-      const float dbn = dv[j] * dswishf_(g[j] * xh + bt[j]);
+      const float dbn = dv[j] * dswish_t<T>(g[j] * xh + bt[j]);
       o[j] = g[j] * is[j] * (dbn - m1[j] - xh * m2[j]);
     }
     if (ok) store8<T>(dy + (long)r * C + c, o);

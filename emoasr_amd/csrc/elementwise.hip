@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(long n, int C, const T* __
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const long m = i / C; const int c = i % C;
     const float a = to_f32(in[m * 2 * C + c]), g = to_f32(in[m * 2 * C + C + c]);
-    out[i] = from_f32<T>(a * sigmoidf_(g));
+    out[i] = from_f32<T>(a * sigmoid_t<T>(g));
   }
 }
 template <typename T>
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(long n, int C, const T* __
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const long m = i / C; const int c = i % C;
     const float a = to_f32(in[m * 2 * C + c]), g = to_f32(in[m * 2 * C + C + c]);
-    const float s = sigmoidf_(g), d = to_f32(dout[i]);
+    const float s = sigmoid_t<T>(g), d = to_f32(dout[i]);
     din[m * 2 * C + c] = from_f32<T>(d * s);
     din[m * 2 * C + C + c] = from_f32<T>(d * a * s * (1.f - s));
   }

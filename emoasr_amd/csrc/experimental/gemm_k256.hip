@@ -296,6 +296,7 @@ bool emo_gemm_nt_k256_wants(int M, int N, int K, long lda, long ldb, long ldc, c
   if (lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ep.out_f32) return false;
   if (ep.residual && ep.ldr % 8 != 0) return false;
   if (ep.residual && ep.dact_pre) return false;   // (one read-back operand per element: see the kernel)
+  if ((ep.act & EMO_ACT_SAVE_DACT) || ep.dact == EMO_DACT_MUL) return false;   // (the saved-factor epilogue is not built here)
   if ((long)M * lda * 2 >= (1L << 32)) return false;   // (the DMA descriptor's 32-bit offsets)
   return true;
 }

@@ -418,18 +418,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
         if (ep.act & EMO_ACT_SAVE_DACT) {
           // the saved tensor is the backward's factor act'(pre) * dropout_scale, not the pre-activation
           float dd[8], mm[8];
-          act_dact_vec<8>(ep.act & 0xFF, v, dd);
+          act_dact_vec<8, T>(ep.act & 0xFF, v, dd);
           dropout_mult8(ep.seed, (uint64_t)row * (uint64_t)g.N + col, ep.drop_p, mm);
 #pragma unroll
           for (int e = 0; e < 8; ++e) { v[e] *= mm[e]; dd[e] *= mm[e]; }
           if (pre_out) store8<T>(pre_out + off, dd);
         } else {
         if (pre_out) store8<T>(pre_out + off, v);
-        act_vec<8>(ep.act, v);
+        act_vec<8, T>(ep.act, v);
         if (dpre) {
           float d[8];
           raw8(pf_dpre[pass], d);
-          dact_vec<8>(ep.dact, d, v);
+          dact_vec<8, T>(ep.dact, d, v);
         }
         // (vec_ok: N % 8 == 0 and col % 8 == 0, so the 8 mask indices start at an even one)
         dropout_apply8(ep.seed, (uint64_t)row * (uint64_t)g.N + col, ep.drop_p, v);
@@ -451,9 +451,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
         for (int e = 0; e < 8 && col + e < g.N; ++e) {
           float x = ep.alpha * v[e] + (ep.bias ? ep.bias[col + e] : 0.f);
           const float msc = ep.drop_p > 0.f ? dropout_scale(ep.seed, (uint64_t)row * (uint64_t)g.N + col + e, ep.drop_p) : 1.f;
-          if (pre_out) pre_out[off + e] = from_f32<T>((ep.act & EMO_ACT_SAVE_DACT) ? apply_dact(ep.act & 0xFF, x) * msc : x);
-          x = apply_act(ep.act & 0xFF, x);
-          if (dpre) x *= apply_dact(ep.dact, to_f32(dpre[off + e]));
+          if (pre_out) pre_out[off + e] = from_f32<T>((ep.act & EMO_ACT_SAVE_DACT) ? apply_dact<T>(ep.act & 0xFF, x) * msc : x);
+          x = apply_act<T>(ep.act & 0xFF, x);
+          if (dpre) x *= apply_dact<T>(ep.dact, to_f32(dpre[off + e]));
           x *= msc;
           if (res) x = to_f32(res[(g.nh > 0 ? c_base : 0) + (long)row * ep.ldr + col + e]) + ep.res_scale * x;
           if (ep.out_f32) static_cast<float*>(g.C)[off + e] = x;

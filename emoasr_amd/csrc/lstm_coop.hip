@@ -331,11 +331,30 @@ long lstm_capacity(const void* kernel, size_t smem) {
 
 void emo_lstm_set_coop(int v) { g_lstm_coop = v; }
 
-// Can the cooperative recurrence take this layer?  (bf16, B <= 8 groups of 64, H a multiple of 32 up to 512)
+// dynamic LDS of the two kernels, and the workgroups of each the device holds at once (attribute set + occupancy query, cached per
+// size; 0 = the query failed).  emoasr_lstm_seq_supported and the two launches share these, so "supported" and the launch-time
+// residency check cannot disagree.
+static size_t lstm_fwd_smem(int H) { return (size_t)2 * 64 * (H + 8) * 2 + 4 * 64 * 17 * 4; }
+static size_t lstm_bwd_smem(int H) { return (size_t)(H + 64) * 72 * 2; }
+static long lstm_cap_of(int which, int H) {
+  static size_t set_bytes[2] = {0, 0}, cap_bytes[2] = {0, 0};
+  static long cap[2] = {0, 0};
+  const void* k = which ? (const void*)lstm_seq_bwd_kernel : (const void*)lstm_seq_fwd_kernel;
+  const size_t smem = which ? lstm_bwd_smem(H) : lstm_fwd_smem(H);
+  if (smem > set_bytes[which]) {
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 0;
+    set_bytes[which] = smem;
+  }
+  if (smem != cap_bytes[which]) { cap[which] = lstm_capacity(k, smem); cap_bytes[which] = smem; }
+  return cap[which];
+}
+
+// Can the cooperative recurrence take this layer?  (bf16, B <= 8 groups of 64, H a multiple of 32 up to 512, and every group's
+// workgroups of BOTH kernels resident together by the occupancy query -- the same numbers the launches check)
 extern "C" int emoasr_lstm_seq_supported(int dtype, int B, int H) {
   if (!(g_lstm_coop && dtype == EMO_BF16 && B >= 1 && B <= L_MAXB * L_MAXGRP && H % 32 == 0 && H >= 32 && H <= L_MAXH)) return 0;
-  // one workgroup per CU (the forward's 150 KB of LDS): all groups' workgroups must be resident together
-  return B <= L_MAXB || (long)lstm_groups(B) * (H / 16) <= lstm_cus();
+  const long need = (long)lstm_groups(B) * (H / 16);
+  return lstm_cap_of(0, H) >= need && lstm_cap_of(1, H) >= need;
 }
 
 // hseq[u], cseq[u], gact[u] for u = 0 .. U - 1 from pre[u] = x_u . W_ih^T + b (bf16 [U][B][4H]) and the recurrent weights
@@ -349,16 +368,8 @@ extern "C" int emoasr_lstm_seq_fwd(int dtype, int U, int B, int H, const void* p
   a.hseq = (bf16*)hseq; a.cseq = cseq; a.gact = (bf16*)gact;
   a.counter = lstm_counter(0, &a.err);
   EMO_CHECK(a.counter, "lstm_seq_fwd: counter allocation failed");
-  const size_t smem = (size_t)2 * 64 * (H + 8) * 2 + 4 * 64 * 17 * 4;
-  static size_t set_bytes = 0;
-  if (smem > set_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    EMO_CHECK(e == hipSuccess, "lstm_seq_fwd: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
-    set_bytes = smem;
-  }
-  static long cap = 0;
-  static size_t cap_bytes = 0;
-  if (smem != cap_bytes) { cap = lstm_capacity((const void*)lstm_seq_fwd_kernel, smem); cap_bytes = smem; }
+  const size_t smem = lstm_fwd_smem(H);
+  const long cap = lstm_cap_of(0, H);
   const int ngrp = lstm_groups(B);
   a.G = H / 16;
   EMO_CHECK(cap >= (long)a.G * ngrp, "lstm_seq_fwd: the device holds %ld of the %d workgroups at once", cap, a.G * ngrp);
@@ -384,16 +395,8 @@ extern "C" int emoasr_lstm_seq_bwd(int dtype, int U, int B, int H, const void* d
   a.dgp = (bf16*)dgp; a.part = (float*)ws;
   a.counter = lstm_counter(1, &a.err);
   EMO_CHECK(a.counter, "lstm_seq_bwd: counter allocation failed");
-  const size_t smem = (size_t)(H + 64) * 72 * 2;
-  static size_t set_bytes = 0;
-  if (smem > set_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    EMO_CHECK(e == hipSuccess, "lstm_seq_bwd: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
-    set_bytes = smem;
-  }
-  static long cap = 0;
-  static size_t cap_bytes = 0;
-  if (smem != cap_bytes) { cap = lstm_capacity((const void*)lstm_seq_bwd_kernel, smem); cap_bytes = smem; }
+  const size_t smem = lstm_bwd_smem(H);
+  const long cap = lstm_cap_of(1, H);
   const int ngrp = lstm_groups(B);
   a.G = H / 16;
   EMO_CHECK(cap >= (long)a.G * ngrp, "lstm_seq_bwd: the device holds %ld of the %d workgroups at once", cap, a.G * ngrp);

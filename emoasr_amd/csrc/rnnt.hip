@@ -22,11 +22,11 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(int B, int H, const 
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int b = i / H, j = i % H;
     const T* g4 = gp + (long)b * 4 * H;
-    const float ig = sigmoidf_(to_f32(g4[j])), fg = sigmoidf_(to_f32(g4[H + j]));
-    const float gg = tanh_fast(to_f32(g4[2 * H + j])), og = sigmoidf_(to_f32(g4[3 * H + j]));
+    const float ig = sigmoid_t<T>(to_f32(g4[j])), fg = sigmoid_t<T>(to_f32(g4[H + j]));
+    const float gg = tanh_t<T>(to_f32(g4[2 * H + j])), og = sigmoid_t<T>(to_f32(g4[3 * H + j]));
     const float cn = fg * (c_prev ? c_prev[i] : 0.f) + ig * gg;
     c[i] = cn;
-    h[(long)b * ldh + j] = from_f32<T>(og * tanh_fast(cn));
+    h[(long)b * ldh + j] = from_f32<T>(og * tanh_t<T>(cn));
     T* a4 = ga + (long)b * 4 * H;
     a4[j] = from_f32<T>(ig); a4[H + j] = from_f32<T>(fg); a4[2 * H + j] = from_f32<T>(gg); a4[3 * H + j] = from_f32<T>(og);
   }
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(int B, int H, const 
     const float ig = to_f32(a4[j]), fg = to_f32(a4[H + j]), gg = to_f32(a4[2 * H + j]), og = to_f32(a4[3 * H + j]);
     float dh = to_f32(dh_out[(long)b * lddh + j]);
     if (dh_rec) dh += to_f32(dh_rec[i]);
-    const float tc = tanh_fast(c[i]);
+    const float tc = tanh_t<T>(c[i]);
     const float dct = dc[i] + dh * og * (1.f - tc * tc);
     const float cp = c_prev ? c_prev[i] : 0.f;
     T* d4 = dgp + (long)b * 4 * H;

@@ -210,10 +210,10 @@ __global__ __launch_bounds__(GT) void rnnt_greedy_kernel(const GreedyArgs a) {
       }
       __syncthreads();
       if (tid < nu) {
-        const float ig = sigmoidf_(red[tid]), fg = sigmoidf_(red[nu + tid]), gg = tanh_fast(red[2 * nu + tid]), og = sigmoidf_(red[3 * nu + tid]);
+        const float ig = sigmoid_t<T>(red[tid]), fg = sigmoid_t<T>(red[nu + tid]), gg = tanh_t<T>(red[2 * nu + tid]), og = sigmoid_t<T>(red[3 * nu + tid]);
         const float cn = fg * cL[l * nu + tid] + ig * gg;
         cL[l * nu + tid] = cn;
-        put64(hx + (long)l * H + u0 + tid, __float_as_uint(rnd<T>(og * tanh_fast(cn))), nlab);
+        put64(hx + (long)l * H + u0 + tid, __float_as_uint(rnd<T>(og * tanh_t<T>(cn))), nlab);
       }
       __syncthreads();   // (red and hprev are rewritten below)
       fetch(hprev, hx + (long)l * H, H, nlab);  // the layer's new hidden state, all units (layer 1 reads it as its input next)
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(GT) void rnnt_greedy_kernel(const GreedyArgs a) {
       for (int k = 0; k < 4; ++k) enext[k] = tid + k * GT < J ? to_f32(en[tid + k * GT]) : 0.f;
     }
     // ---- joint: h = round(tanh(e_t + g)); the own rows of the output product; arg-max candidates -------------------------------
-    for (int i = tid; i < J; i += GT) hj[i] = rnd<T>(tanh_fast(etL[i] + gL[i]));
+    for (int i = tid; i < J; i += GT) hj[i] = rnd<T>(tanh_t<T>(etL[i] + gL[i]));
     __syncthreads();
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int r0 = 0; r0 < nv; r0 += 32) {

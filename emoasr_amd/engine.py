@@ -1621,17 +1621,17 @@ class _RNNTMixin:
             aligns.append(align[:na].tolist())
         return hyps, aligns
 
-    def rnnt_beam_search(self, eouts, beam_width, blank, eos, num_expands=3):
+    def rnnt_beam_search(self, eouts, beam_width, blank, eos, num_expands=3, return_scores=False):
         """alignment-length synchronous beam search for ONE utterance (rnn_transducer.py:242-325,348-359): the expansion round as a
         replayed HIP graph (_rnnt_beam_search_graph) unless EMOASR_RNNT_BEAM_GRAPH=0 or the utterance does not fit its static
-        buffers; then the launch chain below."""
+        buffers; then the launch chain below.  return_scores: (hyps, float64 scores) instead of hyps (tests compare the two forms)."""
         T = eouts.shape[1]
         if (os.environ.get("EMOASR_RNNT_BEAM_GRAPH", "1") != "0" and beam_width <= 16
-                and (T * num_expands + 2) * beam_width + 1 <= self._BEAM_POOL and T <= self._BEAM_TMAX):
-            return self._rnnt_beam_search_graph(eouts, beam_width, blank, eos, num_expands)
-        return self._rnnt_beam_search_chain(eouts, beam_width, blank, eos, num_expands)
+                and (T * num_expands + 2) * beam_width + 1 <= self._BEAM_POOL - 16 and T <= self._BEAM_TMAX):
+            return self._rnnt_beam_search_graph(eouts, beam_width, blank, eos, num_expands, return_scores)
+        return self._rnnt_beam_search_chain(eouts, beam_width, blank, eos, num_expands, return_scores)
 
-    _BEAM_POOL, _BEAM_TMAX = 32768, 4096
+    _BEAM_POOL, _BEAM_TMAX = 32768, 4096   # (the pool's last 16 slots are the warm-up's scratch, never a hypothesis's)
 
     def _rnnt_beam_round_graph(self, beam_width, nb, blank):
         """the device work of ONE expansion round over nb live hypotheses, captured once as a HIP graph over static buffers:
@@ -1674,6 +1674,12 @@ class _RNNTMixin:
                 st.out[:nb, 1:1 + beam_width].copy_(vals)
                 st.out[:nb, 1 + beam_width:1 + 2 * beam_width].copy_(idx)
 
+        # the warm-up runs the body for real: give it control words of its own -- label 0, the zero state of slot 0 as source and
+        # the pool's reserved scratch slots as destination -- so that it never writes a slot a live hypothesis reads (the
+        # caller uploads the round's words after this call, before the replay)
+        st.ctl_host.zero_()
+        st.ctl_host[32:32 + 16] = torch.arange(self._BEAM_POOL - 16, self._BEAM_POOL)
+        st.ctl.copy_(st.ctl_host)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -1686,7 +1692,7 @@ class _RNNTMixin:
         st.graphs[key] = g_
         return st, g_
 
-    def _rnnt_beam_search_graph(self, eouts, beam_width, blank, eos, num_expands=3):
+    def _rnnt_beam_search_graph(self, eouts, beam_width, blank, eos, num_expands=3, return_scores=False):
         """the search of rnnt_beam_search with every expansion round's device work replayed from a HIP graph; the bookkeeping
         (stable sort by float64 score, merge of equal label sequences by log-add, cut to the beam) stays on the host, as in the
         reference and in _rnnt_beam_search_chain, whose arithmetic and launch order the captured body repeats."""
@@ -1744,9 +1750,11 @@ class _RNNTMixin:
                     live = merge(grown)[:beam_width]
                 frame_out.sort(key=lambda c: -c[1])
                 beams = merge(frame_out)[:beam_width]
+            if return_scores:
+                return [hyp for hyp, _, _ in beams], [score for _, score, _ in beams]
             return [hyp for hyp, _, _ in beams]
 
-    def _rnnt_beam_search_chain(self, eouts, beam_width, blank, eos, num_expands=3):
+    def _rnnt_beam_search_chain(self, eouts, beam_width, blank, eos, num_expands=3, return_scores=False):
         """alignment-length synchronous beam search for ONE utterance (rnn_transducer.py:242-325,348-359).
 
         eouts [1,T,d].  Per frame up to `num_expands` rounds; each round is one batched prediction-network
@@ -1822,6 +1830,8 @@ class _RNNTMixin:
                     live = merge(grown)[:beam_width]
                 frame_out.sort(key=lambda c: -c[1])
                 beams = merge(frame_out)[:beam_width]
+            if return_scores:
+                return [hyp for hyp, _, _ in beams], [score for _, score, _ in beams]
             return [hyp for hyp, _, _ in beams]
 
 

@@ -150,7 +150,7 @@ def _compare(model, loss, ld, g, case, dtype):
     relv = (norms - want).abs() / (want + floor * want.max())
     rel, worst = relv.max().item(), [n for n, _ in model.named_parameters()][int(relv.argmax())]
     # (f32: 4.9e-3 / 5.3e-3 measured over two library builds, the worst parameter's gradient ~1e-4 of the largest norm)
-    assert rel < (1e-2 if dtype == torch.float32 else 0.25), (rel, worst, norms[int(relv.argmax())].item(), want.max().item())
+    assert rel < (5e-3 if dtype == torch.float32 else 0.25), (rel, worst, norms[int(relv.argmax())].item(), want.max().item())
 
 
 @pytest.mark.parametrize("case", list(KD_CTC_CASES) + list(KD_INTER_CASES))

@@ -151,6 +151,29 @@ def test_beam_search_f32(dev, graph, monkeypatch):
                 assert scores is None and logits is None and aligns is None
 
 
+def test_beam_search_graph_scores_on_fresh_engine(dev):
+    """the graph form's warm-up before each capture must not touch the live LSTM state pool (it once ran the round's body with
+    the PREVIOUS round's control words: slot 0, the zero state, was overwritten): on a FRESH engine, first utterance first and
+    beam widths ascending -- every search captures new graphs -- the per-hypothesis scores equal the launch chain's"""
+    model, g = _build(torch.float32, dev)
+    model.eval()
+    chain_model, _ = _build(torch.float32, dev)
+    chain_model.eval()
+    with torch.no_grad():
+        for b in range(g["xs"].shape[0]):
+            n = int(g["xlens"][b])
+            for bw in (1, 2, 3, 4, 5):
+                outs = []
+                for m, form in ((model, "_rnnt_beam_search_graph"), (chain_model, "_rnnt_beam_search_chain")):
+                    eouts, elens, _ = m.encoder(g["xs"][b:b + 1, :n].to(dev), g["xlens"][b:b + 1])
+                    eng = m.engine()
+                    outs.append(getattr(eng, form)(eouts[:, :int(elens[0])], bw, m.decoder.blank_id, m.decoder.eos_id,
+                                                   return_scores=True))
+                (h_g, s_g), (h_c, s_c) = outs
+                assert h_g == h_c, (b, bw, h_g, h_c)
+                assert max(abs(a - c) for a, c in zip(s_g, s_c)) < 1e-4, (b, bw, s_g, s_c)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_train_loss_and_grads(dev, dtype):
     model, g = _build(dtype, dev)
