@@ -511,26 +511,34 @@ def parity_mode(dev, batches, steps=4, warmup=2):
     logits' range, greedy token agreement.  The f32 engine is what tests/ hold to the oracle at 1e-3 / bit-exact ids."""
     from emoasr_amd.modeling.asr import ASR
     from emoasr_amd.train import ArenaAdam, noam_lr
-    torch.manual_seed(0)
-    m32 = ASR(SimpleNamespace(**L2), compute_dtype=torch.float32).to(dev).train()
-    opt = ArenaAdam(m32.engine().arena, lambda s: noam_lr(OPT["lr"], L2["enc_hidden_size"], OPT["warmup"], s),
-                    weight_decay=OPT["weight_decay"], clip_grad_norm=OPT["clip_grad_norm"])
+    def timed(mode):
+        torch.manual_seed(0)
+        m32 = ASR(SimpleNamespace(**L2), compute_dtype=mode).to(dev).train()
+        opt = ArenaAdam(m32.engine().arena, lambda s: noam_lr(OPT["lr"], L2["enc_hidden_size"], OPT["warmup"], s),
+                        weight_decay=OPT["weight_decay"], clip_grad_norm=OPT["clip_grad_norm"])
 
-    def step(bt):
-        loss, _ = m32(bt.xs, bt.xlens, bt.ys, bt.ylens, None, None)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+        def step(bt):
+            loss, _ = m32(bt.xs, bt.xlens, bt.ys, bt.ylens, None, None)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
 
-    for bt in batches[:warmup]:
-        step(bt)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for bt in batches[warmup:warmup + steps]:
-        step(bt)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    out = {"f32_frames_per_s": sum(sum(b.xlens) for b in batches[warmup:warmup + steps]) / el, "f32_ms_per_step": 1e3 * el / steps}
+        for bt in batches[:warmup]:
+            step(bt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for bt in batches[warmup:warmup + steps]:
+            step(bt)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return sum(sum(b.xlens) for b in batches[warmup:warmup + steps]) / el, 1e3 * el / steps
+
+    f32_fps, f32_ms = timed(torch.float32)
+    x3_fps, x3_ms = timed("f32x3")
+    out = {"f32_frames_per_s": f32_fps, "f32_ms_per_step": f32_ms,
+           # the throughput mode that meets north_star's tolerances: f32 storage, every matrix product as three bf16 MFMAs over
+           # (hi, lo) operand pairs (compute_dtype "f32x3"); one micro-batch per optimizer step, like the f32 leg
+           "parity_mode_frames_per_s": x3_fps, "parity_mode_ms_per_step": x3_ms, "parity_mode": "f32x3"}
     # bf16 vs f32 on identical weights and inputs, no dropout
     cfg0 = dict(L2, dropout_enc_rate=0.0, dropout_attn_rate=0.0)
     torch.manual_seed(0)
@@ -538,11 +546,13 @@ def parity_mode(dev, batches, steps=4, warmup=2):
     sd = {k: v.clone() for k, v in a32.state_dict().items()}
     a16 = ASR(SimpleNamespace(**cfg0), compute_dtype=torch.bfloat16)
     a16.load_state_dict(sd)
-    a32, a16 = a32.to(dev).eval(), a16.to(dev).eval()
+    ax3 = ASR(SimpleNamespace(**cfg0), compute_dtype="f32x3")
+    ax3.load_state_dict(sd)
+    a32, a16, ax3 = a32.to(dev).eval(), a16.to(dev).eval(), ax3.to(dev).eval()
     bt = batches[0]
     res = []
     with torch.no_grad():
-        for m in (a32, a16):
+        for m in (a32, a16, ax3):
             eouts, elens, _ = m.encoder(bt.xs, bt.xlens)
             logits = m.decoder(eouts, elens).float()
             loss, _ = m(bt.xs, bt.xlens, bt.ys, bt.ylens, None, None)
@@ -555,7 +565,7 @@ def parity_mode(dev, batches, steps=4, warmup=2):
         eng16.f32_head = False
         h16_bf16_head = a16.decode(bt.xs, bt.xlens)[0]
         eng16.f32_head = True
-    (l32, z32, h32, el32), (l16, z16, h16, _) = res
+    (l32, z32, h32, el32), (l16, z16, h16, _), (lx3, zx3, hx3, _) = res
     mask = torch.zeros(z32.shape[:2], dtype=torch.bool, device=dev)
     for b, e in enumerate(el32):
         mask[b, :e] = True
@@ -570,6 +580,11 @@ def parity_mode(dev, batches, steps=4, warmup=2):
                                        "logits_rel": float((z16f - z32)[mask].abs().max() / (z32[mask].max() - z32[mask].min()))},
                           "bf16_head_greedy_frame_agreement": float((a1 == a2).float().mean()),
                           "batch": f"B={len(bt.xlens)}, {sum(bt.xlens)} frames, random-init weights, dropout 0"}
+    out["f32x3_vs_f32"] = {"loss_rel": abs(lx3 - l32) / abs(l32),
+                           "logits_rel": float((zx3 - z32)[mask].abs().max() / (z32[mask].max() - z32[mask].min())),
+                           "greedy_frame_agreement": float((a1 == zx3.argmax(-1)[mask]).float().mean()),
+                           "greedy_hyp_exact": float(np.mean([x == y for x, y in zip(h32, hx3)])),
+                           "batch": f"B={len(bt.xlens)}, {sum(bt.xlens)} frames, random-init weights, dropout 0"}
     return out
 
 

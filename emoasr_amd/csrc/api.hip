@@ -22,6 +22,9 @@ void emo_gemm_set_tn_place(int v);
 void emo_gemm_set_wholek(int v);
 void emo_gemm_set_kb(int v);
 void emo_gemm_set_xcd(int v);
+void emo_gemm_set_f32_split(int v);
+void emo_gemm_set_split_tile(int v);
+void emo_gemm_set_split_kb(int v);
 void emo_gemm_set_conv_big(int v);
 void emo_gemm_set_big_bm(int v);
 void emo_gemm_set_big_korder(int v);
@@ -141,6 +144,10 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "gemm_wholek") == 0) { emo_gemm_set_wholek(value); return 0; }
   if (strcmp(name, "gemm_kb") == 0) { emo_gemm_set_kb(value); return 0; }
   if (strcmp(name, "gemm_xcd") == 0) { emo_gemm_set_xcd(value); return 0; }
+  // f32 products (GEMMs, Conv2d, attention) as three bf16 MFMAs over (hi, lo) operand pairs: csrc/gemm.hip SplitCfg
+  if (strcmp(name, "f32_split") == 0) { emo_gemm_set_f32_split(value); return 0; }
+  if (strcmp(name, "split_tile") == 0) { emo_gemm_set_split_tile(value); return 0; }
+  if (strcmp(name, "split_kb") == 0) { emo_gemm_set_split_kb(value); return 0; }
   if (strcmp(name, "conv_big") == 0) { emo_gemm_set_conv_big(value); return 0; }
   if (strcmp(name, "big_bm") == 0) { emo_gemm_set_big_bm(value); return 0; }
   if (strcmp(name, "big_korder") == 0) { emo_gemm_set_big_korder(value); return 0; }

@@ -29,15 +29,18 @@
 #include "mma.h"
 #include "../../include/emoasr_hip.h"
 
+int emo_gemm_f32_split();   // csrc/gemm.hip: option "f32_split"
+
 namespace {
 
 constexpr int DK = 64;
 
+template <typename T> constexpr bool kSplit = std::is_same<T, f32s>::value;   // f32 storage, split-bf16 products (mma.h)
 template <typename T> struct AttnCfg {
   static constexpr int NK = DK / Mma<T>::KSTEP;         // k-steps over the head dim (4 / 32)
   static constexpr int NS = 32 / Mma<T>::KSTEP;         // k-steps over a 32-row tile (2 / 16)
-  static constexpr int LD = sizeof(T) == 2 ? 72 : 64;   // row stride of staged 64-wide LDS tiles (bf16: 144 B rows ->
-                                                        // conflict-free 16-byte k-contiguous reads)
+  static constexpr int LD = sizeof(T) == 2 ? 72 : (kSplit<T> ? 68 : 64);   // row stride of staged 64-wide LDS tiles (bf16: 144 B
+                                                        // rows, split f32: 272 B rows -> conflict-free 16-byte k-contiguous reads)
 };
 
 // ---- fragments straight from global memory (k-contiguous operand) -----------------
@@ -56,6 +59,18 @@ __device__ __forceinline__ typename Mma<T>::Frag frag_global(const T* base, long
       for (int j = 0; j < 8; ++j) f[j] = (bf16)((float)f[j] + bias[d0 + j]);
     }
     return f;
+  } else if constexpr (kSplit<T>) {
+    const int d0 = kk * 16 + 8 * (lane >> 5);
+    const unsigned off = valid ? (unsigned)(((long)row * ld + d0) * 4) : EMO_OOB;
+    const Vec16<T> a = buf_load16<T>(rs, off), b = buf_load16<T>(rs, valid ? off + 16u : EMO_OOB);
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[j] = a.v[j]; x[4 + j] = b.v[j]; }
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] += bias[d0 + j];
+    }
+    return split_regs8(x);
   } else {
     const int d = kk * 2 + (lane >> 5);
     float v = buf_load_f32<T>(rs, valid ? (unsigned)(((long)row * ld + d) * 4) : EMO_OOB);
@@ -103,6 +118,14 @@ __device__ __forceinline__ typename Mma<T>::Frag chain_a(const T* lds, int ks, i
       for (int j = 0; j < 8; ++j) f[j] = lds[(16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)) * LD + col0 + (lane & 31)];
       return f;
     }
+  } else if constexpr (kSplit<T>) {
+    // the bf16 operand's (permuted) k order, element by element out of the packed tile
+    const int h = lane >> 5;
+    const unsigned* p = reinterpret_cast<const unsigned*>(lds) + col0 + (lane & 31);
+    unsigned w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = p[(16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)) * LD];
+    return split_unpack8(w);
   } else {
     return lds[c_row(ks, lane) * LD + col0 + (lane & 31)];
   }
@@ -114,6 +137,11 @@ __device__ __forceinline__ typename Mma<T>::Frag chain_b(const f32x16& x, int ks
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (bf16)x[8 * ks + j];
     return f;
+  } else if constexpr (kSplit<T>) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = x[8 * ks + j];
+    return split_regs8(v);
   } else {
     return x[ks];
   }
@@ -404,7 +432,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
 #pragma unroll
     for (int i = 0; i < VR; ++i) {
       const int v = lane + 64 * i;
-      store16(Vs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, cur.vr[i]);
+      lds_stage16(Vs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, cur.vr[i]);
     }
     // S^T = K . (Q+u)^T + skew(pos_band . (Q+v)^T)   (rows keys, cols queries; see score_tile)
     f32x16 s;
@@ -424,7 +452,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
     }
     EMO_FSTAMP(2);
     // one register set: every prefetched register has been consumed, refill them with tile j0+32
-    if constexpr (!PF2) fetch(cur, j0 + 32);
+    if constexpr (!PF2) fetch(cur, j0 + 32 * ks);   // (ks > 1: this wave's next key tile is ks tiles on)
     EMO_FSTAMP(3);
     if (rel) {
       __builtin_amdgcn_wave_barrier();
@@ -905,13 +933,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const emoasr_attn_t a
 #pragma unroll
     for (int i = 0; i < KR; ++i) {
       const int v = lane + 64 * i;
-      store16(Ks + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, kreg[i]);
+      lds_stage16(Ks + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, kreg[i]);
     }
     if (rel) {
 #pragma unroll
       for (int i = 0; i < 2 * KR; ++i) {
         const int v = lane + 64 * i;
-        store16(Bs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, preg[i]);
+        lds_stage16(Bs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, preg[i]);
       }
     }
     // dP^T = V . dO^T   (rows keys, cols queries), then the next tile's loads go out
@@ -980,8 +1008,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const emoasr_attn_t a
               float vd[8], vp[8];
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
-                vd[e] = img_ds[kl * IMG + c0 + 8 * g8 + e];
-                vp[e] = img_p[kl * IMG + c0 + 8 * g8 + e];
+                vd[e] = to_f32(img_ds[kl * IMG + c0 + 8 * g8 + e]);
+                vp[e] = to_f32(img_p[kl * IMG + c0 + 8 * g8 + e]);
               }
               store_vec8<T>((T*)a.dsT + o + 8 * g8, vd);
               store_vec8<T>((T*)a.pdT + o + 8 * g8, vp);
@@ -2556,11 +2584,12 @@ int check_args(const emoasr_attn_t* a, int dtype) {
   return 0;
 }
 
-template <typename T>
+// TK: the kernels' element type -- T, or f32s for T = float under option "f32_split" (same memory, split-bf16 products)
+template <typename T, typename TK = T>
 int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
   emoasr_attn_t a = a_in;
   fill_seg_order(a);
-  constexpr int LD = AttnCfg<T>::LD;
+  constexpr int LD = AttnCfg<TK>::LD;
   // waves per workgroup: the waves of this kernel never meet (wave-private LDS), so a workgroup is only a unit of dispatch; stacked
   // launches (thousands of query tiles of uneven length) are handed out wave by wave, which packs the CUs' wave slots tightest
   // key split (ks = 4): launches of at most two query tiles per CU -- decoding a few utterances -- where the tiles' own latency
@@ -2574,28 +2603,29 @@ int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
   const bool split = g_fwd_split && a.nseg <= 1 && !a.st && (long)cdiv(a.Tq, 32) * a.H * a.B <= 2L * n_cu;
   const int ks = split ? 4 : 1;
   const int nw = split ? 4 : (g_fwd_waves ? g_fwd_waves : (a.nseg > 1 ? 1 : 4));
-  const int smem = nw * (64 * 32 * 4 + 32 * LD * (int)sizeof(T));
+  const int smem = nw * (64 * 32 * 4 + 32 * LD * (int)sizeof(TK));
   dim3 grid(cdiv(a.Tq, split ? 32 : 32 * nw), a.H, a.B);   // (stacked micro-batches: Tq = the longest segment, B = all utterances)
   // stacked launches: 1-D, the query tiles of one (head, utterance) on one XCD (attn_block)
   const int nt = (g_attn_xcd && a.nseg > 1) ? (int)grid.x : 0;
   if (nt) grid = dim3(8 * cdiv(a.H * a.B, 8) * nt, 1, 1);
-  const bool one_round = (long)grid.x * grid.y * grid.z * nw <= 4L * n_cu;  // at most one wave per SIMD: see attn_fwd_kernel
+  // at most one wave per SIMD: see attn_fwd_kernel (not for the split type: two prefetch sets of (hi, lo) fragments spill)
+  const bool one_round = !kSplit<TK> && (long)grid.x * grid.y * grid.z * nw <= 4L * n_cu;
   emo_timer_begin(EMO_TIMER_ATTN_FWD, s);
   if (g_tr) {
     if (one_round) {
-      if (set_smem(attn_fwd_kernel<T, true, true>, smem)) return 1;
-      attn_fwd_kernel<T, true, true><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
+      if (set_smem(attn_fwd_kernel<TK, true, true>, smem)) return 1;
+      attn_fwd_kernel<TK, true, true><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
     } else {
-      if (set_smem(attn_fwd_kernel<T, true, false>, smem)) return 1;
-      attn_fwd_kernel<T, true, false><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
+      if (set_smem(attn_fwd_kernel<TK, true, false>, smem)) return 1;
+      attn_fwd_kernel<TK, true, false><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
     }
   } else {
     if (one_round) {
-      if (set_smem(attn_fwd_kernel<T, false, true>, smem)) return 1;
-      attn_fwd_kernel<T, false, true><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
+      if (set_smem(attn_fwd_kernel<TK, false, true>, smem)) return 1;
+      attn_fwd_kernel<TK, false, true><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
     } else {
-      if (set_smem(attn_fwd_kernel<T, false, false>, smem)) return 1;
-      attn_fwd_kernel<T, false, false><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
+      if (set_smem(attn_fwd_kernel<TK, false, false>, smem)) return 1;
+      attn_fwd_kernel<TK, false, false><<<grid, 64 * nw, smem, s>>>(a, nt, ks);
     }
   }
   emo_timer_end(EMO_TIMER_ATTN_FWD, s);
@@ -2622,16 +2652,16 @@ int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
   return 0;
 }
 
-template <typename T, bool TR>
+template <typename T, bool TR, typename TK = T>
 int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
   constexpr int LD = AttnCfg<T>::LD;
   const long rows = (long)a.B * a.Tq * a.H;
   attn_delta_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a);
   if (a.pdT && !a.st) {
-    const int smem = 4 * DqCfg<T>::WAVE_BYTES;
+    const int smem = 4 * DqCfg<TK>::WAVE_BYTES;
     dim3 grid(cdiv(a.Tq, 32), a.H, a.B);
-    if (set_smem(attn_bwd_dq2_kernel<T, TR>, smem)) return 1;
-    attn_bwd_dq2_kernel<T, TR><<<grid, 256, smem, s>>>(a);
+    if (set_smem(attn_bwd_dq2_kernel<TK, TR>, smem)) return 1;
+    attn_bwd_dq2_kernel<TK, TR><<<grid, 256, smem, s>>>(a);
     if (a.dbias_part && (a.dbias_u || a.dbias_v))
       attn_dbias_reduce_kernel<<<2 * a.H, 256, 0, s>>>(a.B * (int)grid.x, a.H, a.dbias_part, a.dbias_u,
                                                         a.pos ? a.dbias_v : nullptr);
@@ -3038,6 +3068,7 @@ void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }
 extern "C" int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream) {
   if (check_args(a, dtype)) return 1;
   if (a->B == 0 || a->Tq == 0) return 0;
+  if (dtype == EMO_F32 && emo_gemm_f32_split()) return launch_fwd<float, f32s>(*a, (hipStream_t)stream);
   EMO_DISPATCH(dtype, return (launch_fwd<T>(*a, (hipStream_t)stream)));
   return 0;
 }
@@ -3053,6 +3084,9 @@ extern "C" int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream) 
     EMO_CHECK(!a->st || a->ldst >= a->Tq, "attn_bwd: bad st");
   }
   if (a->B == 0 || a->Tq == 0) return 0;
+  // f32 under option "f32_split": the score-recomputing dQ kernel (the training path's: pdT without stored scores) runs its
+  // products split; the GEMMs behind it (dV, dK, dpos) follow the same option inside gemm.hip
+  if (dtype == EMO_F32 && emo_gemm_f32_split() && a->pdT && !a->st) return launch_bwd_tr<float, true, f32s>(*a, (hipStream_t)stream);
   EMO_DISPATCH(dtype, {
     if (g_tr) return (launch_bwd_tr<T, true>(*a, (hipStream_t)stream));
     return (launch_bwd_tr<T, false>(*a, (hipStream_t)stream));

@@ -53,6 +53,19 @@ template <> struct Vec16<bf16> {
   }
 };
 
+// f32s: "split" element type of the attention kernels' f32x3 mode (csrc/mma.h Mma<f32s>): plain f32 in HBM and in the kernels'
+// f32 images; only the MFMA operand tiles in LDS hold (hi, lo) bf16 pairs packed into the element's 32 bits
+struct f32s { float x; };
+template <> __device__ __forceinline__ float to_f32<f32s>(f32s v) { return v.x; }
+template <> __device__ __forceinline__ f32s from_f32<f32s>(float v) { return f32s{v}; }
+template <> struct Vec16<f32s> {
+  static constexpr int N = 4;
+  f32x4 v;
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+  __device__ __forceinline__ void zero() { v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+};
+
 template <typename T>
 __device__ __forceinline__ Vec16<T> load16(const T* p) {
   Vec16<T> r;

@@ -14,6 +14,7 @@
 // registers -> LDS (double buffered, one barrier per k-tile); the next k-tile's
 // global loads are issued before the current tile's MFMAs.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 #include "mma.h"
 #include "../../include/emoasr_hip.h"
@@ -65,6 +66,9 @@ int g_tr_read = 1;
 int g_gemm_wholek = 1;   // option "gemm_wholek"
 int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1, g_tn_group_kb = 0, g_tn_place = 0, g_gemm_wide128 = 0;
 int g_tn_group_blocks = 0;  // override of a grouped TN launch's block budget (emoasr_set_option "tn_group_blocks"; 0 = auto)
+int g_f32_split = 0;        // option "f32_split": f32 products as three bf16 MFMAs over (hi, lo) operand pairs (see SplitCfg)
+int g_split_tile = 0;       // option "split_tile": tile of the split NT / NN products (1 = 128x128 where it fills the chip twice, 2 = 128x64, 3 = 64x64; 0 = rule)
+int g_split_kb = 1;         // option "split_kb": 2 = BK 64 for split reductions of K >= 512
 
 // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Reading
 // the linear id as (xcd, slot) makes XCD x work on ONE contiguous range of the logical block list, so
@@ -98,6 +102,29 @@ template <typename T, int KB = 1> struct TileCfg {
 };
 
 
+// "Split" products (SP; T = float): f32 operands in HBM, every product as THREE bf16 MFMAs over (hi, lo) operand pairs --
+//   x = hi + lo,  hi = bf16(x),  lo = bf16(x - hi):   a . b ~= ah . bh + ah . bl + al . bh     (f32 accumulate)
+// -- 16 significand bits per operand (relative error ~2^-17 per product, the dropped lo . lo term 2^-18) at 16 / 3 times the rate
+// of v_mfma_f32_32x32x2_f32.  The f32 tile is split ONCE per workgroup on its way from the staging registers into LDS (two bf16
+// planes per operand, the bf16 kernel's tile geometry); everything outside the k loop -- loads, epilogue, output -- is the f32
+// kernel's.  Selected per process by emoasr_set_option("f32_split", 1): the engine's throughput mode that meets the 1e-3 bar.
+template <int KB> struct SplitCfg {
+  static constexpr int VEC = 4;                 // floats per 16-byte global vector
+  static constexpr int BK = 32 * KB;
+  static constexpr int KV = BK / VEC;
+  static constexpr int LD = BK + 8;             // bf16 elements per LDS row (k-contiguous planes)
+};
+__device__ __forceinline__ void split_store4(bf16* hi, bf16* lo, const Vec16<float>& v) {
+  bf16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (bf16)v.v[e];
+    l[e] = (bf16)(v.v[e] - (float)h[e]);
+  }
+  *reinterpret_cast<bf16x4*>(hi) = h;
+  *reinterpret_cast<bf16x4*>(lo) = l;
+}
+
 template <typename T>
 __device__ __forceinline__ void lds_store_row(T* dst, const Vec16<T>& v) {
   if constexpr (sizeof(T) == 2) {
@@ -114,27 +141,32 @@ __device__ __forceinline__ void lds_store_row(T* dst, const Vec16<T>& v) {
 // zeroed with a select, so the k-loop has no exec-mask branches.  The epilogue transposes each
 // 32x32 accumulator tile through wave-private LDS so that every lane owns 8 consecutive columns
 // of one row: bias / saved-activation / residual traffic and the output are 16-byte accesses.
-template <typename T, int BM, int BN, int AMODE, bool BKM, bool TR, int KB>
+template <typename T, int BM, int BN, int AMODE, bool BKM, bool TR, int KB, bool SP = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
+  static_assert(!SP || (sizeof(T) == 4 && KB < 8), "split products: f32 operands only");
   using Cfg = TileCfg<T, KB>;
   using M_ = Mma<T>;
-  constexpr int VEC = Cfg::VEC, BK = Cfg::BK, KV = Cfg::KV, LD = Cfg::LD;
+  using L = std::conditional_t<SP, bf16, T>;              // element type of the LDS tiles
+  constexpr int VEC = SP ? SplitCfg<KB>::VEC : Cfg::VEC, BK = SP ? SplitCfg<KB>::BK : Cfg::BK;
+  constexpr int KV = SP ? SplitCfg<KB>::KV : Cfg::KV, LD = SP ? SplitCfg<KB>::LD : Cfg::LD;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int LDBK = BN + (sizeof(T) == 2 ? 32 : 0);  // k-major B tile row stride
+  constexpr int LDBK = BN + (sizeof(L) == 2 ? 32 : 0);  // k-major B tile row stride
   constexpr int BVK = BN / VEC;                          // vectors per k row (k-major B)
   constexpr int A_IT = BM * KV / 256, B_IT = BKM ? BK * BVK / 256 : BN * KV / 256;
   static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 threads");
   constexpr int AS_ELEMS = BM * LD, BS_ELEMS = BKM ? BK * LDBK : BN * LD;
+  constexpr int NPL = SP ? 2 : 1;                         // LDS planes per operand (split: hi, lo)
   constexpr int EP_LD = BN + 4;                           // f32 row stride of the staged block tile
   constexpr int NBUF = KB >= 8 ? 1 : 2;   // KB = 8 (whole rows of K = 256 per tile, latency-bound launches): one LDS buffer
-  constexpr int STAGE_BYTES = NBUF * (AS_ELEMS + BS_ELEMS) * (int)sizeof(T);
+  constexpr int STAGE_BYTES = NBUF * NPL * (AS_ELEMS + BS_ELEMS) * (int)sizeof(L);
   constexpr int EPI_ROWS = (BM * BN > 128 * 64) ? BM / 2 : BM;  // the 128x128 tile is staged in two 64-row halves
   constexpr int EPI_BYTES = EPI_ROWS * EP_LD * 4;
   constexpr int SMEM_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
-  T* As0 = reinterpret_cast<T*>(smem);
-  T* Bs0 = As0 + NBUF * AS_ELEMS;
+  // layout: A planes of every buffer ([buf][plane][AS_ELEMS]), then the B planes likewise
+  L* As0 = reinterpret_cast<L*>(smem);
+  L* Bs0 = As0 + NBUF * NPL * AS_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
@@ -234,14 +266,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
     }
   };
   auto store_tile = [&](const Stage& r, int buf) {
-    T* As = As0 + buf * AS_ELEMS;
-    T* Bs = Bs0 + buf * BS_ELEMS;
+    L* As = As0 + buf * NPL * AS_ELEMS;
+    L* Bs = Bs0 + buf * NPL * BS_ELEMS;
+    if constexpr (SP) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) lds_store_row(&As[a_lds[i]], r.a[i]);
+      for (int i = 0; i < A_IT; ++i) split_store4(&As[a_lds[i]], &As[AS_ELEMS + a_lds[i]], r.a[i]);
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      if constexpr (BKM) store16(&Bs[b_lds[i]], r.b[i]);
-      else lds_store_row(&Bs[b_lds[i]], r.b[i]);
+      for (int i = 0; i < B_IT; ++i) split_store4(&Bs[b_lds[i]], &Bs[BS_ELEMS + b_lds[i]], r.b[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) lds_store_row(&As[a_lds[i]], r.a[i]);
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        if constexpr (BKM) store16(&Bs[b_lds[i]], r.b[i]);
+        else lds_store_row(&Bs[b_lds[i]], r.b[i]);
+      }
     }
   };
 
@@ -254,8 +293,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute_tile = [&](int buf) {
-    const T* As = As0 + buf * AS_ELEMS;
-    const T* Bs = Bs0 + buf * BS_ELEMS;
+    const L* As = As0 + buf * NPL * AS_ELEMS;
+    const L* Bs = Bs0 + buf * NPL * BS_ELEMS;
+    if constexpr (SP) {
+      using MB = Mma<bf16>;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += MB::KSTEP) {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = MB::load_kc(As, LD, wm + i * 32, kk, lane);
+          al[i] = MB::load_kc(As + AS_ELEMS, LD, wm + i * 32, kk, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (BKM) {
+            bh[j] = MB::template load_km<TR>(Bs, LDBK, kk, wn + j * 32, lane);
+            bl[j] = MB::template load_km<TR>(Bs + BS_ELEMS, LDBK, kk, wn + j * 32, lane);
+          } else {
+            bh[j] = MB::load_kc(Bs, LD, wn + j * 32, kk, lane);
+            bl[j] = MB::load_kc(Bs + BS_ELEMS, LD, wn + j * 32, kk, lane);
+          }
+        }
+        // (the two small cross terms first, the leading term last)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = MB::mma(al[i], bh[j], acc[i][j]);
+            acc[i][j] = MB::mma(ah[i], bl[j], acc[i][j]);
+            acc[i][j] = MB::mma(ah[i], bh[j], acc[i][j]);
+          }
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < BK; kk += M_::KSTEP) {
       typename M_::Frag af[TM], bfr[TN];
@@ -270,6 +340,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(af[i], bfr[j], acc[i][j]);
+    }
     }
   };
 
@@ -484,20 +555,23 @@ struct TnArgs {
 };
 
 // one (n1 tile, n2 tile, k slice) of a TN product; shared by the plain and the grouped kernels
-template <typename T, int BN1, int BN2, int BMODE, bool TR, int KB>
+template <typename T, int BN1, int BN2, int BMODE, bool TR, int KB, bool SP = false>
 __device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const int by, const int bz, const int nbx) {
+  static_assert(!SP || sizeof(T) == 4, "split products: f32 operands only");
   using Cfg = TileCfg<T, KB>;
   using M_ = Mma<T>;
-  constexpr int VEC = Cfg::VEC, BK = Cfg::BK;
-  constexpr int PAD = sizeof(T) == 2 ? 32 : 0;
+  using L = std::conditional_t<SP, bf16, T>;
+  constexpr int VEC = Cfg::VEC, BK = SP ? SplitCfg<KB>::BK : Cfg::BK;
+  constexpr int PAD = sizeof(L) == 2 ? 32 : 0;
   constexpr int LDA = BN1 + PAD, LDB = BN2 + PAD;
   constexpr int W1 = BN1 / 2, W2 = BN2 / 2, TM = W1 / 32, TN = W2 / 32;
   constexpr int AV = BN1 / VEC, BV = BN2 / VEC;  // vectors per k row
   constexpr int A_IT = BK * AV / 256, B_IT = BK * BV / 256;
   static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");
+  constexpr int NPL = SP ? 2 : 1;   // split: hi plane, then lo plane
 
-  __shared__ __attribute__((aligned(16))) T As[2][BK * LDA];
-  __shared__ __attribute__((aligned(16))) T Bs[2][BK * LDB];
+  __shared__ __attribute__((aligned(16))) L As[2][NPL * BK * LDA];
+  __shared__ __attribute__((aligned(16))) L Bs[2][NPL * BK * LDB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w1 = (wave >> 1) * W1, w2 = (wave & 1) * W2;
@@ -558,12 +632,14 @@ __device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const in
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int v = tid + i * 256, kr = v / AV, nv = (v % AV) * VEC;
-      store16(&As[buf][kr * LDA + nv], st.a[i]);
+      if constexpr (SP) split_store4(&As[buf][kr * LDA + nv], &As[buf][BK * LDA + kr * LDA + nv], st.a[i]);
+      else store16(&As[buf][kr * LDA + nv], st.a[i]);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int v = tid + i * 256, kr = v / BV, nv = (v % BV) * VEC;
-      store16(&Bs[buf][kr * LDB + nv], st.b[i]);
+      if constexpr (SP) split_store4(&Bs[buf][kr * LDB + nv], &Bs[buf][BK * LDB + kr * LDB + nv], st.b[i]);
+      else store16(&Bs[buf][kr * LDB + nv], st.b[i]);
     }
   };
 
@@ -591,8 +667,36 @@ __device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const in
     load_tile(fre, kt + 2);
     if (do_colsum && kt % nbx == bx) {
 #pragma unroll
-      for (int k = 0; k < BK; ++k) csum += to_f32(As[buf][k * LDA + tid]);
+      for (int k = 0; k < BK; ++k) {
+        if constexpr (SP) csum += (float)As[buf][k * LDA + tid] + (float)As[buf][BK * LDA + k * LDA + tid];
+        else csum += to_f32(As[buf][k * LDA + tid]);
+      }
     }
+    if constexpr (SP) {
+      using MB = Mma<bf16>;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += MB::KSTEP) {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = MB::template load_km<TR>(As[buf], LDA, kk, w1 + i * 32, lane);
+          al[i] = MB::template load_km<TR>(As[buf] + BK * LDA, LDA, kk, w1 + i * 32, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = MB::template load_km<TR>(Bs[buf], LDB, kk, w2 + j * 32, lane);
+          bl[j] = MB::template load_km<TR>(Bs[buf] + BK * LDB, LDB, kk, w2 + j * 32, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = MB::mma(al[i], bh[j], acc[i][j]);
+            acc[i][j] = MB::mma(ah[i], bl[j], acc[i][j]);
+            acc[i][j] = MB::mma(ah[i], bh[j], acc[i][j]);
+          }
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < BK; kk += M_::KSTEP) {
       typename M_::Frag af[TM], bfr[TN];
@@ -604,6 +708,7 @@ __device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const in
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(af[i], bfr[j], acc[i][j]);
+    }
     }
     store_tile(nxt, buf ^ 1);
     __syncthreads();
@@ -630,12 +735,12 @@ __device__ __forceinline__ void tn_block(const TnArgs& g, const int bx, const in
   if (do_colsum && n1_0 + tid < g.N1) atomicAdd(&g.colsum[n1_0 + tid], g.colsum_scale * csum);
 }
 
-template <typename T, int BN1, int BN2, int BMODE, bool TR, int KB>
+template <typename T, int BN1, int BN2, int BMODE, bool TR, int KB, bool SP = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs g) {
   // all (n1, n2) tiles of one k slice read the same rows of A and B: keep a slice on one XCD
   const int gx = gridDim.x, gy = gridDim.y;
   const int lin = xcd_remap((blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x, gx * gy * gridDim.z);
-  tn_block<T, BN1, BN2, BMODE, TR, KB>(g, lin % gx, (lin / gx) % gy, lin / (gx * gy), gx);
+  tn_block<T, BN1, BN2, BMODE, TR, KB, SP>(g, lin % gx, (lin / gx) % gy, lin / (gx * gy), gx);
 }
 
 // Grouped form: up to EMOASR_TN_GROUP_MAX independent products in one launch (the ~10 weight
@@ -661,7 +766,7 @@ struct TnGroup {
   TnArgs p[EMOASR_TN_GROUP_MAX];
   TnPlace place;
 };
-template <typename T, bool TR, int KB, int BT>
+template <typename T, bool TR, int KB, int BT, bool SP = false>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup G) {
   if (G.xcd == 1) {
     const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, cnt = G.place.cnt[x];
@@ -671,7 +776,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup G) {
     const TnArgs& g = G.p[G.place.prob[x][e]];
     const int local = slot - G.place.start[x][e];
     const int tx = (g.N2 + BT - 1) / BT;
-    tn_block<T, BT, BT, 0, TR, KB>(g, local % tx, local / tx, G.place.split[x][e], tx);
+    tn_block<T, BT, BT, 0, TR, KB, SP>(g, local % tx, local / tx, G.place.split[x][e], tx);
     return;
   }
   const int bid = G.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;  // see gemm_tn_kernel
@@ -680,13 +785,36 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup G) {
   const TnArgs& g = G.p[p];
   const int local = bid - G.start[p];
   const int tx = (g.N2 + BT - 1) / BT, ty = (g.N1 + BT - 1) / BT;
-  tn_block<T, BT, BT, 0, TR, KB>(g, local % tx, (local / tx) % ty, local / (tx * ty), tx);
+  tn_block<T, BT, BT, 0, TR, KB, SP>(g, local % tx, (local / tx) % ty, local / (tx * ty), tx);
 }
 
-template <typename T, int AMODE, bool BKM, bool TR>
+template <typename T, int AMODE, bool BKM, bool TR, bool SP = false>
 int launch_nt_(const NtArgs& a_in, hipStream_t s, int nz = 1) {
   NtArgs a = a_in;
   a.xcd = g_gemm_xcd;
+  if constexpr (SP) {
+    // split products: the bf16 kernel's tile rule (128x64 while that fills the chip 1.5 times, else 64x64), BK = 32
+    const long t12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64) * nz, t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * nz;
+    // 64x64 everywhere (four workgroups per CU): measured inside the f32x3 training step against the bf16 kernel's rule (128x64
+    // where that fills the chip 1.5 times: 17.17 ms), 128x128 tiles (17.27) and BK = 64 (18.35): 17.00 ms per step
+    (void)t12864;
+    int tile = 3;
+    if (g_split_tile == 1 && t128 >= 512 && a.N % 128 == 0) tile = 1;
+    else if (g_split_tile >= 2) tile = g_split_tile;
+    const int kb = (g_split_kb == 2 && a.K >= 512) ? 2 : 1;
+#define EMO_SP_LAUNCH(BM_, BN_)                                                            \
+  do {                                                                                     \
+    dim3 grid(cdiv(a.N, BN_), cdiv(a.M, BM_), nz);                                         \
+    if (kb == 2) gemm_nt_kernel<T, BM_, BN_, AMODE, BKM, TR, 2, true><<<grid, 256, 0, s>>>(a); \
+    else gemm_nt_kernel<T, BM_, BN_, AMODE, BKM, TR, 1, true><<<grid, 256, 0, s>>>(a);      \
+  } while (0)
+    if (tile == 1) EMO_SP_LAUNCH(128, 128);
+    else if (tile == 2) EMO_SP_LAUNCH(128, 64);
+    else EMO_SP_LAUNCH(64, 64);
+#undef EMO_SP_LAUNCH
+    EMO_LAUNCH_CHECK();
+    return 0;
+  }
   // Tile: 128x64 once that still gives >= 384 blocks (1.5 per CU), else 64x64.  (A 128x128 tile
   // was measured slower than 128x64 on every shape of the L2 model.)  k extent: BK = 64 for long
   // bf16 reductions, 32 for K = 256.  g_gemm_tile / g_gemm_kb: tuning overrides (emoasr_set_option).
@@ -728,19 +856,26 @@ int launch_nt_(const NtArgs& a_in, hipStream_t s, int nz = 1) {
   EMO_LAUNCH_CHECK();
   return 0;
 }
+// f32 with option "f32_split": the split kernels (SP); everything else as before
+template <typename T> constexpr bool is_f32 = sizeof(T) == 4;
 template <typename T, int AMODE>
-int launch_nt(const NtArgs& a, hipStream_t s) { return launch_nt_<T, AMODE, false, true>(a, s); }
+int launch_nt(const NtArgs& a, hipStream_t s) {
+  if constexpr (is_f32<T>) { if (g_f32_split) return launch_nt_<T, AMODE, false, true, true>(a, s); }
+  return launch_nt_<T, AMODE, false, true>(a, s);
+}
 template <typename T>
 int launch_nn(const NtArgs& a, hipStream_t s, int nz = 1) {
+  if constexpr (is_f32<T>) { if (g_f32_split) return launch_nt_<T, 0, true, true, true>(a, s, nz); }
   return g_tr_read ? launch_nt_<T, 0, true, true>(a, s, nz) : launch_nt_<T, 0, true, false>(a, s, nz);
 }
 
-template <typename T, int BMODE>
+template <typename T, int BMODE, bool SP = false>
 int launch_tn(TnArgs a, hipStream_t s) {
+  if constexpr (is_f32<T> && !SP) { if (g_f32_split) return launch_tn<T, BMODE, true>(a, s); }
   const bool big = (long)cdiv(a.N1, 128) * cdiv(a.N2, 128) >= 32 && a.N1 >= 128 && a.N2 >= 128;
   // BK = 32 with the 128x128 tile (three resident blocks per CU instead of two; see emoasr_gemm_tn_grouped), 64 for long reductions on 64x64
   const int kb = sizeof(T) == 2 ? (g_gemm_kb ? g_gemm_kb : (a.K >= 512 && !big ? 2 : 1)) : 1;
-  const int BK = TileCfg<T>::BK * kb;
+  const int BK = (SP ? 32 : TileCfg<T>::BK) * kb;
   const int nk = cdiv(a.K, BK);
   const int bn = big ? 128 : 64;
   const long tiles = (long)cdiv(a.N1, bn) * cdiv(a.N2, bn);
@@ -748,7 +883,7 @@ int launch_tn(TnArgs a, hipStream_t s) {
   // second round) with at least 4 k-tiles each, but keep
   // the f32 atomic traffic (output bytes x slices) around 8 MB: global float atomics run at
   // ~1.3 TB/s chip-wide, so more slices than that make the kernel atomic-bound.
-  const long slots_ = g_tn_group_blocks > 0 ? g_tn_group_blocks : (big && kb == 2 ? 512 : 768);
+  const long slots_ = g_tn_group_blocks > 0 ? g_tn_group_blocks : ((big && kb == 2) || (big && SP) ? 512 : 768);   // (split, 128 tile: 80 KB of LDS)
   int splits = (int)std::max(1L, slots_ / tiles);  // one full round of resident blocks (2 per CU for the 128x128 BK=64 tile, else 3)
   const long out_bytes = (long)a.N1 * a.N2 * 4;
   // ... unless the reduction is so long that the atomics stay below ~10 % of the product's own time
@@ -768,15 +903,20 @@ int launch_tn(TnArgs a, hipStream_t s) {
       if (kb == 2) gemm_tn_kernel<T, BN_, BN_, BMODE, TR_, 2><<<grid, 256, 0, s>>>(a); \
       else gemm_tn_kernel<T, BN_, BN_, BMODE, TR_, 1><<<grid, 256, 0, s>>>(a);         \
     } else {                                                                        \
-      gemm_tn_kernel<T, BN_, BN_, BMODE, TR_, 1><<<grid, 256, 0, s>>>(a);              \
+      gemm_tn_kernel<T, BN_, BN_, BMODE, TR_, 1, SP><<<grid, 256, 0, s>>>(a);          \
     }                                                                               \
   } while (0)
+  if constexpr (SP) {
+    if (big) EMO_TN_LAUNCH(128, true);
+    else EMO_TN_LAUNCH(64, true);
+  } else {
   if (big) {
     if (g_tr_read) EMO_TN_LAUNCH(128, true);
     else EMO_TN_LAUNCH(128, false);
   } else {
     if (g_tr_read) EMO_TN_LAUNCH(64, true);
     else EMO_TN_LAUNCH(64, false);
+  }
   }
 #undef EMO_TN_LAUNCH
   EMO_LAUNCH_CHECK();
@@ -807,6 +947,10 @@ void emo_gemm_set_wholek(int v) { g_gemm_wholek = v; }
 void emo_gemm_set_tn_place(int v) { g_tn_place = v != 0; }
 void emo_gemm_set_tn_group_kb(int v) { g_tn_group_kb = (v == 1 || v == 2) ? v : 0; }
 void emo_gemm_set_xcd(int v) { g_gemm_xcd = v; }
+void emo_gemm_set_f32_split(int v) { g_f32_split = v ? 1 : 0; }
+int emo_gemm_f32_split() { return g_f32_split; }
+void emo_gemm_set_split_tile(int v) { g_split_tile = (v >= 1 && v <= 3) ? v : 0; }
+void emo_gemm_set_split_kb(int v) { g_split_kb = v == 2 ? 2 : 1; }
 
 static int check_vec(long ld, int dtype, const char* what) {
   const int vec = dtype == EMO_BF16 ? 8 : 4;
@@ -907,7 +1051,8 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   // co-resident and the launch read 1.2-1.6x its operands from HBM; BK = 32 reads them once -- 216 -> 185 us at 35 k rows,
   // tools/tn_probe.py.)  Option "gemm_kb" overrides.
   const int kb = dtype == EMO_BF16 ? (g_tn_group_kb ? g_tn_group_kb : g_gemm_kb ? g_gemm_kb : (bt == 128 ? 1 : 2)) : 1;
-  const int BK = (dtype == EMO_BF16 ? 32 : 16) * kb;
+  const bool split = dtype == EMO_F32 && g_f32_split;
+  const int BK = (dtype == EMO_BF16 || split ? 32 : 16) * kb;
   for (int i = 0; i < n; ++i) {
     const emoasr_tn_problem_t& q = probs[i];
     EMO_CHECK(q.N1 > 0 && q.N2 > 0 && q.K > 0, "gemm_tn_grouped: empty problem %d", i);
@@ -920,7 +1065,7 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   // one split factor for the whole group, chosen so that the launch is ONE full round of resident blocks:
   // three blocks per CU for the 128x128 BK=32 tile (40 KB of LDS) and the 64x64 one (48 KB), two for 128x128 BK=64.  Rounding
   // the block count up past that measured slower every time (at 35 k rows: 768 blocks 185 us, 896 blocks 257 us).
-  const long slots = g_tn_group_blocks > 0 ? g_tn_group_blocks : (bt == 128 && kb == 2 ? 512 : 768);
+  const long slots = g_tn_group_blocks > 0 ? g_tn_group_blocks : ((bt == 128 && kb == 2) || (bt == 128 && split) ? 512 : 768);
   const int want = (int)std::max(1L, slots / tiles);
   int start = 0;
   for (int i = 0; i < n; ++i) {
@@ -991,6 +1136,9 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
       if (g_tr_read) gemm_tn_grouped_kernel<bf16, true, 2, 64><<<start, 256, 0, s>>>(G);
       else gemm_tn_grouped_kernel<bf16, false, 2, 64><<<start, 256, 0, s>>>(G);
     }
+  } else if (split) {
+    if (bt == 128) gemm_tn_grouped_kernel<float, true, 1, 128, true><<<start, 256, 0, s>>>(G);
+    else gemm_tn_grouped_kernel<float, true, 1, 64, true><<<start, 256, 0, s>>>(G);
   } else if (dtype == EMO_F32) {
     if (bt == 128) gemm_tn_grouped_kernel<float, true, 1, 128><<<start, 256, 0, s>>>(G);
     else gemm_tn_grouped_kernel<float, true, 1, 64><<<start, 256, 0, s>>>(G);
@@ -1046,8 +1194,9 @@ extern "C" int emoasr_conv2_dgrad(int dtype, int B, int T1, int F1, int C, const
       a.A = dy2; a.lda = 0; a.B = w; a.ldb = 9 * C; a.C = dy1; a.ldc = C;
       a.ep.alpha = 1.f; a.ep.dact_pre = y1; a.ep.dact = EMO_ACT_RELU; a.ep.res_scale = 1.f;
       int rc = 1;
-      EMO_DISPATCH(dtype, rc = (g_tr_read ? launch_nt_<T, 2, true, true>(a, (hipStream_t)stream)
-                                          : launch_nt_<T, 2, true, false>(a, (hipStream_t)stream)));
+      EMO_DISPATCH(dtype, rc = (is_f32<T> && g_f32_split ? launch_nt_<float, 2, true, true, true>(a, (hipStream_t)stream)
+                                : g_tr_read ? launch_nt_<T, 2, true, true>(a, (hipStream_t)stream)
+                                            : launch_nt_<T, 2, true, false>(a, (hipStream_t)stream)));
       if (rc) return rc;
     }
   return 0;

@@ -243,8 +243,11 @@ def h2d_i32(values, device):
 class CTCEngine(_DecoderMixinPlaceholder):
     """Forward / backward of encoder + CTC head on HIP kernels."""
 
-    def __init__(self, cfg, module, compute_dtype=torch.bfloat16, bn_buffers=None):
+    def __init__(self, cfg, module, compute_dtype=torch.bfloat16, bn_buffers=None, f32_split=False):
         self.cfg = cfg
+        # f32 storage with every product as three bf16 MFMAs over (hi, lo) operand pairs (csrc/gemm.hip SplitCfg): the
+        # throughput mode that meets the 1e-3 bar; compute_dtype stays torch.float32
+        self.split = bool(f32_split) and compute_dtype == torch.float32
         self.d = cfg.enc_hidden_size
         self.h = cfg.enc_num_attention_heads
         self.nl = cfg.enc_num_layers
@@ -338,6 +341,14 @@ class CTCEngine(_DecoderMixinPlaceholder):
     def _seed(self, site):
         return (self.seed * 1000003 + self.step_count * 4099 + site) & 0xFFFFFFFFFFFF
 
+    def _apply_mode(self):
+        """re-assert this engine's mode of the f32 products (a process-wide library option: another engine may have changed it)"""
+        if self.dtype == torch.float32:
+            ops.set_f32_split(self.split)
+
+    def _scope(self):
+        return ops.stream_scope(self.split if self.dtype == torch.float32 else None)
+
     def _buffers(self, name):
         b = self._bufs.get(name)
         if b is None or not b.is_cuda:
@@ -349,7 +360,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
     def forward(self, xs, xlens_host, training, stash=None):
         """xs f32 [B,T,F] (device), xlens_host: python list / CPU tensor.
         -> eouts [B,T',d] (compute dtype), elens (list), stash (or None)"""
-        with ops.stream_scope():
+        with self._scope():
             return self._forward(xs, xlens_host, training, stash)
 
     def _forward(self, xs, xlens_host, training, stash):
@@ -520,6 +531,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
     def head_logits(self, eouts, head="decoder.output", out_f32=False):
         """out_f32 (decoding in bf16 only): the logits leave the product as f32 instead of being rounded to bf16 -- an arg-max
         over 10 000 bf16 logits flips on every pair closer than one bf16 ulp (0.03-0.06 at |logit| ~ 8); see bench `bf16_vs_f32`"""
+        self._apply_mode()
         B, T, d = eouts.shape
         A = self.arena
         w = A.w(head + ".weight")
@@ -536,6 +548,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
 
     def ctc_loss(self, logits, elens, ys_host, ylens_host, blank, want_grad, gscale_over_b=None):
         """-> (loss 0-dim f32 tensor = sum_b nll_b / B with infeasible utterances zeroed, ctx)"""
+        self._apply_mode()
         B, T, V = logits.shape
         dev = logits.device
         ylens_host = [int(v) for v in ylens_host]
@@ -552,6 +565,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
         return loss, ctx
 
     def ctc_grad(self, ctx, gscale, gscale_dev=None):
+        self._apply_mode()
         logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll = ctx
         return ops.ctc_grad(logits, lse, labels, elens, ylens, blank, lp, alpha, beta, nll, gscale / logits.shape[0],
                             gscale_dev)
@@ -582,7 +596,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
         assert self.stacked_ok(), "ctc_train_stacked: unsupported configuration (see stacked_ok)"
         self._defer_wgrads = self._group_wgrads
         try:
-            with ops.stream_scope():
+            with self._scope():
                 return self._ctc_train_stacked(batches, blank, scales, head)
         finally:
             self._defer_wgrads = False
@@ -700,13 +714,13 @@ class CTCEngine(_DecoderMixinPlaceholder):
         """the encoder over several micro-batches in one stacked pass, for ANY decoder on top (modeling/functions.py:
         encoder_apply_stacked wraps it into autograd).  -> (eouts [M, d], stash)"""
         assert self.encoder_stacked_ok(), "encoder_forward_stacked: unsupported configuration (see encoder_stacked_ok)"
-        with ops.stream_scope():
+        with self._scope():
             return self._encoder_fwd_stacked(xs_list, xlens_list)
 
     def encoder_backward_stacked(self, st, deouts):
         self._defer_wgrads = self._group_wgrads
         try:
-            with ops.stream_scope():
+            with self._scope():
                 self._encoder_bwd_stacked(st, deouts)
         finally:
             self._defer_wgrads = False
@@ -947,9 +961,10 @@ class CTCEngine(_DecoderMixinPlaceholder):
     def backward(self, st, deouts, deouts_inter=None):
         """deouts: gradient w.r.t. encoder output [B,T',d] (compute dtype); deouts_inter: gradient w.r.t. the
         intermediate branch (or None).  Accumulates into the gradient arena (p.grad views)."""
+        self._apply_mode()
         self._defer_wgrads = self._group_wgrads
         try:
-            with ops.stream_scope():
+            with self._scope():
                 return self._backward(st, deouts, deouts_inter)
         finally:
             self._defer_wgrads = False
@@ -1075,6 +1090,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
 
     def head_backward(self, eouts, dlogits, head="decoder.output"):
         """-> deouts; accumulates the vocabulary head's gradients."""
+        self._apply_mode()
         B, T, d = eouts.shape
         V = dlogits.shape[-1]
         self.arena.attach_grads()
@@ -1115,7 +1131,7 @@ class _DecoderMixin:
 
     def dec_forward(self, eouts, elens_dev, ys_in, ylens_host, training, keep):
         """teacher-forced decoder: -> logits [B, L, V] (compute dtype), stash"""
-        with ops.stream_scope():
+        with self._scope():
             return self._dec_forward(eouts, elens_dev, ys_in, ylens_host, training, keep)
 
     def _dec_forward(self, eouts, elens_dev, ys_in, ylens_host, training, keep):
@@ -1199,7 +1215,7 @@ class _DecoderMixin:
 
     def dec_backward(self, st, dlogits):
         """-> d_eouts [B,T,d]; accumulates decoder parameter gradients"""
-        with ops.stream_scope():
+        with self._scope():
             return self._dec_backward(st, dlogits)
 
     def _dec_backward(self, st, dlogits):
@@ -1359,7 +1375,7 @@ class _RNNTMixin:
         micro-batch paid are paid once.  Padded positions sit behind every real one of their sequence: they change neither the
         real outputs nor (with a zero output gradient) any parameter gradient.
         -> (douts [U_max, B_tot, H] time-major, stash for rnnt_recurrency_bwd, [(b0, b1, U_k)] per micro-batch)"""
-        with ops.stream_scope():
+        with self._scope():
             mats = [torch.as_tensor(y).to(torch.int32) for y in ys_in_list]
             Umax, Btot = max(m.shape[1] for m in mats), sum(m.shape[0] for m in mats)
             ids = torch.zeros(Btot, Umax, dtype=torch.int32)
@@ -1393,7 +1409,7 @@ class _RNNTMixin:
         micro-batches at once (rnnt_prediction_stacked); rnnt_backward then leaves its gradient in st.ddouts
         defer_lattice (fused output layer only): the lattice runs on a side stream and the first value returned is None; the
         caller does other work of the micro-batch (the auxiliary CTC branch), then calls rnnt_lattice_join(st) -> loss"""
-        with ops.stream_scope():
+        with self._scope():
             A, J = self.arena, self.r_J
             B, T, d = eouts.shape
             dev = eouts.device
@@ -1453,7 +1469,7 @@ class _RNNTMixin:
         """-> d_eouts [B,T,d]; accumulates decoder gradients (the logits buffer is overwritten by its gradient).
         extra_dlogits [B*T*U,V] (or (rows int64 [R], [R,V])): gradient of another loss on the same logits
         (distillation), added in."""
-        with ops.stream_scope():
+        with self._scope():
             A, J, H = self.arena, self.r_J, self.r_H
             A.attach_grads()
             B, T, U = st.B, st.T, st.U
@@ -1536,7 +1552,7 @@ class _RNNTMixin:
         non-blank one on the device and brings (index, token) back with one 8-byte copy -- one host round
         trip per emitted label (plus one per all-blank window) instead of one per frame.  The sequence of
         (frame, token) decisions is exactly the reference's."""
-        with ops.stream_scope(), torch.no_grad():
+        with self._scope(), torch.no_grad():
             A, J = self.arena, self.r_J
             A.refresh_shadow()
             dev = eouts.device
@@ -1657,7 +1673,7 @@ class _RNNTMixin:
             return st, st.graphs[key]
 
         def body():
-            with ops.stream_scope():
+            with self._scope():
                 ids = st.ctl[:nb].to(torch.int32).view(1, nb)
                 src, dst, t = st.ctl[16:16 + nb], st.ctl[32:32 + nb], st.ctl[48:49]
                 prev = ([p.index_select(0, src) for p in st.ph], [p.index_select(0, src) for p in st.pc])
@@ -1697,7 +1713,7 @@ class _RNNTMixin:
         (stable sort by float64 score, merge of equal label sequences by log-add, cut to the beam) stays on the host, as in the
         reference and in _rnnt_beam_search_chain, whose arithmetic and launch order the captured body repeats."""
         import numpy as np
-        with ops.stream_scope(), torch.no_grad():
+        with self._scope(), torch.no_grad():
             A, J = self.arena, self.r_J
             A.refresh_shadow()
             T = eouts.shape[1]
@@ -1764,7 +1780,7 @@ class _RNNTMixin:
         of equal label sequences by log-add, cut to the beam) stays on the host like the reference.
         Returns the surviving label sequences best-first, including the leading <sos>."""
         import numpy as np
-        with ops.stream_scope(), torch.no_grad():
+        with self._scope(), torch.no_grad():
             A, J, H, nl = self.arena, self.r_J, self.r_H, self.r_nl
             A.refresh_shadow()
             dev = eouts.device

@@ -4,8 +4,10 @@
     loss, loss_dict = model(xs, xlens, ys, ylens, ys_in, ys_out)       # loss.backward() works
     hyps, scores, logits, aligns = model.decode(xs, xlens, beam_width=1)
 
-`compute_dtype`: torch.bfloat16 (throughput mode; f32 accumulation, statistics and lattices)
-or torch.float32 (parity mode: exact-f32 MFMA).
+`compute_dtype`: torch.bfloat16 (throughput mode; f32 accumulation, statistics and lattices),
+torch.float32 (parity mode: exact-f32 MFMA) or "f32x3" (f32 storage, every matrix product as three bf16
+MFMAs over (hi, lo) operand pairs: 16 significand bits per operand -- meets the 1e-3 bars of the reference
+comparison at several times the exact mode's speed; csrc/gemm.hip SplitCfg).
 """
 import logging
 
@@ -16,13 +18,18 @@ from .decoders.ctc import CTCDecoder
 from .encoders.transformer import TransformerEncoder
 
 
+F32X3 = "f32x3"   # compute_dtype of the split mode (see the module docstring)
+
+
 class ASR(nn.Module):
     def __init__(self, params, phase="train", compute_dtype=torch.bfloat16):
         super().__init__()
         self.encoder_type = params.encoder_type
         self.decoder_type = params.decoder_type
         self.params = params
-        self.compute_dtype = compute_dtype
+        # "f32x3": f32 storage and statistics, every matrix product as three bf16 MFMAs over (hi, lo) operand pairs
+        self.f32_split = compute_dtype == F32X3
+        self.compute_dtype = torch.float32 if self.f32_split else compute_dtype
         if self.encoder_type not in ("transformer", "conformer"):
             raise NotImplementedError(f"emoasr_amd: encoder_type={self.encoder_type!r} is outside the HIP hot path")
         self.encoder = TransformerEncoder(params, is_conformer=(self.encoder_type == "conformer"))
@@ -48,8 +55,9 @@ class ASR(nn.Module):
 
     def engine(self):
         from ..engine import CTCEngine
-        if self._engine is None or self._engine.dtype != self.compute_dtype:
-            self._engine = CTCEngine(self.params, self, self.compute_dtype)
+        if self._engine is None or self._engine.dtype != self.compute_dtype or self._engine.split != self.f32_split:
+            self._engine = CTCEngine(self.params, self, self.compute_dtype, f32_split=self.f32_split)
+        self._engine._apply_mode()
         return self._engine
 
     def forward(self, xs, xlens, ys, ylens, ys_in, ys_out, soft_labels=None, ps=None, plens=None):

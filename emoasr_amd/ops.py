@@ -33,14 +33,32 @@ def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_F32_SPLIT = 0
+
+
+def set_f32_split(on):
+    """library option "f32_split" (csrc/gemm.hip SplitCfg): f32 products as three bf16 MFMAs over (hi, lo) operand pairs.  The
+    option is process-wide; every engine re-asserts its own mode at its entry points (CTCEngine._apply_mode)."""
+    global _F32_SPLIT
+    on = 1 if on else 0
+    if on != _F32_SPLIT:
+        lib.set_option("f32_split", on)
+        _F32_SPLIT = on
+
+
 class stream_scope:
     """Resolve torch's current stream once for a whole forward/backward sequence (the lookup costs
-    more than a kernel launch when done per op)."""
+    more than a kernel launch when done per op).  f32_split: also assert that mode of the f32 products (None: leave it)."""
+
+    def __init__(self, f32_split=None):
+        self.f32_split = f32_split
 
     def __enter__(self):
         global _STREAM_CACHE
         self.prev = _STREAM_CACHE
         _STREAM_CACHE = c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self.f32_split is not None:
+            set_f32_split(self.f32_split)
         return self
 
     def __exit__(self, *exc):

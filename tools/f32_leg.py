@@ -19,7 +19,8 @@ from emoasr_amd.modeling.asr import ASR  # noqa: E402
 from emoasr_amd.train import ArenaAdam, noam_lr  # noqa: E402
 
 torch.manual_seed(0)
-m32 = ASR(SimpleNamespace(**bench.L2), compute_dtype=torch.float32).to(dev).train()
+MODE = "f32x3" if "--split" in sys.argv else torch.float32   # --split: f32 storage, split-bf16 products
+m32 = ASR(SimpleNamespace(**bench.L2), compute_dtype=MODE).to(dev).train()
 opt = ArenaAdam(m32.engine().arena, lambda s: noam_lr(bench.OPT["lr"], 256, bench.OPT["warmup"], s),
                 weight_decay=bench.OPT["weight_decay"], clip_grad_norm=bench.OPT["clip_grad_norm"])
 
@@ -39,4 +40,4 @@ for bt in batches[3:9]:
     step(bt)
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
-print(f"f32: {sum(sum(b.xlens) for b in batches[3:9]) / el:.0f} frames/s, {1e3 * el / 6:.2f} ms per step")
+print(f"{'f32x3' if MODE == 'f32x3' else 'f32'}: {sum(sum(b.xlens) for b in batches[3:9]) / el:.0f} frames/s, {1e3 * el / 6:.2f} ms per step")
