@@ -2,10 +2,41 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include "common.h"
 #include "../../include/emoasr_hip.h"
 
 static thread_local char g_err[512] = "";
+
+// see common.h
+EmoScratch* emo_stream_scratch(int slot, void* stream, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, void*, int>, EmoScratch*> tab;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_tuple(dev, stream, slot);
+  auto it = tab.find(key);
+  if (it != tab.end() && it->second->bytes >= bytes) return it->second;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    emo_set_error("stream scratch %d: first use on a stream that is being captured (run the call once eagerly on this stream)", slot);
+    return nullptr;
+  }
+  void* d = nullptr;
+  // cleared ON the stream that will use the area (ordered before its first launch there): a hipMemset on the null stream is not
+  // ordered against a non-blocking stream, and a launch that started on a half-cleared barrier counter gave up waiting
+  if (hipMalloc(&d, bytes) != hipSuccess || hipMemsetAsync(d, 0, bytes, (hipStream_t)stream) != hipSuccess) {
+    emo_set_error("stream scratch %d: allocation of %zu bytes failed", slot, bytes);
+    return nullptr;
+  }
+  EmoScratch* r = new EmoScratch{};   // (a grown area replaces the record; the old device area is leaked on purpose: launches may still use it)
+  r->dev = d; r->bytes = bytes;
+  tab[key] = r;
+  return r;
+}
 
 void emo_set_error(const char* fmt, ...) {
   va_list ap;
@@ -58,6 +89,7 @@ void emo_attn_set_fw(int v);
 void emo_attn_set_bwd_split(int v);
 void emo_attn_set_kv_dbg(int v);
 void emo_attn_set_side(int v);
+void emo_attn_set_side_prio(int v);
 void emo_attn_set_lpt(int v);
 void emo_attn_set_fwd_split(int v);
 void emo_attn_set_xcd(int v);
@@ -192,6 +224,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "attn_bwd_split") == 0) { emo_attn_set_bwd_split(value); return 0; }
   if (strcmp(name, "attn_kv_dbg") == 0) { emo_attn_set_kv_dbg(value); return 0; }
   if (strcmp(name, "attn_side") == 0) { emo_attn_set_side(value); return 0; }
+  if (strcmp(name, "attn_side_prio") == 0) { emo_attn_set_side_prio(value); return 0; }
   if (strcmp(name, "attn_lpt") == 0) { emo_attn_set_lpt(value); return 0; }
   if (strcmp(name, "attn_fwd_split") == 0) { emo_attn_set_fwd_split(value); return 0; }
   if (strcmp(name, "attn_xcd") == 0) { emo_attn_set_xcd(value); return 0; }

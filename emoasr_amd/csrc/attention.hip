@@ -2766,6 +2766,7 @@ FusedExtras g_fused_extras{};
 //                                `stream` wait for it (csrc/layer.hip: right before the grouped weight-gradient launch)
 // Callers that know nothing of this (ops.attn_bwd) get the join inside the call: same stream semantics as before.
 int g_attn_side = 1;
+int g_side_prio = 0;
 hipStream_t g_side = nullptr;
 hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_mask = nullptr;
 bool g_join_pending = false, g_defer_join = false;
@@ -2774,7 +2775,13 @@ struct MaskTag { const void* buf = nullptr; uint64_t seed = 0; long nrows = -1; 
 bool side_ready() {
   if (!g_attn_side) return false;
   if (g_side) return true;
-  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; g_attn_side = 0; return false; }
+  // option "attn_side_prio" = 1: the side stream at the LOWEST priority -- its launches (keep mask, Q + bias copies, table gradient)
+  // are low-occupancy fillers that should take idle slots, not compete with the chain's kernels for dispatch
+  int lo = 0, hi = 0;
+  hipError_t ce = hipSuccess;
+  if (g_side_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) ce = hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, lo);
+  else ce = hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
+  if (ce != hipSuccess) { g_side = nullptr; g_attn_side = 0; return false; }
   hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming);
   hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming);
   hipEventCreateWithFlags(&g_ev_mask, hipEventDisableTiming);
@@ -3026,6 +3033,7 @@ void emo_attn_bwd_fused_extras(float* zero, long zn, const float* cast_src, void
 }
 
 void emo_attn_set_side(int v) { g_attn_side = v ? 1 : 0; }
+void emo_attn_set_side_prio(int v) { g_side_prio = v ? 1 : 0; }   // (takes effect when the side stream is created)
 void emo_attn_bwd_defer_join(int v) { g_defer_join = v != 0; }
 void emo_attn_bwd_join(void* stream) { side_join((hipStream_t)stream); }
 // Everything of the next emoasr_attn_bwd_fused(a, ws) call that depends on FORWARD data only, now, on the side stream: the keep

@@ -465,6 +465,14 @@ __device__ __forceinline__ float log_add3(float a, float b, float c) {
 // host-side launch helpers
 // ---------------------------------------------------------------------------
 void emo_set_error(const char* fmt, ...);
+// Small device scratch areas that kernels of ONE stream hand from launch to launch (arrival tickets, partial sums, barrier
+// counters): one zero-initialised area per (device, stream, slot), so that launches on different streams -- the attention
+// backward's side stream, the transducer lattice under the CTC branch, two engines on two streams -- never share one.  `host` is a
+// few words of host-side state that belong to the same area (the cooperative LSTM's expected barrier values).  Allocation happens
+// on first use and needs an eager (non-capturing) call; a stream that is being captured may only use an area it has used before.
+struct EmoScratch { void* dev; size_t bytes; unsigned host[32]; };
+enum { EMO_SCRATCH_BN_TICKETS = 0, EMO_SCRATCH_SQNORM = 1, EMO_SCRATCH_LSTM = 2 };
+EmoScratch* emo_stream_scratch(int slot, void* stream, size_t bytes);
 #define EMO_CHECK(cond, ...)            \
   do {                                  \
     if (!(cond)) {                      \

@@ -72,12 +72,18 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const
 // running_var gets the unbiased M2 / (M - 1) like nn.BatchNorm1d.  One block = 16 channels x 64
 // groups of partial blocks (16 blocks for C = 256: the partial table is walked in 7 steps, not 28).
 constexpr int BNF_CH = 16, BNF_G = 64;  // channels x groups of partial blocks per finalize block
-__device__ unsigned g_bn_tickets[2][64];   // arrival tickets per channel group ([0] statistics, [1] backward fold): zero between launches
+// arrival tickets per channel group ([0][64] statistics, [1][64] backward fold; zero between launches): `tickets` argument, one
+// area per (device, stream) from emo_stream_scratch -- a __device__ array was shared by every stream of the process
+#define EMO_BN_TICKETS(stream_)                                                                   \
+  EmoScratch* tsc_ = emo_stream_scratch(EMO_SCRATCH_BN_TICKETS, (void*)(stream_), 2 * 64 * sizeof(unsigned)); \
+  if (!tsc_) return 1;                                                                            \
+  unsigned* tickets_ = static_cast<unsigned*>(tsc_->dev)
 __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B_, int Tn_, int C, const float* __restrict__ part_,
                                                                  float* __restrict__ mean_, float* __restrict__ var_,
                                                                  float* __restrict__ running_mean,
                                                                  float* __restrict__ running_var, float momentum,
-                                                                 long long* __restrict__ num_batches_tracked, const RowSegs sg) {
+                                                                 long long* __restrict__ num_batches_tracked, const RowSegs sg,
+                                                                 unsigned* __restrict__ tickets) {
   __shared__ float red[BNF_G][BNF_CH];
   __shared__ float mean_s[BNF_CH];
   __shared__ int s_last;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B_, int Tn_
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
-    s_last = atomicAdd(&g_bn_tickets[0][blockIdx.x], 1u) == (unsigned)ns - 1;
+    s_last = atomicAdd(&tickets[blockIdx.x], 1u) == (unsigned)ns - 1;
   }
   __syncthreads();
   if (!s_last) return;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B_, int Tn_
     if (running_var) running_var[c] = rv;
   }
   if (threadIdx.x == 0) {
-    g_bn_tickets[0][blockIdx.x] = 0u;
+    tickets[blockIdx.x] = 0u;
     if (num_batches_tracked && blockIdx.x == 0) *num_batches_tracked += ns;
   }
 }
@@ -381,7 +387,8 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(int M, int C, const T*
 // partial rows per block, like bn_stats_finalize_kernel); also dbeta += sum dbn, dgamma += sum dbn*xhat.
 __global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(int npart_, int C, float inv_m_, const float* __restrict__ part_,
                                                            float* __restrict__ tot_, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, const RowSegs sg) {
+                                                           float* __restrict__ dbeta, const RowSegs sg,
+                                                           unsigned* __restrict__ tickets) {
   __shared__ float red[2][64][16];
   __shared__ int s_last;
   const int lane = threadIdx.x % 16, grp = threadIdx.x / 16;
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(int npart_, int C, fl
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
-    s_last = atomicAdd(&g_bn_tickets[1][blockIdx.x], 1u) == (unsigned)ns - 1;
+    s_last = atomicAdd(&tickets[64 + blockIdx.x], 1u) == (unsigned)ns - 1;
   }
   __syncthreads();
   if (!s_last) return;
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(int npart_, int C, fl
     if (dbeta) dbeta[c] += da;
     if (dgamma) dgamma[c] += db;
   }
-  if (threadIdx.x == 0) g_bn_tickets[1][blockIdx.x] = 0u;
+  if (threadIdx.x == 0) tickets[64 + blockIdx.x] = 0u;
 }
 // pass 3: dy = gamma*invstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat))
 template <typename T>
@@ -527,8 +534,9 @@ extern "C" int emoasr_bn_stats_finalize(int B, int Tn, int C, const float* part,
                                         long long* num_batches_tracked, void* stream) {
   EMO_CHECK(B * Tn > 0, "bn_stats_finalize: empty batch");
   EMO_CHECK(cdiv(C, BNF_CH) <= 64, "bn_stats_finalize: C=%d too wide for the ticket table", C);
+  EMO_BN_TICKETS(stream);
   bn_stats_finalize_kernel<<<cdiv(C, BNF_CH), 1024, 0, (hipStream_t)stream>>>(B, Tn, C, part, mean, var, running_mean,
-                                                                          running_var, momentum, num_batches_tracked, RowSegs{});
+                                                                          running_var, momentum, num_batches_tracked, RowSegs{}, tickets_);
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -611,7 +619,8 @@ extern "C" int emoasr_bn_swish_bwd_sums(int dtype, int M, int C, const void* dz,
   EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<sgrid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
                                                                   var, gamma, beta, eps, scratch, RowSegs{})));
   float* tot = scratch + (long)npart * 2 * C;
-  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta, RowSegs{});
+  EMO_BN_TICKETS(s);
+  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta, RowSegs{}, tickets_);
   if (tot_out) *tot_out = tot;
   EMO_LAUNCH_CHECK();
   return 0;
@@ -631,7 +640,8 @@ extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, cons
   EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<sgrid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
                                                                   var, gamma, beta, eps, scratch, RowSegs{})));
   float* tot = scratch + (long)npart * 2 * C;
-  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta, RowSegs{});
+  EMO_BN_TICKETS(s);
+  bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta, RowSegs{}, tickets_);
   EMO_DISPATCH(dtype, (bn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
                                                                   var, gamma, beta, eps, tot, (T*)dy)));
   EMO_LAUNCH_CHECK();
@@ -642,8 +652,9 @@ extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, cons
 int emo_bn_stats_finalize_seg(const RowSegs& sg, int C, const float* part, float* mean, float* var, float* running_mean,
                               float* running_var, float momentum, long long* nbt, hipStream_t s) {
   EMO_CHECK(cdiv(C, BNF_CH) <= 64, "bn_stats_finalize: C=%d too wide for the ticket table", C);
+  EMO_BN_TICKETS(s);
   bn_stats_finalize_kernel<<<dim3(cdiv(C, BNF_CH), sg.n > 1 ? sg.n : 1), 1024, 0, s>>>(sg.b0[1], sg.T[0], C, part, mean, var,
-                                                                                     running_mean, running_var, momentum, nbt, sg);
+                                                                                     running_mean, running_var, momentum, nbt, sg, tickets_);
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -671,8 +682,9 @@ int emo_bn_swish_bwd_sums_seg(const RowSegs& sg, int C, const void* dz, const vo
                                                 sg);
   float* tot = scratch + sg.sums[sg.n] * 2 * C;
   EMO_CHECK(cdiv(C, 16) <= 64, "bn_swish_bwd_sums_seg: C=%d too wide for the ticket table", C);
+  EMO_BN_TICKETS(s);
   bn_bwd_fold_kernel<<<dim3(cdiv(C, 16), sg.n > 1 ? sg.n : 1), 1024, 0, s>>>((int)sg.sums[1], C, 1.f / (float)sg.row[1], scratch, tot,
-                                                                         dgamma, dbeta, sg);
+                                                                         dgamma, dbeta, sg, tickets_);
   if (tot_out) *tot_out = tot;
   EMO_LAUNCH_CHECK();
   return 0;

@@ -303,7 +303,7 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     return emoasr_gemm_nn(dtype, M, d, n_out, dy_, n_out, W, d, dx_, d, &e_, stream);
   };
   auto ffn_bwd = [&](const emoasr_ffn_params_t& P, const emoasr_ffn_params_t& Gp, const emoasr_ffn_stash_t& S, const void* x_in,
-                     const void* dx_in, const void* pre_in, void* du, uint64_t s_in, const void* w1t) {
+                     const void* dx_in, const void* pre_in, void* du, uint64_t s_in, const void* w1t, const void* w2t) {
     const void* dy = p > 0.f ? pre_in : dx_in;
     const float alpha = p > 0.f ? 1.f : 0.5f;
     wgrad(dy, d, d, S.a, F, F, M, Gp.w2, alpha, Gp.b2);
@@ -311,7 +311,9 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     e.alpha = alpha; e.dact_pre = S.u; e.seed = s_in;
     if (g_ffn_save_dact) { e.dact = EMOASR_DACT_MUL; e.drop_p = 0.f; }   // S.u holds Swish'(u) * dropout_scale (ffn_fwd)
     else { e.dact = EMOASR_ACT_SWISH; e.drop_p = p; }
-    if (emoasr_gemm_nn(dtype, M, F, d, dy, d, P.w2, F, du, F, &e, stream)) return 1;
+    // du = (dy . W2) * factor: against the transposed copy W2^T [F, d] as an NT product when the layer carries one
+    if (w2t ? emoasr_gemm_nt(dtype, M, F, d, dy, d, w2t, d, du, F, &e, stream)
+            : emoasr_gemm_nn(dtype, M, F, d, dy, d, P.w2, F, du, F, &e, stream)) return 1;
     wgrad(du, F, F, S.h, d, d, M, Gp.w1, 1.f, Gp.b1);
     return dgrad(F, du, P.w1, w1t, ws + bb.dh);
   };
@@ -329,7 +331,7 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
   if (ln_bwd(0, io->dy, st->ff.y, L->fin_ln_g, st->fin_mean, st->fin_rstd, nullptr, ws + bb.dx1, G->fin_ln_g, G->fin_ln_b,
              ws + bb.pre1, 0.5f, st->seed[6])) return 1;
   // ---- feed-forward -----------------------------------------------------------------------------------------------
-  if (ffn_bwd(L->ff, G->ff, st->ff, st->cv_y, ws + bb.dx1, ws + bb.pre1, ws + bb.du_ff, st->seed[5], L->ff_w1t)) return 1;
+  if (ffn_bwd(L->ff, G->ff, st->ff, st->cv_y, ws + bb.dx1, ws + bb.pre1, ws + bb.du_ff, st->seed[5], L->ff_w1t, L->ff_w2t)) return 1;
   if (ln_bwd(1, ws + bb.dh, st->cv_y, L->ff.ln_g, st->ff.mean, st->ff.rstd, ws + bb.dx1, ws + bb.dx2, G->ff.ln_g, G->ff.ln_b,
              ws + bb.pre2, 1.f, st->seed[4])) return 1;
   // ---- convolution module -----------------------------------------------------------------------------------------
@@ -337,7 +339,8 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     const void* dy = p > 0.f ? ws + bb.pre2 : ws + bb.dx2;
     wgrad(dy, d, d, st->z, d, d, M, G->pw2, 1.f, G->pw2_b);
     emoasr_epilogue_t e = plain_ep();
-    if (emoasr_gemm_nn(dtype, M, d, d, dy, d, L->pw2, d, ws + bb.dz, d, &e, stream)) return 1;
+    if (L->pw2_t ? emoasr_gemm_nt(dtype, M, d, d, dy, d, L->pw2_t, d, ws + bb.dz, d, &e, stream)
+                 : emoasr_gemm_nn(dtype, M, d, d, dy, d, L->pw2, d, ws + bb.dz, d, &e, stream)) return 1;
     if (conv_fused_ok(dtype, d)) {
       // BatchNorm sums + fold, then ONE launch for BatchNorm/Swish apply -> depthwise data gradient -> GLU backward and the
       // depthwise weight-gradient partials (the GLU output is recomputed from g)
@@ -382,7 +385,8 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     const void* dy = p > 0.f ? ws + bb.pre3 : ws + bb.dx3;
     wgrad(dy, d, d, st->o, d, d, M, G->wout, 1.f, G->bout);
     emoasr_epilogue_t e = plain_ep();
-    if (emoasr_gemm_nn(dtype, M, d, d, dy, d, L->wout, d, ws + bb.dout, d, &e, stream)) return 1;
+    if (L->wout_t ? emoasr_gemm_nt(dtype, M, d, d, dy, d, L->wout_t, d, ws + bb.dout, d, &e, stream)
+                  : emoasr_gemm_nn(dtype, M, d, d, dy, d, L->wout, d, ws + bb.dout, d, &e, stream)) return 1;
     // all stacked micro-batches in one set of launches (segment table in the arguments), or one set each (workspace reused)
     const int astep = g_stack_launch ? sv.n : 1;
     for (int si = 0; si < sv.n; si += astep) {
@@ -411,7 +415,7 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
                G->att_ln_b, ws + bb.pre4, 0.5f, st->seed[1])) return 1;
   }
   // ---- macaron feed-forward ---------------------------------------------------------------------------------------
-  if (ffn_bwd(L->ffm, G->ffm, st->ffm, st->x, ws + bb.dx4, ws + bb.pre4, ws + bb.du_ffm, st->seed[0], L->ffm_w1t)) return 1;
+  if (ffn_bwd(L->ffm, G->ffm, st->ffm, st->x, ws + bb.dx4, ws + bb.pre4, ws + bb.du_ffm, st->seed[0], L->ffm_w1t, L->ffm_w2t)) return 1;
   if (ln_bwd(4, ws + bb.dh, st->x, L->ffm.ln_g, st->ffm.mean, st->ffm.rstd, ws + bb.dx4, io->dx, G->ffm.ln_g, G->ffm.ln_b,
              nullptr, 0.f, 0)) return 1;
   // ---- the layer's weight gradients, one launch -----------------------------------------------------------------------

@@ -27,6 +27,9 @@
 //
 // Reference: decoders/rnn_transducer.py:96-135 (nn.LSTM prediction network), torch LSTM gate order i, f, g, o.
 #include <math.h>
+#include <algorithm>
+#include <mutex>
+#include <vector>
 #include "common.h"
 #include "../../include/emoasr_hip.h"
 
@@ -289,23 +292,39 @@ __global__ __launch_bounds__(LT) void lstm_seq_bwd_kernel(const LstmBwdArgs a) {
 }
 
 constexpr int L_CNT_BYTES = 4096;   // [2 directions][L_MAXGRP groups] counters, 64 bytes apart; the error flag behind them
-unsigned* lstm_counter(int which, int** err) {
-  static unsigned* buf = nullptr;
-  if (!buf) {
-    if (hipMalloc(&buf, L_CNT_BYTES) != hipSuccess || hipMemset(buf, 0, L_CNT_BYTES) != hipSuccess) return nullptr;
+// The barrier counters and the host-tracked value each one holds at the start of the next launch belong to ONE stream: launches on
+// a stream are ordered, so the host knows the counter's value without reading it back.  One area per (device, stream)
+// (emo_stream_scratch: EmoScratch::host carries the expected values, [direction][group]); the launches refuse a capturing stream --
+// a replayed graph would start from counter values the host no longer tracks.
+static_assert(2 * L_MAXGRP <= 32, "expected counter values live in EmoScratch::host");
+std::mutex g_lstm_mu;
+std::vector<EmoScratch*> g_lstm_areas;   // every area handed out (emoasr_lstm_coop_status walks them)
+EmoScratch* lstm_area(void* stream) {
+  EmoScratch* sc = emo_stream_scratch(EMO_SCRATCH_LSTM, stream, L_CNT_BYTES);
+  if (sc) {
+    std::lock_guard<std::mutex> lock(g_lstm_mu);
+    if (std::find(g_lstm_areas.begin(), g_lstm_areas.end(), sc) == g_lstm_areas.end()) g_lstm_areas.push_back(sc);
   }
+  return sc;
+}
+unsigned* lstm_counter(EmoScratch* sc, int which, int** err) {
+  unsigned* buf = static_cast<unsigned*>(sc->dev);
   *err = reinterpret_cast<int*>(buf) + 2 * L_MAXGRP * 16;
   return buf + 16 * L_MAXGRP * which;
+}
+bool lstm_capturing(void* stream) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
 }
 
 int g_lstm_coop = 1;
 
 // counter value at the start of the next launch, per counter (0 forward, 1 backward); launches are stream-ordered
-unsigned g_lstm_base[2][L_MAXGRP] = {};
-void lstm_base(int which, int G, int U, int ngrp, unsigned (&base)[L_MAXGRP]) {
+void lstm_base(EmoScratch* sc, int which, int G, int U, int ngrp, unsigned (&base)[L_MAXGRP]) {
+  unsigned* tracked = sc->host + which * L_MAXGRP;
   for (int i = 0; i < L_MAXGRP; ++i) {
-    base[i] = g_lstm_base[which][i];
-    if (i < ngrp) g_lstm_base[which][i] += (unsigned)G * (unsigned)(U - 1);
+    base[i] = tracked[i];
+    if (i < ngrp) tracked[i] += (unsigned)G * (unsigned)(U - 1);
   }
 }
 int lstm_groups(int B) { return (B + L_MAXB - 1) / L_MAXB; }
@@ -366,14 +385,16 @@ extern "C" int emoasr_lstm_seq_fwd(int dtype, int U, int B, int H, const void* p
   a.U = U; a.B = B; a.H = H;
   a.pre = (const bf16*)pre; a.w_hh = (const bf16*)w_hh; a.h0 = (const bf16*)h0; a.c0 = c0;
   a.hseq = (bf16*)hseq; a.cseq = cseq; a.gact = (bf16*)gact;
-  a.counter = lstm_counter(0, &a.err);
-  EMO_CHECK(a.counter, "lstm_seq_fwd: counter allocation failed");
+  EMO_CHECK(!lstm_capturing(stream), "lstm_seq_fwd: the cooperative recurrence cannot be captured into a graph (host-tracked barrier values)");
+  EmoScratch* sc = lstm_area(stream);
+  if (!sc) return 1;
+  a.counter = lstm_counter(sc, 0, &a.err);
   const size_t smem = lstm_fwd_smem(H);
   const long cap = lstm_cap_of(0, H);
   const int ngrp = lstm_groups(B);
   a.G = H / 16;
   EMO_CHECK(cap >= (long)a.G * ngrp, "lstm_seq_fwd: the device holds %ld of the %d workgroups at once", cap, a.G * ngrp);
-  lstm_base(0, a.G, U, ngrp, a.base);
+  lstm_base(sc, 0, a.G, U, ngrp, a.base);
   lstm_seq_fwd_kernel<<<a.G * ngrp, LT, smem, (hipStream_t)stream>>>(a);
   EMO_LAUNCH_CHECK();
   return 0;
@@ -393,14 +414,16 @@ extern "C" int emoasr_lstm_seq_bwd(int dtype, int U, int B, int H, const void* d
   a.U = U; a.B = B; a.H = H;
   a.dh_seq = (const bf16*)dh_seq; a.gact = (const bf16*)gact; a.cseq = cseq; a.c0 = c0; a.w_hh = (const bf16*)w_hh;
   a.dgp = (bf16*)dgp; a.part = (float*)ws;
-  a.counter = lstm_counter(1, &a.err);
-  EMO_CHECK(a.counter, "lstm_seq_bwd: counter allocation failed");
+  EMO_CHECK(!lstm_capturing(stream), "lstm_seq_bwd: the cooperative recurrence cannot be captured into a graph (host-tracked barrier values)");
+  EmoScratch* sc = lstm_area(stream);
+  if (!sc) return 1;
+  a.counter = lstm_counter(sc, 1, &a.err);
   const size_t smem = lstm_bwd_smem(H);
   const long cap = lstm_cap_of(1, H);
   const int ngrp = lstm_groups(B);
   a.G = H / 16;
   EMO_CHECK(cap >= (long)a.G * ngrp, "lstm_seq_bwd: the device holds %ld of the %d workgroups at once", cap, a.G * ngrp);
-  lstm_base(1, a.G, U, ngrp, a.base);
+  lstm_base(sc, 1, a.G, U, ngrp, a.base);
   lstm_seq_bwd_kernel<<<a.G * ngrp, LT, smem, (hipStream_t)stream>>>(a);
   EMO_LAUNCH_CHECK();
   return 0;
@@ -409,15 +432,24 @@ extern "C" int emoasr_lstm_seq_bwd(int dtype, int U, int B, int H, const void* d
 // error flag of the recurrence kernels' barriers (a wait that gave up): 0 = fine.  Synchronises the device; a reported
 // failure is cleared (flag and both counters back to zero), so the launches that follow start from a clean state.
 extern "C" long emoasr_lstm_coop_status(void) {
-  int* err = nullptr;
-  unsigned* c = lstm_counter(0, &err);
-  if (!c) return -1;
-  int e = 0;
-  if (hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if (e) {
-    if (hipDeviceSynchronize() != hipSuccess || hipMemset(c, 0, L_CNT_BYTES) != hipSuccess) return -1;
-    for (int w = 0; w < 2; ++w)
-      for (int i = 0; i < L_MAXGRP; ++i) g_lstm_base[w][i] = 0u;
+  std::vector<EmoScratch*> areas;
+  {
+    std::lock_guard<std::mutex> lock(g_lstm_mu);
+    areas = g_lstm_areas;
   }
-  return e;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  long any = 0;
+  for (EmoScratch* sc : areas) {   // every stream's area of this process (areas of other devices answer through their own pointers)
+    int* err = nullptr;
+    unsigned* c = lstm_counter(sc, 0, &err);
+    int e = 0;
+    if (hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (e) {
+      if (hipDeviceSynchronize() != hipSuccess || hipMemset(c, 0, L_CNT_BYTES) != hipSuccess) return -1;
+      for (int i = 0; i < 2 * L_MAXGRP; ++i) sc->host[i] = 0u;
+      any = e;
+    }
+  }
+  return any;
 }

@@ -86,12 +86,11 @@ inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 4096 ? 4
 extern "C" int emoasr_sqnorm(long n, const float* x, float* out, void* stream) {
   if (n == 0) return 0;
   EMO_CHECK(((uintptr_t)x & 15) == 0, "sqnorm: buffer must be 16-byte aligned");
-  // at most 1024 blocks, each leaving one partial sum; calls are stream-ordered (one scratch per process)
-  static float* scratch = nullptr;
-  if (!scratch) {
-    EMO_CHECK(hipMalloc(&scratch, 1025 * sizeof(float)) == hipSuccess && hipMemset(scratch, 0, 1025 * sizeof(float)) == hipSuccess,
-              "sqnorm: scratch allocation failed");
-  }
+  // at most 1024 blocks, each leaving one partial sum + the arrival counter: one area per (device, stream) -- calls on one stream are
+  // ordered, calls on two streams (two engines, a data-parallel rehearsal on one GPU) no longer share the partials
+  EmoScratch* sc = emo_stream_scratch(EMO_SCRATCH_SQNORM, stream, 1025 * sizeof(float));
+  if (!sc) return 1;
+  float* scratch = static_cast<float*>(sc->dev);
   sqnorm_kernel<<<std::min(ew_grid(n / 4 + 1), 1024), 256, 0, (hipStream_t)stream>>>(n, x, out, scratch,
                                                                                      reinterpret_cast<unsigned*>(scratch + 1024));
   EMO_LAUNCH_CHECK();

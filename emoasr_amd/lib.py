@@ -138,7 +138,8 @@ class ConformerLayer(Structure):
                 ("dw_w", c_void_p), ("dw_b", c_void_p), ("bn_g", c_void_p), ("bn_b", c_void_p),
                 ("bn_rm", c_void_p), ("bn_rv", c_void_p), ("bn_nbt", c_void_p), ("pw2", c_void_p), ("pw2_b", c_void_p),
                 ("fin_ln_g", c_void_p), ("fin_ln_b", c_void_p),
-                ("ffm_w1t", c_void_p), ("ff_w1t", c_void_p), ("wqkv_t", c_void_p), ("pw1_t", c_void_p)]
+                ("ffm_w1t", c_void_p), ("ff_w1t", c_void_p), ("wqkv_t", c_void_p), ("pw1_t", c_void_p),
+                ("ffm_w2t", c_void_p), ("ff_w2t", c_void_p), ("wout_t", c_void_p), ("pw2_t", c_void_p)]
 
 
 class TcItem(Structure):

@@ -571,6 +571,9 @@ typedef struct emoasr_conformer_layer {
    * onto one 256-column tile -- ffm / ff w1 as [d,F], wqkv as [d,3d], pw1 as [d,2d] (emoasr_transpose_cast_batched keeps them
    * current).  dX = dY . W is then the NT product dY . (W^T)^T, which the large-tile kernel takes (csrc/gemm_big.hip). */
   const void *ffm_w1t, *ff_w1t, *wqkv_t, *pw1_t;
+  /* likewise optional (round 5): transposed copies of the K = d products' weights -- ffm / ff w2 as [F,d], wout and pw2 as [d,d] --
+   * so that their data gradients run as NT products too (the k-major B tile of the NN form is read with transposing LDS loads) */
+  const void *ffm_w2t, *ff_w2t, *wout_t, *pw2_t;
 } emoasr_conformer_layer_t;
 typedef struct emoasr_ffn_stash {
   void *h, *u, *a, *y;               /* LN out [M,d], pre-activation [M,F] (optional), activation [M,F], block output [M,d] */

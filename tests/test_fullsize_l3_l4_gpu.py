@@ -139,12 +139,17 @@ def test_l3_teacher_forced_loss_and_grads_full_size(dev, dtype):
         assert cos > (0.9995 if dtype == torch.float32 else 0.97), (name, cos)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, "f32x3", torch.bfloat16], ids=["f32", "f32x3", "bf16"])
 def test_l4_transducer_full_size(dev, dtype):
+    """the transducer gradient has no reference-held pin (the reference calls warp_rnnt): at the full model size it is held to
+    the oracle's autograd through the path-enumeration-validated lattice restatement (oracle/rnnt.py) -- f32 / f32x3: every
+    sampled parameter gradient cosine >= 0.9999 (printed)"""
     from emoasr_amd.modeling.asr import ASR
     from oracle import model as om, rnnt as orn
     torch.manual_seed(0)
+    mode = dtype
     model = ASR(SimpleNamespace(**L4), compute_dtype=dtype)
+    dtype = torch.float32 if mode == "f32x3" else dtype
     with torch.no_grad():
         # random LSTM / joint weights give a joint output that hardly depends on the label history: greedy decoding then
         # repeats one label until the 256-symbol cap.  Louder embedding / projections and a blank bias make it a mixed
@@ -185,7 +190,8 @@ def test_l4_transducer_full_size(dev, dtype):
         if params[name].grad.abs().max() < 1e-8:
             continue
         cos = _cos(grads[name], params[name].grad)
-        assert cos > (0.9995 if dtype == torch.float32 else 0.97), (name, cos)
+        print(f"[measured L4 {mode}] grad cosine {name}: {cos:.6f}")
+        assert cos > (0.9999 if dtype == torch.float32 else 0.97), (name, cos)
     # ---- greedy decoding, eval mode from the ORIGINAL state (the training step above moved the BatchNorm running stats)
     model.load_state_dict({k: v.detach() for k, v in sd.items()})
     model.eval()

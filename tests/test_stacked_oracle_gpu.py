@@ -189,17 +189,18 @@ def test_reference_trace_d256_stacked_bf16(dev):
     assert optimizer.state_dict()["_step"] == int(t["optim/_step"])
 
 
-def test_reference_trace_d256_f32(dev):
+@pytest.mark.parametrize("mode", [torch.float32, "f32x3"], ids=["f32", "f32x3"])
+def test_reference_trace_d256_f32(dev, mode):
     """the same reference trace through the f32 engine, one micro-batch after the other (train.train_step): the north-star mode
     reproduces the reference's twelve updates -- losses 1e-4 (measured 2.7e-6), every stored tensor's update vector cosine
-    0.9999 (measured 1.0000), learning rates exact"""
+    0.9999 (measured 1.0000), learning rates exact.  "f32x3" (split-bf16 products over f32 storage) is held to the same bars."""
     from emoasr_amd.modeling.asr import ASR
     from emoasr_amd.optimizers import Adam, ScheduledOptimizer
     from emoasr_amd.train import train_step
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_trace_d256.npz"))
     t = {k: torch.from_numpy(z[k]) for k in z.files}
     params = SimpleNamespace(**TRACE_CFG)
-    model = ASR(params, compute_dtype=torch.float32)
+    model = ASR(params, compute_dtype=mode)
     sd0 = synthetic_state({k: v.shape for k, v in model.state_dict().items()})
     model.load_state_dict(sd0)
     optimizer = ScheduledOptimizer(Adam(model.parameters(), lr=0, weight_decay=params.weight_decay), params)
@@ -214,7 +215,7 @@ def test_reference_trace_d256_f32(dev):
             lrs.append(optimizer._lr)
     assert np.allclose(lrs, t["lrs"].numpy(), rtol=1e-12, atol=0)
     rel = np.abs(np.array(losses) - t["losses"].numpy()) / t["losses"].numpy()
-    print(f"[measured] f32 replay of the d256 reference trace: loss rel err max {rel.max():.2e}")
+    print(f"[measured] {mode} replay of the d256 reference trace: loss rel err max {rel.max():.2e}")
     assert rel.max() < 1e-4, rel
     sd = model.state_dict()
     for k in [k for k in t if k.startswith("end/") and t[k].dtype.is_floating_point and "running" not in k]:
