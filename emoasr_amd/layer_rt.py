@@ -158,7 +158,9 @@ class ConformerLayerRuntime:
             L.ff_w1t = A.transposed(name + ".feed_forward.w1.weight").data_ptr()
             L.wqkv_t = A.transposed(sa + ".linear_q.weight", sa + ".linear_v.weight", (3 * d, d)).data_ptr()
             L.pw1_t = A.transposed(cv + ".pointwise_conv1.weight", None, (2 * d, d)).data_ptr()
-            if os.environ.get("EMOASR_DGRAD_NT2", "1") != "0":   # the K = d products too (A/B switch)
+            # the K = d products too (A/B switch; round 5, three same-box pairs inside the step: 28.19 / 28.23 / 28.55 ms with,
+            # 28.19 / 28.12 / 28.26 without -- the NN kernel's transposing LDS reads are not what those products wait for: off)
+            if os.environ.get("EMOASR_DGRAD_NT2", "0") != "0":
                 L.ffm_w2t = A.transposed(name + ".feed_forward_macaron.w2.weight").data_ptr()
                 L.ff_w2t = A.transposed(name + ".feed_forward.w2.weight").data_ptr()
                 L.wout_t = A.transposed(sa + ".linear_out.weight").data_ptr()
