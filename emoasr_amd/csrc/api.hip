@@ -72,6 +72,7 @@ void emo_conv1_set_pair(int v);
 void emo_ln_set_bwd_pf(int v);
 void emo_ln_set_bwd_blocks(int v);
 void emo_rnnt_set_greedy_coop(int v);
+void emo_rnnt_set_beam_mfma(int v);
 #ifdef EMOASR_EXPERIMENTAL
 void emo_gemm_set_k256(int v);
 void emo_gemm_set_k256_min_rows(int v);
@@ -196,6 +197,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "ln_bwd_pf") == 0) { emo_ln_set_bwd_pf(value); return 0; }
   if (strcmp(name, "ln_bwd_blocks") == 0) { emo_ln_set_bwd_blocks(value); return 0; }
   if (strcmp(name, "rnnt_greedy_coop") == 0) { emo_rnnt_set_greedy_coop(value); return 0; }
+  if (strcmp(name, "rnnt_beam_mfma") == 0) { emo_rnnt_set_beam_mfma(value); return 0; }
 #ifdef EMOASR_EXPERIMENTAL
   if (strcmp(name, "gemm_k256") == 0) { emo_gemm_set_k256(value); return 0; }
   if (strcmp(name, "gemm_k256_min_rows") == 0) { emo_gemm_set_k256_min_rows(value); return 0; }

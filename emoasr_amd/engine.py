@@ -17,6 +17,7 @@ import weakref
 import os
 
 import torch
+from ctypes import c_void_p
 
 from . import ops
 from .ops import ACT_NONE, ACT_RELU, ACT_SWISH
@@ -1667,12 +1668,50 @@ class _RNNTMixin:
             st.ctl_host = torch.zeros(3 * 16 + 1, dtype=torch.int64).pin_memory()
             st.out = torch.zeros(16, 1 + 2 * 16, device=dev, dtype=torch.float32)
             st.out_host = torch.zeros(16, 1 + 2 * 16, dtype=torch.float32).pin_memory()
+            st.hj = torch.zeros(16, J, device=dev, dtype=self.dtype)
+            st.bias = [self._lstm_bias(f"decoder.rnns.{l}").contiguous() for l in range(nl)]   # (refreshed per search, below)
             st.graphs = {}
         key = (beam_width, nb, blank)
         if key in st.graphs:
             return st, st.graphs[key]
 
+        fused = os.environ.get("EMOASR_RNNT_BEAM_FUSED", "1") != "0" and nl >= 1
+        st.zero_copy = fused
+
+        def body_fused():
+            # csrc/rnnt_beam.hip: five launches -- one per LSTM layer (gather, both products, cell, scatter), the joint input, the
+            # output layer, the pick (log-softmax + blank + top-k into the result record)
+            from . import lib
+            with self._scope():
+                # zero-copy hand-off: the kernels read the control words straight from the PINNED host record (each word once,
+                # through LDS) and the pick kernel writes the result record into pinned host memory -- no upload / download
+                # launches (two ~5 us copy kernels + their enqueue per round)
+                dtc = ops.dt(st.ph[0])
+                words = lambda base: tuple(c_void_p(base.data_ptr() + 8 * o) for o in (0, 16, 32, 48))
+                h_ids, h_src, h_dst, _ = words(st.ctl_host)       # the first launch reads the host record (and copies it over) ...
+                p_ids, p_src, p_dst, p_t = words(st.ctl)          # ... the later ones its device twin
+                emb = A.w("decoder.embed.weight")
+                xtab, ldx, xidx = emb, emb.shape[1], h_ids
+                for l in range(nl):
+                    name = f"decoder.rnns.{l}"
+                    w_ih, w_hh = A.w(name + ".weight_ih_l0"), A.w(name + ".weight_hh_l0")
+                    first = l == 0
+                    lib.call("emoasr_rnnt_beam_lstm", dtc, nb, w_ih.shape[1], H, ops._p(xtab), ldx, xidx, ops._p(w_ih), ops._p(w_hh),
+                             ops._p(st.bias[l]), ops._p(st.ph[l]), ops._p(st.pc[l]), h_src if first else p_src,
+                             h_dst if first else p_dst, ops._p(st.ctl_host) if first else None, ops._p(st.ctl) if first else None,
+                             st.ctl.numel() if first else 0, ops._stream())
+                    xtab, ldx, xidx = st.ph[l], H, p_dst
+                hj = st.hj[:nb]
+                lib.call("emoasr_rnnt_beam_joint", dtc, nb, H, J, self._BEAM_TMAX, ops._p(st.ph[nl - 1]), p_dst,
+                         ops._p(A.w("decoder.w_dec.weight")), ops._p(A.p("decoder.w_dec.bias")), ops._p(st.e), p_t, ops._p(hj),
+                         ops._stream())
+                logits = ops.gemm_nt(hj, A.w("decoder.output.weight"), bias=A.p("decoder.output.bias"))
+                lib.call("emoasr_rnnt_beam_pick", dtc, nb, logits.shape[1], beam_width, blank, ops._p(logits), logits.stride(0),
+                         ops._p(st.out_host), st.out_host.stride(0), ops._stream())
+
         def body():
+            if fused:
+                return body_fused()
             with self._scope():
                 ids = st.ctl[:nb].to(torch.int32).view(1, nb)
                 src, dst, t = st.ctl[16:16 + nb], st.ctl[32:32 + nb], st.ctl[48:49]
@@ -1720,6 +1759,8 @@ class _RNNTMixin:
             e_all = ops.gemm_nt(eouts[0], A.w("decoder.w_enc.weight"), bias=A.p("decoder.w_enc.bias"))  # [T,J]
             st, _ = self._rnnt_beam_round_graph(beam_width, 1, blank)
             st.e[:T].copy_(e_all)
+            for l in range(self.r_nl):   # bias_ih + bias_hh of the current weights, into the buffers the captured launches read
+                st.bias[l].copy_(self._lstm_bias(f"decoder.rnns.{l}"))
             for l in range(self.r_nl):   # slot 0: the zero state every search starts from
                 st.ph[l][0].zero_()
                 st.pc[l][0].zero_()
@@ -1748,9 +1789,11 @@ class _RNNTMixin:
                     for i, (hyp, _, slot) in enumerate(live):
                         ctl[i], ctl[16 + i], ctl[32 + i] = hyp[-1], slot, nslot + i
                     ctl[48] = t
-                    st.ctl.copy_(st.ctl_host, non_blocking=True)
+                    if not st.zero_copy:
+                        st.ctl.copy_(st.ctl_host, non_blocking=True)
                     graph.replay()
-                    st.out_host.copy_(st.out, non_blocking=True)
+                    if not st.zero_copy:
+                        st.out_host.copy_(st.out, non_blocking=True)
                     stream.synchronize()
                     host = out[:nb].astype(np.float64)
                     last = v == num_expands - 1

@@ -538,6 +538,26 @@ int emoasr_rnnt_greedy(int dtype, int T, int E, int H, int J, int V, int blank, 
                        const float* b_out, void* ws, long ws_bytes, int* hyp, int* align, int* lens, void* stream);
 long emoasr_rnnt_greedy_status(const void* ws, void* stream);
 
+/* ---- one expansion round of the transducer beam search in five launches (csrc/rnnt_beam.hip; RNNTDecoder._beam_search,
+ * rnn_transducer.py:242-325: the per-round recurrency + joint + log_softmax + topk of the reference's alignment-length-synchronous
+ * search).  nb <= 16 live hypotheses; LSTM states live in slot-addressed pools ph [slots, H] (compute dtype) / pc [slots, H] (f32).
+ * All index lists are int64 device arrays (the search's uploaded control words), so the launches can be captured into a graph.
+ *   emoasr_rnnt_beam_lstm : one LSTM layer step: x_i = xtab[xidx[i]] (embedding rows by label id / the layer below's new h by slot),
+ *                           (h, c) = pools[src[i]] -> gates = W_ih x + b + W_hh h -> new (h, c) written to pools[dst[i]];
+ *                           bias = bias_ih + bias_hh [4H]; dst must not alias any src of the same round; the index lists may live
+ *                           in pinned host memory (each word is read once); copy_dst != NULL: the launch also copies copy_n <= 192
+ *                           int64 words copy_src -> copy_dst (the host-resident control record to its device twin)
+ *   emoasr_rnnt_beam_joint: hj[i] = tanh(e_all[*t] + w_dec . ph[dst[i]] + b_dec)   (rnn_transducer.py:147-156 without the output layer)
+ *   emoasr_rnnt_beam_pick : out[i] = { log_softmax(logits[i])[blank], the k best of log_softmax(logits[i])[1:] (descending, ties ->
+ *                           lowest index), their indices relative to column 1 (as floats) }, out row stride ldo >= 1 + 2 k */
+int emoasr_rnnt_beam_lstm(int dtype, int nb, int nin, int H, const void* xtab, long ldx, const long long* xidx, const void* w_ih,
+                          const void* w_hh, const float* bias, void* ph, float* pc, const long long* src, const long long* dst,
+                          const long long* copy_src, long long* copy_dst, int copy_n, void* stream);
+int emoasr_rnnt_beam_joint(int dtype, int nb, int H, int J, int Tmax, const void* ph, const long long* dst, const void* w_dec,
+                           const float* b_dec, const void* e_all, const long long* t, void* hj, void* stream);
+int emoasr_rnnt_beam_pick(int dtype, int nb, int V, int k, int blank, const void* logits, long ldl, float* out, long ldo,
+                          void* stream);
+
 /* ---- one Conformer encoder layer, forward, sequenced on the host in C++ ---------
  * ConformerEncoderLayer.forward (asr/modeling/conformer.py:146-225) with relative-position attention:
  *   x += 0.5 * drop(FFN_macaron(LN(x)));  x += drop(RelMHA(LN(x)));  x += drop(ConvModule(LN(x)));

@@ -151,6 +151,85 @@ def test_beam_search_f32(dev, graph, monkeypatch):
                 assert scores is None and logits is None and aligns is None
 
 
+@pytest.mark.parametrize("mfma", [1, 0], ids=["mfma", "valu"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("nb", [1, 5, 16])
+def test_beam_round_kernels(dev, dtype, nb, mfma):
+    """csrc/rnnt_beam.hip against a plain PyTorch fp32 expression of the same round (rnn_transducer.py:242-325: LSTM step of every
+    live hypothesis from / to slot-addressed states, joint input, log-softmax + blank + top-k record): bf16 on the matrix cores
+    (`mfma`) and on the VALU kernels that also serve f32"""
+    from ctypes import c_void_p
+    from emoasr_amd import lib, ops
+    if dtype == torch.float32 and mfma:
+        pytest.skip("the matrix-core form is bf16")
+    lib.set_option("rnnt_beam_mfma", mfma)
+    try:
+        torch.manual_seed(nb)
+        E, H, J, V, POOL, Tm, k = 64, 96, 48, 200, 40, 7, 4
+        r = lambda *s, sc=1.0: (torch.randn(*s, device=dev) * sc).to(dtype)
+        emb, w_ih, w_hh = r(V, E), r(4 * H, E, sc=E ** -0.5), r(4 * H, H, sc=H ** -0.5)
+        bias = torch.randn(4 * H, device=dev) * 0.1
+        ph, pc = r(POOL, H, sc=0.5), torch.randn(POOL, H, device=dev) * 0.5
+        w_dec, b_dec, e_all = r(J, H, sc=H ** -0.5), torch.randn(J, device=dev) * 0.1, r(Tm, J)
+        ids = torch.randint(0, V, (nb,), device=dev)
+        src = torch.randperm(16, device=dev)[:nb]
+        dst = 20 + torch.arange(nb, device=dev)
+        t = torch.tensor([3], device=dev)
+        # reference (f32 math on the values as stored)
+        x, h0, c0 = emb.float()[ids], ph.float()[src], pc[src]
+        g = x @ w_ih.float().t() + bias + h0 @ w_hh.float().t()
+        i_, f_, g_, o_ = g.chunk(4, 1)
+        c1 = torch.sigmoid(f_) * c0 + torch.sigmoid(i_) * torch.tanh(g_)
+        h1 = torch.sigmoid(o_) * torch.tanh(c1)
+        ph_k, pc_k = ph.clone(), pc.clone()
+        ptr = lambda tt: c_void_p(tt.data_ptr())
+        lib.call("emoasr_rnnt_beam_lstm", ops.dt(emb), nb, E, H, ptr(emb), E, ptr(ids), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(ph_k),
+                 ptr(pc_k), ptr(src), ptr(dst), None, None, 0, ops._stream())
+        tol = 1e-5 if dtype == torch.float32 else 3e-2
+        assert (ph_k[dst].float() - h1).abs().max().item() < tol and (pc_k[dst] - c1).abs().max().item() < tol
+        keep = torch.ones(POOL, dtype=torch.bool, device=dev)
+        keep[dst] = False
+        assert torch.equal(ph_k[keep], ph[keep]) and torch.equal(pc_k[keep], pc[keep])   # nothing but the destination slots moved
+        hj = torch.zeros(16, J, device=dev, dtype=dtype)
+        lib.call("emoasr_rnnt_beam_joint", ops.dt(emb), nb, H, J, Tm, ptr(ph_k), ptr(dst), ptr(w_dec), ptr(b_dec), ptr(e_all), ptr(t),
+                 ptr(hj), ops._stream())
+        hj_ref = torch.tanh(e_all.float()[3] + ph_k[dst].float() @ w_dec.float().t() + b_dec)
+        assert (hj[:nb].float() - hj_ref).abs().max().item() < tol
+        for Vp in (V, 1000, 1500):   # <= 1024: the register-resident row; above: the LDS row
+            logits = r(nb, Vp, sc=2.0)
+            out = torch.zeros(16, 1 + 2 * 16, device=dev)
+            lib.call("emoasr_rnnt_beam_pick", ops.dt(logits), nb, Vp, k, 0, ptr(logits), Vp, ptr(out), out.stride(0), ops._stream())
+            lp = torch.log_softmax(logits.float(), -1)
+            vals, idx = torch.topk(lp[:, 1:], k, dim=-1)
+            assert torch.allclose(out[:nb, 0], lp[:, 0], atol=1e-5), Vp
+            assert torch.allclose(out[:nb, 1:1 + k], vals, atol=1e-5), Vp
+            got = out[:nb, 1 + k:1 + 2 * k].long()
+            assert torch.equal(lp[:, 1:].gather(1, got), vals), Vp   # (bf16 logits tie: torch.topk's order among equals is unspecified)
+            tie = vals[:, 1:] == vals[:, :-1]
+            assert bool((got[:, 1:][tie] > got[:, :-1][tie]).all()), Vp   # ties -> lowest index first
+    finally:
+        lib.set_option("rnnt_beam_mfma", 1)
+
+
+def test_beam_search_bf16_fused_round_agrees_with_the_chain(dev, monkeypatch):
+    """bf16 (what bench.py's beam4_rtf runs): the graph form with the fused round kernels returns the launch chain's hypotheses
+    on the fitted golden model (near-ties may flip a late label: token agreement > 0.9)"""
+    model, g = _build(torch.bfloat16, dev)
+    model.eval()
+    outs = {}
+    with torch.no_grad():
+        for form in ("1", "0"):
+            monkeypatch.setenv("EMOASR_RNNT_BEAM_GRAPH", form)
+            res = []
+            for b in range(g["xs"].shape[0]):
+                n = int(g["xlens"][b])
+                res.append(model.decode(g["xs"][b:b + 1, :n].to(dev), g["xlens"][b:b + 1], beam_width=4)[0][0])
+            outs[form] = res
+    same = sum(int(a == c) for ha, hc in zip(outs["1"], outs["0"]) for a, c in zip(ha, hc))
+    tot = sum(max(len(ha), len(hc)) for ha, hc in zip(outs["1"], outs["0"]))
+    assert same / max(tot, 1) > 0.9, (outs["1"], outs["0"])
+
+
 def test_beam_search_graph_scores_on_fresh_engine(dev):
     """the graph form's warm-up before each capture must not touch the live LSTM state pool (it once ran the round's body with
     the PREVIOUS round's control words: slot 0, the zero state, was overwritten): on a FRESH engine, first utterance first and
