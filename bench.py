@@ -307,6 +307,25 @@ def decode_rtf(model, dev, tmpdir):
     return rtf
 
 
+def ctc_beam_rtf(model, dev, dtype, tmpdir, n_utts=3):
+    """CTC prefix beam search with LM shallow fusion for the CTC model itself (asr/modeling/decoders/ctc.py:203-344): beam 10,
+    12-layer Transformer LM at weight 0.3, batch 1, the reference's RTF protocol on a few utterances (random-init weights: a
+    full beam of distinct prefixes at every frame).  Acoustic side on the GPU, one LM call per NEW prefix, bookkeeping on the host."""
+    import logging
+    from emoasr_amd import decode as dec
+    from emoasr_amd.modeling.lm import LM
+    logging.disable(logging.WARNING)
+    torch.manual_seed(3)
+    lm = LM(SimpleNamespace(**LM12), compute_dtype=dtype).to(dev).eval()
+    loader, vocab, _ = rtf_fixture(os.path.join(tmpdir, "ctcbeam"), n_utts, 1)
+    model.eval()
+    dec.test(model, loader, vocab, 10, 0.0, 0.0, False, lm, 0.3, dev, num_samples=1)  # warm-up
+    _, rtf = dec.measure_rtf(model, loader, vocab, 10, 0.0, 0.0, False, lm, 0.3, dev, num_samples=n_utts, num_repeats=1)
+    model.train()
+    logging.disable(logging.NOTSET)
+    return {"rtf": rtf, "beam": 10, "lm_weight": 0.3, "utts": n_utts}
+
+
 def logmel_rate(dev, batch_xlens, repeats=3):
     """on-GPU Kaldi log-mel of one training batch's raw audio (N = 160 (T - 1) + 400 samples of N(0, 0.05) per
     utterance): feature frames per second of the fbank kernel alone"""
@@ -858,6 +877,7 @@ def main():
             import tempfile
             with tempfile.TemporaryDirectory() as tmpdir:
                 res["decode_rtf"] = decode_rtf(model, dev, tmpdir)
+                res["ctc_beam"] = ctc_beam_rtf(model, dev, dtype, tmpdir)
                 res["decode_rtf_batch32"] = decode_rtf_batched(model, dev)
                 res["decode_l33"] = decode_rtf_l33(dev, dtype, tmpdir)
                 res["decode_l33_eos"] = decode_rtf_l33(dev, dtype, tmpdir, n_utts=10, repeats=2, eos_biased=True)

@@ -17,6 +17,7 @@ Reference behaviour kept on purpose (it decides which prefixes survive):
   * hypotheses start with <eos> (the LM's BOS) and scores are returned best first.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -58,18 +59,35 @@ def ctc_prefix_beam_search(dec, eouts, elens, beam_width, len_weight=0.0, lm=Non
         logp = logp_dev.cpu().numpy().astype(np.float64)     # one D2H for the whole utterance
         top = top_dev.cpu().numpy()
     use_lm = lm is not None and lm_weight > 0
+    lm_cache, lm_rows = os.environ.get("EMOASR_CTC_LM_CACHE", "1") != "0", {}
     live = [_Prefix((eos,), 0.0, NEG, 0.0, 0.0, 0.0, 0)]
     for t in range(T):
         row = logp[t]
         lp_blank = float(row[blank])
         cands = [(int(v), float(row[v])) for v in top[t] if int(v) != blank]
         if use_lm:
-            n = max(len(p.toks) for p in live)
-            batch = torch.zeros(len(live), n, dtype=torch.int64)  # 0-padded like pad_sequence (ctc.py:243-246)
-            for i, p in enumerate(live):
-                batch[i, : len(p.toks)] = torch.tensor(p.toks)
-            lm_lp, _ = lm.predict(batch, [len(p.toks) for p in live])
-            lm_lp = lm_lp.cpu().numpy().astype(np.float64)
+            # The reference scores EVERY live prefix with the LM at every frame (ctc.py:241-260) -- the same prefix again and again
+            # while it survives.  The LM's next-token row is a function of the prefix alone, so each distinct prefix is scored
+            # ONCE (the frame it first survives) and its row kept while it is live: a frame costs an LM call only for prefixes
+            # that are new, in one batch (rows of a batched call do not depend on their neighbours).  EMOASR_CTC_LM_CACHE=0:
+            # the reference's recomputation.
+            need = [p for p in live if p.toks not in lm_rows] if lm_cache else list(live)
+            if need:
+                n = max(len(p.toks) for p in need)
+                batch = torch.zeros(len(need), n, dtype=torch.int64)  # 0-padded like pad_sequence (ctc.py:243-246)
+                for i, p in enumerate(need):
+                    batch[i, : len(p.toks)] = torch.tensor(p.toks)
+                rows, _ = lm.predict(batch, [len(p.toks) for p in need])
+                rows = rows.cpu().numpy().astype(np.float64)
+                for i, p in enumerate(need):
+                    lm_rows[p.toks] = rows[i]
+            lm_lp = [lm_rows[p.toks] for p in live]
+            if lm_cache:
+                keep = {p.toks for p in live}
+                for key in [k for k in lm_rows if k not in keep]:
+                    del lm_rows[key]
+            else:
+                lm_rows.clear()
         table, order = {}, []  # prefix -> _Prefix, in first-seen order (dict merge of ctc.py:374-395)
 
         def put(q):
@@ -92,7 +110,7 @@ def ctc_prefix_beam_search(dec, eouts, elens, beam_width, len_weight=0.0, lm=Non
             for v, lp_v in cands:
                 ext_nb = p.p_b + lp_v if v == last else _lse2(p.p_b + lp_v, p.p_nb + lp_v)
                 if use_lm:
-                    lm_run += lm_weight * float(lm_lp[i, v])
+                    lm_run += lm_weight * float(lm_lp[i][v])
                 put(_Prefix(p.toks + (v,), NEG, ext_nb, _lse2(NEG, ext_nb), lm_run, bonus,
                             p.n_plain + (0 if v == eos else 1)))
         order.sort(key=lambda q: q.total, reverse=True)  # stable, like sorted() in ctc.py:338
