@@ -344,11 +344,10 @@ class CTCEngine(_DecoderMixinPlaceholder):
 
     def _apply_mode(self):
         """re-assert this engine's mode of the f32 products (a process-wide library option: another engine may have changed it)"""
-        if self.dtype == torch.float32:
-            ops.set_f32_split(self.split)
+        ops.set_f32_split(self.split)   # (a bf16 engine never launches an f32 product, but leaves the switch in its default state)
 
     def _scope(self):
-        return ops.stream_scope(self.split if self.dtype == torch.float32 else None)
+        return ops.stream_scope(self.split)
 
     def _buffers(self, name):
         b = self._bufs.get(name)
@@ -1653,9 +1652,11 @@ class _RNNTMixin:
     def _rnnt_beam_round_graph(self, beam_width, nb, blank):
         """the device work of ONE expansion round over nb live hypotheses, captured once as a HIP graph over static buffers:
         control words (last labels, source / destination slots of the LSTM states in the pool, frame index) come in through
-        `ctl`, (blank log-prob, top-k log-probs, top-k ids) per hypothesis go out through `out`.  The host loop pays one small
-        upload, one replay and one small download per round instead of ~12 C-ABI calls, ~16 allocations and the torch glue
-        (246 us per round, host-bound: tools/l4_beam_prof.py)."""
+        `ctl`, (blank log-prob, top-k log-probs, top-k ids) per hypothesis go out through `out`.  The host loop pays one replay
+        per round instead of ~12 C-ABI calls, ~16 allocations and the torch glue (246 us per round, host-bound:
+        tools/l4_beam_prof.py).  Round 5: the captured body is five launches (csrc/rnnt_beam.hip) that read the control words from
+        the PINNED host record and write the result record into pinned host memory -- no upload / download launches: 124 -> 66 us
+        per round; EMOASR_RNNT_BEAM_FUSED=0 captures the launch chain with explicit copies as before."""
         st = self.__dict__.setdefault("_beam_static", None)
         A, J, H, nl = self.arena, self.r_J, self.r_H, self.r_nl
         dev = A.flat.device

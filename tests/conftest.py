@@ -18,3 +18,17 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _f32_products_exact_by_default():
+    """the library's "f32_split" switch (f32 products as three bf16 MFMAs, the f32x3 engines' mode) is process-wide: every test
+    starts from the exact f32 products, whatever engine the previous test left behind"""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            from emoasr_amd import ops
+            ops.set_f32_split(0)
+    except Exception:
+        pass
+    yield
