@@ -27,9 +27,7 @@ class ASR(nn.Module):
         self.encoder_type = params.encoder_type
         self.decoder_type = params.decoder_type
         self.params = params
-        # "f32x3": f32 storage and statistics, every matrix product as three bf16 MFMAs over (hi, lo) operand pairs
-        self.f32_split = compute_dtype == F32X3
-        self.compute_dtype = torch.float32 if self.f32_split else compute_dtype
+        self.compute_dtype = compute_dtype   # (property: "f32x3" -> torch.float32 + f32_split)
         if self.encoder_type not in ("transformer", "conformer"):
             raise NotImplementedError(f"emoasr_amd: encoder_type={self.encoder_type!r} is outside the HIP hot path")
         self.encoder = TransformerEncoder(params, is_conformer=(self.encoder_type == "conformer"))
@@ -52,6 +50,19 @@ class ASR(nn.Module):
         self._engine = None
         n = sum(p.numel() for p in self.parameters())
         logging.info(f"ASR model #parameters: {n}")
+
+    @property
+    def compute_dtype(self):
+        return self._compute_dtype
+
+    @compute_dtype.setter
+    def compute_dtype(self, value):
+        # "f32x3": f32 storage and statistics, every matrix product as three bf16 MFMAs over (hi, lo) operand pairs; the engine is
+        # rebuilt at its next use when the mode changed (engine())
+        split = isinstance(value, str) and value == F32X3
+        assert split or value in (torch.float32, torch.bfloat16), f"compute_dtype={value!r}: torch.bfloat16, torch.float32 or 'f32x3'"
+        object.__setattr__(self, "f32_split", split)
+        object.__setattr__(self, "_compute_dtype", torch.float32 if split else value)
 
     def engine(self):
         from ..engine import CTCEngine

@@ -116,7 +116,9 @@ class LM(nn.Module):
         if self.lm_type != "transformer":
             raise NotImplementedError(f"emoasr_amd: lm_type={self.lm_type!r} is outside the HIP hot path")
         self.params = params
-        self.compute_dtype = compute_dtype
+        # "f32x3" (f32 storage, split-bf16 products: modeling/asr.py) -> float32 + the library's split switch asserted per call
+        self.f32_split = isinstance(compute_dtype, str) and compute_dtype == "f32x3"
+        self.compute_dtype = torch.float32 if self.f32_split else compute_dtype
         self.lm = TransformerLM(params)
         self._arena = None
         self._pe = None
@@ -150,7 +152,7 @@ class LM(nn.Module):
         B, N = ys.shape
         dev = A.flat.device
         pre = "lm.transformer.bert."
-        with ops.stream_scope():
+        with ops.stream_scope(self.f32_split if self.compute_dtype == torch.float32 else None):
             ids = h2d_i32(ys.contiguous(), dev)
             klens = h2d_i32([int(v) for v in ylens], dev)
             x = ops.embed_fwd(ids, A.w(pre + "embeddings.word_embeddings.weight"), self._pe, 1.0).view(B * N, d)
