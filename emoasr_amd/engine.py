@@ -745,6 +745,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
         Lmax = max(max(ylens_all), 1)
         lab = torch.zeros(sum(b for b, _ in segs_h), Lmax, dtype=torch.int32)
         row0, tpad, uscale, b0 = [], [], [], 0
+        segw = torch.zeros(n, sum(b for b, _ in segs_h), dtype=torch.float32)   # [segment, utterance]: 1 / B_k on the segment's own
         for k, (_, _, ys, ylens) in enumerate(batches):
             B, T2 = segs_h[k]
             yk = torch.as_tensor(ys)[:, :Lmax].to(torch.int32)
@@ -752,11 +753,12 @@ class CTCEngine(_DecoderMixinPlaceholder):
             row0 += [rows_h[k] + b * T2 for b in range(B)]
             tpad += [T2] * B
             uscale += [scales[k] / B] * B
+            segw[k, b0:b0 + B] = 1.0 / B
             b0 += B
-        elens_d, labels, yl, row0_d, tpad_d, uscale_d = h2d_pack(
+        elens_d, labels, yl, row0_d, tpad_d, uscale_d, segw_d = h2d_pack(
             [torch.tensor(elens_h, dtype=torch.int32), lab, torch.tensor(ylens_all, dtype=torch.int32),
              torch.tensor(row0, dtype=torch.int64), torch.tensor(tpad, dtype=torch.int32),
-             torch.tensor(uscale, dtype=torch.float32)], dev)
+             torch.tensor(uscale, dtype=torch.float32), segw], dev)
         eouts, st = self._encoder_fwd_stacked([b[0] for b in batches], [b[1] for b in batches], elens_dev=elens_d)
         segs, rows, elens, Btot, Tmax = st.segs, st.rows, st.elens, st.Btot, st.Tmax
         assert list(segs) == segs_h and list(rows) == rows_h
@@ -775,11 +777,9 @@ class CTCEngine(_DecoderMixinPlaceholder):
             dlp[:, V:].zero_()
         dlogits = dlp[:, :V]
         lp, alpha, beta, nll = ops.ctc_forward_rows(logits, lse, labels, elens, yl, blank, row0_d, Tmax)
-        nll0 = torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll))
-        bounds = [0]
-        for b, _ in segs:
-            bounds.append(bounds[-1] + b)
-        losses = torch.stack([nll0[bounds[k]:bounds[k + 1]].sum() / segs[k][0] for k in range(n)])
+        # per-micro-batch losses (sum of the utterances' nll / B, infeasible ones zeroed) as ONE masked row reduction instead of a
+        # slice, a sum and a division per segment (17 tiny launches between the lattice and the gradient kernel); deterministic
+        losses = (segw_d * torch.nan_to_num(nll, nan=0.0, posinf=0.0, neginf=0.0)).sum(1)
         ops.ctc_grad_rows(logits, lse, labels, elens, yl, blank, lp, alpha, beta, nll, 1.0, row0_d, tpad_d, uscale_d, dlogits)
         # ---- backward ------------------------------------------------------------------------------------------------
         if self.dtype == torch.bfloat16 and os.environ.get("EMOASR_HEAD_NT", "1") != "0":

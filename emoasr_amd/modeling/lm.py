@@ -9,6 +9,8 @@ State-dict keys match the reference (`lm.transformer.bert.*`, `lm.transformer.cl
 output embedding tied to the word embedding).  Only `lm_type == "transformer"` is on the path.
 """
 import math
+from types import SimpleNamespace
+import os
 
 import torch
 import torch.nn as nn
@@ -142,51 +144,109 @@ class LM(nn.Module):
             self._pe = (A.p(emb + "position_embeddings.weight") + A.p(emb + "token_type_embeddings.weight")[0]).contiguous()
         return self._arena
 
-    def predict_device(self, ys, ylens):
-        """ys CPU int64 [B,N]; ylens list -> f32 log-probs [B, V] on the device (row ylens[b]-1)"""
-        A = self._bind()
-        A.refresh_shadow()
+    def _forward_rows(self, ids, klens, idx, B, N):
+        """ids int32 [B,N], klens int32 [B], idx [B] (flat position b * N + ylens[b] - 1 of every row's last token), all on the
+        device -> f32 log-probs [B, V]"""
+        A = self._arena
         P = self.params
         d, H, nl = P.hidden_size, P.num_attention_heads, P.num_layers
+        pre = "lm.transformer.bert."
+        x = ops.embed_fwd(ids, A.w(pre + "embeddings.word_embeddings.weight"), self._pe, 1.0).view(B * N, d)
+        x, _, _ = ops.layernorm_fwd(x, A.p(pre + "embeddings.LayerNorm.weight"), A.p(pre + "embeddings.LayerNorm.bias"),
+                                    1e-12, False)
+        scale = 1.0 / math.sqrt(d // H)
+        for i in range(nl):
+            lay = f"{pre}encoder.layer.{i}."
+            wqkv = A.w_span(lay + "attention.self.query.weight", lay + "attention.self.value.weight", (3 * d, d))
+            bqkv = A.p_span(lay + "attention.self.query.bias", lay + "attention.self.value.bias", (3 * d,))
+            qkv = ops.gemm_nt(x, wqkv, bias=bqkv).view(B, N, 3 * d)
+            o, _ = ops.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale, klens=klens, causal=True)
+            y = ops.gemm_nt(o.view(B * N, d), A.w(lay + "attention.output.dense.weight"),
+                            bias=A.p(lay + "attention.output.dense.bias"), residual=x, res_scale=1.0)
+            x1, _, _ = ops.layernorm_fwd(y, A.p(lay + "attention.output.LayerNorm.weight"),
+                                         A.p(lay + "attention.output.LayerNorm.bias"), 1e-12, False)
+            u = ops.gemm_nt(x1, A.w(lay + "intermediate.dense.weight"), bias=A.p(lay + "intermediate.dense.bias"),
+                            act=ACT_GELU)
+            y2 = ops.gemm_nt(u, A.w(lay + "output.dense.weight"), bias=A.p(lay + "output.dense.bias"), residual=x1,
+                             res_scale=1.0)
+            x, _, _ = ops.layernorm_fwd(y2, A.p(lay + "output.LayerNorm.weight"), A.p(lay + "output.LayerNorm.bias"),
+                                        1e-12, False)
+        rows = x.index_select(0, idx)
+        cp = "lm.transformer.cls.predictions."
+        t = ops.gemm_nt(rows, A.w(cp + "transform.dense.weight"), bias=A.p(cp + "transform.dense.bias"), act=ACT_GELU)
+        t, _, _ = ops.layernorm_fwd(t, A.p(cp + "transform.LayerNorm.weight"), A.p(cp + "transform.LayerNorm.bias"),
+                                    1e-12, False)
+        logits = ops.gemm_nt(t, A.w(pre + "embeddings.word_embeddings.weight"), bias=A.p(cp + "bias"), out_f32=True)
+        return ops.log_softmax(logits)
+
+    def predict_device(self, ys, ylens):
+        """ys CPU int64 [B,N]; ylens list -> f32 log-probs [B, V] on the device (row ylens[b]-1).
+
+        Up to 16 rows (what the beam searches ask for, one call per output step or per frame): the ~90 launches of the forward
+        are replayed from a HIP graph over static buffers, one graph per (rows padded to 4 / 16, length padded to a multiple of
+        8) -- the call was host-bound (1.5 ms of launch sequencing for ~0.4 ms of kernels).  Padding rows / positions are masked
+        by their key lengths and never read back; the real rows' arithmetic is the eager call's.  EMOASR_LM_GRAPH=0: eager."""
+        arena_before = self._arena
+        A = self._bind()
+        if A is not arena_before:
+            self._graphs = {}     # (captured launches hold the old arena's addresses)
+        A.refresh_shadow()
         ys = torch.as_tensor(ys)
         B, N = ys.shape
         dev = A.flat.device
-        pre = "lm.transformer.bert."
-        with ops.stream_scope(self.f32_split if self.compute_dtype == torch.float32 else None):
+        yl = [int(v) for v in ylens]
+        split = self.f32_split if self.compute_dtype == torch.float32 else None
+        if B <= 16 and dev.type == "cuda" and os.environ.get("EMOASR_LM_GRAPH", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+            return self._predict_graph(ys, yl, B, N, dev, split)
+        with ops.stream_scope(split):
             ids = h2d_i32(ys.contiguous(), dev)
-            klens = h2d_i32([int(v) for v in ylens], dev)
-            x = ops.embed_fwd(ids, A.w(pre + "embeddings.word_embeddings.weight"), self._pe, 1.0).view(B * N, d)
-            x, _, _ = ops.layernorm_fwd(x, A.p(pre + "embeddings.LayerNorm.weight"), A.p(pre + "embeddings.LayerNorm.bias"),
-                                        1e-12, False)
-            scale = 1.0 / math.sqrt(d // H)
-            for i in range(nl):
-                lay = f"{pre}encoder.layer.{i}."
-                wqkv = A.w_span(lay + "attention.self.query.weight", lay + "attention.self.value.weight", (3 * d, d))
-                bqkv = A.p_span(lay + "attention.self.query.bias", lay + "attention.self.value.bias", (3 * d,))
-                qkv = ops.gemm_nt(x, wqkv, bias=bqkv).view(B, N, 3 * d)
-                o, _ = ops.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale, klens=klens, causal=True)
-                y = ops.gemm_nt(o.view(B * N, d), A.w(lay + "attention.output.dense.weight"),
-                                bias=A.p(lay + "attention.output.dense.bias"), residual=x, res_scale=1.0)
-                x1, _, _ = ops.layernorm_fwd(y, A.p(lay + "attention.output.LayerNorm.weight"),
-                                             A.p(lay + "attention.output.LayerNorm.bias"), 1e-12, False)
-                u = ops.gemm_nt(x1, A.w(lay + "intermediate.dense.weight"), bias=A.p(lay + "intermediate.dense.bias"),
-                                act=ACT_GELU)
-                y2 = ops.gemm_nt(u, A.w(lay + "output.dense.weight"), bias=A.p(lay + "output.dense.bias"), residual=x1,
-                                 res_scale=1.0)
-                x, _, _ = ops.layernorm_fwd(y2, A.p(lay + "output.LayerNorm.weight"), A.p(lay + "output.LayerNorm.bias"),
-                                            1e-12, False)
-            yl = [int(v) for v in ylens]
-            if all(v == yl[0] for v in yl):
-                rows = x.view(B, N, d)[:, yl[0] - 1]  # strided view, row stride N*d
-            else:
-                idx = torch.tensor([b * N + v - 1 for b, v in enumerate(yl)], device=dev)
-                rows = x.index_select(0, idx)
-            cp = "lm.transformer.cls.predictions."
-            t = ops.gemm_nt(rows, A.w(cp + "transform.dense.weight"), bias=A.p(cp + "transform.dense.bias"), act=ACT_GELU)
-            t, _, _ = ops.layernorm_fwd(t, A.p(cp + "transform.LayerNorm.weight"), A.p(cp + "transform.LayerNorm.bias"),
-                                        1e-12, False)
-            logits = ops.gemm_nt(t, A.w(pre + "embeddings.word_embeddings.weight"), bias=A.p(cp + "bias"), out_f32=True)
-            return ops.log_softmax(logits)
+            klens = h2d_i32(yl, dev)
+            idx = h2d_i32([b * N + v - 1 for b, v in enumerate(yl)], dev)
+            return self._forward_rows(ids, klens, idx, B, N)
+
+    def _predict_graph(self, ys, yl, B, N, dev, split):
+        Bp, Np = (4 if B <= 4 else 16), (N + 7) // 8 * 8
+        graphs = self.__dict__.setdefault("_graphs", {})
+        g = graphs.get((Bp, Np))
+        if g is None:
+            g = SimpleNamespace()
+            n_ids = Bp * Np
+            g.host = torch.zeros(n_ids + 2 * Bp, dtype=torch.int32).pin_memory()
+            g.dev = torch.zeros(n_ids + 2 * Bp, dtype=torch.int32, device=dev)
+            g.ids, g.klens, g.idx = g.dev[:n_ids].view(Bp, Np), g.dev[n_ids:n_ids + Bp], g.dev[n_ids + Bp:]
+            g.host[n_ids:n_ids + Bp] = 1     # (a valid state for the warm-up run: every row one token long)
+            g.host[n_ids + Bp:] = torch.arange(Bp, dtype=torch.int32) * Np
+            g.dev.copy_(g.host)
+
+            def body():
+                with ops.stream_scope(split):
+                    return self._forward_rows(g.ids, g.klens, g.idx, Bp, Np)
+
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                body()   # warm-up outside the capture (allocator, lazy initialisation, per-stream scratch)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g.graph):
+                g.out = body()
+            graphs[(Bp, Np)] = g
+        n_ids = Bp * Np
+        h = g.host
+        if getattr(g, "ev", None) is not None:
+            g.ev.synchronize()   # (the previous call's upload has left the pinned record)
+        h[:n_ids + Bp] = 0
+        h[:n_ids].view(Bp, Np)[:B, :N] = ys.to(torch.int32)
+        h[n_ids:n_ids + Bp] = 1
+        h[n_ids:n_ids + B] = torch.tensor(yl, dtype=torch.int32)
+        h[n_ids + Bp:] = torch.arange(Bp, dtype=torch.int32) * Np
+        h[n_ids + Bp:n_ids + Bp + B] += torch.tensor(yl, dtype=torch.int32) - 1
+        g.dev.copy_(h, non_blocking=True)
+        g.ev = torch.cuda.Event()
+        g.ev.record()
+        g.graph.replay()
+        return g.out[:B].clone()
 
     def predict(self, ys, ylens, states=None):
         with torch.no_grad():
