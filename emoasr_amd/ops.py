@@ -8,6 +8,8 @@ code (emoasr_amd/engine.py) sequences them explicitly.
 import ctypes
 from ctypes import byref, c_void_p
 
+import os
+
 import torch
 
 from . import lib
@@ -34,13 +36,16 @@ def _stream():
 
 
 _F32_SPLIT = 0
+# EMOASR_FORCE_SPLIT=1: EVERY f32 product of the process runs split, whatever an engine asks for (test aid: the whole GPU suite's f32
+# cases -- all decoders, searches, distillation paths -- then exercise the f32x3 arithmetic against the same goldens and bars)
+_FORCE_SPLIT = os.environ.get("EMOASR_FORCE_SPLIT", "0") == "1"
 
 
 def set_f32_split(on):
     """library option "f32_split" (csrc/gemm.hip SplitCfg): f32 products as three bf16 MFMAs over (hi, lo) operand pairs.  The
     option is process-wide; every engine re-asserts its own mode at its entry points (CTCEngine._apply_mode)."""
     global _F32_SPLIT
-    on = 1 if on else 0
+    on = 1 if (on or _FORCE_SPLIT) else 0
     if on != _F32_SPLIT:
         lib.set_option("f32_split", on)
         _F32_SPLIT = on
