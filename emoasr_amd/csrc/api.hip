@@ -56,6 +56,7 @@ void emo_gemm_set_xcd(int v);
 void emo_gemm_set_f32_split(int v);
 void emo_gemm_set_split_tile(int v);
 void emo_gemm_set_split_kb(int v);
+void emo_gemm_set_split_min128(int v);
 void emo_gemm_set_conv_big(int v);
 void emo_gemm_set_big_bm(int v);
 void emo_gemm_set_big_korder(int v);
@@ -181,6 +182,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "f32_split") == 0) { emo_gemm_set_f32_split(value); return 0; }
   if (strcmp(name, "split_tile") == 0) { emo_gemm_set_split_tile(value); return 0; }
   if (strcmp(name, "split_kb") == 0) { emo_gemm_set_split_kb(value); return 0; }
+  if (strcmp(name, "split_min128") == 0) { emo_gemm_set_split_min128(value); return 0; }
   if (strcmp(name, "conv_big") == 0) { emo_gemm_set_conv_big(value); return 0; }
   if (strcmp(name, "big_bm") == 0) { emo_gemm_set_big_bm(value); return 0; }
   if (strcmp(name, "big_korder") == 0) { emo_gemm_set_big_korder(value); return 0; }

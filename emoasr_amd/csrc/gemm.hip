@@ -69,6 +69,7 @@ int g_tn_group_blocks = 0;  // override of a grouped TN launch's block budget (e
 int g_f32_split = 0;        // option "f32_split": f32 products as three bf16 MFMAs over (hi, lo) operand pairs (see SplitCfg)
 int g_split_tile = 0;       // option "split_tile": tile of the split NT / NN products (1 = 128x128 where it fills the chip twice, 2 = 128x64, 3 = 64x64; 0 = rule)
 int g_split_kb = 1;         // option "split_kb": 2 = BK 64 for split reductions of K >= 512
+int g_split_min128 = 512;   // option "split_min128": 128 x 128 split tiles from this many tiles on
 
 // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Reading
 // the linear id as (xcd, slot) makes XCD x work on ONE contiguous range of the logical block list, so
@@ -367,6 +368,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
       }
     }
     __syncthreads();
+  } else if constexpr (SP && BM * BN > 128 * 64) {
+    // split products on the 128 x 128 tile: ONE register stage (the tile after the one being multiplied), so that the kernel
+    // stays under 256 registers and two workgroups share a CU -- with the 3-deep ring it needs 265 and runs one wave per SIMD
+    Stage s1;
+    load_tile(s1, 0);
+    store_tile(s1, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      load_tile(s1, (kt + 1) * BK);
+      compute_tile(kt & 1);
+      store_tile(s1, (kt + 1) & 1);
+      __syncthreads();
+    }
   } else {
   Stage s0, s1, s2;  // named stages: static register indexing (a runtime-indexed ring would spill)
   load_tile(s0, 0);
@@ -797,9 +811,11 @@ int launch_nt_(const NtArgs& a_in, hipStream_t s, int nz = 1) {
     const long t12864 = (long)cdiv(a.M, 128) * cdiv(a.N, 64) * nz, t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128) * nz;
     // 64x64 everywhere (four workgroups per CU): measured inside the f32x3 training step against the bf16 kernel's rule (128x64
     // where that fills the chip 1.5 times: 17.17 ms), 128x128 tiles (17.27) and BK = 64 (18.35): 17.00 ms per step
+    // ... and 128 x 128 with ONE register stage (two workgroups per CU; with the 3-deep ring it ran one wave per SIMD and lost)
+    // where that tile still fills the chip: 16.70 against 17.12 ms per step
     (void)t12864;
-    int tile = 3;
-    if (g_split_tile == 1 && t128 >= 512 && a.N % 128 == 0) tile = 1;
+    int tile = (t128 >= g_split_min128 && a.N % 128 == 0) ? 1 : 3;
+    if (g_split_tile == 1 && a.N % 128 == 0) tile = 1;
     else if (g_split_tile >= 2) tile = g_split_tile;
     const int kb = (g_split_kb == 2 && a.K >= 512) ? 2 : 1;
 #define EMO_SP_LAUNCH(BM_, BN_)                                                            \
@@ -951,6 +967,7 @@ void emo_gemm_set_f32_split(int v) { g_f32_split = v ? 1 : 0; }
 int emo_gemm_f32_split() { return g_f32_split; }
 void emo_gemm_set_split_tile(int v) { g_split_tile = (v >= 1 && v <= 3) ? v : 0; }
 void emo_gemm_set_split_kb(int v) { g_split_kb = v == 2 ? 2 : 1; }
+void emo_gemm_set_split_min128(int v) { g_split_min128 = v > 0 ? v : 512; }
 
 static int check_vec(long ld, int dtype, const char* what) {
   const int vec = dtype == EMO_BF16 ? 8 : 4;
