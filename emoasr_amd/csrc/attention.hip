@@ -3103,6 +3103,53 @@ extern "C" int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream) 
 }
 
 // rows = B * Tq of a dense batch, or all rows of stacked micro-batches whose longest segment has Tk frames
+// The materialised backward's scratch as two caller-provided areas (what emoasr_amd/ops.py: AttnScratch allocates tensor by
+// tensor): `images` -- P^T, dS^T and the dBD band, which must be ZERO before the first call for a given (B, Tq, Tk, klens) and may
+// then be reused by calls with the same masks -- and `scratch` (cs, Q+u, Q+v, the dbias partials: no initialisation).
+namespace {
+struct MatLayout { size_t pdT, dsT, dbd, img_bytes, cs, qu, qv, part, scr_bytes; long ldpd, ldbd; };
+MatLayout mat_layout(int dtype, int B, int H, int Tq, int Tk, int rel) {
+  const size_t esz = dtype == EMO_BF16 ? 2 : 4;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  MatLayout m{};
+  m.ldpd = (Tq + 7) / 8 * 8;
+  m.ldbd = (2L * Tq - 1 + 7) / 8 * 8;
+  size_t o = 0;
+  m.pdT = o; o += up((size_t)B * H * Tk * m.ldpd * esz);
+  m.dsT = o; o += up((size_t)B * H * Tk * m.ldpd * esz);
+  m.dbd = o; if (rel) o += up((size_t)H * B * Tq * m.ldbd * esz);
+  m.img_bytes = o;
+  o = 0;
+  m.cs = o; if (rel) o += up((size_t)H * m.ldbd * 4);
+  m.qu = o; if (rel) o += up((size_t)B * Tq * H * DK * esz);
+  m.qv = o; if (rel) o += up((size_t)B * Tq * H * DK * esz);
+  m.part = o; o += up((size_t)B * cdiv(Tq, 32) * H * 2 * DK * 4);
+  m.scr_bytes = o;
+  return m;
+}
+}  // namespace
+
+extern "C" size_t emoasr_attn_bwd_mat_bytes(int dtype, int B, int H, int Tq, int Tk, int rel, int which) {
+  if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;
+  const MatLayout m = mat_layout(dtype, B, H, Tq, Tk, rel);
+  return which == 0 ? m.img_bytes : m.scr_bytes;
+}
+
+extern "C" int emoasr_attn_bwd_mat_bind(int dtype, emoasr_attn_t* a, void* images, void* scratch) {
+  EMO_CHECK(a && images && scratch, "attn_bwd_mat_bind: missing arguments");
+  EMO_CHECK(a->DK == DK, "attn_bwd_mat_bind: head dimension %d unsupported", a->DK);
+  const int rel = a->pos != nullptr;
+  const MatLayout m = mat_layout(dtype, a->B, a->H, a->Tq, a->Tk, rel);
+  char *im = static_cast<char*>(images), *sc = static_cast<char*>(scratch);
+  a->pdT = im + m.pdT; a->dsT = im + m.dsT; a->ldpd = m.ldpd;
+  a->dbd = rel ? im + m.dbd : nullptr; a->ldbd = rel ? m.ldbd : 0;
+  a->cs = rel ? reinterpret_cast<float*>(sc + m.cs) : nullptr;
+  const bool dense = rel && a->bias_u && a->bias_v;
+  a->qu = dense ? sc + m.qu : nullptr; a->qv = dense ? sc + m.qv : nullptr;
+  a->dbias_part = reinterpret_cast<float*>(sc + m.part);
+  return 0;
+}
+
 extern "C" size_t emoasr_attn_bwd_fused_ws_bytes_rows(int dtype, long rows, int H, int Tk, int rel) {
   const size_t esz = dtype == EMO_BF16 ? 2 : 4;
   auto up = [](size_t n) { return (n + 255) / 256 * 256; };

@@ -193,7 +193,7 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Backward of one Conformer layer (bf16, relative positions) as ONE crossing of the C ABI: the gradient kernels in
+// Backward of one Conformer layer (relative positions) as ONE crossing of the C ABI: the gradient kernels in
 // the order emoasr_amd/engine.py:_backward issues them (final LayerNorm, feed-forward, convolution module,
 // self-attention, macaron feed-forward; reference autograd of conformer.py:146-225), the layer's nine weight-gradient
 // products as one grouped launch, intermediates in one caller-provided workspace that the next layer reuses.
@@ -210,6 +210,7 @@ struct BwdLayout {
 struct BwdBufs {
   size_t dx1, dx2, dx3, dx4, pre1, pre2, pre3, pre4, dh, du_ff, du_ffm, dz, dc, dgl, dg, dout, dqkv, dpos_t;
   size_t dpos, delta, bn_scr, dw_scr, attn_ws, attn_ws_bytes, total;
+  size_t img[EMOASR_MAX_SEGMENTS + 1];   // f32: offsets of the segments' attention images in the caller's zero-filled area
 };
 
 BwdBufs bwd_layout(int dtype, const SegView& sv, int d, int H, int F, int K) {
@@ -229,10 +230,14 @@ BwdBufs bwd_layout(int dtype, const SegView& sv, int d, int H, int F, int K) {
   for (int i = 0; i < sv.n; ++i) {
     bn_scr = std::max(bn_scr, (size_t)emoasr_bn_swish_bwd_scratch_floats(sv.B[i] * sv.T[i], d) * 4);
     dw_scr = std::max(dw_scr, (size_t)emoasr_dwconv_bwd_w_scratch_floats(sv.B[i], sv.T[i], d, K) * 4);
-    attn_ws = std::max(attn_ws, emoasr_attn_bwd_fused_ws_bytes(dtype, sv.B[i], H, sv.T[i], sv.T[i], 1));
+    // bf16: the single-pass backward's workspace; f32: the plain scratch of the materialised backward (one segment at a time)
+    attn_ws = std::max(attn_ws, dtype == EMO_BF16 ? emoasr_attn_bwd_fused_ws_bytes(dtype, sv.B[i], H, sv.T[i], sv.T[i], 1)
+                                                  : emoasr_attn_bwd_mat_bytes(dtype, sv.B[i], H, sv.T[i], sv.T[i], 1, 1));
     tmax = std::max(tmax, sv.T[i]);
+    b.img[i + 1] = b.img[i] + (dtype == EMO_BF16 ? 0 : emoasr_attn_bwd_mat_bytes(dtype, sv.B[i], H, sv.T[i], sv.T[i], 1, 0));
   }
-  attn_ws = std::max(attn_ws, emoasr_attn_bwd_fused_ws_bytes_rows(dtype, (long)M, H, tmax, 1));   // all segments in one launch
+  if (dtype == EMO_BF16)
+    attn_ws = std::max(attn_ws, emoasr_attn_bwd_fused_ws_bytes_rows(dtype, (long)M, H, tmax, 1));   // all segments in one launch
   if (sv.n > 1) {
     emoasr_segments_t sg{};
     sg.n = sv.n;
@@ -259,6 +264,15 @@ extern "C" size_t emoasr_conformer_layer_bwd_ws_bytes_seg(int dtype, const emoas
   return bwd_layout(dtype, sv, d, H, F, K).total;
 }
 
+extern "C" size_t emoasr_conformer_layer_bwd_img_bytes_seg(int dtype, const emoasr_segments_t* seg, int d, int H) {
+  emoasr_conformer_fwd_t io{};
+  if (!seg || dtype == EMO_BF16) return 0;
+  io.seg = *seg;
+  SegView sv;
+  if (seg->n < 1 || !seg_view(&io, d, &sv)) return 0;
+  return bwd_layout(dtype, sv, d, H, 4 * d, 1).img[sv.n];
+}
+
 extern "C" size_t emoasr_conformer_layer_bwd_ws_bytes(int dtype, int B, int T, int d, int H, int F, int K) {
   emoasr_segments_t seg{};
   seg.n = 1; seg.B[0] = B; seg.T[0] = T;
@@ -268,7 +282,6 @@ extern "C" size_t emoasr_conformer_layer_bwd_ws_bytes(int dtype, int B, int T, i
 extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_layer_t* L, const emoasr_conformer_layer_t* G,
                                           const emoasr_conformer_fwd_t* st, const emoasr_conformer_bwd_t* io, void* stream) {
   EMO_CHECK(L && G && st && io && io->dy && io->dx && io->ws && io->ln_part, "conformer_layer_bwd: missing arguments");
-  EMO_CHECK(dtype == EMO_BF16, "conformer_layer_bwd: bf16 only (f32 is sequenced by the host)");
   const int d = L->d, H = L->H, F = L->F, K = L->K;
   SegView sv;
   EMO_CHECK(seg_view(st, d, &sv), "conformer_layer_bwd: bad batch / segment shapes");
@@ -276,7 +289,10 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
   const BwdBufs bb = bwd_layout(dtype, sv, d, H, F, K);
   EMO_CHECK(io->ws_bytes >= bb.total, "conformer_layer_bwd: workspace %zu < %zu bytes", io->ws_bytes, bb.total);
   char* ws = static_cast<char*>(io->ws);
-  const size_t esz = 2;
+  const size_t esz = dtype == EMO_BF16 ? 2 : 4;
+  EMO_CHECK(dtype == EMO_BF16 || (io->attn_img && io->attn_img_bytes >= bb.img[sv.n]),
+            "conformer_layer_bwd: f32 needs the zero-filled attention image area (%zu bytes, emoasr_conformer_layer_bwd_img_bytes_seg)",
+            bb.img[sv.n]);
   const float p = st->p_enc;
   hipStream_t s = (hipStream_t)stream;
   emoasr_tn_problem_t pr[EMOASR_TN_GROUP_MAX];
@@ -387,9 +403,27 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     emoasr_epilogue_t e = plain_ep();
     if (L->wout_t ? emoasr_gemm_nt(dtype, M, d, d, dy, d, L->wout_t, d, ws + bb.dout, d, &e, stream)
                   : emoasr_gemm_nn(dtype, M, d, d, dy, d, L->wout, d, ws + bb.dout, d, &e, stream)) return 1;
-    // all stacked micro-batches in one set of launches (segment table in the arguments), or one set each (workspace reused)
+    // f32: the materialised backward (P^T / dS^T / dBD images + batched products, csrc/attention.hip: launch_bwd_tr), one
+    // micro-batch at a time; the position-table gradient is f32 already
+    if (dtype != EMO_BF16) {
+      if (hipMemsetAsync(ws + bb.dpos, 0, (size_t)R * d * 4, s) != hipSuccess) return 1;
+      for (int si = 0; si < sv.n; ++si) {
+        const size_t ro = (size_t)sv.row[si], po = (size_t)sv.prow[si];
+        char* dqkv = ws + bb.dqkv + ro * 3 * d * esz;
+        emoasr_attn_t a{};
+        attn_args_for(a, sv, si, si + 1, H, d, esz, st->qkv, st->pp, st->klens, st->seed[2]);
+        a.bias_u = L->bias_u; a.bias_v = L->bias_v; a.drop_p = st->p_att;
+        a.out = (char*)st->o + ro * d * esz; a.lse = st->lse + ro * H;
+        a.dout = ws + bb.dout + ro * d * esz; a.delta = (float*)(ws + bb.delta) + ro * H;
+        a.dq = dqkv; a.dk = dqkv + (size_t)d * esz; a.dv = dqkv + (size_t)2 * d * esz;
+        a.dpos = (float*)(ws + bb.dpos) + po * d; a.dbias_u = (float*)G->bias_u; a.dbias_v = (float*)G->bias_v;
+        if (emoasr_attn_bwd_mat_bind(dtype, &a, (char*)io->attn_img + bb.img[si], ws + bb.attn_ws)) return 1;
+        if (emoasr_attn_bwd(dtype, &a, stream)) return 1;
+      }
+    }
+    // bf16: all stacked micro-batches in one set of launches (segment table in the arguments), or one set each (workspace reused)
     const int astep = g_stack_launch ? sv.n : 1;
-    for (int si = 0; si < sv.n; si += astep) {
+    for (int si = 0; si < sv.n && dtype == EMO_BF16; si += astep) {
       const size_t ro = (size_t)sv.row[si], po = (size_t)sv.prow[si];
       const long Rs = sv.prow[si + astep] - sv.prow[si];
       char* dqkv = ws + bb.dqkv + ro * 3 * d * esz;
@@ -408,7 +442,7 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
       emo_attn_bwd_defer_join(astep == sv.n);
       if (emoasr_attn_bwd_fused(dtype, &a, ws + bb.attn_ws, bb.attn_ws_bytes, stream)) return 1;
     }
-    wgrad(ws + bb.dpos_t, d, d, st->pos_t, d, d, R, G->wpos, 1.f, nullptr);
+    wgrad(dtype == EMO_BF16 ? ws + bb.dpos_t : ws + bb.dpos, d, d, st->pos_t, d, d, R, G->wpos, 1.f, nullptr);
     wgrad(ws + bb.dqkv, 3 * d, 3 * d, st->at_h, d, d, M, G->wqkv, 1.f, G->bqkv);
     if (dgrad(3 * d, ws + bb.dqkv, L->wqkv, L->wqkv_t, ws + bb.dh)) return 1;
     if (ln_bwd(3, ws + bb.dh, st->ffm.y, L->att_ln_g, st->at_mean, st->at_rstd, ws + bb.dx3, ws + bb.dx4, G->att_ln_g,

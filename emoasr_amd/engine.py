@@ -603,9 +603,18 @@ class CTCEngine(_DecoderMixinPlaceholder):
             self._wq = []
             self._ln_deferred = []
 
+    def _stack_dtype_ok(self, single=False):
+        """bf16 always; f32 (exact or split products, the materialised attention backward per micro-batch) unless switched off:
+        EMOASR_F32_CPP_BWD=0 sequences the f32 gradient kernels from the host, EMOASR_F32_STACKED=0 runs f32 micro-batches one by one"""
+        if self.dtype == torch.bfloat16:
+            return True
+        if os.environ.get("EMOASR_F32_CPP_BWD", "1") == "0":
+            return False
+        return single or os.environ.get("EMOASR_F32_STACKED", "1") != "0"
+
     def encoder_stacked_ok(self):
         """can the ENCODER take several micro-batches in one stacked pass (any decoder on top)?"""
-        return (self.conformer and self.rel and self.dtype == torch.bfloat16 and self._cpp_layers and self.attn_fused
+        return (self.conformer and self.rel and self._stack_dtype_ok() and self._cpp_layers and self.attn_fused
                 and not self.attn_store_scores and not self._side_wgrads and self.inter_layer == 0
                 and os.environ.get("EMOASR_CPP_BWD", "1") != "0" and self._implicit_dgrad and self._conv_big
                 and self.d % 256 == 0 and os.environ.get("EMOASR_STACKED", "1") != "0")
@@ -702,11 +711,15 @@ class CTCEngine(_DecoderMixinPlaceholder):
         ops.strided_copy(dwl.view(d, F2, C).permute(0, 2, 1), out=A.g(pre + "output.weight").view(d, C, F2), accumulate=True)
         dy2 = ops.gemm_nn(dlin, st.wlr, dact_pre=st.y2, dact=ACT_RELU)
         dw2 = torch.zeros(C, 9 * C, device=dev, dtype=torch.float32)
-        wt = ops.strided_copy(A.p(pre + "conv.2.weight").permute(1, 2, 3, 0), out_dtype=dt).view(C, 9 * C)
+        kc = dt == torch.bfloat16   # the large-tile kernel's data gradient (all four parity classes in one launch) is bf16 only
+        if kc:
+            wt = ops.strided_copy(A.p(pre + "conv.2.weight").permute(1, 2, 3, 0), out_dtype=dt).view(C, 9 * C)
+        else:
+            w2r = ops.strided_copy(A.p(pre + "conv.2.weight").permute(0, 2, 3, 1), out_dtype=dt).view(C, 9 * C)
         for k, xs in enumerate(st.xs_list):
             dy2_k = dy2[rows[k]:rows[k + 1]].view(-1, C)
             ops.conv2_wgrad(dy2_k, st.y1s[k], dw2, dbias=A.g(pre + "conv.2.bias"), accumulate=True)
-            dy1 = ops.conv2_dgrad_kc(dy2_k, wt, st.y1s[k])
+            dy1 = ops.conv2_dgrad_kc(dy2_k, wt, st.y1s[k]) if kc else ops.conv2_dgrad(dy2_k, w2r, st.y1s[k])
             ops.conv1_wgrad(xs, dy1, A.g(pre + "conv.0.weight").view(C, 9), A.g(pre + "conv.0.bias"), accumulate=True)
         ops.strided_copy(dw2.view(C, 3, 3, C).permute(0, 3, 1, 2), out=A.g(pre + "conv.2.weight"), accumulate=True)
 
@@ -976,7 +989,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
         """the whole-layer C++ backward takes bf16 relative-position Conformer layers whose forward ran through the
         C++ layer runtime (EMOASR_CPP_BWD=0: sequence the gradient kernels from here)"""
         from .layer_rt import LayerStash
-        return (self._cpp_layers and self.conformer and self.rel and self.dtype == torch.bfloat16 and self.attn_fused
+        return (self._cpp_layers and self.conformer and self.rel and self._stack_dtype_ok(True) and self.attn_fused
                 and not self._side_wgrads and os.environ.get("EMOASR_CPP_BWD", "1") != "0"
                 and bool(st.layers) and all(isinstance(s, LayerStash) and s.io is not None for s in st.layers)
                 and st.layers[0].io.training)

@@ -64,7 +64,7 @@ class _Layout:
 class LayerStash:
     """What one layer's forward left behind; iterating yields the (s_ffm, s_att, s_conv, s_ff, s_fin) tuples
     engine._backward expects, with tensor views built on first use."""
-    __slots__ = ("wt", "wf", "lay", "x_in", "seeds", "_tup", "io", "B", "T")
+    __slots__ = ("wt", "wf", "lay", "x_in", "seeds", "_tup", "io", "B", "T", "sweep")
 
     def __init__(self, wt, wf, lay, x_in, seeds):
         self.wt, self.wf, self.lay, self.x_in, self.seeds, self._tup = wt, wf, lay, x_in, seeds, None
@@ -111,6 +111,8 @@ class ConformerLayerRuntime:
         self.grads = {}     # layer index -> (lib.ConformerLayer of gradient pointers, guard)
         self.layouts = {}   # (B, T) -> _Layout
         self.bwd_ws = None  # one backward workspace, shared by all layers (they run one after the other)
+        self.attn_img, self.attn_img_key = None, None  # f32: zero-filled attention images of the current backward sweep
+        self.sweeps = 0
 
     def _layer_params(self, li):
         eng, A = self.eng, self.eng.arena
@@ -186,6 +188,13 @@ class ConformerLayerRuntime:
         site = 100 + li * 20
         seeds = tuple(eng._seed(site + k) for k in (0, 1, 2, 3, 4, 6, 7))
         st = LayerStash(wt, wf, lay, x, seeds)
+        # serial number of the forward sweep this layer belongs to (a sweep starts at the layer that is given a tensor): all its
+        # layers share the utterance lengths, hence the masks of the attention backward's images (backward: attn_img)
+        if isinstance(x, LayerStash):
+            st.sweep = x.sweep
+        else:
+            self.sweeps += 1
+            st.sweep = self.sweeps
         esz = wt.element_size()
         tb, fb = wt.data_ptr(), wf.data_ptr()
         t, f = lay.t, lay.f
@@ -271,6 +280,21 @@ class ConformerLayerRuntime:
         io = lib.ConformerBwd()
         io.dy, io.dx = dy.data_ptr(), dx.data_ptr()
         io.ws, io.ws_bytes = self.bwd_ws.data_ptr(), self.bwd_ws.numel()
+        if st.wt.dtype != torch.bfloat16:
+            # f32: the materialised attention backward's P^T / dS^T / dBD images, zero-filled ONCE per backward sweep (every layer of
+            # a sweep masks the same entries) -- the sweep is known by the forward pass that made its stashes
+            seg = st.io.seg
+            if st.lay.segs is None:
+                seg = lib.Segments()
+                seg.n, seg.B[0], seg.T[0] = 1, B, T
+            ni = lib.img_bytes_seg(ops.dt(st.wt), seg, eng.d, eng.h)
+            key = st.sweep
+            if self.attn_img is None or self.attn_img.numel() < ni:
+                self.attn_img, self.attn_img_key = torch.empty(int(ni * 1.1) + 256, device=dy.device, dtype=torch.uint8), None
+            if self.attn_img_key != key:
+                self.attn_img[:ni].zero_()
+                self.attn_img_key = key
+            io.attn_img, io.attn_img_bytes = self.attn_img.data_ptr(), self.attn_img.numel()
         io.ln_part, io.ln_part_stride = ln_part.data_ptr(), ln_part.stride(0)
         lib.call("emoasr_conformer_layer_bwd", ops.dt(st.wt), ctypes.byref(L), ctypes.byref(G), ctypes.byref(st.io),
                  ctypes.byref(io), ops._stream())

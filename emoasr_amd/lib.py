@@ -174,7 +174,7 @@ class ConformerFwd(Structure):
 
 class ConformerBwd(Structure):
     _fields_ = [("dy", c_void_p), ("dx", c_void_p), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t),
-                ("ln_part", c_void_p), ("ln_part_stride", c_long)]
+                ("ln_part", c_void_p), ("ln_part_stride", c_long), ("attn_img", c_void_p), ("attn_img_bytes", ctypes.c_size_t)]
 
 
 P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
@@ -367,6 +367,14 @@ def ws_bytes_seg(dtype_code, seg, d, H, F, K):
     if n == 0:
         raise EmoasrHipError("emoasr_conformer_layer_bwd_ws_bytes_seg: bad segment description")
     return n
+
+
+def img_bytes_seg(dtype_code, seg, d, H):
+    """emoasr_conformer_layer_bwd_img_bytes_seg: zero-filled attention image area of an f32 layer backward (0 for bf16)"""
+    fn = load().emoasr_conformer_layer_bwd_img_bytes_seg
+    fn.restype = ctypes.c_size_t
+    fn.argtypes = [c_int, POINTER(Segments), c_int, c_int]
+    return int(fn(dtype_code, ctypes.byref(seg), d, H))
 
 
 def timer_read(name, reset=True):

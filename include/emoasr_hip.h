@@ -256,6 +256,14 @@ typedef struct {
 } emoasr_attn_t;
 int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream);
 int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream);
+/* The materialised mode's optional scratch as TWO areas instead of seven pointers: emoasr_attn_bwd_mat_bytes(..., which) bytes each
+ * -- which = 0: the images (P^T, dS^T, dBD band; zero-filled by the caller before the first call for a given (B, Tq, Tk, klens),
+ * reusable by later calls with the same masks, e.g. every layer of a backward sweep); which = 1: plain scratch (cs, Q + bias copies,
+ * dbias partials; no initialisation, reusable by any call).  emoasr_attn_bwd_mat_bind fills pdT / dsT / dbd / ldpd / ldbd / cs /
+ * qu / qv / dbias_part of `a` (B, H, Tq, Tk, pos, bias_u, bias_v already set) from the two base addresses.  Replaces the
+ * tensor-by-tensor allocation of emoasr_amd/ops.py: AttnScratch for C callers (csrc/layer.hip: the f32 layer backward). */
+size_t emoasr_attn_bwd_mat_bytes(int dtype, int B, int H, int Tq, int Tk, int rel, int which);
+int emoasr_attn_bwd_mat_bind(int dtype, emoasr_attn_t* a, void* images, void* scratch);
 /* Single-pass backward (bf16, no causal mask): every score tile is recomputed once; dQ, dK, dV, dbias_u/v and dpos come
  * out of four launches (prologue: delta, Q+u, Q+v, zeroed dQ accumulator; main: one workgroup per (batch, head, 128 keys)
  * sweeping the query tiles; dpos: diagonals of the stored dS; finalize: dQ f32 -> T and dbias_v).  Replaces the
@@ -629,7 +637,7 @@ typedef struct emoasr_conformer_fwd {
 } emoasr_conformer_fwd_t;
 int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* layer,
                                const emoasr_conformer_fwd_t* io, void* stream);
-/* Backward of the same layer (bf16; training-mode forward with stash) as one call: gradient kernels in the order the
+/* Backward of the same layer (training-mode forward with stash) as one call: gradient kernels in the order the
  * reference's autograd runs them (conformer.py:146-225 backwards), the layer's nine weight-gradient products as one grouped
  * launch.  `grads`: the layer struct again with every parameter pointer replaced by the address of its f32 gradient
  * (accumulated into; d/H/F/K and the running-statistics fields are ignored).  `st`: the emoasr_conformer_fwd_t the forward
@@ -643,6 +651,10 @@ typedef struct emoasr_conformer_bwd {
   void* dx;
   void* ws; size_t ws_bytes;
   float* ln_part; long ln_part_stride;
+  /* f32 only (the attention backward of f32 layers is the materialised emoasr_attn_bwd, one call per stacked micro-batch):
+   * emoasr_conformer_layer_bwd_img_bytes_seg(...) bytes holding every micro-batch's P^T / dS^T / dBD images, ZERO-filled by the
+   * caller once per backward sweep (the masks of a sweep are the same in every layer) and passed to every layer's call. */
+  void* attn_img; size_t attn_img_bytes;
 } emoasr_conformer_bwd_t;
 size_t emoasr_conformer_layer_bwd_ws_bytes(int dtype, int B, int T, int d, int H, int F, int K);
 /* The convolution module's per-utterance part for stacked micro-batches, every kernel taking ALL segments in one launch (bf16;
@@ -662,6 +674,7 @@ int emoasr_conv_module_bwd_seg(int dtype, const emoasr_segments_t* seg, int C, i
                                float* dgamma, float* dbeta, const void* g, const float* w, void* dg, float* dw, float* dbias,
                                float* bn_scratch, float* dw_scratch, void* stream);
 size_t emoasr_conformer_layer_bwd_ws_bytes_seg(int dtype, const emoasr_segments_t* seg, int d, int H, int F, int K);
+size_t emoasr_conformer_layer_bwd_img_bytes_seg(int dtype, const emoasr_segments_t* seg, int d, int H);   /* 0 for bf16 */
 int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_layer_t* layer, const emoasr_conformer_layer_t* grads,
                                const emoasr_conformer_fwd_t* st, const emoasr_conformer_bwd_t* io, void* stream);
 

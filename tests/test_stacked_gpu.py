@@ -38,10 +38,10 @@ def _micro_batches():
     return [_batch(1, [203, 187, 150, 96]), _batch(2, [403, 380]), _batch(3, [303, 290, 221])]
 
 
-def _model(dev, **over):
+def _model(dev, mode=torch.bfloat16, **over):
     from emoasr_amd.modeling.asr import ASR
     torch.manual_seed(0)
-    model = ASR(SimpleNamespace(**dict(CFG, **over)), compute_dtype=torch.bfloat16)
+    model = ASR(SimpleNamespace(**dict(CFG, **over)), compute_dtype=mode)
     with torch.no_grad():
         for n, p in model.named_parameters():
             if "batch_norm" in n or ".norm" in n:
@@ -54,8 +54,13 @@ def _cos(a, b):
     return (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
 
 
-def test_stacked_pass_equals_the_separate_passes(dev):
-    model = _model(dev)
+@pytest.mark.parametrize("mode", [torch.bfloat16, torch.float32, "f32x3"], ids=["bf16", "f32", "f32x3"])
+def test_stacked_pass_equals_the_separate_passes(dev, mode):
+    """f32 / f32x3 (the layer backward in C++ with the materialised attention backward per micro-batch): the same comparison at
+    losses 1e-5, gradient cosine 0.99999 and 1e-3 of the norm, running statistics 1e-5"""
+    model = _model(dev, mode)
+    f32 = mode is not torch.bfloat16
+    ltol, cbar, ntol, rtol = (1e-5, 0.99999, 1e-3, 1e-5) if f32 else (1e-3, 0.999, 2e-2, 2e-3)
     eng = model.engine()
     assert eng.stacked_ok()
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -78,7 +83,7 @@ def test_stacked_pass_equals_the_separate_passes(dev):
     torch.cuda.synchronize()
     got = losses.tolist()
     for a, b in zip(got, want_losses):
-        assert abs(a - b) < 1e-3 * abs(b), (got, want_losses)
+        assert abs(a - b) < ltol * abs(b), (got, want_losses)
     A = eng.arena
     worst = (1.0, "")
     gmax = want_grad.abs().max().item()
@@ -95,8 +100,8 @@ def test_stacked_pass_equals_the_separate_passes(dev):
             continue
         cos = _cos(g, w)
         worst = min(worst, (cos, name))
-        assert cos > 0.999, (name, cos)
-        assert abs(g.norm().item() / w.norm().item() - 1) < 2e-2, (name, g.norm().item(), w.norm().item())
+        assert cos > cbar, (name, cos)
+        assert abs(g.norm().item() / w.norm().item() - 1) < ntol, (name, g.norm().item(), w.norm().item())
     print("stacked vs separate: worst gradient cosine", worst)
     for k, v in model.state_dict().items():
         if "tracked" in k:
@@ -106,11 +111,12 @@ def test_stacked_pass_equals_the_separate_passes(dev):
             # (bf16 activations; the separate passes' small attention launches split the keys over four waves, the stacked launch
             # does not: the two differ by the order of the soft-max sums; a few bf16 roundings that flip move the mean of a
             # channel by this much: 1.2e-4 .. 5.8e-4 measured over library builds)
-            assert err < 2e-3, (k, err)
+            assert err < rtol, (k, err)
 
 
-def test_stacked_pass_with_dropout_is_reproducible_and_finite(dev):
-    model = _model(dev, dropout_enc_rate=0.1, dropout_attn_rate=0.1)
+@pytest.mark.parametrize("mode", [torch.bfloat16, "f32x3"], ids=["bf16", "f32x3"])
+def test_stacked_pass_with_dropout_is_reproducible_and_finite(dev, mode):
+    model = _model(dev, mode, dropout_enc_rate=0.1, dropout_attn_rate=0.1)
     eng = model.engine()
     datas = _micro_batches()
     same = [datas[0], datas[0]]   # the same micro-batch twice: independent dropout masks -> different losses

@@ -189,14 +189,16 @@ def test_reference_trace_d256_stacked_bf16(dev):
     assert optimizer.state_dict()["_step"] == int(t["optim/_step"])
 
 
+@pytest.mark.parametrize("stacked", [False, True], ids=["one-by-one", "stacked"])
 @pytest.mark.parametrize("mode", [torch.float32, "f32x3"], ids=["f32", "f32x3"])
-def test_reference_trace_d256_f32(dev, mode):
-    """the same reference trace through the f32 engine, one micro-batch after the other (train.train_step): the north-star mode
-    reproduces the reference's twelve updates -- losses 1e-4 (measured 2.7e-6), every stored tensor's update vector cosine
-    0.9999 (measured 1.0000), learning rates exact.  "f32x3" (split-bf16 products over f32 storage) is held to the same bars."""
+def test_reference_trace_d256_f32(dev, mode, stacked):
+    """the same reference trace through the f32 engine, one micro-batch after the other (train.train_step) or the two micro-batches
+    of a step in one stacked pass (train.train_group): the north-star mode reproduces the reference's twelve updates -- losses 1e-4
+    (measured 2.7e-6), every stored tensor's update vector cosine 0.9999 (measured 1.0000), learning rates exact.  "f32x3"
+    (split-bf16 products over f32 storage) is held to the same bars."""
     from emoasr_amd.modeling.asr import ASR
     from emoasr_amd.optimizers import Adam, ScheduledOptimizer
-    from emoasr_amd.train import train_step
+    from emoasr_amd.train import stacked_ok, train_group, train_step
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_trace_d256.npz"))
     t = {k: torch.from_numpy(z[k]) for k in z.files}
     params = SimpleNamespace(**TRACE_CFG)
@@ -208,14 +210,20 @@ def test_reference_trace_d256_f32(dev, mode):
     optimizer.update_epoch()
     data = lambda i: {k: t[f"batch{i}/{k}"] for k in ("xs", "xlens", "ys", "ylens", "ys_in", "ys_out")}
     losses, lrs = [], []
-    for micro in range(24):
+    if stacked:
+        assert stacked_ok(model, optimizer, params) == "ctc"
+        for step in range(12):
+            dicts = train_group(model, optimizer, [data((2 * step) % 3), data((2 * step + 1) % 3)], params, dev)
+            losses += [d["loss_total"] for d in dicts]
+            lrs.append(optimizer._lr)
+    for micro in range(0 if stacked else 24):
         stepping = micro % 2 == 1
         losses.append(train_step(model, optimizer, data(micro % 3), params, dev, no_grad=not stepping)["loss_total"])
         if stepping:
             lrs.append(optimizer._lr)
     assert np.allclose(lrs, t["lrs"].numpy(), rtol=1e-12, atol=0)
     rel = np.abs(np.array(losses) - t["losses"].numpy()) / t["losses"].numpy()
-    print(f"[measured] {mode} replay of the d256 reference trace: loss rel err max {rel.max():.2e}")
+    print(f"[measured] {mode} {'stacked' if stacked else 'one-by-one'} replay of the d256 reference trace: loss rel err max {rel.max():.2e}")
     assert rel.max() < 1e-4, rel
     sd = model.state_dict()
     for k in [k for k in t if k.startswith("end/") and t[k].dtype.is_floating_point and "running" not in k]:
