@@ -530,27 +530,35 @@ def parity_mode(dev, batches, steps=4, warmup=2):
     logits' range, greedy token agreement.  The f32 engine is what tests/ hold to the oracle at 1e-3 / bit-exact ids."""
     from emoasr_amd.modeling.asr import ASR
     from emoasr_amd.train import ArenaAdam, noam_lr
-    def timed(mode):
+    def timed(mode, accum=1):
+        """accum micro-batches per optimizer step (accum > 1: through engine.ctc_train_stacked, as the headline's are)"""
         torch.manual_seed(0)
         m32 = ASR(SimpleNamespace(**L2), compute_dtype=mode).to(dev).train()
-        opt = ArenaAdam(m32.engine().arena, lambda s: noam_lr(OPT["lr"], L2["enc_hidden_size"], OPT["warmup"], s),
+        eng = m32.engine()
+        opt = ArenaAdam(eng.arena, lambda s: noam_lr(OPT["lr"], L2["enc_hidden_size"], OPT["warmup"], s),
                         weight_decay=OPT["weight_decay"], clip_grad_norm=OPT["clip_grad_norm"])
+        assert accum == 1 or eng.stacked_ok()
 
-        def step(bt):
-            loss, _ = m32(bt.xs, bt.xlens, bt.ys, bt.ylens, None, None)
+        def step(group):
             opt.zero_grad()
-            loss.backward()
+            if accum > 1:
+                eng.ctc_train_stacked([(bt.xs, bt.xlens, bt.ys, bt.ylens) for bt in group], L2["blank_id"])
+            else:
+                loss, _ = m32(group[0].xs, group[0].xlens, group[0].ys, group[0].ylens, None, None)
+                loss.backward()
             opt.step()
 
-        for bt in batches[:warmup]:
-            step(bt)
+        groups = [batches[i * accum:(i + 1) * accum] for i in range(len(batches) // accum)]
+        nw, ns = (warmup, steps) if accum == 1 else (1, min(3, len(groups) - 1))
+        for g in groups[:nw]:
+            step(g)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for bt in batches[warmup:warmup + steps]:
-            step(bt)
+        for g in groups[nw:nw + ns]:
+            step(g)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        return sum(sum(b.xlens) for b in batches[warmup:warmup + steps]) / el, 1e3 * el / steps
+        return sum(sum(b.xlens) for g in groups[nw:nw + ns] for b in g) / el, 1e3 * el / ns
 
     f32_fps, f32_ms = timed(torch.float32)
     x3_fps, x3_ms = timed("f32x3")
@@ -558,6 +566,15 @@ def parity_mode(dev, batches, steps=4, warmup=2):
            # the throughput mode that meets north_star's tolerances: f32 storage, every matrix product as three bf16 MFMAs over
            # (hi, lo) operand pairs (compute_dtype "f32x3"); one micro-batch per optimizer step, like the f32 leg
            "parity_mode_frames_per_s": x3_fps, "parity_mode_ms_per_step": x3_ms, "parity_mode": "f32x3"}
+    acc = 5
+    if len(batches) >= 2 * acc:
+        # ... and with the headline's accumulation: five micro-batches per optimizer step in one stacked pass
+        s_fps, s_ms = timed("f32x3", acc)
+        out.update({"parity_mode_one_by_one_frames_per_s": x3_fps, "parity_mode_one_by_one_ms_per_step": x3_ms,
+                    "parity_mode_frames_per_s": s_fps, "parity_mode_ms_per_step": s_ms, "parity_mode_accum_grad": acc,
+                    "parity_mode_stacked_micro_batches": True})
+        f_fps, f_ms = timed(torch.float32, acc)
+        out.update({"f32_stacked_frames_per_s": f_fps, "f32_stacked_ms_per_step": f_ms})
     # bf16 vs f32 on identical weights and inputs, no dropout
     cfg0 = dict(L2, dropout_enc_rate=0.0, dropout_attn_rate=0.0)
     torch.manual_seed(0)

@@ -32,6 +32,26 @@ def step(bt):
     opt.step()
 
 
+def step_stacked(group):
+    opt.zero_grad()
+    m32.engine().ctc_train_stacked([(bt.xs, bt.xlens, bt.ys, bt.ylens) for bt in group], bench.L2["blank_id"])
+    opt.step()
+
+
+if "--stacked" in sys.argv:   # five micro-batches per optimizer step in one stacked pass (9 steps, 3 of them warm-up)
+    batches = bench.make_batches(0, 1, 45, dev)
+    groups = [batches[5 * i:5 * i + 5] for i in range(9)]
+    for g in groups[:3]:
+        step_stacked(g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for g in groups[3:9]:
+        step_stacked(g)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    nfr = sum(sum(b.xlens) for g in groups[3:9] for b in g)
+    print(f"{'f32x3' if MODE == 'f32x3' else 'f32'} stacked x5: {nfr / el:.0f} frames/s, {1e3 * el / 6:.2f} ms per step")
+    sys.exit(0)
 for bt in batches[:3]:
     step(bt)
 torch.cuda.synchronize()
