@@ -63,6 +63,7 @@ void emo_gemm_set_big_korder(int v);
 void emo_gemm_set_big_min_tiles(int v);
 void emo_conv_set_dwconv_lds(int v);
 void emo_layer_set_conv_fused(int v);
+void emo_layer_set_wgrad_side(int v);
 void emo_layer_set_stack_launch(int v);
 void emo_layer_set_ffn_save_dact(int v);
 void emo_ln_set_fwd8(int v);
@@ -189,6 +190,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "big_min_tiles") == 0) { emo_gemm_set_big_min_tiles(value); return 0; }
   if (strcmp(name, "dwconv_lds") == 0) { emo_conv_set_dwconv_lds(value); return 0; }
   if (strcmp(name, "conv_fused") == 0) { emo_layer_set_conv_fused(value); return 0; }
+  if (strcmp(name, "wgrad_side") == 0) { emo_layer_set_wgrad_side(value); return 0; }
   if (strcmp(name, "stack_launch") == 0) { emo_layer_set_stack_launch(value); return 0; }
   if (strcmp(name, "ffn_save_dact") == 0) { emo_layer_set_ffn_save_dact(value); return 0; }
   if (strcmp(name, "conv1_pair") == 0) { emo_conv1_set_pair(value); return 0; }

@@ -5,6 +5,9 @@
 // MHA, convolution module, FFN, final LayerNorm; residual scales 0.5 / 1 / 1 / 0.5).
 #include <math.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 #include "../../include/emoasr_hip.h"
 
@@ -31,6 +34,40 @@ int g_stack_launch = 1;  // stacked micro-batches: 1 = the per-utterance kernels
                          // their arguments), 0 = one launch per segment (same arithmetic; A/B switch, option "stack_launch")
 int g_conv_fused = 1;  // bf16: the fused convolution-module kernels of csrc/convfused.hip (bit-identical to the separate launches)
 bool conv_fused_ok(int dtype, int d) { return g_conv_fused && dtype == EMO_BF16 && d % 8 == 0; }
+
+// Option "wgrad_side": the layer backward's grouped weight-gradient launch (nine products, ~0.2 ms at the stacked row count, 0.7
+// rounds of workgroups) goes to a SIDE stream and runs under the NEXT layer's gradient chain, most of whose launches leave CUs
+// idle; nothing on that chain reads a weight gradient.  One side stream + two completion events per (device, caller stream).  The
+// launch reads the layer's workspace, so callers alternate between TWO workspaces from call to call (emoasr_amd/layer_rt.py); a
+// call first waits for the launch issued two calls earlier (the last reader of its workspace).  emoasr_wgrad_side_join makes
+// the caller's stream wait for the launches still in flight (before the optimizer, a gradient hook or a workspace release).
+int g_wgrad_side = 0;
+struct WgSide {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
+  bool pending[2] = {false, false};
+  unsigned n = 0;   // launches so far: launch k signals done[k & 1]
+};
+std::mutex g_wg_mu;
+std::map<std::pair<int, hipStream_t>, WgSide> g_wg;
+
+WgSide* wg_side_of(hipStream_t s, bool create) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;   // (captured launches stay inline)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_wg_mu);
+  auto it = g_wg.find({dev, s});
+  if (it != g_wg.end()) return &it->second;
+  if (!create) return nullptr;
+  WgSide w;
+  if (hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&w.fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&w.done[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&w.done[1], hipEventDisableTiming) != hipSuccess)
+    return nullptr;
+  return &(g_wg[{dev, s}] = w);
+}
 
 int ffn_fwd(int dtype, int M, int d, int F, const emoasr_ffn_params_t& p, const void* x, float res_scale,
             float p_enc, uint64_t s_in, uint64_t s_out, const emoasr_ffn_stash_t& st, void* stream) {
@@ -100,6 +137,21 @@ void attn_args_for(emoasr_attn_t& a, const SegView& sv, int s0, int s1, int H, i
 
 }  // namespace
 
+void emo_layer_set_wgrad_side(int v) { g_wgrad_side = v ? 1 : 0; }
+extern "C" int emoasr_wgrad_side_join(int keep, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  WgSide* w = wg_side_of(s, false);
+  if (!w) return 0;
+  // launch n - 1 signals done[(n - 1) & 1] (the latest), launch n - 2 the other one
+  for (int back = 2; back > (keep > 0 ? 1 : 0); --back) {
+    if (w->n < (unsigned)back) continue;
+    const int slot = (w->n - back) & 1;
+    if (!w->pending[slot]) continue;
+    if (hipStreamWaitEvent(s, w->done[slot], 0) != hipSuccess) { emo_set_error("wgrad_side_join: hipStreamWaitEvent failed"); return 1; }
+    w->pending[slot] = false;
+  }
+  return 0;
+}
 void emo_layer_set_conv_fused(int v) { g_conv_fused = v; }
 void emo_layer_set_stack_launch(int v) { g_stack_launch = v; }
 void emo_layer_set_ffn_save_dact(int v) { g_ffn_save_dact = v ? 1 : 0; }
@@ -297,6 +349,11 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
   hipStream_t s = (hipStream_t)stream;
   emoasr_tn_problem_t pr[EMOASR_TN_GROUP_MAX];
   int npr = 0;
+  WgSide* wgs = g_wgrad_side ? wg_side_of(s, true) : nullptr;
+  if (wgs && wgs->pending[wgs->n & 1]) {   // the launch of two calls ago read THIS workspace (callers alternate between two)
+    if (hipStreamWaitEvent(s, wgs->done[wgs->n & 1], 0) != hipSuccess) return 1;
+    wgs->pending[wgs->n & 1] = false;
+  }
   auto wgrad = [&](const void* dy, long lddy, int N1, const void* x, long ldx, int N2, int Kred, const void* gw, float alpha,
                    const void* gb) {
     pr[npr++] = emoasr_tn_problem_t{N1, N2, Kred, dy, lddy, x, ldx, (float*)gw, (long)N2, alpha, (float*)gb, alpha};
@@ -454,5 +511,16 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
              nullptr, 0.f, 0)) return 1;
   // ---- the layer's weight gradients, one launch -----------------------------------------------------------------------
   emo_attn_bwd_join(stream);
-  return emoasr_gemm_tn_grouped(dtype, npr, pr, stream);
+  if (!wgs) return emoasr_gemm_tn_grouped(dtype, npr, pr, stream);
+  // fork: everything this call put on the caller's stream precedes the side launch; its completion is an event of its own
+  const int slot = wgs->n & 1;
+  if (hipEventRecord(wgs->fork, s) != hipSuccess || hipStreamWaitEvent(wgs->side, wgs->fork, 0) != hipSuccess) {
+    emo_set_error("conformer_layer_bwd: fork to the weight-gradient stream failed");
+    return 1;
+  }
+  if (emoasr_gemm_tn_grouped(dtype, npr, pr, wgs->side)) return 1;
+  if (hipEventRecord(wgs->done[slot], wgs->side) != hipSuccess) { emo_set_error("conformer_layer_bwd: hipEventRecord failed"); return 1; }
+  wgs->pending[slot] = true;
+  ++wgs->n;
+  return 0;
 }

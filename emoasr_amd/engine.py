@@ -701,9 +701,12 @@ class CTCEngine(_DecoderMixinPlaceholder):
             if self.grad_hook is not None:
                 self._flush_wgrads()
                 ops.layernorm_bwd_finalize(self._ln_deferred)
-                self.grad_hook(self._layer_offset(li))
+                self._hook_after_layer(li)
         self._flush_wgrads()
+        self._layer_rt.join_wgrads()
         ops.layernorm_bwd_finalize(self._ln_deferred)
+        if self.grad_hook is not None and self._layer_rt.wgrad_side:
+            self.grad_hook(self._layer_offset(0))
         # positional scaling, Linear (all rows at once), then the two convolutions per micro-batch
         dlin = ops.scale_dropout(dx, math.sqrt(d), self.p_enc, st.s_pe)
         dwl = torch.zeros(d, F2 * C, device=dev, dtype=torch.float32)  # (f, c) order
@@ -827,6 +830,17 @@ class CTCEngine(_DecoderMixinPlaceholder):
             self._wq.append((dy, x_in, out, alpha, colsum, colsum_scale))
         else:
             ops.gemm_tn(dy, x_in, out=out, alpha=alpha, accumulate=True, colsum=colsum, colsum_scale=colsum_scale)
+
+    def _hook_after_layer(self, li):
+        """gradient hook after layer li's backward call.  With the layers' weight-gradient launches on the side stream
+        (layer_rt.wgrad_side) the hook runs ONE LAYER BEHIND the sweep: layer li's launch has just been issued, every earlier one is
+        waited for, so what is final are the gradients from layer li + 1 up."""
+        if not self._layer_rt.wgrad_side:
+            self.grad_hook(self._layer_offset(li))
+            return
+        self._layer_rt.join_wgrads(keep=1)
+        if li + 1 < self.nl:
+            self.grad_hook(self._layer_offset(li + 1))
 
     def _layer_offset(self, li):
         """lowest gradient-arena offset of encoder layer li's parameters"""
@@ -1035,7 +1049,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
                 dx = out
                 if self.grad_hook is not None and li + 1 <= (inter if inter > 0 else nl):
                     ops.layernorm_bwd_finalize(self._ln_deferred)
-                    self.grad_hook(self._layer_offset(li))
+                    self._hook_after_layer(li)
                 continue
             s_ffm, s_att, s_conv, s_ff, s_fin = st.layers[li]
             if li + 1 == inter:
@@ -1076,6 +1090,10 @@ class CTCEngine(_DecoderMixinPlaceholder):
                 # (with an intermediate branch, encoder.norm's gradient is final only once layer inter-1 is done)
                 ops.layernorm_bwd_finalize(self._ln_deferred)  # this layer's LayerNorm gradients must be final too
                 self.grad_hook(self._layer_offset(li))
+        if cpp_bwd:
+            self._layer_rt.join_wgrads()
+            if self.grad_hook is not None and self._layer_rt.wgrad_side:
+                self.grad_hook(self._layer_offset(0))
         ops.layernorm_bwd_finalize(self._ln_deferred)
         # ---- positional scaling, Linear, Conv2d x2 -----------------------------------
         pre = "encoder.conv."

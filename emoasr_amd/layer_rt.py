@@ -110,7 +110,12 @@ class ConformerLayerRuntime:
         self.params = {}    # layer index -> (lib.ConformerLayer, guard)
         self.grads = {}     # layer index -> (lib.ConformerLayer of gradient pointers, guard)
         self.layouts = {}   # (B, T) -> _Layout
-        self.bwd_ws = None  # one backward workspace, shared by all layers (they run one after the other)
+        # backward workspaces: one shared by all layers (they run one after the other) -- two, taken in turn, when the layers' weight-
+        # gradient launches run on the side stream (option "wgrad_side": a launch reads its layer's workspace under the next layer)
+        self.bwd_ws = [None, None]
+        self.wgrad_side = os.environ.get("EMOASR_CPP_WGRAD_SIDE", "0") != "0"
+        lib.set_option("wgrad_side", int(self.wgrad_side))
+        self.calls = 0
         self.attn_img, self.attn_img_key = None, None  # f32: zero-filled attention images of the current backward sweep
         self.sweeps = 0
 
@@ -275,11 +280,14 @@ class ConformerLayerRuntime:
             nb = lib.size_query("emoasr_conformer_layer_bwd_ws_bytes", ops.dt(st.wt), B, T, eng.d, eng.h, L.F, L.K)
         else:
             nb = lib.ws_bytes_seg(ops.dt(st.wt), st.io.seg, eng.d, eng.h, L.F, L.K)
-        if self.bwd_ws is None or self.bwd_ws.numel() < nb:
-            self.bwd_ws = torch.empty(int(nb * 1.1) + 256, device=dy.device, dtype=torch.uint8)
+        k = (self.calls & 1) if self.wgrad_side else 0
+        self.calls += 1
+        if self.bwd_ws[k] is None or self.bwd_ws[k].numel() < nb:
+            self.join_wgrads()   # (a launch in flight may still read the buffer that is being replaced)
+            self.bwd_ws[k] = torch.empty(int(nb * 1.1) + 256, device=dy.device, dtype=torch.uint8)
         io = lib.ConformerBwd()
         io.dy, io.dx = dy.data_ptr(), dx.data_ptr()
-        io.ws, io.ws_bytes = self.bwd_ws.data_ptr(), self.bwd_ws.numel()
+        io.ws, io.ws_bytes = self.bwd_ws[k].data_ptr(), self.bwd_ws[k].numel()
         if st.wt.dtype != torch.bfloat16:
             # f32: the materialised attention backward's P^T / dS^T / dBD images, zero-filled ONCE per backward sweep (every layer of
             # a sweep masks the same entries) -- the sweep is known by the forward pass that made its stashes
@@ -302,6 +310,11 @@ class ConformerLayerRuntime:
         M = st.lay.M
         for k, norm in enumerate(("norm_final", "norm_ff", "norm_conv", "norm_self_attn", "norm_ff_macaron")):
             deferred.append((M, eng.d, ln_part[k], A.g(f"{name}.{norm}.weight"), A.g(f"{name}.{norm}.bias")))
+
+    def join_wgrads(self, keep=0):
+        """the current stream waits for the weight-gradient launches on the side stream: all (keep = 0) or all but the latest"""
+        if self.wgrad_side:
+            lib.call("emoasr_wgrad_side_join", int(keep), ops._stream())
 
 
 def tb_prev(x, esz):

@@ -241,6 +241,7 @@ SIGNATURES = {
     "emoasr_ctc_forward": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, P],
     "emoasr_ctc_grad": [I, I, I, I, I, P, L, P, P, P, P, I, P, P, P, P, F, P, P, L, P],
     "emoasr_rnnt_greedy": [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P],
+    "emoasr_wgrad_side_join": [I, P],
     "emoasr_rnnt_beam_lstm": [I, I, I, I, P, L, P, P, P, P, P, P, P, P, P, P, I, P],
     "emoasr_rnnt_beam_joint": [I, I, I, I, I, P, P, P, P, P, P, P, P],
     "emoasr_rnnt_beam_pick": [I, I, I, I, I, P, L, P, L, P],

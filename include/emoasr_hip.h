@@ -674,6 +674,14 @@ int emoasr_conv_module_bwd_seg(int dtype, const emoasr_segments_t* seg, int C, i
                                float* dgamma, float* dbeta, const void* g, const float* w, void* dg, float* dw, float* dbias,
                                float* bn_scratch, float* dw_scratch, void* stream);
 size_t emoasr_conformer_layer_bwd_ws_bytes_seg(int dtype, const emoasr_segments_t* seg, int d, int H, int F, int K);
+/* emoasr_set_option("wgrad_side", 1): emoasr_conformer_layer_bwd puts its grouped weight-gradient launch on a side stream (one
+ * per (device, caller stream)) where it runs under the NEXT layer's gradient chain.  The launch reads the call's workspace: callers
+ * then alternate between TWO workspaces from call to call (a call waits for the launch issued two calls earlier before it touches
+ * its workspace) and call emoasr_wgrad_side_join(keep, stream) before anything reads the weight gradients or frees a workspace:
+ * the caller's stream waits for the launches in flight -- all of them (keep = 0) or all but the latest (keep = 1: the gradients of
+ * every layer but the one just finished are final; for a per-layer gradient hook one layer behind the sweep).  Captured streams run
+ * the launch inline. */
+int emoasr_wgrad_side_join(int keep, void* stream);
 size_t emoasr_conformer_layer_bwd_img_bytes_seg(int dtype, const emoasr_segments_t* seg, int d, int H);   /* 0 for bf16 */
 int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_layer_t* layer, const emoasr_conformer_layer_t* grads,
                                const emoasr_conformer_fwd_t* st, const emoasr_conformer_bwd_t* io, void* stream);
