@@ -137,6 +137,47 @@ def test_stacked_pass_with_dropout_is_reproducible_and_finite(dev, mode):
     assert (g1 - g2).abs().max().item() < 2e-3 * g1.abs().max().item()   # (float atomics in the weight gradients)
 
 
+@pytest.mark.parametrize("mode", [torch.bfloat16, "f32x3"], ids=["bf16", "f32x3"])
+def test_weight_gradients_on_the_side_stream_equal_the_inline_launches(dev, mode):
+    """option wgrad_side: every layer's grouped weight-gradient launch on the side stream, two workspaces in turn -- the same
+    gradients as the inline launches (float atomics aside), gradient hooks one layer behind the sweep and still in order"""
+    from emoasr_amd import lib
+    model = _model(dev, mode, dropout_enc_rate=0.1, dropout_attn_rate=0.1)
+    eng = model.engine()
+    datas = _micro_batches()
+    batches = [(d["xs"].to(dev), [int(v) for v in d["xlens"]], d["ys"], [int(v) for v in d["ylens"]]) for d in datas]
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    res = {}
+    try:
+        for side in (False, True, False):
+            model.load_state_dict(sd0)
+            eng.step_count = 5
+            eng.arena.grad.zero_()
+            if eng._layer_rt is not None:
+                eng._layer_rt.wgrad_side = side
+            lib.set_option("wgrad_side", int(side))
+            seen = []
+            eng.grad_hook = seen.append
+            losses = eng.ctc_train_stacked(batches, 0)
+            if eng._layer_rt.wgrad_side != side:   # (the runtime was created by this first pass: switch and repeat)
+                eng._layer_rt.wgrad_side = side
+            torch.cuda.synchronize()
+            res.setdefault(side, []).append((losses.tolist(), eng.arena.grad.clone(), seen))
+    finally:
+        eng.grad_hook = None
+        lib.set_option("wgrad_side", 0)
+        if eng._layer_rt is not None:
+            eng._layer_rt.wgrad_side = False
+    (l0, g0, h0), (l1, g1, h1) = res[False][0], res[True][0]
+    assert l0 == l1
+    gmax = g0.abs().max().item()
+    noise = (res[False][1][1] - g0).abs().max().item()     # two inline runs: the float-atomic reordering alone
+    assert (g1 - g0).abs().max().item() <= max(4 * noise, 1e-6 * gmax), ((g1 - g0).abs().max().item(), noise, gmax)
+    # hooks: descending offsets; the side-stream sweep reports every layer one call later and layer 0 after the join
+    assert h0 == sorted(h0, reverse=True) and h1 == sorted(h1, reverse=True)
+    assert set(h1) <= set(h0) and min(h1) == min(h0)
+
+
 def test_train_loop_takes_the_stacked_path(dev, monkeypatch):
     """train.train with accum_grad 3: two optimizer steps through train_group == six train_step calls"""
     from emoasr_amd import train as tr
