@@ -33,8 +33,10 @@ def _batch(seed, xlens):
     return dict(xs=xs, xlens=xlens, ys=ys, ylens=ylens, ys_in=None, ys_out=None)
 
 
-def _micro_batches():
+def _micro_batches(shape="regular"):
     # different batch sizes AND different padded lengths (T' = 49 / 99 / 74), ragged utterances inside each
+    if shape == "extreme":   # ... down to segments of one encoder frame (7 input frames) next to a 50-frame one
+        return [_batch(1, [203, 35]), _batch(2, [7, 7]), _batch(3, [11, 7, 7])]
     return [_batch(1, [203, 187, 150, 96]), _batch(2, [403, 380]), _batch(3, [303, 290, 221])]
 
 
@@ -54,8 +56,9 @@ def _cos(a, b):
     return (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
 
 
+@pytest.mark.parametrize("shape", ["regular", "extreme"])
 @pytest.mark.parametrize("mode", [torch.bfloat16, torch.float32, "f32x3"], ids=["bf16", "f32", "f32x3"])
-def test_stacked_pass_equals_the_separate_passes(dev, mode):
+def test_stacked_pass_equals_the_separate_passes(dev, mode, shape):
     """f32 / f32x3 (the layer backward in C++ with the materialised attention backward per micro-batch): the same comparison at
     losses 1e-5, gradient cosine 0.99999 and 1e-3 of the norm, running statistics 1e-5"""
     model = _model(dev, mode)
@@ -64,7 +67,7 @@ def test_stacked_pass_equals_the_separate_passes(dev, mode):
     eng = model.engine()
     assert eng.stacked_ok()
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    datas = _micro_batches()
+    datas = _micro_batches(shape)
     n = len(datas)
     # ---- one after the other (module API, autograd): loss / n each
     eng.arena.grad.zero_()
