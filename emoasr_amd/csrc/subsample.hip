@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256) void conv1_fwd2_kernel(int Tn, int F, int T1, 
 // (the f1 lanes of a channel group are adjacent lanes: 16-byte dy1 loads, 128-byte row segments, and a
 // 3-step shuffle folds them at the end).  The input rows of C1_SUB t1 rows are staged in LDS at a time.
 // One atomic per (block, output): large row chunks keep the same-address contention low.
-constexpr int C1_TROWS = 32;
+#ifndef EMO_C1_TROWS
+#define EMO_C1_TROWS 32
+#endif
+constexpr int C1_TROWS = EMO_C1_TROWS;   // (-DEMO_C1_TROWS=16 | 8: build variants for the A/B of tools/r05_run24.sh)
 constexpr int C1_SUB = 8;
 constexpr int C1_FJ = 8;   // f1 positions per lane (8 lanes stride 8): F1 <= 64
 template <typename T>
