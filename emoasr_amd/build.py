@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libemoasr_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "elementwise.hip", "convmodule.hip",
-           "subsample.hip", "ctc.hip", "attention.hip", "optim.hip", "feats.hip", "decoder.hip", "rnnt.hip", "layer.hip", "decode_rt.hip", "distill.hip", "gemm_big.hip", "convfused.hip", "rowlin.hip", "decode_coop.hip", "lstm_coop.hip", "rnnt_greedy.hip", "rnnt_beam.hip"]
+           "subsample.hip", "ctc.hip", "attention.hip", "optim.hip", "feats.hip", "decoder.hip", "rnnt.hip", "layer.hip", "decode_rt.hip", "distill.hip", "gemm_big.hip", "convfused.hip", "rowlin.hip", "decode_coop.hip", "lstm_coop.hip", "rnnt_greedy.hip", "rnnt_beam.hip", "ctc_beam_host.hip"]
 # measured-slower variants kept reproducible: linked in only when EMOASR_EXPERIMENTAL=1 is set at build time
 EXPERIMENTAL = ["experimental/decode_wg.hip", "experimental/gemm_k256.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-Wno-comment",

@@ -3,10 +3,13 @@ asr/modeling/decoders/ctc.py:203-344 (`CTCDecoder._beam_search`) and :372-397 (`
 
 Split of work: the acoustic side runs once per utterance on the GPU (output projection, log-softmax
 and the per-frame top-k, all frames in one launch each: emoasr_gemm_nt / emoasr_log_softmax /
-emoasr_topk) and comes to the host in one copy; the Transformer LM scores all live prefixes of a frame
-in one batched device call (LM.predict, as the reference batches them with pad_sequence, ctc.py:241-260);
-the prefix bookkeeping itself -- a few dozen scalar updates per frame -- is host code in float64, like
-the reference's python floats.
+emoasr_topk) and comes to the host in one copy; the Transformer LM scores the NEW prefixes of a frame
+in one batched device call (LM.predict, as the reference batches them with pad_sequence, ctc.py:241-260),
+its rows stay on the device while their prefix is live and a frame brings only its k candidate columns to
+the host; the prefix bookkeeping itself -- ~110 candidates per frame: extend, merge, stable sort, prune --
+is native host code in IEEE doubles, like the reference's python floats (csrc/ctc_beam_host.hip:
+emoasr_ctc_beam_step, 20 us per frame).  EMOASR_CTC_BEAM_NATIVE=0 runs the same bookkeeping as the Python
+loop below (bit-identical results; tests/test_ctc_beam_gpu.py compares the two).
 
 Reference behaviour kept on purpose (it decides which prefixes survive):
   * the LM score of the k-th candidate extension of a prefix also contains the LM scores of the
@@ -45,6 +48,67 @@ class _Prefix:
         return self.asr + self.lm + self.len_bonus
 
 
+def _search_native(logp_dev, top_dev, T, V, k, blank, eos, beam_width, len_weight, lm, lm_weight):
+    """the frame loop over csrc/ctc_beam_host.hip: per frame one C call (bookkeeping), and -- with an LM -- one batched LM call for
+    the prefixes that are new plus one [live, k] gather of their cached rows (the frame's only device-to-host copy)"""
+    import ctypes
+    from .. import lib
+    L = lib.load()
+    L.emoasr_ctc_beam_new.restype = ctypes.c_void_p
+    L.emoasr_ctc_beam_new.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    L.emoasr_ctc_beam_free.argtypes = [ctypes.c_void_p]
+    L.emoasr_ctc_beam_free.restype = None
+    L.emoasr_ctc_beam_step.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
+    L.emoasr_ctc_beam_scores.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    use_lm = lm is not None and lm_weight > 0
+    logp = logp_dev.cpu().numpy()                      # f32 [T, V]: one D2H for the whole utterance (rows read as doubles in C)
+    top = np.ascontiguousarray(top_dev.cpu().numpy().astype(np.int32))
+    h = L.emoasr_ctc_beam_new(int(beam_width), int(blank), int(eos), float(len_weight), float(lm_weight if use_lm else 0.0))
+    assert h, "emoasr_ctc_beam_new failed"
+    try:
+        parent = np.zeros(beam_width, dtype=np.int32)
+        tok = np.zeros(beam_width, dtype=np.int32)
+        live = [(eos,)]
+        dev = logp_dev.device
+        if use_lm:
+            nslot = 2 * beam_width + 2
+            cache = torch.empty(nslot, V, device=dev, dtype=torch.float32)   # LM rows of the live prefixes
+            slot_of, free = {}, list(range(nslot))
+            top_long = top_dev.long()
+        for t in range(T):
+            lm_ptr = None
+            if use_lm:
+                need = [p for p in live if p not in slot_of]
+                if need:
+                    n = max(len(p) for p in need)
+                    batch = torch.zeros(len(need), n, dtype=torch.int64)   # 0-padded like pad_sequence (ctc.py:243-246)
+                    for i, p in enumerate(need):
+                        batch[i, : len(p)] = torch.tensor(p)
+                    rows, _ = lm.predict(batch, [len(p) for p in need])
+                    ids = []
+                    for p in need:
+                        slot_of[p] = free.pop()
+                        ids.append(slot_of[p])
+                    cache.index_copy_(0, torch.tensor(ids, device=dev), rows.float())
+                sl = torch.tensor([slot_of[p] for p in live], device=dev)
+                vals = cache.index_select(0, sl).index_select(1, top_long[t]).cpu().numpy().astype(np.float64)   # [live, k]
+                vals = np.ascontiguousarray(vals)
+                lm_ptr = vals.ctypes.data
+            n = L.emoasr_ctc_beam_step(h, logp[t].ctypes.data, top[t].ctypes.data, int(k), lm_ptr, parent.ctypes.data, tok.ctypes.data)
+            if n < 0:
+                raise lib.EmoasrHipError("emoasr_ctc_beam_step failed: " + L.emoasr_last_error().decode())
+            live = [live[parent[i]] + ((int(tok[i]),) if tok[i] >= 0 else ()) for i in range(n)]
+            if use_lm:
+                keep = set(live)
+                for key in [q for q in slot_of if q not in keep]:
+                    free.append(slot_of.pop(key))
+        scores = np.zeros(len(live), dtype=np.float64)
+        L.emoasr_ctc_beam_scores(h, scores.ctypes.data)
+        return [list(p) for p in live], [float(v) for v in scores]
+    finally:
+        L.emoasr_ctc_beam_free(h)
+
+
 def ctc_prefix_beam_search(dec, eouts, elens, beam_width, len_weight=0.0, lm=None, lm_weight=0.0):
     """-> (hyps, scores, logits) for ONE utterance (the reference asserts batch size 1, ctc.py:212)."""
     assert eouts.shape[0] == 1, "CTC beam search decodes one utterance at a time (ctc.py:212)"
@@ -56,6 +120,9 @@ def ctc_prefix_beam_search(dec, eouts, elens, beam_width, len_weight=0.0, lm=Non
         logp_dev = ops.log_softmax(logits.view(T, V))        # f32 [T, V]
         k = min(beam_width, V)
         _, top_dev, _ = ops.topk(logp_dev, k)                # ids sorted by descending score, per frame
+        if os.environ.get("EMOASR_CTC_BEAM_NATIVE", "1") != "0":
+            hyps, scores = _search_native(logp_dev, top_dev, T, V, k, blank, eos, beam_width, len_weight, lm, lm_weight)
+            return hyps, scores, logits
         logp = logp_dev.cpu().numpy().astype(np.float64)     # one D2H for the whole utterance
         top = top_dev.cpu().numpy()
     use_lm = lm is not None and lm_weight > 0

@@ -856,6 +856,24 @@ int emoasr_fbank(const float* wav, long n_samples, int frame_len, int frame_shif
 /* (x - mean[f]) / std[f] in place, f32 [M,F] */
 int emoasr_cmvn(int M, int F, float* x, const float* mean, const float* std, void* stream);
 
+/* ---- CTC prefix beam search: per-frame bookkeeping (host) ------------------------------------------------- */
+/* The prefix bookkeeping of CTCDecoder._beam_search / _merge_ctc_paths (asr/modeling/decoders/ctc.py:262-344, 372-397) as native
+ * HOST code in IEEE doubles, bit-identical to the reference's python floats: extend every live prefix by blank / repeat and by the
+ * frame's top-k labels, merge equal label sequences (path probabilities folded, the first path's LM / length scores kept), stable
+ * sort by asr + lm + length bonus, keep beam_width.  The acoustic side (projection, log-soft-max, top-k) and the LM stay device
+ * calls (emoasr_gemm_nt / emoasr_log_softmax / emoasr_topk; LM rows cached on the device, a frame brings only its k candidate
+ * columns to the host).  emoasr_ctc_beam_step: row = the frame's log-probabilities f32 [V] (host), top = its k best labels (best
+ * first; the blank is skipped), lm_lp = [live, k] LM log-probabilities of those labels after each live prefix or NULL;
+ * parent / tok [beam_width] receive how each surviving prefix was formed (index into the previous live set; appended label or
+ * -1 for an unchanged prefix).  -> number of live prefixes (< 0: error).  A search starts with the single prefix (<eos>). */
+typedef struct emoasr_ctc_beam emoasr_ctc_beam_t;
+emoasr_ctc_beam_t* emoasr_ctc_beam_new(int beam_width, int blank, int eos, double len_weight, double lm_weight);
+void emoasr_ctc_beam_free(emoasr_ctc_beam_t* h);
+int emoasr_ctc_beam_size(const emoasr_ctc_beam_t* h);
+int emoasr_ctc_beam_step(emoasr_ctc_beam_t* h, const float* row, const int* top, int k, const double* lm_lp, int* parent, int* tok);
+int emoasr_ctc_beam_prefix(const emoasr_ctc_beam_t* h, int i, int* toks, int cap);   /* -> length of live prefix i */
+int emoasr_ctc_beam_scores(const emoasr_ctc_beam_t* h, double* total);              /* -> number of live prefixes */
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,3 +64,20 @@ def test_lm_predict_graph_replay_equals_the_eager_call(dev, dtype, monkeypatch):
         got, _ = lm.predict(ys, lens)
         again, _ = lm.predict(ys, lens)
         assert torch.equal(got, want) and torch.equal(again, want), (B, N)
+
+
+@pytest.mark.parametrize("si", range(len(CTC_BEAM_SETTINGS)))
+def test_native_bookkeeping_equals_the_python_loop(dev, si, monkeypatch):
+    """the prefix bookkeeping in C (csrc/ctc_beam_host.hip; LM rows cached on the device, a frame reads its k candidate columns)
+    against the Python loop it replaces: the same hypotheses and BIT-identical float64 scores"""
+    model, lm, g2, gb = _build(torch.float32, dev)
+    st = CTC_BEAM_SETTINGS[si]
+    for b in (1, 2, 3):
+        n = int(g2["xlens"][b])
+        xs, xl = g2["xs"][b:b + 1, :n].to(dev), g2["xlens"][b:b + 1]
+        monkeypatch.setenv("EMOASR_CTC_BEAM_NATIVE", "0")
+        want_h, want_s, _, _ = model.decode(xs, xl, lm=lm, **st)
+        monkeypatch.setenv("EMOASR_CTC_BEAM_NATIVE", "1")
+        got_h, got_s, _, _ = model.decode(xs, xl, lm=lm, **st)
+        assert got_h == want_h, (si, b)
+        assert list(got_s) == list(want_s), (si, b, got_s, want_s)
