@@ -310,7 +310,8 @@ def decode_rtf(model, dev, tmpdir):
 def ctc_beam_rtf(model, dev, dtype, tmpdir, n_utts=3):
     """CTC prefix beam search with LM shallow fusion for the CTC model itself (asr/modeling/decoders/ctc.py:203-344): beam 10,
     12-layer Transformer LM at weight 0.3, batch 1, the reference's RTF protocol on a few utterances (random-init weights: a
-    full beam of distinct prefixes at every frame).  Acoustic side on the GPU, one LM call per NEW prefix, bookkeeping on the host."""
+    full beam of distinct prefixes at every frame).  Acoustic side on the GPU, one LM call per NEW prefix (rows cached on the device),
+    the per-frame bookkeeping in native host code (csrc/ctc_beam_host.hip)."""
     import logging
     from emoasr_amd import decode as dec
     from emoasr_amd.modeling.lm import LM
