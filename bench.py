@@ -554,9 +554,21 @@ def parity_mode(dev, batches, steps=4, warmup=2):
         for g in groups[:nw]:
             step(g)
         torch.cuda.synchronize()
+        if accum > 1:
+            # every group has its own stacked shapes: its first pass grows the caching allocator's pool by gigabytes (hipMalloc inside
+            # the region: one run read 119 ms per step for 79 ms of kernels) -- the timed groups run once untimed first
+            for g in groups[nw:nw + ns]:
+                step(g)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for g in groups[nw:nw + ns]:
             step(g)
+            if os.environ.get("EMOASR_BENCH_TRACE"):
+                from emoasr_amd import ops as _ops
+                torch.cuda.synchronize()
+                print("[parity %s x%d] %.1f ms since start, split flag %d, mem %.1f / %.1f GiB" % (
+                    mode, accum, 1e3 * (time.perf_counter() - t0), _ops._F32_SPLIT, torch.cuda.memory_allocated() / 2**30,
+                    torch.cuda.memory_reserved() / 2**30), file=sys.stderr, flush=True)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         return sum(sum(b.xlens) for g in groups[nw:nw + ns] for b in g) / el, 1e3 * el / ns
@@ -768,6 +780,7 @@ def main():
     emo_lib.set_option("timer_stride", stride)
     emo_lib.set_option("timers", emo_lib.timer_mask(dominant))
     emo_lib.timer_read_ex(dominant)
+    stats0 = torch.cuda.memory_stats(dev) if os.environ.get("EMOASR_BENCH_TRACE") else None
     t0 = time.perf_counter()
     pairs = 0.0
     for bt in batches[args.warmup:]:
@@ -775,6 +788,11 @@ def main():
         loss = step(bt)
     sync()
     elapsed = time.perf_counter() - t0
+    if stats0 is not None:   # did the caching allocator call the driver inside the timed region?
+        st1 = torch.cuda.memory_stats(dev)
+        print("[headline] hipMalloc calls in the timed region: %d (segments %d -> %d, reserved %.1f -> %.1f GiB)" % (
+            st1["num_device_alloc"] - stats0["num_device_alloc"], stats0["segment.all.current"], st1["segment.all.current"],
+            stats0["reserved_bytes.all.current"] / 2**30, st1["reserved_bytes.all.current"] / 2**30), file=sys.stderr, flush=True)
     emo_lib.set_option("timers", 0)
     emo_lib.set_option("timer_stride", 1)
     dom = family_table(emo_lib, attn_work(pairs)).get(dominant, {"calls": 0, "ms": 0.0})
