@@ -770,25 +770,29 @@ def run_rnnt_align_xcheck():
     numba.cuda = cuda
     sys.modules["numba"], sys.modules["numba.cuda"] = numba, cuda
     ra = importlib.import_module("asr.modeling.decoders.rnnt_aligner")
-    g = torch.Generator().manual_seed(7)
-    B, T, L, V = 3, 7, 4, 6
-    lp = torch.log_softmax(2.0 * torch.randn(B, T, L + 1, V, generator=g), -1)
-    ys = torch.randint(1, V, (B, L), generator=g)
-    elens, ylens = torch.tensor([7, 5, 3]), torch.tensor([4, 2, 3])
-    # the aligner's own buffers, reproduced here so that alpha / beta / log_p can be stored as well (rnnt_aligner.py:158-181)
-    alpha = torch.zeros(B, T, L + 1)
-    beta = torch.zeros(B, T, L + 1)
-    lpa, lpb = torch.zeros(B), torch.zeros(B)
-    lock = torch.zeros(B, L + 1, dtype=torch.int32)
-    ra.cu_kernel_forward[B, L + 1](lp, ys.int(), alpha, lpa, elens.int(), ylens.int(), 0, lock)
-    lock = lock * 0
-    ra.cu_kernel_backward[B, L + 1](lp, ys.int(), beta, lpb, elens.int(), ylens.int(), 0, lock)
-    aligns = ra.RNNTForcedAligner(blank_id=0)(lp, elens, ys, ylens)
-    np.savez_compressed(os.path.join(OUT, "rnnt_align_xcheck.npz"), log_probs=lp.numpy(), ys=ys.numpy(), elens=elens.numpy(),
-                        ylens=ylens.numpy(), alpha=alpha.numpy(), beta=beta.numpy(), log_p_alpha=lpa.numpy(),
-                        log_p_beta=lpb.numpy(), aligns=aligns.numpy())
-    print("rnnt aligner cross-check: log_p alpha", lpa.tolist(), "beta", lpb.tolist(), "aligns", aligns.tolist(),
-          "lock tests that found the lock closed:", _Atomic.spins)
+    # two sets: the round-4 lattices (3 x 7 x 5 x 6), and a larger ragged set -- 6 utterances up to 23 frames x 11 labels over 13
+    # classes, among them a single-frame utterance, a single-label one and one whose labels fill every frame but one
+    sets = [("rnnt_align_xcheck.npz", 7, (3, 7, 4, 6), [7, 5, 3], [4, 2, 3]),
+            ("rnnt_align_xcheck2.npz", 11, (6, 23, 11, 13), [23, 17, 1, 9, 12, 20], [11, 5, 1, 1, 11, 3])]
+    for fname, seed, (B, T, L, V), el, yl in sets:
+        g = torch.Generator().manual_seed(seed)
+        lp = torch.log_softmax(2.0 * torch.randn(B, T, L + 1, V, generator=g), -1)
+        ys = torch.randint(1, V, (B, L), generator=g)
+        elens, ylens = torch.tensor(el), torch.tensor(yl)
+        # the aligner's own buffers, reproduced here so that alpha / beta / log_p can be stored as well (rnnt_aligner.py:158-181)
+        alpha = torch.zeros(B, T, L + 1)
+        beta = torch.zeros(B, T, L + 1)
+        lpa, lpb = torch.zeros(B), torch.zeros(B)
+        lock = torch.zeros(B, L + 1, dtype=torch.int32)
+        ra.cu_kernel_forward[B, L + 1](lp, ys.int(), alpha, lpa, elens.int(), ylens.int(), 0, lock)
+        lock = lock * 0
+        ra.cu_kernel_backward[B, L + 1](lp, ys.int(), beta, lpb, elens.int(), ylens.int(), 0, lock)
+        aligns = ra.RNNTForcedAligner(blank_id=0)(lp, elens, ys, ylens)
+        np.savez_compressed(os.path.join(OUT, fname), log_probs=lp.numpy(), ys=ys.numpy(), elens=elens.numpy(),
+                            ylens=ylens.numpy(), alpha=alpha.numpy(), beta=beta.numpy(), log_p_alpha=lpa.numpy(),
+                            log_p_beta=lpb.numpy(), aligns=aligns.numpy())
+        print(fname, "rnnt aligner cross-check: log_p alpha", lpa.tolist(), "beta", lpb.tolist(), "aligns", aligns.tolist(),
+              "lock tests that found the lock closed:", _Atomic.spins)
 
 
 if __name__ == "__main__":

@@ -211,7 +211,8 @@ def test_rnnt_forced_aligner(dev):
     assert got.dtype == torch.int32 and torch.equal(got.cpu(), want)
 
 
-def test_rnnt_lattice_against_the_reference_aligner_kernels(dev):
+@pytest.mark.parametrize("fixture", ["rnnt_align_xcheck.npz", "rnnt_align_xcheck2.npz"])
+def test_rnnt_lattice_against_the_reference_aligner_kernels(dev, fixture):
     """the HIP transducer lattice (emoasr_rnnt_forward: alpha, beta, nll) and RNNTForcedAligner against what the reference's OWN
     recursion bodies gave (rnnt_aligner.py:14-198 executed as plain Python by make_golden.py: rnnt_align_xcheck.npz) -- a
     cross-check of the lattice the transducer loss runs on; the loss value's third-party source (warp_rnnt) stays unpinned"""
@@ -221,7 +222,7 @@ def test_rnnt_lattice_against_the_reference_aligner_kernels(dev):
 
     from emoasr_amd import ops
     from emoasr_amd.modeling.decoders.rnnt_aligner import RNNTForcedAligner
-    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "rnnt_align_xcheck.npz"))
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))   # (the second set: 6 ragged lattices up to 23 x 12 x 13)
     lp, ys = torch.from_numpy(z["log_probs"]), torch.from_numpy(z["ys"])
     elens, ylens = torch.from_numpy(z["elens"]), torch.from_numpy(z["ylens"])
     got = RNNTForcedAligner(blank_id=0)(lp.to(dev), elens, ys, ylens)

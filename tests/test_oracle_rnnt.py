@@ -4,6 +4,7 @@ the network around it is pinned to the reference through tests/golden/l4_tiny.np
 import itertools
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import model as om
@@ -100,7 +101,8 @@ def test_beam_search_pinned_to_reference():
                 assert orn.rnnt_beam_search(sd, cfg, eouts, bw) == want[bw][b], (b, bw)
 
 
-def test_lattice_against_the_reference_aligner_kernels():
+@pytest.mark.parametrize("fixture", ["rnnt_align_xcheck.npz", "rnnt_align_xcheck2.npz"])
+def test_lattice_against_the_reference_aligner_kernels(fixture):
     """CROSS-CHECK (does not pin the loss value: warp_rnnt stays absent).  asr/modeling/decoders/rnnt_aligner.py:14-152 is the
     reference's own statement of the transducer forward / backward recursions; tests/golden/make_golden.py
     (run_rnnt_align_xcheck) executed those two kernel bodies as plain Python and stored alpha, beta, log_p and the alignments
@@ -109,7 +111,7 @@ def test_lattice_against_the_reference_aligner_kernels():
     import os
 
     from oracle import distill as od
-    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "rnnt_align_xcheck.npz"))
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))   # (the second set: 6 ragged lattices up to 23 x 12 x 13)
     lp, ys = torch.from_numpy(z["log_probs"]), torch.from_numpy(z["ys"])
     elens, ylens = torch.from_numpy(z["elens"]), torch.from_numpy(z["ylens"])
     for b in range(lp.shape[0]):
