@@ -23,10 +23,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const T* __restrict__ x,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ bias, T* __restrict__ y,
-                                                     int flip, float* __restrict__ part) {
+                                                     int flip, float* __restrict__ part, const RowSegs sg) {
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
-  const int b = blockIdx.z, t0 = blockIdx.x * DW_TT, pad = (K - 1) / 2;
+  int b = blockIdx.z;
+  if (sg.n > 1) {   // stacked micro-batches: this utterance's segment (own padded length, own area of the partial table)
+    const int si = rowsegs_of_utt(sg, b);
+    Tn = sg.T[si];
+    x += sg.row[si] * C; y += sg.row[si] * C;
+    if (part) part += sg.part[si];
+    b -= sg.b0[si];
+    if ((int)blockIdx.x * DW_TT >= Tn) return;   // (the grid follows the longest segment)
+  }
+  const int nx = (Tn + DW_TT - 1) / DW_TT;
+  const int t0 = blockIdx.x * DW_TT, pad = (K - 1) / 2;
   float wr[DW_MAXK];
 #pragma unroll
   for (int j = 0; j < DW_MAXK; ++j) wr[j] = j < K ? w[c * K + (flip ? K - 1 - j : j)] : 0.f;
@@ -61,7 +71,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int Tn, int C, int K, const
       const float d = out[i] - mb;
       m2 += i < n ? d * d : 0.f;
     }
-    float* p = part + ((long)b * gridDim.x + blockIdx.x) * 2 * C + c;
+    float* p = part + ((long)b * nx + blockIdx.x) * 2 * C + c;
     p[0] = s;
     p[C] = m2;
   }
@@ -165,10 +175,17 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(int B_, int Tn_
 // dw[c,j] += sum_{b,t} dy[b,t,c] * x[b,t+j-pad,c];  dbias[c] += sum dy
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(int Tn, int C, int K, const T* __restrict__ dy,
-                                                           const T* __restrict__ x, float* __restrict__ part) {
+                                                           const T* __restrict__ x, float* __restrict__ part, const RowSegs sg) {
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
-  const int b = blockIdx.z, pad = (K - 1) / 2;
+  int b = blockIdx.z;
+  const int pad = (K - 1) / 2;
+  if (sg.n > 1) {   // stacked micro-batches: this utterance's segment; a block past its segment's end leaves a zero partial row
+    const int si = rowsegs_of_utt(sg, b);
+    Tn = sg.T[si];
+    x += sg.row[si] * C; dy += sg.row[si] * C;
+    b -= sg.b0[si];
+  }
   float acc[DW_MAXK];
 #pragma unroll
   for (int j = 0; j < DW_MAXK; ++j) acc[j] = 0.f;
@@ -453,10 +470,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int C, const T
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps,
                                                            const float* __restrict__ tot,
-                                                           T* __restrict__ dy) {
+                                                           T* __restrict__ dy, const RowSegs sg) {
   const int hl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 256 + hl * 8;
   if (c >= C) return;
+  if (sg.n > 1) {   // stacked micro-batches: blockIdx.z = segment (own rows, statistics and means)
+    const int si = blockIdx.z;
+    M = (int)(sg.row[si + 1] - sg.row[si]);
+    if ((int)blockIdx.y * BN_APPLY_ROWS >= M) return;
+    dz += sg.row[si] * C; y += sg.row[si] * C; dy += sg.row[si] * C;
+    mean += (long)si * C; var += (long)si * C; tot += (long)si * 2 * C;
+  }
   float mu[8], is[8], g[8], bt[8], m1[8], m2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -507,7 +531,7 @@ extern "C" int emoasr_dwconv_fwd(int dtype, int B, int Tn, int C, int K, const v
   if (use_lds(dtype, Tn, C)) return emo_dwconv_lds(B, Tn, C, K, x, w, bias, y, 0, nullptr, (hipStream_t)stream);
   dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
   EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)x, w,
-                                                                              bias, (T*)y, 0, nullptr)));
+                                                                              bias, (T*)y, 0, nullptr, RowSegs{})));
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -524,7 +548,7 @@ extern "C" int emoasr_dwconv_fwd_stats(int dtype, int B, int Tn, int C, int K, c
   if (use_lds(dtype, Tn, C)) return emo_dwconv_lds(B, Tn, C, K, x, w, bias, y, 0, part, (hipStream_t)stream);
   dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
   EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)x, w,
-                                                                              bias, (T*)y, 0, part)));
+                                                                              bias, (T*)y, 0, part, RowSegs{})));
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -547,7 +571,7 @@ extern "C" int emoasr_dwconv_bwd_x(int dtype, int B, int Tn, int C, int K, const
   if (use_lds(dtype, Tn, C)) return emo_dwconv_lds(B, Tn, C, K, dy, w, nullptr, dx, 1, nullptr, (hipStream_t)stream);
   dim3 grid(cdiv(Tn, DW_TT), cdiv(C, 256), B);
   EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(Tn, C, K, (const T*)dy, w,
-                                                                              nullptr, (T*)dx, 1, nullptr)));
+                                                                              nullptr, (T*)dx, 1, nullptr, RowSegs{})));
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -566,7 +590,7 @@ extern "C" int emoasr_dwconv_bwd_w(int dtype, int B, int Tn, int C, int K, const
   if (B * Tn == 0) return 0;
   EMO_CHECK(scratch != nullptr, "dwconv_bwd_w: scratch of emoasr_dwconv_bwd_w_scratch_floats() floats required");
   dim3 grid(cdiv(Tn, DW_TT * DW_WCHUNKS), cdiv(C, 256), B);
-  EMO_DISPATCH(dtype, (dwconv_bwd_w_kernel<T><<<grid, 256, 0, s>>>(Tn, C, K, (const T*)dy, (const T*)x, scratch)));
+  EMO_DISPATCH(dtype, (dwconv_bwd_w_kernel<T><<<grid, 256, 0, s>>>(Tn, C, K, (const T*)dy, (const T*)x, scratch, RowSegs{})));
   const int nblk = grid.x * B;
   dwconv_bwd_w_reduce_kernel<<<cdiv((K + 1) * C, 64), 256, 0, s>>>(nblk, C, K, scratch, dw, dbias);
   EMO_LAUNCH_CHECK();
@@ -643,7 +667,7 @@ extern "C" int emoasr_bn_swish_bwd(int dtype, int M, int C, const void* dz, cons
   EMO_BN_TICKETS(s);
   bn_bwd_fold_kernel<<<cdiv(C, 16), 1024, 0, s>>>(npart, C, 1.f / M, scratch, tot, dgamma, dbeta, RowSegs{}, tickets_);
   EMO_DISPATCH(dtype, (bn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean,
-                                                                  var, gamma, beta, eps, tot, (T*)dy)));
+                                                                  var, gamma, beta, eps, tot, (T*)dy, RowSegs{})));
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -659,27 +683,84 @@ int emo_bn_stats_finalize_seg(const RowSegs& sg, int C, const float* part, float
   return 0;
 }
 
-int emo_bn_swish_fwd_seg(const RowSegs& sg, int C, const void* y, const float* mean, const float* var, const float* gamma,
-                         const float* beta, float eps, void* z, hipStream_t s) {
+int emo_bn_swish_fwd_seg_dt(int dtype, const RowSegs& sg, int C, const void* y, const float* mean, const float* var,
+                            const float* gamma, const float* beta, float eps, void* z, hipStream_t s) {
   const long n = sg.row[sg.n] * C;
   if (n == 0) return 0;
-  if (C % 8 == 0) bn_swish_fwd8_kernel<bf16><<<ew_grid(n / 8), 256, 0, s>>>(n / 8, C, (const bf16*)y, mean, var, gamma, beta, eps, (bf16*)z, sg);
-  else bn_swish_fwd_kernel<bf16><<<ew_grid(n), 256, 0, s>>>(n, C, (const bf16*)y, mean, var, gamma, beta, eps, (bf16*)z, sg);
+  if (C % 8 == 0) {
+    EMO_DISPATCH(dtype, (bn_swish_fwd8_kernel<T><<<ew_grid(n / 8), 256, 0, s>>>(n / 8, C, (const T*)y, mean, var, gamma, beta, eps, (T*)z, sg)));
+  } else {
+    EMO_DISPATCH(dtype, (bn_swish_fwd_kernel<T><<<ew_grid(n), 256, 0, s>>>(n, C, (const T*)y, mean, var, gamma, beta, eps, (T*)z, sg)));
+  }
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+int emo_bn_swish_fwd_seg(const RowSegs& sg, int C, const void* y, const float* mean, const float* var, const float* gamma,
+                         const float* beta, float eps, void* z, hipStream_t s) {
+  return emo_bn_swish_fwd_seg_dt(EMO_BF16, sg, C, y, mean, var, gamma, beta, eps, z, s);
+}
+// the apply pass of emoasr_bn_swish_bwd alone (tot = the two means of emoasr_bn_swish_bwd_sums / emo_bn_swish_bwd_sums_seg_dt)
+int emo_bn_bwd_apply(int dtype, int M, int C, const void* dz, const void* y, const float* mean, const float* var, const float* gamma,
+                     const float* beta, float eps, const float* tot, void* dy, hipStream_t s) {
+  dim3 grid(cdiv(C, 256), cdiv(M, BN_APPLY_ROWS));
+  EMO_DISPATCH(dtype, (bn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>(M, C, (const T*)dz, (const T*)y, mean, var, gamma, beta, eps, tot, (T*)dy, RowSegs{})));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+// ... and over all stacked micro-batches in one launch (mean / var [n, C], tot [n, 2, C])
+int emo_bn_bwd_apply_seg(int dtype, const RowSegs& sg, int C, const void* dz, const void* y, const float* mean, const float* var,
+                         const float* gamma, const float* beta, float eps, const float* tot, void* dy, hipStream_t s) {
+  long mmax = 0;
+  for (int i = 0; i < sg.n; ++i) mmax = std::max(mmax, sg.row[i + 1] - sg.row[i]);
+  dim3 grid(cdiv(C, 256), cdiv((int)mmax, BN_APPLY_ROWS), sg.n);
+  EMO_DISPATCH(dtype, (bn_bwd_apply_kernel<T><<<grid, 256, 0, s>>>((int)mmax, C, (const T*)dz, (const T*)y, mean, var, gamma, beta, eps,
+                                                                  tot, (T*)dy, sg)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+// the depthwise convolution (flip = 0: forward, with the BatchNorm partial statistics when part != NULL; flip = 1: data gradient)
+// and its weight gradient over all stacked micro-batches in one launch each (the separate kernels: any dtype)
+int emo_dwconv_seg(int dtype, const RowSegs& sg, int tmax, int C, int K, const void* x, const float* w, const float* bias, void* y,
+                   int flip, float* part, hipStream_t s) {
+  EMO_CHECK(K <= DW_MAXK && (K & 1), "dwconv: K=%d unsupported (odd, <= %d)", K, DW_MAXK);
+  if (sg.b0[sg.n] == 0 || tmax == 0) return 0;
+  dim3 grid(cdiv(tmax, DW_TT), cdiv(C, 256), sg.b0[sg.n]);
+  EMO_DISPATCH(dtype, (dwconv_kernel<T><<<grid, 256, 0, s>>>(tmax, C, K, (const T*)x, w, bias, (T*)y, flip, part, sg)));
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
+int emo_dwconv_bwd_w_seg(int dtype, const RowSegs& sg, int tmax, int C, int K, const void* dy, const void* x, float* dw, float* dbias,
+                         float* scratch, hipStream_t s) {
+  EMO_CHECK(K <= DW_MAXK && (K & 1), "dwconv: K=%d unsupported", K);
+  if (sg.b0[sg.n] == 0 || tmax == 0) return 0;
+  EMO_CHECK(scratch != nullptr, "dwconv_bwd_w_seg: scratch of emoasr_dwconv_bwd_w_scratch_floats(all utterances, longest) floats required");
+  dim3 grid(cdiv(tmax, DW_TT * DW_WCHUNKS), cdiv(C, 256), sg.b0[sg.n]);
+  EMO_DISPATCH(dtype, (dwconv_bwd_w_kernel<T><<<grid, 256, 0, s>>>(tmax, C, K, (const T*)dy, (const T*)x, scratch, sg)));
+  const int nblk = grid.x * sg.b0[sg.n];
+  dwconv_bwd_w_reduce_kernel<<<dim3(cdiv((K + 1) * C, 64), nblk >= 1024 ? 4 : 1), 256, 0, s>>>(nblk, C, K, scratch, dw, dbias);
   EMO_LAUNCH_CHECK();
   return 0;
 }
 
 // scratch: [sum over segments of cdiv(M_s, BN_SUM_ROWS) partial rows][2][C], then the means tot [n][2][C] (returned in *tot_out), then
 // the segments' raw sums [n][2][C]
+int emo_bn_swish_bwd_sums_seg_dt(int dtype, const RowSegs& sg, int C, const void* dz, const void* y, const float* mean, const float* var,
+                                 const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta, float* scratch,
+                                 float** tot_out, hipStream_t s);
 int emo_bn_swish_bwd_sums_seg(const RowSegs& sg, int C, const void* dz, const void* y, const float* mean, const float* var,
                               const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta, float* scratch,
                               float** tot_out, hipStream_t s) {
+  return emo_bn_swish_bwd_sums_seg_dt(EMO_BF16, sg, C, dz, y, mean, var, gamma, beta, eps, dgamma, dbeta, scratch, tot_out, s);
+}
+int emo_bn_swish_bwd_sums_seg_dt(int dtype, const RowSegs& sg, int C, const void* dz, const void* y, const float* mean, const float* var,
+                                 const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta, float* scratch,
+                                 float** tot_out, hipStream_t s) {
   long mmax = 0;
   for (int i = 0; i < sg.n; ++i) mmax = std::max(mmax, sg.row[i + 1] - sg.row[i]);
-  EMO_CHECK(sg.row[sg.n] * C * 2 < (1L << 32), "bn_swish_bwd_sums_seg: activation larger than 4 GiB");
+  EMO_CHECK(sg.row[sg.n] * C * (dtype == EMO_BF16 ? 2 : 4) < (1L << 32), "bn_swish_bwd_sums_seg: activation larger than 4 GiB");
   dim3 sgrid(cdiv(C, 256), cdiv((int)mmax, BN_SUM_ROWS), sg.n);
-  bn_bwd_sums_kernel<bf16><<<sgrid, 256, 0, s>>>((int)mmax, C, (const bf16*)dz, (const bf16*)y, mean, var, gamma, beta, eps, scratch,
-                                                sg);
+  EMO_DISPATCH(dtype, (bn_bwd_sums_kernel<T><<<sgrid, 256, 0, s>>>((int)mmax, C, (const T*)dz, (const T*)y, mean, var, gamma, beta, eps,
+                                                                  scratch, sg)));
   float* tot = scratch + sg.sums[sg.n] * 2 * C;
   EMO_CHECK(cdiv(C, 16) <= 64, "bn_swish_bwd_sums_seg: C=%d too wide for the ticket table", C);
   EMO_BN_TICKETS(s);

@@ -16,6 +16,21 @@ void emo_attn_bwd_defer_join(int v);
 void emo_attn_bwd_join(void* stream);
 int emo_attn_bwd_prelaunch(int dtype, const emoasr_attn_t* a, void* ws, size_t ws_bytes, float* zero, long zn, void* stream);
 
+// csrc/convmodule.hip: the BatchNorm kernels over ALL stacked micro-batches in one launch each (any dtype)
+int emo_bn_stats_finalize_seg(const RowSegs& sg, int C, const float* part, float* mean, float* var, float* running_mean,
+                              float* running_var, float momentum, long long* nbt, hipStream_t s);
+int emo_bn_swish_fwd_seg_dt(int dtype, const RowSegs& sg, int C, const void* y, const float* mean, const float* var,
+                            const float* gamma, const float* beta, float eps, void* z, hipStream_t s);
+int emo_bn_swish_bwd_sums_seg_dt(int dtype, const RowSegs& sg, int C, const void* dz, const void* y, const float* mean, const float* var,
+                                 const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta, float* scratch,
+                                 float** tot_out, hipStream_t s);
+int emo_bn_bwd_apply_seg(int dtype, const RowSegs& sg, int C, const void* dz, const void* y, const float* mean, const float* var,
+                         const float* gamma, const float* beta, float eps, const float* tot, void* dy, hipStream_t s);
+int emo_dwconv_seg(int dtype, const RowSegs& sg, int tmax, int C, int K, const void* x, const float* w, const float* bias, void* y,
+                   int flip, float* part, hipStream_t s);
+int emo_dwconv_bwd_w_seg(int dtype, const RowSegs& sg, int tmax, int C, int K, const void* dy, const void* x, float* dw, float* dbias,
+                         float* scratch, hipStream_t s);
+
 namespace {
 
 emoasr_epilogue_t plain_ep() {
@@ -107,6 +122,19 @@ bool seg_view(const emoasr_conformer_fwd_t* io, int d, SegView* v) {
     v->part[i + 1] = v->part[i] + emoasr_dwconv_stats_floats(v->B[i], v->T[i], d);
   }
   return true;
+}
+
+RowSegs row_segs_of(const SegView& sv, int C) {   // (as csrc/convfused.hip: row_segs)
+  RowSegs sg{};
+  sg.n = sv.n;
+  for (int i = 0; i < sv.n; ++i) {
+    sg.b0[i + 1] = sg.b0[i] + sv.B[i];
+    sg.T[i] = sv.T[i];
+    sg.row[i + 1] = sv.row[i + 1];
+    sg.part[i + 1] = sv.part[i + 1];
+    sg.sums[i + 1] = sg.sums[i] + (emoasr_bn_swish_bwd_scratch_floats(sv.B[i] * sv.T[i], C) / (2 * C) - 1);
+  }
+  return sg;
 }
 
 // attention arguments of segments [s0, s1) of a stacked pass (s1 - s0 == 1: a dense batch at the segment's offsets)
@@ -209,7 +237,19 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
         emoasr_conv_module_fwd_seg(dtype, &io->seg, d, L->K, io->g, L->dw_w, L->dw_b, io->c, io->bn_part, io->bmean, io->bvar,
                                    L->bn_rm, L->bn_rv, 0.1f, L->bn_nbt, L->bn_g, L->bn_b, 1e-5f, io->z, io->training, stream))
       return 1;
-    for (int si = 0; si < sv.n && !conv_one_launch; ++si) {   // each micro-batch: its own zero padding, its own batch statistics
+    // f32 / f32x3 (the separate kernels), training: the depthwise convolution per micro-batch, then the BatchNorm statistics'
+    // finalize and the BatchNorm + Swish apply over all micro-batches in ONE launch each
+    const bool bn_one_launch = !fused && io->training && sv.n > 1 && g_stack_launch;
+    if (bn_one_launch) {
+      const RowSegs sg = row_segs_of(sv, d);
+      int tmax = 0;
+      for (int si = 0; si < sv.n; ++si) tmax = std::max(tmax, sv.T[si]);
+      if (emo_dwconv_seg(dtype, sg, tmax, d, L->K, io->gl, L->dw_w, L->dw_b, io->c, 0, io->bn_part, (hipStream_t)stream)) return 1;
+      if (emo_bn_stats_finalize_seg(sg, d, io->bn_part, io->bmean, io->bvar, L->bn_rm, L->bn_rv, 0.1f, L->bn_nbt, (hipStream_t)stream))
+        return 1;
+      if (emo_bn_swish_fwd_seg_dt(dtype, sg, d, io->c, io->bmean, io->bvar, L->bn_g, L->bn_b, 1e-5f, io->z, (hipStream_t)stream)) return 1;
+    }
+    for (int si = 0; si < sv.n && !conv_one_launch && !bn_one_launch; ++si) {   // each micro-batch: its own zero padding, its own batch statistics
       const size_t ro = (size_t)sv.row[si];
       const int B = sv.B[si], T = sv.T[si];
       const char* g = (const char*)io->g + ro * 2 * d * esz;
@@ -435,7 +475,22 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
                                   (float*)G->dw_b, (float*)(ws + bb.dw_scr), stream)) return 1;
       }
     } else {
-      for (int si = 0; si < sv.n; ++si) {
+      // f32 / f32x3: the BatchNorm gradient sums + fold of all micro-batches in one launch each, then per micro-batch the apply
+      // pass and the depthwise convolution's two gradients
+      const bool bn_one_launch = sv.n > 1 && g_stack_launch;
+      if (bn_one_launch) {   // every kernel of the chain over all micro-batches in one launch
+        const RowSegs sg = row_segs_of(sv, d);
+        int tmax = 0;
+        for (int si = 0; si < sv.n; ++si) tmax = std::max(tmax, sv.T[si]);
+        float* tot = nullptr;
+        if (emo_bn_swish_bwd_sums_seg_dt(dtype, sg, d, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f, (float*)G->bn_g,
+                                         (float*)G->bn_b, (float*)(ws + bb.bn_scr), &tot, s)) return 1;
+        if (emo_bn_bwd_apply_seg(dtype, sg, d, ws + bb.dz, st->c, st->bmean, st->bvar, L->bn_g, L->bn_b, 1e-5f, tot, ws + bb.dc, s)) return 1;
+        if (emo_dwconv_seg(dtype, sg, tmax, d, K, ws + bb.dc, L->dw_w, nullptr, ws + bb.dgl, 1, nullptr, s)) return 1;
+        if (emo_dwconv_bwd_w_seg(dtype, sg, tmax, d, K, ws + bb.dc, st->gl, (float*)G->dw_w, (float*)G->dw_b, (float*)(ws + bb.dw_scr), s))
+          return 1;
+      }
+      for (int si = 0; si < sv.n && !bn_one_launch; ++si) {
         const size_t ro = (size_t)sv.row[si];
         const int B = sv.B[si], T = sv.T[si];
         const float *bmean = st->bmean + (size_t)si * d, *bvar = st->bvar + (size_t)si * d;
