@@ -25,10 +25,13 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS S
   rm -rf $O/a$i
 done
 unset B T MODES
-# the f32x3 (parity) step's kernel table
+# the f32x3 (parity) step's kernel tables: one micro-batch per step, and five stacked
 rocprofv3 --kernel-trace --stats -d $O/kx -o kx -- python3 tools/f32_leg.py --split > $O/kx.log 2>&1
 python3 tools/kstats.py $O/kx/kx_results.db 9 $O/${TAG}_f32x3_kernel_stats.csv > $O/f32x3_kstats.txt 2>&1
 rm -rf $O/kx
+rocprofv3 --kernel-trace --stats -d $O/ky -o ky -- python3 tools/f32_leg.py --split --stacked > $O/ky.log 2>&1
+python3 tools/kstats.py $O/ky/ky_results.db 9 $O/${TAG}_f32x3_stacked_kernel_stats.csv > $O/f32x3_stacked_kstats.txt 2>&1
+rm -rf $O/ky
 ( time python3 -m pytest tests -m gpu -q ) > $O/${TAG}_gputest.log 2>&1
 python3 bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 tail -3 $O/${TAG}_gputest.log
