@@ -1,5 +1,6 @@
 """Log-mel front end: the host constants against the oracle's independent restatement (CPU), the HIP kernel
-against the oracle (GPU).  Parity with the reference's torchaudio call is UNPINNED (see oracle/fbank.py)."""
+against the oracle (GPU).  Parity with the reference's torchaudio call itself is UNPINNED (see oracle/fbank.py); the oracle is
+cross-checked against an independent published implementation of the same recipe (transformers.audio_utils)."""
 import numpy as np
 import pytest
 import torch
@@ -29,6 +30,27 @@ def test_mel_banks_and_window_match_oracle_structure():
     assert abs(int(feats.mean(0).argmax()) - int(fb[:, tone_bin].argmax())) <= 1
     w = ft.hamming_window(400)
     assert abs(w[0] - 0.08) < 1e-12 and abs(w[199] - w[200]) < 1e-12 and abs(w.max() - 1.0) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["noise", "tone", "short"])
+def test_oracle_against_an_independent_kaldi_fbank(name):
+    """CROSS-CHECK of oracle/fbank.py (the reference's own dependency, torchaudio.compliance.kaldi.fbank, is not installed and
+    cannot be fetched): `transformers.audio_utils` carries an independent, published implementation of the same Kaldi recipe --
+    the torchaudio-free path of the Hugging Face feature extractors (ASTFeatureExtractor._extract_fbank_features: `spectrogram`
+    with remove_dc_offset, pre-emphasis 0.97, a Kaldi-scale mel bank triangularised in mel space, log floored at FLT_EPSILON) --
+    here called with the reference's call-site options (hamming window, 80 bins from 20 Hz; wav_to_feats.py:26-33).  The two
+    restatements agree to 1e-5 on log-mel values of magnitude ~30 (measured 1.0e-6)."""
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    x = _signals()[name] * 2 ** 15
+    win = audio_utils.window_function(400, "hamming", periodic=False)
+    mel = audio_utils.mel_filter_bank(num_frequency_bins=257, num_mel_filters=80, min_frequency=20, max_frequency=8000,
+                                      sampling_rate=16000, norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    other = audio_utils.spectrogram(x, win, frame_length=400, hop_length=160, fft_length=512, power=2.0, center=False,
+                                    preemphasis=0.97, mel_filters=mel, log_mel="log", mel_floor=1.192092955078125e-07,
+                                    remove_dc_offset=True).T
+    ours = of.fbank(x)
+    assert ours.shape == other.shape
+    assert np.abs(ours - other).max() < 1e-5, np.abs(ours - other).max()
 
 
 @pytest.mark.gpu
