@@ -12,8 +12,6 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libemoasr_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "elementwise.hip", "convmodule.hip",
            "subsample.hip", "ctc.hip", "attention.hip", "optim.hip", "feats.hip", "decoder.hip", "rnnt.hip", "layer.hip", "decode_rt.hip", "distill.hip", "gemm_big.hip", "convfused.hip", "rowlin.hip", "decode_coop.hip", "lstm_coop.hip", "rnnt_greedy.hip", "rnnt_beam.hip", "ctc_beam_host.hip"]
-# measured-slower variants kept reproducible: linked in only when EMOASR_EXPERIMENTAL=1 is set at build time
-EXPERIMENTAL = ["experimental/decode_wg.hip", "experimental/gemm_k256.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-Wno-comment",
          "-ffp-contract=off"]
 
@@ -31,14 +29,8 @@ def build(force=False, verbose=True, variant=None, defines=()):
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in ("common.h", "mma.h")]
     headers.append(os.path.join(HERE, "..", "include", "emoasr_hip.h"))
-    experimental = os.environ.get("EMOASR_EXPERIMENTAL", "0") == "1"
-    sources = SOURCES + (EXPERIMENTAL if experimental else [])
-    flags = FLAGS + (["-DEMOASR_EXPERIMENTAL"] if experimental else []) + ["-D" + d for d in defines]
-    # a flavour change (default <-> experimental) rebuilds everything: the flag changes code in several units
-    stamp = os.path.join(objdir, "flavour")
-    flavour = "experimental" if experimental else "default"
-    if not os.path.exists(stamp) or open(stamp).read() != flavour:
-        force = True
+    sources = SOURCES
+    flags = FLAGS + ["-D" + d for d in defines]
     obj_of = lambda src: os.path.join(objdir, src.replace("/", "_").replace(".hip", ".o"))
     jobs = []
     for src in sources:
@@ -62,8 +54,6 @@ def build(force=False, verbose=True, variant=None, defines=()):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    with open(stamp, "w") as f:
-        f.write(flavour)
     return LIB
 
 

@@ -75,15 +75,6 @@ void emo_ln_set_bwd_pf(int v);
 void emo_ln_set_bwd_blocks(int v);
 void emo_rnnt_set_greedy_coop(int v);
 void emo_rnnt_set_beam_mfma(int v);
-#ifdef EMOASR_EXPERIMENTAL
-void emo_gemm_set_k256(int v);
-void emo_gemm_set_k256_min_rows(int v);
-void emo_gemm_set_k256_dbg(int v);
-#endif
-void emo_decode_set_fused(int v);
-#ifdef EMOASR_EXPERIMENTAL
-void emo_decode_set_wg(int v);
-#endif
 void emo_decode_set_coop(int v);
 void emo_lstm_set_coop(int v);
 void emo_decode_set_coop_merge(int v);
@@ -159,13 +150,6 @@ extern "C" int emoasr_timer_read(const char* name, int* calls, double* ms, int r
 
 extern "C" const char* emoasr_last_error(void) { return g_err; }
 extern "C" int emoasr_version(void) { return 1; }
-extern "C" int emoasr_experimental(void) {
-#ifdef EMOASR_EXPERIMENTAL
-  return 1;
-#else
-  return 0;
-#endif
-}
 extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "tr_read") == 0) {
     emo_gemm_set_tr_read(value);
@@ -202,27 +186,6 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "ln_bwd_blocks") == 0) { emo_ln_set_bwd_blocks(value); return 0; }
   if (strcmp(name, "rnnt_greedy_coop") == 0) { emo_rnnt_set_greedy_coop(value); return 0; }
   if (strcmp(name, "rnnt_beam_mfma") == 0) { emo_rnnt_set_beam_mfma(value); return 0; }
-#ifdef EMOASR_EXPERIMENTAL
-  if (strcmp(name, "gemm_k256") == 0) { emo_gemm_set_k256(value); return 0; }
-  if (strcmp(name, "gemm_k256_min_rows") == 0) { emo_gemm_set_k256_min_rows(value); return 0; }
-  if (strcmp(name, "gemm_k256_dbg") == 0) { emo_gemm_set_k256_dbg(value); return 0; }
-#else
-  if (strcmp(name, "gemm_k256") == 0 || strcmp(name, "gemm_k256_dbg") == 0) {
-    if (value == 0) return 0;
-    emo_set_error("option '%s' needs a library built with EMOASR_EXPERIMENTAL=1 (csrc/experimental/gemm_k256.hip)", name);
-    return 1;
-  }
-#endif
-#ifdef EMOASR_EXPERIMENTAL
-  if (strcmp(name, "decode_fused") == 0) { emo_decode_set_fused(value); return 0; }
-  if (strcmp(name, "decode_wg") == 0) { emo_decode_set_wg(value); return 0; }
-#else
-  if (strcmp(name, "decode_fused") == 0 || strcmp(name, "decode_wg") == 0) {
-    if (value == 0) return 0;
-    emo_set_error("option '%s' needs a library built with EMOASR_EXPERIMENTAL=1 (measured-slower variants, csrc/experimental/)", name);
-    return 1;
-  }
-#endif
   if (strcmp(name, "decode_coop") == 0) { emo_decode_set_coop(value); return 0; }
   if (strcmp(name, "lstm_coop") == 0) { emo_lstm_set_coop(value); return 0; }
   if (strcmp(name, "decode_coop_merge") == 0) { emo_decode_set_coop_merge(value); return 0; }

@@ -187,28 +187,12 @@ __global__ __launch_bounds__(256) void cache_gather_kernel(int nl, int nb, int L
 }
 
 }  // namespace
-#ifdef EMOASR_EXPERIMENTAL
-// csrc/experimental/decode_wg.hip (opt-in build, measured slower): the whole stack of either network for one step in ONE
-// single-workgroup launch (bf16)
-bool emo_decode_wg_ok(int dtype, int nb, int nl, int max_layers, int d, int H, int F);
-int emo_bert_lm_step_wg(int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_step_t* io, void* out_hidden, hipStream_t s);
-int emo_transformer_decoder_step_wg(int nl, const emoasr_decoder_layer_t* layers, const emoasr_decoder_step_t* io, void* out_x,
-                                    hipStream_t s);
-constexpr bool kExperimental = true;
-#else
-constexpr bool kExperimental = false;   // the measured-slower variants are compiled only with EMOASR_EXPERIMENTAL=1 (build.py)
-#endif
 // csrc/decode_coop.hip: the same in one launch of 16 cooperating workgroups with grid barriers between the stages (bf16)
 bool emo_decode_coop_ok(int dtype, int nb, int nl, int max_layers, int d, int H, int F, int T);
 int emo_bert_lm_step_coop(int nl, const emoasr_bert_layer_t* layers, const emoasr_bert_step_t* io, void* out_hidden, hipStream_t s);
 int emo_transformer_decoder_step_coop(int nl, const emoasr_decoder_layer_t* layers, const emoasr_decoder_step_t* io, void* out_x,
                                       hipStream_t s);
 namespace {
-
-int g_decode_fused = 0;  // bf16: LayerNorm / residual / cache-append folded into rowlin + attn_step (csrc/rowlin.hip): 8 / 5
-                         // launches per decoder / LM layer instead of 12 / 8 -- measured SLOWER (0.74 vs 0.68 ms per step: a
-                         // rowlin launch with a LayerNorm inside takes 8 us against 4.7 + 4.5 for GEMM + LayerNorm, and the
-                         // single-query attention 5.5 us), so off unless emoasr_set_option("decode_fused", 1)
 
 // y = act(LN?(x) . W^T + b) (+ r | LN(r)) for the step's <= 16 rows (bf16)
 int rl(int M, int N, int K, const void* x, const emoasr_lnp_t* lna, const emoasr_lin_t& l, int act, const void* res,
@@ -229,8 +213,6 @@ int attn_cached(int dtype, int nb, int Lmax, int d, int H, const void* qkv, cons
 }
 
 }  // namespace
-
-void emo_decode_set_fused(int v) { g_decode_fused = v; }
 
 extern "C" size_t emoasr_decode_step_ws_bytes(int dtype, int nb, int d, int H, int F, int V) {
   const size_t esz = dtype == EMO_BF16 ? 2 : 4;
@@ -271,42 +253,9 @@ extern "C" int emoasr_transformer_decoder_step(int dtype, int nl, const emoasr_d
     if (emo_transformer_decoder_step_coop(nl, layers, io, x, s)) return 1;
     return rl(nb, io->V, dd, x, &io->ln_out, io->out, EMOASR_ACT_NONE, nullptr, nullptr, io->logits_last, 0, stream);
   }
-#ifdef EMOASR_EXPERIMENTAL
-  if (emo_decode_wg_ok(dtype, nb, nl, 8, dd, H, F)) {
-    // the whole stack in one single-workgroup launch, then the final LayerNorm + vocabulary projection across the chip
-    if (emo_transformer_decoder_step_wg(nl, layers, io, x, s)) return 1;
-    return rl(nb, io->V, dd, x, &io->ln_out, io->out, EMOASR_ACT_NONE, nullptr, nullptr, io->logits_last, 0, stream);
-  }
-#endif
   EMO_DISPATCH(dtype, (step_embed_kernel<T><<<cdiv(nb * dd, 256), 256, 0, s>>>(nb, dd, io->ids, (const T*)io->embed, io->pe,
                                                                                 io->emb_scale, io->pos, (T*)x)));
   const size_t layer_bytes = (size_t)nb * Lmax * dd * esz;
-  if (kExperimental && g_decode_fused && dtype == EMO_BF16 && nb <= 16 && dd <= 1024 && F <= 1024 && dd % 32 == 0 && F % 32 == 0 && (dd / H) % 8 == 0) {
-    // 8 launches per layer instead of 12: LayerNorms inside the following projection, cache append inside the attention
-    for (int li = 0; li < nl; ++li) {
-      const emoasr_decoder_layer_t& Ly = layers[li];
-      char* kc = (char*)io->kcache + li * layer_bytes;
-      char* vc = (char*)io->vcache + li * layer_bytes;
-      if (rl(nb, 3 * dd, dd, x, &Ly.ln1, Ly.qkv, EMOASR_ACT_NONE, nullptr, nullptr, qkv, 0, stream)) return 1;
-      if (emoasr_attn_step(nb, dd, H, Lmax, qkv, kc, vc, io->pos, o, stream)) return 1;
-      if (rl(nb, dd, dd, o, nullptr, Ly.out, EMOASR_ACT_NONE, x, nullptr, x2, 0, stream)) return 1;
-      if (rl(nb, dd, dd, x2, &Ly.ln2, Ly.q2, EMOASR_ACT_NONE, nullptr, nullptr, q, 0, stream)) return 1;
-      {
-        emoasr_attn_t a{};
-        a.B = nb; a.H = H; a.DK = dd / H; a.Tq = 1; a.Tk = T;
-        a.ldq = dd; a.ldk = a.ldv = 2 * dd; a.ldo = dd;
-        a.q = q; a.k = io->kv[li]; a.v = (const char*)io->kv[li] + (size_t)dd * esz;
-        a.klens = io->kmem; a.scale = 1.f / sqrtf((float)(dd / H));
-        a.out = o; a.lse = lse;
-        if (emoasr_attn_fwd(dtype, &a, stream)) return 1;
-      }
-      if (rl(nb, dd, dd, o, nullptr, Ly.out2, EMOASR_ACT_NONE, x2, nullptr, x, 0, stream)) return 1;
-      if (rl(nb, F, dd, x, &Ly.ln3, Ly.w1, EMOASR_ACT_RELU, nullptr, nullptr, act, 0, stream)) return 1;
-      if (rl(nb, dd, F, act, nullptr, Ly.w2, EMOASR_ACT_NONE, x, nullptr, x2, 0, stream)) return 1;
-      void* t = x; x = x2; x2 = t;
-    }
-    return rl(nb, io->V, dd, x, &io->ln_out, io->out, EMOASR_ACT_NONE, nullptr, nullptr, io->logits_last, 0, stream);
-  }
   for (int li = 0; li < nl; ++li) {
     const emoasr_decoder_layer_t& Ly = layers[li];
     char* kc = (char*)io->kcache + li * layer_bytes;
@@ -363,41 +312,9 @@ extern "C" int emoasr_bert_lm_step(int dtype, int nl, const emoasr_bert_layer_t*
     if (rl(nb, V, d, t1, &io->ln_transform, tied_co, EMOASR_ACT_NONE, nullptr, nullptr, logits, 1, stream)) return 1;
     return emoasr_log_softmax(EMO_F32, nb, V, logits, V, nullptr, 0, 0.f, io->logp, V, stream);
   }
-#ifdef EMOASR_EXPERIMENTAL
-  if (emo_decode_wg_ok(dtype, nb, nl, 12, d, H, F)) {
-    if (emo_bert_lm_step_wg(nl, layers, io, t1, s)) return 1;
-    emoasr_lin_t tied_wg{io->word_emb, io->out_bias};
-    if (io->raw_logits) return rl(nb, V, d, t1, &io->ln_transform, tied_wg, EMOASR_ACT_NONE, nullptr, nullptr, io->logp, 1, stream);
-    if (rl(nb, V, d, t1, &io->ln_transform, tied_wg, EMOASR_ACT_NONE, nullptr, nullptr, logits, 1, stream)) return 1;
-    return emoasr_log_softmax(EMO_F32, nb, V, logits, V, nullptr, 0, 0.f, io->logp, V, stream);
-  }
-#endif
   EMO_DISPATCH(dtype, (step_embed_kernel<T><<<cdiv(nb * d, 256), 256, 0, s>>>(nb, d, io->ids, (const T*)io->word_emb, io->pe, 1.f,
                                                                               io->pos, (T*)y)));
   const size_t layer_bytes = (size_t)nb * Lmax * d * esz;
-  if (kExperimental && g_decode_fused && dtype == EMO_BF16 && nb <= 16 && d <= 1024 && F <= 1024 && d % 32 == 0 && F % 32 == 0 && (d / H) % 8 == 0) {
-    // post-LN blocks, 5 launches per layer instead of 8: `y` holds the block's pre-LayerNorm output and `pend` the
-    // LayerNorm still to be applied to it -- inside the next projection (A operand) and inside the next residual add
-    const emoasr_lnp_t* pend = &io->ln_emb;
-    void* ycur = y;   // embeddings, not yet normalised
-    void* yalt = x;
-    for (int li = 0; li < nl; ++li) {
-      const emoasr_bert_layer_t& Ly = layers[li];
-      char* kc = (char*)io->kcache + li * layer_bytes;
-      char* vc = (char*)io->vcache + li * layer_bytes;
-      if (rl(nb, 3 * d, d, ycur, pend, Ly.qkv, EMOASR_ACT_NONE, nullptr, nullptr, qkv, 0, stream)) return 1;
-      if (emoasr_attn_step(nb, d, H, Lmax, qkv, kc, vc, io->pos, o, stream)) return 1;
-      if (rl(nb, d, d, o, nullptr, Ly.attn_out, EMOASR_ACT_NONE, ycur, pend, yalt, 0, stream)) return 1;       // y1
-      if (rl(nb, F, d, yalt, &Ly.ln_attn, Ly.inter, 3 /* GELU */, nullptr, nullptr, act, 0, stream)) return 1;
-      if (rl(nb, d, F, act, nullptr, Ly.out, EMOASR_ACT_NONE, yalt, &Ly.ln_attn, ycur, 0, stream)) return 1;  // y2
-      pend = &Ly.ln_out;
-    }
-    if (rl(nb, d, d, ycur, pend, io->transform, 3, nullptr, nullptr, t1, 0, stream)) return 1;
-    emoasr_lin_t tied{io->word_emb, io->out_bias};
-    if (io->raw_logits) return rl(nb, V, d, t1, &io->ln_transform, tied, EMOASR_ACT_NONE, nullptr, nullptr, io->logp, 1, stream);
-    if (rl(nb, V, d, t1, &io->ln_transform, tied, EMOASR_ACT_NONE, nullptr, nullptr, logits, 1, stream)) return 1;
-    return emoasr_log_softmax(EMO_F32, nb, V, logits, V, nullptr, 0, 0.f, io->logp, V, stream);
-  }
   if (emoasr_layernorm_fwd(dtype, nb, d, y, io->ln_emb.g, io->ln_emb.b, 1e-12f, x, nullptr, nullptr, stream)) return 1;
   for (int li = 0; li < nl; ++li) {
     const emoasr_bert_layer_t& Ly = layers[li];

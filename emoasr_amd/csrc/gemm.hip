@@ -947,12 +947,6 @@ int emo_gemm_nt_big_ep(int M, int N, int K, const void* A, long lda, const void*
                        const emoasr_epilogue_t& ep, hipStream_t s);
 int emo_conv2_fwd_big(int B, int T1, int F1, int C, const void* y1, const void* w, void* y2, const float* bias,
                       int relu, hipStream_t s);
-#ifdef EMOASR_EXPERIMENTAL
-// csrc/experimental/gemm_k256.hip (opt-in build, measured slower): persistent, weight-stationary kernel for K = 256 products
-bool emo_gemm_nt_k256_wants(int M, int N, int K, long lda, long ldb, long ldc, const emoasr_epilogue_t& ep);
-int emo_gemm_nt_k256(int M, int N, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
-                     const emoasr_epilogue_t& ep, hipStream_t s);
-#endif
 
 void emo_gemm_set_tr_read(int v) { g_tr_read = v; }
 void emo_gemm_set_tile(int v) { g_gemm_tile = v; }
@@ -985,11 +979,6 @@ extern "C" int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, lon
   const double esz_ = dtype == EMO_BF16 ? 2.0 : 4.0;   // algorithmic work of the launch, for the family timer (bench.py)
   EmoTimerScope timer_(EMO_TIMER_GEMM_NT_NN, (hipStream_t)stream, 2.0 * M * N * K,
                        ((double)M * K + (double)N * K + (double)M * N * (1 + (a.ep.residual ? 1 : 0) + (a.ep.pre_out ? 1 : 0))) * esz_);
-#ifdef EMOASR_EXPERIMENTAL
-  // K = 256 products over many rows: the persistent weight-stationary kernel of experimental/gemm_k256.hip (option "gemm_k256")
-  if (dtype == EMO_BF16 && emo_gemm_nt_k256_wants(M, N, K, lda, ldb, ldc, a.ep))
-    return emo_gemm_nt_k256(M, N, A, lda, B, ldb, C, ldc, a.ep, (hipStream_t)stream);
-#endif
   // wide bf16 products over many rows (q/k/v, feed-forward w1, pointwise conv 1): the large-tile kernel of gemm_big.hip
   if (dtype == EMO_BF16 && emo_gemm_nt_big_wants(M, N, K, lda, ldb, ldc, a.ep))
     return emo_gemm_nt_big_ep(M, N, K, A, lda, B, ldb, C, ldc, a.ep, (hipStream_t)stream);

@@ -309,10 +309,7 @@ def load():
     lib.emoasr_version.restype = c_int
     lib.emoasr_set_option.argtypes = [c_char_p, c_int]
     lib.emoasr_set_option.restype = c_int
-    lib.emoasr_experimental.restype = c_int
     for name, args in SIGNATURES.items():
-        if name in EXPERIMENTAL_ONLY and not lib.emoasr_experimental():
-            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = args
         fn.restype = c_int
@@ -326,14 +323,6 @@ def load():
 
 
 _FN = {}
-# entry points that exist only in a library built with EMOASR_EXPERIMENTAL=1 (csrc/experimental/)
-EXPERIMENTAL_ONLY = set()
-
-
-def experimental():
-    return bool(load().emoasr_experimental())
-
-
 
 def call(name, *args):
     fn = _FN.get(name)

@@ -72,12 +72,8 @@ def joint_beam_search_device(dec, eouts, elens, beam_width, len_weight=0, lm=Non
     Lmax = max_steps + 1
     A = eng.arena
     timing = os.environ.get("EMOASR_BEAM_TIMING") == "1"
-    if os.environ.get("EMOASR_DECODE_WG"):      # A/B switch of csrc/decode_wg.hip (one launch per network and step)
-        lib.set_option("decode_wg", int(os.environ["EMOASR_DECODE_WG"]))
     if os.environ.get("EMOASR_DECODE_COOP"):    # A/B switch of csrc/decode_coop.hip (one cooperative launch per network and step)
         lib.set_option("decode_coop", int(os.environ["EMOASR_DECODE_COOP"]))
-    if os.environ.get("EMOASR_DECODE_FUSED"):   # A/B switch of csrc/rowlin.hip inside the cached steps
-        lib.set_option("decode_fused", int(os.environ["EMOASR_DECODE_FUSED"]))
     if timing:
         torch.cuda.synchronize()
         t_start = time.perf_counter()

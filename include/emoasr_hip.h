@@ -38,9 +38,6 @@ enum { EMOASR_ACT_NONE = 0, EMOASR_ACT_RELU = 1, EMOASR_ACT_SWISH = 2,
 
 const char* emoasr_last_error(void);
 int emoasr_version(void);
-/* 1 when the library was built with EMOASR_EXPERIMENTAL=1 (the measured-slower variants of csrc/experimental/ are linked in and
- * the options "decode_wg", "decode_fused" exist), else 0 */
-int emoasr_experimental(void);
 /* options: "tr_read" (1 = ds_read_b64_tr_b16 operand reads, 0 = scalar fallback); tuning: "gemm_tile", "gemm_kb",
  * "gemm_xcd", "gemm_wholek", "tn_group_blocks", "tn_group_kb", "tn_place", "attn_lpt", "attn_xcd", "attn_fwd_waves", "attn_fwd_split", "attn_fw" (key tiles per workgroup of the single-pass attention backward: 2, 4, 0 = auto);
  * round 4: "attn_bwd_split", "attn_side", "ffn_save_dact", "big_n256" (long reductions onto one / two 256-column tiles on the

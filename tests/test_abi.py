@@ -14,7 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "emoasr_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    src = re.sub(r"#ifdef EMOASR_EXPERIMENTAL.*?#endif", "", src, flags=re.S)   # opt-in build only (csrc/experimental/)
     return sorted(set(re.findall(r"\b(emoasr_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -26,8 +25,6 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in emoasr_hip.h but not exported"
     for n in lib.SIGNATURES:
-        if n in lib.EXPERIMENTAL_ONLY:
-            continue
         assert n in names, f"{n} bound in lib.py but not declared in the header"
     assert handle.emoasr_version() >= 1
 

@@ -209,7 +209,7 @@ def test_device_beam_search_equals_host_bookkeeping(dev, dtype, monkeypatch):
                     assert hyps[0] == hyps_h[0] and abs(scores[0] - scores_h[0]) < 2e-2 * abs(scores_h[0]) + 1e-3
 
 
-@pytest.mark.parametrize("option", ["decode_coop", "decode_coop_merge3", "decode_coop_merge0", "decode_wg", "decode_fused"])
+@pytest.mark.parametrize("option", ["decode_coop", "decode_coop_merge3", "decode_coop_merge0"])
 def test_alternative_decode_step_kernels_agree(dev, option):
     """the forms of the cached decode steps -- csrc/decode_coop.hip (the default: one launch of 16 cooperating workgroups per
     network, grid barriers between the stages), and the two measured-and-not-kept ones, csrc/decode_wg.hip (one workgroup per
@@ -217,8 +217,6 @@ def test_alternative_decode_step_kernels_agree(dev, option):
     plain launch chain (bf16: scores to 2 %)"""
     from emoasr_amd import lib
     from emoasr_amd.modeling.lm import LM
-    if option in ("decode_wg", "decode_fused") and not lib.experimental():
-        pytest.skip("measured-slower variant: only in a library built with EMOASR_EXPERIMENTAL=1")
     model, g = _build(torch.bfloat16, dev)
     model.eval()
     lm = LM(SimpleNamespace(**LM_CFG), compute_dtype=torch.bfloat16)

@@ -6,8 +6,8 @@ from emoasr_amd import ops
 
 dev = torch.device("cuda:0")
 from emoasr_amd import lib as _lib
-for _o in ('gemm_tile', 'gemm_kb', 'gemm_xcd', 'big_min_tiles', 'gemm_k256', 'gemm_k256_dbg'):
-    if os.environ.get(_o.upper()) is not None and (not _o.startswith('gemm_k256') or _lib.experimental()): _lib.set_option(_o, int(os.environ[_o.upper()]))
+for _o in ('gemm_tile', 'gemm_kb', 'gemm_xcd', 'big_min_tiles'):
+    if os.environ.get(_o.upper()) is not None: _lib.set_option(_o, int(os.environ[_o.upper()]))
 M = int(os.environ.get("M", 7200))
 dt = torch.bfloat16
 shapes_nt = [("ffn1", M, 1024, 256), ("ffn2", M, 256, 1024), ("qkv", M, 768, 256), ("out", M, 256, 256),
