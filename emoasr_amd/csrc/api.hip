@@ -53,7 +53,6 @@ void emo_gemm_set_tn_place(int v);
 void emo_gemm_set_wholek(int v);
 void emo_gemm_set_kb(int v);
 void emo_gemm_set_xcd(int v);
-void emo_gemm_set_f32_split(int v);
 void emo_gemm_set_split_tile(int v);
 void emo_gemm_set_split_kb(int v);
 void emo_gemm_set_split_min128(int v);
@@ -66,6 +65,7 @@ void emo_layer_set_conv_fused(int v);
 void emo_layer_set_wgrad_side(int v);
 void emo_layer_set_stack_launch(int v);
 void emo_layer_set_ffn_save_dact(int v);
+void emo_layer_set_att_bits(int v);
 void emo_ln_set_fwd8(int v);
 void emo_gemm_set_wide128(int v);
 void emo_gemm_set_big_n256(int v);
@@ -81,7 +81,6 @@ void emo_decode_set_coop_merge(int v);
 void emo_attn_set_tr_read(int v);
 void emo_attn_set_fw(int v);
 void emo_attn_set_bwd_split(int v);
-void emo_attn_set_kv_dbg(int v);
 void emo_attn_set_side(int v);
 void emo_attn_set_side_prio(int v);
 void emo_attn_set_lpt(int v);
@@ -163,8 +162,6 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "gemm_wholek") == 0) { emo_gemm_set_wholek(value); return 0; }
   if (strcmp(name, "gemm_kb") == 0) { emo_gemm_set_kb(value); return 0; }
   if (strcmp(name, "gemm_xcd") == 0) { emo_gemm_set_xcd(value); return 0; }
-  // f32 products (GEMMs, Conv2d, attention) as three bf16 MFMAs over (hi, lo) operand pairs: csrc/gemm.hip SplitCfg
-  if (strcmp(name, "f32_split") == 0) { emo_gemm_set_f32_split(value); return 0; }
   if (strcmp(name, "split_tile") == 0) { emo_gemm_set_split_tile(value); return 0; }
   if (strcmp(name, "split_kb") == 0) { emo_gemm_set_split_kb(value); return 0; }
   if (strcmp(name, "split_min128") == 0) { emo_gemm_set_split_min128(value); return 0; }
@@ -177,6 +174,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "wgrad_side") == 0) { emo_layer_set_wgrad_side(value); return 0; }
   if (strcmp(name, "stack_launch") == 0) { emo_layer_set_stack_launch(value); return 0; }
   if (strcmp(name, "ffn_save_dact") == 0) { emo_layer_set_ffn_save_dact(value); return 0; }
+  if (strcmp(name, "attn_mask_bits") == 0) { emo_layer_set_att_bits(value); return 0; }
   if (strcmp(name, "conv1_pair") == 0) { emo_conv1_set_pair(value); return 0; }
   if (strcmp(name, "big_waves") == 0) { emo_gemm_set_big_waves(value); return 0; }
   if (strcmp(name, "big_n256") == 0) { emo_gemm_set_big_n256(value); return 0; }
@@ -191,7 +189,6 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "decode_coop_merge") == 0) { emo_decode_set_coop_merge(value); return 0; }
   if (strcmp(name, "attn_fw") == 0) { emo_attn_set_fw(value); return 0; }
   if (strcmp(name, "attn_bwd_split") == 0) { emo_attn_set_bwd_split(value); return 0; }
-  if (strcmp(name, "attn_kv_dbg") == 0) { emo_attn_set_kv_dbg(value); return 0; }
   if (strcmp(name, "attn_side") == 0) { emo_attn_set_side(value); return 0; }
   if (strcmp(name, "attn_side_prio") == 0) { emo_attn_set_side_prio(value); return 0; }
   if (strcmp(name, "attn_lpt") == 0) { emo_attn_set_lpt(value); return 0; }

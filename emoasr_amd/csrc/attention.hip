@@ -29,7 +29,6 @@
 #include "mma.h"
 #include "../../include/emoasr_hip.h"
 
-int emo_gemm_f32_split();   // csrc/gemm.hip: option "f32_split"
 
 namespace {
 
@@ -76,6 +75,24 @@ __device__ __forceinline__ typename Mma<T>::Frag frag_global(const T* base, long
     float v = buf_load_f32<T>(rs, valid ? (unsigned)(((long)row * ld + d) * 4) : EMO_OOB);
     if (bias) v += bias[d];
     return v;
+  }
+}
+
+// the same fragment at a BYTE offset that already holds the row and the lane's half (frag_half_bytes): k-step kk is a constant
+// added to it -- no row arithmetic, no guard (the descriptor's size is the guard: make_rsrc_n)
+template <typename T> __device__ __forceinline__ unsigned frag_half_bytes(int lane) {
+  return (sizeof(T) == 2 ? 16u : (kSplit<T> ? 32u : 4u)) * (unsigned)(lane >> 5);
+}
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::Frag frag_at(__amdgpu_buffer_rsrc_t rs, unsigned off, int kk) {
+  if constexpr (sizeof(T) == 2) {
+    return buf_load16<T>(rs, off + 32u * kk).v;
+  } else if constexpr (kSplit<T>) {
+    const Vec16<T> a = buf_load16<T>(rs, off + 64u * kk), b = buf_load16<T>(rs, off + 64u * kk + 16u);
+    const float x[8] = {a.v[0], a.v[1], a.v[2], a.v[3], b.v[0], b.v[1], b.v[2], b.v[3]};
+    return split_regs8(x);
+  } else {
+    return buf_load_f32<T>(rs, off + 8u * kk);
   }
 }
 
@@ -241,6 +258,7 @@ __device__ __forceinline__ void seg_apply(emoasr_attn_t& a, const SegRef& g) {
   a.lse += r * a.H;
   if (a.delta) a.delta += r * a.H;
   if (a.klens) a.klens += g.b0;
+  if (a.keep_mask) a.keep_mask += r * a.H * a.keep_nw;
   a.B = g.nb;
   a.Tq = a.Tk = g.T;
   a.seed += 0x9E3779B97F4A7C15ull * (uint64_t)g.s;
@@ -357,6 +375,10 @@ __device__ __forceinline__ void store_dT(T* dst, long ld, int r0, int rlimit, co
 // at most one block per CU; otherwise one set, refilled as soon as the score MFMAs have read it, and two
 // blocks per CU (bf16).  Measured at B 20, T' 340 (240 blocks): 36 us with two sets, 45 us with one; at 264
 // blocks the two-set kernel's second round of blocks costs 80 us against 62.
+template <typename T> constexpr int fwd_wave_bytes() {
+  constexpr int g = 32 * 68 * 4, v = 32 * AttnCfg<T>::LD * (int)sizeof(T);
+  return g > v ? g : v;
+}
 template <typename T, bool TR, bool PF2>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fwd_kernel(const emoasr_attn_t a_in, const int nt, const int ks) {
   using M_ = Mma<T>;
@@ -375,9 +397,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
   // query tiles for 256 CUs): the four waves share ONE query tile and take every fourth key tile; their soft-max states meet in LDS
   const int i0 = (ks > 1 ? blk.x : blk.x * (blockDim.x >> 6) + wave) * 32, h = blk.y;
   if (i0 >= a.Tq) return;
-  constexpr int WAVE_BYTES = 64 * 32 * 4 + 32 * LD * (int)sizeof(T);
+  // wave-private LDS: the f32 skew tile G[query][band column] ([32][LDG]) and, AFTER the skew has been read, the V tile in the same
+  // bytes (round 6: 8.7 KB per wave instead of 12.6 -- the stacked launches' one-wave workgroups were LDS-limited to 12 per CU)
+  constexpr int LDG = 68;
+  constexpr int WAVE_BYTES = fwd_wave_bytes<T>();
   float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
-  T* Vs = reinterpret_cast<T*>(smem + wave * WAVE_BYTES + 64 * 32 * 4);
+  T* Vs = reinterpret_cast<T*>(smem + wave * WAVE_BYTES);
 
   const HeadPtrs hp = head_ptrs<T>(a, b, h);
   const int qi = i0 + (lane & 31);
@@ -400,40 +425,57 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
   // one wave per SIMD at the L2 batch size, loading each tile right where it was needed exposed two global
   // round trips per tile.
   constexpr int VEC = 16 / sizeof(T), PER_ROW = DK / VEC, VR = 32 * PER_ROW / 64;
-  struct Pre { typename M_::Frag kf[NK]; typename M_::Frag pf[2][NK]; Vec16<T> vr[VR]; };
+  struct Pre { typename M_::Frag kf[NK]; typename M_::Frag pf[2][NK]; Vec16<T> vr[VR]; unsigned mw; };
   const bool rel = hp.pos != nullptr;
-  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(hp.v);
-  auto fetch = [&](Pre& p, int j0) {
-    const bool live = j0 < kend;  // past the last tile: out-of-range offsets, no traffic
-    const int krow = j0 + (lane & 31);
+  // Operand descriptors sized to the valid rows (keys < kend, table rows < 2 Tq - 1): rows past them -- the last tile's tail, the
+  // prefetch behind the last tile, band rows of (query, key) pairs outside the utterance -- read zeros by the descriptor, so a
+  // fetch is 16 loads at lane-constant offsets + one stride multiple per operand: no compare / select / 64-bit multiply per load
+  // (round 5: 34 exec-mask regions around these loads)
+  constexpr unsigned ESZ = sizeof(T);
+  const unsigned kstride = (unsigned)a.ldk * ESZ, vstride = (unsigned)a.ldv * ESZ, pstride = (unsigned)a.ldp * ESZ;
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc_n(hp.k, kend > 0 ? (unsigned)(kend - 1) * kstride + DK * ESZ : 0u);
+  const __amdgpu_buffer_rsrc_t rsV = make_rsrc_n(hp.v, kend > 0 ? (unsigned)(kend - 1) * vstride + DK * ESZ : 0u);
+  const __amdgpu_buffer_rsrc_t rsP = make_rsrc_n(rel ? hp.pos : hp.k, rel ? (unsigned)(2 * a.Tq - 2) * pstride + DK * ESZ : 0u);
+  const unsigned k_lane = (unsigned)(lane & 31) * kstride + frag_half_bytes<T>(lane);
+  const unsigned p_lane = (unsigned)(lane & 31) * pstride + frag_half_bytes<T>(lane);
+  unsigned v_lane[VR];
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk)
-      p.kf[kk] = frag_global<T>((const T*)hp.k, a.ldk, krow, live && krow < a.Tk, kk, lane, nullptr);
+  for (int i = 0; i < VR; ++i) {
+    const int v = lane + 64 * i;
+    v_lane[i] = (unsigned)(v / PER_ROW) * vstride + (unsigned)((v % PER_ROW) * VEC) * ESZ;
+  }
+  // the attention-dropout keep mask as bits (emoasr_attn_dropmask hashed it once for this forward AND the backward): one word per
+  // (query row, head, 32-key tile), fetched with the tile's operands; without it the mask is hashed inline (dropout_keep2)
+  const bool mbits = a.keep_mask != nullptr && a.drop_p > 0.f;
+  const __amdgpu_buffer_rsrc_t rsM = make_rsrc(a.keep_mask);
+  const unsigned mrow = (unsigned)((((long)b * a.Tq + qi) * a.H + h) * a.keep_nw * 4);
+  // `prev`: the register set that holds the band of key tile j0 - 32 ks... only for ks == 1 (consecutive tiles): the band of tile
+  // j0 is rows rbase(j0) + [0, 64) and rbase moves by 32 per tile, so its lower half IS the previous tile's upper half -- four
+  // fragment loads per tile instead of eight
+  auto fetch = [&](Pre& p, int j0, const Pre* prev) {
+    const unsigned ko = k_lane + (unsigned)j0 * kstride;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) p.kf[kk] = frag_at<T>(rsK, ko, kk);
     if (rel) {
-      const int rbase = a.Tq - 32 - i0 + j0, rmax = 2 * a.Tq - 2;
+      // band row of lane l of tile ct: Tq - 32 - i0 + j0 + 32 ct + l (negative: the offset wraps out of range); nothing past kend
+      const unsigned po = (unsigned)((a.Tq - 32 - i0 + j0) * (int)pstride) + p_lane + (j0 < kend ? 0u : 0x80000000u);
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int prow = clampi(rbase + 32 * ct + (lane & 31), 0, rmax);
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk)
-          p.pf[ct][kk] = frag_global<T>((const T*)hp.pos, a.ldp, prow, live, kk, lane, nullptr);
+      for (int kk = 0; kk < NK; ++kk) {
+        p.pf[0][kk] = prev ? prev->pf[1][kk] : frag_at<T>(rsP, po, kk);
+        p.pf[1][kk] = frag_at<T>(rsP, po + 32u * pstride, kk);
       }
     }
 #pragma unroll
-    for (int i = 0; i < VR; ++i) {
-      const int v = lane + 64 * i, r = v / PER_ROW, piece = (v % PER_ROW) * VEC, row = j0 + r;
-      p.vr[i] = buf_load16<T>(rsV, live && row < a.Tk ? (unsigned)(((long)row * a.ldv + piece) * sizeof(T)) : EMO_OOB);
-    }
+    for (int i = 0; i < VR; ++i) p.vr[i] = buf_load16<T>(rsV, v_lane[i] + (unsigned)j0 * vstride);
+    p.mw = mbits ? __builtin_amdgcn_raw_buffer_load_b32(rsM, (j0 < kend && qval) ? mrow + 4u * (unsigned)(j0 >> 5) : EMO_OOB, 0, 0) : 0u;
   };
+  constexpr bool FAST = sizeof(T) == 2;   // bf16: soft-max in the exp2 domain (one multiply less per element, no -inf tests per element)
+  const float c2 = a.scale * 1.4426950408889634f;
+  const unsigned keep_bits = __float_as_uint(a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f);
   auto tile = [&](Pre& cur, Pre& nxt, int j0) {
     EMO_FSTAMP(0);
-    if constexpr (PF2) fetch(nxt, j0 + 32 * ks);
+    if constexpr (PF2) fetch(nxt, j0 + 32 * ks, ks == 1 ? &cur : nullptr);
     EMO_FSTAMP(1);
-#pragma unroll
-    for (int i = 0; i < VR; ++i) {
-      const int v = lane + 64 * i;
-      lds_stage16(Vs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, cur.vr[i]);
-    }
     // S^T = K . (Q+u)^T + skew(pos_band . (Q+v)^T)   (rows keys, cols queries; see score_tile)
     f32x16 s;
     zero16(s);
@@ -446,23 +488,27 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
         zero16(g);
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) g = M_::mma(cur.pf[ct][kk], qv[kk], g);  // g[c][i]
+        // G[query il][c]: accumulator registers 4 q .. 4 q + 3 are four consecutive band columns -> one 16-byte store
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Gs[(32 * ct + c_row(r, lane)) * 32 + (lane & 31)] = g[r];
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(Gs + (lane & 31) * LDG + 32 * ct + 8 * q + 4 * (lane >> 5)) = f32x4{g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]};
       }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] += Gs[(lane & 31) * (LDG - 1) + 31 + c_row(r, lane)];   // G[il][31 - il + jl]
+      __builtin_amdgcn_wave_barrier();
     }
     EMO_FSTAMP(2);
-    // one register set: every prefetched register has been consumed, refill them with tile j0+32
-    if constexpr (!PF2) fetch(cur, j0 + 32 * ks);   // (ks > 1: this wave's next key tile is ks tiles on)
-    EMO_FSTAMP(3);
-    if (rel) {
-      __builtin_amdgcn_wave_barrier();
+    // the V tile takes the skew tile's place
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jl = c_row(r, lane), il = lane & 31;
-        s[r] += Gs[(31 - il + jl) * 32 + il];
-      }
-      __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < VR; ++i) {
+      const int v = lane + 64 * i;
+      lds_stage16(Vs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, cur.vr[i]);
     }
+    const unsigned mw = cur.mw >> (4 * (lane >> 5));   // this half wave's keys are 8 g + 4 hh + e
+    // one register set: every prefetched register has been consumed, refill them with tile j0+32
+    if constexpr (!PF2) fetch(cur, j0 + 32 * ks, ks == 1 ? &cur : nullptr);   // (ks > 1: this wave's next key tile is ks tiles on)
+    EMO_FSTAMP(3);
     if (a.st && qval) {  // keep the scaled scores for the backward pass (32 queries contiguous per key row)
       float* srow = a.st + (((long)b * a.H + h) * a.Tk + j0) * a.ldst + qi;
 #pragma unroll
@@ -473,10 +519,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
     }
     EMO_FSTAMP(4);
     float mt = -INFINITY;
+    const float sc = FAST ? c2 : a.scale;
     if (j0 + 32 <= hp.klen && !a.causal) {  // (wave-uniform) a tile without masked keys: no per-element range tests
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] *= a.scale;
+        s[r] *= sc;
         mt = fmaxf(mt, s[r]);
       }
     } else {
@@ -484,19 +531,31 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
       for (int r = 0; r < 16; ++r) {
         const int kj = j0 + c_row(r, lane);
         const bool masked = kj >= hp.klen || (a.causal && kj > qi);
-        s[r] = masked ? -INFINITY : s[r] * a.scale;
+        s[r] = masked ? -INFINITY : s[r] * sc;
         mt = fmaxf(mt, s[r]);
       }
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float mn = fmaxf(m, mt);
-    const float alpha = (m == -INFINITY) ? 0.f : __expf(m - mn);
-    float rs = 0.f;
+    float alpha, rs = 0.f;
+    if constexpr (FAST) {
+      // m, mn in the exp2 domain; a row without a valid key so far keeps mn = -inf: subtract 0 instead (exp2(-inf) = 0 either way)
+      const float mref = (mn == -INFINITY) ? 0.f : mn;
+      alpha = __builtin_amdgcn_exp2f(m - mref);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - mn);
-      rs += p;
-      s[r] = p;
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[r] - mref);
+        rs += p;
+        s[r] = p;
+      }
+    } else {
+      alpha = (m == -INFINITY) ? 0.f : __expf(m - mn);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - mn);
+        rs += p;
+        s[r] = p;
+      }
     }
     rs += __shfl_xor(rs, 32, 64);
     l = l * alpha + rs;
@@ -504,18 +563,25 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
     if (a.drop_p > 0.f) {
-      // accumulator rows 4 g .. 4 g + 3 are keys j0 + 8 g + 4 (lane >> 5) + 0 .. 3: two hash pairs (row base and j0 are even)
-      const float keep = 1.f / (1.f - a.drop_p);
-      const uint32_t thr = dropout_thr(a.drop_p);
-      const uint64_t dbase = drop_index(a, b, h, qi, j0 + 4 * (lane >> 5));
+      if (mbits) {
+        // bit 8 g + e of the half wave's word: 0 / -1 -> 0 / keep
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const uint64_t pr = (dbase + (uint64_t)(8 * g)) >> 1;
-        bool k0, k1, k2, k3;
-        dropout_keep2(a.seed, pr, thr, k0, k1);
-        dropout_keep2(a.seed, pr + 1, thr, k2, k3);
-        s[4 * g] *= k0 ? keep : 0.f; s[4 * g + 1] *= k1 ? keep : 0.f;
-        s[4 * g + 2] *= k2 ? keep : 0.f; s[4 * g + 3] *= k3 ? keep : 0.f;
+        for (int r = 0; r < 16; ++r)
+          s[r] *= __uint_as_float((unsigned)__builtin_amdgcn_sbfe(mw, 8 * (r >> 2) + (r & 3), 1) & keep_bits);
+      } else {
+        // accumulator rows 4 g .. 4 g + 3 are keys j0 + 8 g + 4 (lane >> 5) + 0 .. 3: two hash pairs (row base and j0 are even)
+        const float keep = 1.f / (1.f - a.drop_p);
+        const uint32_t thr = dropout_thr(a.drop_p);
+        const uint64_t dbase = drop_index(a, b, h, qi, j0 + 4 * (lane >> 5));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint64_t pr = (dbase + (uint64_t)(8 * g)) >> 1;
+          bool k0, k1, k2, k3;
+          dropout_keep2(a.seed, pr, thr, k0, k1);
+          dropout_keep2(a.seed, pr + 1, thr, k2, k3);
+          s[4 * g] *= k0 ? keep : 0.f; s[4 * g + 1] *= k1 ? keep : 0.f;
+          s[4 * g + 2] *= k2 ? keep : 0.f; s[4 * g + 3] *= k3 ? keep : 0.f;
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -531,20 +597,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
   const int jstep = 32 * ks, jfirst = ks > 1 ? 32 * wave : 0;
   if constexpr (PF2) {
     Pre pa, pb;
-    fetch(pa, jfirst);
+    fetch(pa, jfirst, nullptr);
     for (int j0 = jfirst; j0 < kend; j0 += 2 * jstep) {
       tile(pa, pb, j0);
       if (j0 + jstep < kend) tile(pb, pa, j0 + jstep);
     }
   } else {
     Pre pc;
-    fetch(pc, jfirst);
+    fetch(pc, jfirst, nullptr);
     for (int j0 = jfirst; j0 < kend; j0 += jstep) tile(pc, pc, j0);
   }
   if (ks > 1) {
     // merge the four waves' (m, l, O) of the same 32 queries: every register of a lane belongs to query lane & 31, so the
     // states combine lane by lane.  Each wave parks its O in its own Gs image (2048 floats) and m / l at the head of its Vs.
-    float* sml = reinterpret_cast<float*>(Vs);
+    float* sml = Gs + 2048;   // (behind the parked O image: 64 floats)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -555,14 +621,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
     float mw[4], lw[4], sc[4], mm = -INFINITY;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const float* q = reinterpret_cast<const float*>(smem + w * WAVE_BYTES + 64 * 32 * 4);
+      const float* q = reinterpret_cast<const float*>(smem + w * WAVE_BYTES) + 2048;
       mw[w] = q[lane & 31]; lw[w] = q[32 + (lane & 31)];
       mm = fmaxf(mm, mw[w]);
     }
     l = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      sc[w] = mw[w] == -INFINITY ? 0.f : __expf(mw[w] - mm);
+      sc[w] = mw[w] == -INFINITY ? 0.f : (FAST ? __builtin_amdgcn_exp2f(mw[w] - mm) : __expf(mw[w] - mm));
       l += lw[w] * sc[w];
     }
     m = mm;
@@ -578,7 +644,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
   }
   const float inv = l > 0.f ? 1.f / l : 0.f;
   store_dT<T>((T*)hp.out, a.ldo, i0, a.Tq, o, inv, lane);
-  if (lane < 32 && qval) hp.lse[qi] = l > 0.f ? m + __logf(l) : -INFINITY;
+  if (lane < 32 && qval) hp.lse[qi] = l > 0.f ? (FAST ? m * 0.6931471805599453f : m) + __logf(l) : -INFINITY;
 }
 
 // delta[b,h,i] = sum_d dout[b,i,h,d] * out[b,i,h,d]; optionally also Q + pos_bias_u / Q + pos_bias_v as
@@ -1839,107 +1905,131 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
 // dS is gathered with 2-byte loads (consecutive lanes = consecutive keys) as the A operand, the 32x64 (Q+v) tile comes in
 // with 16-byte loads and goes through wave-private LDS (transposed reads) as the B operand; the next item's loads are in
 // flight while this one is multiplied.  Waves are reduced through LDS before one set of atomics (rows of 64 d).
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Position-table gradient, round 6 (bf16): dpos[r] = sum_{b,i} dS_b[i, j = i - (T-1) + r] (Q+v)_b[i] from the stored dS image, one
+// DIAGONAL of 32 x 32 tiles per workgroup.  Every tile (i0, j0 = i0 + 32 dg) of a diagonal maps to the SAME 64 table rows
+// rbase + c, rbase = T - 32 + 32 dg, c = 31 - il + jl, so a wave keeps ONE [64 c][64 d] accumulator for all the tiles and all the
+// utterances it visits and the workgroup leaves with one 16 KB atomic flush.  Per tile: the dS tile (2 KB) and the (Q+v) tile
+// (4 KB) arrive by 16-byte loads one item ahead; the dS tile sits in wave-private LDS between two zero-filled 32-column wings, so
+// the skewed operand dG^T[c][i] = dS[i][c + i - 31] is 32 two-byte LDS reads at COMPILE-TIME offsets from one per-lane base (the
+// wings supply the zeros of the band's corners); (Q+v) is read k-major with transposing reads.  attn_bwd_dpos2_kernel gathered
+// the diagonal elements from global memory with two-byte loads: 84 non-matrix instructions per MFMA, 141 us per layer launch at
+// the bench's shapes (profiles/r05_attn_counters.txt).
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct Dpos3Plan { int nseg, nch; int wg0[EMOASR_MAX_SEGMENTS + 1]; };   // workgroups of segment s: [wg0[s], wg0[s+1]) = H x (2 nt - 1) x nch
 template <typename T, bool TR>
-__global__ __launch_bounds__(256) void attn_bwd_dpos2_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int bchunk_in,
-                                                             const int nchunk, const int nt) {
+__global__ __launch_bounds__(256) void attn_bwd_dpos3_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const Dpos3Plan plan) {
   using M_ = Mma<T>;
-  constexpr int RT = 2;  // 32-row table tiles per block: the staged (Q+v) tile is multiplied into both
-  // (nt > 0: the table tiles of one (head, segment, batch chunk) on one XCD -- they read the same (Q+v) rows and neighbouring
-  // pieces of the same dS rows; see attn_block)
-  const Blk3 blk = attn_block(nt, a_in.H, nchunk * (a_in.nseg > 1 ? a_in.nseg : 1));
-  if (!blk.ok) return;
-  constexpr int LD = AttnCfg<T>::LD, VEC = 16 / sizeof(T), PER_ROW = DK / VEC, QR = 32 * PER_ROW / 64;
-  constexpr int QS_BYTES = 32 * LD * (int)sizeof(T), RED_BYTES = 4 * RT * 2 * 16 * 64 * 4;
-  __shared__ __attribute__((aligned(16))) char smem[(4 * QS_BYTES > RED_BYTES) ? 4 * QS_BYTES : RED_BYTES];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, hh = lane >> 5;
+  static_assert(sizeof(T) == 2, "bf16 only");
+  constexpr int LD = AttnCfg<T>::LD;            // (Q+v) tile row stride
+  constexpr int LDS_ = 104;                     // dS tile row stride: [32 zeros | 32 keys | 32 zeros | pad]
+  constexpr int DS_BYTES = 32 * LDS_ * 2, QV_BYTES = 32 * LD * 2, WAVE_BYTES = DS_BYTES + QV_BYTES;
+  constexpr int RED_BYTES = 4 * 2 * 16 * 64 * 4;   // one 32-row table tile of all four waves at a time
+  __shared__ __attribute__((aligned(16))) char smem[(4 * WAVE_BYTES > RED_BYTES) ? 4 * WAVE_BYTES : RED_BYTES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), il = lane & 31, hh = lane >> 5;
   emoasr_attn_t a = a_in;
   FusedWs ws = ws_in;
-  int bchunk = bchunk_in, zc = blk.z;
-  if (a_in.nseg > 1) {   // stacked micro-batches: blk.z = segment * nchunk + batch chunk; every segment has its own table
-    const int sgi = blk.z / nchunk;
-    zc = blk.z - sgi * nchunk;
+  int sgi = 0;
+  for (int k = 1; k < EMOASR_MAX_SEGMENTS; ++k) sgi += (k < plan.nseg && (int)blockIdx.x >= plan.wg0[k]) ? 1 : 0;
+  int w = blockIdx.x - plan.wg0[sgi];
+  if (a_in.nseg > 1) {
     const SegRef g = seg_ref(a_in, sgi);
     seg_apply<T>(a, g);
     ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
     ws.dsq = (T*)ws.dsq + g.row * a.H * ws.ldds;
-    bchunk = (a.B + nchunk - 1) / nchunk;
   }
-  const int r0 = blk.x * (32 * RT), h = blk.y;
-  if (r0 >= 2 * a.Tq - 1) return;
-  const int b_lo = zc * bchunk, b_hi = min(a.B, b_lo + bchunk);
-  const int nit = (a.Tq + 31) / 32;
-  T* qs = reinterpret_cast<T*>(smem + wave * QS_BYTES);
-  f32x16 acc[RT][2];
+  const int nt = (a.Tq + 31) / 32, ndiag = 2 * nt - 1;
+  const int chunk = w % plan.nch; w /= plan.nch;
+  const int dgi = w % ndiag, h = w / ndiag;
+  const int dg = dgi - (nt - 1);                       // j0 = i0 + 32 dg
+  const int len = nt - (dg < 0 ? -dg : dg), t_lo = dg < 0 ? -dg : 0;   // tiles of the diagonal: i0 = 32 (t_lo + k), k < len
+  const int bper = (a.B + plan.nch - 1) / plan.nch, b_lo = chunk * bper, b_hi = min(a.B, b_lo + bper);
+  const int nitem = (b_hi - b_lo) * len;
+  T* dss = reinterpret_cast<T*>(smem + wave * WAVE_BYTES);
+  T* qs = reinterpret_cast<T*>(smem + wave * WAVE_BYTES + DS_BYTES);
+  // the wings: written once
+  for (int v = lane; v < 32 * 9; v += 64) {   // per row: columns [0,32) and [64,104) = 4 + 5 pieces of 8
+    const int row = v / 9, pc = v % 9;
+    Vec16<T> z; z.zero();
+    store16(dss + row * LDS_ + (pc < 4 ? 8 * pc : 64 + 8 * (pc - 4)), z);
+  }
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int t = 0; t < RT; ++t) { zero16(acc[t][0]); zero16(acc[t][1]); }
-  int item = wave;
-  for (int b = b_lo; b < b_hi; ++b) {
+  for (int t = 0; t < 2; ++t) { zero16(acc[t][0]); zero16(acc[t][1]); }
+  const long ldqu2 = ws.ldqu * 2, ldds2 = ws.ldds * 2;
+  Vec16<T> xs[2], xq[4];
+  auto fetch = [&](const int item) {
+    const bool on = item < nitem;
+    const int bo = on ? item / len : 0, k = item - bo * len, b = b_lo + bo;
+    const int i0 = 32 * (t_lo + k), j0 = i0 + 32 * dg;
     const int klen = a.klens ? min(a.klens[b], a.Tk) : a.Tk;
-    const __amdgpu_buffer_rsrc_t rsS = make_rsrc((const T*)ws.dsq + ((long)b * a.H + h) * a.Tq * ws.ldds);
-    const __amdgpu_buffer_rsrc_t rsQ = make_rsrc((const T*)ws.qv + (long)b * a.Tq * ws.ldqu + (long)h * DK);
-    for (; item < nit; item += 4) {
-      const int i0 = item * 32;
-      const int jmin = i0 - (a.Tq - 1) + r0;  // keys of the block's band: jmin .. jmin + 32 RT + 30
-      if (jmin + 32 * RT + 30 < 0 || jmin >= klen) continue;
-      Vec16<T> xq[QR];
+    const bool live = on && j0 < klen;   // key tiles without a valid key were never written
+    const __amdgpu_buffer_rsrc_t rsS = make_rsrc((const T*)ws.dsq + (((long)b * a.H + h) * a.Tq + i0) * ws.ldds + j0);
+    const __amdgpu_buffer_rsrc_t rsQ = make_rsrc((const T*)ws.qv + ((long)b * a.Tq + i0) * ws.ldqu + (long)h * DK);
 #pragma unroll
-      for (int k = 0; k < QR; ++k) {
-        const int p = lane + 64 * k, row = p / PER_ROW, piece = (p % PER_ROW) * VEC;
-        xq[k] = buf_load16<T>(rsQ, i0 + row < a.Tq ? (unsigned)(((i0 + row) * (int)ws.ldqu + piece) * (int)sizeof(T)) : EMO_OOB);
-      }
-      // element (i, r) of the band sits at dS[i][j = i - (Tq-1) + r]: element offset i * (ldds + 1) + r - (Tq-1)
-      typename M_::Frag fa[RT][2];
+    for (int q = 0; q < 2; ++q) {   // dS tile: 32 rows x 4 pieces
+      const int p = lane + 64 * q, row = p >> 2, pc = p & 3;
+      xs[q] = buf_load16<T>(rsS, (live && i0 + row < a.Tq) ? (unsigned)(row * ldds2 + 16 * pc) : EMO_OOB);
+    }
 #pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        const int r = r0 + 32 * t + il;
-        const int base = (i0 + 8 * hh) * ((int)ws.ldds + 1) + r - (a.Tq - 1);
+    for (int q = 0; q < 4; ++q) {   // (Q+v) tile: 32 rows x 8 pieces
+      const int p = lane + 64 * q, row = p >> 3, pc = p & 7;
+      xq[q] = buf_load16<T>(rsQ, (live && i0 + row < a.Tq) ? (unsigned)(row * ldqu2 + 16 * pc) : EMO_OOB);
+    }
+  };
+  // per-lane base of the skewed reads: element e of k-step ks of table tile t is dS[i = 16 ks + 8 hh + e][jl = 32 t + il + i - 31],
+  // stored at column 32 + jl
+  const T* gbase = dss + (8 * hh) * (LDS_ + 1) + il + 1;
+  fetch(wave);
+  for (int item = wave; item < nitem; item += 4) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+    for (int q = 0; q < 2; ++q) {
+      const int p = lane + 64 * q;
+      store16(dss + (p >> 2) * LDS_ + 32 + 8 * (p & 3), xs[q]);
+    }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int i = i0 + 16 * ks + 8 * hh + e;
-            const int j = i - (a.Tq - 1) + r;
-            const bool ok = r < 2 * a.Tq - 1 && i < a.Tq && j >= 0 && j < klen;
-            const float v = buf_load_f32<T>(rsS, ok ? (unsigned)((base + (16 * ks + e) * ((int)ws.ldds + 1)) * (int)sizeof(T)) : EMO_OOB);
-            if constexpr (sizeof(T) == 2) fa[t][ks][e] = (bf16)v;
-          }
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int p = lane + 64 * q;
+      store16(qs + (p >> 3) * LD + 8 * (p & 7), xq[q]);
+    }
+    fetch(item + 4);
+    __builtin_amdgcn_wave_barrier();
+    typename M_::Frag fa[2][2];
 #pragma unroll
-      for (int k = 0; k < QR; ++k) {
-        const int p = lane + 64 * k;
-        store16(qs + (p / PER_ROW) * LD + (p % PER_ROW) * VEC, xq[k]);
-      }
-      __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const typename M_::Frag fb = M_::template load_km<TR>(qs, LD, 16 * ks, 32 * dt, lane);
+        for (int e = 0; e < 8; ++e) fa[t][ks][e] = gbase[(16 * ks + e) * (LDS_ + 1) + 32 * t];
 #pragma unroll
-          for (int t = 0; t < RT; ++t) acc[t][dt] = M_::mma(fa[t][ks], fb, acc[t][dt]);
-        }
-      __builtin_amdgcn_wave_barrier();
-    }
-    item -= nit;
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const typename M_::Frag fb = M_::template load_km<TR>(qs, LD, 16 * ks, 32 * dt, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t][dt] = M_::mma(fa[t][ks], fb, acc[t][dt]);
+      }
+    __builtin_amdgcn_wave_barrier();
   }
-  __syncthreads();
+  const int rbase = a.Tq - 32 + 32 * dg;
   float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int t = 0; t < RT; ++t)
+  for (int t = 0; t < 2; ++t) {
+    __syncthreads();
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int rg = 0; rg < 16; ++rg) red[(((wave * RT + t) * 2 + dt) * 16 + rg) * 64 + lane] = acc[t][dt][rg];
-  __syncthreads();
-  // thread -> (tile, dt, reg, lane) of the summed tiles: RT * 2048 values, RT * 8 per thread
+      for (int rg = 0; rg < 16; ++rg) red[((wave * 2 + dt) * 16 + rg) * 64 + lane] = acc[t][dt][rg];
+    __syncthreads();
 #pragma unroll
-  for (int k = 0; k < RT * 8; ++k) {
-    const int idx = threadIdx.x + 256 * k, ln = idx & 63, rg = (idx >> 6) & 15, dt = (idx >> 10) & 1, t = idx >> 11;
-    float v = 0.f;
+    for (int k = 0; k < 8; ++k) {   // 2048 values of the tile, 8 per thread
+      const int idx = threadIdx.x + 256 * k, ln = idx & 63, rg = (idx >> 6) & 15, dt = idx >> 10;
+      float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += red[(((w * RT + t) * 2 + dt) * 16 + rg) * 64 + ln];
-    const int row = r0 + 32 * t + c_row(rg, ln);
-    if (row < 2 * a.Tq - 1) atomicAdd(&a.dpos[(long)row * (a.H * DK) + h * DK + 32 * dt + (ln & 31)], v);
+      for (int wv = 0; wv < 4; ++wv) v += red[((wv * 2 + dt) * 16 + rg) * 64 + ln];
+      const int row = rbase + 32 * t + c_row(rg, ln);
+      if (row >= 0 && row < 2 * a.Tq - 1 && nitem > 0) atomicAdd(&a.dpos[(long)row * (a.H * DK) + h * DK + 32 * dt + (ln & 31)], v);
+    }
   }
 }
 
@@ -1968,9 +2058,11 @@ template <typename T, int FW> struct SplitCfg {
   static constexpr int LD = AttnCfg<T>::LD;
   static constexpr int BAND_ROWS = 32 * FW + 32;
   static constexpr int LDG = 72;                     // dG image row stride ([32 queries][64 band columns] + padding)
-  static constexpr int GS_BYTES = 64 * 32 * 4;       // per wave: the f32 skew tile (the Q pass's dG image reuses it)
+  static constexpr int LDGS = 68;                    // f32 skew tile G[query][band column] row stride (Q pass; see attn_fwd_kernel)
+  static constexpr int GS_BYTES = 32 * LDGS * 4;     // per wave: the f32 skew tile (the Q pass's dG image reuses it)
   static constexpr int ROWC_BYTES = 64 * 4 + FW * 32 * 4;   // KV pass: lse * log2(e), delta and the waves' keep-mask words of the step's 32 queries
-  static constexpr int kv_rows(bool rel) { return rel ? 96 + BAND_ROWS : 64; }   // Q+u, Q+v, dO, band | Q, dO
+  static constexpr int RING_BLOCKS = FW + 2;         // KV pass: the band as a ring of 32-row blocks (FW + 1 in use, one being refilled)
+  static constexpr int kv_rows(bool rel) { return rel ? 96 + 32 * RING_BLOCKS : 64; }   // Q+u, Q+v, dO, band ring | Q, dO
   static constexpr int q_rows(bool rel) { return rel ? 64 + BAND_ROWS : 64; }    // K, V, band | K, V
   static constexpr int kv_stage_bytes(bool rel) { return kv_rows(rel) * LD * (int)sizeof(T) + ROWC_BYTES; }
   static constexpr int q_stage_bytes(bool rel) { return q_rows(rel) * LD * (int)sizeof(T); }
@@ -2018,15 +2110,25 @@ __global__ __launch_bounds__(1024) void attn_dropmask_kernel(const emoasr_attn_t
   mask[(row * a_in.H + h) * nw + w] = bits;
 }
 
+#ifndef EMO_KV_DBG
+#define EMO_KV_DBG 0   // timing ablations of attn_bwd_kv_kernel, build variants only (results are then wrong): 1 no band loads, 2 no
+#endif                 // lane rotation, 4 no query-side loads.  (As a kernel ARGUMENT -- rounds 4-5 -- every use was a scalar branch:
+                       // each of the 32 rotations of a step sat in a basic block of its own.)
 template <typename T, bool TR, bool REL, int FW>
-__global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int nt, const int dbg) {
+__global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int nt) {
+  constexpr int dbg = EMO_KV_DBG;
   using M_ = Mma<T>;
   using C_ = SplitCfg<T, FW>;
   constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = C_::LD;
   constexpr int VEC = 16 / sizeof(T), PER_ROW = DK / VEC;
   constexpr int NTHR = 64 * FW;
-  constexpr int NROWS = C_::kv_rows(REL), NPIECE = NROWS * PER_ROW, PPT = NPIECE / NTHR;
-  static_assert(NPIECE % NTHR == 0, "staging pieces must divide evenly");
+  constexpr int NROWS = C_::kv_rows(REL);
+  // pieces a thread stages per step: the 32-row tiles Q+u, (Q+v,) dO and -- relative positions -- ONE new 32-row block of the band
+  // (round 6: the union of the waves' bands moves down by 32 rows per step, so 128 of its 160 rows are already in LDS; the band is a
+  // ring of FW + 2 blocks, the new block lands in the slot no wave reads this step.  20 KB of the 32 KB a step fetched were
+  // re-fetched band rows, and the fetch + stash phases were two thirds of a step: profiles/r06_attn_phases.txt)
+  constexpr int PPT = (REL ? 3 : 2) + (REL ? 1 : 0), NRING = C_::RING_BLOCKS;
+  static_assert(NTHR / PER_ROW == 32, "one piece per thread covers one 32-row tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, hh = lane >> 5;
   emoasr_attn_t a = a_in;
@@ -2065,8 +2167,13 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   const long ho = (long)h * DK;
   const T* qu_base = (const T*)ws.qu + (long)b * a.Tq * ws.ldqu + ho;
   const T* qv_base = REL ? (const T*)ws.qv + (long)b * a.Tq * ws.ldqu + ho : qu_base;
-  const __amdgpu_buffer_rsrc_t rsQu = make_rsrc(qu_base), rsQv = make_rsrc(qv_base), rsDo = make_rsrc(hp.dout),
-                               rsP = make_rsrc(REL ? hp.pos : hp.dout);
+  // descriptors sized to the valid rows (queries < Tq, table rows < 2 Tq - 1): a row guard is the descriptor's bounds check, a
+  // fetch is PPT loads at lane-constant offsets + a multiple of the row stride (see attn_fwd_kernel)
+  const unsigned qstride = (unsigned)ws.ldqu * 2u, ostride = (unsigned)a.ldo * 2u, pstride = (unsigned)a.ldp * 2u;
+  const unsigned qbytes = (unsigned)(a.Tq - 1) * qstride + DK * 2u;
+  const __amdgpu_buffer_rsrc_t rsQu = make_rsrc_n(qu_base, qbytes), rsQv = make_rsrc_n(qv_base, qbytes),
+                               rsDo = make_rsrc_n(hp.dout, (unsigned)(a.Tq - 1) * ostride + DK * 2u),
+                               rsP = make_rsrc_n(REL ? hp.pos : hp.dout, REL ? (unsigned)(2 * a.Tq - 2) * pstride + DK * 2u : 0u);
   const int nstep = (a.Tq + 31) / 32;
 
   // ---- one-step-ahead operand fetch (whole block): registers now, LDS between the step's two barriers ------------------
@@ -2078,45 +2185,50 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   bool pre_ok = false;
   unsigned pre_mask = 0xFFFFFFFFu;
   const bool has_mask = ws.mask != nullptr;
-  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(hp.lse), rsD = make_rsrc(hp.delta), rsM = make_rsrc(ws.mask);
+  const __amdgpu_buffer_rsrc_t rsL = make_rsrc_n(hp.lse, (unsigned)a.Tq * 4u), rsD = make_rsrc_n(hp.delta, (unsigned)a.Tq * 4u),
+                               rsM = make_rsrc(ws.mask);
   static_assert(NTHR >= 32 * FW, "one mask word per thread");
+  const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
+  const unsigned q_lane = (unsigned)trow * qstride + (unsigned)piece * 2u, o_lane = (unsigned)trow * ostride + (unsigned)piece * 2u;
+  const unsigned p_lane = (unsigned)((a.Tq - 32 + jblk + trow) * (int)pstride) + (unsigned)piece * 2u;   // band row t of step 0
   auto fetch = [&](const int step) {
     const int i0 = step * 32;
-    const bool on = step < nstep;
-    const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
     if (wave == 0) {
-      pre_ok = on && i0 + il < a.Tq;
-      const unsigned o = pre_ok ? (unsigned)((i0 + il) * 4) : EMO_OOB;
-      pre_lse = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsL, o, 0, 0));
-      pre_del = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, o, 0, 0));
+      pre_ok = i0 + il < a.Tq;
+      pre_lse = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsL, (unsigned)(i0 + il) * 4u, 0, 0));
+      pre_del = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, (unsigned)(i0 + il) * 4u, 0, 0));
     }
     if (has_mask && tid < 32 * FW) {   // thread (wave slot tid >> 5, query tid & 31): word of key tile jblk / 32 + (tid >> 5)
       const int i = i0 + (tid & 31), w = jblk / 32 + (tid >> 5);
-      const bool ok = on && i < a.Tq && w < ws.mask_nw;
+      const bool ok = i < a.Tq && w < ws.mask_nw;
       pre_mask = __builtin_amdgcn_raw_buffer_load_b32(rsM, ok ? (unsigned)(((((long)b * a.Tq + i) * a.H + h) * ws.mask_nw + w) * 4) : EMO_OOB, 0, 0);
     }
+    const unsigned qo = q_lane + (unsigned)i0 * qstride, oo = o_lane + (unsigned)i0 * ostride;
+    const unsigned po = p_lane - (unsigned)i0 * pstride;   // (wraps below row 0: out of range)
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
       const int srow = p * RPP;
       if (srow < 32 * NMAT) {
-        const int mat = srow / 32, i = i0 + srow % 32 + trow;
-        const bool ok = on && i < a.Tq && !(dbg & 4);
-        if (mat == 0) pre[p] = buf_load16<T>(rsQu, ok ? (unsigned)(((long)i * ws.ldqu + piece) * sizeof(T)) : EMO_OOB);
-        else if (REL && mat == 1) pre[p] = buf_load16<T>(rsQv, ok ? (unsigned)(((long)i * ws.ldqu + piece) * sizeof(T)) : EMO_OOB);
-        else pre[p] = buf_load16<T>(rsDo, ok ? (unsigned)(((long)i * a.ldo + piece) * sizeof(T)) : EMO_OOB);
+        const int mat = srow / 32;
+        const unsigned ro = (unsigned)(srow % 32);
+        if (dbg & 4) pre[p].zero();
+        else if (mat == 0) pre[p] = buf_load16<T>(rsQu, qo + ro * qstride);
+        else if (REL && mat == 1) pre[p] = buf_load16<T>(rsQv, qo + ro * qstride);
+        else pre[p] = buf_load16<T>(rsDo, oo + ro * ostride);
       } else {
-        // the union of the waves' position bands: rows r = Tq - 32 - i0 + jblk + t, t in [0, 32 FW + 32)
-        const int r = a.Tq - 32 - i0 + jblk + (srow - 32 * NMAT) + trow;
-        const bool ok = on && r >= 0 && r < 2 * a.Tq - 1 && !(dbg & 1);
-        pre[p] = buf_load16<T>(rsP, ok ? (unsigned)(((long)r * a.ldp + piece) * sizeof(T)) : EMO_OOB);
+        // the band block this step adds: rows Tq - 32 - i0 + jblk + [0, 32) (block -step of the ring)
+        if (dbg & 1) pre[p].zero();
+        else pre[p] = buf_load16<T>(rsP, po);
       }
     }
   };
-  auto stash = [&]() {
+  T* ring = stage0 + 96 * LD;   // (REL) blocks of 32 band rows: block n = rows Tq - 32 + jblk + 32 n + [0, 32) in slot n mod NRING
+  auto ring_slot = [&](const int n) { return ((n % NRING) + NRING) % NRING; };
+  auto stash = [&](const int step) {   // the tiles of `step` (fetched one step earlier)
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
-      const int pid = tid + NTHR * p;
-      store16(stage0 + (pid / PER_ROW) * LD + (pid % PER_ROW) * VEC, pre[p]);
+      if (p < NMAT) store16(stage0 + (32 * p + trow) * LD + piece, pre[p]);
+      else store16(ring + (ring_slot(-step) * 32 + trow) * LD + piece, pre[p]);
     }
     if (wave == 0 && hh == 0) {
       // p = exp2(c_exp * s - lse * log2 e): padding queries and rows without a valid key (lse = -inf) get +inf -> p = 0
@@ -2145,8 +2257,13 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   f32x16 dk[2], dv[2];
   zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
   float csum = 0.f;  // sum over this lane's queries of dS[:, key kj]
+  if constexpr (REL) {   // blocks 1 .. FW of step 0 (block 0 comes with fetch(0))
+#pragma unroll
+    for (int n = 1; n <= FW; ++n)
+      store16(ring + (n * 32 + trow) * LD + piece, (dbg & 1) ? Vec16<T>{} : buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride));
+  }
   fetch(0);
-  stash();
+  stash(0);
   fetch(1);
   __syncthreads();
   const bool kvalid = kj < hp.klen;
@@ -2161,7 +2278,9 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
     const T* Qus = stage0;
     const T* Qvs = stage0 + 32 * LD;
     const T* dOs = stage0 + (REL ? 64 : 32) * LD;
-    const T* Bs = stage0 + (96 + 32 * wave) * LD;  // this wave's 64 band rows (REL)
+    // this wave's 64 band rows (REL): blocks wave - step and wave - step + 1 of the ring
+    const T* Bs0 = ring + ring_slot(wave - step) * 32 * LD;
+    const T* Bs1 = ring + ring_slot(wave - step + 1) * 32 * LD;
     EMO_STAMP(0);
     if (live) {
       // (Requesting every LDS operand of a phase ahead of its MFMAs -- 64 fragment registers in flight -- was measured: 373 against
@@ -2182,8 +2301,8 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
           const typename M_::Frag fv = M_::load_kc(Qvs, LD, 0, kk * M_::KSTEP, lane);
-          g0 = M_::mma(fv, M_::load_kc(Bs, LD, 0, kk * M_::KSTEP, lane), g0);
-          g1 = M_::mma(fv, M_::load_kc(Bs + 32 * LD, LD, 0, kk * M_::KSTEP, lane), g1);
+          g0 = M_::mma(fv, M_::load_kc(Bs0, LD, 0, kk * M_::KSTEP, lane), g0);
+          g1 = M_::mma(fv, M_::load_kc(Bs1, LD, 0, kk * M_::KSTEP, lane), g1);
         }
         EMO_STAMP(2);
 #pragma unroll
@@ -2230,7 +2349,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
     EMO_STAMP(5);
     lds_barrier();   // every wave has read the stage
     EMO_STAMP(6);
-    stash();         // tiles of step + 1 (fetched during the previous step)
+    stash(step + 1);   // tiles of step + 1 (fetched during the previous step)
     EMO_STAMP(7);
     fetch(step + 2);
     EMO_STAMP(8);
@@ -2285,36 +2404,38 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
 
   T* stage0 = reinterpret_cast<T*>(smem);
   char* mine = smem + C_::q_stage_bytes(REL) + wave * C_::wave_bytes(REL);
-  float* Gs = reinterpret_cast<float*>(mine);   // [64 band rows][32 queries] f32 ...
+  float* Gs = reinterpret_cast<float*>(mine);   // G[32 queries][LDGS band columns] f32 (16-byte stores of four band columns) ...
+  constexpr int LDGS = C_::LDGS;
   T* img_g = reinterpret_cast<T*>(mine);        // ... then dG[query][band column] ([32][LDG]), read back k-contiguous
 
   const long ho = (long)h * DK;
   const T* qu_base = (const T*)ws.qu + (long)b * a.Tq * ws.ldqu + ho;
   const T* qv_base = REL ? (const T*)ws.qv + (long)b * a.Tq * ws.ldqu + ho : qu_base;
-  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k), rsV = make_rsrc(hp.v), rsP = make_rsrc(REL ? hp.pos : hp.k);
+  // descriptors sized to the valid rows (keys < Tk, table rows < 2 Tq - 1): see attn_fwd_kernel
+  const unsigned kstride = (unsigned)a.ldk * 2u, vstride = (unsigned)a.ldv * 2u, pstride = (unsigned)a.ldp * 2u;
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc_n(hp.k, (unsigned)(a.Tk - 1) * kstride + DK * 2u),
+                               rsV = make_rsrc_n(hp.v, (unsigned)(a.Tk - 1) * vstride + DK * 2u),
+                               rsP = make_rsrc_n(REL ? hp.pos : hp.k, REL ? (unsigned)(2 * a.Tq - 2) * pstride + DK * 2u : 0u);
   const int nstep = (hp.klen + 31) / 32;   // key tiles with at least one valid key
 
   constexpr int RPP = NTHR / PER_ROW;
   static_assert(32 % RPP == 0, "a piece index must stay inside one 32-row operand tile");
   Vec16<T> pre[PPT];
+  const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
+  const unsigned k_lane = (unsigned)trow * kstride + (unsigned)piece * 2u, v_lane = (unsigned)trow * vstride + (unsigned)piece * 2u;
+  // band rows of the block's 32 FW queries against key tile j0: r = Tq - 32 FW - iblk + j0 + t, t in [0, 32 FW + 32)
+  const unsigned p_lane = (unsigned)((a.Tq - 32 * FW - iblk + trow) * (int)pstride) + (unsigned)piece * 2u;
   auto fetch = [&](const int step) {
     const int j0 = step * 32;
-    const bool on = step < nstep;
-    const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
+    const unsigned dead = step < nstep ? 0u : 0x80000000u;   // behind the last key tile: nothing is read
+    const unsigned ko = (k_lane + (unsigned)j0 * kstride) | dead, vo = (v_lane + (unsigned)j0 * vstride) | dead;
+    const unsigned po = (p_lane + (unsigned)j0 * pstride) | dead;
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
       const int srow = p * RPP;
-      if (srow < 64) {
-        const int j = j0 + srow % 32 + trow;
-        const bool ok = on && j < a.Tk;
-        if (srow < 32) pre[p] = buf_load16<T>(rsK, ok ? (unsigned)(((long)j * a.ldk + piece) * sizeof(T)) : EMO_OOB);
-        else pre[p] = buf_load16<T>(rsV, ok ? (unsigned)(((long)j * a.ldv + piece) * sizeof(T)) : EMO_OOB);
-      } else {
-        // band rows of the block's 32 FW queries against this key tile: r = Tq - 32 FW - iblk + j0 + t, t in [0, 32 FW + 32)
-        const int r = a.Tq - 32 * FW - iblk + j0 + (srow - 64) + trow;
-        const bool ok = on && r >= 0 && r < 2 * a.Tq - 1;
-        pre[p] = buf_load16<T>(rsP, ok ? (unsigned)(((long)r * a.ldp + piece) * sizeof(T)) : EMO_OOB);
-      }
+      if (srow < 32) pre[p] = buf_load16<T>(rsK, ko + (unsigned)srow * kstride);
+      else if (srow < 64) pre[p] = buf_load16<T>(rsV, vo + (unsigned)(srow - 32) * vstride);
+      else pre[p] = buf_load16<T>(rsP, po + (unsigned)(srow - 64) * pstride);
     }
   };
   auto stash = [&]() {
@@ -2377,9 +2498,9 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
           g1 = M_::mma(M_::load_kc(Bs + 32 * LD, LD, 0, kk * M_::KSTEP, lane), fqv[kk], g1);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          Gs[c_row(r, lane) * 32 + il] = g0[r];
-          Gs[(32 + c_row(r, lane)) * 32 + il] = g1[r];
+        for (int q = 0; q < 4; ++q) {   // accumulator registers 4 q .. 4 q + 3 are band columns 8 q + 4 hh + 0 .. 3 of query il
+          *reinterpret_cast<f32x4*>(Gs + il * LDGS + 8 * q + 4 * hh) = f32x4{g0[4 * q], g0[4 * q + 1], g0[4 * q + 2], g0[4 * q + 3]};
+          *reinterpret_cast<f32x4*>(Gs + il * LDGS + 32 + 8 * q + 4 * hh) = f32x4{g1[4 * q], g1[4 * q + 1], g1[4 * q + 2], g1[4 * q + 3]};
         }
       }
 #pragma unroll
@@ -2392,7 +2513,14 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
         __builtin_amdgcn_wave_barrier();
         // element (key jl, query il) sits in band column c = 31 - il + jl
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] += Gs[(31 - il + c_row(r, lane)) * 32 + il];
+        for (int r = 0; r < 16; ++r) s[r] += Gs[il * (LDGS - 1) + 31 + c_row(r, lane)];   // G[il][31 - il + key]
+        __builtin_amdgcn_wave_barrier();
+        // the dG image takes the skew tile's place: cleared with 16-byte stores, the tile's 32 x 32 entries written below
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int v = lane + 64 * q;   // 32 rows x 8 pieces of 8 columns
+          *reinterpret_cast<u32x4*>(img_g + (v >> 3) * LDG + 8 * (v & 7)) = u32x4{0u, 0u, 0u, 0u};
+        }
         __builtin_amdgcn_wave_barrier();
       }
       EMO_STAMP(2);
@@ -2411,11 +2539,8 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
           const bf16 dsv = (bf16)(p * (dp[r] * m - del_q) * a.scale);
           df[g >> 1][4 * (g & 1) + e] = dsv;
           if constexpr (REL) {
-            // dG[query il][band column c = key - il + 31]; the image shares its LDS with the f32 skew tile, so the column no key
-            // of this tile maps to ((c + 32) mod 64: the two sets partition the row) is cleared alongside
-            const int c = c_row(r, lane) + 31 - il;
-            img_g[il * LDG + c] = dsv;
-            img_g[il * LDG + ((c + 32) & 63)] = (bf16)0.f;
+            // dG[query il][band column c = key - il + 31] (the image was cleared after the skew read)
+            img_g[il * LDG + c_row(r, lane) + 31 - il] = dsv;
           }
         }
       }
@@ -2546,7 +2671,6 @@ int set_smem(K kernel, int bytes) {
 }
 
 int g_tr = 1;
-int g_kv_dbg = 0;     // option "attn_kv_dbg": timing ablations of attn_bwd_kv_kernel (results are then wrong)
 int g_bwd_split = 1;  // option "attn_bwd_split": the two-pass backward (attn_bwd_kv_kernel + attn_bwd_q_kernel); 0 = the single-pass kernel
 int g_fused_fw = 0;  // key tiles per workgroup of the single-pass backward (0 = by grid size; emoasr_set_option "attn_fw")
 
@@ -2584,7 +2708,7 @@ int check_args(const emoasr_attn_t* a, int dtype) {
   return 0;
 }
 
-// TK: the kernels' element type -- T, or f32s for T = float under option "f32_split" (same memory, split-bf16 products)
+// TK: the kernels' element type -- T, or f32s for T = float under dtype EMO_F32X3 (same memory, split-bf16 products)
 template <typename T, typename TK = T>
 int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
   emoasr_attn_t a = a_in;
@@ -2603,7 +2727,7 @@ int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
   const bool split = g_fwd_split && a.nseg <= 1 && !a.st && (long)cdiv(a.Tq, 32) * a.H * a.B <= 2L * n_cu;
   const int ks = split ? 4 : 1;
   const int nw = split ? 4 : (g_fwd_waves ? g_fwd_waves : (a.nseg > 1 ? 1 : 4));
-  const int smem = nw * (64 * 32 * 4 + 32 * LD * (int)sizeof(TK));
+  const int smem = nw * fwd_wave_bytes<TK>();
   dim3 grid(cdiv(a.Tq, split ? 32 : 32 * nw), a.H, a.B);   // (stacked micro-batches: Tq = the longest segment, B = all utterances)
   // stacked launches: 1-D, the query tiles of one (head, utterance) on one XCD (attn_block)
   const int nt = (g_attn_xcd && a.nseg > 1) ? (int)grid.x : 0;
@@ -2824,6 +2948,24 @@ int launch_dropmask(const emoasr_attn_t& a, unsigned* maskbuf, int nw, long nrow
   return 0;
 }
 
+// the position-table gradient of one attention backward (attn_bwd_dpos3_kernel): one workgroup per (segment, head, tile diagonal,
+// batch chunk); the chunks (<= 4) keep the grid a few rounds deep while a workgroup's one 16 KB flush stays amortised
+template <typename T>
+void launch_dpos3(const emoasr_attn_t& a, const FusedWs& ws, hipStream_t s) {
+  Dpos3Plan pl{};
+  const int nseg = a.nseg > 1 ? a.nseg : 1;
+  int bmin = a.B;
+  for (int k = 0; k < a.nseg && a.nseg > 1; ++k) bmin = std::min(bmin, a.seg_b0[k + 1] - a.seg_b0[k]);
+  pl.nseg = nseg;
+  pl.nch = std::max(1, std::min(4, bmin));
+  for (int k = 0; k < nseg; ++k) {
+    const int T_ = a.nseg > 1 ? a.seg_T[k] : a.Tq, nt = cdiv(T_, 32);
+    pl.wg0[k + 1] = pl.wg0[k] + a.H * (2 * nt - 1) * pl.nch;
+  }
+  if (g_tr) attn_bwd_dpos3_kernel<T, true><<<pl.wg0[nseg], 256, 0, s>>>(a, ws, pl);
+  else attn_bwd_dpos3_kernel<T, false><<<pl.wg0[nseg], 256, 0, s>>>(a, ws, pl);
+}
+
 template <typename T>
 int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStream_t s) {
   emoasr_attn_t a = a_in;
@@ -2833,7 +2975,7 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
   const long nqd = nrows * a.H * DK;
   side_join(s);   // (a table gradient left on the side stream by a caller that never joined: it used this workspace)
   FusedWs ws{};
-  const bool want_mask = g_bwd_split && a.drop_p > 0.f;
+  const bool want_mask = g_bwd_split && a.drop_p > 0.f && !a.keep_mask;
   const FusedLayout lay = fused_layout<T>(a, want_mask);
   EMO_CHECK(lay.total <= bytes, "attn_bwd_fused: workspace too small (%zu < %zu bytes)", bytes, lay.total);
   ws.dq_slab = nqd;
@@ -2849,7 +2991,11 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
     ws.qu = a.q; ws.qv = a.q; ws.ldqu = a.ldq;
   }
   unsigned* maskbuf = nullptr;
-  if (want_mask) {
+  const bool ext_mask = a.keep_mask != nullptr && a.drop_p > 0.f && g_bwd_split;   // (the single-pass kernel hashes inline: same mask)   // the forward's bits (emoasr_attn_dropmask): nothing to hash here
+  if (ext_mask) {
+    ws.mask_nw = a.keep_nw;
+    ws.mask = a.keep_mask;
+  } else if (want_mask) {
     ws.mask_nw = lay.mask_nw;
     maskbuf = reinterpret_cast<unsigned*>(mem + lay.mask);
     ws.mask = maskbuf;
@@ -2897,7 +3043,7 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
   do {                                                                                                              \
     if (set_smem(attn_bwd_kv_kernel<T, TR_, REL_, FW>, SC::kv_smem(REL_))) return 1;                                \
     if (set_smem(attn_bwd_q_kernel<T, TR_, REL_, FW>, SC::q_smem(REL_))) return 1;                                  \
-    attn_bwd_kv_kernel<T, TR_, REL_, FW><<<gk, 64 * FW, SC::kv_smem(REL_), s>>>(a, ws, ntk, g_kv_dbg);                      \
+    attn_bwd_kv_kernel<T, TR_, REL_, FW><<<gk, 64 * FW, SC::kv_smem(REL_), s>>>(a, ws, ntk);                      \
     if (ws.stamp) ws.stamp += 64 * 13;                                                                              \
     attn_bwd_q_kernel<T, TR_, REL_, FW><<<gq, 64 * FW, SC::q_smem(REL_), s>>>(a, ws, ntq);                          \
   } while (0)
@@ -2914,15 +3060,8 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
       st2 = g_side;
     }
     if (rel && a.dpos) {
-      int bmin = a.B;
-      for (int k = 0; k < a.nseg && a.nseg > 1; ++k) bmin = std::min(bmin, a.seg_b0[k + 1] - a.seg_b0[k]);
-      const int nchunk = bmin < 8 ? bmin : 8;
-      dim3 g2(cdiv(2 * a.Tq - 1, 64), a.H, nchunk * (a.nseg > 1 ? a.nseg : 1));
-      const int nt2 = (g_attn_xcd && a.nseg > 1) ? (int)g2.x : 0;
-      if (nt2) g2 = dim3(8 * cdiv((int)(g2.y * g2.z), 8) * nt2, 1, 1);
       emo_timer_begin(EMO_TIMER_ATTN_BWD_DPOS, st2);
-      if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, st2>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
-      else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, st2>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
+      launch_dpos3<T>(a, ws, st2);
       emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, st2);
     }
 #ifdef EMO_ATTN_STAMP
@@ -2976,16 +3115,8 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
     if (fw == 2) EMO_FUSED_LAUNCH(true, 2); else EMO_FUSED_LAUNCH(true, 4);
     emo_timer_end(EMO_TIMER_ATTN_BWD_MAIN, s);
     if (a.dpos) {
-      // batch chunks per table tile (stacked micro-batches: per segment, each with its own table: grid.z = segments x chunks)
-      int bmin = a.B;
-      for (int k = 0; k < a.nseg && a.nseg > 1; ++k) bmin = std::min(bmin, a.seg_b0[k + 1] - a.seg_b0[k]);
-      const int nchunk = bmin < 8 ? bmin : 8;
-      dim3 g2(cdiv(2 * a.Tq - 1, 64), a.H, nchunk * (a.nseg > 1 ? a.nseg : 1));
-      const int nt2 = (g_attn_xcd && a.nseg > 1) ? (int)g2.x : 0;
-      if (nt2) g2 = dim3(8 * cdiv((int)(g2.y * g2.z), 8) * nt2, 1, 1);
       emo_timer_begin(EMO_TIMER_ATTN_BWD_DPOS, s);
-      if (g_tr) attn_bwd_dpos2_kernel<T, true><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
-      else attn_bwd_dpos2_kernel<T, false><<<g2, 256, 0, s>>>(a, ws, cdiv(a.B, nchunk), nchunk, nt2);
+      launch_dpos3<T>(a, ws, s);
       emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, s);
     }
   } else {
@@ -3043,7 +3174,7 @@ int emo_attn_bwd_prelaunch(int dtype, const emoasr_attn_t* a_in, void* ws, size_
   if (dtype != EMO_BF16 || !g_bwd_split || !side_ready()) return 0;
   emoasr_attn_t a = *a_in;
   fill_seg_order(a);
-  const bool rel = a.pos != nullptr, want_mask = a.drop_p > 0.f;
+  const bool rel = a.pos != nullptr, want_mask = a.drop_p > 0.f && !a.keep_mask;
   if (!rel && !want_mask) return 0;
   const FusedLayout lay = fused_layout<bf16>(a, want_mask);
   if (lay.total > ws_bytes) return 0;
@@ -3070,13 +3201,55 @@ void emo_attn_set_fwd_split(int v) { g_fwd_split = v; }
 void emo_attn_set_xcd(int v) { g_attn_xcd = v; }
 void emo_attn_set_fwd_waves(int v) { g_fwd_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
 void emo_attn_set_bwd_split(int v) { g_bwd_split = v ? 1 : 0; }
-void emo_attn_set_kv_dbg(int v) { g_kv_dbg = v; }
 void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }
+
+extern "C" long emoasr_attn_dropmask_words(int Tk) { return cdiv(Tk, 32); }
+// The keep mask of one attention launch as bits, for its forward AND its backward (emoasr_attn_t::keep_mask).  When the library has
+// its side stream (option "attn_side") the hashing runs THERE, forked from `stream` at this point, and the first emoasr_attn_fwd
+// given this mask waits for it: called at the top of a layer (csrc/layer.hip) the 50-60 us of integer hashing run under the
+// macaron feed-forward block's products.
+namespace {
+bool g_fmask_pending = false;   // a mask is being hashed on the side stream: the next forward given a mask waits for g_ev_fmask
+hipEvent_t g_ev_fmask = nullptr;
+}
+extern "C" int emoasr_attn_dropmask(int dtype, const emoasr_attn_t* a_in, unsigned* mask, int nw, void* stream) {
+  EMO_CHECK(a_in && mask, "attn_dropmask: missing arguments");
+  EMO_CHECK(nw >= cdiv(a_in->Tk, 32), "attn_dropmask: %d words per row for %d keys", nw, a_in->Tk);
+  if (a_in->drop_p <= 0.f || a_in->B == 0 || a_in->Tq == 0) return 0;
+  emoasr_attn_t a = *a_in;
+  fill_seg_order(a);
+  const long nrows = a.nseg > 1 ? a.seg_row[a.nseg] : (long)a.B * a.Tq;
+  hipStream_t s = (hipStream_t)stream, st = s;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  hipStreamIsCapturing(s, &cap);
+  const bool side = cap == hipStreamCaptureStatusNone && side_ready();
+  if (side) {
+    if (!g_ev_fmask) hipEventCreateWithFlags(&g_ev_fmask, hipEventDisableTiming);
+    hipEventRecord(g_ev_fork, s);
+    hipStreamWaitEvent(g_side, g_ev_fork, 0);
+    st = g_side;
+  }
+  int rc;
+  if (dtype == EMO_BF16) rc = launch_dropmask<bf16>(a, mask, nw, nrows, st);
+  else rc = launch_dropmask<float>(a, mask, nw, nrows, st);
+  if (rc) return 1;
+  if (side) {
+    hipEventRecord(g_ev_fmask, g_side);
+    g_fmask_pending = true;
+  }
+  EMO_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream) {
   if (check_args(a, dtype)) return 1;
   if (a->B == 0 || a->Tq == 0) return 0;
-  if (dtype == EMO_F32 && emo_gemm_f32_split()) return launch_fwd<float, f32s>(*a, (hipStream_t)stream);
+  EMO_CHECK(!a->keep_mask || a->keep_nw >= cdiv(a->Tk, 32), "attn_fwd: keep mask of %d words per row for %d keys", a->keep_nw, a->Tk);
+  if (a->keep_mask && g_fmask_pending) {   // hashed on the side stream (emoasr_attn_dropmask): join; later calls on this stream are behind the wait
+    hipStreamWaitEvent((hipStream_t)stream, g_ev_fmask, 0);
+    g_fmask_pending = false;
+  }
+  if (dtype == EMO_F32X3) return launch_fwd<float, f32s>(*a, (hipStream_t)stream);
   EMO_DISPATCH(dtype, return (launch_fwd<T>(*a, (hipStream_t)stream)));
   return 0;
 }
@@ -3092,9 +3265,9 @@ extern "C" int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream) 
     EMO_CHECK(!a->st || a->ldst >= a->Tq, "attn_bwd: bad st");
   }
   if (a->B == 0 || a->Tq == 0) return 0;
-  // f32 under option "f32_split": the score-recomputing dQ kernel (the training path's: pdT without stored scores) runs its
+  // dtype EMO_F32X3: the score-recomputing dQ kernel (the training path's: pdT without stored scores) runs its
   // products split; the GEMMs behind it (dV, dK, dpos) follow the same option inside gemm.hip
-  if (dtype == EMO_F32 && emo_gemm_f32_split() && a->pdT && !a->st) return launch_bwd_tr<float, true, f32s>(*a, (hipStream_t)stream);
+  if (dtype == EMO_F32X3 && a->pdT && !a->st) return launch_bwd_tr<float, true, f32s>(*a, (hipStream_t)stream);
   EMO_DISPATCH(dtype, {
     if (g_tr) return (launch_bwd_tr<T, true>(*a, (hipStream_t)stream));
     return (launch_bwd_tr<T, false>(*a, (hipStream_t)stream));

@@ -88,6 +88,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFF, 0x00020000);
 }
+// descriptor of exactly `bytes` bytes: every offset past the operand's last valid byte reads zeros BY THE DESCRIPTOR -- row guards
+// need no per-load compare / select at all (negative row indices wrap to huge unsigned offsets: out of range as well)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_n(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
 template <typename T>
 __device__ __forceinline__ Vec16<T> buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
@@ -506,10 +511,15 @@ struct EmoTimerScope {
   ~EmoTimerScope() { emo_timer_end(id, s); }
 };
 
-enum { EMO_F32 = 0, EMO_BF16 = 1 };
+// EMO_F32X3 (round 6): f32 storage, statistics and epilogues exactly as EMO_F32, every matrix product as three bf16 MFMAs over
+// (hi, lo) operand pairs (csrc/gemm.hip SplitCfg, csrc/mma.h Mma<f32s>).  The mode travels in the dtype argument of every call --
+// there is no library state behind it (rounds 4-5: a process-wide option) -- and every entry point that is not a product treats it
+// as EMO_F32 (EMO_DISPATCH; element size 4).
+enum { EMO_F32 = 0, EMO_BF16 = 1, EMO_F32X3 = 2 };
+__host__ __device__ inline bool emo_is_f32(int dtype) { return dtype == EMO_F32 || dtype == EMO_F32X3; }
 #define EMO_DISPATCH(dtype, ...)                                        \
   do {                                                                  \
-    if ((dtype) == EMO_F32) { typedef float T; __VA_ARGS__; }           \
+    if ((dtype) == EMO_F32 || (dtype) == EMO_F32X3) { typedef float T; __VA_ARGS__; } \
     else if ((dtype) == EMO_BF16) { typedef bf16 T; __VA_ARGS__; }      \
     else { emo_set_error("bad dtype %d", (int)(dtype)); return 1; }     \
   } while (0)

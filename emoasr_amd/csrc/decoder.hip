@@ -483,7 +483,7 @@ extern "C" int emoasr_beam_scores_topk(int dtype, int M, int V, int k, const voi
   if (dtype == EMO_BF16) {
     if (bytes > 60 * 1024) hipFuncSetAttribute((const void*)beam_scores_topk_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     beam_scores_topk_kernel<bf16><<<M, 1024, bytes, (hipStream_t)stream>>>(V, k, (const bf16*)dec, ldd, lm, ldl, mu, vals, idx, lm_at, lm_lds);
-  } else if (dtype == EMO_F32) {
+  } else if (emo_is_f32(dtype)) {
     if (bytes > 60 * 1024) hipFuncSetAttribute((const void*)beam_scores_topk_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     beam_scores_topk_kernel<float><<<M, 1024, bytes, (hipStream_t)stream>>>(V, k, (const float*)dec, ldd, lm, ldl, mu, vals, idx, lm_at, lm_lds);
   } else {

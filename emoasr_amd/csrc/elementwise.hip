@@ -119,6 +119,8 @@ extern "C" int emoasr_strided_copy(int dtype_in, int dtype_out, const void* in, 
     if (dense) dense_copy_kernel<TI, TO><<<ew_grid(n / 8), 256, 0, s>>>((const TI*)in, (TO*)out, n / 8, accumulate); \
     else strided_copy_kernel<TI, TO><<<ew_grid(n), 256, 0, s>>>((const TI*)in, (TO*)out, d1, d2, d3, s0, s1, s2, s3, n, accumulate); \
   } while (0)
+  if (dtype_in == EMO_F32X3) dtype_in = EMO_F32;
+  if (dtype_out == EMO_F32X3) dtype_out = EMO_F32;
   if (dtype_in == EMO_F32 && dtype_out == EMO_F32) SC(float, float);
   else if (dtype_in == EMO_F32 && dtype_out == EMO_BF16) SC(float, bf16);
   else if (dtype_in == EMO_BF16 && dtype_out == EMO_F32) SC(bf16, float);
@@ -175,7 +177,7 @@ extern "C" int emoasr_transpose_cast_batched(int dtype_out, int n, const emoasr_
   }
   G.tile0[n] = tiles;
   if (dtype_out == EMO_BF16) transpose_cast_kernel<bf16><<<tiles, 256, 0, (hipStream_t)stream>>>(G);
-  else if (dtype_out == EMO_F32) transpose_cast_kernel<float><<<tiles, 256, 0, (hipStream_t)stream>>>(G);
+  else if (emo_is_f32(dtype_out)) transpose_cast_kernel<float><<<tiles, 256, 0, (hipStream_t)stream>>>(G);
   else { emo_set_error("transpose_cast_batched: bad dtype"); return 1; }
   EMO_LAUNCH_CHECK();
   return 0;

@@ -66,7 +66,15 @@ int g_tr_read = 1;
 int g_gemm_wholek = 1;   // option "gemm_wholek"
 int g_gemm_tile = 0, g_gemm_kb = 0, g_gemm_xcd = 1, g_tn_group_kb = 0, g_tn_place = 0, g_gemm_wide128 = 0;
 int g_tn_group_blocks = 0;  // override of a grouped TN launch's block budget (emoasr_set_option "tn_group_blocks"; 0 = auto)
-int g_f32_split = 0;        // option "f32_split": f32 products as three bf16 MFMAs over (hi, lo) operand pairs (see SplitCfg)
+// f32 products as three bf16 MFMAs over (hi, lo) operand pairs (see SplitCfg): asked for PER CALL by the dtype code EMO_F32X3.  The
+// entry points of this file note it here for the launch helpers below them (thread-local, for the duration of the call: two engines
+// in different modes on two streams, or an autograd thread, cannot see each other's mode)
+thread_local int t_f32_split = 0;
+struct SplitScope {
+  int prev;
+  explicit SplitScope(int dtype) : prev(t_f32_split) { t_f32_split = dtype == EMO_F32X3 ? 1 : 0; }
+  ~SplitScope() { t_f32_split = prev; }
+};
 int g_split_tile = 0;       // option "split_tile": tile of the split NT / NN products (1 = 128x128 where it fills the chip twice, 2 = 128x64, 3 = 64x64; 0 = rule)
 int g_split_kb = 1;         // option "split_kb": 2 = BK 64 for split reductions of K >= 512
 int g_split_min128 = 512;   // option "split_min128": 128 x 128 split tiles from this many tiles on
@@ -108,7 +116,7 @@ template <typename T, int KB = 1> struct TileCfg {
 // -- 16 significand bits per operand (relative error ~2^-17 per product, the dropped lo . lo term 2^-18) at 16 / 3 times the rate
 // of v_mfma_f32_32x32x2_f32.  The f32 tile is split ONCE per workgroup on its way from the staging registers into LDS (two bf16
 // planes per operand, the bf16 kernel's tile geometry); everything outside the k loop -- loads, epilogue, output -- is the f32
-// kernel's.  Selected per process by emoasr_set_option("f32_split", 1): the engine's throughput mode that meets the 1e-3 bar.
+// kernel's.  Selected per process by the dtype code EMO_F32X3 (include/emoasr_hip.h): the engine's throughput mode that meets the 1e-3 bar.
 template <int KB> struct SplitCfg {
   static constexpr int VEC = 4;                 // floats per 16-byte global vector
   static constexpr int BK = 32 * KB;
@@ -872,22 +880,22 @@ int launch_nt_(const NtArgs& a_in, hipStream_t s, int nz = 1) {
   EMO_LAUNCH_CHECK();
   return 0;
 }
-// f32 with option "f32_split": the split kernels (SP); everything else as before
+// f32 storage with dtype EMO_F32X3: the split kernels (SP); everything else as before
 template <typename T> constexpr bool is_f32 = sizeof(T) == 4;
 template <typename T, int AMODE>
 int launch_nt(const NtArgs& a, hipStream_t s) {
-  if constexpr (is_f32<T>) { if (g_f32_split) return launch_nt_<T, AMODE, false, true, true>(a, s); }
+  if constexpr (is_f32<T>) { if (t_f32_split) return launch_nt_<T, AMODE, false, true, true>(a, s); }
   return launch_nt_<T, AMODE, false, true>(a, s);
 }
 template <typename T>
 int launch_nn(const NtArgs& a, hipStream_t s, int nz = 1) {
-  if constexpr (is_f32<T>) { if (g_f32_split) return launch_nt_<T, 0, true, true, true>(a, s, nz); }
+  if constexpr (is_f32<T>) { if (t_f32_split) return launch_nt_<T, 0, true, true, true>(a, s, nz); }
   return g_tr_read ? launch_nt_<T, 0, true, true>(a, s, nz) : launch_nt_<T, 0, true, false>(a, s, nz);
 }
 
 template <typename T, int BMODE, bool SP = false>
 int launch_tn(TnArgs a, hipStream_t s) {
-  if constexpr (is_f32<T> && !SP) { if (g_f32_split) return launch_tn<T, BMODE, true>(a, s); }
+  if constexpr (is_f32<T> && !SP) { if (t_f32_split) return launch_tn<T, BMODE, true>(a, s); }
   const bool big = (long)cdiv(a.N1, 128) * cdiv(a.N2, 128) >= 32 && a.N1 >= 128 && a.N2 >= 128;
   // BK = 32 with the 128x128 tile (three resident blocks per CU instead of two; see emoasr_gemm_tn_grouped), 64 for long reductions on 64x64
   const int kb = sizeof(T) == 2 ? (g_gemm_kb ? g_gemm_kb : (a.K >= 512 && !big ? 2 : 1)) : 1;
@@ -957,8 +965,6 @@ void emo_gemm_set_wholek(int v) { g_gemm_wholek = v; }
 void emo_gemm_set_tn_place(int v) { g_tn_place = v != 0; }
 void emo_gemm_set_tn_group_kb(int v) { g_tn_group_kb = (v == 1 || v == 2) ? v : 0; }
 void emo_gemm_set_xcd(int v) { g_gemm_xcd = v; }
-void emo_gemm_set_f32_split(int v) { g_f32_split = v ? 1 : 0; }
-int emo_gemm_f32_split() { return g_f32_split; }
 void emo_gemm_set_split_tile(int v) { g_split_tile = (v >= 1 && v <= 3) ? v : 0; }
 void emo_gemm_set_split_kb(int v) { g_split_kb = v == 2 ? 2 : 1; }
 void emo_gemm_set_split_min128(int v) { g_split_min128 = v > 0 ? v : 512; }
@@ -971,6 +977,7 @@ static int check_vec(long ld, int dtype, const char* what) {
 
 extern "C" int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B,
                               long ldb, void* C, long ldc, const emoasr_epilogue_t* ep, void* stream) {
+  SplitScope split_scope(dtype);
   EMO_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem %d %d %d", M, N, K);
   if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") || check_vec(K, dtype, "K")) return 1;
   NtArgs a{};
@@ -988,6 +995,7 @@ extern "C" int emoasr_gemm_nt(int dtype, int M, int N, int K, const void* A, lon
 // C[M,N] = epilogue(A[M,K] . B[K,N])  -- B k-major; dgrad: dX = dY . W with W stored [out,in].
 extern "C" int emoasr_gemm_nn(int dtype, int M, int N, int K, const void* A, long lda, const void* B,
                               long ldb, void* C, long ldc, const emoasr_epilogue_t* ep, void* stream) {
+  SplitScope split_scope(dtype);
   EMO_CHECK(M > 0 && N > 0 && K > 0, "gemm_nn: empty problem %d %d %d", M, N, K);
   if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") || check_vec(K, dtype, "K") ||
       check_vec(N, dtype, "N")) return 1;
@@ -1007,6 +1015,7 @@ extern "C" int emoasr_gemm_nn_batched(int dtype, int M, int N, int K, const void
                                       long sa_h, const void* B, long ldb, long sb_b, long sb_h, void* C,
                                       long ldc, long sc_b, long sc_h, int nb, int nh, float alpha,
                                       int accumulate, void* stream) {
+  SplitScope split_scope(dtype);
   EMO_CHECK(M > 0 && N > 0 && K > 0 && nb > 0 && nh > 0, "gemm_nn_batched: empty problem");
   // K need not be a multiple of the vector width: rows of A are padded up to lda (zero-filled)
   if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") ||
@@ -1024,6 +1033,7 @@ extern "C" int emoasr_gemm_nn_batched(int dtype, int M, int N, int K, const void
 extern "C" int emoasr_gemm_tn(int dtype, int N1, int N2, int K, const void* A, long lda, const void* B,
                               long ldb, float* C, long ldc, float alpha, int accumulate, float* colsum,
                               float colsum_scale, void* stream) {
+  SplitScope split_scope(dtype);
   EMO_CHECK(N1 > 0 && N2 > 0 && K > 0, "gemm_tn: empty problem");
   // N1 may be ragged when lda is padded (rows readable up to lda)
   if (check_vec(lda, dtype, "lda") || check_vec(ldb, dtype, "ldb") || check_vec(N2, dtype, "N2")) return 1;
@@ -1057,7 +1067,7 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   // co-resident and the launch read 1.2-1.6x its operands from HBM; BK = 32 reads them once -- 216 -> 185 us at 35 k rows,
   // tools/tn_probe.py.)  Option "gemm_kb" overrides.
   const int kb = dtype == EMO_BF16 ? (g_tn_group_kb ? g_tn_group_kb : g_gemm_kb ? g_gemm_kb : (bt == 128 ? 1 : 2)) : 1;
-  const bool split = dtype == EMO_F32 && g_f32_split;
+  const bool split = dtype == EMO_F32X3;
   const int BK = (dtype == EMO_BF16 || split ? 32 : 16) * kb;
   for (int i = 0; i < n; ++i) {
     const emoasr_tn_problem_t& q = probs[i];
@@ -1145,7 +1155,7 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
   } else if (split) {
     if (bt == 128) gemm_tn_grouped_kernel<float, true, 1, 128, true><<<start, 256, 0, s>>>(G);
     else gemm_tn_grouped_kernel<float, true, 1, 64, true><<<start, 256, 0, s>>>(G);
-  } else if (dtype == EMO_F32) {
+  } else if (emo_is_f32(dtype)) {
     if (bt == 128) gemm_tn_grouped_kernel<float, true, 1, 128><<<start, 256, 0, s>>>(G);
     else gemm_tn_grouped_kernel<float, true, 1, 64><<<start, 256, 0, s>>>(G);
   } else {
@@ -1161,6 +1171,7 @@ extern "C" int emoasr_gemm_tn_grouped(int dtype, int n, const emoasr_tn_problem_
 //   y2[(b,t2,f2), n] = relu(bias[n] + sum_{kh,kw,c} y1[b,2t2+kh,2f2+kw,c] * W[n,(kh,kw,c)])
 extern "C" int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const void* y1, const void* w,
                                 void* y2, const emoasr_epilogue_t* ep, void* stream) {
+  SplitScope split_scope(dtype);
   EMO_CHECK(T1 >= 3 && F1 >= 3, "conv2: input too small (T1=%d F1=%d)", T1, F1);
   const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
   EMO_CHECK(C % 32 == 0, "conv2: C must be a multiple of 32");
@@ -1180,6 +1191,7 @@ extern "C" int emoasr_conv2_fwd(int dtype, int B, int T1, int F1, int C, const v
 // (t1, f1), with K = 4C / 2C / 2C / C -- see DgradGeom.  w = the forward's [C, 9C] weight layout.
 extern "C" int emoasr_conv2_dgrad(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* w,
                                   const void* y1, void* dy1, void* stream) {
+  SplitScope split_scope(dtype);
   EMO_CHECK(T1 >= 3 && F1 >= 3, "conv2_dgrad: input too small (T1=%d F1=%d)", T1, F1);
   EMO_CHECK(C % 64 == 0, "conv2_dgrad: C must be a multiple of 64");
   const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
@@ -1200,7 +1212,7 @@ extern "C" int emoasr_conv2_dgrad(int dtype, int B, int T1, int F1, int C, const
       a.A = dy2; a.lda = 0; a.B = w; a.ldb = 9 * C; a.C = dy1; a.ldc = C;
       a.ep.alpha = 1.f; a.ep.dact_pre = y1; a.ep.dact = EMO_ACT_RELU; a.ep.res_scale = 1.f;
       int rc = 1;
-      EMO_DISPATCH(dtype, rc = (is_f32<T> && g_f32_split ? launch_nt_<float, 2, true, true, true>(a, (hipStream_t)stream)
+      EMO_DISPATCH(dtype, rc = (is_f32<T> && t_f32_split ? launch_nt_<float, 2, true, true, true>(a, (hipStream_t)stream)
                                 : g_tr_read ? launch_nt_<T, 2, true, true>(a, (hipStream_t)stream)
                                             : launch_nt_<T, 2, true, false>(a, (hipStream_t)stream)));
       if (rc) return rc;
@@ -1211,6 +1223,7 @@ extern "C" int emoasr_conv2_dgrad(int dtype, int B, int T1, int F1, int C, const
 // dW[n, (kh,kw,c)] (+)= sum_{(b,t2,f2)} dy2[(b,t2,f2), n] * y1[b,2t2+kh,2f2+kw,c]
 extern "C" int emoasr_conv2_wgrad(int dtype, int B, int T1, int F1, int C, const void* dy2, const void* y1,
                                   float* dw, float* dbias, int accumulate, void* stream) {
+  SplitScope split_scope(dtype);
   const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
   EMO_CHECK(T1 >= 3 && F1 >= 3, "conv2_wgrad: input too small");
   EMO_CHECK(C % 128 == 0, "conv2_wgrad: C must be a multiple of 128");

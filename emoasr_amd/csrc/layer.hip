@@ -43,6 +43,7 @@ emoasr_epilogue_t plain_ep() {
 // x + res_scale * drop(W2 act(W1 LN(x) + b1) + b2): LayerNorm + two products.  (The block as ONE launch -- 64 rows per workgroup, the
 // F-wide intermediate consumed on chip -- was built in round 2 and measured again at the stacked size in round 4: 263 us against
 // 120 us at M = 35 145, 90 against 36 at M = 7 029; every CU streams both weight matrices for its 64 rows.  Deleted.)
+int g_att_bits = 1;       // option "attn_mask_bits": the layer hashes its attention keep mask once, as bits, in the forward
 int g_ffn_save_dact = 1;  // option "ffn_save_dact": the feed-forward blocks save Swish'(u) * dropout_scale instead of u (common.h:
                           // EMO_ACT_SAVE_DACT); must not change between a forward and its backward
 int g_stack_launch = 1;  // stacked micro-batches: 1 = the per-utterance kernels take all segments in ONE launch (segment table in
@@ -183,6 +184,7 @@ extern "C" int emoasr_wgrad_side_join(int keep, void* stream) {
 void emo_layer_set_conv_fused(int v) { g_conv_fused = v; }
 void emo_layer_set_stack_launch(int v) { g_stack_launch = v; }
 void emo_layer_set_ffn_save_dact(int v) { g_ffn_save_dact = v ? 1 : 0; }
+void emo_layer_set_att_bits(int v) { g_att_bits = v ? 1 : 0; }
 
 extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* L,
                                           const emoasr_conformer_fwd_t* io, void* stream) {
@@ -194,6 +196,16 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
   const int M = (int)sv.M(), R = (int)sv.R();
   const size_t esz = dtype == EMO_BF16 ? 2 : 4;
   const float p_enc = io->p_enc;
+  // the attention-dropout keep mask of this layer as bits, hashed now (on the attention's side stream: it runs under the macaron
+  // block's products) for the attention forward below and both passes of its backward
+  const bool att_bits = g_att_bits && io->att_mask && io->training && io->p_att > 0.f && dtype == EMO_BF16;
+  const int astep_m = g_stack_launch ? sv.n : 1;
+  for (int si = 0; si < sv.n && att_bits; si += astep_m) {
+    emoasr_attn_t am{};
+    attn_args_for(am, sv, si, si + astep_m, H, d, esz, io->qkv, io->pp, io->klens, io->seed[2]);
+    am.drop_p = io->p_att;
+    if (emoasr_attn_dropmask(dtype, &am, io->att_mask + (size_t)sv.row[si] * H * io->att_mask_nw, io->att_mask_nw, stream)) return 1;
+  }
   // ---- macaron feed-forward ---------------------------------------------------------------------
   if (ffn_fwd(dtype, M, d, F, L->ffm, io->x, 0.5f, p_enc, io->seed[0], io->seed[1], io->ffm, stream)) return 1;
   const void* x1 = io->ffm.y;
@@ -214,6 +226,7 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
       attn_args_for(a, sv, si, si + astep, H, d, esz, io->qkv, io->pp, io->klens, io->seed[2]);
       a.bias_u = L->bias_u; a.bias_v = L->bias_v; a.drop_p = io->p_att;
       a.out = (char*)io->o + ro * d * esz; a.lse = io->lse + ro * H;
+      if (att_bits) { a.keep_mask = io->att_mask + ro * H * io->att_mask_nw; a.keep_nw = io->att_mask_nw; }
       if (emoasr_attn_fwd(dtype, &a, stream)) return 1;
     }
     emoasr_epilogue_t eo = plain_ep();
@@ -438,6 +451,7 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
     emoasr_attn_t am{};
     attn_args_for(am, sv, 0, sv.n, H, d, esz, st->qkv, st->pp, st->klens, st->seed[2]);
     am.bias_u = L->bias_u; am.bias_v = L->bias_v; am.drop_p = st->p_att;
+    if (g_att_bits && st->att_mask && st->p_att > 0.f) { am.keep_mask = st->att_mask; am.keep_nw = st->att_mask_nw; }
     if (emo_attn_bwd_prelaunch(dtype, &am, ws + bb.attn_ws, bb.attn_ws_bytes, (float*)(ws + bb.dpos), (long)sv.R() * d, stream)) return 1;
   }
   // ---- final LayerNorm ------------------------------------------------------------------------------------------
@@ -543,6 +557,7 @@ extern "C" int emoasr_conformer_layer_bwd(int dtype, const emoasr_conformer_laye
       attn_args_for(a, sv, si, si + astep, H, d, esz, st->qkv, st->pp, st->klens, st->seed[2]);
       a.bias_u = L->bias_u; a.bias_v = L->bias_v; a.drop_p = st->p_att;
       a.out = (char*)st->o + ro * d * esz; a.lse = st->lse + ro * H;
+      if (g_att_bits && st->att_mask && st->p_att > 0.f) { a.keep_mask = st->att_mask + ro * H * st->att_mask_nw; a.keep_nw = st->att_mask_nw; }
       a.dout = ws + bb.dout + ro * d * esz; a.delta = (float*)(ws + bb.delta) + ro * H;
       a.dq = dqkv; a.dk = dqkv + (size_t)d * esz; a.dv = dqkv + (size_t)2 * d * esz;
       float* dpos = (float*)(ws + bb.dpos) + po * d;

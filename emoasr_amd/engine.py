@@ -343,8 +343,9 @@ class CTCEngine(_DecoderMixinPlaceholder):
         return (self.seed * 1000003 + self.step_count * 4099 + site) & 0xFFFFFFFFFFFF
 
     def _apply_mode(self):
-        """re-assert this engine's mode of the f32 products (a process-wide library option: another engine may have changed it)"""
-        ops.set_f32_split(self.split)   # (a bf16 engine never launches an f32 product, but leaves the switch in its default state)
+        """this engine's mode of the f32 products for the calling thread: exact f32 MFMAs, or "f32x3" -- the dtype code lib.F32X3 that
+        ops.dt() then puts into every C call (the library itself keeps no mode)"""
+        ops.split_products(self.split)   # this thread's f32 products from here on: the dtype code of every call (ops.dt)
 
     def _scope(self):
         return ops.stream_scope(self.split)
@@ -1327,6 +1328,7 @@ class _RNNTMixin:
     def rnnt_recurrency(self, ids_tm, state, training, keep):
         """prediction network, TIME-MAJOR: ids_tm int32 [U,B] -> douts [U,B,H]; state = (hs, cs) lists of
         per-layer [B,H] tensors (h in compute dtype, c f32) or None."""
+        self._apply_mode()
         A, H = self.arena, self.r_H
         U, B = ids_tm.shape
         p_emb = self.p_emb if training else 0.0
@@ -1370,6 +1372,7 @@ class _RNNTMixin:
 
     def rnnt_recurrency_bwd(self, st, dy):
         """dy [U,B,H] gradient w.r.t. the prediction-network output; accumulates parameter gradients"""
+        self._apply_mode()
         A, H = self.arena, self.r_H
         U, B = st.ids.shape
         for l in reversed(range(self.r_nl)):
@@ -1707,8 +1710,15 @@ class _RNNTMixin:
         if key in st.graphs:
             return st, st.graphs[key]
 
-        fused = os.environ.get("EMOASR_RNNT_BEAM_FUSED", "1") != "0" and nl >= 1
-        st.zero_copy = fused
+        # the fused round's kernels have LDS plans of their own (csrc/rnnt_beam.hip: a vocabulary row of <= 60 KB in the pick
+        # kernel, 16 rows of H floats in the joint kernel, nin + H columns in the f32 LSTM step); a model outside them decodes
+        # through the launch chain as before round 5 -- decided here from the same limits, and once more by the warm-up below
+        # (an entry point that still refuses turns the round into the chain body instead of failing the search)
+        V_ = A.w("decoder.output.weight").shape[0]
+        nin_max = max(A.w(f"decoder.rnns.{l}.weight_ih_l0").shape[1] for l in range(nl)) if nl else 0
+        fits = V_ * 4 <= 60 * 1024 and 16 * H * 4 <= 64 * 1024 and (self.dtype == torch.bfloat16 or nin_max + H <= 2368)
+        mode = {"fused": os.environ.get("EMOASR_RNNT_BEAM_FUSED", "1") != "0" and nl >= 1 and fits}
+        st.zero_copy = mode["fused"]
 
         def body_fused():
             # csrc/rnnt_beam.hip: five launches -- one per LSTM layer (gather, both products, cell, scatter), the joint input, the
@@ -1742,7 +1752,7 @@ class _RNNTMixin:
                          ops._p(st.out_host), st.out_host.stride(0), ops._stream())
 
         def body():
-            if fused:
+            if mode["fused"]:
                 return body_fused()
             with self._scope():
                 ids = st.ctl[:nb].to(torch.int32).view(1, nb)
@@ -1769,8 +1779,16 @@ class _RNNTMixin:
         st.ctl.copy_(st.ctl_host)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
+        from . import lib
         with torch.cuda.stream(side):
-            body()   # warm-up outside the capture (allocator, lazy initialisation)
+            try:
+                body()   # warm-up outside the capture (allocator, lazy initialisation)
+            except lib.EmoasrHipError:
+                if not mode["fused"]:
+                    raise
+                mode["fused"] = st.zero_copy = False   # outside a fused kernel's limits: the launch chain's body
+                st.ctl.copy_(st.ctl_host)
+                body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g_ = torch.cuda.CUDAGraph()

@@ -34,6 +34,8 @@ class _Layout:
             qkv_shape, o_shape, lse_shape, nstat = (M, 3 * d), (M, d), (H * M,), len(segs)
             npart = sum(lib.size_query("emoasr_dwconv_stats_floats", b, t, d) for b, t in segs)
         self.M, self.R = M, R
+        # attention keep mask as bits (uint32 [M, H, nw], emoasr_attn_t::keep_mask): hashed once per layer in the forward
+        self.mask_nw = lib.size_query("emoasr_attn_dropmask_words", T if segs is None else max(t for _, t in segs))
         t_fields = [("ffm_h", (M, d)), ("ffm_u", (M, F)), ("ffm_a", (M, F)), ("ffm_y", (M, d)),
                     ("at_h", (M, d)), ("qkv", qkv_shape), ("pp", (R, d)), ("o", o_shape), ("at_y", (M, d)),
                     ("cv_h", (M, d)), ("g", (M, 2 * d)), ("gl", (M, d)), ("c", (M, d)), ("z", (M, d)), ("cv_y", (M, d)),
@@ -41,7 +43,7 @@ class _Layout:
         f_fields = [("ffm_mean", (M,)), ("ffm_rstd", (M,)), ("lse", lse_shape), ("at_mean", (M,)), ("at_rstd", (M,)),
                     ("bmean", (nstat * d,)), ("bvar", (nstat * d,)), ("bn_part", (npart,)),
                     ("cv_mean", (M,)), ("cv_rstd", (M,)), ("ff_mean", (M,)), ("ff_rstd", (M,)),
-                    ("fin_mean", (M,)), ("fin_rstd", (M,))]
+                    ("fin_mean", (M,)), ("fin_rstd", (M,)), ("att_mask", (M * H * self.mask_nw,))]
         self.t, self.f = {}, {}
         off = 0
         for name, shape in t_fields:
@@ -221,6 +223,8 @@ class ConformerLayerRuntime:
         for k in ("at_h", "qkv", "pp", "o", "at_y", "cv_h", "g", "gl", "c", "z", "cv_y", "y"):
             setattr(io, k, tb + t[k][0] * esz)
         io.lse = fb + f["lse"][0] * 4
+        if training and p_att > 0 and wt.dtype == torch.bfloat16:
+            io.att_mask, io.att_mask_nw = fb + f["att_mask"][0] * 4, lay.mask_nw
         io.bmean, io.bvar, io.bn_part = fb + f["bmean"][0] * 4, fb + f["bvar"][0] * 4, fb + f["bn_part"][0] * 4
         if keep:
             io.ffm.mean, io.ffm.rstd = fb + f["ffm_mean"][0] * 4, fb + f["ffm_rstd"][0] * 4

@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_long, c_uint
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMOASR_HIP_LIB") or os.path.join(_HERE, "libemoasr_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2   # (F32X3: f32 buffers, split-bf16 products -- the mode travels in every call's dtype argument)
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_GELU = 0, 1, 2, 3
 
 
@@ -36,7 +36,8 @@ class AttnArgs(Structure):
                 ("ldpd", c_long), ("ldbd", c_long), ("cs", c_void_p),
                 ("st", c_void_p), ("ldst", c_long),
                 ("qu", c_void_p), ("qv", c_void_p), ("dbias_part", c_void_p),
-                ("nseg", c_int), ("seg_b0", c_int * 9), ("seg_T", c_int * 8), ("seg_row", c_long * 9), ("seg_prow", c_long * 9), ("seg_order", c_int * 8)]
+                ("nseg", c_int), ("seg_b0", c_int * 9), ("seg_T", c_int * 8), ("seg_row", c_long * 9), ("seg_prow", c_long * 9), ("seg_order", c_int * 8),
+                ("keep_mask", c_void_p), ("keep_nw", c_int)]
 
 
 class TnProblem(Structure):
@@ -170,7 +171,8 @@ class ConformerFwd(Structure):
                 ("cv_h", c_void_p), ("g", c_void_p), ("gl", c_void_p), ("c", c_void_p), ("z", c_void_p),
                 ("cv_y", c_void_p), ("bmean", c_void_p), ("bvar", c_void_p), ("bn_part", c_void_p),
                 ("cv_mean", c_void_p), ("cv_rstd", c_void_p),
-                ("y", c_void_p), ("fin_mean", c_void_p), ("fin_rstd", c_void_p), ("seg", Segments)]
+                ("y", c_void_p), ("fin_mean", c_void_p), ("fin_rstd", c_void_p), ("seg", Segments),
+                ("att_mask", c_void_p), ("att_mask_nw", c_int)]
 
 class ConformerBwd(Structure):
     _fields_ = [("dy", c_void_p), ("dx", c_void_p), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t),
@@ -215,6 +217,7 @@ SIGNATURES = {
     "emoasr_joint_beam_step_parts": [I, POINTER(JointStep), I, P],
     "emoasr_joint_beam_graph_build": [I, POINTER(JointStep), I, I, P],
     "emoasr_joint_beam_graph_launch": [I, I, P],
+    "emoasr_attn_dropmask": [I, POINTER(AttnArgs), P, I, P],
     "emoasr_attn_fwd": [I, POINTER(AttnArgs), P],
     "emoasr_attn_bwd": [I, POINTER(AttnArgs), P],
     "emoasr_attn_bwd_fused": [I, POINTER(AttnArgs), P, ctypes.c_size_t, P],

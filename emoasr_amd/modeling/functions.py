@@ -326,7 +326,7 @@ class _PredNetFn(torch.autograd.Function):
     def backward(ctx, g):
         from .. import ops
         eng = ctx.eng
-        with ops.stream_scope():
+        with eng._scope():   # (the engine's own product mode: this runs on an autograd thread)
             eng.arena.attach_grads()
             eng.rnnt_recurrency_bwd(ctx.rst, g.contiguous())
         ctx.rst = None

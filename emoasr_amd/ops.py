@@ -9,16 +9,20 @@ import ctypes
 from ctypes import byref, c_void_p
 
 import os
+import threading
 
 import torch
 
 from . import lib
-from .lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SWISH, BF16, F32, AttnArgs, Epilogue  # noqa: F401
+from .lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SWISH, BF16, F32, F32X3, AttnArgs, Epilogue  # noqa: F401
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
 def dt(t):
+    """dtype code of a call on tensor t: F32 / BF16, or F32X3 for an f32 tensor while the calling thread's engine runs split products"""
+    if t.dtype == torch.float32 and split_products():
+        return F32X3
     return _DT[t.dtype]
 
 
@@ -35,20 +39,21 @@ def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_F32_SPLIT = 0
+# "f32x3" (lib.F32X3): f32 tensors whose matrix products run as three bf16 MFMAs over (hi, lo) operand pairs.  The mode is an
+# argument of every C call (the dtype code dt() returns); on this side it is a property of the calling engine, held per THREAD for
+# the duration of the engine's entry point (an autograd thread or a second engine never sees another's mode; there is no library
+# state to go stale -- rounds 4-5 had a process-wide option).
 # EMOASR_FORCE_SPLIT=1: EVERY f32 product of the process runs split, whatever an engine asks for (test aid: the whole GPU suite's f32
-# cases -- all decoders, searches, distillation paths -- then exercise the f32x3 arithmetic against the same goldens and bars)
+# cases under the split arithmetic, profiles/r05_forced_split_suite.txt)
 _FORCE_SPLIT = os.environ.get("EMOASR_FORCE_SPLIT", "0") == "1"
+_mode = threading.local()
 
 
-def set_f32_split(on):
-    """library option "f32_split" (csrc/gemm.hip SplitCfg): f32 products as three bf16 MFMAs over (hi, lo) operand pairs.  The
-    option is process-wide; every engine re-asserts its own mode at its entry points (CTCEngine._apply_mode)."""
-    global _F32_SPLIT
-    on = 1 if (on or _FORCE_SPLIT) else 0
-    if on != _F32_SPLIT:
-        lib.set_option("f32_split", on)
-        _F32_SPLIT = on
+def split_products(on=None):
+    """the calling thread's f32 product mode: split_products(True / False) sets it, split_products() reads it"""
+    if on is not None:
+        _mode.split = bool(on)
+    return bool(getattr(_mode, "split", False)) or _FORCE_SPLIT
 
 
 class stream_scope:
@@ -63,7 +68,7 @@ class stream_scope:
         self.prev = _STREAM_CACHE
         _STREAM_CACHE = c_void_p(torch.cuda.current_stream().cuda_stream)
         if self.f32_split is not None:
-            set_f32_split(self.f32_split)
+            split_products(self.f32_split)
         return self
 
     def __exit__(self, *exc):
@@ -326,8 +331,19 @@ def _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, se
     return a
 
 
+def attn_dropmask(q, k, H, klens=None, drop_p=0.0, seed=0):
+    """the attention-dropout keep mask of an attn_fwd / attn_bwd call with these arguments as bits: uint32 [B * Tq, H, ceil(Tk / 32)]
+    (emoasr_attn_t::keep_mask: hashed once, tested by the forward and both passes of the fused backward)"""
+    B, Tq, _ = q.shape
+    nw = lib.size_query("emoasr_attn_dropmask_words", k.shape[1])
+    a = _attn_args(q, k, k, H, None, None, None, klens, False, 1.0, drop_p, seed)
+    mask = torch.zeros(B * Tq, H, nw, device=q.device, dtype=torch.int32)
+    lib.call("emoasr_attn_dropmask", dt(q), byref(a), mask.data_ptr(), nw, _stream())
+    return mask
+
+
 def attn_fwd(q, k, v, H, scale, pos=None, bias_u=None, bias_v=None, klens=None, causal=False, drop_p=0.0,
-             seed=0, store_scores=False):
+             seed=0, store_scores=False, keep_mask=None):
     """q [B,Tq,D], k/v [B,Tk,D] (views with a row stride are fine) -> out [B,Tq,D], lse [B,H,Tq]
     (+ st f32 [B,H,Tk,ldst], the scaled scores S^T kept for the backward, if store_scores)"""
     B, Tq, D = q.shape
@@ -335,6 +351,8 @@ def attn_fwd(q, k, v, H, scale, pos=None, bias_u=None, bias_v=None, klens=None, 
     out = torch.empty(B, Tq, D, device=q.device, dtype=q.dtype)
     lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
     a.out, a.ldo, a.lse = out.data_ptr(), D, lse.data_ptr()
+    if keep_mask is not None:
+        a.keep_mask, a.keep_nw = keep_mask.data_ptr(), keep_mask.shape[-1]
     st = None
     if store_scores:
         st = torch.empty(B, H, k.shape[1], (Tq + 7) // 8 * 8, device=q.device, dtype=torch.float32)
@@ -381,7 +399,7 @@ def _fused_ws(device, nbytes):
 
 def attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=None, bias_u=None, bias_v=None, klens=None,
              causal=False, drop_p=0.0, seed=0, dpos=None, dbias_u=None, dbias_v=None, scratch=None,
-             materialise=True, st=None):
+             materialise=True, st=None, keep_mask=None):
     """dq/dk/dv are written (same strides as q/k/v); dpos/dbias_* are accumulated into.
     materialise="fused": the single-pass kernel (bf16, no causal mask; see fused_attn_bwd_ok);
     materialise=True: dV/dK/dpos through batched GEMMs over stored P^T/dS^T (scratch is allocated
@@ -390,6 +408,8 @@ def attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=None, bias_u=Non
     if materialise == "fused":
         assert fused_attn_bwd_ok(q, pos, bias_u, bias_v, causal)
         a = _attn_args(q, k, v, H, pos, bias_u, bias_v, klens, causal, scale, drop_p, seed)
+        if keep_mask is not None:
+            a.keep_mask, a.keep_nw = keep_mask.data_ptr(), keep_mask.shape[-1]
         assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
         assert dout.is_contiguous() and out.is_contiguous()
         delta = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)

@@ -10,8 +10,13 @@
  * Conventions
  *   - every function returns 0 on success, non-zero on error;
  *     emoasr_last_error() returns a message for the calling thread's last error.
- *   - dtype: EMOASR_F32 (parity mode: exact-f32 MFMA) or EMOASR_BF16 (bf16 MFMA,
- *     f32 accumulate).  "T*" below means a buffer of that element type.
+ *   - dtype: EMOASR_F32 (exact mode: f32 MFMA, a bit-exact k-ordered fmaf chain), EMOASR_BF16 (bf16 MFMA,
+ *     f32 accumulate) or EMOASR_F32X3 (the PARITY mode at throughput: f32 buffers, statistics and epilogues
+ *     exactly as EMOASR_F32, every matrix product as three bf16 MFMAs over (hi, lo) operand pairs -- 16
+ *     significand bits per operand; meets north_star's 1e-3 / bit-exact-ids tolerances, tests/test_fullsize_gpu.py).
+ *     The mode is an argument of every call: the library keeps no precision state (rounds 4-5 had a
+ *     process-wide option "f32_split"; it is gone).  Entry points without a matrix product treat EMOASR_F32X3
+ *     as EMOASR_F32.  "T*" below means a buffer of the dtype's element type (float for both f32 codes).
  *   - statistics, losses, lattices, parameter gradients and optimizer state are
  *     always f32; lengths / labels are int32.
  *   - all pointers are device pointers unless noted; kernels are enqueued on
@@ -26,7 +31,7 @@
 extern "C" {
 #endif
 
-enum { EMOASR_F32 = 0, EMOASR_BF16 = 1 };
+enum { EMOASR_F32 = 0, EMOASR_BF16 = 1, EMOASR_F32X3 = 2 };
 enum { EMOASR_ACT_NONE = 0, EMOASR_ACT_RELU = 1, EMOASR_ACT_SWISH = 2,
        /* emoasr_epilogue_t.dact only: the tensor behind dact_pre IS the factor to multiply by (saved by a forward epilogue whose
         * act carried EMOASR_ACT_SAVE_DACT); pass drop_p = 0 with it, the mask is part of the factor */
@@ -250,7 +255,18 @@ typedef struct {
   /* filled by the library (callers leave it zero): the order in which a stacked launch hands out its segments' workgroups --
    * longest segment first, so that the short ones fill the tail of the launch */
   int seg_order[EMOASR_MAX_SEGMENTS];
+  /* optional (round 6, bf16 training): the attention-dropout keep mask of this launch as BITS -- uint32 [rows, H, keep_nw], one word
+   * per (query row, head, 32-key tile), bit k of word w = key 32 w + k kept; rows = B * Tq (stacked: all segments' rows, in order).
+   * emoasr_attn_dropmask hashes it ONCE per layer and step (dropout(p=dropout_attn_rate) of transformer.py:88); emoasr_attn_fwd and
+   * both passes of emoasr_attn_bwd_fused then test a bit (2-3 instructions per element) instead of hashing the counter-based mask
+   * again (13-26 per element).  NULL: the kernels hash inline / the backward fills a mask of its own. */
+  const unsigned* keep_mask;
+  int keep_nw;
 } emoasr_attn_t;
+/* words per (row, head) of a keep mask for keys 0 .. Tk-1, and the mask of the launch described by `a` (q / k / v pointers are not
+ * read: B, H, Tq, Tk, klens, drop_p, seed and the segment table are) written to mask [rows, H, nw] */
+long emoasr_attn_dropmask_words(int Tk);
+int emoasr_attn_dropmask(int dtype, const emoasr_attn_t* a, unsigned* mask, int nw, void* stream);
 int emoasr_attn_fwd(int dtype, const emoasr_attn_t* a, void* stream);
 int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream);
 /* The materialised mode's optional scratch as TWO areas instead of seven pointers: emoasr_attn_bwd_mat_bytes(..., which) bytes each
@@ -631,6 +647,11 @@ typedef struct emoasr_conformer_fwd {
   emoasr_segments_t seg;             /* stacked micro-batches; lse is [H * M]: segment s at H * (its first row), laid out
                                       * [B[s], H, T[s]]; bmean / bvar are [n, d]; bn_part holds the segments' partial-sum
                                       * areas (emoasr_dwconv_stats_floats(B[s], T[s], d) floats each) back to back */
+  /* optional (bf16 training with attention dropout): room for the layer's attention keep mask as bits, uint32
+   * [M, H, att_mask_nw] with att_mask_nw >= emoasr_attn_dropmask_words(longest T).  The forward hashes the mask once (on the
+   * attention's side stream, under the macaron feed-forward block) and the attention forward and both backward passes test bits
+   * (emoasr_attn_t::keep_mask); it is part of the stash the backward takes.  NULL: every kernel hashes for itself. */
+  unsigned* att_mask; int att_mask_nw;
 } emoasr_conformer_fwd_t;
 int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* layer,
                                const emoasr_conformer_fwd_t* io, void* stream);

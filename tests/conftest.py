@@ -22,13 +22,13 @@ def dev():
 
 @pytest.fixture(autouse=True)
 def _f32_products_exact_by_default():
-    """the library's "f32_split" switch (f32 products as three bf16 MFMAs, the f32x3 engines' mode) is process-wide: every test
-    starts from the exact f32 products, whatever engine the previous test left behind"""
+    """the f32 product mode (exact, or "f32x3": three bf16 MFMAs) is a per-thread property of the calling engine (ops.split_products):
+    every test starts from the exact f32 products, whatever engine the previous test left behind on this thread"""
     try:
         import torch
         if torch.cuda.is_available():
             from emoasr_amd import ops
-            ops.set_f32_split(0)
+            ops.split_products(False)
     except Exception:
         pass
     yield

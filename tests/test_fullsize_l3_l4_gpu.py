@@ -204,5 +204,11 @@ def test_l4_transducer_full_size(dev, dtype):
     if dtype == torch.float32:
         assert hyps == want, (hyps, want)
     else:
-        agree = sum(int(a == b) for h, w in zip(hyps, want) for a, b in zip(h, w)) / max(1, sum(len(w) for w in want))
+        # agreement by ALIGNMENT (1 - edit distance / reference length, emoasr_amd.metrics): a position-by-position comparison of
+        # the label sequences counts every label behind one inserted / dropped label as wrong -- on these random-init weights
+        # (near-ties over the vocabulary) it moved between 0.75 and 0.9 with the rounding of one attention kernel
+        from emoasr_amd.metrics import compute_wer
+        errs = sum(compute_wer([str(t) for t in h], [str(t) for t in w])[1]["wer"] * len(w) / 100.0 for h, w in zip(hyps, want) if len(w))
+        agree = 1.0 - errs / max(1, sum(len(w) for w in want))
+        print(f"[measured L4 {dtype}] greedy label agreement (1 - edit distance / length) {agree:.4f}")
         assert agree > 0.8, agree

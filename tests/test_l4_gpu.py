@@ -253,6 +253,33 @@ def test_beam_search_graph_scores_on_fresh_engine(dev):
                 assert max(abs(a - c) for a, c in zip(s_g, s_c)) < 1e-4, (b, bw, s_g, s_c)
 
 
+def test_beam_search_outside_the_fused_round_limits(dev):
+    """a vocabulary wider than the fused round's pick kernel holds in LDS (V * 4 B > 60 KB, csrc/rnnt_beam.hip): the graph form must
+    decode through the launch chain's body (as before round 5) instead of failing in its warm-up -- same hypotheses and scores as
+    _rnnt_beam_search_chain"""
+    from emoasr_amd.modeling.asr import ASR
+    cfg = dict(CONFIGS["l4_tiny"], vocab_size=16001)
+    torch.manual_seed(5)
+    models = []
+    for _ in range(2):
+        m = ASR(SimpleNamespace(**cfg), compute_dtype=torch.float32)
+        if models:
+            m.load_state_dict(models[0].state_dict())
+        models.append(m)
+    models = [m.to(dev).eval() for m in models]
+    _, _, g = load_golden("l4_tiny")
+    with torch.no_grad():
+        n = int(g["xlens"][0])
+        outs = []
+        for m, form in zip(models, ("_rnnt_beam_search_graph", "_rnnt_beam_search_chain")):
+            eouts, elens, _ = m.encoder(g["xs"][:1, :n].to(dev), g["xlens"][:1])
+            outs.append(getattr(m.engine(), form)(eouts[:, :int(elens[0])], 3, m.decoder.blank_id, m.decoder.eos_id,
+                                                  return_scores=True))
+        (h_g, s_g), (h_c, s_c) = outs
+        assert h_g == h_c, (h_g, h_c)
+        assert max(abs(a - c) for a, c in zip(s_g, s_c)) < 1e-4, (s_g, s_c)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_train_loss_and_grads(dev, dtype):
     model, g = _build(dtype, dev)

@@ -531,6 +531,47 @@ def test_attention_dropout(dev):
     assert torch.equal(out1, out2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_attention_keep_mask_bits_equal_the_inline_hash(dev, dtype):
+    """emoasr_attn_dropmask (round 6): the keep mask hashed ONCE as bits gives the forward -- and both passes of the fused backward --
+    exactly what hashing the counter-based mask inline gives: same outputs, bit for bit; the bits' drop rate is p"""
+    from emoasr_amd import ops
+    B, T, H, D, p = 3, 150, 4, 256, 0.3
+    torch.manual_seed(3)
+    qkv = (torch.randn(B, T, 3 * D, device=dev) * 0.5).to(dtype)
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    pos = (torch.randn(2 * T - 1, D, device=dev) * 0.5).to(dtype)
+    bu, bv = torch.randn(D, device=dev) * 0.1, torch.randn(D, device=dev) * 0.1
+    klens = torch.tensor([150, 131, 97], device=dev, dtype=torch.int32)
+    mask = ops.attn_dropmask(q, k, H, klens=klens, drop_p=p, seed=11)
+    torch.cuda.synchronize()
+    bits = 0
+    for b in range(B):
+        n = int(klens[b])
+        w = mask.view(B, T, H, -1)[b].cpu().numpy().astype("uint32")
+        import numpy as np
+        un = np.unpackbits(w.view("uint8"), axis=-1, bitorder="little")[..., :n]
+        bits += un.mean() / B
+    assert abs(bits - (1 - p)) < 0.01, bits
+    kw = dict(pos=pos, bias_u=bu, bias_v=bv, klens=klens, drop_p=p, seed=11)
+    out0, lse0 = ops.attn_fwd(q, k, v, H, 0.125, **kw)
+    out1, lse1 = ops.attn_fwd(q, k, v, H, 0.125, keep_mask=mask, **kw)
+    assert torch.equal(out0, out1) and torch.equal(lse0, lse1)
+    if dtype == torch.bfloat16:
+        dout = torch.randn(B, T, D, device=dev).to(dtype)
+        res = []
+        for km in (None, mask):
+            dqkv = torch.empty_like(qkv)
+            dpos = torch.zeros(2 * T - 1, D, device=dev)
+            dbu, dbv = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+            ops.attn_bwd(dout, out0, lse0, q, k, v, H, 0.125, dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:], dpos=dpos,
+                         dbias_u=dbu, dbias_v=dbv, materialise="fused", keep_mask=km, **kw)
+            torch.cuda.synchronize()
+            res.append((dqkv, dpos))
+        assert torch.equal(res[0][0], res[1][0])
+        _close(res[1][1], res[0][1], 1e-3, "dpos with the forward's mask")   # (float atomics: order differs from run to run)
+
+
 @pytest.mark.parametrize("case", ["rel", "plain", "rel_ragged"])
 def test_attention_bwd_fused_vs_materialised(dev, case):
     """The single-pass backward against the materialised one on identical bf16 inputs WITH dropout (same counter-based

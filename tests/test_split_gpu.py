@@ -22,9 +22,9 @@ def _seed():
 def split(monkeypatch):
     from emoasr_amd import ops
     monkeypatch.setattr(T, "_tol", lambda dtype, f32=2e-5, bf16=2e-2: max(f32, SPLIT_TOL) if dtype == F32 else bf16)
-    ops.set_f32_split(1)
+    ops.split_products(True)
     yield
-    ops.set_f32_split(0)
+    ops.split_products(False)
 
 
 @pytest.fixture()
@@ -69,11 +69,11 @@ def test_split_is_live_and_sixteen_bits_wide(dev):
     ref = a.double() @ b.double().t()
     scale = ref.abs().max().item()
     exact = ops.gemm_nt(a, b)
-    ops.set_f32_split(1)
+    ops.split_products(True)
     try:
         got = ops.gemm_nt(a, b)
     finally:
-        ops.set_f32_split(0)
+        ops.split_products(False)
     e_exact = (exact.double() - ref).abs().max().item() / scale
     e_split = (got.double() - ref).abs().max().item() / scale
     e_bf16 = (ops.gemm_nt(a.bfloat16(), b.bfloat16()).double() - ref).abs().max().item() / scale

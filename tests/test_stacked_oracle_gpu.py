@@ -172,8 +172,10 @@ def test_reference_trace_d256_stacked_bf16(dev):
         if not want.dtype.is_floating_point:
             assert torch.equal(got, want), k
         elif "running" in k:
+            # (max over the statistic's elements after twelve bf16 steps; three runs of ONE build gave 1.9e-2 / 2.0e-2 / 2.3e-2 --
+            # float atomics in the weight gradients make a bf16 trajectory differ from run to run -- so the bar sits above that spread)
             err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
-            assert err < 2e-2, (k, err)
+            assert err < 3.5e-2, (k, err)
         else:
             # twelve Adam updates: compare the update VECTORS (the first updates are sign-like, so noise-level gradient
             # elements may move either way: cosine, not element-wise maxima)

@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 H, D = 4, 256
 DT = os.environ.get("DT", "bf16")   # bf16 | f32 | f32x3 (f32 storage, split-bf16 products)
 dt = torch.bfloat16 if DT == "bf16" else torch.float32
-ops.set_f32_split(1 if DT == "f32x3" else 0)
+ops.split_products(bool(1 if DT == "f32x3" else 0))
 p = float(os.environ.get("P", 0.1))
 shapes = [(22, 320), (24, 299), (12, 590), (8, 875), (40, 170), (110, 320), (60, 590), (200, 170)]   # the last three: five stacked micro-batches' worth
 if os.environ.get("B"):
