@@ -126,3 +126,50 @@ def test_two_engines_forward_on_two_streams(dev):
         bs, bc = dict(serial_models[k].named_buffers()), dict(conc_models[k].named_buffers())
         for name in bs:
             assert torch.equal(bs[name], bc[name]), (k, name)
+
+
+def test_f32_and_f32x3_engines_on_two_streams(dev):
+    """the f32 product mode is an argument of every call (dtype code EMO_F32X3, round 6), not a library switch: an exact-f32 engine
+    and an f32x3 engine working at once on two streams -- forward and backward, launches interleaved call by call -- give what each
+    gives alone, bit for bit; and the two modes do differ from each other (the test would also pass if both ran one mode)"""
+    from emoasr_amd.modeling.asr import ASR
+    cfg, sd, g = load_golden("l2_tiny")
+
+    def build(mode):
+        m = ASR(SimpleNamespace(**CONFIGS["l2_tiny"]), compute_dtype=mode)
+        m.load_state_dict(sd)
+        return m.to(dev).train()
+
+    xs, xlens, ys, ylens = g["xs"].to(dev), g["xlens"], g["ys"], g["ylens"]
+    R = 4
+
+    def run(models, concurrent):
+        outs = [[], []]
+
+        def work(k):
+            def f(r):
+                models[k].zero_grad(set_to_none=True)
+                loss, _ = models[k](xs, xlens, ys, ylens, None, None)
+                loss.backward()
+                outs[k].append((loss.detach().clone(), models[k].decoder.output.weight.grad.clone(),
+                                models[k].encoder.conv.conv[0].weight.grad.clone()))
+            return f
+        if concurrent:
+            _two_streams(work(0), work(1), R)
+        else:
+            for k in range(2):
+                for r in range(R):
+                    work(k)(r)
+            torch.cuda.synchronize()
+        return outs
+
+    want = run([build(torch.float32), build("f32x3")], False)
+    got = run([build(torch.float32), build("f32x3")], True)
+    for k in range(2):
+        assert torch.equal(got[k][0][0], want[k][0][0]), (k, got[k][0][0].item(), want[k][0][0].item())
+        for r in range(R):
+            assert torch.equal(got[k][r][0], want[k][r][0]), (k, r)
+            for a, b in zip(got[k][r][1:], want[k][r][1:]):
+                # (the weight gradients of the split-K products are summed with float atomics: equal to rounding, not bitwise)
+                assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item(), (k, r)
+    assert not torch.equal(want[0][0][1], want[1][0][1])   # exact f32 and f32x3 are different arithmetic
