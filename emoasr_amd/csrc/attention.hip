@@ -647,6 +647,197 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
   if (lane < 32 && qval) hp.lse[qi] = l > 0.f ? (FAST ? m * 0.6931471805599453f : m) + __logf(l) : -INFINITY;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Forward, block-staged (round 6; bf16, relative positions, no causal mask / stored scores): the training launches.
+// attn_fwd_kernel above lets every wave fetch its own K / band / V fragments straight from global memory: 12-16 loads per wave and
+// key tile whose lanes sit in 32 different rows (32 cache lines touched for 1 KB of payload) -- in-kernel stamps put 40-45 % of a
+// tile's cycles into issuing them and waiting for them (profiles/r06_attn_phases.txt), with 12 KB per wave and tile crossing the
+// CU's vector-memory path.  Here the four waves of a workgroup take FOUR CONSECUTIVE query tiles of one (utterance, head) and
+// share the key tile: K and V (32 rows each) and the union of their position bands are staged once per step through LDS by
+// coalesced 16-byte pieces (8 lanes per 128-byte row), registers one step ahead.  The band union moves up by 32 rows per key
+// tile, so it is a ring of FW + 2 blocks of 32 rows and a step fetches ONE new block: 3 loads per thread and step, 12 KB per
+// WORKGROUP and step instead of 48.  Per-wave work is the old kernel's: S^T = K (Q+u)^T + skew(band (Q+v)^T) with the query on
+// the lane, online soft-max in the exp2 domain, keep-mask bits (or the inline hash), P chained into O^T += V^T P.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int FW> struct Fwd4Cfg {
+  static constexpr int LD = AttnCfg<bf16>::LD, LDG = 68, NRING = FW + 2;
+  static constexpr int STAGE_ROWS = 64 + 32 * NRING;                   // K, V, band ring
+  static constexpr int GS_BYTES = 32 * LDG * 4;                        // per wave: f32 skew tile
+  static constexpr int smem() { return STAGE_ROWS * LD * 2 + FW * GS_BYTES; }
+};
+template <bool TR, int FW>
+__global__ __launch_bounds__(64 * FW, 2) void attn_fwd4_kernel(const emoasr_attn_t a_in, const int nt) {
+  using T = bf16;
+  using M_ = Mma<T>;
+  using C_ = Fwd4Cfg<FW>;
+  constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = C_::LD, LDG = C_::LDG, NRING = C_::NRING;
+  constexpr int VEC = 8, PER_ROW = DK / VEC, NTHR = 64 * FW;
+  static_assert(NTHR / PER_ROW == 32, "one piece per thread covers one 32-row tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), il = lane & 31, hh = lane >> 5;
+  emoasr_attn_t a = a_in;
+  const Blk3 blk = attn_block(nt, a_in.H, a_in.B);
+  if (!blk.ok) return;
+  int b = blk.z;
+  if (a_in.nseg > 1) {
+    const SegRef g = seg_of_slot(a_in, blk.z, b);
+    seg_apply<T>(a, g);
+  }
+  const int iblk = blk.x * (32 * FW), h = blk.y;
+  if (iblk >= a.Tq) return;   // (a shorter segment of a stacked launch: the grid follows the longest)
+  const HeadPtrs hp = head_ptrs<T>(a, b, h);
+  const int i0 = iblk + 32 * wave;
+  const bool live = i0 < a.Tq;   // a dead wave still stages and joins the barriers
+  const int qi = i0 + il;
+  const bool qval = qi < a.Tq;
+
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* Vs = Ks + 32 * LD;
+  T* ring = Ks + 64 * LD;   // block n = table rows Tq - 32 FW - iblk + 32 n + [0, 32) in slot n mod NRING
+  float* Gs = reinterpret_cast<float*>(smem + C_::STAGE_ROWS * LD * 2 + wave * C_::GS_BYTES);
+
+  const int kend = hp.klen, nstep = (kend + 31) / 32;
+  const unsigned kstride = (unsigned)a.ldk * 2u, vstride = (unsigned)a.ldv * 2u, pstride = (unsigned)a.ldp * 2u;
+  // descriptors sized to the valid rows (keys < klen, table rows < 2 Tq - 1): see attn_fwd_kernel
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc_n(hp.k, kend > 0 ? (unsigned)(kend - 1) * kstride + DK * 2u : 0u),
+                               rsV = make_rsrc_n(hp.v, kend > 0 ? (unsigned)(kend - 1) * vstride + DK * 2u : 0u),
+                               rsP = make_rsrc_n(hp.pos, (unsigned)(2 * a.Tq - 2) * pstride + DK * 2u);
+  const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
+  const unsigned k_lane = (unsigned)trow * kstride + (unsigned)piece * 2u, v_lane = (unsigned)trow * vstride + (unsigned)piece * 2u;
+  const unsigned p_lane = (unsigned)((a.Tq - 32 * FW - iblk + trow) * (int)pstride) + (unsigned)piece * 2u;   // block 0
+  Vec16<T> pre[3];
+  auto fetch = [&](const int step) {   // K / V tile of `step` and the band block it adds (block step + FW)
+    const unsigned dead = step < nstep ? 0u : 0x80000000u;
+    pre[0] = buf_load16<T>(rsK, (k_lane + (unsigned)(32 * step) * kstride) | dead);
+    pre[1] = buf_load16<T>(rsV, (v_lane + (unsigned)(32 * step) * vstride) | dead);
+    pre[2] = buf_load16<T>(rsP, (p_lane + (unsigned)(32 * (step + FW)) * pstride) | dead);
+  };
+  auto stash = [&](const int step) {
+    store16(Ks + trow * LD + piece, pre[0]);
+    store16(Vs + trow * LD + piece, pre[1]);
+    store16(ring + (((step + FW) % NRING) * 32 + trow) * LD + piece, pre[2]);
+  };
+  // stationary operands of this wave's query tile (B operands: query on the lane), biases added on the way in
+  typename M_::Frag qu[NK], qv[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    qu[kk] = frag_global<T>((const T*)hp.q, a.ldq, qi, live && qval, kk, lane, hp.bias_u);
+    qv[kk] = frag_global<T>((const T*)hp.q, a.ldq, qi, live && qval, kk, lane, hp.bias_v);
+  }
+  // blocks 0 .. FW - 1 of step 0 (block FW comes with fetch(0))
+#pragma unroll
+  for (int n = 0; n < FW; ++n) store16(ring + (n * 32 + trow) * LD + piece, buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride));
+  fetch(0);
+  stash(0);
+  fetch(1);
+  __syncthreads();
+
+  const bool mbits = a.keep_mask != nullptr && a.drop_p > 0.f;
+  const __amdgpu_buffer_rsrc_t rsM = make_rsrc(a.keep_mask);
+  const unsigned mrow = (unsigned)((((long)b * a.Tq + qi) * a.H + h) * a.keep_nw * 4);
+  auto mask_word = [&](const int step) -> unsigned {
+    return mbits ? __builtin_amdgcn_raw_buffer_load_b32(rsM, (live && qval && step < nstep) ? mrow + 4u * (unsigned)step : EMO_OOB, 0, 0) : 0u;
+  };
+  unsigned mw_next = mask_word(0);
+  const float c2 = a.scale * 1.4426950408889634f;
+  const unsigned keep_bits = __float_as_uint(a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f);
+  float m = -INFINITY, l = 0.f;   // (m in the exp2 domain)
+  f32x16 o[2];
+  zero16(o[0]); zero16(o[1]);
+
+  for (int step = 0; step < nstep; ++step) {
+    const int j0 = step * 32;
+    const unsigned mw = mw_next >> (4 * hh);   // this half wave's keys are 8 g + 4 hh + e
+    mw_next = mask_word(step + 1);
+    if (live) {
+      // this wave's 64 band rows: blocks FW - 1 - wave + step and the next
+      const T* Bs0 = ring + ((FW - 1 - wave + step) % NRING) * 32 * LD;
+      const T* Bs1 = ring + ((FW - wave + step) % NRING) * 32 * LD;
+      f32x16 s, g0, g1;
+      zero16(s); zero16(g0); zero16(g1);
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        g0 = M_::mma(M_::load_kc(Bs0, LD, 0, kk * M_::KSTEP, lane), qv[kk], g0);   // g[c][i]
+        g1 = M_::mma(M_::load_kc(Bs1, LD, 0, kk * M_::KSTEP, lane), qv[kk], g1);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // accumulator registers 4 q .. 4 q + 3 are band columns 8 q + 4 hh + 0 .. 3 of query il
+        *reinterpret_cast<f32x4*>(Gs + il * LDG + 8 * q + 4 * hh) = f32x4{g0[4 * q], g0[4 * q + 1], g0[4 * q + 2], g0[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(Gs + il * LDG + 32 + 8 * q + 4 * hh) = f32x4{g1[4 * q], g1[4 * q + 1], g1[4 * q + 2], g1[4 * q + 3]};
+      }
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) s = M_::mma(M_::load_kc(Ks, LD, 0, kk * M_::KSTEP, lane), qu[kk], s);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] += Gs[il * (LDG - 1) + 31 + c_row(r, lane)];   // G[il][31 - il + key]
+      __builtin_amdgcn_wave_barrier();
+      float mt = -INFINITY;
+      if (j0 + 32 <= kend) {   // (wave-uniform) a tile without masked keys
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] *= c2;
+          mt = fmaxf(mt, s[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] = (j0 + c_row(r, lane) >= kend) ? -INFINITY : s[r] * c2;
+          mt = fmaxf(mt, s[r]);
+        }
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float mn = fmaxf(m, mt);
+      const float mref = (mn == -INFINITY) ? 0.f : mn;
+      const float alpha = __builtin_amdgcn_exp2f(m - mref);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[r] - mref);
+        rs += p;
+        s[r] = p;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l = l * alpha + rs;
+      m = mn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      if (a.drop_p > 0.f) {
+        if (mbits) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            s[r] *= __uint_as_float((unsigned)__builtin_amdgcn_sbfe(mw, 8 * (r >> 2) + (r & 3), 1) & keep_bits);
+        } else {
+          const float keep = 1.f / (1.f - a.drop_p);
+          const uint32_t thr = dropout_thr(a.drop_p);
+          const uint64_t dbase = drop_index(a, b, h, qi, j0 + 4 * hh);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const uint64_t pr = (dbase + (uint64_t)(8 * g)) >> 1;
+            bool k0, k1, k2, k3;
+            dropout_keep2(a.seed, pr, thr, k0, k1);
+            dropout_keep2(a.seed, pr + 1, thr, k2, k3);
+            s[4 * g] *= k0 ? keep : 0.f; s[4 * g + 1] *= k1 ? keep : 0.f;
+            s[4 * g + 2] *= k2 ? keep : 0.f; s[4 * g + 3] *= k3 ? keep : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks)
+          o[dt] = M_::mma(chain_a<T, TR>(Vs, ks, 32 * dt, lane), chain_b<T>(s, ks), o[dt]);
+    }
+    lds_barrier();   // every wave has read the stage
+    stash(step + 1);
+    fetch(step + 2);
+    lds_barrier();   // stage ready
+  }
+  if (!live) return;
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  store_dT<T>((T*)hp.out, a.ldo, i0, a.Tq, o, inv, lane);
+  if (lane < 32 && qval) hp.lse[qi] = l > 0.f ? m * 0.6931471805599453f + __logf(l) : -INFINITY;
+}
+
 // delta[b,h,i] = sum_d dout[b,i,h,d] * out[b,i,h,d]; optionally also Q + pos_bias_u / Q + pos_bias_v as
 // dense [B,Tq,H*DK] tensors (operands of the dK and dpos GEMMs).  8 lanes x 8 elements per (b,i,h) row.
 template <typename T>
@@ -2674,6 +2865,7 @@ int g_tr = 1;
 int g_bwd_split = 1;  // option "attn_bwd_split": the two-pass backward (attn_bwd_kv_kernel + attn_bwd_q_kernel); 0 = the single-pass kernel
 int g_fused_fw = 0;  // key tiles per workgroup of the single-pass backward (0 = by grid size; emoasr_set_option "attn_fw")
 
+int g_fwd4 = 1;       // option "attn_fwd4": the block-staged forward (attn_fwd4_kernel) for the training launches
 int g_fwd_split = 1;  // option "attn_fwd_split": key split for small launches
 int g_fwd_waves = 0;  // option "attn_fwd_waves": waves per workgroup of attn_fwd_kernel (0 = 1 for stacked launches, else 4)
 int g_attn_xcd = 1;   // option "attn_xcd": stacked forward / fused-backward launches keep a (head, utterance) group on one XCD
@@ -2723,6 +2915,27 @@ int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
     int dev = 0;
     hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  // training launches (bf16, relative positions, plain masks): the block-staged kernel, four query tiles per workgroup
+  if constexpr (std::is_same<TK, bf16>::value) {
+    constexpr int FW = 4;
+    const long ntile = (long)cdiv(a.Tq, 32) * a.H * a.B;
+    if (g_fwd4 && a.pos && !a.causal && !a.st && a.Tq == a.Tk && ((a.Tq >= 64 && ntile > 4L * n_cu) || g_fwd4 == 2)) {   // (option value 2: whenever eligible -- tests)
+      dim3 g4(cdiv(a.Tq, 32 * FW), a.H, a.B);
+      const int nt4 = (g_attn_xcd && a.nseg > 1) ? (int)g4.x : 0;
+      if (nt4) g4 = dim3(8 * cdiv(a.H * a.B, 8) * nt4, 1, 1);
+      emo_timer_begin(EMO_TIMER_ATTN_FWD, s);
+      if (g_tr) {
+        if (set_smem(attn_fwd4_kernel<true, FW>, Fwd4Cfg<FW>::smem())) return 1;
+        attn_fwd4_kernel<true, FW><<<g4, 64 * FW, Fwd4Cfg<FW>::smem(), s>>>(a, nt4);
+      } else {
+        if (set_smem(attn_fwd4_kernel<false, FW>, Fwd4Cfg<FW>::smem())) return 1;
+        attn_fwd4_kernel<false, FW><<<g4, 64 * FW, Fwd4Cfg<FW>::smem(), s>>>(a, nt4);
+      }
+      emo_timer_end(EMO_TIMER_ATTN_FWD, s);
+      EMO_LAUNCH_CHECK();
+      return 0;
+    }
   }
   const bool split = g_fwd_split && a.nseg <= 1 && !a.st && (long)cdiv(a.Tq, 32) * a.H * a.B <= 2L * n_cu;
   const int ks = split ? 4 : 1;
@@ -3198,6 +3411,7 @@ int emo_attn_bwd_prelaunch(int dtype, const emoasr_attn_t* a_in, void* ws, size_
 void emo_attn_set_tr_read(int v) { g_tr = v; }
 void emo_attn_set_lpt(int v) { g_attn_lpt = v; }
 void emo_attn_set_fwd_split(int v) { g_fwd_split = v; }
+void emo_attn_set_fwd4(int v) { g_fwd4 = v; }
 void emo_attn_set_xcd(int v) { g_attn_xcd = v; }
 void emo_attn_set_fwd_waves(int v) { g_fwd_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
 void emo_attn_set_bwd_split(int v) { g_bwd_split = v ? 1 : 0; }

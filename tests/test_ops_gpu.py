@@ -572,6 +572,38 @@ def test_attention_keep_mask_bits_equal_the_inline_hash(dev, dtype):
         _close(res[1][1], res[0][1], 1e-3, "dpos with the forward's mask")   # (float atomics: order differs from run to run)
 
 
+@pytest.mark.parametrize("shape", [(3, 150), (2, 33), (5, 257)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_attention_fwd_block_staged_equals_per_wave_kernel(dev, shape, p):
+    """attn_fwd4_kernel (round 6: four query tiles per workgroup share LDS-staged K / V tiles and a ring of position-band blocks)
+    against attn_fwd_kernel (every wave fetches its own fragments): the same MFMA order, soft-max and mask -> outputs and
+    log-sum-exp bit for bit, ragged key lengths and keep-mask bits included"""
+    from emoasr_amd import lib, ops
+    B, T = shape
+    H, D = 4, 256
+    torch.manual_seed(9)
+    qkv = (torch.randn(B, T, 3 * D, device=dev) * 0.5).to(torch.bfloat16)
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    pos = (torch.randn(2 * T - 1, D, device=dev) * 0.5).to(torch.bfloat16)
+    bu, bv = torch.randn(D, device=dev) * 0.1, torch.randn(D, device=dev) * 0.1
+    klens = torch.tensor([max(1, T - 19 * i) for i in range(B)], device=dev, dtype=torch.int32)
+    kw = dict(pos=pos, bias_u=bu, bias_v=bv, klens=klens, drop_p=p, seed=4)
+    mask = ops.attn_dropmask(q, k, H, klens=klens, drop_p=p, seed=4) if p > 0 else None
+    outs = {}
+    try:
+        lib.set_option("attn_fwd_split", 0)   # (small launches of the per-wave kernel split the KEYS over four waves: another summation order)
+        for flag in (0, 2):
+            lib.set_option("attn_fwd4", flag)
+            outs[flag] = [ops.attn_fwd(q, k, v, H, 0.125, **kw), ops.attn_fwd(q, k, v, H, 0.125, keep_mask=mask, **kw)]
+            torch.cuda.synchronize()
+    finally:
+        lib.set_option("attn_fwd4", 1)
+        lib.set_option("attn_fwd_split", 1)
+    for (o0, l0), (o2, l2) in zip(outs[0], outs[2]):
+        assert torch.equal(o0, o2) and torch.equal(l0, l2)
+    assert torch.isfinite(outs[2][0][0].float()).all()
+
+
 @pytest.mark.parametrize("case", ["rel", "plain", "rel_ragged"])
 def test_attention_bwd_fused_vs_materialised(dev, case):
     """The single-pass backward against the materialised one on identical bf16 inputs WITH dropout (same counter-based
