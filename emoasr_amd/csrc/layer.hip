@@ -186,6 +186,27 @@ void emo_layer_set_stack_launch(int v) { g_stack_launch = v; }
 void emo_layer_set_ffn_save_dact(int v) { g_ffn_save_dact = v ? 1 : 0; }
 void emo_layer_set_att_bits(int v) { g_att_bits = v ? 1 : 0; }
 
+extern "C" int emoasr_conformer_attn_masks(int dtype, int nl, const emoasr_segments_t* seg, int B, int T, int H, int d, const int* klens,
+                                           float p_att, const uint64_t* seeds, unsigned* masks, long layer_stride_words, int nw,
+                                           void* stream) {
+  EMO_CHECK(seg && seeds && masks && nl >= 0 && H > 0 && d % H == 0, "conformer_attn_masks: bad arguments");
+  if (p_att <= 0.f) return 0;
+  emoasr_conformer_fwd_t io{};
+  io.B = B; io.T = T; io.seg = *seg;
+  SegView sv;
+  EMO_CHECK(seg_view(&io, d, &sv), "conformer_attn_masks: bad batch / segment shapes");
+  const size_t esz = dtype == EMO_BF16 ? 2 : 4;
+  const int astep = g_stack_launch ? sv.n : 1;
+  for (int l = 0; l < nl; ++l)
+    for (int si = 0; si < sv.n; si += astep) {
+      emoasr_attn_t am{};
+      attn_args_for(am, sv, si, si + astep, H, d, esz, nullptr, nullptr, klens, seeds[l]);
+      am.drop_p = p_att;
+      if (emoasr_attn_dropmask(dtype, &am, masks + (size_t)l * layer_stride_words + (size_t)sv.row[si] * H * nw, nw, stream)) return 1;
+    }
+  return 0;
+}
+
 extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* L,
                                           const emoasr_conformer_fwd_t* io, void* stream) {
   EMO_CHECK(L && io && io->x && io->pos_t, "conformer_layer_fwd: missing arguments");
@@ -200,7 +221,7 @@ extern "C" int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_laye
   // block's products) for the attention forward below and both passes of its backward
   const bool att_bits = g_att_bits && io->att_mask && io->training && io->p_att > 0.f && dtype == EMO_BF16;
   const int astep_m = g_stack_launch ? sv.n : 1;
-  for (int si = 0; si < sv.n && att_bits; si += astep_m) {
+  for (int si = 0; si < sv.n && att_bits && !io->att_mask_ready; si += astep_m) {
     emoasr_attn_t am{};
     attn_args_for(am, sv, si, si + astep_m, H, d, esz, io->qkv, io->pp, io->klens, io->seed[2]);
     am.drop_p = io->p_att;

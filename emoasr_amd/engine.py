@@ -650,6 +650,16 @@ class CTCEngine(_DecoderMixinPlaceholder):
         for b, t in segs:
             rows.append(rows[-1] + b * t)
         M = rows[-1]
+        elens_host = [((v - 1) // 2 - 1) // 2 for v in xlens_all]
+        elens = elens_dev if elens_dev is not None else h2d_i32(elens_host, dev)
+        if self._layer_rt is None:
+            from .layer_rt import ConformerLayerRuntime
+            self._layer_rt = ConformerLayerRuntime(self)
+        Btot, Tmax = sum(b for b, _ in segs), max(t for _, t in segs)
+        # the layers' attention keep masks as bits, all hashed now on the attention's side stream: under the front-end's products
+        masks = None
+        if p_att > 0 and dt == torch.bfloat16 and os.environ.get("EMOASR_MASKS_UPFRONT", "1") != "0":
+            masks = self._layer_rt.hash_attn_masks(self.nl, Btot, Tmax, elens, p_att, tuple(segs))
         y2 = torch.empty(M, F2 * C, device=dev, dtype=dt)
         for k, xs in enumerate(xs_list):
             y1 = ops.conv1_fwd(xs, w1, A.p(pre + "conv.0.bias"), dt)
@@ -658,8 +668,6 @@ class CTCEngine(_DecoderMixinPlaceholder):
         wl = A.p(pre + "output.weight")  # [d, C*F2] channel-major -> [d, F2*C]
         wlr = ops.strided_copy(wl.view(d, C, F2).permute(0, 2, 1), out_dtype=dt).view(d, F2 * C)
         x = ops.gemm_nt(y2, wlr, bias=A.p(pre + "output.bias"))
-        elens_host = [((v - 1) // 2 - 1) // 2 for v in xlens_all]
-        elens = elens_dev if elens_dev is not None else h2d_i32(elens_host, dev)
         s_pe = self._seed(1)
         x = ops.posenc(x.view(1, M, d), None, math.sqrt(d), p_enc, s_pe).view(M, d)
         # every micro-batch has its own relative-position table (rows <-> rel = T-1 ... -(T-1)), dropped out independently
@@ -668,13 +676,10 @@ class CTCEngine(_DecoderMixinPlaceholder):
         if p_enc > 0:
             pos_t = ops.scale_dropout(pos_t, 1.0, p_enc, self._seed(2))
         # ---- encoder layers: one C-ABI call each over the stacked rows ------------------------------------------------
-        if self._layer_rt is None:
-            from .layer_rt import ConformerLayerRuntime
-            self._layer_rt = ConformerLayerRuntime(self)
-        Btot, Tmax = sum(b for b, _ in segs), max(t for _, t in segs)
         cur, layers = x, []
         for li in range(self.nl):
-            cur = self._layer_rt.forward(li, cur, Btot, Tmax, elens, pos_t, p_enc, p_att, True, True, segs=tuple(segs))
+            cur = self._layer_rt.forward(li, cur, Btot, Tmax, elens, pos_t, p_enc, p_att, True, True, segs=tuple(segs),
+                                         att_mask=None if masks is None else masks[li])
             layers.append(cur)
         x_final = cur.tv("y")
         eouts, fin_mean, fin_rstd = ops.layernorm_fwd(x_final, A.p("encoder.norm.weight"), A.p("encoder.norm.bias"), 1e-12, True)
@@ -682,6 +687,7 @@ class CTCEngine(_DecoderMixinPlaceholder):
         st.xs_list, st.y1s, st.y2, st.wlr, st.segs, st.rows, st.M, st.F2 = xs_list, y1s, y2, wlr, segs, rows, M, F2
         st.elens, st.elens_host, st.s_pe, st.layers = elens, elens_host, s_pe, layers
         st.pos_t = pos_t   # (the layers' C structs hold its raw address: it must live until the backward sweep is done)
+        st.att_masks = masks   # (likewise)
         st.x_final, st.fin_mean, st.fin_rstd, st.Btot, st.Tmax = x_final, fin_mean, fin_rstd, Btot, Tmax
         return eouts, st
 

@@ -177,18 +177,38 @@ class ConformerLayerRuntime:
         self.params[li] = (L, guard)
         return L
 
-    def forward(self, li, x, B, T, elens, pos_t, p_enc, p_att, training, keep, segs=None):
-        """x: tensor [B*T, d] or the previous layer's LayerStash.  -> LayerStash (its tv("y") is the output).
-        segs: ((B_0, T_0), ...) -- stacked micro-batches (x has sum B_s T_s rows, pos_t the segments' tables back to back,
-        elens all utterances in order); B / T are then the totals / maximum."""
+    def hash_attn_masks(self, nl, B, T, elens, p_att, segs):
+        """the attention keep masks of all nl layers of one stacked training pass, hashed NOW on the attention's side stream (call
+        before the convolution front-end: the hashing runs under its MFMA-bound products) -> int32 [nl, M * H * nw]; forward() is
+        then given layer li's slice (att_mask=...)"""
         eng = self.eng
-        L = self._layer_params(li)
+        lay = self._layout(B, T, self._layer_params(0).F, segs)
+        masks = torch.empty(nl, lay.M * eng.h * lay.mask_nw, device=elens.device, dtype=torch.int32)
+        seeds = (ctypes.c_uint64 * nl)(*[eng._seed(100 + li * 20 + 2) for li in range(nl)])
+        seg = lib.Segments()
+        seg.n = len(segs)
+        for k, (sb, stt) in enumerate(segs):
+            seg.B[k], seg.T[k] = sb, stt
+        lib.call("emoasr_conformer_attn_masks", lib.BF16, nl, ctypes.byref(seg), B, T, eng.h, eng.d, elens.data_ptr(), p_att, seeds,
+                 masks.data_ptr(), masks.stride(0), lay.mask_nw, ops._stream())
+        return masks
+
+    def _layout(self, B, T, F, segs):
         key = (B, T) if segs is None else tuple(segs)
         lay = self.layouts.get(key)
         if lay is None:
             if len(self.layouts) > 64:
                 self.layouts.clear()
-            lay = self.layouts[key] = _Layout(B, T, eng.d, eng.h, L.F, segs)
+            lay = self.layouts[key] = _Layout(B, T, self.eng.d, self.eng.h, F, segs)
+        return lay
+
+    def forward(self, li, x, B, T, elens, pos_t, p_enc, p_att, training, keep, segs=None, att_mask=None):
+        """x: tensor [B*T, d] or the previous layer's LayerStash.  -> LayerStash (its tv("y") is the output).
+        segs: ((B_0, T_0), ...) -- stacked micro-batches (x has sum B_s T_s rows, pos_t the segments' tables back to back,
+        elens all utterances in order); B / T are then the totals / maximum."""
+        eng = self.eng
+        L = self._layer_params(li)
+        lay = self._layout(B, T, L.F, segs)
         dev = pos_t.device
         wt = torch.empty(lay.nt, device=dev, dtype=eng.dtype)
         wf = torch.empty(lay.nf, device=dev, dtype=torch.float32)
@@ -224,7 +244,10 @@ class ConformerLayerRuntime:
             setattr(io, k, tb + t[k][0] * esz)
         io.lse = fb + f["lse"][0] * 4
         if training and p_att > 0 and wt.dtype == torch.bfloat16:
-            io.att_mask, io.att_mask_nw = fb + f["att_mask"][0] * 4, lay.mask_nw
+            if att_mask is not None:   # hashed up front for all layers (hash_attn_masks)
+                io.att_mask, io.att_mask_nw, io.att_mask_ready = att_mask.data_ptr(), lay.mask_nw, 1
+            else:
+                io.att_mask, io.att_mask_nw = fb + f["att_mask"][0] * 4, lay.mask_nw
         io.bmean, io.bvar, io.bn_part = fb + f["bmean"][0] * 4, fb + f["bvar"][0] * 4, fb + f["bn_part"][0] * 4
         if keep:
             io.ffm.mean, io.ffm.rstd = fb + f["ffm_mean"][0] * 4, fb + f["ffm_rstd"][0] * 4

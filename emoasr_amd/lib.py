@@ -172,7 +172,7 @@ class ConformerFwd(Structure):
                 ("cv_y", c_void_p), ("bmean", c_void_p), ("bvar", c_void_p), ("bn_part", c_void_p),
                 ("cv_mean", c_void_p), ("cv_rstd", c_void_p),
                 ("y", c_void_p), ("fin_mean", c_void_p), ("fin_rstd", c_void_p), ("seg", Segments),
-                ("att_mask", c_void_p), ("att_mask_nw", c_int)]
+                ("att_mask", c_void_p), ("att_mask_nw", c_int), ("att_mask_ready", c_int)]
 
 class ConformerBwd(Structure):
     _fields_ = [("dy", c_void_p), ("dx", c_void_p), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t),
@@ -202,6 +202,7 @@ SIGNATURES = {
     "emoasr_layernorm_bwd_ex": [I, I, I, P, P, P, P, P, P, P, P, P, P, POINTER(LnBwdOpts), P],
     "emoasr_layernorm_bwd_finalize": [I, POINTER(LnFinalizeItem), P],
     "emoasr_conformer_layer_fwd": [I, POINTER(ConformerLayer), POINTER(ConformerFwd), P],
+    "emoasr_conformer_attn_masks": [I, I, POINTER(Segments), I, I, I, I, P, F, P, P, L, I, P],
     "emoasr_conformer_layer_bwd": [I, POINTER(ConformerLayer), POINTER(ConformerLayer), POINTER(ConformerFwd),
                                    POINTER(ConformerBwd), P],
     "emoasr_transformer_decoder_infer": [I, I, POINTER(DecoderLayer), POINTER(DecoderInfer), P],

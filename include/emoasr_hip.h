@@ -652,7 +652,15 @@ typedef struct emoasr_conformer_fwd {
    * attention's side stream, under the macaron feed-forward block) and the attention forward and both backward passes test bits
    * (emoasr_attn_t::keep_mask); it is part of the stash the backward takes.  NULL: every kernel hashes for itself. */
   unsigned* att_mask; int att_mask_nw;
+  int att_mask_ready;                /* 1: att_mask already holds (or is being filled on the attention's side stream with) this layer's
+                                      * bits -- emoasr_conformer_attn_masks hashed all layers' masks at the start of the pass */
 } emoasr_conformer_fwd_t;
+/* The attention keep masks of ALL nl layers of an encoder pass, hashed up front on the attention's side stream (forked from
+ * `stream` here): called before the convolution front-end, the ~0.05 ms of integer hashing per layer run under its MFMA-bound
+ * products instead of beside each layer's memory-bound kernels.  seeds[l] = the layer's att_probs dropout stream (seed[2] of its
+ * emoasr_conformer_fwd_t); masks + l * layer_stride_words = its att_mask [M, H, nw]. */
+int emoasr_conformer_attn_masks(int dtype, int nl, const emoasr_segments_t* seg, int B, int T, int H, int d, const int* klens,
+                                float p_att, const uint64_t* seeds, unsigned* masks, long layer_stride_words, int nw, void* stream);
 int emoasr_conformer_layer_fwd(int dtype, const emoasr_conformer_layer_t* layer,
                                const emoasr_conformer_fwd_t* io, void* stream);
 /* Backward of the same layer (training-mode forward with stash) as one call: gradient kernels in the order the

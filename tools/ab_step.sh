@@ -7,7 +7,15 @@ run() {  # $1 = option string
   local opts="$1" libv=""
   if [[ "$opts" == lib:* ]]; then libv="${opts%%,*}"; libv="${libv#lib:}"; opts="${opts#lib:$libv}"; opts="${opts#,}"; fi
   [ "$opts" = "-" ] && opts=""
-  ( [ -n "$libv" ] && export EMOASR_HIP_LIB=$GRAFT_REPO_ROOT/emoasr_amd/build/libemoasr_hip_$libv.so
+  # items in capitals are environment variables of the Python side (NAME=value), the rest library options
+  local envs="" lo=""
+  IFS=',' read -ra items <<< "$opts"
+  for it in "${items[@]}"; do
+    if [[ "$it" =~ ^[A-Z_0-9]+= ]]; then envs="$envs $it"; else lo="${lo:+$lo,}$it"; fi
+  done
+  opts="$lo"
+  ( [ -n "$envs" ] && export $envs
+    [ -n "$libv" ] && export EMOASR_HIP_LIB=$GRAFT_REPO_ROOT/emoasr_amd/build/libemoasr_hip_$libv.so
     EMOASR_OPTIONS="$opts" python3 bench.py --steps 10 --warmup 3 --no-decode --no-cpu-baseline 2>/dev/null |
     python3 -c "import json,sys;d=json.loads(sys.stdin.read());f=d['families'];print('%.3f ms/step  %.3f M/s  '%(d['ms_per_step'],d['value']/1e6)+' '.join('%s %.2f'%(k.replace('_kernel',''),v['ms']) for k,v in f.items() if isinstance(v,dict)))" )
 }
