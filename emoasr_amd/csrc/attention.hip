@@ -2254,7 +2254,7 @@ template <typename T, int FW> struct SplitCfg {
   static constexpr int ROWC_BYTES = 64 * 4 + FW * 32 * 4;   // KV pass: lse * log2(e), delta and the waves' keep-mask words of the step's 32 queries
   static constexpr int RING_BLOCKS = FW + 2;         // KV pass: the band as a ring of 32-row blocks (FW + 1 in use, one being refilled)
   static constexpr int kv_rows(bool rel) { return rel ? 96 + 32 * RING_BLOCKS : 64; }   // Q+u, Q+v, dO, band ring | Q, dO
-  static constexpr int q_rows(bool rel) { return rel ? 64 + BAND_ROWS : 64; }    // K, V, band | K, V
+  static constexpr int q_rows(bool rel) { return rel ? 64 + 32 * RING_BLOCKS : 64; }    // K, V, band ring | K, V
   static constexpr int kv_stage_bytes(bool rel) { return kv_rows(rel) * LD * (int)sizeof(T) + ROWC_BYTES; }
   static constexpr int q_stage_bytes(bool rel) { return q_rows(rel) * LD * (int)sizeof(T); }
   static constexpr int wave_bytes(bool rel) { return rel ? GS_BYTES : 256; }
@@ -2567,8 +2567,8 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
   constexpr int NK = AttnCfg<T>::NK, NS = AttnCfg<T>::NS, LD = C_::LD, LDG = C_::LDG;
   constexpr int VEC = 16 / sizeof(T), PER_ROW = DK / VEC;
   constexpr int NTHR = 64 * FW;
-  constexpr int NROWS = C_::q_rows(REL), NPIECE = NROWS * PER_ROW, PPT = NPIECE / NTHR;
-  static_assert(NPIECE % NTHR == 0, "staging pieces must divide evenly");
+  constexpr int PPT = REL ? 3 : 2, NRING = C_::RING_BLOCKS;   // K, V and (relative positions) the ONE band block a step adds: the
+  static_assert(NTHR / PER_ROW == 32, "one piece per thread covers one 32-row tile");   // band is a ring (see attn_bwd_kv_kernel)
   static_assert(sizeof(T) == 2, "the two-pass backward is bf16 only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, hh = lane >> 5;
@@ -2609,9 +2609,8 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
                                rsP = make_rsrc_n(REL ? hp.pos : hp.k, REL ? (unsigned)(2 * a.Tq - 2) * pstride + DK * 2u : 0u);
   const int nstep = (hp.klen + 31) / 32;   // key tiles with at least one valid key
 
-  constexpr int RPP = NTHR / PER_ROW;
-  static_assert(32 % RPP == 0, "a piece index must stay inside one 32-row operand tile");
   Vec16<T> pre[PPT];
+  T* ring = stage0 + 64 * LD;   // (REL) block n = table rows Tq - 32 FW - iblk + 32 n + [0, 32) in slot n mod NRING
   const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
   const unsigned k_lane = (unsigned)trow * kstride + (unsigned)piece * 2u, v_lane = (unsigned)trow * vstride + (unsigned)piece * 2u;
   // band rows of the block's 32 FW queries against key tile j0: r = Tq - 32 FW - iblk + j0 + t, t in [0, 32 FW + 32)
@@ -2620,21 +2619,14 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
     const int j0 = step * 32;
     const unsigned dead = step < nstep ? 0u : 0x80000000u;   // behind the last key tile: nothing is read
     const unsigned ko = (k_lane + (unsigned)j0 * kstride) | dead, vo = (v_lane + (unsigned)j0 * vstride) | dead;
-    const unsigned po = (p_lane + (unsigned)j0 * pstride) | dead;
-#pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const int srow = p * RPP;
-      if (srow < 32) pre[p] = buf_load16<T>(rsK, ko + (unsigned)srow * kstride);
-      else if (srow < 64) pre[p] = buf_load16<T>(rsV, vo + (unsigned)(srow - 32) * vstride);
-      else pre[p] = buf_load16<T>(rsP, po + (unsigned)(srow - 64) * pstride);
-    }
+    pre[0] = buf_load16<T>(rsK, ko);
+    pre[1] = buf_load16<T>(rsV, vo);
+    if constexpr (REL) pre[2] = buf_load16<T>(rsP, (p_lane + (unsigned)(j0 + 32 * FW) * pstride) | dead);   // block step + FW
   };
-  auto stash = [&]() {
-#pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const int pid = tid + NTHR * p;
-      store16(stage0 + (pid / PER_ROW) * LD + (pid % PER_ROW) * VEC, pre[p]);
-    }
+  auto stash = [&](const int step) {
+    store16(stage0 + trow * LD + piece, pre[0]);
+    store16(stage0 + (32 + trow) * LD + piece, pre[1]);
+    if constexpr (REL) store16(ring + (((step + FW) % NRING) * 32 + trow) * LD + piece, pre[2]);
   };
 
   // ---- stationary operands of this wave's query tile (B operands: query on the lane) ---------------------------
@@ -2653,8 +2645,12 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
   }
   f32x16 dq[2];
   zero16(dq[0]); zero16(dq[1]);
+  if constexpr (REL) {   // blocks 0 .. FW - 1 of step 0 (block FW comes with fetch(0))
+#pragma unroll
+    for (int n = 0; n < FW; ++n) store16(ring + (n * 32 + trow) * LD + piece, buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride));
+  }
   fetch(0);
-  stash();
+  stash(0);
   fetch(1);
   __syncthreads();
   const float c_exp = a.scale * 1.4426950408889634f;
@@ -2673,7 +2669,9 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
     const int j0 = step * 32;
     const T* Ks = stage0;
     const T* Vs = stage0 + 32 * LD;
-    const T* Bs = stage0 + (64 + 32 * (FW - 1 - wave)) * LD;  // this wave's 64 band rows (REL)
+    // this wave's 64 band rows (REL): blocks FW - 1 - wave + step and the next
+    const T* Bs0 = ring + ((FW - 1 - wave + step) % NRING) * 32 * LD;
+    const T* Bs1 = ring + ((FW - wave + step) % NRING) * 32 * LD;
     const unsigned mw = mw_next >> (4 * hh);   // this half wave's keys are 8 g + 4 hh + e
     mw_next = mask_word(step + 1);
     EMO_STAMP(0);
@@ -2685,8 +2683,8 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
         zero16(g0); zero16(g1);
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
-          g0 = M_::mma(M_::load_kc(Bs, LD, 0, kk * M_::KSTEP, lane), fqv[kk], g0);   // g[c][i]
-          g1 = M_::mma(M_::load_kc(Bs + 32 * LD, LD, 0, kk * M_::KSTEP, lane), fqv[kk], g1);
+          g0 = M_::mma(M_::load_kc(Bs0, LD, 0, kk * M_::KSTEP, lane), fqv[kk], g0);   // g[c][i]
+          g1 = M_::mma(M_::load_kc(Bs1, LD, 0, kk * M_::KSTEP, lane), fqv[kk], g1);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {   // accumulator registers 4 q .. 4 q + 3 are band columns 8 q + 4 hh + 0 .. 3 of query il
@@ -2765,7 +2763,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
             const typename M_::Frag dg = M_::load_kc(img_g, LDG, 0, 32 * ct + ks * M_::KSTEP, lane);  // dG^T[c][i], c contiguous
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-              dq[dt] = M_::mma(M_::template load_km<TR>(Bs + 32 * ct * LD, LD, ks * M_::KSTEP, 32 * dt, lane), dg, dq[dt]);
+              dq[dt] = M_::mma(M_::template load_km<TR>(ct ? Bs1 : Bs0, LD, ks * M_::KSTEP, 32 * dt, lane), dg, dq[dt]);
           }
         __builtin_amdgcn_wave_barrier();   // the image has been read: the region takes the next step's skew tile
       }
@@ -2773,7 +2771,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
     EMO_STAMP(5);
     lds_barrier();   // every wave has read the stage
     EMO_STAMP(6);
-    stash();
+    stash(step + 1);
     EMO_STAMP(7);
     fetch(step + 2);
     EMO_STAMP(8);
