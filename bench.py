@@ -90,7 +90,7 @@ def cpu_model():
 # kernel families timed inside the library (emoasr_timer_read_ex); value: the kernel-table symbol(s) of profiles/*_kernel_stats.csv
 FAMILIES = {"gemm_nt_nn": "gemm_nt_kernel / gemm_nn (big_nt_kernel for wide products): forward and data-gradient products",
             "gemm_tn": "gemm_tn_grouped_kernel / gemm_tn_kernel: weight gradients",
-            "attn_bwd_fused_kernel": "attn_dropmask_kernel + attn_bwd_kv_kernel + attn_bwd_q_kernel (the two-pass backward; the family keeps its round-2 timer name)", "attn_bwd_dpos2_kernel": "attn_bwd_dpos2_kernel",
+            "attn_bwd_fused_kernel": "attn_bwd_kv_kernel + attn_bwd_q_kernel (the two-pass backward; the family keeps its round-2 timer name; the keep-mask bits are hashed up front by attn_dropmask_kernel on the side stream)", "attn_bwd_dpos_kernel": "attn_bwd_dpos3_kernel (position-table gradient, side stream)",
             "attn_fwd_kernel": "attn_fwd_kernel", "layernorm": "ln_fwd_kernel + ln_bwd8_kernel",
             "conv_module": "cf_dwconv / bn_* / cf_conv_bwd kernels (convolution module, per-utterance part)"}
 RIDGE_FLOP_PER_BYTE = 2500e12 / 8000e9  # bf16 dense MFMA peak / HBM peak
@@ -109,7 +109,7 @@ def family_table(emo_lib, attn_work, elapsed_s=None):
             fl = attn_work[0]
         elif name == "attn_bwd_fused_kernel":
             fl = attn_work[1]
-        elif name == "attn_bwd_dpos2_kernel":
+        elif name == "attn_bwd_dpos_kernel":
             fl = attn_work[2]
         row = {"calls": calls, "ms": ms, "avg_us": 1e3 * ms / calls}
         if fl:
@@ -751,10 +751,37 @@ def main():
         unit = 2.0 * DK_ * H_ * pairs * NL_
         return 3 * unit, 7 * unit, 1 * unit
 
+    def analytic_families(group, nparams):
+        """algorithmic GFLOP / GB per optimizer step of the kernel families that the library's timers do not cover (they carry no
+        work counters): formulas of DESIGN.md section 4.2, evaluated on the micro-batch shapes of the instrumented step.  The rows
+        of DESIGN.md section 4.1 (tools/evidence_table.py) divide them by the kernel table's times."""
+        C, V, d = L2["enc_hidden_size"], L2["vocab_size"], L2["enc_hidden_size"]
+        fe_fl = fe_by = ctc_fl = ctc_by = aux_fl = aux_by = 0.0
+        for bt in group:
+            B, T = len(bt.xlens), max(bt.xlens)
+            T1, F1 = (T - 3) // 2 + 1, (80 - 3) // 2 + 1
+            T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+            y1, y2, M = B * T1 * F1 * C * 2.0, B * T2 * F2 * C * 2.0, B * T2
+            # Conv2d(1 -> C) forward + weight gradient (VALU), Conv2d(C -> C) forward / data gradient / weight gradient (MFMA)
+            fe_fl += 2 * (2.0 * B * T1 * F1 * C * 9) + 3 * (2.0 * B * T2 * F2 * C * 9 * C)
+            fe_by += (B * T * 80 * 4.0 + y1) * 2 + (y1 + y2) + (y2 + 2 * y1) + (y1 + y2)
+            # vocabulary head (logits stored once, read by the gradient kernel, gradient rows written) + its soft-max partials
+            ctc_fl += 2.0 * M * V * d
+            ctc_by += 3.0 * M * V * 2 + M * d * 2.0
+            # attention side kernels of the 12 layers: keep-mask words written, Q + bias copies / delta, the table gradient
+            # (dS image read once + (Q+v) rows; 1 product of 2 DK flop per (query, key, head) pair over the PADDED square)
+            nw = (T2 + 31) // 32
+            aux_fl += NL_ * 2.0 * DK_ * H_ * B * T2 * T2
+            aux_by += NL_ * (M * H_ * nw * 4.0 + 5 * M * d * 2.0 + M * H_ * 4.0 + B * H_ * T2 * T2 * 2.0 + M * d * 2.0)
+        return {"front_end_conv2d": {"gflop": fe_fl / 1e9, "gbytes": fe_by / 1e9},
+                "ctc_head_loss": {"gflop": ctc_fl / 1e9, "gbytes": ctc_by / 1e9},
+                "attention_aux_side_stream": {"gflop": aux_fl / 1e9, "gbytes": aux_by / 1e9},
+                "optimizer": {"gflop": 0.0, "gbytes": nparams * 32.0 / 1e9}}
+
     # warm-up; the LAST warm-up step is instrumented (every kernel family timed inside the library with HIP events on the launch
     # stream): it gives the per-family table and picks the dominant family, which alone is then timed over the timed region
     breakdown = None
-    families = {}
+    families, families_analytic = {}, {}
     for i in range(args.warmup):
         if i == args.warmup - 1:
             sync()
@@ -773,6 +800,7 @@ def main():
             t_w = time.perf_counter() - t_w
             emo_lib.set_option("timers", 0)
             families = family_table(emo_lib, attn_work(attn_pairs(batches[i])), t_w)
+            families_analytic = analytic_families(batches[i], sum(p.numel() for p in model.parameters()))
         else:
             step(batches[i])
     # the roofline object is about ONE kernel family, chosen at run time: the one with the most device time in the instrumented
@@ -889,6 +917,8 @@ def main():
             res["roofline"] = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": None, "traffic": None, "launches": 0}
         res["families"] = {"step": "the last warm-up step, every family timed (HIP events inside the library)", **families}
+        res["families_analytic"] = {"what": "algorithmic GFLOP / GB per optimizer step of the families without in-library counters "
+                                            "(formulas: bench.py analytic_families; times: the kernel table)", **families_analytic}
         if args.breakdown and breakdown:
             tot = sum(v["ms"] for v in breakdown.values())
             for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]):

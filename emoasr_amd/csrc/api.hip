@@ -94,7 +94,7 @@ void emo_attn_set_fwd_waves(int v);
 // off by default: emoasr_set_option("timers", 1))
 #include <vector>
 namespace {
-const char* const kTimerNames[EMO_TIMER_COUNT] = {"attn_bwd_fused_kernel", "attn_bwd_dpos2_kernel", "attn_fwd_kernel",
+const char* const kTimerNames[EMO_TIMER_COUNT] = {"attn_bwd_fused_kernel", "attn_bwd_dpos_kernel", "attn_fwd_kernel",
                                                   "gemm_tn_grouped_kernel", "gemm_nt_nn", "gemm_tn", "layernorm", "conv_module"};
 struct TimerRec { hipEvent_t e0, e1; double flops, bytes; bool ended; };
 std::vector<TimerRec> g_rec[EMO_TIMER_COUNT];

@@ -1608,7 +1608,7 @@ __global__ __launch_bounds__(256) void attn_dbias_v_kernel(const emoasr_attn_t a
 //     stores (LDS float atomics measured ~170 cycles per wave-instruction, global float atomics would make dQ depend on
 //     arrival order: bf16 rounding flips of dQ then propagate through every layer below); the finalize pass adds the key
 //     blocks' partials in block order, so dQ is bit-reproducible;
-//   * dS (query-major, bf16) is stored for attn_bwd_dpos2_kernel, which walks its diagonals: dpos[r] = sum_{b,i}
+//   * dS (query-major, bf16) is stored for attn_bwd_dpos3_kernel, which walks its diagonals: dpos[r] = sum_{b,i}
 //     dS[b,i,i-(Tq-1)+r] (Q+v)[b,i].  dbias_v = colsum(dQ) - dbias_u: the flush also sums the dQ rows it stores.
 // ====================================================================================
 
@@ -1627,7 +1627,7 @@ struct FusedWs {       // workspace carved by emoasr_attn_bwd_fused
 };
 
 // prologue: delta[b,h,i] = dO.O, dense Q+u / Q+v.  8 lanes x 8 elements per (b,i,h) row.
-// zero / zn: optional f32 buffer cleared on the side (the position-table gradient that attn_bwd_dpos2_kernel accumulates into:
+// zero / zn: optional f32 buffer cleared on the side (the position-table gradient that attn_bwd_dpos3_kernel accumulates into:
 // saves the separate memset launch of the per-layer backward)
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t a, T* __restrict__ qu, T* __restrict__ qv,
@@ -2103,7 +2103,7 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
 // utterances it visits and the workgroup leaves with one 16 KB atomic flush.  Per tile: the dS tile (2 KB) and the (Q+v) tile
 // (4 KB) arrive by 16-byte loads one item ahead; the dS tile sits in wave-private LDS between two zero-filled 32-column wings, so
 // the skewed operand dG^T[c][i] = dS[i][c + i - 31] is 32 two-byte LDS reads at COMPILE-TIME offsets from one per-lane base (the
-// wings supply the zeros of the band's corners); (Q+v) is read k-major with transposing reads.  attn_bwd_dpos2_kernel gathered
+// wings supply the zeros of the band's corners); (Q+v) is read k-major with transposing reads.  the round 2-5 kernel (attn_bwd_dpos2_kernel) gathered
 // the diagonal elements from global memory with two-byte loads: 84 non-matrix instructions per MFMA, 141 us per layer launch at
 // the bench's shapes (profiles/r05_attn_counters.txt).
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -2236,7 +2236,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dpos3_kernel(const emoasr_attn_t
 //   attn_bwd_q_kernel   query-stationary, S^T[key][query] with the QUERY on the lane: dS^T chains into dQ^T += K^T dS^T, the band
 //                       part through the un-skewed dG image (as before); dQ is complete in ONE workgroup and is stored once, in the
 //                       compute dtype: no partial slabs, no finalize pass, bit-reproducible.  Writes the dS image the position-table
-//                       gradient (attn_bwd_dpos2_kernel) walks.
+//                       gradient (attn_bwd_dpos3_kernel) walks.
 // Both: 4 waves per workgroup, the per-step operand tiles staged once per workgroup (registers one step ahead -> LDS), 65-70 KB
 // of LDS and <= 256 registers: TWO workgroups per CU, two waves per SIMD -- one wave's soft-max / dropout VALU work runs under
 // the other's MFMAs and LDS round trips.
@@ -2811,7 +2811,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fin_kernel(const long rows, cons
                                                            const float* __restrict__ cast_src, T* __restrict__ cast_dst,
                                                            const long cast_n, const FinSegs sg) {
   // on the side: the finished f32 position-table gradient rounded to the compute dtype for its weight-gradient product
-  // (this launch follows attn_bwd_dpos2_kernel; saves the separate cast launch of the per-layer backward)
+  // (this launch follows attn_bwd_dpos3_kernel; saves the separate cast launch of the per-layer backward)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < cast_n; i += (long)gridDim.x * 256) cast_dst[i] = from_f32<T>(cast_src[i]);
   const int ngrp = ncol / 8, rpb = 256 / ngrp;  // column groups of 8, rows per pass
   const int cg = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;

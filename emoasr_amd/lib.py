@@ -382,7 +382,7 @@ def timer_read(name, reset=True):
     return calls.value, ms.value
 
 
-TIMER_FAMILIES = ("attn_bwd_fused_kernel", "attn_bwd_dpos2_kernel", "attn_fwd_kernel", "gemm_tn_grouped_kernel", "gemm_nt_nn",
+TIMER_FAMILIES = ("attn_bwd_fused_kernel", "attn_bwd_dpos_kernel", "attn_fwd_kernel", "gemm_tn_grouped_kernel", "gemm_nt_nn",
                   "gemm_tn", "layernorm", "conv_module")
 
 

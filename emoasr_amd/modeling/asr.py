@@ -5,9 +5,12 @@
     hyps, scores, logits, aligns = model.decode(xs, xlens, beam_width=1)
 
 `compute_dtype`: torch.bfloat16 (throughput mode; f32 accumulation, statistics and lattices),
-torch.float32 (parity mode: exact-f32 MFMA) or "f32x3" (f32 storage, every matrix product as three bf16
+torch.float32 (exact mode: f32 MFMA) or "f32x3" (f32 storage, every matrix product as three bf16
 MFMAs over (hi, lo) operand pairs: 16 significand bits per operand -- meets the 1e-3 bars of the reference
-comparison at several times the exact mode's speed; csrc/gemm.hip SplitCfg).
+comparison at 1.6-1.7 x the exact mode's training rate, 0.37 of the bf16 rate; csrc/gemm.hip SplitCfg).  The constructor
+logs ONE line naming the mode and its measured distance from the reference arithmetic (MODE_NOTES): the default, bf16, is
+BASELINE.json's benchmark mode and is OUTSIDE north_star's 1e-3 / bit-exact-ids tolerance -- a caller who swaps the import
+for parity passes compute_dtype="f32x3".
 """
 import logging
 
@@ -19,6 +22,18 @@ from .encoders.transformer import TransformerEncoder
 
 
 F32X3 = "f32x3"   # compute_dtype of the split mode (see the module docstring)
+
+# what a constructor call is told about its mode: measured at the full L2 size against oracle/model.py
+# (tests/test_fullsize_gpu.py::test_full_model_against_oracle, test_bench_sized_batch_against_oracle)
+MODE_NOTES = {
+    "bf16": "compute_dtype=bf16 (the benchmark's mode): logits within 1.3e-2 of their range of the f32 reference, greedy CTC frames agree "
+            "0.96-0.98 on random-init weights (identical hypotheses on fitted weights) -- OUTSIDE the 1e-3 / bit-exact-ids tolerance; "
+            "pass compute_dtype='f32x3' for parity",
+    "f32x3": "compute_dtype='f32x3': f32 storage, split-bf16 products -- loss 2e-7, logits 9e-6 of range, greedy ids bit-exact against "
+             "the f32 reference (inside the 1e-3 tolerance) at 0.37 of the bf16 training rate",
+    "f32": "compute_dtype=float32: exact f32 MFMA chains -- loss / logits 1e-6 of the f32 reference, greedy ids bit-exact, at 0.22 of "
+           "the bf16 training rate",
+}
 
 
 class ASR(nn.Module):
@@ -50,6 +65,7 @@ class ASR(nn.Module):
         self._engine = None
         n = sum(p.numel() for p in self.parameters())
         logging.info(f"ASR model #parameters: {n}")
+        logging.info("emoasr_amd: " + MODE_NOTES["f32x3" if self.f32_split else ("bf16" if self.compute_dtype == torch.bfloat16 else "f32")])
 
     @property
     def compute_dtype(self):

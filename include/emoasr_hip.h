@@ -52,7 +52,7 @@ int emoasr_version(void);
  * "timers" (see emoasr_timer_read) */
 int emoasr_set_option(const char* name, int value);
 /* Device time of selected kernels that sit behind composite entry points, measured with HIP events on the launch stream
- * while emoasr_set_option("timers", 1) is in effect.  name: "attn_bwd_fused_kernel", "attn_bwd_dpos2_kernel",
+ * while emoasr_set_option("timers", 1) is in effect.  name: "attn_bwd_fused_kernel", "attn_bwd_dpos_kernel",
  * "attn_fwd_kernel", "gemm_tn_grouped_kernel".  -> number of launches recorded and their summed milliseconds
  * (synchronises on the recorded events); reset != 0 clears the record.  bench.py's roofline object reads this. */
 int emoasr_timer_read(const char* name, int* calls, double* ms, int reset);
@@ -60,7 +60,7 @@ int emoasr_timer_read(const char* name, int* calls, double* ms, int reset);
  * was called; 0 where the library cannot know it).  Families: "gemm_nt_nn" (emoasr_gemm_nt + emoasr_gemm_nn, forward and
  * data-gradient products), "gemm_tn" (emoasr_gemm_tn + _grouped, weight gradients), "layernorm" (forward + backward),
  * "conv_module" (emoasr_conv_module_fwd_seg / _bwd_seg), and the kernels named above.  "timers" = 1 records every family, a
- * bit mask 1 << (index + 1) only the chosen ones (index = position in this list: attn_bwd_fused_kernel 0, attn_bwd_dpos2_kernel
+ * bit mask 1 << (index + 1) only the chosen ones (index = position in this list: attn_bwd_fused_kernel 0, attn_bwd_dpos3_kernel
  * 1, attn_fwd_kernel 2, gemm_tn_grouped_kernel 3, gemm_nt_nn 4, gemm_tn 5, layernorm 6, conv_module 7).  Option
  * "timer_stride" = n records every n-th launch of a family only (an event pair per launch costs device time). */
 int emoasr_timer_read_ex(const char* name, int* calls, double* ms, double* flops, double* bytes, int reset);

@@ -33,7 +33,7 @@ def family(name):
         return "front-end Conv2d" if m and m.group(3) == "1" else "weight gradients"
     if "attn_bwd_q" in n or "attn_bwd_kv" in n:
         return "attention bwd (kv + q pass)"
-    if "attn_bwd_dpos2" in n or "attn_dropmask" in n or "attn_bwd_prep" in n or "attn_cast" in n:
+    if "attn_bwd_dpos" in n or "attn_dropmask" in n or "attn_bwd_prep" in n or "attn_cast" in n:
         return "attention bwd aux (side stream)"
     if "attn_fwd" in n:
         return "attention fwd"
@@ -115,6 +115,9 @@ print(f"`{tag}` evidence, commit `{pmc.get('commit')}`, one box: **{bench['value
       " and 8 TB/s.\n")
 print("| family | launches / step | ms / step | algorithmic GFLOP, GB / step | achieved (algorithmic) | of MFMA peak | of HBM peak | MFMA busy (counters) | bound | counter traffic GB / step (x algorithmic) |")
 print("|---|---|---|---|---|---|---|---|---|---|")
+ANA = {"front-end Conv2d": "front_end_conv2d", "CTC head + loss": "ctc_head_loss",
+       "attention bwd aux (side stream)": "attention_aux_side_stream", "optimizer": "optimizer"}
+fana = bench.get("families_analytic", {})
 for fam, a in sorted(rows.items(), key=lambda kv: -kv[1]["us"]):
     ms = a["us"] / 1e3
     gf = gb = 0.0
@@ -122,6 +125,8 @@ for fam, a in sorted(rows.items(), key=lambda kv: -kv[1]["us"]):
         if t in fams:
             gf += fams[t].get("gflop", 0.0)
             gb += fams[t].get("gbytes", 0.0)
+    if fam in ANA and ANA[fam] in fana:   # no in-library counters: the analytic work of bench.py analytic_families
+        gf, gb = fana[ANA[fam]]["gflop"], fana[ANA[fam]]["gbytes"]
     tr = traffic(a["kern"]) / 1e9
     mu = mfma_util(a["kern"], US)
     mus = f"{mu:.3f}" if mu > 0 else "—"
