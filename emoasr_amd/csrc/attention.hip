@@ -375,9 +375,13 @@ __device__ __forceinline__ void store_dT(T* dst, long ld, int r0, int rlimit, co
 // at most one block per CU; otherwise one set, refilled as soon as the score MFMAs have read it, and two
 // blocks per CU (bf16).  Measured at B 20, T' 340 (240 blocks): 36 us with two sets, 45 us with one; at 264
 // blocks the two-set kernel's second round of blocks costs 80 us against 62.
+// bf16 / f32: the V tile takes the skew tile's bytes (staged after the skew has been read) and the lower band half is reused from
+// the previous tile's registers; the split type keeps V in a region of its own, staged at the top of the tile, and loads both band
+// halves -- holding V's and the band's (hi, lo) registers across the score phase put it into scratch (288-320 registers + 0.5-1 KB
+// of private memory: the f32x3 forward ran 3.4 x slower; the exact f32 one gained 15 % from the new order)
 template <typename T> constexpr int fwd_wave_bytes() {
   constexpr int g = 32 * 68 * 4, v = 32 * AttnCfg<T>::LD * (int)sizeof(T);
-  return g > v ? g : v;
+  return !kSplit<T> ? (g > v ? g : v) : g + v;
 }
 template <typename T, bool TR, bool PF2>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fwd_kernel(const emoasr_attn_t a_in, const int nt, const int ks) {
@@ -401,8 +405,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
   // bytes (round 6: 8.7 KB per wave instead of 12.6 -- the stacked launches' one-wave workgroups were LDS-limited to 12 per CU)
   constexpr int LDG = 68;
   constexpr int WAVE_BYTES = fwd_wave_bytes<T>();
+  constexpr bool LEAN = !kSplit<T>;
   float* Gs = reinterpret_cast<float*>(smem + wave * WAVE_BYTES);
-  T* Vs = reinterpret_cast<T*>(smem + wave * WAVE_BYTES);
+  T* Vs = reinterpret_cast<T*>(smem + wave * WAVE_BYTES + (LEAN ? 0 : 32 * LDG * 4));
 
   const HeadPtrs hp = head_ptrs<T>(a, b, h);
   const int qi = i0 + (lane & 31);
@@ -461,7 +466,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
       const unsigned po = (unsigned)((a.Tq - 32 - i0 + j0) * (int)pstride) + p_lane + (j0 < kend ? 0u : 0x80000000u);
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) {
-        p.pf[0][kk] = prev ? prev->pf[1][kk] : frag_at<T>(rsP, po, kk);
+        if constexpr (LEAN) p.pf[0][kk] = prev ? prev->pf[1][kk] : frag_at<T>(rsP, po, kk);
+        else p.pf[0][kk] = frag_at<T>(rsP, po, kk);
         p.pf[1][kk] = frag_at<T>(rsP, po + 32u * pstride, kk);
       }
     }
@@ -476,6 +482,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
     EMO_FSTAMP(0);
     if constexpr (PF2) fetch(nxt, j0 + 32 * ks, ks == 1 ? &cur : nullptr);
     EMO_FSTAMP(1);
+    if constexpr (!LEAN) {
+#pragma unroll
+      for (int i = 0; i < VR; ++i) {
+        const int v = lane + 64 * i;
+        lds_stage16(Vs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, cur.vr[i]);
+      }
+    }
     // S^T = K . (Q+u)^T + skew(pos_band . (Q+v)^T)   (rows keys, cols queries; see score_tile)
     f32x16 s;
     zero16(s);
@@ -500,10 +513,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
     }
     EMO_FSTAMP(2);
     // the V tile takes the skew tile's place
+    if constexpr (LEAN) {
 #pragma unroll
-    for (int i = 0; i < VR; ++i) {
-      const int v = lane + 64 * i;
-      lds_stage16(Vs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, cur.vr[i]);
+      for (int i = 0; i < VR; ++i) {
+        const int v = lane + 64 * i;
+        lds_stage16(Vs + (v / PER_ROW) * LD + (v % PER_ROW) * VEC, cur.vr[i]);
+      }
     }
     const unsigned mw = cur.mw >> (4 * (lane >> 5));   // this half wave's keys are 8 g + 4 hh + e
     // one register set: every prefetched register has been consumed, refill them with tile j0+32
@@ -2988,7 +3003,7 @@ int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
 }
 
 template <typename T, bool TR, typename TK = T>
-int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
+int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s, const int dtype) {   // dtype: the call's code (EMO_F32X3: the batched products below run split too)
   constexpr int LD = AttnCfg<T>::LD;
   const long rows = (long)a.B * a.Tq * a.H;
   attn_delta_kernel<T><<<cdiv(rows * 8, 256), 256, 0, s>>>(a);
@@ -3013,7 +3028,6 @@ int launch_bwd_tr(const emoasr_attn_t& a, hipStream_t s) {
   }
   if (a.pdT) {
     // materialised mode: dV = Pd . dO, dK = dS . (Q + u), dpos_h = dBD_h^T . (Q_h + v)
-    const int dtype = sizeof(T) == 2 ? EMO_BF16 : EMO_F32;
     const long sp_b = (long)a.H * a.Tk * a.ldpd, sp_h = (long)a.Tk * a.ldpd;
     EMO_LAUNCH_CHECK();
     if (emoasr_gemm_nn_batched(dtype, a.Tk, DK, a.Tq, a.pdT, a.ldpd, sp_b, sp_h, a.dout, a.ldo,
@@ -3479,10 +3493,10 @@ extern "C" int emoasr_attn_bwd(int dtype, const emoasr_attn_t* a, void* stream) 
   if (a->B == 0 || a->Tq == 0) return 0;
   // dtype EMO_F32X3: the score-recomputing dQ kernel (the training path's: pdT without stored scores) runs its
   // products split; the GEMMs behind it (dV, dK, dpos) follow the same option inside gemm.hip
-  if (dtype == EMO_F32X3 && a->pdT && !a->st) return launch_bwd_tr<float, true, f32s>(*a, (hipStream_t)stream);
+  if (dtype == EMO_F32X3 && a->pdT && !a->st) return launch_bwd_tr<float, true, f32s>(*a, (hipStream_t)stream, dtype);
   EMO_DISPATCH(dtype, {
-    if (g_tr) return (launch_bwd_tr<T, true>(*a, (hipStream_t)stream));
-    return (launch_bwd_tr<T, false>(*a, (hipStream_t)stream));
+    if (g_tr) return (launch_bwd_tr<T, true>(*a, (hipStream_t)stream, dtype));
+    return (launch_bwd_tr<T, false>(*a, (hipStream_t)stream, dtype));
   });
   return 0;
 }
