@@ -848,7 +848,10 @@ int launch_nt_(const NtArgs& a_in, hipStream_t s, int nz = 1) {
   // (round 4, same shapes one by one: the 128-row tile is the faster one where the output is wide -- N >= 512: ffn1 45 / 50 us, qkv
   // 36 / 43, d_ffn2 38 / 44 -- and the slower one for N = 256 -- ffn2 47 / 44, out 18.5 / 17.2.  INSIDE the training step the mixed
   // rule is slower, three A/B pairs on one box: 29.89 against 29.65 ms per step -- option "gemm_wide128", off)
-  const bool stacked64 = AMODE == 0 && a.M >= 16384 && !(g_gemm_wide128 && a.N >= 512);
+  // (round 6, after the attention kernels stopped hammering the CUs' vector-memory paths: the mixed rule IS faster inside the step --
+  // 128-row tiles from N = 768 on, four A/B pairs on one box: 26.85 against 26.94 ms (N >= 512), 26.96 against 27.10 (all shapes);
+  // one by one at 35 k rows: ffn1 with its epilogue 75.9 -> 72.6 us, qkv 40.5 -> 36.6, d_ffn2 48.8 -> 43.3, N = 256 products 8 % slower)
+  const bool stacked64 = AMODE == 0 && a.M >= 16384 && !(a.N >= (g_gemm_wide128 ? 512 : 768));
   const int tile = g_gemm_tile ? g_gemm_tile : (stacked64 ? 3 : (t12864 >= 384 ? 2 : 3));
   const int kb = sizeof(T) == 2 ? (g_gemm_kb ? g_gemm_kb : (a.K >= 512 ? 2 : 1)) : 1;
 #define EMO_NT_LAUNCH(BM_, BN_)                                                           \
