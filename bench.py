@@ -46,7 +46,7 @@ def fwd_flops_per_utt(T, F=1024, V=10000, d=256, layers=12):
     return conv1 + conv2 + lin + layers * layer + head
 
 
-PMC_FILE = os.path.join("profiles", "r05_pmc.json")
+PMC_FILE = os.path.join("profiles", "r06_pmc.json")
 
 
 def pmc_kernel(kernel, key):

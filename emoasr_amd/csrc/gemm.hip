@@ -134,6 +134,9 @@ __device__ __forceinline__ void split_store4(bf16* hi, bf16* lo, const Vec16<flo
   *reinterpret_cast<bf16x4*>(lo) = l;
 }
 
+#ifndef EMO_GEMM_SWZ
+#define EMO_GEMM_SWZ 1
+#endif
 template <typename T>
 __device__ __forceinline__ void lds_store_row(T* dst, const Vec16<T>& v) {
   if constexpr (sizeof(T) == 2) {
@@ -157,7 +160,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
   using M_ = Mma<T>;
   using L = std::conditional_t<SP, bf16, T>;              // element type of the LDS tiles
   constexpr int VEC = SP ? SplitCfg<KB>::VEC : Cfg::VEC, BK = SP ? SplitCfg<KB>::BK : Cfg::BK;
-  constexpr int KV = SP ? SplitCfg<KB>::KV : Cfg::KV, LD = SP ? SplitCfg<KB>::LD : Cfg::LD;
+  // SWZ (round 6; bf16, BK = 32): k-contiguous tiles with UNPADDED 64-byte rows whose four 16-byte pieces are XOR-swizzled by
+  // (row >> 2) & 3.  With the padded 80-byte rows the two rows of an 8-lane 16-byte store group overlapped in four banks (counters:
+  // a third of the LDS cycles of the K = 256 products were bank conflicts, the LDS busy 45 % of the kernel); the swizzled image is
+  // conflict-free for the stores (two rows = 128 contiguous bytes) AND for the fragment reads (the four rows of one residue class
+  // mod 4 in a 16-lane read group get four different pieces).
+  constexpr bool SWZ = EMO_GEMM_SWZ && !SP && sizeof(T) == 2 && KB == 1;
+  constexpr int KV = SP ? SplitCfg<KB>::KV : Cfg::KV, LD = SP ? SplitCfg<KB>::LD : (SWZ ? Cfg::BK : Cfg::LD);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int LDBK = BN + (sizeof(L) == 2 ? 32 : 0);  // k-major B tile row stride
   constexpr int BVK = BN / VEC;                          // vectors per k row (k-major B)
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int v = tid + i * 256, r = v / KV, kv = v % KV;
-    a_kv[i] = kv * VEC; a_lds[i] = r * LD + kv * VEC;
+    a_kv[i] = kv * VEC; a_lds[i] = r * LD + (SWZ ? (kv ^ ((r >> 2) & 3)) : kv) * VEC;
     a_ok[i] = (m0 + r) < g.M;
     const int row = a_ok[i] ? (m0 + r) : 0;
     if constexpr (AMODE == 1) a_off[i] = (unsigned)(conv_row_base(g.cg, row) * SZ);
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
       b_off[i] = (unsigned)((n0 + nv) * SZ);
     } else {
       const int r = v / KV, kv = v % KV;
-      b_kv[i] = kv * VEC; b_lds[i] = r * LD + kv * VEC;
+      b_kv[i] = kv * VEC; b_lds[i] = r * LD + (SWZ ? (kv ^ ((r >> 2) & 3)) : kv) * VEC;
       b_ok[i] = (n0 + r) < g.N;
       b_off[i] = (unsigned)((long)(b_ok[i] ? (n0 + r) : 0) * g.ldb * SZ);
     }
@@ -338,12 +347,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs g) {
 #pragma unroll
     for (int kk = 0; kk < BK; kk += M_::KSTEP) {
       typename M_::Frag af[TM], bfr[TN];
+      // (swizzled tiles: the fragment of k-step kk is piece kk / 8 + (lane >> 5) of row lane & 31 -- block rows are multiples of
+      // 32, so the XOR term depends on the lane only)
+      auto frag_kc = [&](const L* base, int row0) {
+        if constexpr (SWZ) {
+          const int piece = (kk / 8 + (lane >> 5)) ^ (((lane & 31) >> 2) & 3);
+          return *reinterpret_cast<const typename M_::Frag*>(base + (row0 + (lane & 31)) * LD + piece * 8);
+        } else {
+          return M_::load_kc(base, LD, row0, kk, lane);
+        }
+      };
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = M_::load_kc(As, LD, wm + i * 32, kk, lane);
+      for (int i = 0; i < TM; ++i) af[i] = frag_kc(As, wm + i * 32);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if constexpr (BKM) bfr[j] = M_::template load_km<TR>(Bs, LDBK, kk, wn + j * 32, lane);
-        else bfr[j] = M_::load_kc(Bs, LD, wn + j * 32, kk, lane);
+        else bfr[j] = frag_kc(Bs, wn + j * 32);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)

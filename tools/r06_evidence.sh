@@ -1,9 +1,9 @@
-# Round-5 evidence set (run on the GPU box through gpurun): kernel table / sequence / launch shapes of the bench step, the three
+# Round-6 evidence set (run on the GPU box through gpurun): kernel table / sequence / launch shapes of the bench step, the three
 # counter passes behind roofline.traffic / mfma_util, the attention kernels' SQ instruction counters, the f32x3 step's kernel
-# table, the full GPU suite and the bench line.   EV_COMMIT=<sha> bash tools/r05_evidence.sh
+# table, the full GPU suite and the bench line.   EV_COMMIT=<sha> bash tools/r06_evidence.sh
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=r05; O=gpurun_out/${TAG}_ev; mkdir -p $O
+TAG=r06; O=gpurun_out/${TAG}_ev; mkdir -p $O
 CMD="python3 bench.py --steps 6 --warmup 2 --no-decode --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $CMD > $O/kt.log 2>&1
 python3 tools/kstats.py $O/kt/kt_results.db 8 $O/${TAG}_kernel_stats.csv > $O/kstats.txt 2>&1
@@ -32,6 +32,13 @@ rm -rf $O/kx
 rocprofv3 --kernel-trace --stats -d $O/ky -o ky -- python3 tools/f32_leg.py --split --stacked > $O/ky.log 2>&1
 python3 tools/kstats.py $O/ky/ky_results.db 9 $O/${TAG}_f32x3_stacked_kernel_stats.csv > $O/f32x3_stacked_kstats.txt 2>&1
 rm -rf $O/ky
+# in-kernel phase stamps of the attention kernels (a -DEMO_ATTN_STAMP build variant: wave 0 of workgroup 0, cycles per key / query step)
+if [ -f emoasr_amd/build/libemoasr_hip_stamp.so ]; then
+  ( export EMOASR_HIP_LIB=$GRAFT_REPO_ROOT/emoasr_amd/build/libemoasr_hip_stamp.so
+    for bt in "110 320" "36 208" "11 651"; do set -- $bt; B=$1 T=$2 MODES=fused python3 tools/attn_bench.py 2>&1 | grep -v amdgpu.ids; done ) > $O/${TAG}_attn_phases.txt 2>&1
+fi
+MODES=fused python3 tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_attn_bench.txt
+BLAS=1 EPI=1 M=35145 python3 tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_35k_rows.txt
 ( time python3 -m pytest tests -m gpu -q ) > $O/${TAG}_gputest.log 2>&1
 python3 bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 tail -3 $O/${TAG}_gputest.log
