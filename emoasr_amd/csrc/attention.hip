@@ -775,13 +775,16 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_fwd4_kernel(const emoasr_attn
         g0 = M_::mma(M_::load_kc(Bs0, LD, 0, kk * M_::KSTEP, lane), qv[kk], g0);   // g[c][i]
         g1 = M_::mma(M_::load_kc(Bs1, LD, 0, kk * M_::KSTEP, lane), qv[kk], g1);
       }
+      // (the score product is issued BEFORE the band tiles are stored: the stores wait for the band MFMAs' results while the matrix
+      // pipe works on S)
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) s = M_::mma(M_::load_kc(Ks, LD, 0, kk * M_::KSTEP, lane), qu[kk], s);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {   // accumulator registers 4 q .. 4 q + 3 are band columns 8 q + 4 hh + 0 .. 3 of query il
         *reinterpret_cast<f32x4*>(Gs + il * LDG + 8 * q + 4 * hh) = f32x4{g0[4 * q], g0[4 * q + 1], g0[4 * q + 2], g0[4 * q + 3]};
         *reinterpret_cast<f32x4*>(Gs + il * LDG + 32 + 8 * q + 4 * hh) = f32x4{g1[4 * q], g1[4 * q + 1], g1[4 * q + 2], g1[4 * q + 3]};
       }
-#pragma unroll
-      for (int kk = 0; kk < NK; ++kk) s = M_::mma(M_::load_kc(Ks, LD, 0, kk * M_::KSTEP, lane), qu[kk], s);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] += Gs[il * (LDG - 1) + 31 + c_row(r, lane)];   // G[il][31 - il + key]
@@ -2701,16 +2704,25 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
           g0 = M_::mma(M_::load_kc(Bs0, LD, 0, kk * M_::KSTEP, lane), fqv[kk], g0);   // g[c][i]
           g1 = M_::mma(M_::load_kc(Bs1, LD, 0, kk * M_::KSTEP, lane), fqv[kk], g1);
         }
+        // (S and dP are issued BEFORE the band tiles are stored: the stores wait for the band MFMAs' results while the matrix pipe
+        // works on the two other products)
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          s = M_::mma(M_::load_kc(Ks, LD, 0, kk * M_::KSTEP, lane), fqu[kk], s);
+          dp = M_::mma(M_::load_kc(Vs, LD, 0, kk * M_::KSTEP, lane), fdo[kk], dp);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {   // accumulator registers 4 q .. 4 q + 3 are band columns 8 q + 4 hh + 0 .. 3 of query il
           *reinterpret_cast<f32x4*>(Gs + il * LDGS + 8 * q + 4 * hh) = f32x4{g0[4 * q], g0[4 * q + 1], g0[4 * q + 2], g0[4 * q + 3]};
           *reinterpret_cast<f32x4*>(Gs + il * LDGS + 32 + 8 * q + 4 * hh) = f32x4{g1[4 * q], g1[4 * q + 1], g1[4 * q + 2], g1[4 * q + 3]};
         }
-      }
+      } else {
 #pragma unroll
-      for (int kk = 0; kk < NK; ++kk) {
-        s = M_::mma(M_::load_kc(Ks, LD, 0, kk * M_::KSTEP, lane), fqu[kk], s);
-        dp = M_::mma(M_::load_kc(Vs, LD, 0, kk * M_::KSTEP, lane), fdo[kk], dp);
+        for (int kk = 0; kk < NK; ++kk) {
+          s = M_::mma(M_::load_kc(Ks, LD, 0, kk * M_::KSTEP, lane), fqu[kk], s);
+          dp = M_::mma(M_::load_kc(Vs, LD, 0, kk * M_::KSTEP, lane), fdo[kk], dp);
+        }
       }
       EMO_STAMP(1);
       if constexpr (REL) {
