@@ -81,6 +81,7 @@ void emo_decode_set_coop_merge(int v);
 void emo_attn_set_tr_read(int v);
 void emo_attn_set_fw(int v);
 void emo_attn_set_fwd4(int v);
+void emo_attn_set_q2(int v);
 void emo_attn_set_bwd_split(int v);
 void emo_attn_set_side(int v);
 void emo_attn_set_side_prio(int v);
@@ -190,6 +191,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "decode_coop_merge") == 0) { emo_decode_set_coop_merge(value); return 0; }
   if (strcmp(name, "attn_fw") == 0) { emo_attn_set_fw(value); return 0; }
   if (strcmp(name, "attn_fwd4") == 0) { emo_attn_set_fwd4(value); return 0; }
+  if (strcmp(name, "attn_q2") == 0) { emo_attn_set_q2(value); return 0; }
   if (strcmp(name, "attn_bwd_split") == 0) { emo_attn_set_bwd_split(value); return 0; }
   if (strcmp(name, "attn_side") == 0) { emo_attn_set_side(value); return 0; }
   if (strcmp(name, "attn_side_prio") == 0) { emo_attn_set_side_prio(value); return 0; }

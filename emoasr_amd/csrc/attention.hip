@@ -1642,6 +1642,7 @@ struct FusedWs {       // workspace carved by emoasr_attn_bwd_fused
   // bit k of word w = key 32 w + k kept (attn_dropmask_kernel; nullptr without dropout)
   const unsigned* mask;
   int mask_nw;
+  int img_from_kv;     // R6: the key pass writes the dS image and the query pass (attn_bwd_q2_kernel) reads it instead of recomputing
 };
 
 // prologue: delta[b,h,i] = dO.O, dense Q+u / Q+v.  8 lanes x 8 elements per (b,i,h) row.
@@ -2476,6 +2477,13 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   fetch(1);
   __syncthreads();
   const bool kvalid = kj < hp.klen;
+  // R6: this pass writes the dS image (bf16, query-major [b, h, i, ldds]) that the query pass (attn_bwd_q2_kernel) and the table
+  // gradient read: the query pass no longer recomputes S, dP, the band product and the soft-max.  Lane = key: one 2-byte store per
+  // accumulator register, the 32 lanes of a half wave cover 64 contiguous bytes; rows past Tq fall outside the descriptor.
+  const bool has_img = REL && ws.dsq != nullptr && ws.img_from_kv;
+  const __amdgpu_buffer_rsrc_t rsI = make_rsrc_n(has_img ? (const T*)ws.dsq + ((long)b * a.H + h) * a.Tq * ws.ldds : (const T*)hp.k,
+                                                 has_img ? (unsigned)a.Tq * (unsigned)ws.ldds * 2u : 0u);
+  const unsigned img_lane = (unsigned)kj * 2u, img_rstride = (unsigned)ws.ldds * 2u;
   const float c_exp = a.scale * 1.4426950408889634f;
   const unsigned keep_bits = __float_as_uint(a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f);
   // the band skew as a lane rotation (ds_bpermute: no LDS storage): accumulator row rr + 4 hh of the band tiles G[query][c] gives
@@ -2542,6 +2550,9 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
           csum += dsv;
           pf[g >> 1][4 * (g & 1) + e] = (bf16)(p * m);
           df[g >> 1][4 * (g & 1) + e] = (bf16)dsv;
+          if (has_img)
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16)dsv), rsI,
+                                                  img_lane + (unsigned)(i0 + 8 * g + 4 * hh + e) * img_rstride, 0, 0);
         }
       }
       EMO_STAMP(4);
@@ -2823,6 +2834,162 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Query pass, round 6 (bf16, relative positions): dQ from the dS image the key pass wrote.  attn_bwd_q_kernel recomputed every score
+// tile a second time -- band product (8 MFMAs), S and dP (8), skew through LDS, soft-max, mask -- only to arrive at the dS the key
+// pass had just formed; 16 of its 28 MFMAs and ~200 of its ~250 VALU instructions per tile were recomputation.  Here a wave reads
+// its query tile's dS rows back (four 8-byte loads per lane and key tile, one step ahead: exactly the values, rounded to bf16, that
+// the old pass fed its MFMAs) and does what only this orientation can: dQ^T += K^T dS^T, and the band part through the un-skewed
+// dG image -- 12 MFMAs per tile, no exponentials.  LDS: the K tile + the band ring (32 KB) + a 4.6 KB image per wave: three
+// workgroups per CU; ~100 registers.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int FW> struct Q2Cfg {
+  static constexpr int LD = AttnCfg<bf16>::LD, LDG = 72, NRING = FW + 2;
+  static constexpr int STAGE_ROWS = 32 + 32 * NRING;   // K, band ring
+  static constexpr int IMG_BYTES = 32 * LDG * 2;
+  static constexpr int smem() { return STAGE_ROWS * LD * 2 + FW * IMG_BYTES; }
+};
+template <bool TR, int FW>
+__global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_attn_t a_in, const FusedWs ws_in, const int nt) {
+  using T = bf16;
+  using M_ = Mma<T>;
+  using C_ = Q2Cfg<FW>;
+  constexpr int NS = AttnCfg<T>::NS, LD = C_::LD, LDG = C_::LDG, NRING = C_::NRING;
+  constexpr int VEC = 8, PER_ROW = DK / VEC, NTHR = 64 * FW;
+  static_assert(NTHR / PER_ROW == 32, "one piece per thread covers one 32-row tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), il = lane & 31, hh = lane >> 5;
+  emoasr_attn_t a = a_in;
+  FusedWs ws = ws_in;
+  const Blk3 blk = attn_block(nt, a_in.H, a_in.B);
+  if (!blk.ok) return;
+  int b = blk.z;
+  if (a_in.nseg > 1) {
+    const SegRef g = seg_of_slot(a_in, blk.z, b);
+    seg_apply<T>(a, g);
+    ws.dsq = (T*)ws.dsq + g.row * a.H * ws.ldds;
+  }
+  const int iblk = blk.x * (32 * FW), h = blk.y;
+  if (iblk >= a.Tq) return;
+  const HeadPtrs hp = head_ptrs<T>(a, b, h);
+  const int i0 = iblk + 32 * wave;
+  const bool live = i0 < a.Tq;   // a dead wave still stages and joins the barriers
+  const int qi = i0 + il;
+  const bool qval = qi < a.Tq;
+
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* ring = Ks + 32 * LD;   // block n = table rows Tq - 32 FW - iblk + 32 n + [0, 32) in slot n mod NRING
+  T* img_g = reinterpret_cast<T*>(smem + C_::STAGE_ROWS * LD * 2 + wave * C_::IMG_BYTES);   // dG[query][band column] ([32][LDG])
+
+  const int nstep = (hp.klen + 31) / 32;   // key tiles with at least one valid key (the only ones the key pass wrote)
+  const unsigned kstride = (unsigned)a.ldk * 2u, pstride = (unsigned)a.ldp * 2u, istride = (unsigned)ws.ldds * 2u;
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc_n(hp.k, (unsigned)(a.Tk - 1) * kstride + DK * 2u),
+                               rsP = make_rsrc_n(hp.pos, (unsigned)(2 * a.Tq - 2) * pstride + DK * 2u),
+                               rsI = make_rsrc_n((const T*)ws.dsq + ((long)b * a.H + h) * a.Tq * ws.ldds, (unsigned)a.Tq * istride);
+  const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
+  const unsigned k_lane = (unsigned)trow * kstride + (unsigned)piece * 2u;
+  const unsigned p_lane = (unsigned)((a.Tq - 32 * FW - iblk + trow) * (int)pstride) + (unsigned)piece * 2u;   // block 0
+  Vec16<T> pre[2];
+  auto fetch = [&](const int step) {   // K tile of `step` and the band block it adds (block step + FW)
+    const unsigned dead = step < nstep ? 0u : 0x80000000u;
+    pre[0] = buf_load16<T>(rsK, (k_lane + (unsigned)(32 * step) * kstride) | dead);
+    pre[1] = buf_load16<T>(rsP, (p_lane + (unsigned)(32 * (step + FW)) * pstride) | dead);
+  };
+  auto stash = [&](const int step) {
+    store16(Ks + trow * LD + piece, pre[0]);
+    store16(ring + (((step + FW) % NRING) * 32 + trow) * LD + piece, pre[1]);
+  };
+  // this lane's dS values of key tile `step`: row qi, keys 32 step + 8 g + 4 hh + 0 .. 3 (the B-operand order of the dQ product)
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  const unsigned i_lane = (unsigned)qi * istride + (unsigned)(4 * hh) * 2u;
+  auto fetch_ds = [&](u32x2 (&d)[4], const int step) {
+    const unsigned dead = (live && qval && step < nstep) ? 0u : 0x80000000u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned off = (i_lane + (unsigned)(32 * step + 8 * g) * 2u) | dead;
+      d[g][0] = __builtin_amdgcn_raw_buffer_load_b32(rsI, off, 0, 0);
+      d[g][1] = __builtin_amdgcn_raw_buffer_load_b32(rsI, off + 4u, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int n = 0; n < FW; ++n) store16(ring + (n * 32 + trow) * LD + piece, buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride));
+  fetch(0);
+  stash(0);
+  fetch(1);
+  u32x2 dnext[4];
+  fetch_ds(dnext, 0);
+  __syncthreads();
+  f32x16 dq[2];
+  zero16(dq[0]); zero16(dq[1]);
+
+  for (int step = 0; step < nstep; ++step) {
+    u32x2 dcur[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dcur[g] = dnext[g];
+    fetch_ds(dnext, step + 1);
+    if (live) {
+      const T* Bs0 = ring + ((FW - 1 - wave + step) % NRING) * 32 * LD;
+      const T* Bs1 = ring + ((FW - wave + step) % NRING) * 32 * LD;
+      // the dG image: cleared with 16-byte stores, then the tile's 32 x 32 entries at band column c = key - il + 31
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int v = lane + 64 * q;   // 32 rows x 8 pieces of 8 columns
+        *reinterpret_cast<u32x4*>(img_g + (v >> 3) * LDG + 8 * (v & 7)) = u32x4{0u, 0u, 0u, 0u};
+      }
+      __builtin_amdgcn_wave_barrier();
+      typename M_::Frag df[NS];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        union { u32x2 u; bf16x4 h; } cv;
+        cv.u = dcur[g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          df[g >> 1][4 * (g & 1) + e] = cv.h[e];
+          img_g[il * LDG + 8 * g + 4 * hh + e + 31 - il] = cv.h[e];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // dQ^T += K^T dS^T (key index in the registers) + band^T unskew(dS^T)
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = M_::mma(chain_a<T, TR>(Ks, ks, 32 * dt, lane), df[ks], dq[dt]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+          const typename M_::Frag dg = M_::load_kc(img_g, LDG, 0, 32 * ct + ks * M_::KSTEP, lane);  // dG^T[c][i], c contiguous
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            dq[dt] = M_::mma(M_::template load_km<TR>(ct ? Bs1 : Bs0, LD, ks * M_::KSTEP, 32 * dt, lane), dg, dq[dt]);
+        }
+      __builtin_amdgcn_wave_barrier();   // the image has been read
+    }
+    lds_barrier();   // every wave has read the stage
+    stash(step + 1);
+    fetch(step + 2);
+    lds_barrier();   // stage ready
+  }
+  if (!live) return;
+  store_dT<T>((T*)hp.dq, a.ldq, i0, a.Tq, dq, 1.f, lane);
+  if (a.dbias_v) {
+    // dbias_v[d] += colsum(dQ)[d] (attn_bwd_kv_kernel subtracts dbias_u): sum over the queries = the 32 lanes of a half wave
+    float* cs = reinterpret_cast<float*>(img_g);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = dq[dt][r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (il == 0) cs[32 * dt + c_row(r, lane)] = v;
+      }
+    __builtin_amdgcn_wave_barrier();
+    atomicAdd(&a.dbias_v[h * DK + lane], cs[lane]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, const long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = from_f32<T>(src[i]);
@@ -2887,6 +3054,7 @@ int set_smem(K kernel, int bytes) {
 }
 
 int g_tr = 1;
+int g_q2 = 1;         // option "attn_q2": the query pass reads the dS image the key pass wrote (attn_bwd_q2_kernel) instead of recomputing it
 int g_bwd_split = 1;  // option "attn_bwd_split": the two-pass backward (attn_bwd_kv_kernel + attn_bwd_q_kernel); 0 = the single-pass kernel
 int g_fused_fw = 0;  // key tiles per workgroup of the single-pass backward (0 = by grid size; emoasr_set_option "attn_fw")
 
@@ -3279,11 +3447,18 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
 #define EMO_SPLIT_LAUNCH(TR_, REL_)                                                                                 \
   do {                                                                                                              \
     if (set_smem(attn_bwd_kv_kernel<T, TR_, REL_, FW>, SC::kv_smem(REL_))) return 1;                                \
-    if (set_smem(attn_bwd_q_kernel<T, TR_, REL_, FW>, SC::q_smem(REL_))) return 1;                                  \
-    attn_bwd_kv_kernel<T, TR_, REL_, FW><<<gk, 64 * FW, SC::kv_smem(REL_), s>>>(a, ws, ntk);                      \
+    attn_bwd_kv_kernel<T, TR_, REL_, FW><<<gk, 64 * FW, SC::kv_smem(REL_), s>>>(a, ws, ntk);                        \
     if (ws.stamp) ws.stamp += 64 * 13;                                                                              \
-    attn_bwd_q_kernel<T, TR_, REL_, FW><<<gq, 64 * FW, SC::q_smem(REL_), s>>>(a, ws, ntq);                          \
+    if (REL_ && use_q2) {                                                                                           \
+      if (set_smem(attn_bwd_q2_kernel<TR_, FW>, Q2Cfg<FW>::smem())) return 1;                                       \
+      attn_bwd_q2_kernel<TR_, FW><<<gq, 64 * FW, Q2Cfg<FW>::smem(), s>>>(a, ws, ntq);                               \
+    } else {                                                                                                        \
+      if (set_smem(attn_bwd_q_kernel<T, TR_, REL_, FW>, SC::q_smem(REL_))) return 1;                                \
+      attn_bwd_q_kernel<T, TR_, REL_, FW><<<gq, 64 * FW, SC::q_smem(REL_), s>>>(a, ws, ntq);                        \
+    }                                                                                                               \
   } while (0)
+    const bool use_q2 = g_q2 && rel && sizeof(T) == 2;
+    ws.img_from_kv = use_q2 ? 1 : 0;
     if (rel) { if (g_tr) EMO_SPLIT_LAUNCH(true, true); else EMO_SPLIT_LAUNCH(false, true); }
     else     { if (g_tr) EMO_SPLIT_LAUNCH(true, false); else EMO_SPLIT_LAUNCH(false, false); }
 #undef EMO_SPLIT_LAUNCH
@@ -3439,6 +3614,7 @@ void emo_attn_set_fwd4(int v) { g_fwd4 = v; }
 void emo_attn_set_xcd(int v) { g_attn_xcd = v; }
 void emo_attn_set_fwd_waves(int v) { g_fwd_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
 void emo_attn_set_bwd_split(int v) { g_bwd_split = v ? 1 : 0; }
+void emo_attn_set_q2(int v) { g_q2 = v ? 1 : 0; }
 void emo_attn_set_fw(int v) { g_fused_fw = (v == 2 || v == 4) ? v : 0; }
 
 extern "C" long emoasr_attn_dropmask_words(int Tk) { return cdiv(Tk, 32); }
