@@ -2907,8 +2907,7 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const unsigned off = (i_lane + (unsigned)(32 * step + 8 * g) * 2u) | dead;
-      d[g][0] = __builtin_amdgcn_raw_buffer_load_b32(rsI, off, 0, 0);
-      d[g][1] = __builtin_amdgcn_raw_buffer_load_b32(rsI, off + 4u, 0, 0);
+      d[g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsI, off, 0, 0));
     }
   };
 #pragma unroll
@@ -3444,11 +3443,14 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
     if (ntq) gq = dim3(8 * cdiv(a.H * a.B, 8) * ntq, 1, 1);
     emo_timer_begin(EMO_TIMER_ATTN_BWD_MAIN, s);
     if (maskbuf && !prepared && launch_dropmask<T>(a, maskbuf, ws.mask_nw, nrows, s)) return 1;
-#define EMO_SPLIT_LAUNCH(TR_, REL_)                                                                                 \
+#define EMO_KV_LAUNCH(TR_, REL_)                                                                                    \
   do {                                                                                                              \
     if (set_smem(attn_bwd_kv_kernel<T, TR_, REL_, FW>, SC::kv_smem(REL_))) return 1;                                \
     attn_bwd_kv_kernel<T, TR_, REL_, FW><<<gk, 64 * FW, SC::kv_smem(REL_), s>>>(a, ws, ntk);                        \
     if (ws.stamp) ws.stamp += 64 * 13;                                                                              \
+  } while (0)
+#define EMO_Q_LAUNCH(TR_, REL_)                                                                                     \
+  do {                                                                                                              \
     if (REL_ && use_q2) {                                                                                           \
       if (set_smem(attn_bwd_q2_kernel<TR_, FW>, Q2Cfg<FW>::smem())) return 1;                                       \
       attn_bwd_q2_kernel<TR_, FW><<<gq, 64 * FW, Q2Cfg<FW>::smem(), s>>>(a, ws, ntq);                               \
@@ -3459,23 +3461,31 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
   } while (0)
     const bool use_q2 = g_q2 && rel && sizeof(T) == 2;
     ws.img_from_kv = use_q2 ? 1 : 0;
-    if (rel) { if (g_tr) EMO_SPLIT_LAUNCH(true, true); else EMO_SPLIT_LAUNCH(false, true); }
-    else     { if (g_tr) EMO_SPLIT_LAUNCH(true, false); else EMO_SPLIT_LAUNCH(false, false); }
-#undef EMO_SPLIT_LAUNCH
-    emo_timer_end(EMO_TIMER_ATTN_BWD_MAIN, s);
+    if (rel) { if (g_tr) EMO_KV_LAUNCH(true, true); else EMO_KV_LAUNCH(false, true); }
+    else     { if (g_tr) EMO_KV_LAUNCH(true, false); else EMO_KV_LAUNCH(false, false); }
     // the position-table gradient (+ its cast for the weight-gradient product): on the side stream when there is one
     hipStream_t st2 = s;
     const bool forked = rel && a.dpos && side_ready();
-    if (forked) {
-      hipEventRecord(g_ev_fork, s);
-      hipStreamWaitEvent(g_side, g_ev_fork, 0);
-      st2 = g_side;
-    }
-    if (rel && a.dpos) {
-      emo_timer_begin(EMO_TIMER_ATTN_BWD_DPOS, st2);
-      launch_dpos3<T>(a, ws, st2);
-      emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, st2);
-    }
+    auto table_grad = [&]() {
+      if (forked) {
+        hipEventRecord(g_ev_fork, s);
+        hipStreamWaitEvent(g_side, g_ev_fork, 0);
+        st2 = g_side;
+      }
+      if (rel && a.dpos) {
+        emo_timer_begin(EMO_TIMER_ATTN_BWD_DPOS, st2);
+        launch_dpos3<T>(a, ws, st2);
+        emo_timer_end(EMO_TIMER_ATTN_BWD_DPOS, st2);
+      }
+    };
+    // (forked right behind the KEY pass -- which writes the dS image since R6 -- the table gradient ran beside the query pass and
+    // both stretched by what was hidden: query pass 2.93 -> 3.51 ms per step, the step 26.19 against 26.27 ms; it stays behind both)
+    if (rel) { if (g_tr) EMO_Q_LAUNCH(true, true); else EMO_Q_LAUNCH(false, true); }
+    else     { if (g_tr) EMO_Q_LAUNCH(true, false); else EMO_Q_LAUNCH(false, false); }
+#undef EMO_KV_LAUNCH
+#undef EMO_Q_LAUNCH
+    emo_timer_end(EMO_TIMER_ATTN_BWD_MAIN, s);
+    table_grad();
 #ifdef EMO_ATTN_STAMP
     {  // debug builds: per-phase cycle counts of wave 0 of workgroup 0 of both passes, averaged over the sweep
       static int printed = 0;
