@@ -828,6 +828,9 @@ def main():
         print("[headline] hipMalloc calls in the timed region: %d (segments %d -> %d, reserved %.1f -> %.1f GiB)" % (
             st1["num_device_alloc"] - stats0["num_device_alloc"], stats0["segment.all.current"], st1["segment.all.current"],
             stats0["reserved_bytes.all.current"] / 2**30, st1["reserved_bytes.all.current"] / 2**30), file=sys.stderr, flush=True)
+    # a rate measured on broken arithmetic is no measurement: the last loss and every parameter must be finite after the timed steps
+    if not (bool(torch.isfinite(loss.detach()).all()) and bool(torch.isfinite(eng.arena.flat).all())):
+        raise SystemExit("bench.py: non-finite loss or parameters after the timed steps (loss %r)" % (float(loss.detach()),))
     emo_lib.set_option("timers", 0)
     emo_lib.set_option("timer_stride", 1)
     dom = family_table(emo_lib, attn_work(pairs)).get(dominant, {"calls": 0, "ms": 0.0})

@@ -342,6 +342,23 @@ __device__ __forceinline__ uint64_t drop_index(const emoasr_attn_t& a, int b, in
   return (((uint64_t)b * a.H + h) * a.Tq + i) * (uint64_t)((a.Tk + 1) & ~1) + j;
 }
 
+// Sum over the 32 lanes of each half wave without the LDS pipeline: four DPP adds inside the rows of 16 (quad swaps, half mirror, mirror),
+// then row_bcast:15 carries row 0's total into row 1 (row 2's into row 3).  The total is valid in lanes 16..31 of each half -- callers read
+// lane il == 31.  (__shfl_xor is a ds_bpermute: the five-step trees over 32 accumulator registers were 160 LDS round trips per wave and the
+// bias-gradient epilogues took 20 k cycles of a 72 k cycle workgroup.)
+template <int CTRL, int ROWS = 0xf> __device__ __forceinline__ float dpp_take(const float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ float half_sum32(float v) {
+  v += dpp_take<0xB1>(v);          // quad_perm [1, 0, 3, 2]
+  v += dpp_take<0x4E>(v);          // quad_perm [2, 3, 0, 1]
+  v += dpp_take<0x141>(v);         // row_half_mirror
+  v += dpp_take<0x140>(v);         // row_mirror: every lane of a row holds the row's sum
+  v += dpp_take<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+  return v;
+}
+
+
 // write a [64 d][32 cols] transposed accumulator pair (rows d in registers, col = row index
 // of the destination matrix on the lane) to dst[row = r0 + (lane&31)][d], optionally summed
 // with a second pair.
@@ -1096,9 +1113,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const emoasr_attn_t a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float su = qval ? dqu[dt][r] : 0.f, sv = qval ? dqv[dt][r] : 0.f;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { su += __shfl_xor(su, o, 64); sv += __shfl_xor(sv, o, 64); }
-        if ((lane & 31) == 0) {
+        su = half_sum32(su);
+        sv = half_sum32(sv);
+        if ((lane & 31) == 31) {
           const int d = h * DK + 32 * dt + c_row(r, lane);
           if (a.dbias_u) atomicAdd(&a.dbias_u[d], su);
           if (!STORED && a.dbias_v && hp.pos) atomicAdd(&a.dbias_v[d], sv);
@@ -1369,9 +1386,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const emoasr_attn_t a
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float su = qval ? dqu[dt][r] : 0.f, sv = qval ? dqv[dt][r] : 0.f;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { su += __shfl_xor(su, o, 64); sv += __shfl_xor(sv, o, 64); }
-        if (il == 0) {
+        su = half_sum32(su);
+        sv = half_sum32(sv);
+        if (il == 31) {
           const int d = 32 * dt + c_row(r, lane);
           if (a.dbias_part) {  // per-(batch, query tile) partials, folded by attn_dbias_reduce_kernel
             float* pp = a.dbias_part + ((((long)b * gridDim.x + blockIdx.x) * a.H + h) * 2) * DK + d;
@@ -2081,9 +2098,8 @@ __global__ __launch_bounds__(64 * FW, 1) void attn_bwd_fused_kernel(const emoasr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = csum[r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (il == 0) cs[c_row(r, lane)] = v;
+        v = half_sum32(v);
+        if (il == 31) cs[c_row(r, lane)] = v;
       }
       __builtin_amdgcn_wave_barrier();
       const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k);
@@ -2352,6 +2368,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
     ws.qu = (const T*)ws.qu + g.row * ws.ldqu;
     ws.qv = (const T*)ws.qv + g.row * ws.ldqu;
     if (ws.mask) ws.mask += g.row * a.H * ws.mask_nw;
+    if (ws.dsq) ws.dsq = (T*)ws.dsq + g.row * a.H * ws.ldds;   // the dS image this pass writes (R6), as the query pass reads it
   }
   const int jblk = blk.x * (32 * FW), h = blk.y;
   if (jblk >= a.Tk) return;
@@ -2825,9 +2842,8 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_q_kernel(const emoasr_att
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = dq[dt][r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (il == 0) cs[32 * dt + c_row(r, lane)] = v;
+        v = half_sum32(v);
+        if (il == 31) cs[32 * dt + c_row(r, lane)] = v;
       }
     __builtin_amdgcn_wave_barrier();
     atomicAdd(&a.dbias_v[h * DK + lane], cs[lane]);
@@ -2861,6 +2877,9 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), il = lane & 31, hh = lane >> 5;
   emoasr_attn_t a = a_in;
   FusedWs ws = ws_in;
+#ifdef EMO_ATTN_STAMP
+  if (ws_in.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ws_in.stamp[60 * 13] = __builtin_amdgcn_s_memtime();
+#endif
   const Blk3 blk = attn_block(nt, a_in.H, a_in.B);
   if (!blk.ok) return;
   int b = blk.z;
@@ -2889,13 +2908,16 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
   const int trow = tid / PER_ROW, piece = (tid % PER_ROW) * VEC;
   const unsigned k_lane = (unsigned)trow * kstride + (unsigned)piece * 2u;
   const unsigned p_lane = (unsigned)((a.Tq - 32 * FW - iblk + trow) * (int)pstride) + (unsigned)piece * 2u;   // block 0
-  Vec16<T> pre[2];
-  auto fetch = [&](const int step) {   // K tile of `step` and the band block it adds (block step + FW)
+  // K tile of `step` and the band block it adds (block step + FW): THREE named register sets, tile t in set t mod 3, so a load
+  // has three steps to land before its stash (with one step of lead a workgroup's time was nstep x the memory round trip:
+  // 12 MFMAs per tile are far shorter than that)
+  Vec16<T> pA[2], pB[2], pC[2];
+  auto fetch = [&](Vec16<T> (&pre)[2], const int step) {
     const unsigned dead = step < nstep ? 0u : 0x80000000u;
     pre[0] = buf_load16<T>(rsK, (k_lane + (unsigned)(32 * step) * kstride) | dead);
     pre[1] = buf_load16<T>(rsP, (p_lane + (unsigned)(32 * (step + FW)) * pstride) | dead);
   };
-  auto stash = [&](const int step) {
+  auto stash = [&](const Vec16<T> (&pre)[2], const int step) {
     store16(Ks + trow * LD + piece, pre[0]);
     store16(ring + (((step + FW) % NRING) * 32 + trow) * LD + piece, pre[1]);
   };
@@ -2912,30 +2934,37 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
   };
 #pragma unroll
   for (int n = 0; n < FW; ++n) store16(ring + (n * 32 + trow) * LD + piece, buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride));
-  fetch(0);
-  stash(0);
-  fetch(1);
-  u32x2 dnext[4];
-  fetch_ds(dnext, 0);
+  fetch(pA, 0);
+  stash(pA, 0);
+  fetch(pB, 1);
+  fetch(pC, 2);
+  fetch(pA, 3);
+  // the dS rows come straight from global memory into registers, THREE key tiles ahead (three named register sets: with one tile
+  // of lead the pass waited a memory round trip per step -- 12 MFMAs per tile leave nothing to hide it behind)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int v = lane + 64 * q;   // 32 rows x 8 pieces of 8 columns
+    *reinterpret_cast<u32x4*>(img_g + (v >> 3) * LDG + 8 * (v & 7)) = u32x4{0u, 0u, 0u, 0u};
+  }
+  u32x2 dr0[4], dr1[4], dr2[4];
+  fetch_ds(dr0, 0);
+  fetch_ds(dr1, 1);
+  fetch_ds(dr2, 2);
   __syncthreads();
   f32x16 dq[2];
   zero16(dq[0]); zero16(dq[1]);
 
-  for (int step = 0; step < nstep; ++step) {
+  auto body = [&](const int step, u32x2 (&dset)[4], Vec16<T> (&pset)[2]) __attribute__((always_inline)) {
     u32x2 dcur[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) dcur[g] = dnext[g];
-    fetch_ds(dnext, step + 1);
+    for (int g = 0; g < 4; ++g) dcur[g] = dset[g];
+    EMO_STAMP(0);
+    fetch_ds(dset, step + 3);
     if (live) {
       const T* Bs0 = ring + ((FW - 1 - wave + step) % NRING) * 32 * LD;
       const T* Bs1 = ring + ((FW - wave + step) % NRING) * 32 * LD;
-      // the dG image: cleared with 16-byte stores, then the tile's 32 x 32 entries at band column c = key - il + 31
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int v = lane + 64 * q;   // 32 rows x 8 pieces of 8 columns
-        *reinterpret_cast<u32x4*>(img_g + (v >> 3) * LDG + 8 * (v & 7)) = u32x4{0u, 0u, 0u, 0u};
-      }
-      __builtin_amdgcn_wave_barrier();
+      // the dG image: the tile's 32 x 32 entries at band column c = key - il + 31 -- the same entries at every step, so the rest of the
+      // image was cleared once, ahead of the loop
       typename M_::Frag df[NS];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -2948,12 +2977,14 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
         }
       }
       __builtin_amdgcn_wave_barrier();
+      EMO_STAMP(1);
       // dQ^T += K^T dS^T (key index in the registers) + band^T unskew(dS^T)
 #pragma unroll
       for (int ks = 0; ks < NS; ++ks) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) dq[dt] = M_::mma(chain_a<T, TR>(Ks, ks, 32 * dt, lane), df[ks], dq[dt]);
       }
+      EMO_STAMP(2);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -2965,11 +2996,27 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
         }
       __builtin_amdgcn_wave_barrier();   // the image has been read
     }
+    EMO_STAMP(3); EMO_STAMP(4); EMO_STAMP(5);
     lds_barrier();   // every wave has read the stage
-    stash(step + 1);
-    fetch(step + 2);
+    EMO_STAMP(6);
+    stash(pset, step + 1);
+    EMO_STAMP(7);
+    fetch(pset, step + 4);
+    EMO_STAMP(8);
     lds_barrier();   // stage ready
+    EMO_STAMP(9);
+  };
+#ifdef EMO_ATTN_STAMP
+  if (ws.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ws.stamp[60 * 13 + 1] = __builtin_amdgcn_s_memtime();
+#endif
+  for (int step = 0; step < nstep; step += 3) {
+    body(step, dr0, pB);
+    if (step + 1 < nstep) body(step + 1, dr1, pC);
+    if (step + 2 < nstep) body(step + 2, dr2, pA);
   }
+#ifdef EMO_ATTN_STAMP
+  if (ws.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ws.stamp[60 * 13 + 2] = __builtin_amdgcn_s_memtime();
+#endif
   if (!live) return;
   store_dT<T>((T*)hp.dq, a.ldq, i0, a.Tq, dq, 1.f, lane);
   if (a.dbias_v) {
@@ -2980,13 +3027,15 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = dq[dt][r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (il == 0) cs[32 * dt + c_row(r, lane)] = v;
+        v = half_sum32(v);
+        if (il == 31) cs[32 * dt + c_row(r, lane)] = v;
       }
     __builtin_amdgcn_wave_barrier();
     atomicAdd(&a.dbias_v[h * DK + lane], cs[lane]);
   }
+#ifdef EMO_ATTN_STAMP
+  if (ws.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ws.stamp[60 * 13 + 3] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 template <typename T>
@@ -3506,6 +3555,10 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
           double tot = 0;
           for (int k = 1; k < 10; ++k) { fprintf(stderr, " %s %.0f", nm[kq][k], acc[k] / (cnt > 0 ? cnt : 1)); tot += acc[k] / (cnt > 0 ? cnt : 1); }
           fprintf(stderr, " | total %.0f\n", tot);
+          if (kq && use_q2)   // the image-reading query pass also stamps its entry, loop start, loop end and exit
+            fprintf(stderr, "[attn stamp q2] prologue %.0f  loop %.0f  epilogue %.0f cycles (phases: 1 image, 2 K MFMAs, 3 band MFMAs)\n",
+                    (double)(h[64 * 13 + 60 * 13 + 1] - h[64 * 13 + 60 * 13]), (double)(h[64 * 13 + 60 * 13 + 2] - h[64 * 13 + 60 * 13 + 1]),
+                    (double)(h[64 * 13 + 60 * 13 + 3] - h[64 * 13 + 60 * 13 + 2]));
         }
       }
     }
