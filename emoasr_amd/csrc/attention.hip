@@ -1738,8 +1738,14 @@ template <typename T, int FW> struct FusedCfg {
     if (ws.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)               \
       ws.stamp[step * 13 + (k)] = __builtin_amdgcn_s_memtime();                                               \
   } while (0)
+#define EMO_WSTAMP(W, k)                                                                                     \
+  do {                                                                                                        \
+    if ((W).stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)              \
+      (W).stamp[60 * 13 + (k)] = __builtin_amdgcn_s_memtime();                                                \
+  } while (0)
 #else
 #define EMO_STAMP(k) do {} while (0)
+#define EMO_WSTAMP(W, k) do {} while (0)
 #endif
 
 // the workgroup barrier of the sweep: LDS traffic only (no vmcnt: the prefetch loads, the dS stores and the dQ
@@ -2359,6 +2365,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, hh = lane >> 5;
   emoasr_attn_t a = a_in;
   FusedWs ws = ws_in;
+  EMO_WSTAMP(ws_in, 0);
   const Blk3 blk = attn_block(nt, a_in.H, a_in.B);
   if (!blk.ok) return;
   int b = blk.z;
@@ -2470,26 +2477,37 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
     const __amdgpu_buffer_rsrc_t rsK = make_rsrc(hp.k), rsV = make_rsrc(hp.v);
     T* kt0 = reinterpret_cast<T*>(smem + C_::kv_stage_bytes(REL));
     constexpr int KPT = 32 * FW * PER_ROW / NTHR;   // pieces per thread and operand (= 4)
+    // every load of the prologue -- K, V, the band blocks 1 .. FW of step 0 (block 0 comes with fetch(0)) and the first step's
+    // operands -- is issued before the first LDS store: ONE memory round trip ahead of the loop instead of three (the prologue and
+    // epilogue were 30 % of a workgroup's time, in-kernel stamps of round 6)
+    Vec16<T> kx[KPT], vx[KPT], rg[REL ? FW : 1];
 #pragma unroll
     for (int p = 0; p < KPT; ++p) {
       const int pid = tid + NTHR * p, row = pid / PER_ROW, piece = (pid % PER_ROW) * VEC;
       const bool ok = jblk + row < a.Tk;
-      const Vec16<T> kx = buf_load16<T>(rsK, ok ? (unsigned)(((long)(jblk + row) * a.ldk + piece) * sizeof(T)) : EMO_OOB);
-      const Vec16<T> vx = buf_load16<T>(rsV, ok ? (unsigned)(((long)(jblk + row) * a.ldv + piece) * sizeof(T)) : EMO_OOB);
-      store16(kt0 + row * LD + piece, kx);
-      store16(kt0 + (32 * FW + row) * LD + piece, vx);
+      kx[p] = buf_load16<T>(rsK, ok ? (unsigned)(((long)(jblk + row) * a.ldk + piece) * sizeof(T)) : EMO_OOB);
+      vx[p] = buf_load16<T>(rsV, ok ? (unsigned)(((long)(jblk + row) * a.ldv + piece) * sizeof(T)) : EMO_OOB);
+    }
+    if constexpr (REL) {
+#pragma unroll
+      for (int n = 1; n <= FW; ++n) rg[n - 1] = (dbg & 1) ? Vec16<T>{} : buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride);
+    }
+    fetch(0);
+#pragma unroll
+    for (int p = 0; p < KPT; ++p) {
+      const int pid = tid + NTHR * p, row = pid / PER_ROW, piece = (pid % PER_ROW) * VEC;
+      store16(kt0 + row * LD + piece, kx[p]);
+      store16(kt0 + (32 * FW + row) * LD + piece, vx[p]);
+    }
+    if constexpr (REL) {
+#pragma unroll
+      for (int n = 1; n <= FW; ++n) store16(ring + (n * 32 + trow) * LD + piece, rg[n - 1]);
     }
   }
   const int kj = j0 + il;
   f32x16 dk[2], dv[2];
   zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
   float csum = 0.f;  // sum over this lane's queries of dS[:, key kj]
-  if constexpr (REL) {   // blocks 1 .. FW of step 0 (block 0 comes with fetch(0))
-#pragma unroll
-    for (int n = 1; n <= FW; ++n)
-      store16(ring + (n * 32 + trow) * LD + piece, (dbg & 1) ? Vec16<T>{} : buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride));
-  }
-  fetch(0);
   stash(0);
   fetch(1);
   __syncthreads();
@@ -2507,6 +2525,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   // its element c = 31 - (rr + 4 hh) + il to lane il -- from tile 0 (c < 32, i.e. il <= row) or tile 1, the same source lane
   const int skew_base = il + 31 - 4 * hh;
 
+  EMO_WSTAMP(ws, 1);
   for (int step = 0; step < nstep; ++step) {
     const int i0 = step * 32;
     const T* Qus = stage0;
@@ -2567,7 +2586,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
           csum += dsv;
           pf[g >> 1][4 * (g & 1) + e] = (bf16)(p * m);
           df[g >> 1][4 * (g & 1) + e] = (bf16)dsv;
-          if (has_img)
+          if (has_img)   // (pairing two lanes' values into 4-byte stores over DPP was measured: 110 against 103 us at B 110, T' 320)
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16)dsv), rsI,
                                                   img_lane + (unsigned)(i0 + 8 * g + 4 * hh + e) * img_rstride, 0, 0);
         }
@@ -2593,6 +2612,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
     lds_barrier();   // stage ready
     EMO_STAMP(9);
   }
+  EMO_WSTAMP(ws, 2);
   store_dT<T>((T*)hp.dk, a.ldk, j0, a.Tk, dk, 1.f, lane);  // (a dead wave stores zeros)
   store_dT<T>((T*)hp.dv, a.ldv, j0, a.Tk, dv, 1.f, lane);
   if (REL && a.dbias_u && live) {
@@ -2604,6 +2624,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
     atomicAdd(&a.dbias_u[h * DK + lane], acc);
     atomicAdd(&a.dbias_v[h * DK + lane], -acc);
   }
+  EMO_WSTAMP(ws, 3);
 }
 
 template <typename T, bool TR, bool REL, int FW>
@@ -2877,9 +2898,7 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), il = lane & 31, hh = lane >> 5;
   emoasr_attn_t a = a_in;
   FusedWs ws = ws_in;
-#ifdef EMO_ATTN_STAMP
-  if (ws_in.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ws_in.stamp[60 * 13] = __builtin_amdgcn_s_memtime();
-#endif
+  EMO_WSTAMP(ws_in, 0);
   const Blk3 blk = attn_block(nt, a_in.H, a_in.B);
   if (!blk.ok) return;
   int b = blk.z;
@@ -3006,17 +3025,13 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
     lds_barrier();   // stage ready
     EMO_STAMP(9);
   };
-#ifdef EMO_ATTN_STAMP
-  if (ws.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ws.stamp[60 * 13 + 1] = __builtin_amdgcn_s_memtime();
-#endif
+  EMO_WSTAMP(ws, 1);
   for (int step = 0; step < nstep; step += 3) {
     body(step, dr0, pB);
     if (step + 1 < nstep) body(step + 1, dr1, pC);
     if (step + 2 < nstep) body(step + 2, dr2, pA);
   }
-#ifdef EMO_ATTN_STAMP
-  if (ws.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ws.stamp[60 * 13 + 2] = __builtin_amdgcn_s_memtime();
-#endif
+  EMO_WSTAMP(ws, 2);
   if (!live) return;
   store_dT<T>((T*)hp.dq, a.ldq, i0, a.Tq, dq, 1.f, lane);
   if (a.dbias_v) {
@@ -3033,9 +3048,7 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
     __builtin_amdgcn_wave_barrier();
     atomicAdd(&a.dbias_v[h * DK + lane], cs[lane]);
   }
-#ifdef EMO_ATTN_STAMP
-  if (ws.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ws.stamp[60 * 13 + 3] = __builtin_amdgcn_s_memtime();
-#endif
+  EMO_WSTAMP(ws, 3);
 }
 
 template <typename T>
@@ -3555,10 +3568,11 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
           double tot = 0;
           for (int k = 1; k < 10; ++k) { fprintf(stderr, " %s %.0f", nm[kq][k], acc[k] / (cnt > 0 ? cnt : 1)); tot += acc[k] / (cnt > 0 ? cnt : 1); }
           fprintf(stderr, " | total %.0f\n", tot);
-          if (kq && use_q2)   // the image-reading query pass also stamps its entry, loop start, loop end and exit
-            fprintf(stderr, "[attn stamp q2] prologue %.0f  loop %.0f  epilogue %.0f cycles (phases: 1 image, 2 K MFMAs, 3 band MFMAs)\n",
-                    (double)(h[64 * 13 + 60 * 13 + 1] - h[64 * 13 + 60 * 13]), (double)(h[64 * 13 + 60 * 13 + 2] - h[64 * 13 + 60 * 13 + 1]),
-                    (double)(h[64 * 13 + 60 * 13 + 3] - h[64 * 13 + 60 * 13 + 2]));
+          if (!kq || use_q2) {   // the key pass and the image-reading query pass also stamp their entry, loop start, loop end and exit
+            const unsigned long long* w = h + kq * 64 * 13 + 60 * 13;
+            fprintf(stderr, "[attn stamp %s] prologue %.0f  loop %.0f  epilogue %.0f cycles%s\n", kq ? "q2" : "kv", (double)(w[1] - w[0]),
+                    (double)(w[2] - w[1]), (double)(w[3] - w[2]), kq ? " (phases: 1 image, 2 K MFMAs, 3 band MFMAs)" : "");
+          }
         }
       }
     }
