@@ -756,10 +756,15 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_fwd4_kernel(const emoasr_attn
     qu[kk] = frag_global<T>((const T*)hp.q, a.ldq, qi, live && qval, kk, lane, hp.bias_u);
     qv[kk] = frag_global<T>((const T*)hp.q, a.ldq, qi, live && qval, kk, lane, hp.bias_v);
   }
-  // blocks 0 .. FW - 1 of step 0 (block FW comes with fetch(0))
+  // blocks 0 .. FW - 1 of step 0 (block FW comes with fetch(0)): every load of the prologue is issued before the first LDS store
+  {
+    Vec16<T> rg[FW];
 #pragma unroll
-  for (int n = 0; n < FW; ++n) store16(ring + (n * 32 + trow) * LD + piece, buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride));
-  fetch(0);
+    for (int n = 0; n < FW; ++n) rg[n] = buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride);
+    fetch(0);
+#pragma unroll
+    for (int n = 0; n < FW; ++n) store16(ring + (n * 32 + trow) * LD + piece, rg[n]);
+  }
   stash(0);
   fetch(1);
   __syncthreads();
@@ -2951,9 +2956,14 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
       d[g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsI, off, 0, 0));
     }
   };
+  {
+    Vec16<T> rg[FW];
 #pragma unroll
-  for (int n = 0; n < FW; ++n) store16(ring + (n * 32 + trow) * LD + piece, buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride));
-  fetch(pA, 0);
+    for (int n = 0; n < FW; ++n) rg[n] = buf_load16<T>(rsP, p_lane + (unsigned)(32 * n) * pstride);
+    fetch(pA, 0);
+#pragma unroll
+    for (int n = 0; n < FW; ++n) store16(ring + (n * 32 + trow) * LD + piece, rg[n]);
+  }
   stash(pA, 0);
   fetch(pB, 1);
   fetch(pC, 2);
