@@ -3567,21 +3567,23 @@ int launch_bwd_fused(const emoasr_attn_t& a_in, char* mem, size_t bytes, hipStre
         hipStreamSynchronize(s);
         hipMemcpy(h, ws.stamp - 64 * 13, sizeof(h), hipMemcpyDeviceToHost);
         const int ns = (a.Tq + 31) / 32 < 64 ? (a.Tq + 31) / 32 : 64;
-        const char* nm[2][10] = {{"", "loads+S+dP", "band+skew write", "skew read", "soft-max", "dV+dK", "barrier1", "stash", "fetch", "barrier2"},
-                                 {"", "band+skew write+S+dP", "skew read", "soft-max+image", "dS store", "dQ", "barrier1", "stash", "fetch", "barrier2"}};
+        const char* nm[3][10] = {{"", "loads+S+dP", "band+skew write", "skew read", "soft-max", "dV+dK", "barrier1", "stash", "fetch", "barrier2"},
+                                 {"", "band+skew write+S+dP", "skew read", "soft-max+image", "dS store", "dQ", "barrier1", "stash", "fetch", "barrier2"},
+                                 {"", "dS registers -> dG image", "dQ from K", "dQ from the band", "-", "-", "barrier1", "stash", "fetch", "barrier2"}};
         for (int kq = 0; kq < 2; ++kq) {
           double acc[10] = {0};
           int cnt = 0;
           for (int st = 1; st + 1 < ns; ++st, ++cnt)
             for (int k = 1; k < 10; ++k) acc[k] += (double)(h[kq * 64 * 13 + st * 13 + k] - h[kq * 64 * 13 + st * 13 + k - 1]);
-          fprintf(stderr, "[attn stamp %s] B %d T %d: per step (cycles):", kq ? "q" : "kv", a.B, a.Tq);
+          fprintf(stderr, "[attn stamp %s] B %d T %d: per step (cycles):", kq ? (use_q2 ? "q2" : "q") : "kv", a.B, a.Tq);
           double tot = 0;
-          for (int k = 1; k < 10; ++k) { fprintf(stderr, " %s %.0f", nm[kq][k], acc[k] / (cnt > 0 ? cnt : 1)); tot += acc[k] / (cnt > 0 ? cnt : 1); }
+          const int names = kq ? (use_q2 ? 2 : 1) : 0;
+          for (int k = 1; k < 10; ++k) { fprintf(stderr, " %s %.0f", nm[names][k], acc[k] / (cnt > 0 ? cnt : 1)); tot += acc[k] / (cnt > 0 ? cnt : 1); }
           fprintf(stderr, " | total %.0f\n", tot);
           if (!kq || use_q2) {   // the key pass and the image-reading query pass also stamp their entry, loop start, loop end and exit
             const unsigned long long* w = h + kq * 64 * 13 + 60 * 13;
             fprintf(stderr, "[attn stamp %s] prologue %.0f  loop %.0f  epilogue %.0f cycles%s\n", kq ? "q2" : "kv", (double)(w[1] - w[0]),
-                    (double)(w[2] - w[1]), (double)(w[3] - w[2]), kq ? " (phases: 1 image, 2 K MFMAs, 3 band MFMAs)" : "");
+                    (double)(w[2] - w[1]), (double)(w[3] - w[2]), "");
           }
         }
       }
