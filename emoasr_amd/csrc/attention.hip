@@ -2523,7 +2523,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   const bool has_img = REL && ws.dsq != nullptr && ws.img_from_kv;
   const __amdgpu_buffer_rsrc_t rsI = make_rsrc_n(has_img ? (const T*)ws.dsq + ((long)b * a.H + h) * a.Tq * ws.ldds : (const T*)hp.k,
                                                  has_img ? (unsigned)a.Tq * (unsigned)ws.ldds * 2u : 0u);
-  const unsigned img_lane = (unsigned)kj * 2u, img_rstride = (unsigned)ws.ldds * 2u;
+  const unsigned img_rstride = (unsigned)ws.ldds * 2u, img_lane = (unsigned)kj * 2u + (unsigned)(4 * hh) * img_rstride;
   const float c_exp = a.scale * 1.4426950408889634f;
   const unsigned keep_bits = __float_as_uint(a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f);
   // the band skew as a lane rotation (ds_bpermute: no LDS storage): accumulator row rr + 4 hh of the band tiles G[query][c] gives
@@ -2591,9 +2591,11 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
           csum += dsv;
           pf[g >> 1][4 * (g & 1) + e] = (bf16)(p * m);
           df[g >> 1][4 * (g & 1) + e] = (bf16)dsv;
-          if (has_img)   // (pairing two lanes' values into 4-byte stores over DPP was measured: 110 against 103 us at B 110, T' 320)
-            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16)dsv), rsI,
-                                                  img_lane + (unsigned)(i0 + 8 * g + 4 * hh + e) * img_rstride, 0, 0);
+          // UNCONDITIONAL: without an image the descriptor has no records and the store falls outside it (an `if (has_img)` here was
+          // a scalar branch per element: 16 basic blocks per step that nothing could be scheduled across).  The row's offset is the
+          // scalar operand.  (Pairing two lanes' values into 4-byte stores over DPP was measured: 110 against 103 us at B 110, T' 320.)
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16)dsv), rsI, img_lane,
+                                                (unsigned)(i0 + 8 * g + e) * img_rstride, 0);
         }
       }
       EMO_STAMP(4);
