@@ -287,13 +287,13 @@ def test_gemm_nt_long_reductions_on_one_column_tile(dev, M, N, K):
     x0 = _rnd(dev, M, N, dtype=torch.bfloat16)
     outs = []
     try:
-        for big in (2, 0):   # (2: N = 256 from K = 512 on; the default, 1, takes K >= 2048 only)
+        for big in (2, 0):   # (2, the default: N = 256 from K = 512 on; 1 takes K >= 2048 only)
             lib.set_option("big_n256", big)
             x = x0.clone()
             ops.gemm_nt(a, b, out=x, bias=bias, residual=x, res_scale=0.5, drop_p=0.1, seed=91)   # in place
             outs.append((x, ops.gemm_nt(a, b, bias=bias, residual=x0, res_scale=0.5), ops.gemm_nt(a, b, bias=bias)))
     finally:
-        lib.set_option("big_n256", 1)
+        lib.set_option("big_n256", 2)   # (the library's default)
     (x1, r1, p1), (x0_, r0, p0) = outs
     assert torch.equal(x1 == x0, x0_ == x0), "dropout masks differ"
     ref = a.float() @ b.float().t() + bias
