@@ -2348,7 +2348,10 @@ __global__ __launch_bounds__(1024) void attn_dropmask_kernel(const emoasr_attn_t
 }
 
 #ifndef EMO_KV_DBG
-#define EMO_KV_DBG 0   // timing ablations of attn_bwd_kv_kernel, build variants only (results are then wrong): 1 no band loads, 2 no
+#define EMO_KV_DBG 0
+#ifndef EMO_KV_SRCSEL
+#define EMO_KV_SRCSEL 1
+#endif   // timing ablations of attn_bwd_kv_kernel, build variants only (results are then wrong): 1 no band loads, 2 no
 #endif                 // lane rotation, 4 no query-side loads.  (As a kernel ARGUMENT -- rounds 4-5 -- every use was a scalar branch:
                        // each of the 32 rotations of a step sat in a basic block of its own.)
 template <typename T, bool TR, bool REL, int FW>
@@ -2470,9 +2473,10 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
       else store16(ring + (ring_slot(-step) * 32 + trow) * LD + piece, pre[p]);
     }
     if (wave == 0 && hh == 0) {
-      // p = exp2(c_exp * s - lse * log2 e): padding queries and rows without a valid key (lse = -inf) get +inf -> p = 0
-      rowc[il] = (pre_ok && pre_lse != -INFINITY) ? pre_lse * 1.4426950408889634f : INFINITY;
-      rowc[32 + il] = pre_del;
+      // p = exp2(fma(s, c_exp, -lse * log2 e)): padding queries and rows without a valid key (lse = -inf) get -inf -> p = 0;
+      // dS = p * fma(dP, keep * scale, -delta * scale): both row constants are stored negated (and delta scaled) for the fused multiply-adds
+      rowc[il] = (pre_ok && pre_lse != -INFINITY) ? -pre_lse * 1.4426950408889634f : -INFINITY;
+      rowc[32 + il] = -pre_del * a.scale;
     }
     if (tid < 32 * FW) maskw[tid] = pre_mask;   // (without dropout: all ones)
   };
@@ -2517,6 +2521,8 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   fetch(1);
   __syncthreads();
   const bool kvalid = kj < hp.klen;
+  // a key past the utterance's length starts its score accumulator at -1e30: exp2 gives p = 0 exactly, and no select per element
+  const float s_init = kvalid ? 0.f : -1e30f;
   // R6: this pass writes the dS image (bf16, query-major [b, h, i, ldds]) that the query pass (attn_bwd_q2_kernel) and the table
   // gradient read: the query pass no longer recomputes S, dP, the band product and the soft-max.  Lane = key: one 2-byte store per
   // accumulator register, the 32 lanes of a half wave cover 64 contiguous bytes; rows past Tq fall outside the descriptor.
@@ -2526,6 +2532,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   const unsigned img_rstride = (unsigned)ws.ldds * 2u, img_lane = (unsigned)kj * 2u + (unsigned)(4 * hh) * img_rstride;
   const float c_exp = a.scale * 1.4426950408889634f;
   const unsigned keep_bits = __float_as_uint(a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f);
+  const unsigned keep_bits_s = __float_as_uint((a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f) * a.scale);
   // the band skew as a lane rotation (ds_bpermute: no LDS storage): accumulator row rr + 4 hh of the band tiles G[query][c] gives
   // its element c = 31 - (rr + 4 hh) + il to lane il -- from tile 0 (c < 32, i.e. il <= row) or tile 1, the same source lane
   const int skew_base = il + 31 - 4 * hh;
@@ -2545,7 +2552,9 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
       // 363 us at B 110, T' 320; the compiler's own placement, each read next to its MFMA, with the second wave of the SIMD
       // covering the round trip, stays.)
       f32x16 s, dp;
-      zero16(s); zero16(dp);
+      zero16(dp);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = s_init;
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) {
         s = M_::mma(M_::load_kc(Qus, LD, 0, kk * M_::KSTEP, lane), M_::load_kc(Kt, LD, 0, kk * M_::KSTEP, lane), s);
@@ -2567,37 +2576,63 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2);
           const int addr = (((skew_base - rr) & 31) + 32 * hh) * 4;
+          // the choice between the two band tiles is made on the SOURCE lane: lane c of row q holds band column c of tile 0 and 32 + c
+          // of tile 1, and the one reader of that lane and row wants tile 0 exactly when c >= 31 - q -- one rotation per element, not two
+#if EMO_KV_SRCSEL
+          const float gv = (il >= 31 - (rr + 4 * hh)) ? g0[r] : g1[r];
+          s[r] += (dbg & 2) ? gv : __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(gv)));
+#else
           const float x0 = (dbg & 2) ? g0[r] : __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(g0[r])));
           const float x1 = (dbg & 2) ? g1[r] : __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(g1[r])));
           s[r] += (il <= rr + 4 * hh) ? x0 : x1;
+#endif
         }
       }
       EMO_STAMP(3);
       // soft-max, dropout, dS: accumulator rows 4 g .. 4 g + 3 are queries i0 + 8 g + 4 hh + 0 .. 3
       typename M_::Frag pf[NS], df[NS];   // P and dS as the next products' B operands (accumulator rows 8 ks .. 8 ks + 7, chain_b's order)
+      unsigned dsw[8];                    // dS of rows (8 g + 4 hh + 2 h2, + 1) as bf16 pairs: word 2 g + h2
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(rowc + 8 * g + 4 * hh);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(rowc + 32 + 8 * g + 4 * hh);
         const u32x4 m4 = *reinterpret_cast<const u32x4*>(maskw + 32 * wave + 8 * g + 4 * hh);   // keep bits of the rows' keys j0 .. j0 + 31
+        float dsf[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          float p = __builtin_amdgcn_exp2f(s[r] * c_exp - l4[e]);
-          p = kvalid ? p : 0.f;
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c_exp, l4[e]));
           // bit il of the row's word: 0 / -1 -> 0 / keep (attn_dropmask_kernel hashed the mask once for both passes)
-          const float m = __uint_as_float((unsigned)__builtin_amdgcn_sbfe(m4[e], il, 1) & keep_bits);
-          const float dsv = p * (dp[r] * m - d4[e]) * a.scale;
+          const unsigned kb = (unsigned)__builtin_amdgcn_sbfe(m4[e], il, 1);
+          const float m = __uint_as_float(kb & keep_bits);
+          const float dsv = p * __builtin_fmaf(dp[r], __uint_as_float(kb & keep_bits_s), d4[e]);
           csum += dsv;
           pf[g >> 1][4 * (g & 1) + e] = (bf16)(p * m);
-          df[g >> 1][4 * (g & 1) + e] = (bf16)dsv;
-          // UNCONDITIONAL: without an image the descriptor has no records and the store falls outside it (an `if (has_img)` here was
-          // a scalar branch per element: 16 basic blocks per step that nothing could be scheduled across).  The row's offset is the
-          // scalar operand.  (Pairing two lanes' values into 4-byte stores over DPP was measured: 110 against 103 us at B 110, T' 320.)
-          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16)dsv), rsI, img_lane,
-                                                (unsigned)(i0 + 8 * g + e) * img_rstride, 0);
+          dsf[e] = dsv;
+        }
+        // dS as explicit bf16 PAIRS: one conversion per pair serves the operand register and both image stores (low / high half)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          bf16x2 pr;
+          pr[0] = (bf16)dsf[2 * h2];
+          pr[1] = (bf16)dsf[2 * h2 + 1];
+          dsw[2 * g + h2] = __builtin_bit_cast(unsigned, pr);
         }
       }
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+        df[ks] = __builtin_bit_cast(typename M_::Frag, u32x4{dsw[4 * ks], dsw[4 * ks + 1], dsw[4 * ks + 2], dsw[4 * ks + 3]});
+      // the image rows, from the PACKED words (low / high halves: no second conversion per element; extracting the elements of the
+      // operand vector with __builtin_bit_cast compiled into 16 stores of two registers -- a wrong image).  UNCONDITIONAL: without
+      // an image the descriptor has no records and the store falls outside it (an `if (has_img)` here was a scalar branch per element:
+      // 16 basic blocks per step that nothing could be scheduled across).  The row's offset is the scalar operand.  (Pairing two lanes'
+      // values into 4-byte stores over DPP was measured: 110 against 103 us at B 110, T' 320.)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(dsw[2 * g + (e >> 1)] >> (16 * (e & 1))), rsI, img_lane,
+                                                (unsigned)(i0 + 8 * g + e) * img_rstride, 0);
       EMO_STAMP(4);
       // dV^T += dO^T P,  dK^T += (Q+u)^T dS: the accumulators are the B operands (query index in the registers)
 #pragma unroll
