@@ -697,7 +697,9 @@ template <int FW> struct Fwd4Cfg {
   static constexpr int GS_BYTES = 32 * LDG * 4;                        // per wave: f32 skew tile
   static constexpr int smem() { return STAGE_ROWS * LD * 2 + FW * GS_BYTES; }
 };
-template <bool TR, int FW>
+// DM: the dropout mode as a template parameter (0 none, 1 keep-mask bits, 2 inline hash) -- as run-time tests of `a.drop_p` and
+// `a.keep_mask` they were scalar branches inside the key loop, which cut the step into blocks nothing is scheduled across
+template <bool TR, int FW, int DM>
 __global__ __launch_bounds__(64 * FW, 2) void attn_fwd4_kernel(const emoasr_attn_t a_in, const int nt) {
   using T = bf16;
   using M_ = Mma<T>;
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_fwd4_kernel(const emoasr_attn
   fetch(1);
   __syncthreads();
 
-  const bool mbits = a.keep_mask != nullptr && a.drop_p > 0.f;
+  constexpr bool mbits = DM == 1;
   const __amdgpu_buffer_rsrc_t rsM = make_rsrc(a.keep_mask);
   const unsigned mrow = (unsigned)((((long)b * a.Tq + qi) * a.H + h) * a.keep_nw * 4);
   auto mask_word = [&](const int step) -> unsigned {
@@ -841,8 +843,8 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_fwd4_kernel(const emoasr_attn
       m = mn;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-      if (a.drop_p > 0.f) {
-        if (mbits) {
+      if constexpr (DM != 0) {
+        if constexpr (mbits) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             s[r] *= __uint_as_float((unsigned)__builtin_amdgcn_sbfe(mw, 8 * (r >> 2) + (r & 3), 1) & keep_bits);
@@ -3226,13 +3228,15 @@ int launch_fwd(const emoasr_attn_t& a_in, hipStream_t s) {
       const int nt4 = (g_attn_xcd && a.nseg > 1) ? (int)g4.x : 0;
       if (nt4) g4 = dim3(8 * cdiv(a.H * a.B, 8) * nt4, 1, 1);
       emo_timer_begin(EMO_TIMER_ATTN_FWD, s);
-      if (g_tr) {
-        if (set_smem(attn_fwd4_kernel<true, FW>, Fwd4Cfg<FW>::smem())) return 1;
-        attn_fwd4_kernel<true, FW><<<g4, 64 * FW, Fwd4Cfg<FW>::smem(), s>>>(a, nt4);
-      } else {
-        if (set_smem(attn_fwd4_kernel<false, FW>, Fwd4Cfg<FW>::smem())) return 1;
-        attn_fwd4_kernel<false, FW><<<g4, 64 * FW, Fwd4Cfg<FW>::smem(), s>>>(a, nt4);
-      }
+#define EMO_FWD4_LAUNCH(TR_, DM_)                                                                  \
+  do {                                                                                             \
+    if (set_smem(attn_fwd4_kernel<TR_, FW, DM_>, Fwd4Cfg<FW>::smem())) return 1;                    \
+    attn_fwd4_kernel<TR_, FW, DM_><<<g4, 64 * FW, Fwd4Cfg<FW>::smem(), s>>>(a, nt4);                \
+  } while (0)
+      const int dm = a.drop_p > 0.f ? (a.keep_mask ? 1 : 2) : 0;   // no dropout / keep-mask bits / inline hash
+      if (g_tr) { if (dm == 1) EMO_FWD4_LAUNCH(true, 1); else if (dm == 2) EMO_FWD4_LAUNCH(true, 2); else EMO_FWD4_LAUNCH(true, 0); }
+      else      { if (dm == 1) EMO_FWD4_LAUNCH(false, 1); else if (dm == 2) EMO_FWD4_LAUNCH(false, 2); else EMO_FWD4_LAUNCH(false, 0); }
+#undef EMO_FWD4_LAUNCH
       emo_timer_end(EMO_TIMER_ATTN_FWD, s);
       EMO_LAUNCH_CHECK();
       return 0;

@@ -25,7 +25,7 @@ def family(name):
     m = re.search(r"big_nt_kernel<(\d+), (\d)>", n) or re.search(r"big_nt_kernelILi(\d+)ELi(\d)E", n)
     if m:
         return {"0": "gemm_nt_big", "1": "conv2_fwd_big", "2": "conv2_dgrad_big"}[m.group(2)] + f"[{32 * int(m.group(1))}x256]"
-    m = re.search(r"(gemm_tn_grouped_kernel|cf_conv_bwd_kernel|cf_dwconv_kernel|gemm_tn_kernel|attn_bwd_fused_kernel|attn_bwd_kv_kernel|attn_bwd_q_kernel|attn_dropmask_kernel|attn_bwd_dpos3_kernel|attn_bwd_fin_kernel|attn_fwd4_kernel|"
+    m = re.search(r"(gemm_tn_grouped_kernel|cf_conv_bwd_kernel|cf_dwconv_kernel|gemm_tn_kernel|attn_bwd_fused_kernel|attn_bwd_kv_kernel|attn_bwd_q2_kernel|attn_bwd_q_kernel|attn_dropmask_kernel|attn_bwd_dpos3_kernel|attn_bwd_fin_kernel|attn_fwd4_kernel|"
                   r"attn_bwd_prep_kernel|attn_fwd_kernel|ln_bwd8_kernel|ln_fwd_kernel)", n)
     if m:
         return m.group(1)
