@@ -307,6 +307,29 @@ EmoScratch* lstm_area(void* stream) {
   }
   return sc;
 }
+// Cooperative launches of DIFFERENT streams must not overlap: the residency check below is per launch, and two launches that are each
+// partly resident would spin on their barriers until the give-up flag fires (two large recurrences -- B > 64 groups at H = 512, one
+// workgroup per CU -- on two streams).  A process-wide event chain per device orders them: a launch waits for the previous
+// cooperative launch if that went to another stream, and records the event behind itself.  (Same stream: already ordered.)
+struct CoopChain { hipEvent_t ev = nullptr; void* last = nullptr; bool armed = false; };
+CoopChain g_coop_chain[16];
+std::mutex g_coop_mu;
+struct CoopOrder {
+  CoopChain* ch = nullptr;
+  void* stream;
+  std::unique_lock<std::mutex> lock;
+  explicit CoopOrder(void* s) : stream(s), lock(g_coop_mu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+    ch = &g_coop_chain[dev];
+    if (!ch->ev && hipEventCreateWithFlags(&ch->ev, hipEventDisableTiming) != hipSuccess) { ch->ev = nullptr; ch = nullptr; return; }
+    if (ch->armed && ch->last != stream) hipStreamWaitEvent((hipStream_t)stream, ch->ev, 0);
+  }
+  ~CoopOrder() {   // (runs after the launch: the event sits right behind the cooperative kernel)
+    if (ch && hipEventRecord(ch->ev, (hipStream_t)stream) == hipSuccess) { ch->armed = true; ch->last = stream; }
+  }
+};
+
 unsigned* lstm_counter(EmoScratch* sc, int which, int** err) {
   unsigned* buf = static_cast<unsigned*>(sc->dev);
   *err = reinterpret_cast<int*>(buf) + 2 * L_MAXGRP * 16;
@@ -395,7 +418,10 @@ extern "C" int emoasr_lstm_seq_fwd(int dtype, int U, int B, int H, const void* p
   a.G = H / 16;
   EMO_CHECK(cap >= (long)a.G * ngrp, "lstm_seq_fwd: the device holds %ld of the %d workgroups at once", cap, a.G * ngrp);
   lstm_base(sc, 0, a.G, U, ngrp, a.base);
-  lstm_seq_fwd_kernel<<<a.G * ngrp, LT, smem, (hipStream_t)stream>>>(a);
+  {
+    CoopOrder order(stream);
+    lstm_seq_fwd_kernel<<<a.G * ngrp, LT, smem, (hipStream_t)stream>>>(a);
+  }
   EMO_LAUNCH_CHECK();
   return 0;
 }
@@ -424,7 +450,10 @@ extern "C" int emoasr_lstm_seq_bwd(int dtype, int U, int B, int H, const void* d
   a.G = H / 16;
   EMO_CHECK(cap >= (long)a.G * ngrp, "lstm_seq_bwd: the device holds %ld of the %d workgroups at once", cap, a.G * ngrp);
   lstm_base(sc, 1, a.G, U, ngrp, a.base);
-  lstm_seq_bwd_kernel<<<a.G * ngrp, LT, smem, (hipStream_t)stream>>>(a);
+  {
+    CoopOrder order(stream);
+    lstm_seq_bwd_kernel<<<a.G * ngrp, LT, smem, (hipStream_t)stream>>>(a);
+  }
   EMO_LAUNCH_CHECK();
   return 0;
 }

@@ -479,7 +479,8 @@ int emoasr_lstm_cell_bwd(int dtype, int B, int H, const void* dh_out, long lddh,
                          void* stream);
 /* The whole recurrence of one LSTM layer in one cooperative launch (csrc/lstm_coop.hip; bf16, B <= 64, H % 32 == 0, H <= 512):
  * pre [U][B][4H] = x . W_ih^T + b_ih + b_hh, w_hh [4H][H]; outputs hseq [U][B][H], cseq f32 [U][B][H], gact [U][B][4H] (activated
- * i | f | g | o).  h0 / c0 may be NULL (zeros).  emoasr_lstm_seq_supported() -> 1 if this shape runs here (option "lstm_coop"). */
+ * i | f | g | o).  h0 / c0 may be NULL (zeros).  emoasr_lstm_seq_supported() -> 1 if this shape runs here (option "lstm_coop").  Launches on DIFFERENT streams are ordered against each other by a per-device event chain (two partly resident cooperative
+ * launches would wait for each other's workgroups): streams overlap everything else, not two recurrences. */
 int emoasr_lstm_seq_supported(int dtype, int B, int H);
 int emoasr_lstm_seq_fwd(int dtype, int U, int B, int H, const void* pre, const void* w_hh, const void* h0, const float* c0,
                         void* hseq, float* cseq, void* gact, void* stream);
