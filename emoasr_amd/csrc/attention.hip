@@ -2350,10 +2350,7 @@ __global__ __launch_bounds__(1024) void attn_dropmask_kernel(const emoasr_attn_t
 }
 
 #ifndef EMO_KV_DBG
-#define EMO_KV_DBG 0
-#ifndef EMO_KV_SRCSEL
-#define EMO_KV_SRCSEL 1
-#endif   // timing ablations of attn_bwd_kv_kernel, build variants only (results are then wrong): 1 no band loads, 2 no
+#define EMO_KV_DBG 0   // timing ablations of attn_bwd_kv_kernel, build variants only (results are then wrong): 1 no band loads, 2 no
 #endif                 // lane rotation, 4 no query-side loads.  (As a kernel ARGUMENT -- rounds 4-5 -- every use was a scalar branch:
                        // each of the 32 rotations of a step sat in a basic block of its own.)
 template <typename T, bool TR, bool REL, int FW>
@@ -2580,14 +2577,8 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
           const int addr = (((skew_base - rr) & 31) + 32 * hh) * 4;
           // the choice between the two band tiles is made on the SOURCE lane: lane c of row q holds band column c of tile 0 and 32 + c
           // of tile 1, and the one reader of that lane and row wants tile 0 exactly when c >= 31 - q -- one rotation per element, not two
-#if EMO_KV_SRCSEL
           const float gv = (il >= 31 - (rr + 4 * hh)) ? g0[r] : g1[r];
           s[r] += (dbg & 2) ? gv : __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(gv)));
-#else
-          const float x0 = (dbg & 2) ? g0[r] : __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(g0[r])));
-          const float x1 = (dbg & 2) ? g1[r] : __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(g1[r])));
-          s[r] += (il <= rr + 4 * hh) ? x0 : x1;
-#endif
         }
       }
       EMO_STAMP(3);
