@@ -201,10 +201,20 @@ __device__ __forceinline__ void ln_store8(T* p, const float (&o)[8]) {
     store16(p + 4, w);
   }
 }
+// Sum over the 32 lanes of a half wave, in every lane, without the LDS pipeline (__shfl_xor is a ds_bpermute: the five-step trees
+// were ten LDS round trips per row in the backward): four DPP adds inside the rows of 16 (quad swaps, half mirror, mirror), then
+// v_permlane16_swap hands every lane its partner row's sum.  Sources stay inside the half wave: a half that has left the loop
+// (exec off) is never read.
+template <int CTRL> __device__ __forceinline__ float ln_dpp(const float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float half_wave_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += ln_dpp<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += ln_dpp<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += ln_dpp<0x141>(v);   // row_half_mirror
+  v += ln_dpp<0x140>(v);   // row_mirror: every lane of a row of 16 holds the row's sum
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // (own row, partner row) in either order
 }
 
 // 8 consecutive features as they come from memory (16 bytes of bf16, 32 of f32): kept raw across a loop iteration so that the
