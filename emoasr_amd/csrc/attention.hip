@@ -349,6 +349,24 @@ __device__ __forceinline__ uint64_t drop_index(const emoasr_attn_t& a, int b, in
 template <int CTRL, int ROWS = 0xf> __device__ __forceinline__ float dpp_take(const float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
 }
+// the other half wave's value in every lane, without the LDS pipeline: v_permlane32_swap with both operands = v leaves (lower half's
+// value, upper half's value) in the two results of every lane (__shfl_xor(v, 32) is a ds_bpermute round trip -- two per key tile on the
+// critical path of the forward's online soft-max)
+__device__ __forceinline__ float xhalf_max(const float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(const float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over groups of 8 lanes on DPP: quad swaps + row_half_mirror
+__device__ __forceinline__ float sum8(float v) {
+  v += dpp_take<0xB1>(v);
+  v += dpp_take<0x4E>(v);
+  v += dpp_take<0x141>(v);
+  return v;
+}
 __device__ __forceinline__ float half_sum32(float v) {
   v += dpp_take<0xB1>(v);          // quad_perm [1, 0, 3, 2]
   v += dpp_take<0x4E>(v);          // quad_perm [2, 3, 0, 1]
@@ -567,7 +585,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
         mt = fmaxf(mt, s[r]);
       }
     }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    mt = xhalf_max(mt);
     const float mn = fmaxf(m, mt);
     float alpha, rs = 0.f;
     if constexpr (FAST) {
@@ -589,7 +607,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && !PF2) ? 2 : 1) void attn_fw
         s[r] = p;
       }
     }
-    rs += __shfl_xor(rs, 32, 64);
+    rs = xhalf_sum(rs);
     l = l * alpha + rs;
     m = mn;
 #pragma unroll
@@ -827,7 +845,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_fwd4_kernel(const emoasr_attn
           mt = fmaxf(mt, s[r]);
         }
       }
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      mt = xhalf_max(mt);
       const float mn = fmaxf(m, mt);
       const float mref = (mn == -INFINITY) ? 0.f : mn;
       const float alpha = __builtin_amdgcn_exp2f(m - mref);
@@ -838,7 +856,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_fwd4_kernel(const emoasr_attn
         rs += p;
         s[r] = p;
       }
-      rs += __shfl_xor(rs, 32, 64);
+      rs = xhalf_sum(rs);
       l = l * alpha + rs;
       m = mn;
 #pragma unroll
@@ -896,7 +914,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const emoasr_attn_t a) 
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) s += dv[j] * ov[j];
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  s = sum8(s);
   if (!ok) return;
   const int i = (int)(bt % a.Tq), b = (int)(bt / a.Tq);
   if (d0 == 0) a.delta[((long)b * a.H + h) * a.Tq + i] = s;
@@ -1689,7 +1707,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const emoasr_attn_t 
     load8<T>((const T*)a.out + bt * a.ldo + h * DK + d0, ov);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += dv[j] * ov[j];
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    s = sum8(s);
   }
   if (!ok) return;
   if (d0 == 0 && a.dout) {
