@@ -71,6 +71,7 @@ void emo_gemm_set_wide128(int v);
 void emo_gemm_set_big_n256(int v);
 void emo_gemm_set_big_waves(int v);
 void emo_conv1_set_pair(int v);
+void emo_attn_set_prelaunch(int v);
 void emo_ln_set_bwd_pf(int v);
 void emo_ln_set_bwd_blocks(int v);
 void emo_rnnt_set_greedy_coop(int v);
@@ -177,6 +178,7 @@ extern "C" int emoasr_set_option(const char* name, int value) {
   if (strcmp(name, "stack_launch") == 0) { emo_layer_set_stack_launch(value); return 0; }
   if (strcmp(name, "ffn_save_dact") == 0) { emo_layer_set_ffn_save_dact(value); return 0; }
   if (strcmp(name, "attn_mask_bits") == 0) { emo_layer_set_att_bits(value); return 0; }
+  if (strcmp(name, "attn_prelaunch") == 0) { emo_attn_set_prelaunch(value); return 0; }
   if (strcmp(name, "conv1_pair") == 0) { emo_conv1_set_pair(value); return 0; }
   if (strcmp(name, "big_waves") == 0) { emo_gemm_set_big_waves(value); return 0; }
   if (strcmp(name, "big_n256") == 0) { emo_gemm_set_big_n256(value); return 0; }

@@ -3717,6 +3717,11 @@ void emo_attn_bwd_fused_extras(float* zero, long zn, const float* cast_src, void
 void emo_attn_set_side(int v) { g_attn_side = v ? 1 : 0; }
 void emo_attn_set_side_prio(int v) { g_side_prio = v ? 1 : 0; }   // (takes effect when the side stream is created)
 void emo_attn_bwd_defer_join(int v) { g_defer_join = v != 0; }
+// With the keep mask handed over by the forward (round 6) the prelaunch has only the Q + bias copies left (~6 us of the call's own
+// prologue), and a fork + a join of the side stream cost the main queue ~6 us EACH (the kernel sequence of the step shows the bubbles):
+// 1 = prelaunch only when there is a mask to hash.  Option "attn_prelaunch" (value 1 = always prelaunch, as before).
+int g_prelaunch_mask_only = 1;
+void emo_attn_set_prelaunch(int v) { g_prelaunch_mask_only = v ? 0 : 1; }
 void emo_attn_bwd_join(void* stream) { side_join((hipStream_t)stream); }
 // Everything of the next emoasr_attn_bwd_fused(a, ws) call that depends on FORWARD data only, now, on the side stream: the keep
 // mask (with dropout), the dense Q + pos_bias_u / Q + pos_bias_v copies, the clearing of the position-table gradient (zero, zn).
@@ -3727,6 +3732,7 @@ int emo_attn_bwd_prelaunch(int dtype, const emoasr_attn_t* a_in, void* ws, size_
   fill_seg_order(a);
   const bool rel = a.pos != nullptr, want_mask = a.drop_p > 0.f && !a.keep_mask;
   if (!rel && !want_mask) return 0;
+  if (!want_mask && g_prelaunch_mask_only) return 0;   // option "attn_prelaunch": see g_prelaunch_mask_only
   const FusedLayout lay = fused_layout<bf16>(a, want_mask);
   if (lay.total > ws_bytes) return 0;
   const long nrows = a.nseg > 1 ? a.seg_row[a.nseg] : (long)a.B * a.Tq;
