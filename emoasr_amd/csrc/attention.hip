@@ -2554,6 +2554,14 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
   // its element c = 31 - (rr + 4 hh) + il to lane il -- from tile 0 (c < 32, i.e. il <= row) or tile 1, the same source lane
   const int skew_base = il + 31 - 4 * hh;
 
+  // this wave's K / V tile as MFMA operands, read from LDS once (round 6: the kernel is at 128 registers, the 32 these take no longer
+  // push it past 256; they were 8 of the 40 16-byte LDS reads of a step)
+  typename M_::Frag kf[NK], vf[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    kf[kk] = M_::load_kc(Kt, LD, 0, kk * M_::KSTEP, lane);
+    vf[kk] = M_::load_kc(Vt, LD, 0, kk * M_::KSTEP, lane);
+  }
   EMO_WSTAMP(ws, 1);
   for (int step = 0; step < nstep; ++step) {
     const int i0 = step * 32;
@@ -2574,8 +2582,8 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_bwd_kv_kernel(const emoasr_at
       for (int r = 0; r < 16; ++r) s[r] = s_init;
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) {
-        s = M_::mma(M_::load_kc(Qus, LD, 0, kk * M_::KSTEP, lane), M_::load_kc(Kt, LD, 0, kk * M_::KSTEP, lane), s);
-        dp = M_::mma(M_::load_kc(dOs, LD, 0, kk * M_::KSTEP, lane), M_::load_kc(Vt, LD, 0, kk * M_::KSTEP, lane), dp);
+        s = M_::mma(M_::load_kc(Qus, LD, 0, kk * M_::KSTEP, lane), kf[kk], s);
+        dp = M_::mma(M_::load_kc(dOs, LD, 0, kk * M_::KSTEP, lane), vf[kk], dp);
       }
       EMO_STAMP(1);
       if constexpr (REL) {
