@@ -802,20 +802,27 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_fwd4_kernel(const emoasr_attn
   f32x16 o[2];
   zero16(o[0]); zero16(o[1]);
 
+  typename M_::Frag bcar[NK];   // fragments of this wave's lower band block of the coming step (block FW - 1 - wave + step)
+  if (live) {
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) bcar[kk] = M_::load_kc(ring + ((FW - 1 - wave) % NRING) * 32 * LD, LD, 0, kk * M_::KSTEP, lane);
+  }
   for (int step = 0; step < nstep; ++step) {
     const int j0 = step * 32;
     const unsigned mw = mw_next >> (4 * hh);   // this half wave's keys are 8 g + 4 hh + e
     mw_next = mask_word(step + 1);
     if (live) {
       // this wave's 64 band rows: blocks FW - 1 - wave + step and the next
-      const T* Bs0 = ring + ((FW - 1 - wave + step) % NRING) * 32 * LD;
+      // (the upper block's fragments stay in registers: they are the next step's lower block -- one block read from LDS per step)
       const T* Bs1 = ring + ((FW - wave + step) % NRING) * 32 * LD;
       f32x16 s, g0, g1;
       zero16(s); zero16(g0); zero16(g1);
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) {
-        g0 = M_::mma(M_::load_kc(Bs0, LD, 0, kk * M_::KSTEP, lane), qv[kk], g0);   // g[c][i]
-        g1 = M_::mma(M_::load_kc(Bs1, LD, 0, kk * M_::KSTEP, lane), qv[kk], g1);
+        const typename M_::Frag bn = M_::load_kc(Bs1, LD, 0, kk * M_::KSTEP, lane);
+        g0 = M_::mma(bcar[kk], qv[kk], g0);   // g[c][i]
+        g1 = M_::mma(bn, qv[kk], g1);
+        bcar[kk] = bn;
       }
       // (the score product is issued BEFORE the band tiles are stored: the stores wait for the band MFMAs' results while the matrix
       // pipe works on S)
@@ -3038,6 +3045,13 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
   __syncthreads();
   f32x16 dq[2];
   zero16(dq[0]); zero16(dq[1]);
+  typename M_::Frag bcar[NS][2];   // fragments of this wave's lower band block of the coming step (block FW - 1 - wave + step)
+  if (live) {
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) bcar[ks][dt] = M_::template load_km<TR>(ring + ((FW - 1 - wave) % NRING) * 32 * LD, LD, ks * M_::KSTEP, 32 * dt, lane);
+  }
 
   auto body = [&](const int step, u32x2 (&dset)[4], Vec16<T> (&pset)[2]) __attribute__((always_inline)) {
     u32x2 dcur[4];
@@ -3046,7 +3060,6 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
     EMO_STAMP(0);
     fetch_ds(dset, step + 3);
     if (live) {
-      const T* Bs0 = ring + ((FW - 1 - wave + step) % NRING) * 32 * LD;
       const T* Bs1 = ring + ((FW - wave + step) % NRING) * 32 * LD;
       // the dG image: the tile's 32 x 32 entries at band column c = key - il + 31 -- the same entries at every step, so the rest of the
       // image was cleared once, ahead of the loop
@@ -3070,15 +3083,25 @@ __global__ __launch_bounds__(64 * FW, 3) void attn_bwd_q2_kernel(const emoasr_at
         for (int dt = 0; dt < 2; ++dt) dq[dt] = M_::mma(chain_a<T, TR>(Ks, ks, 32 * dt, lane), df[ks], dq[dt]);
       }
       EMO_STAMP(2);
+      // the band operands: this step's upper block (Bs1) is the next step's lower one (Bs0) -- its fragments stay in registers
+      // (`bcar`), so a step reads ONE block's fragments from LDS, not two
+      typename M_::Frag bnew[NS][2];
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) bnew[ks][dt] = M_::template load_km<TR>(Bs1, LD, ks * M_::KSTEP, 32 * dt, lane);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
           const typename M_::Frag dg = M_::load_kc(img_g, LDG, 0, 32 * ct + ks * M_::KSTEP, lane);  // dG^T[c][i], c contiguous
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-            dq[dt] = M_::mma(M_::template load_km<TR>(ct ? Bs1 : Bs0, LD, ks * M_::KSTEP, 32 * dt, lane), dg, dq[dt]);
+          for (int dt = 0; dt < 2; ++dt) dq[dt] = M_::mma(ct ? bnew[ks][dt] : bcar[ks][dt], dg, dq[dt]);
         }
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) bcar[ks][dt] = bnew[ks][dt];
       __builtin_amdgcn_wave_barrier();   // the image has been read
     }
     EMO_STAMP(3); EMO_STAMP(4); EMO_STAMP(5);
