@@ -352,6 +352,23 @@ template <int CTRL, int ROWS = 0xf> __device__ __forceinline__ float dpp_take(co
 // the other half wave's value in every lane, without the LDS pipeline: v_permlane32_swap with both operands = v leaves (lower half's
 // value, upper half's value) in the two results of every lane (__shfl_xor(v, 32) is a ds_bpermute round trip -- two per key tile on the
 // critical path of the forward's online soft-max)
+// bit `K` of a mask word as 0 / -1 in ONE instruction (v_bfe_i32 with width 1 sign-extends).  Written as inline assembly: with a
+// compile-time bit index the compiler rewrites `sbfe(w, K, 1) & keep` into and + compare + select (three instructions per element).
+template <int K> __device__ __forceinline__ unsigned bit_mask(const unsigned w) {
+  unsigned r;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(w), "n"(K));
+  return r;
+}
+// the keep bit of accumulator row r (key 8 (r >> 2) + (r & 3) of this half wave's byte-shifted word) as 0 / -1
+__device__ __forceinline__ unsigned bit_of_row(const unsigned w, const int r) {
+  switch (r) {
+#define EMO_BR(R_) case R_: return bit_mask<8 * (R_ >> 2) + (R_ & 3)>(w);
+    EMO_BR(0) EMO_BR(1) EMO_BR(2) EMO_BR(3) EMO_BR(4) EMO_BR(5) EMO_BR(6) EMO_BR(7)
+    EMO_BR(8) EMO_BR(9) EMO_BR(10) EMO_BR(11) EMO_BR(12) EMO_BR(13) EMO_BR(14) EMO_BR(15)
+#undef EMO_BR
+  }
+  return 0u;
+}
 __device__ __forceinline__ float xhalf_max(const float v) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -872,7 +889,7 @@ __global__ __launch_bounds__(64 * FW, 2) void attn_fwd4_kernel(const emoasr_attn
         if constexpr (mbits) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            s[r] *= __uint_as_float((unsigned)__builtin_amdgcn_sbfe(mw, 8 * (r >> 2) + (r & 3), 1) & keep_bits);
+            s[r] *= __uint_as_float(bit_of_row(mw, r) & keep_bits);
         } else {
           const float keep = 1.f / (1.f - a.drop_p);
           const uint32_t thr = dropout_thr(a.drop_p);
