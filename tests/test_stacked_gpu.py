@@ -252,6 +252,39 @@ def test_one_launch_per_kernel_equals_one_launch_per_segment(dev):
     assert scale > 0 and (g1 - g0).abs().max().item() < 2e-3 * scale, (g1 - g0).abs().max().item() / scale
 
 
+def test_query_pass_from_the_image_equals_the_recomputing_query_pass(dev):
+    """option "attn_q2": the query pass of the attention backward reads the dS image the key pass wrote (1, default) or recomputes
+    every score itself (0, the round-4 kernel) -- stacked micro-batches of different lengths (segment offsets of the image), dropout
+    on.  Same keep mask, the same dS up to its bf16 rounding on the way through the image: losses identical, gradients within 5e-3
+    of their scale."""
+    from emoasr_amd import lib
+    model = _model(dev, dropout_enc_rate=0.1, dropout_attn_rate=0.1)
+    eng = model.engine()
+    datas = _micro_batches()
+    batches = [(d["xs"].to(dev), [int(v) for v in d["xlens"]], d["ys"], [int(v) for v in d["ylens"]]) for d in datas]
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def run(flag):
+        lib.set_option("attn_q2", flag)
+        try:
+            model.load_state_dict(sd0)
+            eng.step_count = 5
+            eng.arena.grad.zero_()
+            losses = eng.ctc_train_stacked(batches, 0)
+            torch.cuda.synchronize()
+            return losses.tolist(), eng.arena.grad.clone()
+        finally:
+            lib.set_option("attn_q2", 1)
+
+    l1, g1 = run(1)
+    l0, g0 = run(0)
+    assert l1 == l0, (l1, l0)
+    assert torch.isfinite(g1).all()
+    scale = g0.abs().max().item()
+    assert scale > 0 and (g1 - g0).abs().max().item() < 5e-3 * scale, (g1 - g0).abs().max().item() / scale
+    assert _cos(g1, g0) > 0.9999
+
+
 DEC_CFGS = {
     "rnnt": dict(decoder_type="rnn_transducer", vocab_size=96, embedding_size=64, dec_hidden_size=128, dec_num_layers=2,
                  joint_hidden_size=128, dropout_emb_rate=0.0, dropout_dec_rate=0.0, mtl_ctc_weight=0.3, lsm_prob=0.0),
