@@ -31,6 +31,8 @@ def build(force=False, verbose=True, variant=None, defines=()):
     headers.append(os.path.join(HERE, "..", "include", "emoasr_hip.h"))
     sources = SOURCES
     flags = FLAGS + ["-D" + d for d in defines]
+    if variant:   # compiler-option A/Bs: extra hipcc flags for a VARIANT build only (EMOASR_HIPCC_FLAGS="-mllvm -amdgpu-...")
+        flags = flags + os.environ.get("EMOASR_HIPCC_FLAGS", "").split()
     obj_of = lambda src: os.path.join(objdir, src.replace("/", "_").replace(".hip", ".o"))
     jobs = []
     for src in sources:
